@@ -1,0 +1,159 @@
+"""Camera containers for the BA path.
+
+Mirrors the part of the reference's ``cameras/camera_array.py`` that the hot path touches:
+``CameraData`` fields (``camera_array.py:18-41``), ``extrinsics_to_vector`` /
+``extrinsics_from_vector`` (``:115-133``), the posed / non-ignored ordering that fixes the
+parameter-vector layout (``:240-272``) and the ``camera_array.toml`` reader (``:377-441``).
+The reference delegates Rodrigues conversions to OpenCV; here they are a few lines of numpy
+(host side only, O(cameras)) so that no OpenCV is required.
+
+Convention: ``rotation`` / ``translation`` map world -> camera, ``X_cam = R @ X_world + t``.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict
+
+import numpy as np
+
+_TINY = np.finfo(np.float64).eps
+
+
+def rvec_to_matrix(rvec) -> np.ndarray:
+    """Axis-angle -> rotation matrix (what ``cv2.Rodrigues(rvec)[0]`` returns)."""
+    r = np.asarray(rvec, dtype=np.float64).reshape(3)
+    angle = float(np.sqrt(r @ r))
+    if angle < _TINY:
+        return np.eye(3)
+    ax = r / angle
+    ca, sa = np.cos(angle), np.sin(angle)
+    cross = np.array([[0.0, -ax[2], ax[1]], [ax[2], 0.0, -ax[0]], [-ax[1], ax[0], 0.0]])
+    return ca * np.eye(3) + (1.0 - ca) * np.outer(ax, ax) + sa * cross
+
+
+def matrix_to_rvec(R) -> np.ndarray:
+    """Rotation matrix -> axis-angle (what ``cv2.Rodrigues(R)[0].ravel()`` returns)."""
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    u, _, vt = np.linalg.svd(R)  # OpenCV projects onto SO(3) first
+    R = u @ vt
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    half_sin = 0.5 * float(np.sqrt(w @ w))
+    cos_a = min(1.0, max(-1.0, 0.5 * (float(np.trace(R)) - 1.0)))
+    angle = float(np.arccos(cos_a))
+    if half_sin >= 1e-5:
+        return w * (angle / (2.0 * half_sin))
+    if cos_a > 0.0:
+        return np.zeros(3)
+    # angle ~ pi: read the axis off the diagonal, signs from the off-diagonals
+    ax = np.sqrt(np.maximum((np.diag(R) + 1.0) * 0.5, 0.0))
+    if R[0, 1] < 0:
+        ax[1] = -ax[1]
+    if R[0, 2] < 0:
+        ax[2] = -ax[2]
+    if abs(ax[0]) < abs(ax[1]) and abs(ax[0]) < abs(ax[2]) and ((R[1, 2] > 0) != (ax[1] * ax[2] > 0)):
+        ax[2] = -ax[2]
+    return ax * (angle / float(np.linalg.norm(ax)))
+
+
+@dataclass
+class CameraData:
+    cam_id: int
+    size: tuple[int, int]
+    rotation_count: int = 0
+    error: float | None = None
+    matrix: np.ndarray | None = None
+    distortions: np.ndarray | None = None
+    exposure: int | None = None
+    grid_count: int | None = None
+    ignore: bool = False
+    translation: np.ndarray | None = None
+    rotation: np.ndarray | None = None
+    fisheye: bool = False
+
+    def extrinsics_to_vector(self) -> np.ndarray:
+        """``[rvec(3), tvec(3)]`` — the first six parameters of this camera's block."""
+        if self.rotation is None or self.translation is None:
+            raise ValueError(f"Camera {self.cam_id} has no pose")
+        return np.concatenate([matrix_to_rvec(self.rotation), np.asarray(self.translation, dtype=np.float64).ravel()])
+
+    def extrinsics_from_vector(self, row) -> None:
+        row = np.asarray(row, dtype=np.float64)
+        self.rotation = rvec_to_matrix(row[0:3])
+        self.translation = row[3:6].copy()
+
+    @property
+    def position(self) -> np.ndarray:
+        """Camera centre in world coordinates, ``-R^T t``."""
+        return -np.asarray(self.rotation).T @ np.asarray(self.translation).ravel()
+
+
+@dataclass
+class CameraArray:
+    cameras: Dict[int, CameraData] = field(default_factory=dict)
+
+    @property
+    def posed_cameras(self) -> Dict[int, CameraData]:
+        return {c: cam for c, cam in self.cameras.items() if cam.rotation is not None and cam.translation is not None}
+
+    @property
+    def unposed_cameras(self) -> Dict[int, CameraData]:
+        return {c: cam for c, cam in self.cameras.items() if cam.rotation is None or cam.translation is None}
+
+    @property
+    def posed_cam_id_to_index(self) -> Dict[int, int]:
+        """cam_id -> optimisation index: posed AND not ignored, ascending cam_id."""
+        ids = sorted(c for c, cam in self.posed_cameras.items() if not cam.ignore)
+        return {c: i for i, c in enumerate(ids)}
+
+    @property
+    def posed_index_to_cam_id(self) -> Dict[int, int]:
+        return {i: c for c, i in self.posed_cam_id_to_index.items()}
+
+    def __getitem__(self, cam_id: int) -> CameraData:
+        return self.cameras[cam_id]
+
+    def __setitem__(self, cam_id: int, camera: CameraData) -> None:
+        self.cameras[cam_id] = camera
+
+    # -- persistence (reader only; reference camera_array.py:377-441) -------------------------
+    @classmethod
+    def from_toml(cls, path: Path | str) -> "CameraArray":
+        import tomli
+
+        path = Path(path)
+        if not path.exists():
+            raise FileNotFoundError(f"CameraArray file not found: {path}")
+        with open(path, "rb") as fh:
+            doc = tomli.load(fh)
+        out: Dict[int, CameraData] = {}
+        for key, entry in (doc.get("cameras") or {}).items():
+            def arr(name):
+                v = entry.get(name)
+                return None if v is None or v == "null" else np.asarray(v, dtype=np.float64)
+
+            rot = arr("rotation")
+            if rot is not None:
+                if rot.shape == (3, 3):
+                    pass  # legacy files store the matrix
+                elif rot.size == 3:
+                    rot = rvec_to_matrix(rot.ravel())
+                else:
+                    raise ValueError(f"Camera {key}: invalid rotation shape {rot.shape}")
+            size = entry["size"]
+            out[int(key)] = CameraData(
+                cam_id=int(key),
+                size=(int(size[0]), int(size[1])),
+                rotation_count=int(entry.get("rotation_count", 0)),
+                error=entry.get("error"),
+                matrix=arr("matrix"),
+                distortions=arr("distortions"),
+                exposure=entry.get("exposure"),
+                grid_count=entry.get("grid_count"),
+                ignore=bool(entry.get("ignore", False)),
+                translation=arr("translation"),
+                rotation=rot,
+                fisheye=bool(entry.get("fisheye", False)),
+            )
+        return cls(out)

@@ -1,0 +1,32 @@
+"""Provenance of tests/golden/: copies of the reference's OWN data fixtures (not source code).
+
+Run in the build container (where /root/reference is mounted):  python tests/golden/make_golden.py
+
+  default_ring_baseline/image_points_noisy.csv
+      <- /root/reference/tests/fixtures/synthetic/default_ring_baseline/image_points_noisy.csv
+      the golden vector produced by the real cv2.projectPoints + numpy default_rng(42)
+      (pinned by reference tests/synthetic/primitives/test_scene.py:641-664, atol 1e-10).
+  post_optimization/{camera_array.toml,xy_CHARUCO.csv,xyz_CHARUCO.csv}
+      <- /root/reference/tests/sessions/post_optimization/...
+      a real calibrated 4-camera session (BASELINE.json configs[0]); used by the reference in
+      tests/test_reprojection_report.py and tests/test_capture_volume.py.
+  scipy_trajectories.json  <- tests/golden/make_scipy_golden.py (scipy run on the oracle, see there).
+"""
+import shutil
+from pathlib import Path
+
+REF = Path("/root/reference/tests")
+HERE = Path(__file__).parent
+
+COPIES = {
+    REF / "fixtures/synthetic/default_ring_baseline/image_points_noisy.csv": HERE / "default_ring_baseline/image_points_noisy.csv",
+    REF / "sessions/post_optimization/camera_array.toml": HERE / "post_optimization/camera_array.toml",
+    REF / "sessions/post_optimization/calibration/extrinsic/CHARUCO/xy_CHARUCO.csv": HERE / "post_optimization/xy_CHARUCO.csv",
+    REF / "sessions/post_optimization/calibration/extrinsic/CHARUCO/xyz_CHARUCO.csv": HERE / "post_optimization/xyz_CHARUCO.csv",
+}
+
+if __name__ == "__main__":
+    for src, dst in COPIES.items():
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        shutil.copyfile(src, dst)
+        print(f"{src} -> {dst} ({dst.stat().st_size} bytes)")
