@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Headline benchmark: observations/sec per LM iteration (+ final RMS reprojection error, px).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--no-cpu] [--also cfg2,cfg3]
+
+A *step* is one trust-region (LM) iteration of the hot path over the whole observation set: trial-point
+evaluation plus — for accepted steps — linearisation (residuals, Jacobian blocks, J^T J / J^T r
+accumulation) and the Schur-complement solve.  Steps are produced by running the solver from the
+device-resident initial guess with the reference's default tolerances, restarting it when it converges, until
+exactly K trial iterations have been executed (this is the reference's own normalisation,
+``N_obs * (nfev - 1) / T_solve``).  Observations, initial guess and all solver state are
+resident in HBM before the timed region starts; nothing but scalars crosses PCIe inside it.
+
+Workload (``config.workload``): BASELINE.json's multi-GPU configuration cfg4 — 64 cameras / 200k points /
+2M observations, extrinsics-only, linear loss — per GPU (weak scaling: every rank owns a 200k-point shard seen
+by the same 64 cameras; the reduced camera system is all-reduced over RCCL each iteration).  The single-GPU
+configs cfg2 / cfg3 are run untimed-by-the-driver after the headline and reported under ``also``.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(n_obs, n_points, n_cams, ncp, nct):
+    """Per-launch algorithmic HBM bytes of each per-observation kernel.
+
+    Storage model: observation record u,v f64 + cam,pt i32 = 24 B; point 24 B; V_p 48 B;
+    g_p / scale / step 24 B each; packed camera block 8*(nc(nc+1)/2+nc) B."""
+    ustride = nct * (nct + 1) // 2 + nct
+    N, P = n_obs, n_points
+    return {
+        "cost": 24 * N + 24 * P,
+        "build": 24 * N + 24 * P + 72 * P + 8 * n_cams * ustride,
+        "jv": 24 * N + 24 * P + 24 * P,
+        "schur": 24 * N + 24 * P + 48 * P + 24 * P + 24 * P + 8 * ncp * ncp + 8 * ncp,
+        "backsub": 24 * N + 24 * P + 48 * P + 24 * P + 24 * P + 24 * P,
+    }
+
+
+def build_problem(name, seed=42, **overrides):
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+    from caliscope_amd.engine import BAProblem
+    from caliscope_amd.synthetic import CONFIGS, make_config
+
+    sc = make_config(name, seed=seed, **overrides)
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=len(sc.points_init), refine_intrinsics=sc.refine_intrinsics)
+    x0 = par.pack(sc.cameras_init, sc.points_init)
+    f_scale = sc.f_scale_1px() if sc.loss != "linear" else 1.0
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=sc.loss, f_scale=f_scale)
+    return sc, par, x0, prob, CONFIGS[name]
+
+
+def run_iterations(engine, k_steps, solve_kw):
+    """Execute exactly k_steps trial iterations; returns (n_solves, last_result)."""
+    from caliscope_amd.trf import trf_solve
+
+    done, solves, last = 0, 0, None
+    while done < k_steps:
+        last = trf_solve(engine, None, max_nfev=(k_steps - done) + 1, fetch_x=False, **solve_kw)
+        done += last.nfev - 1
+        solves += 1
+        if last.nfev <= 1:  # already converged at x0: nothing to iterate on
+            break
+    return solves, last
+
+
+def rms_px(engine, par, x, cam_idx):
+    r, _ = engine.residuals(x)
+    fx = np.array([b.fx_initial for b in par.blocks])[cam_idx]
+    e = r.reshape(-1, 2) * fx[:, None]
+    return float(np.sqrt(np.mean(np.sum(e * e, axis=1))))
+
+
+def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, **overrides):
+    from caliscope_amd.hip_engine import HipEngine
+    from caliscope_amd.trf import trf_solve
+
+    solve_kw = solve_kw or {}
+    t_gen = time.time()
+    sc, par, x0, prob, cfg = build_problem(name, seed=seed, **overrides)
+    t_gen = time.time() - t_gen
+    eng = HipEngine(prob, device_id=device_id)
+    info = eng.info()
+    eng.begin(x0)
+    run_iterations(eng, max(warmup, 1), solve_kw)
+    if timers:
+        eng.enable_timers(True)
+        eng.reset_timers()
+    t0 = time.perf_counter()
+    solves, last = run_iterations(eng, steps, solve_kw)
+    elapsed = time.perf_counter() - t0
+    tm = eng.timers() if timers else {}
+    eng.enable_timers(False)
+    # untimed: full solve for the accuracy figure
+    full = trf_solve(eng, None, **solve_kw)
+    rms = rms_px(eng, par, full.x, prob.camera_indices)
+    rms0 = rms_px(eng, par, x0, prob.camera_indices)
+    eng.close()
+    return {
+        "name": name, "n_obs": prob.n_obs, "n_points": par.n_points, "n_cams": len(par.blocks), "ncp": par.n_camera_params,
+        "nct": 9 if any(b.n_params == 9 for b in par.blocks) else 6, "loss": prob.loss, "elapsed": elapsed, "steps": steps,
+        "solves": solves, "timers": tm, "final_rms_px": rms, "initial_rms_px": rms0, "full_nfev": full.nfev,
+        "full_status": full.status, "full_cost": full.cost, "info": info, "t_generate_s": t_gen,
+        "scene": sc, "par": par, "x0": x0,
+    }
+
+
+def roofline_from(m):
+    tm = m["timers"]
+    if not tm:
+        return None
+    alg = algorithmic_bytes(m["n_obs"], m["n_points"], m["n_cams"], m["ncp"], m["nct"])
+    fam = {k: v for k, v in tm.items() if k in alg and v[1] > 0}
+    if not fam:
+        return None
+    dom = max(fam, key=lambda k: fam[k][0])
+    ms, calls = fam[dom]
+    avg_s = ms / calls * 1e-3
+    achieved = alg[dom] / avg_s / 1e9
+    table = {k: {"ms_total": round(v[0], 4), "launches": v[1], "avg_us": round(v[0] / v[1] * 1e3, 2),
+                 **({"alg_bytes": alg[k], "GBps": round(alg[k] / (v[0] / v[1] * 1e-3) / 1e9, 1)} if k in alg else {})}
+             for k, v in tm.items() if v[1] > 0}
+    return {
+        "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg[dom],
+        "avg_launch_us": round(avg_s * 1e6, 2), "kernels": table,
+    }
+
+
+def cpu_baseline(budget_s=25.0):
+    """The reference's scipy call on the oracle callables, one host core, on a bounded sample of the workload:
+    cfg4's cameras and visibility recipe at half the points (64 cams / 100k points / 1M obs), full solve with
+    the reference's default tolerances."""
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+    from caliscope_amd.synthetic import make_scene
+    from oracle.solver import optimize_scipy
+
+    sc = make_scene("cfg4-sample", n_cams=64, n_points=100_000, n_obs=1_000_000)
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=100_000, refine_intrinsics=False)
+    x0 = par.pack(sc.cameras_init, sc.points_init)
+    t0 = time.perf_counter()
+    res = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0)
+    dt = time.perf_counter() - t0
+    iters = max(res.nfev - 1, 1)
+    return {
+        "value": round(sc.n_obs * iters / dt, 1), "unit": "obs/s", "cores": 1, "kind": "port",
+        "sample": f"64 cams / 100k points / 1M obs (half of cfg4), scipy least_squares trf+lsmr, default tolerances: "
+                  f"{res.nfev} evaluations in {dt:.1f} s; host has {os.cpu_count()} cores, the scipy path is single-threaded",
+        "seconds": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--also", default="cfg2,cfg3")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world > 1:
+        raise SystemExit("multi-GPU bench is not wired up in this revision")
+
+    import __graft_entry__ as entry
+
+    entry.build()
+    m = measure(args.workload, args.steps, args.warmup, device_id=local_rank)
+    total_obs = m["n_obs"] * world
+    value = total_obs * m["steps"] / m["elapsed"]
+    out = {
+        "metric": "observations/sec per LM iteration",
+        "value": round(value, 1),
+        "unit": "obs/s",
+        "n_gpus": world,
+        "steps": m["steps"],
+        "warmup": args.warmup,
+        "ms_per_step": round(m["elapsed"] / m["steps"] * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {m['n_cams']} cams / {m['n_points']} points / {m['n_obs']} obs per GPU, "
+                        f"{'extrinsics+intrinsics' if m['nct'] == 9 else 'extrinsics-only'} BA, {m['loss']} loss",
+            "n_obs_total": total_obs, "params_per_camera": m["nct"], "parallelism": f"points sharded x{world}",
+            "tolerances": "ftol=xtol=gtol=1e-8 (reference defaults)", "solves_in_timed_region": m["solves"],
+        },
+        "final_rms_px": round(m["final_rms_px"], 6),
+        "initial_rms_px": round(m["initial_rms_px"], 4),
+        "solve": {"nfev": m["full_nfev"], "status": m["full_status"], "cost": m["full_cost"]},
+        "roofline": roofline_from(m),
+        "engine": m["info"],
+    }
+    if not args.no_cpu and rank == 0 and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as exc:  # the baseline must never break the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "obs/s", "cores": 1, "kind": "port", "sample": f"failed: {exc}"}
+    also = {}
+    if rank == 0 and world == 1 and args.also:
+        for name in [s for s in args.also.split(",") if s and s != args.workload]:
+            try:
+                kw = {}
+                a = measure(name, args.steps, args.warmup, device_id=local_rank, solve_kw=kw)
+                rf = roofline_from(a)
+                also[name] = {
+                    "value": round(a["n_obs"] * a["steps"] / a["elapsed"], 1), "unit": "obs/s",
+                    "ms_per_step": round(a["elapsed"] / a["steps"] * 1e3, 4), "final_rms_px": round(a["final_rms_px"], 6),
+                    "workload": f"{a['n_cams']} cams / {a['n_points']} points / {a['n_obs']} obs, {a['loss']} loss",
+                    "nfev": a["full_nfev"], "status": a["full_status"],
+                    "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us")},
+                }
+            except Exception as exc:
+                also[name] = {"error": str(exc)}
+    if also:
+        out["also"] = also
+    if rank == 0:
+        print(json.dumps(out, default=lambda o: int(o) if isinstance(o, np.integer) else float(o)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Build libcaliscope_ba.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m caliscope_amd.build [--force]
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OUT = HERE / "libcaliscope_ba.so"
+SOURCES = [CSRC / "cba_lib.hip"]
+DEPENDS = [CSRC / "cba_kernels.h", CSRC / "ba_math.h", HERE.parent / "include" / "caliscope_ba.h"]
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def needs_build() -> bool:
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + DEPENDS)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not needs_build():
+        return OUT
+    cmd = [
+        hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
+        "-Wall", "-Wno-unused-function", *map(str, SOURCES), "-o", str(OUT),
+    ]
+    if verbose:
+        print("[caliscope_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=str(CSRC))
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

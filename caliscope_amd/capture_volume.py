@@ -1,0 +1,281 @@
+"""``CaptureVolume.optimize()`` on the MI355X — host-side mirror of the reference's hot-path entry point.
+
+Same public surface as the reference's ``core/capture_volume.py`` for the BA path:
+
+* ``OptimizationStatus``                    <- ``capture_volume.py:45-67``
+* ``CaptureVolume.optimize(ftol, max_nfev, verbose, strict, use_constraints, pixel_sigma, *,
+  refine_intrinsics, loss, f_scale)``       <- ``:322-444`` (same kwargs, same defaults, immutable self,
+  ``CalibrationError`` when ``strict`` and not converged)
+* ``CaptureVolume.pixel_f_scale``           <- ``:141-148``
+* ``CaptureVolume.reprojection_report``     <- ``:150-235`` (``overall_rmse = sqrt(mean(ex^2+ey^2))`` in pixels)
+* ``CaptureVolume.filter_by_percentile_error`` (the stage between the product's passes,
+  ``calibrate_extrinsics.py:244``)
+
+The marshalling of DataFrames into flat arrays follows ``:346-358`` but is vectorised (the reference uses a
+Python list comprehension over every observation, and a Python loop to build ``img_to_obj_map``).  The solver
+call goes through :func:`caliscope_amd.least_squares.least_squares`, i.e. the MI355X engine; constraints
+(rigid distances) are not handled by the engine yet and raise.
+"""
+
+from __future__ import annotations
+
+import logging
+from copy import deepcopy
+from dataclasses import dataclass, field
+from functools import cached_property
+
+import numpy as np
+import pandas as pd
+
+from caliscope_amd.bundle_parameterization import BundleParameterization
+from caliscope_amd.cameras import CameraArray
+from caliscope_amd.engine import BAProblem
+from caliscope_amd.exceptions import CalibrationError
+from caliscope_amd.least_squares import least_squares
+from caliscope_amd.point_data import ImagePoints, WorldPoints
+from caliscope_amd.trf import STATUS_REASONS
+
+logger = logging.getLogger(__name__)
+
+_KEY = ["sync_index", "object_id", "keypoint_id"]
+
+
+@dataclass(frozen=True)
+class OptimizationStatus:
+    converged: bool
+    termination_reason: str
+    iterations: int  # number of residual evaluations (scipy's nfev)
+    final_cost: float
+    bound_warnings: tuple = ()
+
+
+@dataclass(frozen=True)
+class ReprojectionReport:
+    overall_rmse: float
+    by_camera: dict
+    by_point: dict
+    n_unmatched_observations: int
+    unmatched_rate: float
+    unmatched_by_camera: dict
+    raw_errors: pd.DataFrame
+    n_observations_matched: int
+    n_observations_total: int
+    n_cameras: int
+    n_points: int
+
+
+@dataclass(frozen=True)
+class CaptureVolume:
+    camera_array: CameraArray
+    image_points: ImagePoints
+    world_points: WorldPoints
+    constraints: object | None = None
+    img_to_obj_map: np.ndarray = field(init=False)
+    _optimization_status: OptimizationStatus | None = field(default=None, compare=False)
+
+    @property
+    def optimization_status(self) -> OptimizationStatus | None:
+        return self._optimization_status
+
+    def __post_init__(self):
+        object.__setattr__(self, "img_to_obj_map", self._compute_img_to_obj_map())
+        n_img, n_world = len(self.image_points), len(self.world_points)
+        if n_img == 0:
+            raise ValueError("No image observations provided")
+        if n_world == 0:
+            raise ValueError("No world points provided")
+        if len(self.camera_array.posed_cameras) == 0:
+            raise ValueError("No posed cameras in array")
+        if int(np.sum(self.img_to_obj_map >= 0)) == 0:
+            raise ValueError("No image observations have corresponding world points")
+
+    def _compute_img_to_obj_map(self) -> np.ndarray:
+        """Row of ``world_points`` for every image observation, -1 when unmatched (vectorised merge)."""
+        world = self.world_points._df[_KEY].copy()
+        world["world_idx"] = np.arange(len(world), dtype=np.int64)
+        world = world.drop_duplicates(subset=_KEY, keep="last")
+        merged = self.image_points._df[_KEY].merge(world, on=_KEY, how="left")
+        return merged["world_idx"].fillna(-1).to_numpy(dtype=np.int32)
+
+    # -- marshalling (reference :346-358) ------------------------------------------------------------
+    def _matched_arrays(self):
+        df = self.image_points._df
+        index_of = self.camera_array.posed_cam_id_to_index
+        cam_lookup = pd.Series(index_of, dtype="float64")
+        cam_idx = df["cam_id"].map(cam_lookup)
+        mask = (self.img_to_obj_map >= 0) & cam_idx.notna().to_numpy()
+        camera_indices = cam_idx.to_numpy()[mask].astype(np.int32)
+        image_coords = df[["img_loc_x", "img_loc_y"]].to_numpy(dtype=np.float64)[mask]
+        obj_indices = self.img_to_obj_map[mask].astype(np.int32)
+        return mask, camera_indices, image_coords, obj_indices
+
+    def pixel_f_scale(self, px: float = 1.0) -> float:
+        focal = [cam.matrix[0, 0] for cam in self.camera_array.posed_cameras.values() if cam.matrix is not None]
+        return px / float(np.median(focal))
+
+    # -- the hot path ----------------------------------------------------------------------------------
+    def optimize(
+        self,
+        ftol: float = 1e-8,
+        max_nfev: int | None = None,
+        verbose: int = 0,
+        strict: bool = True,
+        use_constraints: bool = True,
+        pixel_sigma: float = 1.0,
+        *,
+        refine_intrinsics: bool = False,
+        loss: str = "linear",
+        f_scale: float = 1.0,
+        _engine_factory=None,
+    ) -> "CaptureVolume":
+        """Bundle adjustment via pixel-space residuals, on the MI355X engine."""
+        if use_constraints and self.constraints is not None:
+            raise CalibrationError(
+                "This capture volume carries rigid-distance constraints, which the MI355X engine does not "
+                "implement yet.  Pass use_constraints=False (or keep the scipy path for this volume)."
+            )
+        _, camera_indices, image_coords, obj_indices = self._matched_arrays()
+        new_cameras = deepcopy(self.camera_array)
+        par = BundleParameterization.from_camera_array(
+            new_cameras, n_points=len(self.world_points), refine_intrinsics=refine_intrinsics
+        )
+        x0 = par.pack(new_cameras, self.world_points.points)
+        logger.info(f"Beginning bundle adjustment on {len(image_coords)} observations")
+        result = least_squares(
+            None,
+            x0,
+            args=(par, camera_indices, image_coords, obj_indices, None, None, None, None),
+            jac=None,
+            verbose=verbose,
+            x_scale="jac",
+            loss=loss,
+            f_scale=f_scale,
+            ftol=ftol,
+            max_nfev=max_nfev,
+            method="trf",
+            bounds=par.bounds(),
+            engine_factory=_engine_factory,
+        )
+        reason = STATUS_REASONS.get(result.status, f"unknown_{result.status}")
+        converged = result.status in (1, 2, 3, 4)
+        if strict and not converged:
+            raise CalibrationError(
+                f"Bundle adjustment did not converge: {reason}\n"
+                f"Pass strict=False to suppress this error and inspect the result."
+            )
+        new_points = par.unpack_into(new_cameras, result.x)
+        status = OptimizationStatus(
+            converged=converged,
+            termination_reason=reason,
+            iterations=int(result.nfev),
+            final_cost=float(result.cost),
+            bound_warnings=par.bound_warnings(result.x),
+        )
+        world_df = self.world_points.df
+        world_df[["x_coord", "y_coord", "z_coord"]] = new_points
+        return CaptureVolume(
+            camera_array=new_cameras,
+            image_points=self.image_points,
+            world_points=WorldPoints(world_df),
+            constraints=self.constraints,
+            _optimization_status=status,
+        )
+
+    # -- metric of record --------------------------------------------------------------------------------
+    def _pixel_errors(self, camera_indices, image_coords, obj_indices, _engine_factory=None) -> np.ndarray:
+        """(projected - observed) in pixels with the stored intrinsics/extrinsics, evaluated on the device:
+        residuals are ``/fx_initial`` of a locked parameterization, so pixels = residual * fx."""
+        par = BundleParameterization.from_camera_array(
+            self.camera_array, n_points=len(self.world_points), refine_intrinsics=False
+        )
+        x = par.pack(self.camera_array, self.world_points.points)
+        problem = BAProblem(par, camera_indices, image_coords, obj_indices)
+        if _engine_factory is None:
+            from caliscope_amd.hip_engine import HipEngine
+
+            _engine_factory = HipEngine
+        eng = _engine_factory(problem)
+        try:
+            r, _ = eng.residuals(x)
+        finally:
+            close = getattr(eng, "close", None)
+            if close is not None:
+                close()
+        fx = np.array([b.fx_initial for b in par.blocks])[camera_indices]
+        return r.reshape(-1, 2) * fx[:, None]
+
+    def compute_reprojection_report(self, _engine_factory=None) -> ReprojectionReport:
+        mask, camera_indices, image_coords, obj_indices = self._matched_arrays()
+        n_total, n_matched = len(mask), int(mask.sum())
+        if n_matched == 0:
+            raise ValueError("No matched observations for reprojection error calculation")
+        err = self._pixel_errors(camera_indices, image_coords, obj_indices, _engine_factory)
+        sq = np.sum(err * err, axis=1)
+        df = self.image_points._df[mask]
+        raw = pd.DataFrame(
+            {
+                "sync_index": df["sync_index"].to_numpy(), "cam_id": df["cam_id"].to_numpy(),
+                "object_id": df["object_id"].to_numpy(), "keypoint_id": df["keypoint_id"].to_numpy(),
+                "error_x": err[:, 0], "error_y": err[:, 1], "euclidean_error": np.sqrt(sq),
+            }
+        )
+        index_of = self.camera_array.posed_cam_id_to_index
+        n_cam = len(index_of)
+        cam_sum = np.bincount(camera_indices, weights=sq, minlength=n_cam)
+        cam_cnt = np.bincount(camera_indices, minlength=n_cam)
+        by_camera = {cid: 0.0 for cid in self.camera_array.posed_cameras}
+        for cid, i in index_of.items():
+            by_camera[cid] = float(np.sqrt(cam_sum[i] / cam_cnt[i])) if cam_cnt[i] else 0.0
+        grp = raw.assign(sq=sq).groupby(["object_id", "keypoint_id"])["sq"].mean()
+        by_point = {(int(o), int(k)): float(np.sqrt(v)) for (o, k), v in grp.items()}
+        all_df = self.image_points._df
+        total_by_cam = all_df["cam_id"].value_counts()
+        matched_by_cam = df["cam_id"].value_counts()
+        unmatched_by_camera = {
+            int(c): int(total_by_cam.get(c, 0) - matched_by_cam.get(c, 0)) for c in self.camera_array.cameras
+        }
+        return ReprojectionReport(
+            overall_rmse=float(np.sqrt(np.mean(sq))), by_camera=by_camera, by_point=by_point,
+            n_unmatched_observations=n_total - n_matched, unmatched_rate=(n_total - n_matched) / n_total,
+            unmatched_by_camera=unmatched_by_camera, raw_errors=raw, n_observations_matched=n_matched,
+            n_observations_total=n_total, n_cameras=len(self.camera_array.posed_cameras), n_points=len(self.world_points),
+        )
+
+    @cached_property
+    def reprojection_report(self) -> ReprojectionReport:
+        return self.compute_reprojection_report()
+
+    def filter_by_percentile_error(self, percentile: float, _engine_factory=None) -> "CaptureVolume":
+        """Drop the worst ``percentile`` percent of matched observations by pixel error (global threshold),
+        then drop world points left with fewer than two views; optimisation status is cleared."""
+        if not 0 < percentile < 100:
+            raise ValueError("percentile must be in (0, 100)")
+        report = self.compute_reprojection_report(_engine_factory)
+        mask, *_ = self._matched_arrays()
+        e = report.raw_errors["euclidean_error"].to_numpy()
+        thr = np.percentile(e, 100.0 - percentile)
+        keep_rows = np.ones(len(mask), dtype=bool)
+        keep_rows[np.flatnonzero(mask)[e > thr]] = False
+        img_df = self.image_points._df[keep_rows]
+        obj = self.img_to_obj_map[keep_rows]
+        views = np.bincount(obj[obj >= 0], minlength=len(self.world_points))
+        world_df = self.world_points._df[views >= 2].reset_index(drop=True)
+        return CaptureVolume(self.camera_array, ImagePoints(img_df.reset_index(drop=True)), WorldPoints(world_df), self.constraints)
+
+    @classmethod
+    def from_arrays(cls, camera_array: CameraArray, camera_ids, image_coords, obj_indices, points_xyz) -> "CaptureVolume":
+        """Build a volume from flat arrays (synthetic scenes): observation i is keypoint 0 of object
+        ``obj_indices[i]`` at sync_index 0 — one world point per object."""
+        obj_indices = np.asarray(obj_indices)
+        n_pts = len(points_xyz)
+        img = pd.DataFrame(
+            {
+                "sync_index": 0, "cam_id": np.asarray(camera_ids), "object_id": obj_indices, "keypoint_id": 0,
+                "img_loc_x": np.asarray(image_coords)[:, 0], "img_loc_y": np.asarray(image_coords)[:, 1],
+            }
+        )
+        pts = np.asarray(points_xyz, dtype=np.float64)
+        world = pd.DataFrame(
+            {"sync_index": 0, "object_id": np.arange(n_pts), "keypoint_id": 0, "x_coord": pts[:, 0], "y_coord": pts[:, 1], "z_coord": pts[:, 2]}
+        )
+        return cls(camera_array, ImagePoints(img), WorldPoints(world))

@@ -1,0 +1,796 @@
+// HIP kernels of the bundle-adjustment engine for gfx950 (MI355X).  Included by cba_lib.hip only.
+//
+// Data layout in HBM:
+//   observations, sorted by world point:  obs_u[N], obs_v[N] (f64), obs_cam[N], obs_pt[N] (i32)   SoA
+//   chunk table: chunk_start[n_chunks+1] — contiguous observation ranges that contain whole points and at
+//                most CHUNK (=256) observations; one 256-thread workgroup processes one chunk at a time
+//   vectors (x, x_new, g, s, scale_inv, v1, v2): [ncp_pad | X[Ppad] | Y[Ppad] | Z[Ppad]]  (points SoA)
+//   V blocks: 6 arrays of Ppad (xx xy xz yy yz zz)
+//   camera table: C x 48 doubles, recomputed per evaluation point, staged in LDS by every workgroup
+//
+// No MFMA: the blocks are 2x6 / 2x9 / 2x3, contraction depth 2-3.  The kernels are FP64 VALU + LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_math.h"
+
+namespace cba {
+
+constexpr int BLOCK = 256;
+constexpr int CHUNK = 256;
+constexpr int WAVE = 64;
+
+struct VecLayout {
+  int ncp;      // number of camera parameters
+  int ncp_pad;  // padded to a multiple of 32 doubles
+  int P;        // number of world points
+  int Ppad;     // padded to a multiple of 32
+  __host__ __device__ long total() const { return (long)ncp_pad + 3L * Ppad; }
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
+  return v;
+}
+// Sum over the workgroup; result valid in thread 0.  `sh` holds BLOCK/WAVE doubles.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < BLOCK / WAVE; ++i) r += sh[i];
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double* sh) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < BLOCK / WAVE; ++i) r = fmax(r, sh[i]);
+  return r;
+}
+
+__device__ __forceinline__ void lds_add(double* addr, double v) { unsafeAtomicAdd(addr, v); }
+
+__device__ __forceinline__ void stage_camtab(double* sh_tab, const double* tab, int n_cams) {
+  for (int i = threadIdx.x; i < n_cams * CAMTAB_DOUBLES; i += BLOCK) sh_tab[i] = tab[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-camera constants of an evaluation point
+__global__ void k_cam_prep(const double* __restrict__ xvec, const double* __restrict__ cam_const,
+                           const int* __restrict__ cam_model, const int* __restrict__ cam_np,
+                           const int* __restrict__ cam_off, int n_cams, double* __restrict__ tab) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cams) return;
+  double xc[MAX_NC];
+  const int np = cam_np[c];
+  for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? xvec[cam_off[c] + i] : 0.0;
+  CamTab t;
+  cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t);
+  const double* src = reinterpret_cast<const double*>(&t);
+  for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab[c * CAMTAB_DOUBLES + i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// cost (and optionally the residual vector) at xvec:   0.5 * sum rho  is formed by the caller
+template <bool WRITE_R>
+__global__ void __launch_bounds__(BLOCK)
+k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+       const int* __restrict__ obs_pt, long n_obs, const double* __restrict__ xvec, VecLayout lay,
+       const double* __restrict__ tab, int n_cams, int loss, double f_scale, double* __restrict__ partial,
+       int* __restrict__ flags, double* __restrict__ r_out, const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_tab = sh;
+  double* sh_red = sh + n_cams * CAMTAB_DOUBLES;
+  stage_camtab(sh_tab, tab, n_cams);
+  __syncthreads();
+  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
+  const double* px = xvec + lay.ncp_pad;
+  double acc = 0.0;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
+    const int cam = obs_cam[i], pt = obs_pt[i];
+    double e[2];
+    project_residual(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], e);
+    if (!(isfinite(e[0]) && isfinite(e[1]))) bad = true;
+    acc += robust_cost_one(loss, f_scale, e[0]) + robust_cost_one(loss, f_scale, e[1]);
+    if (WRITE_R) {
+      const long o = order[i];
+      r_out[2 * o] = e[0];
+      r_out[2 * o + 1] = e[1];
+    }
+  }
+  if (bad) flags[0] = 1;
+  const double tot = block_sum(acc, sh_red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// sum `nrow` rows of length `width`:  out[j] = sum_b partial[b*width + j]   (ordered => deterministic)
+__global__ void k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  double s = 0.0;
+  for (int b = 0; b < nrow; ++b) s += partial[(long)b * width + j];
+  out[j] = s;
+}
+__global__ void k_reduce_rows_max(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  double s = 0.0;
+  for (int b = 0; b < nrow; ++b) s = fmax(s, partial[(long)b * width + j]);
+  out[j] = s;
+}
+
+// Shared front end of the per-observation passes: project, differentiate, apply the robust-loss scaling.
+// After the call e, A, B are the rows of scipy's scaled (J, f); returns this observation's rho-sum.
+template <int NC>
+__device__ __forceinline__ double obs_linearize(const CamTab& c, double X, double Y, double Z, double u, double v,
+                                                int loss, double f_scale, double* e, double (*A)[MAX_NC],
+                                                double (*B)[3]) {
+  project_full(c, X, Y, Z, u, v, e, A, B);
+  double rho = 0.0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double rs, er;
+    rho += robust_one(loss, f_scale, e[r], &rs, &er);
+    e[r] = er;
+    if (loss != LOSS_LINEAR) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) A[r][k] *= rs;
+      B[r][0] *= rs; B[r][1] *= rs; B[r][2] *= rs;
+    }
+  }
+  return rho;
+}
+
+template <int NC> struct UPack {
+  static constexpr int TRI = NC * (NC + 1) / 2;
+  static constexpr int STRIDE = TRI + NC;  // upper triangle + gradient
+  __host__ __device__ static constexpr int idx(int r, int c) { return r * NC - r * (r - 1) / 2 + (c - r); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// build pass: residuals + Jacobian blocks -> per-point V_p, g_p (segmented sums through LDS), per-camera
+// U_c, g_c (LDS atomics, flushed as per-workgroup partials), cost partials.
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+        const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
+        int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams,
+        int loss, double f_scale, double* __restrict__ Vblk, double* __restrict__ gvec,
+        double* __restrict__ partialU, double* __restrict__ partial_cost) {
+  using UP = UPack<NC>;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_tab = sh;
+  double* sh_U = sh_tab + n_cams * CAMTAB_DOUBLES;
+  double* sh_pt = sh_U + n_cams * UP::STRIDE;
+  double* sh_red = sh_pt + 9 * CHUNK;
+  stage_camtab(sh_tab, tab, n_cams);
+  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
+  __syncthreads();
+  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
+  const double* px = xvec + lay.ncp_pad;
+  double* gp = gvec + lay.ncp_pad;
+  double cost = 0.0;
+  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+    const int i = o0 + threadIdx.x;
+    double pv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) pv[q] = 0.0;
+    if (i < o1) {
+      const int cam = obs_cam[i], pt = obs_pt[i];
+      double e[2], A[2][MAX_NC], B[2][3];
+      cost += obs_linearize<NC>(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss,
+                                f_scale, e, A, B);
+      pv[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
+      pv[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
+      pv[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
+      pv[3] = B[0][1] * B[0][1] + B[1][1] * B[1][1];
+      pv[4] = B[0][1] * B[0][2] + B[1][1] * B[1][2];
+      pv[5] = B[0][2] * B[0][2] + B[1][2] * B[1][2];
+      pv[6] = B[0][0] * e[0] + B[1][0] * e[1];
+      pv[7] = B[0][1] * e[0] + B[1][1] * e[1];
+      pv[8] = B[0][2] * e[0] + B[1][2] * e[1];
+      const int np = (int)ct[cam].nparams;
+      double* Uc = sh_U + cam * UP::STRIDE;
+#pragma unroll
+      for (int r = 0; r < NC; ++r) {
+        if (r < np) {
+#pragma unroll
+          for (int c = r; c < NC; ++c)
+            if (c < np) lds_add(&Uc[UP::idx(r, c)], A[0][r] * A[0][c] + A[1][r] * A[1][c]);
+          lds_add(&Uc[UP::TRI + r], A[0][r] * e[0] + A[1][r] * e[1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sh_pt[q * CHUNK + threadIdx.x] = pv[q];
+    __syncthreads();
+    const int cp0 = obs_pt[o0], npts = obs_pt[o1 - 1] - cp0 + 1;
+    for (int lp = threadIdx.x; lp < npts; lp += BLOCK) {
+      const int p = cp0 + lp;
+      const int a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
+      if (b > a) {
+        double acc[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+        for (int j = a; j < b; ++j) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) acc[q] += sh_pt[q * CHUNK + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Vblk[(long)q * lay.Ppad + p] = acc[q];
+        gp[p] = acc[6];
+        gp[lay.Ppad + p] = acc[7];
+        gp[2 * lay.Ppad + p] = acc[8];
+      }
+    }
+    __syncthreads();
+  }
+  double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
+  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
+  const double tot = block_sum(cost, sh_red);
+  if (threadIdx.x == 0) partial_cost[blockIdx.x] = tot;
+}
+
+// unpack the reduced camera blocks: gradient -> gvec camera part
+template <int NC>
+__global__ void k_unpack_camera_grad(const double* __restrict__ Upacked, const int* __restrict__ cam_off,
+                                     const int* __restrict__ cam_np, int n_cams, double* __restrict__ gvec) {
+  using UP = UPack<NC>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = t / NC, r = t % NC;
+  if (c >= n_cams || r >= cam_np[c]) return;
+  gvec[cam_off[c] + r] = Upacked[c * UP::STRIDE + UP::TRI + r];
+}
+
+// Jacobi scaling  scale_inv = sqrt(diag(J^T J))  with scipy's rules: zeros -> 1 on the first call,
+// monotone max with the previous scale afterwards (common.py:598-610).
+template <int NC>
+__global__ void k_scale_update(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
+                               const int* __restrict__ param_cam, const int* __restrict__ param_loc, VecLayout lay,
+                               int first, double* __restrict__ sinv) {
+  using UP = UPack<NC>;
+  const long total = lay.total();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    double v;
+    if (i < lay.ncp_pad) {
+      if (i >= lay.ncp) continue;  // padding keeps scale 1
+      const int r = param_loc[i];
+      v = Upacked[param_cam[i] * UP::STRIDE + UP::idx(r, r)];
+    } else {
+      const long k = (i - lay.ncp_pad) / lay.Ppad, p = (i - lay.ncp_pad) % lay.Ppad;
+      if (p >= lay.P) continue;
+      const int q = (k == 0) ? 0 : (k == 1 ? 3 : 5);
+      v = Vblk[(long)q * lay.Ppad + p];
+    }
+    v = sqrt(v);
+    if (first) { if (v == 0.0) v = 1.0; }
+    else v = fmax(v, sinv[i]);
+    sinv[i] = v;
+  }
+}
+
+// scalars of the linearisation + v1 = g / scale_inv^2 (the direction of the gradient in scaled space)
+//   partial[b][0..3] = sum (g/sinv)^2, sum (x sinv)^2, sum x^2, (unused) ; partial_max[b] = max |g|
+__global__ void __launch_bounds__(BLOCK)
+k_lin_scalars(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
+              long total, double* __restrict__ v1, double* __restrict__ partial, double* __restrict__ partial_max) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  double s0 = 0, s1 = 0, s2 = 0, m = 0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+    const double gi = g[i], si = sinv[i], xi = x[i];
+    const double gh = gi / si;
+    s0 += gh * gh;
+    s1 += (xi * si) * (xi * si);
+    s2 += xi * xi;
+    m = fmax(m, fabs(gi));
+    v1[i] = gh / si;
+  }
+  double r;
+  r = block_sum(s0, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
+  r = block_sum(s1, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
+  r = block_sum(s2, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = r;
+  if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = 0.0;
+  r = block_max(m, sh_red); if (threadIdx.x == 0) partial_max[blockIdx.x] = r;
+}
+
+// out = a * g / sinv^2 + b * s
+__global__ void k_combine(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s,
+                          double a, double b, long total, double* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const double si = sinv[i];
+    out[i] = a * g[i] / (si * si) + b * s[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// J.v for one or two vectors: partial[b][0..2] = sum |Jv1|^2, <Jv1,Jv2>, |Jv2|^2
+template <int NC, int NV>
+__global__ void __launch_bounds__(BLOCK)
+k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+     const int* __restrict__ obs_pt, long n_obs, const double* __restrict__ xvec, VecLayout lay,
+     const double* __restrict__ tab, const int* __restrict__ cam_off, int n_cams, int loss, double f_scale,
+     const double* __restrict__ v1, const double* __restrict__ v2, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_tab = sh;
+  double* sh_v = sh_tab + n_cams * CAMTAB_DOUBLES;  // NV * ncp_pad
+  double* sh_red = sh_v + NV * lay.ncp_pad;
+  stage_camtab(sh_tab, tab, n_cams);
+  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) {
+    sh_v[i] = v1[i];
+    if (NV == 2) sh_v[lay.ncp_pad + i] = v2[i];
+  }
+  __syncthreads();
+  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
+  const double* px = xvec + lay.ncp_pad;
+  const double* p1 = v1 + lay.ncp_pad;
+  const double* p2 = (NV == 2) ? v2 + lay.ncp_pad : nullptr;
+  double s11 = 0, s12 = 0, s22 = 0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
+    const int cam = obs_cam[i], pt = obs_pt[i];
+    double e[2], A[2][MAX_NC], B[2][3];
+    obs_linearize<NC>(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e,
+                      A, B);
+    const int np = (int)ct[cam].nparams;
+    const double* vc = sh_v + cam_off[cam];
+    double a0 = B[0][0] * p1[pt] + B[0][1] * p1[lay.Ppad + pt] + B[0][2] * p1[2 * lay.Ppad + pt];
+    double a1 = B[1][0] * p1[pt] + B[1][1] * p1[lay.Ppad + pt] + B[1][2] * p1[2 * lay.Ppad + pt];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (k < np) { a0 += A[0][k] * vc[k]; a1 += A[1][k] * vc[k]; }
+    s11 += a0 * a0 + a1 * a1;
+    if (NV == 2) {
+      const double* wc = vc + lay.ncp_pad;
+      double b0 = B[0][0] * p2[pt] + B[0][1] * p2[lay.Ppad + pt] + B[0][2] * p2[2 * lay.Ppad + pt];
+      double b1 = B[1][0] * p2[pt] + B[1][1] * p2[lay.Ppad + pt] + B[1][2] * p2[2 * lay.Ppad + pt];
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k < np) { b0 += A[0][k] * wc[k]; b1 += A[1][k] * wc[k]; }
+      s12 += a0 * b0 + a1 * b1;
+      s22 += b0 * b0 + b1 * b1;
+    }
+  }
+  double r;
+  r = block_sum(s11, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
+  r = block_sum(s12, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
+  r = block_sum(s22, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = r;
+  if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Schur pass.  Per observation i of point p (V'_p = V_p + lam D_p^2 = L L^T):
+//     Z_i = B_i L^-T (2x3),   y_p = L^-1 g_p,   b_{c_i} += A_i^T (Z_i y_p)
+// and per pair (i <= j) of observations of the same point
+//     Sacc[c_i, c_j] += A_i^T (Z_i Z_j^T) A_j          ( = W_i V'^-1 W_j^T )
+// The reduced system is S = U + lam D_c^2 - Sacc, rhs = -g_c + b   (SURVEY.md Appendix A.4).
+// Sacc is accumulated with LDS atomics into a workgroup-private copy when (ncp^2 doubles) fit in LDS
+// (flushed as per-workgroup partials), otherwise with FP64 global atomics.
+template <int NC, bool S_IN_LDS>
+__global__ void __launch_bounds__(BLOCK)
+k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+        const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
+        int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
+        const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
+        const double* __restrict__ Vblk, const double* __restrict__ gvec, const double* __restrict__ sinv,
+        double* __restrict__ S_global, double* __restrict__ partial, int* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int ncp = lay.ncp;
+  double* sh_tab = sh;
+  double* sh_A = sh_tab + n_cams * CAMTAB_DOUBLES;  // [2*NC][CHUNK]
+  double* sh_Z = sh_A + 2 * NC * CHUNK;              // [6][CHUNK]
+  double* sh_b = sh_Z + 6 * CHUNK;                   // [ncp_pad]
+  double* sh_S = sh_b + lay.ncp_pad;                 // [ncp*ncp] if S_IN_LDS
+  int* sh_cam = reinterpret_cast<int*>(sh_S + (S_IN_LDS ? ncp * ncp : 0));  // [CHUNK] cam, [CHUNK] seg end
+  stage_camtab(sh_tab, tab, n_cams);
+  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_b[i] = 0.0;
+  if (S_IN_LDS)
+    for (int i = threadIdx.x; i < ncp * ncp; i += BLOCK) sh_S[i] = 0.0;
+  __syncthreads();
+  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
+  const double* px = xvec + lay.ncp_pad;
+  const double* gp = gvec + lay.ncp_pad;
+  const double* dp = sinv + lay.ncp_pad;
+  double* Sdst = S_IN_LDS ? sh_S : S_global;
+  bool fail = false;
+  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+    const int i = o0 + threadIdx.x;
+    const bool active = i < o1;
+    double Ai[2][MAX_NC], Zi[2][3];
+    int cam_i = 0, np_i = 0, seg_end = 0;
+    if (active) {
+      const int pt = obs_pt[i];
+      cam_i = obs_cam[i];
+      seg_end = pt_start[pt + 1] - o0;
+      double e[2], B[2][3];
+      obs_linearize<NC>(ct[cam_i], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
+                        e, Ai, B);
+      np_i = (int)ct[cam_i].nparams;
+      double Vd[6], L[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
+      const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
+      Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+      if (!chol3(Vd, L)) {
+        fail = true;
+        L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
+      }
+      chol3_fwd(L, B[0], Zi[0]);
+      chol3_fwd(L, B[1], Zi[1]);
+      const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
+      double y[3];
+      chol3_fwd(L, gpt, y);
+      const double zy0 = Zi[0][0] * y[0] + Zi[0][1] * y[1] + Zi[0][2] * y[2];
+      const double zy1 = Zi[1][0] * y[0] + Zi[1][1] * y[1] + Zi[1][2] * y[2];
+      double* bc = sh_b + cam_off[cam_i];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (k < np_i) lds_add(&bc[k], Ai[0][k] * zy0 + Ai[1][k] * zy1);
+        else { Ai[0][k] = 0.0; Ai[1][k] = 0.0; }
+      }
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        sh_A[k * CHUNK + threadIdx.x] = Ai[0][k];
+        sh_A[(NC + k) * CHUNK + threadIdx.x] = Ai[1][k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sh_Z[k * CHUNK + threadIdx.x] = Zi[0][k];
+        sh_Z[(3 + k) * CHUNK + threadIdx.x] = Zi[1][k];
+      }
+      sh_cam[threadIdx.x] = cam_i;
+    }
+    __syncthreads();
+    if (active) {
+      const int off_i = cam_off[cam_i];
+      for (int j = threadIdx.x; j < seg_end; ++j) {
+        const int cam_j = sh_cam[j];
+        const int off_j = cam_off[cam_j];
+        double Zj[2][3], Aj[2][NC];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Zj[0][k] = sh_Z[k * CHUNK + j]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j]; }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { Aj[0][k] = sh_A[k * CHUNK + j]; Aj[1][k] = sh_A[(NC + k) * CHUNK + j]; }
+        double M[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) M[a][b] = Zi[a][0] * Zj[b][0] + Zi[a][1] * Zj[b][1] + Zi[a][2] * Zj[b][2];
+        const bool same = (j == (int)threadIdx.x);
+        const int np_j = (int)ct[cam_j].nparams;
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+          if (r >= np_i) continue;
+          const double t0 = Ai[0][r] * M[0][0] + Ai[1][r] * M[1][0];
+          const double t1 = Ai[0][r] * M[0][1] + Ai[1][r] * M[1][1];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            if (c >= np_j) continue;
+            const double val = t0 * Aj[0][c] + t1 * Aj[1][c];  // block(r, c) of W_i V'^-1 W_j^T
+            if (same) {
+              if (c >= r) lds_add(&Sdst[(long)(off_i + r) * ncp + off_i + c], val);
+            } else if (cam_i == cam_j) {
+              // two different observations of one camera: block + block^T lands on the diagonal block
+              const int lo = r < c ? r : c, hi = r < c ? c : r;
+              lds_add(&Sdst[(long)(off_i + lo) * ncp + off_i + hi], (r == c) ? 2.0 * val : val);
+            } else if (off_i < off_j) {
+              lds_add(&Sdst[(long)(off_i + r) * ncp + off_j + c], val);
+            } else {
+              lds_add(&Sdst[(long)(off_j + c) * ncp + off_i + r], val);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (fail) flags[1] = 1;
+  // flush: [S (if in LDS) | b]
+  const int width = (S_IN_LDS ? ncp * ncp : 0) + lay.ncp_pad;
+  double* dst = partial + (long)blockIdx.x * width;
+  if (S_IN_LDS)
+    for (int i = threadIdx.x; i < ncp * ncp; i += BLOCK) dst[i] = sh_S[i];
+  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) dst[(S_IN_LDS ? ncp * ncp : 0) + i] = sh_b[i];
+}
+
+// S = U + lam D_c^2 - Sacc (symmetric, both triangles written), rhs = -g_c + b
+template <int NC>
+__global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,
+                                 const double* __restrict__ Upacked, const double* __restrict__ gvec,
+                                 const double* __restrict__ sinv, const int* __restrict__ param_cam,
+                                 const int* __restrict__ param_loc, int ncp, double lam, double* __restrict__ S,
+                                 double* __restrict__ rhs) {
+  using UP = UPack<NC>;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)ncp * ncp) return;
+  const int row = (int)(t / ncp), col = (int)(t % ncp);
+  if (col < row) return;
+  double v = -Sacc[(long)row * ncp + col];
+  if (param_cam[row] == param_cam[col]) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
+  if (row == col) {
+    v += lam * sinv[row] * sinv[row];
+    rhs[row] = -gvec[row] + bacc[row];
+  }
+  S[(long)row * ncp + col] = v;
+  S[(long)col * ncp + row] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense Cholesky S = L L^T (lower triangle, row-major, in place in a copy), blocked right-looking, NB = 32.
+constexpr int NB = 32;
+
+__global__ void __launch_bounds__(NB * NB)
+k_potrf_diag(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
+  __shared__ double T[NB][NB + 1];
+  const int nb = min(NB, n - k0);
+  const int r = threadIdx.y, c = threadIdx.x;
+  if (r < nb && c < nb) T[r][c] = M[(long)(k0 + r) * n + k0 + c];
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    if (r == j && c == j) {
+      const double d = T[j][j];
+      if (!(d > 0.0) || !isfinite(d)) { flags[2] = 1; T[j][j] = 1.0; }
+      else T[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    if (c == j && r > j && r < nb) T[r][j] /= T[j][j];
+    __syncthreads();
+    if (r > j && c > j && c <= r && r < nb) T[r][c] -= T[r][j] * T[c][j];
+    __syncthreads();
+  }
+  if (r < nb && c < nb && c <= r) M[(long)(k0 + r) * n + k0 + c] = T[r][c];
+}
+
+// rows below the diagonal block:  L_ik = M_ik L_kk^-T   (one thread per row)
+__global__ void __launch_bounds__(BLOCK)
+k_trsm_panel(double* __restrict__ M, int n, int k0) {
+  __shared__ double T[NB][NB + 1];
+  const int nb = min(NB, n - k0);
+  for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
+    const int r = t / NB, c = t % NB;
+    T[r][c] = (r < nb && c <= r) ? M[(long)(k0 + r) * n + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int i = k0 + nb + blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double x[NB];
+  double* row = M + (long)i * n + k0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? row[j] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j < nb) {
+      double v = x[j];
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        if (t < j) v -= x[t] * T[j][t];
+      x[j] = v / T[j][j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (j < nb) row[j] = x[j];
+}
+
+// trailing update: M_ij -= L_i,panel L_j,panel^T for tiles with i >= j beyond the panel
+__global__ void __launch_bounds__(BLOCK)
+k_syrk_trailing(double* __restrict__ M, int n, int k0) {
+  __shared__ double Li[NB][NB + 1], Lj[NB][NB + 1];
+  const int nb = min(NB, n - k0);
+  const int base = k0 + nb;
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;
+  const int i0 = base + ti * NB, j0 = base + tj * NB;
+  for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
+    const int r = t / NB, c = t % NB;
+    Li[r][c] = (i0 + r < n && c < nb) ? M[(long)(i0 + r) * n + k0 + c] : 0.0;
+    Lj[r][c] = (j0 + r < n && c < nb) ? M[(long)(j0 + r) * n + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
+    const int r = t / NB, c = t % NB;
+    const int gi = i0 + r, gj = j0 + c;
+    if (gi < n && gj < n && gj <= gi) {
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) acc += Li[r][q] * Lj[c][q];
+      M[(long)gi * n + gj] -= acc;
+    }
+  }
+}
+
+// solve L L^T x = rhs with one workgroup; x is written to out[0..n)
+__global__ void __launch_bounds__(BLOCK)
+k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double y[];  // n
+  for (int i = threadIdx.x; i < n; i += BLOCK) y[i] = rhs[i];
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1);
+  // forward: L y = rhs
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = min(NB, n - k0);
+    if (threadIdx.x < WAVE) {
+      double yj = (lane < nb) ? y[k0 + lane] : 0.0;
+      for (int t = 0; t < nb; ++t) {
+        const double ltt = L[(long)(k0 + t) * n + k0 + t];
+        const double yt = __shfl(yj, t, WAVE) / ltt;
+        if (lane == t) yj = yt;
+        else if (lane > t && lane < nb) yj -= L[(long)(k0 + lane) * n + k0 + t] * yt;
+      }
+      if (lane < nb) y[k0 + lane] = yj;
+    }
+    __syncthreads();
+    for (int i = k0 + nb + threadIdx.x; i < n; i += BLOCK) {
+      const double* row = L + (long)i * n + k0;
+      double acc = 0.0;
+      for (int t = 0; t < nb; ++t) acc += row[t] * y[k0 + t];
+      y[i] -= acc;
+    }
+    __syncthreads();
+  }
+  // backward: L^T x = y
+  const int nblk = (n + NB - 1) / NB;
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int k0 = kb * NB;
+    const int nb = min(NB, n - k0);
+    if (threadIdx.x < WAVE) {
+      double xj = (lane < nb) ? y[k0 + lane] : 0.0;
+      for (int t = nb - 1; t >= 0; --t) {
+        const double ltt = L[(long)(k0 + t) * n + k0 + t];
+        const double xt = __shfl(xj, t, WAVE) / ltt;
+        if (lane == t) xj = xt;
+        else if (lane < t) xj -= L[(long)(k0 + t) * n + k0 + lane] * xt;
+      }
+      if (lane < nb) y[k0 + lane] = xj;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < k0; i += BLOCK) {
+      double acc = 0.0;
+      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * n + i] * y[k0 + t];
+      y[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += BLOCK) out[i] = y[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// back-substitution:  dp = -V'^-1 (g_p + sum_i W_i^T dc_{c_i}),  W_i^T dc = B_i^T (A_i dc)
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+          const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
+          int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
+          const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
+          const double* __restrict__ Vblk, const double* __restrict__ gvec, const double* __restrict__ sinv,
+          double* __restrict__ svec) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_tab = sh;
+  double* sh_dc = sh_tab + n_cams * CAMTAB_DOUBLES;  // ncp_pad
+  double* sh_pt = sh_dc + lay.ncp_pad;               // [3][CHUNK]
+  stage_camtab(sh_tab, tab, n_cams);
+  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_dc[i] = svec[i];
+  __syncthreads();
+  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
+  const double* px = xvec + lay.ncp_pad;
+  const double* gp = gvec + lay.ncp_pad;
+  const double* dp = sinv + lay.ncp_pad;
+  double* sp = svec + lay.ncp_pad;
+  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+    const int i = o0 + threadIdx.x;
+    double t[3] = {0.0, 0.0, 0.0};
+    if (i < o1) {
+      const int cam = obs_cam[i], pt = obs_pt[i];
+      double e[2], A[2][MAX_NC], B[2][3];
+      obs_linearize<NC>(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
+                        e, A, B);
+      const int np = (int)ct[cam].nparams;
+      const double* dc = sh_dc + cam_off[cam];
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k < np) { a0 += A[0][k] * dc[k]; a1 += A[1][k] * dc[k]; }
+      t[0] = B[0][0] * a0 + B[1][0] * a1;
+      t[1] = B[0][1] * a0 + B[1][1] * a1;
+      t[2] = B[0][2] * a0 + B[1][2] * a1;
+    }
+    sh_pt[threadIdx.x] = t[0];
+    sh_pt[CHUNK + threadIdx.x] = t[1];
+    sh_pt[2 * CHUNK + threadIdx.x] = t[2];
+    __syncthreads();
+    const int cp0 = obs_pt[o0], npts = obs_pt[o1 - 1] - cp0 + 1;
+    for (int lp = threadIdx.x; lp < npts; lp += BLOCK) {
+      const int p = cp0 + lp;
+      const int a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
+      if (b > a) {
+        double q[3] = {gp[p], gp[lay.Ppad + p], gp[2 * lay.Ppad + p]};
+        for (int j = a; j < b; ++j) { q[0] += sh_pt[j]; q[1] += sh_pt[CHUNK + j]; q[2] += sh_pt[2 * CHUNK + j]; }
+        double Vd[6], L[6], y[3], x[3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Vd[k] = Vblk[(long)k * lay.Ppad + p];
+        const double d0 = dp[p], d1 = dp[lay.Ppad + p], d2 = dp[2 * lay.Ppad + p];
+        Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+        if (chol3(Vd, L)) {
+          chol3_fwd(L, q, y);
+          chol3_bwd(L, y, x);
+        } else {
+          x[0] = x[1] = x[2] = 0.0;  // flagged by the Schur pass already
+        }
+        sp[p] = -x[0];
+        sp[lay.Ppad + p] = -x[1];
+        sp[2 * lay.Ppad + p] = -x[2];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// scalars of the Newton step: partial[b][0] = sum (s sinv)^2, [1] = sum g s
+__global__ void __launch_bounds__(BLOCK)
+k_step_scalars(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s, long total,
+               double* __restrict__ partial) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  double s0 = 0, s1 = 0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+    const double p = s[i] * sinv[i];
+    s0 += p * p;
+    s1 += g[i] * s[i];
+  }
+  double r;
+  r = block_sum(s0, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
+  r = block_sum(s1, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
+  if (threadIdx.x == 0) { partial[blockIdx.x * 4 + 2] = 0.0; partial[blockIdx.x * 4 + 3] = 0.0; }
+}
+// w_sq = sum (s sinv - c g / sinv)^2 with c = scal[idx_gdot] / gh_sq   (device-side scalars, no host round trip)
+__global__ void __launch_bounds__(BLOCK)
+k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s, long total,
+           const double* __restrict__ scal_gdot, double gh_sq, double* __restrict__ partial) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  const double c = scal_gdot[0] / gh_sq;
+  double s0 = 0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+    const double w = s[i] * sinv[i] - c * g[i] / sinv[i];
+    s0 += w * w;
+  }
+  const double r = block_sum(s0, sh_red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// x_new = x + alpha g / sinv^2 + beta s ; partial[b] = sum step^2
+__global__ void __launch_bounds__(BLOCK)
+k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
+               const double* __restrict__ s, double alpha, double beta, long total, double* __restrict__ x_new,
+               double* __restrict__ partial) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  double s0 = 0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+    const double si = sinv[i];
+    const double st = alpha * g[i] / (si * si) + beta * s[i];
+    x_new[i] = x[i] + st;
+    s0 += st * st;
+  }
+  const double r = block_sum(s0, sh_red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void k_fill(double* __restrict__ p, double v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace cba

@@ -1,0 +1,801 @@
+// libcaliscope_ba.so — host side of the MI355X bundle-adjustment engine (C ABI of include/caliscope_ba.h).
+//
+// One cba_problem owns: the observations re-sorted by world point (SoA, HBM-resident for the whole solve),
+// the chunk table, every vector of the trust-region iteration and the scratch of the Schur solve.  Every
+// entry point enqueues its kernels on the handle's own HIP stream, waits once, and returns scalars.
+// There is no CPU code path for the arithmetic: without a device, cba_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/caliscope_ba.h"
+#include "cba_kernels.h"
+
+using namespace cba;
+
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(CBA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+enum TimerId {
+  T_CAM_PREP = 0, T_COST, T_BUILD, T_BUILD_REDUCE, T_SCALE_SCALARS, T_JV, T_SCHUR, T_SCHUR_REDUCE, T_CHOLESKY,
+  T_BACKSUB, T_VECTOR, T_COUNT
+};
+static const char* kTimerNames[T_COUNT] = {
+    "cam_prep", "cost", "build", "build_reduce", "scale_scalars", "jv", "schur", "schur_reduce_finalize",
+    "cholesky_solve", "backsub", "vector_ops"};
+
+struct EventPair { hipEvent_t a, b; };
+
+struct cba_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int C = 0, P = 0, ncp = 0, nct = 6;
+  long N = 0;
+  VecLayout lay{};
+  int n_chunks = 0, grid = 0, max_obs_per_point = 0;
+  bool schur_lds = false;
+  int loss = 0;
+  double f_scale = 1.0;
+  long device_bytes = 0;
+  // observations (sorted by point) + plan
+  double *obs_u = nullptr, *obs_v = nullptr;
+  int *obs_cam = nullptr, *obs_pt = nullptr, *pt_start = nullptr, *chunk_start = nullptr, *order = nullptr;
+  // cameras
+  double* cam_const = nullptr;
+  int *cam_model = nullptr, *cam_np = nullptr, *cam_off = nullptr, *param_cam = nullptr, *param_loc = nullptr;
+  double *tab = nullptr, *tab_new = nullptr;
+  // vectors
+  double *x0 = nullptr, *x = nullptr, *x_new = nullptr, *g = nullptr, *s = nullptr, *sinv = nullptr, *v1 = nullptr, *v2 = nullptr;
+  double *V = nullptr, *Upacked = nullptr;
+  double *partial = nullptr, *partial4 = nullptr, *partial1 = nullptr;
+  long partial_width = 0;
+  double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr;
+  double* scal = nullptr;  // device scalars
+  int* flags = nullptr;
+  double* h_scal = nullptr;  // pinned
+  int* h_flags = nullptr;
+  bool first_scale = true;
+  bool have_x0 = false;
+  bool begun = false, linearized = false, stepped = false, have_trial = false;
+  double gh_sq = 0.0;
+  std::vector<int> h_cam_off, h_cam_np;
+  std::vector<double> h_vec;  // staging for layout conversion
+  // timers
+  bool timers_on = false;
+  std::vector<EventPair> pending[T_COUNT];
+  std::vector<EventPair> free_events;
+  double t_ms[T_COUNT] = {0};
+  long t_calls[T_COUNT] = {0};
+  std::vector<void*> allocs;
+};
+
+template <typename T>
+static int dev_alloc(cba_problem* p, T** out, size_t count) {
+  void* ptr = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIPCHK(hipMalloc(&ptr, bytes));
+  p->allocs.push_back(ptr);
+  p->device_bytes += (long)bytes;
+  *out = static_cast<T*>(ptr);
+  return CBA_OK;
+}
+template <typename T>
+static int dev_upload(cba_problem* p, T** out, const std::vector<T>& h) {
+  int rc = dev_alloc(p, out, h.size());
+  if (rc) return rc;
+  if (!h.empty()) HIPCHK(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return CBA_OK;
+}
+
+struct ScopedTimer {
+  cba_problem* p;
+  int id;
+  EventPair ev{};
+  bool on;
+  ScopedTimer(cba_problem* p_, int id_) : p(p_), id(id_), on(p_->timers_on) {
+    if (!on) return;
+    if (!p->free_events.empty()) { ev = p->free_events.back(); p->free_events.pop_back(); }
+    else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+    (void)hipEventRecord(ev.a, p->stream);
+  }
+  ~ScopedTimer() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, p->stream);
+    p->pending[id].push_back(ev);
+  }
+};
+
+static void drain_timers(cba_problem* p) {
+  for (int t = 0; t < T_COUNT; ++t) {
+    for (auto& ev : p->pending[t]) {
+      float ms = 0.f;
+      if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+        p->t_ms[t] += ms;
+        p->t_calls[t] += 1;
+      }
+      p->free_events.push_back(ev);
+    }
+    p->pending[t].clear();
+  }
+}
+
+static int sync_scalars(cba_problem* p, int n_scal) {
+  HIPCHK(hipMemcpyAsync(p->h_scal, p->scal, n_scal * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipMemcpyAsync(p->h_flags, p->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return CBA_OK;
+}
+
+static inline int vec_grid(long total) { return (int)std::min<long>((total + BLOCK - 1) / BLOCK, 1024); }
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* cba_last_error(void) { return g_last_error.c_str(); }
+int cba_version(void) { return CBA_VERSION; }
+int cba_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int cba_timer_count(void) { return T_COUNT; }
+const char* cba_timer_name(int32_t i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }
+
+int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, int32_t chunk_cap, int64_t* order_out,
+                      int64_t* pt_start_out, int64_t* chunk_start_out) {
+  if (n_points < 0 || n_obs < 0 || chunk_cap <= 0 || (n_obs > 0 && !obs_pt)) return fail(CBA_ERR_INVALID, "cba_host_plan: bad arguments");
+  std::vector<int64_t> count((size_t)n_points + 1, 0);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    const int32_t p = obs_pt[i];
+    if (p < 0 || p >= n_points) return fail(CBA_ERR_INVALID, "observation %lld: world-point index %d out of range", (long long)i, p);
+    count[p + 1]++;
+  }
+  for (int32_t p = 0; p < n_points; ++p) {
+    if (count[p + 1] > chunk_cap)
+      return fail(CBA_ERR_UNSUPPORTED, "world point %d has %lld observations; this build supports at most %d per point",
+                  p, (long long)count[p + 1], chunk_cap);
+    count[p + 1] += count[p];
+  }
+  for (int32_t p = 0; p <= n_points; ++p) pt_start_out[p] = count[p];
+  std::vector<int64_t> cursor(count.begin(), count.end() - 1);
+  for (int64_t i = 0; i < n_obs; ++i) order_out[cursor[obs_pt[i]]++] = i;  // stable counting sort
+  int64_t n_chunks = 0;
+  int64_t start = 0;
+  chunk_start_out[0] = 0;
+  for (int32_t p = 0; p < n_points; ++p) {
+    const int64_t end = pt_start_out[p + 1];
+    if (end - start > chunk_cap) {  // close the chunk before this point
+      chunk_start_out[++n_chunks] = pt_start_out[p];
+      start = pt_start_out[p];
+    }
+  }
+  if (n_obs > start) chunk_start_out[++n_chunks] = n_obs;
+  return n_chunks;
+}
+
+void cba_destroy(cba_problem* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  drain_timers(p);
+  for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (void* a : p->allocs) (void)hipFree(a);
+  if (p->h_scal) (void)hipHostFree(p->h_scal);
+  if (p->h_flags) (void)hipHostFree(p->h_flags);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+}  // extern "C"
+
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return fail(CBA_ERR_UNSUPPORTED, "kernel needs %zu bytes of LDS (> 160 KiB)", bytes);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CBA_OK;
+}
+
+static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_DOUBLES + 8) * 8; }
+template <int NC> static size_t lds_build(const cba_problem* p) {
+  return ((size_t)p->C * CAMTAB_DOUBLES + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
+}
+static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_DOUBLES + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
+template <int NC> static size_t lds_schur(const cba_problem* p, bool s_lds) {
+  return ((size_t)p->C * CAMTAB_DOUBLES + 2 * NC * CHUNK + 6 * CHUNK + p->lay.ncp_pad + (s_lds ? (size_t)p->ncp * p->ncp : 0)) * 8 +
+         CHUNK * sizeof(int);
+}
+static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_DOUBLES + p->lay.ncp_pad + 3 * CHUNK) * 8; }
+
+template <int NC>
+static int configure_kernels(cba_problem* p) {
+  int rc;
+  if ((rc = allow_lds(k_cost<false>, lds_cost(p)))) return rc;
+  if ((rc = allow_lds(k_cost<true>, lds_cost(p)))) return rc;
+  if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
+  if ((rc = allow_lds(k_jv<NC, 1>, lds_jv(p, 1)))) return rc;
+  if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
+  p->schur_lds = lds_schur<NC>(p, true) <= 150 * 1024;
+  if (p->schur_lds) { if ((rc = allow_lds(k_schur<NC, true>, lds_schur<NC>(p, true)))) return rc; }
+  else { if ((rc = allow_lds(k_schur<NC, false>, lds_schur<NC>(p, false)))) return rc; }
+  if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
+  if ((rc = allow_lds(k_chol_solve, (size_t)p->ncp * 8))) return rc;
+  return CBA_OK;
+}
+
+extern "C" {
+
+int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** out) {
+  if (!d || !out) return fail(CBA_ERR_INVALID, "cba_create: null argument");
+  *out = nullptr;
+  if (d->n_cams <= 0 || d->n_points <= 0 || d->n_obs <= 0) return fail(CBA_ERR_INVALID, "cba_create: empty problem (cams=%d points=%d obs=%lld)", d->n_cams, d->n_points, (long long)d->n_obs);
+  if (d->n_obs >= (1LL << 31)) return fail(CBA_ERR_UNSUPPORTED, "cba_create: more than 2^31 observations");
+  if (!d->cam_n_params || !d->cam_model || !d->cam_const || !d->obs_cam || !d->obs_pt || !d->obs_uv) return fail(CBA_ERR_INVALID, "cba_create: null array");
+  if (d->loss < CBA_LOSS_LINEAR || d->loss > CBA_LOSS_ARCTAN) return fail(CBA_ERR_INVALID, "cba_create: unknown loss %d", d->loss);
+  if (d->loss != CBA_LOSS_LINEAR && !(d->f_scale > 0.0)) return fail(CBA_ERR_INVALID, "cba_create: f_scale must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(CBA_ERR_NO_DEVICE, "no HIP device available: the MI355X engine has no CPU fallback");
+  int dev = (opt && opt->device_id >= 0) ? opt->device_id : 0;
+  if (!(opt && opt->device_id >= 0)) (void)hipGetDevice(&dev);
+  if (dev >= ndev) return fail(CBA_ERR_INVALID, "device %d requested, %d available", dev, ndev);
+  HIPCHK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
+
+  cba_problem* p = new cba_problem();
+  p->device = dev;
+  p->C = d->n_cams; p->P = d->n_points; p->N = d->n_obs;
+  p->loss = d->loss; p->f_scale = d->f_scale;
+  int rc = CBA_OK;
+  auto bail = [&](int code) { cba_destroy(p); return code; };
+
+  // camera tables
+  std::vector<int> np(p->C), model(p->C), off(p->C);
+  int ncp = 0, nct = 6;
+  for (int c = 0; c < p->C; ++c) {
+    np[c] = d->cam_n_params[c]; model[c] = d->cam_model[c];
+    if (np[c] != 6 && np[c] != 9) return bail(fail(CBA_ERR_INVALID, "camera %d: n_params must be 6 or 9, got %d", c, np[c]));
+    if (model[c] != CBA_MODEL_PINHOLE_BC5 && model[c] != CBA_MODEL_FISHEYE4) return bail(fail(CBA_ERR_INVALID, "camera %d: unknown model %d", c, model[c]));
+    if (model[c] == CBA_MODEL_FISHEYE4 && np[c] != 6) return bail(fail(CBA_ERR_INVALID, "camera %d: fisheye cameras are always locked (6 params)", c));
+    if (!(d->cam_const[c * 12] > 0.0)) return bail(fail(CBA_ERR_INVALID, "camera %d: fx_initial must be positive", c));
+    off[c] = ncp; ncp += np[c];
+    if (np[c] == 9) nct = 9;
+  }
+  p->ncp = ncp; p->nct = nct;
+  p->h_cam_off = off; p->h_cam_np = np;
+  p->lay.ncp = ncp; p->lay.ncp_pad = (ncp + 31) / 32 * 32;
+  p->lay.P = p->P; p->lay.Ppad = (p->P + 31) / 32 * 32;
+  std::vector<int> pcam(p->lay.ncp_pad, 0), ploc(p->lay.ncp_pad, 0);
+  for (int c = 0; c < p->C; ++c)
+    for (int r = 0; r < np[c]; ++r) { pcam[off[c] + r] = c; ploc[off[c] + r] = r; }
+
+  // plan: sort by point, chunk table
+  std::vector<int64_t> order(p->N), pstart((size_t)p->P + 1), cstart((size_t)p->N + 2);
+  for (int64_t i = 0; i < p->N; ++i)
+    if (d->obs_cam[i] < 0 || d->obs_cam[i] >= p->C) return bail(fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, d->obs_cam[i]));
+  int64_t nch = cba_host_plan(p->P, p->N, d->obs_pt, CHUNK, order.data(), pstart.data(), cstart.data());
+  if (nch < 0) return bail((int)nch);
+  p->n_chunks = (int)nch;
+  std::vector<double> hu(p->N), hv(p->N);
+  std::vector<int> hcam(p->N), hpt(p->N), hord(p->N), hps((size_t)p->P + 1), hcs((size_t)nch + 1);
+  for (int64_t i = 0; i < p->N; ++i) {
+    const int64_t o = order[i];
+    hu[i] = d->obs_uv[2 * o]; hv[i] = d->obs_uv[2 * o + 1];
+    hcam[i] = d->obs_cam[o]; hpt[i] = d->obs_pt[o]; hord[i] = (int)o;
+  }
+  int maxk = 0;
+  for (int q = 0; q <= p->P; ++q) { hps[q] = (int)pstart[q]; if (q) maxk = std::max<int>(maxk, (int)(pstart[q] - pstart[q - 1])); }
+  for (int64_t q = 0; q <= nch; ++q) hcs[q] = (int)cstart[q];
+  p->max_obs_per_point = maxk;
+
+  HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocDefault));
+
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;
+  p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
+
+#define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
+  TRY(dev_upload(p, &p->obs_u, hu)); TRY(dev_upload(p, &p->obs_v, hv));
+  TRY(dev_upload(p, &p->obs_cam, hcam)); TRY(dev_upload(p, &p->obs_pt, hpt));
+  TRY(dev_upload(p, &p->order, hord)); TRY(dev_upload(p, &p->pt_start, hps)); TRY(dev_upload(p, &p->chunk_start, hcs));
+  std::vector<double> cc(d->cam_const, d->cam_const + (size_t)p->C * 12);
+  TRY(dev_upload(p, &p->cam_const, cc));
+  TRY(dev_upload(p, &p->cam_model, model)); TRY(dev_upload(p, &p->cam_np, np)); TRY(dev_upload(p, &p->cam_off, off));
+  TRY(dev_upload(p, &p->param_cam, pcam)); TRY(dev_upload(p, &p->param_loc, ploc));
+  TRY(dev_alloc(p, &p->tab, (size_t)p->C * CAMTAB_DOUBLES)); TRY(dev_alloc(p, &p->tab_new, (size_t)p->C * CAMTAB_DOUBLES));
+  const long tot = p->lay.total();
+  for (double** v : {&p->x0, &p->x, &p->x_new, &p->g, &p->s, &p->sinv, &p->v1, &p->v2}) {
+    TRY(dev_alloc(p, v, (size_t)tot));
+    if (hipMemset(*v, 0, tot * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
+  }
+  TRY(dev_alloc(p, &p->V, (size_t)6 * p->lay.Ppad));
+  HIPCHK(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
+  const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
+  TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
+  if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
+  const long w_build = (long)p->C * ustride;
+  const long w_schur = (p->schur_lds ? (long)ncp * ncp : 0) + p->lay.ncp_pad;
+  p->partial_width = std::max(w_build, w_schur);
+  TRY(dev_alloc(p, &p->partial, (size_t)p->grid * p->partial_width));
+  TRY(dev_alloc(p, &p->partial4, (size_t)1024 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)1024));
+  TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
+  TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); TRY(dev_alloc(p, &p->Lbuf, (size_t)ncp * ncp));
+  TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
+  TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4));
+  HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
+  HIPCHK(hipMemset(p->flags, 0, 4 * sizeof(int)));
+  HIPCHK(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
+#undef TRY
+  p->h_vec.resize((size_t)tot);
+  HIPCHK(hipDeviceSynchronize());
+  *out = p;
+  return CBA_OK;
+}
+
+int cba_get_info(cba_problem* p, cba_info* o) {
+  if (!p || !o) return fail(CBA_ERR_INVALID, "null argument");
+  o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
+  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_lds ? 1 : 0;
+  o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes;
+  return CBA_OK;
+}
+
+int cba_enable_timers(cba_problem* p, int32_t on) { if (!p) return fail(CBA_ERR_INVALID, "null"); p->timers_on = on != 0; return CBA_OK; }
+int cba_reset_timers(cba_problem* p) {
+  if (!p) return fail(CBA_ERR_INVALID, "null");
+  (void)hipSetDevice(p->device);
+  drain_timers(p);
+  for (int t = 0; t < T_COUNT; ++t) { p->t_ms[t] = 0; p->t_calls[t] = 0; }
+  return CBA_OK;
+}
+int cba_get_timers(cba_problem* p, double* ms, int64_t* calls) {
+  if (!p) return fail(CBA_ERR_INVALID, "null");
+  (void)hipSetDevice(p->device);
+  drain_timers(p);
+  for (int t = 0; t < T_COUNT; ++t) { if (ms) ms[t] = p->t_ms[t]; if (calls) calls[t] = p->t_calls[t]; }
+  return CBA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// layout conversion between the reference parameter vector and the device vector (points SoA)
+static void pack_host(const cba_problem* p, const double* x_ref, double* v, double pad_value) {
+  const VecLayout& L = p->lay;
+  std::fill(v, v + L.total(), pad_value);
+  for (int i = 0; i < L.ncp; ++i) v[i] = x_ref[i];
+  const double* pts = x_ref + L.ncp;
+  double* vx = v + L.ncp_pad;
+  for (int q = 0; q < L.P; ++q) {
+    vx[q] = pts[3 * q]; vx[L.Ppad + q] = pts[3 * q + 1]; vx[2 * L.Ppad + q] = pts[3 * q + 2];
+  }
+}
+static void unpack_host(const cba_problem* p, const double* v, double* x_ref) {
+  const VecLayout& L = p->lay;
+  for (int i = 0; i < L.ncp; ++i) x_ref[i] = v[i];
+  double* pts = x_ref + L.ncp;
+  const double* vx = v + L.ncp_pad;
+  for (int q = 0; q < L.P; ++q) {
+    pts[3 * q] = vx[q]; pts[3 * q + 1] = vx[L.Ppad + q]; pts[3 * q + 2] = vx[2 * L.Ppad + q];
+  }
+}
+
+static int launch_cam_prep(cba_problem* p, const double* xvec, double* tab) {
+  ScopedTimer t(p, T_CAM_PREP);
+  hipLaunchKernelGGL(k_cam_prep, dim3((p->C + 63) / 64), dim3(64), 0, p->stream, xvec, p->cam_const, p->cam_model,
+                     p->cam_np, p->cam_off, p->C, tab);
+  return CBA_OK;
+}
+
+// cost at (xvec, tab) -> scal[slot]; flags[0] set when a residual is not finite
+static int launch_cost(cba_problem* p, const double* xvec, const double* tab, int slot, double* r_out) {
+  const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
+  {
+    ScopedTimer t(p, T_COST);
+    if (r_out)
+      hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(BLOCK), lds_cost(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                         p->obs_pt, p->N, xvec, p->lay, tab, p->C, p->loss, p->f_scale, p->partial1, p->flags, r_out, p->order);
+    else
+      hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(BLOCK), lds_cost(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                         p->obs_pt, p->N, xvec, p->lay, tab, p->C, p->loss, p->f_scale, p->partial1, p->flags,
+                         (double*)nullptr, (const int*)nullptr);
+  }
+  ScopedTimer t(p, T_VECTOR);
+  hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, grid, 1, p->scal + slot);
+  return CBA_OK;
+}
+
+template <int NC>
+static int run_build(cba_problem* p) {
+  {
+    ScopedTimer t(p, T_BUILD);
+    hipLaunchKernelGGL(k_build<NC>, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                       p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->C, p->loss, p->f_scale,
+                       p->V, p->g, p->partial, p->partial1);
+  }
+  {
+    ScopedTimer t(p, T_BUILD_REDUCE);
+    const int w = p->C * UPack<NC>::STRIDE;
+    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 255) / 256), dim3(256), 0, p->stream, p->partial, p->grid, w, p->Upacked);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
+    hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->Upacked,
+                       p->cam_off, p->cam_np, p->C, p->g);
+  }
+  return CBA_OK;
+}
+
+template <int NC>
+static int run_jv(cba_problem* p, int nv) {
+  ScopedTimer t(p, T_JV);
+  const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
+  if (nv == 1)
+    hipLaunchKernelGGL((k_jv<NC, 1>), dim3(grid), dim3(BLOCK), lds_jv(p, 1), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
+                       p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
+  else
+    hipLaunchKernelGGL((k_jv<NC, 2>), dim3(grid), dim3(BLOCK), lds_jv(p, 2), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
+                       p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
+  hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial4, grid, 4, p->scal + 12);
+  return CBA_OK;
+}
+
+template <int NC>
+static int run_linearize(cba_problem* p, cba_linearization* out) {
+  run_build<NC>(p);
+  const long tot = p->lay.total();
+  const int vg = vec_grid(tot);
+  {
+    ScopedTimer t(p, T_SCALE_SCALARS);
+    hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
+                       p->lay, p->first_scale ? 1 : 0, p->sinv);
+    hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->v1, p->partial4, p->partial1);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
+    hipLaunchKernelGGL(k_reduce_rows_max, dim3(1), dim3(64), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
+  }
+  run_jv<NC>(p, 1);
+  int rc = sync_scalars(p, 16);
+  if (rc) return rc;
+  p->first_scale = false;
+  p->gh_sq = p->h_scal[0];
+  out->gh_sq = p->h_scal[0];
+  out->x_scaled_norm = std::sqrt(p->h_scal[1]);
+  out->x_norm = std::sqrt(p->h_scal[2]);
+  out->g_norm_inf = p->h_scal[4];
+  out->cost = 0.5 * p->h_scal[8];
+  out->jg_sq = p->h_scal[12];
+  return CBA_OK;
+}
+
+static int run_cholesky(cba_problem* p) {
+  ScopedTimer t(p, T_CHOLESKY);
+  const int n = p->ncp;
+  HIPCHK(hipMemcpyAsync(p->Lbuf, p->S, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(NB, NB), 0, p->stream, p->Lbuf, n, k0, p->flags);
+    const int rest = n - (k0 + NB);
+    if (rest > 0) {
+      hipLaunchKernelGGL(k_trsm_panel, dim3((rest + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0);
+      const int tiles = (rest + NB - 1) / NB;
+      hipLaunchKernelGGL(k_syrk_trailing, dim3(tiles, tiles), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0);
+    }
+  }
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(BLOCK), (size_t)n * 8, p->stream, p->Lbuf, n, p->rhs, p->s);
+  return CBA_OK;
+}
+
+template <int NC>
+static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
+  const int ncp = p->ncp;
+  HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
+  const long w = (p->schur_lds ? (long)ncp * ncp : 0) + p->lay.ncp_pad;
+  {
+    ScopedTimer t(p, T_SCHUR);
+    if (p->schur_lds) {
+      hipLaunchKernelGGL((k_schur<NC, true>), dim3(p->grid), dim3(BLOCK), lds_schur<NC>(p, true), p->stream, p->obs_u, p->obs_v,
+                         p->obs_cam, p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C,
+                         p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->Sacc, p->partial, p->flags);
+    } else {
+      HIPCHK(hipMemsetAsync(p->Sacc, 0, (size_t)ncp * ncp * sizeof(double), p->stream));
+      hipLaunchKernelGGL((k_schur<NC, false>), dim3(p->grid), dim3(BLOCK), lds_schur<NC>(p, false), p->stream, p->obs_u, p->obs_v,
+                         p->obs_cam, p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C,
+                         p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->Sacc, p->partial, p->flags);
+    }
+  }
+  {
+    ScopedTimer t(p, T_SCHUR_REDUCE);
+    double* dst = p->schur_lds ? p->Sacc : p->Sacc + (size_t)ncp * ncp;
+    hipLaunchKernelGGL(k_reduce_rows, dim3((int)((w + 255) / 256)), dim3(256), 0, p->stream, p->partial, p->grid, (int)w, dst);
+    const long nn = (long)ncp * ncp;
+    hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
+                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs);
+  }
+  int rc = run_cholesky(p);
+  if (rc) return rc;
+  {
+    ScopedTimer t(p, T_BACKSUB);
+    hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                       p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
+                       p->f_scale, lam, p->V, p->g, p->sinv, p->s);
+  }
+  {
+    ScopedTimer t(p, T_VECTOR);
+    const long tot = p->lay.total();
+    const int vg = vec_grid(tot);
+    hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, p->partial4);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
+    hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, p->scal + 17, p->gh_sq, p->partial1);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
+  }
+  rc = sync_scalars(p, 24);
+  if (rc) return rc;
+  out->ok = (p->h_flags[1] == 0 && p->h_flags[2] == 0) ? 1 : 0;
+  out->p_sq = p->h_scal[16];
+  out->gh_dot_p = p->h_scal[17];
+  out->w_sq = p->h_scal[20];
+  if (out->ok && !(std::isfinite(out->p_sq) && std::isfinite(out->gh_dot_p) && std::isfinite(out->w_sq))) out->ok = 0;
+  return CBA_OK;
+}
+
+#define DISPATCH_NC(p, call6, call9) ((p)->nct == 9 ? (call9) : (call6))
+
+extern "C" {
+
+static int begin_common(cba_problem* p, double* cost_out);
+
+int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
+  if (!p || !x0 || !cost_out) return fail(CBA_ERR_INVALID, "cba_begin: null argument");
+  HIPCHK(hipSetDevice(p->device));
+  pack_host(p, x0, p->h_vec.data(), 0.0);
+  HIPCHK(hipMemcpyAsync(p->x0, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  p->have_x0 = true;
+  return begin_common(p, cost_out);
+}
+
+int cba_restart(cba_problem* p, double* cost_out) {
+  if (!p || !cost_out) return fail(CBA_ERR_INVALID, "cba_restart: null argument");
+  if (!p->have_x0) return fail(CBA_ERR_INVALID, "cba_restart: call cba_begin first");
+  HIPCHK(hipSetDevice(p->device));
+  return begin_common(p, cost_out);
+}
+
+static int begin_common(cba_problem* p, double* cost_out) {
+  HIPCHK(hipMemcpyAsync(p->x, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
+  hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
+  launch_cam_prep(p, p->x, p->tab);
+  launch_cost(p, p->x, p->tab, 24, nullptr);
+  int rc = sync_scalars(p, 32);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->first_scale = true;
+  p->begun = true; p->linearized = false; p->stepped = false; p->have_trial = false;
+  *cost_out = p->h_flags[0] ? NAN : 0.5 * p->h_scal[24];
+  return CBA_OK;
+}
+
+int cba_linearize(cba_problem* p, cba_linearization* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_linearize: null argument");
+  if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize: call cba_begin first");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = DISPATCH_NC(p, run_linearize<6>(p, out), run_linearize<9>(p, out));
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->linearized = true; p->stepped = false;
+  return CBA_OK;
+}
+
+int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_newton_step: null argument");
+  if (!p->linearized) return fail(CBA_ERR_INVALID, "cba_newton_step: call cba_linearize first");
+  if (!(lam >= 0.0) || !std::isfinite(lam)) return fail(CBA_ERR_INVALID, "cba_newton_step: lam must be finite and >= 0");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = DISPATCH_NC(p, run_newton<6>(p, lam, out), run_newton<9>(p, lam, out));
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->stepped = true;
+  return CBA_OK;
+}
+
+int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2, double* gram_out) {
+  if (!p || !gram_out) return fail(CBA_ERR_INVALID, "cba_subspace_gram: null argument");
+  if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_subspace_gram: call cba_newton_step first");
+  HIPCHK(hipSetDevice(p->device));
+  const long tot = p->lay.total();
+  {
+    ScopedTimer t(p, T_VECTOR);
+    hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a1, b1, tot, p->v1);
+    hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a2, b2, tot, p->v2);
+  }
+  DISPATCH_NC(p, run_jv<6>(p, 2), run_jv<9>(p, 2));
+  int rc = sync_scalars(p, 16);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  gram_out[0] = p->h_scal[12]; gram_out[1] = p->h_scal[13]; gram_out[2] = p->h_scal[14];
+  return CBA_OK;
+}
+
+int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_trial: null argument");
+  if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_trial: call cba_newton_step first");
+  HIPCHK(hipSetDevice(p->device));
+  const long tot = p->lay.total();
+  const int vg = vec_grid(tot);
+  HIPCHK(hipMemsetAsync(p->flags, 0, sizeof(int), p->stream));
+  {
+    ScopedTimer t(p, T_VECTOR);
+    hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->x_new, p->partial1);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
+  }
+  launch_cam_prep(p, p->x_new, p->tab_new);
+  launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
+  int rc = sync_scalars(p, 32);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  const double c = 0.5 * p->h_scal[24];
+  out->finite = (p->h_flags[0] == 0 && std::isfinite(c)) ? 1 : 0;
+  out->cost = out->finite ? c : NAN;
+  out->step_norm = std::sqrt(p->h_scal[28]);
+  p->have_trial = true;
+  return CBA_OK;
+}
+
+int cba_accept(cba_problem* p) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_accept: null argument");
+  if (!p->have_trial) return fail(CBA_ERR_INVALID, "cba_accept: no trial point");
+  std::swap(p->x, p->x_new);
+  std::swap(p->tab, p->tab_new);
+  p->have_trial = false; p->linearized = false; p->stepped = false;
+  return CBA_OK;
+}
+
+int cba_get_vector(cba_problem* p, int32_t which, double* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_vector: null argument");
+  HIPCHK(hipSetDevice(p->device));
+  const double* src = nullptr;
+  switch (which) {
+    case CBA_VEC_X: src = p->x; break;
+    case CBA_VEC_X_NEW: src = p->x_new; break;
+    case CBA_VEC_GRAD: src = p->g; break;
+    case CBA_VEC_STEP: src = p->s; break;
+    case CBA_VEC_SCALE_INV: src = p->sinv; break;
+    default: return fail(CBA_ERR_INVALID, "cba_get_vector: unknown vector %d", which);
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  HIPCHK(hipMemcpy(p->h_vec.data(), src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+  unpack_host(p, p->h_vec.data(), out);
+  return CBA_OK;
+}
+
+int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_camera_params: null argument");
+  HIPCHK(hipSetDevice(p->device));
+  const double* src = nullptr;
+  switch (which) {
+    case CBA_VEC_X: src = p->x; break;
+    case CBA_VEC_X_NEW: src = p->x_new; break;
+    case CBA_VEC_GRAD: src = p->g; break;
+    case CBA_VEC_STEP: src = p->s; break;
+    case CBA_VEC_SCALE_INV: src = p->sinv; break;
+    default: return fail(CBA_ERR_INVALID, "cba_get_camera_params: unknown vector %d", which);
+  }
+  HIPCHK(hipMemcpyAsync(out, src, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return CBA_OK;
+}
+
+int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out) {
+  if (!p || !x || !r_out) return fail(CBA_ERR_INVALID, "cba_residuals: null argument");
+  HIPCHK(hipSetDevice(p->device));
+  // scratch: v2 holds the vector, tab_new the camera table (both are dead between solver calls)
+  double* d_r = nullptr;
+  HIPCHK(hipMalloc((void**)&d_r, (size_t)2 * p->N * sizeof(double)));
+  pack_host(p, x, p->h_vec.data(), 0.0);
+  hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(p->flags, 0, sizeof(int), p->stream);
+  if (e == hipSuccess) {
+    launch_cam_prep(p, p->v2, p->tab_new);
+    launch_cost(p, p->v2, p->tab_new, 24, d_r);
+    e = hipMemcpyAsync(r_out, d_r, (size_t)2 * p->N * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+  }
+  int rc = (e == hipSuccess) ? sync_scalars(p, 32) : fail(CBA_ERR_HIP, "cba_residuals: %s", hipGetErrorString(e));
+  (void)hipFree(d_r);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->have_trial = false;  // tab_new was overwritten
+  if (cost_out) *cost_out = 0.5 * p->h_scal[24];
+  return CBA_OK;
+}
+
+int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, double* gc, double* gp) {
+  if (!p || !x) return fail(CBA_ERR_INVALID, "cba_normal_blocks: null argument");
+  HIPCHK(hipSetDevice(p->device));
+  // Runs the real build pass on x: swap it in as the current point, then restore.
+  double cost;
+  std::vector<double> saved((size_t)p->lay.total());
+  HIPCHK(hipStreamSynchronize(p->stream));
+  HIPCHK(hipMemcpy(saved.data(), p->x, saved.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const bool was_begun = p->begun;
+  const bool first = p->first_scale;
+  pack_host(p, x, p->h_vec.data(), 0.0);
+  HIPCHK(hipMemcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
+  launch_cam_prep(p, p->x, p->tab);
+  DISPATCH_NC(p, run_build<6>(p), run_build<9>(p));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  HIPCHK(hipGetLastError());
+  (void)cost;
+  const int ustride = (p->nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
+  const int tri = (p->nct == 9) ? UPack<9>::TRI : UPack<6>::TRI;
+  std::vector<double> hU((size_t)p->C * ustride);
+  HIPCHK(hipMemcpy(hU.data(), p->Upacked, hU.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (U) {
+    std::fill(U, U + (size_t)p->C * 81, 0.0);
+    for (int c = 0; c < p->C; ++c) {
+      const int np = p->h_cam_np[c];
+      for (int r = 0; r < np; ++r)
+        for (int k = r; k < np; ++k) {
+          const int idx = r * p->nct - r * (r - 1) / 2 + (k - r);
+          const double v = hU[(size_t)c * ustride + idx];
+          U[(size_t)c * 81 + r * 9 + k] = v;
+          U[(size_t)c * 81 + k * 9 + r] = v;
+        }
+    }
+  }
+  if (gc)
+    for (int c = 0; c < p->C; ++c)
+      for (int r = 0; r < p->h_cam_np[c]; ++r) gc[p->h_cam_off[c] + r] = hU[(size_t)c * ustride + tri + r];
+  if (V) {
+    std::vector<double> hV((size_t)6 * p->lay.Ppad);
+    HIPCHK(hipMemcpy(hV.data(), p->V, hV.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int q = 0; q < p->P; ++q)
+      for (int k = 0; k < 6; ++k) V[(size_t)q * 6 + k] = hV[(size_t)k * p->lay.Ppad + q];
+  }
+  if (gp) {
+    HIPCHK(hipMemcpy(p->h_vec.data(), p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+    const double* vx = p->h_vec.data() + p->lay.ncp_pad;
+    for (int q = 0; q < p->P; ++q) {
+      gp[3 * q] = vx[q]; gp[3 * q + 1] = vx[p->lay.Ppad + q]; gp[3 * q + 2] = vx[2 * p->lay.Ppad + q];
+    }
+  }
+  // restore the solver's current point (its blocks must be rebuilt by the next cba_linearize)
+  HIPCHK(hipMemcpy(p->x, saved.data(), saved.size() * sizeof(double), hipMemcpyHostToDevice));
+  launch_cam_prep(p, p->x, p->tab);
+  HIPCHK(hipStreamSynchronize(p->stream));
+  p->begun = was_begun; p->first_scale = first; p->linearized = false; p->stepped = false;
+  return CBA_OK;
+}
+
+int cba_reduced_system(cba_problem* p, double* S, double* rhs) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_reduced_system: null argument");
+  if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_reduced_system: call cba_newton_step first");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (S) HIPCHK(hipMemcpy(S, p->S, (size_t)p->ncp * p->ncp * sizeof(double), hipMemcpyDeviceToHost));
+  if (rhs) HIPCHK(hipMemcpy(rhs, p->rhs, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost));
+  return CBA_OK;
+}
+
+}  // extern "C"

@@ -100,6 +100,9 @@ class BAEngine(Protocol):
     def trial(self, alpha: float, beta: float) -> Trial:
         """Form ``x_new = x + alpha * d^2 * g + beta * s`` and evaluate the cost there."""
 
+    def camera_params(self, which: int = 0) -> np.ndarray:
+        """Camera part of x (``which=0``) or of the last trial point (``which=1``)."""
+
     def accept(self) -> None:
         """Make the last trial point the current point."""
 

@@ -1,0 +1,183 @@
+"""BAEngine on the MI355X: thin ctypes wrapper over libcaliscope_ba.so (include/caliscope_ba.h).
+
+Everything this class does is marshalling: it flattens a :class:`BAProblem` into the C descriptor and
+forwards each protocol call to the matching ``cba_*`` entry point.  All arithmetic runs in the HIP kernels
+of ``caliscope_amd/csrc``; if the library or a device is missing the constructor raises
+:class:`BackendError` — there is no fallback path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from caliscope_amd import _lib
+from caliscope_amd.engine import LOSS_CODES, BAProblem, Linearization, NewtonStep, Trial
+from caliscope_amd.exceptions import BackendError
+
+VEC_X, VEC_X_NEW, VEC_GRAD, VEC_STEP, VEC_SCALE_INV = range(5)
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_int32_p)
+
+
+class HipEngine:
+    def __init__(self, problem: BAProblem, device_id: int = -1, max_blocks: int = 0):
+        self.lib = _lib.load()
+        self.problem = problem
+        par = problem.parameterization
+        tabs = par.device_tables()
+        self._keep = [
+            np.ascontiguousarray(tabs["cam_n_params"], dtype=np.int32),
+            np.ascontiguousarray(tabs["cam_model"], dtype=np.int32),
+            np.ascontiguousarray(tabs["cam_const"], dtype=np.float64),
+            np.ascontiguousarray(problem.camera_indices, dtype=np.int32),
+            np.ascontiguousarray(problem.obj_indices, dtype=np.int32),
+            np.ascontiguousarray(problem.image_coords, dtype=np.float64),
+        ]
+        desc = _lib.ProblemDesc(
+            n_cams=len(par.blocks), n_points=par.n_points, n_obs=problem.n_obs,
+            cam_n_params=_ip(self._keep[0]), cam_model=_ip(self._keep[1]), cam_const=_dp(self._keep[2]),
+            obs_cam=_ip(self._keep[3]), obs_pt=_ip(self._keep[4]), obs_uv=_dp(self._keep[5]),
+            loss=LOSS_CODES[problem.loss], f_scale=float(problem.f_scale),
+        )
+        opt = _lib.Options(device_id=device_id, max_blocks=max_blocks, deterministic=0, reserved=0)
+        handle = C.c_void_p()
+        self._h = None
+        _lib.check(self.lib, self.lib.cba_create(C.byref(desc), C.byref(opt), C.byref(handle)), "cba_create")
+        self._h = handle
+        self.n_params = par.n_params
+        self.n_cam_params = par.n_camera_params
+        self.n_obs = problem.n_obs
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None:
+            self.lib.cba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        _lib.check(self.lib, rc, what)
+
+    # -- BAEngine protocol ---------------------------------------------------------------------------
+    def begin(self, x0: np.ndarray) -> float:
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if x0.shape != (self.n_params,):
+            raise ValueError(f"x0 has shape {x0.shape}, expected ({self.n_params},)")
+        cost = C.c_double()
+        self._check(self.lib.cba_begin(self._h, _dp(x0), C.byref(cost)), "cba_begin")
+        return cost.value
+
+    def restart(self) -> float:
+        """begin() again from the x0 that is already on the device."""
+        cost = C.c_double()
+        self._check(self.lib.cba_restart(self._h, C.byref(cost)), "cba_restart")
+        return cost.value
+
+    def linearize(self) -> Linearization:
+        o = _lib.Linearization()
+        self._check(self.lib.cba_linearize(self._h, C.byref(o)), "cba_linearize")
+        self.last_cost = o.cost
+        return Linearization(o.g_norm_inf, o.gh_sq, o.jg_sq, o.x_scaled_norm, o.x_norm)
+
+    def newton_step(self, lam: float) -> NewtonStep:
+        o = _lib.NewtonInfo()
+        self._check(self.lib.cba_newton_step(self._h, float(lam), C.byref(o)), "cba_newton_step")
+        return NewtonStep(bool(o.ok), o.p_sq, o.gh_dot_p, o.w_sq)
+
+    def subspace_gram(self, a1, b1, a2, b2):
+        out = np.zeros(3)
+        self._check(self.lib.cba_subspace_gram(self._h, float(a1), float(b1), float(a2), float(b2), _dp(out)), "cba_subspace_gram")
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def trial(self, alpha: float, beta: float) -> Trial:
+        o = _lib.TrialInfo()
+        self._check(self.lib.cba_trial(self._h, float(alpha), float(beta), C.byref(o)), "cba_trial")
+        return Trial(o.cost, o.step_norm, bool(o.finite))
+
+    def accept(self) -> None:
+        self._check(self.lib.cba_accept(self._h), "cba_accept")
+
+    def current_x(self) -> np.ndarray:
+        return self.get_vector(VEC_X)
+
+    # -- parity hooks --------------------------------------------------------------------------------
+    def get_vector(self, which: int) -> np.ndarray:
+        out = np.empty(self.n_params)
+        self._check(self.lib.cba_get_vector(self._h, int(which), _dp(out)), "cba_get_vector")
+        return out
+
+    def camera_params(self, which: int = VEC_X) -> np.ndarray:
+        out = np.empty(self.n_cam_params)
+        self._check(self.lib.cba_get_camera_params(self._h, int(which), _dp(out)), "cba_get_camera_params")
+        return out
+
+    def residuals(self, x: np.ndarray) -> tuple[np.ndarray, float]:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        r = np.empty(2 * self.n_obs)
+        cost = C.c_double()
+        self._check(self.lib.cba_residuals(self._h, _dp(x), _dp(r), C.byref(cost)), "cba_residuals")
+        return r, cost.value
+
+    def normal_blocks(self, x: np.ndarray):
+        """(U [C,9,9], V [P,6], g_c [ncp], g_p [P,3]) of the robust-scaled J^T J, J^T f at x."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        par = self.problem.parameterization
+        U = np.zeros((len(par.blocks), 9, 9))
+        V = np.zeros((par.n_points, 6))
+        gc = np.zeros(self.n_cam_params)
+        gp = np.zeros((par.n_points, 3))
+        self._check(self.lib.cba_normal_blocks(self._h, _dp(x), _dp(U), _dp(V), _dp(gc), _dp(gp)), "cba_normal_blocks")
+        return U, V, gc, gp
+
+    def reduced_system(self):
+        n = self.n_cam_params
+        S, rhs = np.zeros((n, n)), np.zeros(n)
+        self._check(self.lib.cba_reduced_system(self._h, _dp(S), _dp(rhs)), "cba_reduced_system")
+        return S, rhs
+
+    def info(self) -> dict:
+        o = _lib.Info()
+        self._check(self.lib.cba_get_info(self._h, C.byref(o)), "cba_get_info")
+        return {name: getattr(o, name) for name, _ in o._fields_}
+
+    # -- device timers (HIP events on the engine's stream) ------------------------------------------
+    def enable_timers(self, on: bool = True) -> None:
+        self._check(self.lib.cba_enable_timers(self._h, 1 if on else 0), "cba_enable_timers")
+
+    def reset_timers(self) -> None:
+        self._check(self.lib.cba_reset_timers(self._h), "cba_reset_timers")
+
+    def timers(self) -> dict[str, tuple[float, int]]:
+        n = self.lib.cba_timer_count()
+        ms = np.zeros(n)
+        calls = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.cba_get_timers(self._h, _dp(ms), calls.ctypes.data_as(_lib.c_int64_p)), "cba_get_timers")
+        return {self.lib.cba_timer_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
+
+
+def device_count() -> int:
+    return int(_lib.load().cba_device_count())
+
+
+def require_device() -> None:
+    if device_count() <= 0:
+        raise BackendError("no HIP device visible: the MI355X bundle-adjustment engine has no CPU fallback")

@@ -1,0 +1,166 @@
+"""Drop-in for the one solver call of the reference's hot path.
+
+``CaptureVolume.optimize`` (reference ``core/capture_volume.py:387-411``) calls::
+
+    result = least_squares(joint_residuals, x0,
+        args=(parameterization, camera_indices, image_coords, image_to_world_indices,
+              constraint_groups_a, constraint_groups_b, constraint_distances, constraint_weights),
+        jac=joint_jacobian, verbose=verbose, x_scale="jac", loss=loss, f_scale=f_scale,
+        ftol=ftol, max_nfev=max_nfev, method="trf", bounds=parameterization.bounds())
+
+and consumes ``result.status``, ``.x``, ``.nfev`` and ``.cost`` (``:413-432``).  :func:`least_squares` here
+accepts exactly that call and runs it on the MI355X engine: the problem is identified by ``args`` (the
+callables ``fun`` / ``jac`` are the reference's ``joint_residuals`` / ``joint_jacobian``, whose arithmetic the
+HIP kernels implement; they are never invoked).  INTEGRATION.md shows the one-line patch.
+
+Semantics kept from scipy 1.15.3: cost definition, robust losses, ``x_scale='jac'``, termination codes,
+``nfev`` accounting, ``max_nfev=None -> 100 n``, ``ValueError`` for bad options, infeasible ``x0`` or
+non-finite initial residuals.  Differences: the regularised Gauss-Newton step is exact
+(Schur complement) instead of LSMR at 1e-6; finite bounds (free intrinsics) are enforced as a feasibility
+filter on trial points rather than by reflective steps.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from caliscope_amd.engine import LOSS_CODES, BAProblem
+from caliscope_amd.exceptions import BackendError
+from caliscope_amd.trf import STATUS_REASONS, trf_solve
+
+TERMINATION_MESSAGES = {
+    -1: "Improper input parameters status returned from `leastsq`",
+    0: "The maximum number of function evaluations is exceeded.",
+    1: "`gtol` termination condition is satisfied.",
+    2: "`ftol` termination condition is satisfied.",
+    3: "`xtol` termination condition is satisfied.",
+    4: "Both `ftol` and `xtol` termination conditions are satisfied.",
+}
+
+
+class OptimizeResult(dict):
+    """Attribute-style result, same fields the reference reads from scipy's OptimizeResult."""
+
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _make_strictly_feasible(x, lb, ub, rstep=1e-10):
+    """scipy's ``make_strictly_feasible`` (common.py:437-463): nudge points sitting on a bound inside."""
+    x = x.copy()
+    lower_thr = rstep * np.maximum(1, np.abs(lb))
+    upper_thr = rstep * np.maximum(1, np.abs(ub))
+    with np.errstate(invalid="ignore"):
+        lo = np.isfinite(lb) & (x - lb <= np.minimum(ub - x, lower_thr))
+        hi = np.isfinite(ub) & (ub - x <= np.minimum(x - lb, upper_thr))
+    x[lo] = lb[lo] + lower_thr[lo]
+    x[hi] = ub[hi] - upper_thr[hi]
+    bad = (x < lb) | (x > ub)
+    x[bad] = 0.5 * (lb[bad] + ub[bad])
+    return x
+
+
+def least_squares(
+    fun,
+    x0,
+    jac="2-point",
+    bounds=(-np.inf, np.inf),
+    method="trf",
+    ftol=1e-8,
+    xtol=1e-8,
+    gtol=1e-8,
+    x_scale=1.0,
+    loss="linear",
+    f_scale=1.0,
+    diff_step=None,
+    tr_solver=None,
+    tr_options=None,
+    jac_sparsity=None,
+    max_nfev=None,
+    verbose=0,
+    args=(),
+    kwargs=None,
+    *,
+    engine_factory=None,
+):
+    """Solve the bundle-adjustment problem described by ``args`` on the MI355X.
+
+    ``engine_factory(problem) -> BAEngine`` is a test hook (defaults to the HIP engine).
+    """
+    if method != "trf":
+        raise ValueError("the MI355X backend implements method='trf' only (what the reference uses)")
+    if not (isinstance(x_scale, str) and x_scale == "jac"):
+        raise ValueError("the MI355X backend implements x_scale='jac' only (what the reference uses)")
+    if loss not in LOSS_CODES:
+        raise ValueError(f"`loss` must be one of {sorted(LOSS_CODES)} (callables are not supported)")
+    if verbose not in (0, 1, 2):
+        raise ValueError("`verbose` must be in [0, 1, 2].")
+    if max_nfev is not None and max_nfev <= 0:
+        raise ValueError("`max_nfev` must be None or positive integer.")
+    if len(args) < 4:
+        raise ValueError("args must be (parameterization, camera_indices, image_coords, obj_indices, ...) as in CaptureVolume.optimize")
+    parameterization, camera_indices, image_coords, obj_indices = args[:4]
+    if any(a is not None for a in args[4:8]):
+        raise BackendError(
+            "constraint rows (rigid distances) are not implemented in the MI355X engine yet; "
+            "call optimize(use_constraints=False) or use the scipy path for constrained volumes"
+        )
+    x0 = np.atleast_1d(np.asarray(x0, dtype=np.float64))
+    if x0.ndim != 1:
+        raise ValueError("`x0` must have at most 1 dimension.")
+    if x0.size != parameterization.n_params:
+        raise ValueError(f"x0 has {x0.size} entries, the parameterization expects {parameterization.n_params}")
+    for name, tol in (("ftol", ftol), ("xtol", xtol), ("gtol", gtol)):
+        if tol is None:
+            raise ValueError(f"`{name}` must be a number for the MI355X backend")
+    eps = np.finfo(np.float64).eps
+    if ftol < eps and xtol < eps and gtol < eps:
+        raise ValueError(f"At least one of the tolerances must be higher than machine epsilon ({eps:.2e}).")
+
+    lb, ub = (np.broadcast_to(np.asarray(b, dtype=np.float64), x0.shape).copy() for b in bounds)
+    if np.any(lb >= ub):
+        raise ValueError("Each lower bound must be strictly less than each upper bound.")
+    if np.any((x0 < lb) | (x0 > ub)):
+        raise ValueError("Initial guess is outside of provided bounds")
+    bounded = bool(np.any(np.isfinite(lb)) or np.any(np.isfinite(ub)))
+    if bounded:
+        ncp = parameterization.n_camera_params
+        if np.any(np.isfinite(lb[ncp:])) or np.any(np.isfinite(ub[ncp:])):
+            raise BackendError("bounds on world points are not supported (the reference never sets them)")
+        x0 = _make_strictly_feasible(x0, lb, ub)
+
+    problem = BAProblem(parameterization, camera_indices, image_coords, obj_indices, loss=loss, f_scale=float(f_scale))
+    if engine_factory is None:
+        from caliscope_amd.hip_engine import HipEngine
+
+        engine_factory = HipEngine
+    engine = engine_factory(problem)
+    try:
+        feasible = None
+        if bounded:
+            ncp = parameterization.n_camera_params
+            lbc, ubc = lb[:ncp], ub[:ncp]
+
+            def feasible(cam_params):
+                return bool(np.all(cam_params > lbc) and np.all(cam_params < ubc))
+
+        res = trf_solve(engine, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
+    finally:
+        close = getattr(engine, "close", None)
+        if close is not None:
+            close()
+
+    out = OptimizeResult(
+        x=res.x, cost=res.cost, optimality=res.optimality, nfev=res.nfev, njev=res.njev, status=res.status,
+        message=TERMINATION_MESSAGES.get(res.status, STATUS_REASONS.get(res.status, "")), success=res.status > 0,
+        active_mask=np.zeros_like(res.x), n_iterations=res.n_iterations, trace=res.trace,
+    )
+    if verbose >= 1:
+        print(out.message)
+        print(f"Function evaluations {out.nfev}, initial cost {res.trace[0]['cost'] if res.trace else out.cost:.4e}, "
+              f"final cost {out.cost:.4e}, first-order optimality {out.optimality:.2e}.")
+    if not math.isfinite(out.cost):
+        out.status, out.success = -1, False
+    return out

@@ -144,13 +144,24 @@ def trf_solve(
     max_nfev: int | None = None,
     verbose: int = 0,
     max_damping_retries: int = 12,
+    feasible=None,
+    fetch_x: bool = True,
 ) -> TrfResult:
-    """Run the unbounded trust-region loop on ``engine`` starting from ``x0``."""
-    x0 = np.ascontiguousarray(x0, dtype=np.float64)
-    if max_nfev is None:
-        max_nfev = int(x0.size) * 100
+    """Run the trust-region loop on ``engine`` starting from ``x0``.
 
-    cost = engine.begin(x0)
+    ``feasible(camera_params) -> bool`` (optional) is evaluated on the camera part of every trial point;
+    an infeasible trial is treated like a non-finite one (the radius shrinks), which keeps the iterates
+    strictly inside the intrinsic bounds of ``BundleParameterization.bounds()``.
+    """
+    if x0 is None:  # restart from the x0 the engine already holds (bench loops; no host transfer)
+        if max_nfev is None:
+            max_nfev = int(engine.n_params) * 100
+        cost = engine.restart()
+    else:
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if max_nfev is None:
+            max_nfev = int(x0.size) * 100
+        cost = engine.begin(x0)
     if not math.isfinite(cost):
         raise ValueError("Residuals are not finite in the initial point.")
     nfev = 1
@@ -231,7 +242,7 @@ def trf_solve(
             tr = engine.trial(alpha, beta)
             nfev += 1
             step_h_norm = math.hypot(p_S[0], p_S[1])
-            if not tr.finite:
+            if not tr.finite or (feasible is not None and not feasible(engine.camera_params(1))):
                 radius = 0.25 * step_h_norm
                 continue
             cost_new = tr.cost
@@ -257,6 +268,6 @@ def trf_solve(
     if status is None:
         status = 0
     return TrfResult(
-        x=engine.current_x(), cost=float(cost), optimality=float(g_norm), nfev=nfev, njev=njev, status=status,
+        x=engine.current_x() if fetch_x else None, cost=float(cost), optimality=float(g_norm), nfev=nfev, njev=njev, status=status,
         n_iterations=iteration, trace=trace,
     )

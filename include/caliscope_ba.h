@@ -1,0 +1,184 @@
+/* caliscope_ba.h — C ABI of the MI355X-native bundle-adjustment engine (libcaliscope_ba.so).
+ *
+ * The reference has no FFI for this path: the seam is the single Python call
+ *     scipy.optimize.least_squares(joint_residuals, x0, args=(parameterization, camera_indices,
+ *         image_coords, image_to_world_indices, ...), jac=joint_jacobian, x_scale="jac", loss=...,
+ *         f_scale=..., ftol=..., max_nfev=..., method="trf", bounds=...)
+ * at /root/reference/src/caliscope/core/capture_volume.py:387-411.  The entry points below are what a
+ * ctypes binding for that seam needs: a problem object built from exactly the arrays that call
+ * receives, the evaluation primitives of one trust-region iteration (the arithmetic of
+ * core/reprojection.py:75-119 `joint_residuals` and :128-234 `joint_jacobian`, of scipy's
+ * `scale_for_robust_loss_function`, `compute_grad`, `compute_jac_scale` and of the regularised
+ * Gauss-Newton step that scipy gets from LSMR), and parity hooks that expose intermediate results.
+ * The trust-region control flow itself stays on the host (caliscope_amd/trf.py) and sees scalars only.
+ *
+ * Conventions
+ *  - all pointers are caller-owned host memory, C-contiguous, valid for the duration of the call only;
+ *  - every function returns 0 on success, a negative code on error; cba_last_error() (thread-local)
+ *    describes the last failure; no C++ exception crosses this boundary;
+ *  - a cba_problem is not re-entrant (serialise calls per handle); different handles may be used from
+ *    different threads; every entry point selects the handle's device itself;
+ *  - parameter vectors `x` use the reference layout (core/bundle_parameterization.py:36-51,114-149):
+ *    camera i at x[off_i .. off_i+n_i) = [rvec(3), tvec(3) (, s, k1, k2)], then points row-major (P,3);
+ *  - there is NO CPU fallback: without a HIP device cba_create fails with CBA_ERR_NO_DEVICE.
+ */
+#ifndef CALISCOPE_BA_H
+#define CALISCOPE_BA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBA_VERSION 100 /* 0.1.0 */
+
+enum {
+  CBA_OK = 0,
+  CBA_ERR_INVALID = -1,    /* bad argument / inconsistent sizes */
+  CBA_ERR_NO_DEVICE = -2,  /* no usable HIP device */
+  CBA_ERR_HIP = -3,        /* a HIP runtime call failed */
+  CBA_ERR_UNSUPPORTED = -4,/* valid input the engine does not handle yet */
+  CBA_ERR_COMM = -5        /* RCCL failure */
+};
+
+enum { CBA_MODEL_PINHOLE_BC5 = 0, CBA_MODEL_FISHEYE4 = 1 };
+enum { CBA_LOSS_LINEAR = 0, CBA_LOSS_HUBER = 1, CBA_LOSS_SOFT_L1 = 2, CBA_LOSS_CAUCHY = 3, CBA_LOSS_ARCTAN = 4 };
+
+typedef struct cba_problem cba_problem; /* opaque; owns all device memory */
+
+/* The arrays least_squares receives through `args` (capture_volume.py:389-399), flattened.
+ * Replaces: BundleParameterization (blocks -> cam_* tables), camera_indices (int16 in the reference,
+ * widened), image_coords (N,2 AoS float64), image_to_world_indices (int32). */
+typedef struct {
+  int32_t n_cams;
+  int32_t n_points;
+  int64_t n_obs;
+  const int32_t* cam_n_params; /* [C] 6 (locked) or 9 (free intrinsics: + s, k1, k2)          */
+  const int32_t* cam_model;    /* [C] CBA_MODEL_*                                              */
+  const double* cam_const;     /* [C][12] fx0 fy0 cx cy | k1 k2 p1 p2 k3 (pinhole) or k1..k4 0 (fisheye) | 0 0 0 */
+  const int32_t* obs_cam;      /* [N] camera index of each observation                         */
+  const int32_t* obs_pt;       /* [N] world-point row of each observation                      */
+  const double* obs_uv;        /* [N][2] observed pixel (img_loc_x, img_loc_y)                 */
+  int32_t loss;                /* CBA_LOSS_* — scipy's `loss`                                  */
+  double f_scale;              /* scipy's `f_scale`                                            */
+} cba_problem_desc;
+
+typedef struct {
+  int32_t device_id;     /* HIP device ordinal; -1 = current device                                  */
+  int32_t max_blocks;    /* 0 = default (4 workgroups per CU); upper bound on persistent grid size   */
+  int32_t deterministic; /* reserved (reductions through per-workgroup partials are already ordered) */
+  int32_t reserved;
+} cba_options;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int cba_create(const cba_problem_desc* desc, const cba_options* opt, cba_problem** out);
+void cba_destroy(cba_problem* p);
+
+/* ---- one trust-region iteration, as primitives (scalars out, vectors stay on the device) ------ */
+
+/* Upload x0 (reference layout, length n = sum(cam_n_params) + 3 P), evaluate the residuals there.
+ * cost_out = 0.5 * sum rho(f) — scipy's `cost` (least_squares.py:838-864).  Resets the Jacobi scaling. */
+int cba_begin(cba_problem* p, const double* x0, double* cost_out);
+
+/* Same as cba_begin with the x0 of the last cba_begin, which is kept on the device (no host transfer). */
+int cba_restart(cba_problem* p, double* cost_out);
+
+typedef struct {
+  double g_norm_inf;    /* ||J^T f||_inf                      (trf.py:459)                       */
+  double gh_sq;         /* ||g_h||^2,  g_h = g / scale_inv    (trf.py:469)                       */
+  double jg_sq;         /* ||J_h g_h||^2                      (build_quadratic_1d, trf.py:480)   */
+  double x_scaled_norm; /* ||x * scale_inv||                  (trf.py:428, initial Delta)        */
+  double x_norm;        /* ||x||                              (check_termination)                */
+  double cost;          /* cost at the current x (re-evaluated with the build pass)              */
+} cba_linearization;
+
+/* Residuals + Jacobian blocks at the current x, robust-loss scaling (common.py:720-731), g = J^T f,
+ * U_c = sum A^T A, V_p = sum B^T B, Jacobi scale with the monotone-max rule (common.py:598-610). */
+int cba_linearize(cba_problem* p, cba_linearization* out);
+
+typedef struct {
+  int32_t ok;       /* 0: a Cholesky pivot was not positive (raise `lam` and retry)              */
+  int32_t reserved;
+  double p_sq;      /* ||p||^2,  p = scale_inv * s   (scaled step)                                */
+  double gh_dot_p;  /* <g_h, p> = <g, s>                                                          */
+  double w_sq;      /* ||p - (<g_h,p>/||g_h||^2) g_h||^2                                          */
+} cba_newton_info;
+
+/* Solve (J^T J + lam * diag(scale_inv^2)) s = -g by Schur complement on the reduced camera system:
+ * replaces lsmr(J_h, f, damp=sqrt(reg_term)) at trf.py:485 with an exact damped step. */
+int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out);
+
+/* gram_out = { |J v1|^2, <J v1, J v2>, |J v2|^2 },  v_i = a_i * g / scale_inv^2 + b_i * s
+ * (explicit J_h @ S of trf.py:488-489; only used when the subspace basis is ill-conditioned). */
+int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2, double* gram_out);
+
+typedef struct {
+  double cost;      /* 0.5 * sum rho(f(x_new)); NaN if any residual is not finite                 */
+  double step_norm; /* ||x_new - x||                                                              */
+  int32_t finite;
+  int32_t reserved;
+} cba_trial_info;
+
+/* x_new = x + alpha * g / scale_inv^2 + beta * s ; evaluate the cost there (trf.py:496-511). */
+int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out);
+
+/* x <- x_new (trf.py:525-526). */
+int cba_accept(cba_problem* p);
+
+/* ---- parity hooks / readback -------------------------------------------------------------------- */
+enum { CBA_VEC_X = 0, CBA_VEC_X_NEW = 1, CBA_VEC_GRAD = 2, CBA_VEC_STEP = 3, CBA_VEC_SCALE_INV = 4 };
+
+/* Download a device vector in the reference layout (length n). */
+int cba_get_vector(cba_problem* p, int32_t which, double* out);
+
+/* Download only the camera part (first n_cam_params entries) of a device vector — cheap (<= 9 KB);
+ * used by the host to test trial points against the intrinsic bounds. */
+int cba_get_camera_params(cba_problem* p, int32_t which, double* out);
+
+/* joint_residuals(x) in the caller's observation order, interleaved (x0,y0,x1,y1,...) [2N], and the
+ * (robust) cost.  Does not disturb the solver state. */
+int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out);
+
+/* Blocks of J^T J and J^T f at x (robust-scaled like scipy's J, f):
+ *   U [C][9][9] dense symmetric (upper-left n_c x n_c used), V [P][6] = xx xy xz yy yz zz,
+ *   gc [sum n_c], gp [P][3].  Does not disturb the solver state except the scratch blocks. */
+int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, double* gc, double* gp);
+
+/* The reduced camera system of the LAST cba_newton_step: S [ncp][ncp] symmetric (full), rhs [ncp]. */
+int cba_reduced_system(cba_problem* p, double* S, double* rhs);
+
+/* ---- introspection ------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t n_cams, n_points, n_cam_params, n_params;
+  int64_t n_obs;
+  int32_t n_chunks, grid_blocks;
+  int32_t schur_in_lds;   /* 1: S accumulated in LDS tiles, 0: global atomics */
+  int32_t max_obs_per_point;
+  int64_t device_bytes;
+} cba_info;
+int cba_get_info(cba_problem* p, cba_info* out);
+
+/* Accumulated device time per kernel family since the last reset, measured with HIP events on the
+ * engine's stream; names/ms arrays of length >= cba_timer_count(). */
+int cba_timer_count(void);
+const char* cba_timer_name(int32_t i);
+int cba_get_timers(cba_problem* p, double* ms_out, int64_t* calls_out);
+int cba_reset_timers(cba_problem* p);
+int cba_enable_timers(cba_problem* p, int32_t on);
+
+/* Host-side planning only (no device needed): observation order sorted by point (stable), CSR offsets
+ * per point and the chunk table (whole points per chunk, at most `chunk_cap` observations).
+ * order_out [N], pt_start_out [P+1], chunk_start_out [N+1 worst case]; returns the number of chunks
+ * (>= 0) or a negative error (a point with more than chunk_cap observations is CBA_ERR_UNSUPPORTED). */
+int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, int32_t chunk_cap,
+                      int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out);
+
+const char* cba_last_error(void);
+int cba_version(void);
+int cba_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALISCOPE_BA_H */

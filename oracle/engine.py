@@ -222,6 +222,9 @@ class OracleEngine:
         cost = self._cost(self.f_new)
         return _Trial(cost, float(np.sqrt(self._norm_sq(step))), bool(np.isfinite(cost)))
 
+    def camera_params(self, which=0):
+        return (self.x_new if which == 1 else self.x)[: self.ncp].copy()
+
     def accept(self):
         self.x = self.x_new
         self.f_raw = self.f_new

@@ -1,0 +1,53 @@
+// CPU harness around caliscope_amd/csrc/ba_math.h — TEST INFRASTRUCTURE (built by g++ in
+// tests/test_native_math.py).  It lets the non-GPU test-suite compare the exact per-observation
+// arithmetic the HIP kernels inline (projection, Jacobian blocks, robust-loss scaling, 3x3 Cholesky)
+// with the numpy oracle.  It is not a CPU fallback: nothing in caliscope_amd/ loads it.
+#include "ba_math.h"
+
+extern "C" {
+
+// A_out: [2][9] row-major (unused columns zero), B_out: [2][3]
+void mh_project_full(const double* x_cam, const double* cconst, int model, int nparams, const double* X,
+                     const double* uv, double* e_out, double* A_out, double* B_out) {
+  cba::CamTab tab;
+  cba::cam_prepare(x_cam, cconst, model, nparams, &tab);
+  double A[2][cba::MAX_NC] = {{0}}, B[2][3];
+  cba::project_full(tab, X[0], X[1], X[2], uv[0], uv[1], e_out, A, B);
+  for (int r = 0; r < 2; ++r) {
+    for (int c = 0; c < cba::MAX_NC; ++c) A_out[r * cba::MAX_NC + c] = (c < nparams) ? A[r][c] : 0.0;
+    for (int c = 0; c < 3; ++c) B_out[r * 3 + c] = B[r][c];
+  }
+}
+
+void mh_project_residual(const double* x_cam, const double* cconst, int model, int nparams, const double* X,
+                         const double* uv, double* e_out) {
+  cba::CamTab tab;
+  cba::cam_prepare(x_cam, cconst, model, nparams, &tab);
+  cba::project_residual(tab, X[0], X[1], X[2], uv[0], uv[1], e_out);
+}
+
+void mh_cam_table(const double* x_cam, const double* cconst, int model, int nparams, double* out48) {
+  cba::CamTab tab;
+  cba::cam_prepare(x_cam, cconst, model, nparams, &tab);
+  const double* p = reinterpret_cast<const double*>(&tab);
+  for (int i = 0; i < cba::CAMTAB_DOUBLES; ++i) out48[i] = p[i];
+}
+
+// out: rho0*fs^2, row_scale, r_scaled, cost_only
+void mh_robust(int loss, double f_scale, double r, double* out) {
+  double rs, rr;
+  out[0] = cba::robust_one(loss, f_scale, r, &rs, &rr);
+  out[1] = rs;
+  out[2] = rr;
+  out[3] = cba::robust_cost_one(loss, f_scale, r);
+}
+
+// solves V x = b via chol3; returns 1 on success
+int mh_chol3_solve(const double* v6, const double* b, double* x) {
+  double L[6], y[3];
+  if (!cba::chol3(v6, L)) return 0;
+  cba::chol3_fwd(L, b, y);
+  cba::chol3_bwd(L, y, x);
+  return 1;
+}
+}

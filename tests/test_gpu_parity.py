@@ -1,0 +1,288 @@
+"""HIP engine vs the oracle, through the C ABI, on a real MI355X (run with ``-m gpu``).
+
+Tiers: (i) evaluation parity — residual vector, cost, J^T J blocks, J^T f — at <= 1e-11
+relative; (ii) step parity — the damped Gauss-Newton step of one (x, lam) against the numpy Schur solve;
+(iii) converged parity — full solves against the reference's scipy call, gauge-aligned <= 1e-6 relative,
+cost equal to 1e-8 relative, RMS reprojection error within 1e-4 px.
+"""
+import numpy as np
+import pandas as pd
+import pytest
+
+from caliscope_amd.bundle_parameterization import BundleParameterization
+from caliscope_amd.cameras import CameraArray
+from caliscope_amd.engine import BAProblem
+from caliscope_amd.least_squares import least_squares
+from caliscope_amd.synthetic import make_scene
+from caliscope_amd.trf import trf_solve
+from tests.helpers import aligned_difference, small_problem
+from tests.test_oracle_pins import _mixed_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from caliscope_amd import build
+    from caliscope_amd.hip_engine import require_device
+
+    build.build(verbose=False)
+    require_device()  # fail loudly: these tests must never pass without the HIP extension
+
+
+def _engines(par, cam, uv, obj, loss="linear", f_scale=1.0):
+    from caliscope_amd.hip_engine import HipEngine
+    from oracle.engine import OracleEngine
+
+    hip = HipEngine(BAProblem(par, cam, uv, obj, loss=loss, f_scale=f_scale))
+    ora = OracleEngine(par, cam, uv, obj, loss=loss, f_scale=f_scale)
+    return hip, ora
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+CASES = {
+    "pinhole_locked_C8": dict(n_cams=8, n_points=500, k=8),
+    "pinhole_refine_C6": dict(n_cams=6, n_points=300, k=6, refine=True),
+    "huber_outliers_C8": dict(n_cams=8, n_points=400, k=8, loss="huber", outliers=0.05),
+    "softl1_outliers_C5": dict(n_cams=5, n_points=300, k=5, loss="soft_l1", outliers=0.05),
+    "global_atomics_C24": dict(n_cams=24, n_points=600, k=10),
+    "refine_global_C16": dict(n_cams=16, n_points=400, k=8, refine=True),
+}
+
+
+def _case(name):
+    cfg = dict(CASES[name])
+    loss = cfg.pop("loss", "linear")
+    sc, par, x0 = small_problem(loss=loss, **cfg)
+    fs = sc.f_scale_1px() * 2.0 if loss != "linear" else 1.0
+    return sc, par, x0, loss, fs
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_evaluation_parity(name):
+    from oracle.residuals import joint_jacobian, joint_residuals
+    from scipy.optimize._lsq.common import scale_for_robust_loss_function
+    from scipy.optimize._lsq.least_squares import construct_loss_function
+
+    sc, par, x0, loss, fs = _case(name)
+    hip, _ = _engines(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss, fs)
+    r_ref = joint_residuals(x0, par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    r, cost = hip.residuals(x0)
+    assert _rel(r, r_ref) < 1e-12
+    J = joint_jacobian(x0, par, sc.camera_indices, sc.image_coords, sc.obj_indices).tocsr()
+    f = r_ref.copy()
+    if loss == "linear":
+        cost_ref = 0.5 * float(f @ f)
+    else:
+        fn = construct_loss_function(len(f), loss, fs)
+        cost_ref = float(fn(f, cost_only=True))
+        J, f = scale_for_robust_loss_function(J, f, fn(f))
+    assert abs(cost - cost_ref) <= 1e-13 * cost_ref
+    H = (J.T @ J).toarray()
+    g = np.asarray(J.T @ f).ravel()
+    U, V, gc, gp = hip.normal_blocks(x0)
+    ncp = par.n_camera_params
+    hscale = np.abs(H).max()
+    for c, blk in enumerate(par.blocks):
+        o, n = par.camera_param_offsets[c], blk.n_params
+        assert np.abs(U[c, :n, :n] - H[o : o + n, o : o + n]).max() < 1e-11 * hscale, c
+    P = par.n_points
+    Vref = np.stack([H[ncp + 3 * np.arange(P) + a, ncp + 3 * np.arange(P) + b] for a, b in ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))], axis=1)
+    assert np.abs(V - Vref).max() < 1e-11 * hscale
+    assert _rel(gc, g[:ncp]) < 1e-11
+    assert np.abs(gp.reshape(-1) - g[ncp:]).max() < 1e-11 * np.abs(g).max()
+    hip.close()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_step_parity(name):
+    sc, par, x0, loss, fs = _case(name)
+    hip, ora = _engines(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss, fs)
+    c_h, c_o = hip.begin(x0), ora.begin(x0)
+    assert abs(c_h - c_o) <= 1e-13 * c_o
+    lh, lo = hip.linearize(), ora.linearize()
+    for fld in ("g_norm_inf", "gh_sq", "jg_sq", "x_scaled_norm", "x_norm"):
+        assert abs(getattr(lh, fld) - getattr(lo, fld)) <= 1e-10 * abs(getattr(lo, fld)), fld
+    assert _rel(hip.get_vector(4), ora.scale_inv) < 1e-12  # scale_inv
+    assert np.abs(hip.get_vector(2) - ora.g).max() < 1e-11 * np.abs(ora.g).max()
+    info = hip.info()
+    assert info["schur_in_lds"] == (0 if "global" in name else 1)
+    for lam in (1e-3, 1e-7):
+        sh, so = hip.newton_step(lam), ora.newton_step(lam)
+        assert sh.ok and so.ok
+        s_h = hip.get_vector(3)
+        assert np.abs(s_h - ora.s).max() < 1e-8 * np.abs(ora.s).max(), lam
+        for fld in ("p_sq", "gh_dot_p", "w_sq"):
+            assert abs(getattr(sh, fld) - getattr(so, fld)) <= 1e-7 * abs(getattr(so, fld)), (fld, lam)
+        # the reduced camera system itself
+        S, rhs = hip.reduced_system()
+        assert np.allclose(S, S.T, rtol=0, atol=1e-14 * np.abs(S).max())
+        assert np.linalg.norm(S @ s_h[: par.n_camera_params] - rhs) < 1e-8 * np.linalg.norm(rhs)
+        gh, go = hip.subspace_gram(0.3, -1.2, 1.1, 0.4), ora.subspace_gram(0.3, -1.2, 1.1, 0.4)
+        assert np.allclose(gh, go, rtol=1e-7)
+        th, to = hip.trial(-1e-3, 0.5), ora.trial(-1e-3, 0.5)
+        assert th.finite and abs(th.cost - to.cost) <= 1e-9 * to.cost
+        assert abs(th.step_norm - to.step_norm) <= 1e-7 * to.step_norm
+    hip.accept(); ora.accept()
+    lh, lo = hip.linearize(), ora.linearize()  # second linearisation exercises the monotone-max scale rule
+    assert abs(lh.gh_sq - lo.gh_sq) <= 1e-7 * lo.gh_sq and abs(lh.jg_sq - lo.jg_sq) <= 1e-7 * lo.jg_sq
+    assert _rel(hip.get_vector(4), ora.scale_inv) < 1e-9
+    hip.close()
+
+
+def test_mixed_fisheye_pinhole_blocks_and_solve():
+    from oracle.residuals import joint_jacobian, joint_residuals
+
+    ca, points, uv, cam_idx, obj_idx = _mixed_arrays()
+    par = BundleParameterization.from_camera_array(ca, n_points=len(points), refine_intrinsics=True)
+    x0 = par.pack(ca, points)
+    hip, ora = _engines(par, cam_idx.astype(np.int32), uv, obj_idx)
+    r, _ = hip.residuals(x0)
+    assert _rel(r, joint_residuals(x0, par, cam_idx, uv, obj_idx)) < 1e-12
+    J = joint_jacobian(x0, par, cam_idx, uv, obj_idx)
+    U, V, gc, gp = hip.normal_blocks(x0)
+    H = (J.T @ J).toarray()
+    assert np.abs(U[0, :6, :6] - H[:6, :6]).max() < 1e-11 * np.abs(H).max()
+    assert np.abs(U[1, :9, :9] - H[6:15, 6:15]).max() < 1e-11 * np.abs(H).max()
+    hip.begin(x0); ora.begin(x0)
+    hip.linearize(); ora.linearize()
+    sh, so = hip.newton_step(1e-4), ora.newton_step(1e-4)
+    assert sh.ok and np.abs(hip.get_vector(3) - ora.s).max() < 1e-8 * np.abs(ora.s).max()
+    hip.close()
+
+
+def test_ragged_views_unobserved_points_and_shuffled_rows():
+    """Points with 2..9 views, two points without any observation, rows in random order."""
+    from oracle.residuals import joint_residuals
+
+    rng = np.random.default_rng(5)
+    sc = make_scene(n_cams=9, n_points=350, n_obs=350 * 9)
+    keep = np.ones(sc.n_obs, dtype=bool)
+    for p in range(350):
+        rows = np.flatnonzero(sc.obj_indices == p)
+        drop = rng.integers(0, 8) if p not in (17, 200) else 9
+        keep[rng.permutation(rows)[:drop]] = False
+    perm = rng.permutation(np.flatnonzero(keep))
+    cam, uv, obj = sc.camera_indices[perm], sc.image_coords[perm], sc.obj_indices[perm]
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=350, refine_intrinsics=False)
+    x0 = par.pack(sc.cameras_init, sc.points_init)
+    hip, ora = _engines(par, cam, uv, obj)
+    r, _ = hip.residuals(x0)
+    assert _rel(r, joint_residuals(x0, par, cam, uv, obj)) < 1e-12  # caller's row order is preserved
+    hip.begin(x0); ora.begin(x0)
+    lh, lo = hip.linearize(), ora.linearize()
+    assert abs(lh.jg_sq - lo.jg_sq) <= 1e-10 * lo.jg_sq
+    sh, so = hip.newton_step(1e-6), ora.newton_step(1e-6)
+    s = hip.get_vector(3)
+    assert sh.ok and np.abs(s - ora.s).max() < 1e-8 * np.abs(ora.s).max()
+    ncp = par.n_camera_params
+    assert np.all(s[ncp + 3 * 17 : ncp + 3 * 18] == 0) and np.all(s[ncp + 3 * 200 : ncp + 3 * 201] == 0)
+    hip.close()
+
+
+def _solve_both(par, cam, uv, obj, x0, loss="linear", f_scale=1.0, **tol):
+    from oracle.solver import optimize_scipy
+
+    ref = optimize_scipy(par, cam, uv, obj, x0, loss=loss, f_scale=f_scale, **tol)
+    got = least_squares(None, x0, args=(par, cam, uv, obj, None, None, None, None), x_scale="jac", loss=loss,
+                        f_scale=f_scale, bounds=par.bounds(), method="trf", **tol)
+    return ref, got
+
+
+@pytest.mark.parametrize("name", ["pinhole_locked_C8", "huber_outliers_C8", "global_atomics_C24", "pinhole_refine_C6"])
+def test_converged_parity_with_scipy(name):
+    from oracle.solver import rms_reprojection_px
+
+    sc, par, x0, loss, fs = _case(name)
+    tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=400)
+    ref, got = _solve_both(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, loss, fs, **tol)
+    assert got.status > 0
+    assert got.cost <= ref.cost * (1 + 1e-8)
+    args = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    assert abs(rms_reprojection_px(*args, got.x) - rms_reprojection_px(*args, ref.x)) < 1e-4
+    pos, ang, _ = aligned_difference(par, got.x, ref.x)
+    lim = 1e-6 if "refine" not in name else 1e-5  # free f/k1/k2 has a weakly determined scale-focal direction
+    assert pos < lim and ang < lim, (pos, ang)
+
+
+def test_default_tolerances_match_scipy_iteration_count():
+    sc, par, x0, loss, fs = _case("pinhole_locked_C8")
+    ref, got = _solve_both(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0)
+    assert got.status in (1, 2, 3, 4) and abs(got.nfev - ref.nfev) <= 2
+    assert abs(got.cost - ref.cost) <= 1e-8 * ref.cost
+
+
+def test_capture_volume_optimize_real_session(golden_dir):
+    """BASELINE.json configs[0]: the reference's 4-camera ChArUco session through the mirrored
+    CaptureVolume.optimize() -> filter -> optimize() sequence (reference tests/test_capture_volume.py:354-415)."""
+    from caliscope_amd.capture_volume import CaptureVolume
+    from caliscope_amd.point_data import ImagePoints, WorldPoints
+    from oracle.solver import optimize_scipy, rms_reprojection_px
+
+    d = golden_dir / "post_optimization"
+    cv = CaptureVolume(CameraArray.from_toml(d / "camera_array.toml"), ImagePoints.from_csv(d / "xy_CHARUCO.csv"),
+                       WorldPoints.from_csv(d / "xyz_CHARUCO.csv"))
+    r0 = cv.reprojection_report.overall_rmse
+    assert cv.reprojection_report.n_observations_matched == 2175 and abs(r0 - 1.6625073265) < 1e-6
+    opt = cv.optimize()
+    st = opt.optimization_status
+    assert st.converged and st.termination_reason.startswith("converged") and st.iterations >= 2
+    assert cv.optimization_status is None and cv.camera_array is not opt.camera_array  # immutability
+    r1 = opt.reprojection_report.overall_rmse
+    # same inputs through the reference's scipy call
+    _, cam, uv, obj = cv._matched_arrays()
+    par = BundleParameterization.from_camera_array(cv.camera_array, n_points=len(cv.world_points), refine_intrinsics=False)
+    ref = optimize_scipy(par, cam, uv, obj, par.pack(cv.camera_array, cv.world_points.points))
+    assert abs(r1 - rms_reprojection_px(par, cam, uv, obj, ref.x)) < 1e-4 and r1 < r0
+    assert abs(st.final_cost - ref.cost) <= 1e-8 * ref.cost
+    filtered = opt.filter_by_percentile_error(50.0)
+    assert filtered.optimization_status is None
+    r2 = filtered.reprojection_report.overall_rmse
+    r3 = filtered.optimize().reprojection_report.overall_rmse
+    assert r3 <= r2 < r1
+
+
+def test_strict_raises_when_not_converged_and_soft_l1_stage():
+    from caliscope_amd.capture_volume import CaptureVolume
+    from caliscope_amd.exceptions import CalibrationError
+
+    sc = make_scene(n_cams=6, n_points=300, n_obs=1800, outliers=0.05)
+    cv = CaptureVolume.from_arrays(sc.cameras_init, sc.camera_indices, sc.image_coords, sc.obj_indices, sc.points_init)
+    with pytest.raises(CalibrationError, match="max_evaluations"):
+        cv.optimize(max_nfev=2, ftol=1e-15)
+    loose = cv.optimize(max_nfev=2, ftol=1e-15, strict=False)
+    assert not loose.optimization_status.converged and loose.optimization_status.iterations == 2
+    # the product's robust stage (calibrate_extrinsics.py:230-238)
+    robust = cv.optimize(loss="soft_l1", f_scale=cv.pixel_f_scale(1.0), max_nfev=2000, ftol=1e-4, strict=False)
+    assert robust.optimization_status.final_cost < cv.optimize(max_nfev=1, strict=False, loss="soft_l1", f_scale=cv.pixel_f_scale(1.0)).optimization_status.final_cost
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE cfg 2 at full size (8 cams / 5k points / 40k obs): size-independent properties —
+    cost equals 0.5*|r|^2 of the returned residual vector, the gradient vanishes at the solution,
+    a second solve from the solution stops immediately, and the linear model is exact for J.v."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc = make_scene("cfg2", n_cams=8, n_points=5000, n_obs=40000)
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=5000, refine_intrinsics=False)
+    x0 = par.pack(sc.cameras_init, sc.points_init)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    with HipEngine(prob) as eng:
+        r, cost = eng.residuals(x0)
+        assert abs(cost - 0.5 * float(r @ r)) <= 1e-12 * cost
+        res = trf_solve(eng, x0)
+        assert res.status > 0 and res.cost < 0.01 * cost
+        px = np.sqrt(np.mean(np.sum((eng.residuals(res.x)[0].reshape(-1, 2) * 1394.6) ** 2, axis=1)))
+        assert 0.55 < px < 0.75  # ~ sigma*sqrt(2) of the 0.5 px noise (reference tests/synthetic/README.md:155)
+        again = trf_solve(eng, res.x, gtol=1e-6)
+        assert again.nfev == 1 and again.status == 1
+        # finite-difference check of J.v through the cost: d/dt cost(x + t v) = g.v
+        eng.begin(x0)
+        lin = eng.linearize()
+        eng.newton_step(1e-6)
+        t = 1e-7
+        c_plus, c_minus = eng.trial(t, 0.0).cost, eng.trial(-t, 0.0).cost
+        assert abs((c_plus - c_minus) / (2 * t) - lin.gh_sq) <= 1e-5 * lin.gh_sq

@@ -1,0 +1,85 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/caliscope_ba.h declares;
+host-side planning (no device needed) is checked against numpy."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from caliscope_amd import _lib, build
+from caliscope_amd.exceptions import BackendError
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    header = (ROOT / "include" / "caliscope_ba.h").read_text()
+    declared = set(re.findall(r"\b(cba_[a-z_0-9]+)\s*\(", header))
+    declared -= {"cba_problem"}
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.cba_version() == 100
+    assert lib.cba_timer_count() == 11 and lib.cba_timer_name(2) == b"build"
+
+
+def test_create_fails_loudly_without_device(lib):
+    if lib.cba_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    from caliscope_amd.engine import BAProblem
+    from caliscope_amd.hip_engine import HipEngine
+    from tests.helpers import small_problem
+
+    sc, par, _ = small_problem(n_cams=3, n_points=10, k=3)
+    with pytest.raises(BackendError, match="no HIP device|NO_DEVICE|no CPU fallback"):
+        HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices))
+
+
+def _plan(lib, n_points, obs_pt, cap):
+    obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+    n = len(obs_pt)
+    order = np.zeros(max(n, 1), dtype=np.int64)
+    pstart = np.zeros(n_points + 1, dtype=np.int64)
+    cstart = np.zeros(n + 2, dtype=np.int64)
+    nch = lib.cba_host_plan(n_points, n, obs_pt.ctypes.data_as(_lib.c_int32_p), cap,
+                            order.ctypes.data_as(_lib.c_int64_p), pstart.ctypes.data_as(_lib.c_int64_p),
+                            cstart.ctypes.data_as(_lib.c_int64_p))
+    return nch, order[:n], pstart, cstart[: max(nch, 0) + 1]
+
+
+def test_host_plan_sorts_by_point_and_chunks_whole_points(lib):
+    rng = np.random.default_rng(0)
+    n_points = 500
+    counts = rng.integers(0, 12, n_points)  # ragged, including points without observations
+    obs_pt = np.repeat(np.arange(n_points), counts)
+    rng.shuffle(obs_pt)
+    nch, order, pstart, cstart = _plan(lib, n_points, obs_pt, 256)
+    assert nch > 0
+    assert np.array_equal(order, np.argsort(obs_pt, kind="stable"))
+    assert np.array_equal(pstart, np.concatenate([[0], np.cumsum(counts)]))
+    assert cstart[0] == 0 and cstart[-1] == len(obs_pt)
+    sizes = np.diff(cstart)
+    assert sizes.min() > 0 and sizes.max() <= 256
+    assert np.all(np.isin(cstart, pstart)), "chunk boundaries must coincide with point boundaries"
+    # greedy packing: a chunk plus the next point would overflow
+    sorted_pts = obs_pt[order]
+    for c in range(nch - 1):
+        nxt = sorted_pts[cstart[c + 1]]
+        assert sizes[c] + counts[nxt] > 256
+
+
+def test_host_plan_rejects_bad_input(lib):
+    nch, *_ = _plan(lib, 4, np.array([0, 1, 7]), 256)
+    assert nch == -1 and b"out of range" in lib.cba_last_error()
+    nch, *_ = _plan(lib, 2, np.zeros(300, dtype=np.int32), 256)
+    assert nch == -4 and b"at most 256" in lib.cba_last_error()
+    nch, order, pstart, cstart = _plan(lib, 3, np.array([], dtype=np.int32), 256)
+    assert nch == 0
