@@ -64,8 +64,16 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
 
 __device__ __forceinline__ void lds_add(double* addr, double v) { unsafeAtomicAdd(addr, v); }
 
+// LDS copy of the camera table.  Rows are padded to 49 doubles: with the natural stride of 48 doubles
+// (96 dwords == 32 mod 64 banks) the lanes of a wave, each reading the same field of a different camera,
+// would land on two bank pairs (32-way conflict); an odd stride spreads 32 cameras over all bank pairs.
+constexpr int CAMTAB_LDS = CAMTAB_DOUBLES + 1;
 __device__ __forceinline__ void stage_camtab(double* sh_tab, const double* tab, int n_cams) {
-  for (int i = threadIdx.x; i < n_cams * CAMTAB_DOUBLES; i += BLOCK) sh_tab[i] = tab[i];
+  for (int i = threadIdx.x; i < n_cams * CAMTAB_DOUBLES; i += BLOCK)
+    sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[i];
+}
+__device__ __forceinline__ const CamTab& cam_at(const double* sh_tab, int cam) {
+  return *reinterpret_cast<const CamTab*>(sh_tab + cam * CAMTAB_LDS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -94,17 +102,16 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
        int* __restrict__ flags, double* __restrict__ r_out, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_red = sh + n_cams * CAMTAB_DOUBLES;
+  double* sh_red = sh + n_cams * CAMTAB_LDS;
   stage_camtab(sh_tab, tab, n_cams);
   __syncthreads();
-  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
   const double* px = xvec + lay.ncp_pad;
   double acc = 0.0;
   bool bad = false;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
     const int cam = obs_cam[i], pt = obs_pt[i];
     double e[2];
-    project_residual(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], e);
+    project_residual(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], e);
     if (!(isfinite(e[0]) && isfinite(e[1]))) bad = true;
     acc += robust_cost_one(loss, f_scale, e[0]) + robust_cost_one(loss, f_scale, e[1]);
     if (WRITE_R) {
@@ -118,20 +125,41 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-// sum `nrow` rows of length `width`:  out[j] = sum_b partial[b*width + j]   (ordered => deterministic)
-__global__ void k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= width) return;
-  double s = 0.0;
-  for (int b = 0; b < nrow; ++b) s += partial[(long)b * width + j];
-  out[j] = s;
+// out[j] = sum_b partial[b*width + j]  (fixed order => deterministic).  Launch with blockDim = (64, 4):
+// x indexes columns (coalesced), y splits the rows four ways; partial sums meet in LDS.
+__global__ void __launch_bounds__(256)
+k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
+  __shared__ double sh[4][64];
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (j < width) {
+    int b = threadIdx.y;
+    for (; b + 12 < nrow; b += 16) {
+      s0 += partial[(long)b * width + j];
+      s1 += partial[(long)(b + 4) * width + j];
+      s2 += partial[(long)(b + 8) * width + j];
+      s3 += partial[(long)(b + 12) * width + j];
+    }
+    for (; b < nrow; b += 4) s0 += partial[(long)b * width + j];
+  }
+  sh[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.y == 0 && j < width) out[j] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
-__global__ void k_reduce_rows_max(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= width) return;
-  double s = 0.0;
-  for (int b = 0; b < nrow; ++b) s = fmax(s, partial[(long)b * width + j]);
-  out[j] = s;
+// narrow case (width <= 4): one workgroup, every thread strides over the rows
+template <bool MAX>
+__global__ void __launch_bounds__(BLOCK)
+k_reduce_narrow(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  for (int j = 0; j < width; ++j) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nrow; b += BLOCK) {
+      const double v = partial[(long)b * width + j];
+      s = MAX ? fmax(s, v) : s + v;
+    }
+    const double r = MAX ? block_max(s, sh_red) : block_sum(s, sh_red);
+    if (threadIdx.x == 0) out[j] = r;
+  }
 }
 
 // Shared front end of the per-observation passes: project, differentiate, apply the robust-loss scaling.
@@ -175,13 +203,12 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   using UP = UPack<NC>;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_U = sh_tab + n_cams * CAMTAB_DOUBLES;
+  double* sh_U = sh_tab + n_cams * CAMTAB_LDS;
   double* sh_pt = sh_U + n_cams * UP::STRIDE;
   double* sh_red = sh_pt + 9 * CHUNK;
   stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
   __syncthreads();
-  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
   const double* px = xvec + lay.ncp_pad;
   double* gp = gvec + lay.ncp_pad;
   double cost = 0.0;
@@ -194,7 +221,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     if (i < o1) {
       const int cam = obs_cam[i], pt = obs_pt[i];
       double e[2], A[2][MAX_NC], B[2][3];
-      cost += obs_linearize<NC>(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss,
+      cost += obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss,
                                 f_scale, e, A, B);
       pv[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
       pv[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
@@ -205,7 +232,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       pv[6] = B[0][0] * e[0] + B[1][0] * e[1];
       pv[7] = B[0][1] * e[0] + B[1][1] * e[1];
       pv[8] = B[0][2] * e[0] + B[1][2] * e[1];
-      const int np = (int)ct[cam].nparams;
+      const int np = (int)cam_at(sh_tab, cam).nparams;
       double* Uc = sh_U + cam * UP::STRIDE;
 #pragma unroll
       for (int r = 0; r < NC; ++r) {
@@ -328,7 +355,7 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
      const double* __restrict__ v1, const double* __restrict__ v2, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_v = sh_tab + n_cams * CAMTAB_DOUBLES;  // NV * ncp_pad
+  double* sh_v = sh_tab + n_cams * CAMTAB_LDS;  // NV * ncp_pad
   double* sh_red = sh_v + NV * lay.ncp_pad;
   stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) {
@@ -336,7 +363,6 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
     if (NV == 2) sh_v[lay.ncp_pad + i] = v2[i];
   }
   __syncthreads();
-  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
   const double* px = xvec + lay.ncp_pad;
   const double* p1 = v1 + lay.ncp_pad;
   const double* p2 = (NV == 2) ? v2 + lay.ncp_pad : nullptr;
@@ -344,9 +370,9 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
     const int cam = obs_cam[i], pt = obs_pt[i];
     double e[2], A[2][MAX_NC], B[2][3];
-    obs_linearize<NC>(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e,
+    obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e,
                       A, B);
-    const int np = (int)ct[cam].nparams;
+    const int np = (int)cam_at(sh_tab, cam).nparams;
     const double* vc = sh_v + cam_off[cam];
     double a0 = B[0][0] * p1[pt] + B[0][1] * p1[lay.Ppad + pt] + B[0][2] * p1[2 * lay.Ppad + pt];
     double a1 = B[1][0] * p1[pt] + B[1][1] * p1[lay.Ppad + pt] + B[1][2] * p1[2 * lay.Ppad + pt];
@@ -391,7 +417,7 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int ncp = lay.ncp;
   double* sh_tab = sh;
-  double* sh_A = sh_tab + n_cams * CAMTAB_DOUBLES;  // [2*NC][CHUNK]
+  double* sh_A = sh_tab + n_cams * CAMTAB_LDS;  // [2*NC][CHUNK]
   double* sh_Z = sh_A + 2 * NC * CHUNK;              // [6][CHUNK]
   double* sh_b = sh_Z + 6 * CHUNK;                   // [ncp_pad]
   double* sh_S = sh_b + lay.ncp_pad;                 // [ncp*ncp] if S_IN_LDS
@@ -401,7 +427,6 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   if (S_IN_LDS)
     for (int i = threadIdx.x; i < ncp * ncp; i += BLOCK) sh_S[i] = 0.0;
   __syncthreads();
-  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
@@ -418,9 +443,9 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       cam_i = obs_cam[i];
       seg_end = pt_start[pt + 1] - o0;
       double e[2], B[2][3];
-      obs_linearize<NC>(ct[cam_i], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
+      obs_linearize<NC>(cam_at(sh_tab, cam_i), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
                         e, Ai, B);
-      np_i = (int)ct[cam_i].nparams;
+      np_i = (int)cam_at(sh_tab, cam_i).nparams;
       double Vd[6], L[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
@@ -472,7 +497,7 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
 #pragma unroll
           for (int b = 0; b < 2; ++b) M[a][b] = Zi[a][0] * Zj[b][0] + Zi[a][1] * Zj[b][1] + Zi[a][2] * Zj[b][2];
         const bool same = (j == (int)threadIdx.x);
-        const int np_j = (int)ct[cam_j].nparams;
+        const int np_j = (int)cam_at(sh_tab, cam_j).nparams;
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
           if (r >= np_i) continue;
@@ -614,23 +639,29 @@ k_syrk_trailing(double* __restrict__ M, int n, int k0) {
   }
 }
 
-// solve L L^T x = rhs with one workgroup; x is written to out[0..n)
+// solve L L^T x = rhs with one workgroup; x is written to out[0..n).  The 32x32 diagonal block of each
+// step is staged in LDS so that the serial part of the substitution never waits on global memory.
 __global__ void __launch_bounds__(BLOCK)
 k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double y[];  // n
+  __shared__ double D[NB][NB + 1];
   for (int i = threadIdx.x; i < n; i += BLOCK) y[i] = rhs[i];
-  __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
   // forward: L y = rhs
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = min(NB, n - k0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
+      const int r = t / NB, c = t % NB;
+      D[r][c] = (r < nb && c <= r) ? L[(long)(k0 + r) * n + k0 + c] : 0.0;
+    }
+    __syncthreads();
     if (threadIdx.x < WAVE) {
       double yj = (lane < nb) ? y[k0 + lane] : 0.0;
       for (int t = 0; t < nb; ++t) {
-        const double ltt = L[(long)(k0 + t) * n + k0 + t];
-        const double yt = __shfl(yj, t, WAVE) / ltt;
+        const double yt = __shfl(yj, t, WAVE) / D[t][t];
         if (lane == t) yj = yt;
-        else if (lane > t && lane < nb) yj -= L[(long)(k0 + lane) * n + k0 + t] * yt;
+        else if (lane > t && lane < nb) yj -= D[lane][t] * yt;
       }
       if (lane < nb) y[k0 + lane] = yj;
     }
@@ -641,20 +672,24 @@ k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs
       for (int t = 0; t < nb; ++t) acc += row[t] * y[k0 + t];
       y[i] -= acc;
     }
-    __syncthreads();
   }
   // backward: L^T x = y
   const int nblk = (n + NB - 1) / NB;
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * NB;
     const int nb = min(NB, n - k0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
+      const int r = t / NB, c = t % NB;
+      D[r][c] = (r < nb && c <= r) ? L[(long)(k0 + r) * n + k0 + c] : 0.0;
+    }
+    __syncthreads();
     if (threadIdx.x < WAVE) {
       double xj = (lane < nb) ? y[k0 + lane] : 0.0;
       for (int t = nb - 1; t >= 0; --t) {
-        const double ltt = L[(long)(k0 + t) * n + k0 + t];
-        const double xt = __shfl(xj, t, WAVE) / ltt;
+        const double xt = __shfl(xj, t, WAVE) / D[t][t];
         if (lane == t) xj = xt;
-        else if (lane < t) xj -= L[(long)(k0 + t) * n + k0 + lane] * xt;
+        else if (lane < t) xj -= D[t][lane] * xt;
       }
       if (lane < nb) y[k0 + lane] = xj;
     }
@@ -664,8 +699,8 @@ k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs
       for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * n + i] * y[k0 + t];
       y[i] -= acc;
     }
-    __syncthreads();
   }
+  __syncthreads();
   for (int i = threadIdx.x; i < n; i += BLOCK) out[i] = y[i];
 }
 
@@ -681,12 +716,11 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
           double* __restrict__ svec) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_dc = sh_tab + n_cams * CAMTAB_DOUBLES;  // ncp_pad
+  double* sh_dc = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad
   double* sh_pt = sh_dc + lay.ncp_pad;               // [3][CHUNK]
   stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_dc[i] = svec[i];
   __syncthreads();
-  const CamTab* ct = reinterpret_cast<const CamTab*>(sh_tab);
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
@@ -698,9 +732,9 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     if (i < o1) {
       const int cam = obs_cam[i], pt = obs_pt[i];
       double e[2], A[2][MAX_NC], B[2][3];
-      obs_linearize<NC>(ct[cam], px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
+      obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
                         e, A, B);
-      const int np = (int)ct[cam].nparams;
+      const int np = (int)cam_at(sh_tab, cam).nparams;
       const double* dc = sh_dc + cam_off[cam];
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll

@@ -218,16 +218,16 @@ static int allow_lds(K kernel, size_t bytes) {
   return CBA_OK;
 }
 
-static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_DOUBLES + 8) * 8; }
+static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + 8) * 8; }
 template <int NC> static size_t lds_build(const cba_problem* p) {
-  return ((size_t)p->C * CAMTAB_DOUBLES + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
+  return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
 }
-static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_DOUBLES + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
+static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_LDS + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
 template <int NC> static size_t lds_schur(const cba_problem* p, bool s_lds) {
-  return ((size_t)p->C * CAMTAB_DOUBLES + 2 * NC * CHUNK + 6 * CHUNK + p->lay.ncp_pad + (s_lds ? (size_t)p->ncp * p->ncp : 0)) * 8 +
+  return ((size_t)p->C * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + p->lay.ncp_pad + (s_lds ? (size_t)p->ncp * p->ncp : 0)) * 8 +
          CHUNK * sizeof(int);
 }
-static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_DOUBLES + p->lay.ncp_pad + 3 * CHUNK) * 8; }
+static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 template <int NC>
 static int configure_kernels(cba_problem* p) {
@@ -426,7 +426,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
                          (double*)nullptr, (const int*)nullptr);
   }
   ScopedTimer t(p, T_VECTOR);
-  hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, grid, 1, p->scal + slot);
+  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, grid, 1, p->scal + slot);
   return CBA_OK;
 }
 
@@ -441,8 +441,8 @@ static int run_build(cba_problem* p) {
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
     const int w = p->C * UPack<NC>::STRIDE;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 255) / 256), dim3(256), 0, p->stream, p->partial, p->grid, w, p->Upacked);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
+    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, 4), 0, p->stream, p->partial, p->grid, w, p->Upacked);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
     hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->Upacked,
                        p->cam_off, p->cam_np, p->C, p->g);
   }
@@ -459,7 +459,7 @@ static int run_jv(cba_problem* p, int nv) {
   else
     hipLaunchKernelGGL((k_jv<NC, 2>), dim3(grid), dim3(BLOCK), lds_jv(p, 2), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                        p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
-  hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial4, grid, 4, p->scal + 12);
+  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, grid, 4, p->scal + 12);
   return CBA_OK;
 }
 
@@ -473,8 +473,8 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
                        p->lay, p->first_scale ? 1 : 0, p->sinv);
     hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->v1, p->partial4, p->partial1);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
-    hipLaunchKernelGGL(k_reduce_rows_max, dim3(1), dim3(64), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
+    hipLaunchKernelGGL(k_reduce_narrow<true>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
   }
   run_jv<NC>(p, 1);
   int rc = sync_scalars(p, 16);
@@ -528,7 +528,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
     double* dst = p->schur_lds ? p->Sacc : p->Sacc + (size_t)ncp * ncp;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((int)((w + 255) / 256)), dim3(256), 0, p->stream, p->partial, p->grid, (int)w, dst);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((int)((w + 63) / 64)), dim3(64, 4), 0, p->stream, p->partial, p->grid, (int)w, dst);
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
                        p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs);
@@ -546,9 +546,9 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     const long tot = p->lay.total();
     const int vg = vec_grid(tot);
     hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, p->partial4);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
     hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, p->scal + 17, p->gh_sq, p->partial1);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
   }
   rc = sync_scalars(p, 24);
   if (rc) return rc;
@@ -648,7 +648,7 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) {
   {
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->x_new, p->partial1);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
   launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
