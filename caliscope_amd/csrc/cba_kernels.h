@@ -404,48 +404,96 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
 // and per pair (i <= j) of observations of the same point
 //     Sacc[c_i, c_j] += A_i^T (Z_i Z_j^T) A_j          ( = W_i V'^-1 W_j^T )
 // The reduced system is S = U + lam D_c^2 - Sacc, rhs = -g_c + b   (SURVEY.md Appendix A.4).
-// Sacc is accumulated with LDS atomics into a workgroup-private copy when (ncp^2 doubles) fit in LDS
-// (flushed as per-workgroup partials), otherwise with FP64 global atomics.
-template <int NC, bool S_IN_LDS>
+//
+// Scatter-reducing Sacc is the expensive part (k(k+1)/2 blocks of nc^2 per point).  FP64 global atomics
+// manage ~2e10 updates/s on this chip, LDS atomics (ds_add_f64) ~1e13, so Sacc must live in LDS.  It does
+// not fit for more than ~18 cameras, hence the cameras are cut into G groups of g and the block-upper-
+// triangle of Sacc into G(G+1)/2 tiles (a <= b) of (g nc)^2 doubles.  Because the sparsity pattern is
+// static, cba_create lays out one observation STREAM per tile: the observations (sorted by point, then
+// camera) whose camera is in group a or b and whose point is seen from both groups, chunked like the main
+// array, each with the [jbeg, jend) range of its pair partners inside the chunk.  A workgroup is bound to
+// one tile, keeps that tile in LDS across all of the tile's chunks, and flushes it once (per-workgroup
+// partials, reduced in fixed order).  The Jacobian blocks are recomputed per stream (G times per
+// observation) rather than stored: 24 B + ~600 flop beats 144 B of HBM traffic per use.
+struct TilePlan {
+  const double* u;
+  const double* v;
+  const int* pt;
+  const unsigned char* camloc;   // camera index inside the tile: [0,g) group a, [g,2g) group b
+  const unsigned short* jbeg;    // chunk-local partner range of each observation
+  const unsigned short* jend;
+  const int* chunk_start;        // [n_tile_chunks + 1] offsets into the stream arrays
+  const int* tile_chunk_begin;   // [n_tiles + 1]
+  const int* wg_tile;            // [grid] tile of each workgroup
+  const int* wg_rank;            // [grid] rank of the workgroup inside its tile
+  const int* tile_nwg;           // [n_tiles]
+  const int* tile_a;             // [n_tiles] group ids
+  const int* tile_b;
+  const int* group_cam_begin;    // [G + 1]
+  const int* group_par_begin;    // [G + 1]
+  int g;                         // cameras per group (max)
+  int tile_elems;                // (g nc)^2 + g nc : width of one workgroup's partial
+};
+
+template <int NC>
 __global__ void __launch_bounds__(BLOCK)
-k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
-        const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
-        int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
-        const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
-        const double* __restrict__ Vblk, const double* __restrict__ gvec, const double* __restrict__ sinv,
-        double* __restrict__ S_global, double* __restrict__ partial, int* __restrict__ flags) {
+k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
+             const int* __restrict__ cam_off, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
+             const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ partial,
+             int* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int ncp = lay.ncp;
-  double* sh_tab = sh;
-  double* sh_A = sh_tab + n_cams * CAMTAB_LDS;  // [2*NC][CHUNK]
-  double* sh_Z = sh_A + 2 * NC * CHUNK;              // [6][CHUNK]
-  double* sh_b = sh_Z + 6 * CHUNK;                   // [ncp_pad]
-  double* sh_S = sh_b + lay.ncp_pad;                 // [ncp*ncp] if S_IN_LDS
-  int* sh_cam = reinterpret_cast<int*>(sh_S + (S_IN_LDS ? ncp * ncp : 0));  // [CHUNK] cam, [CHUNK] seg end
-  stage_camtab(sh_tab, tab, n_cams);
-  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_b[i] = 0.0;
-  if (S_IN_LDS)
-    for (int i = threadIdx.x; i < ncp * ncp; i += BLOCK) sh_S[i] = 0.0;
+  const int g = tp.g;
+  const int gn = g * NC;
+  double* sh_tab = sh;                          // [2g][CAMTAB_LDS]
+  double* sh_A = sh_tab + 2 * g * CAMTAB_LDS;   // [2*NC][CHUNK]
+  double* sh_Z = sh_A + 2 * NC * CHUNK;         // [6][CHUNK]
+  double* sh_b = sh_Z + 6 * CHUNK;              // [gn]
+  double* sh_S = sh_b + gn;                     // [gn][gn]
+  int* sh_loff = reinterpret_cast<int*>(sh_S + gn * gn);  // [2g] local parameter offset of each tile camera
+  int* sh_cam = sh_loff + 2 * g;                          // [CHUNK]
+
+  const int t = tp.wg_tile[blockIdx.x];
+  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
+  const bool diag = (ga == gb);
+  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+  const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
+  const int ld = tp.group_par_begin[gb + 1] - pb0;  // columns of the tile (== rows for a diagonal tile)
+
+  for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += BLOCK)
+    sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)ca0 * CAMTAB_DOUBLES + i];
+  if (!diag)
+    for (int i = threadIdx.x; i < nb * CAMTAB_DOUBLES; i += BLOCK)
+      sh_tab[(g + i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)cb0 * CAMTAB_DOUBLES + i];
+  for (int i = threadIdx.x; i < 2 * g; i += BLOCK) {
+    int off = 0;
+    if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }
+    else if (i - g < nb) off = cam_off[cb0 + i - g] - pb0;
+    sh_loff[i] = off;
+  }
+  for (int i = threadIdx.x; i < gn + gn * gn; i += BLOCK) sh_b[i] = 0.0;  // sh_b and sh_S are contiguous
   __syncthreads();
+
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
-  double* Sdst = S_IN_LDS ? sh_S : S_global;
   bool fail = false;
-  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+  const int ch_end = tp.tile_chunk_begin[t + 1];
+  for (int ch = tp.tile_chunk_begin[t] + tp.wg_rank[blockIdx.x]; ch < ch_end; ch += tp.tile_nwg[t]) {
+    const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
     const int i = o0 + threadIdx.x;
     const bool active = i < o1;
     double Ai[2][MAX_NC], Zi[2][3];
-    int cam_i = 0, np_i = 0, seg_end = 0;
+    int cl_i = 0, np_i = 0, jb = 0, je = 0;
     if (active) {
-      const int pt = obs_pt[i];
-      cam_i = obs_cam[i];
-      seg_end = pt_start[pt + 1] - o0;
+      const int pt = tp.pt[i];
+      cl_i = tp.camloc[i];
+      jb = tp.jbeg[i];
+      je = tp.jend[i];
+      const CamTab& ct = cam_at(sh_tab, cl_i);
       double e[2], B[2][3];
-      obs_linearize<NC>(cam_at(sh_tab, cam_i), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
-                        e, Ai, B);
-      np_i = (int)cam_at(sh_tab, cam_i).nparams;
+      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], tp.u[i], tp.v[i], loss, f_scale, e, Ai, B);
+      np_i = (int)ct.nparams;
       double Vd[6], L[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
@@ -457,19 +505,20 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       }
       chol3_fwd(L, B[0], Zi[0]);
       chol3_fwd(L, B[1], Zi[1]);
-      const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
-      double y[3];
-      chol3_fwd(L, gpt, y);
-      const double zy0 = Zi[0][0] * y[0] + Zi[0][1] * y[1] + Zi[0][2] * y[2];
-      const double zy1 = Zi[1][0] * y[0] + Zi[1][1] * y[1] + Zi[1][2] * y[2];
-      double* bc = sh_b + cam_off[cam_i];
+      if (diag) {  // every observation lives in exactly one diagonal tile: accumulate the rhs term there
+        const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
+        double y[3];
+        chol3_fwd(L, gpt, y);
+        const double zy0 = Zi[0][0] * y[0] + Zi[0][1] * y[1] + Zi[0][2] * y[2];
+        const double zy1 = Zi[1][0] * y[0] + Zi[1][1] * y[1] + Zi[1][2] * y[2];
+        double* bc = sh_b + sh_loff[cl_i];
 #pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        if (k < np_i) lds_add(&bc[k], Ai[0][k] * zy0 + Ai[1][k] * zy1);
-        else { Ai[0][k] = 0.0; Ai[1][k] = 0.0; }
+        for (int k = 0; k < NC; ++k)
+          if (k < np_i) lds_add(&bc[k], Ai[0][k] * zy0 + Ai[1][k] * zy1);
       }
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
+        if (k >= np_i) { Ai[0][k] = 0.0; Ai[1][k] = 0.0; }
         sh_A[k * CHUNK + threadIdx.x] = Ai[0][k];
         sh_A[(NC + k) * CHUNK + threadIdx.x] = Ai[1][k];
       }
@@ -478,14 +527,14 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         sh_Z[k * CHUNK + threadIdx.x] = Zi[0][k];
         sh_Z[(3 + k) * CHUNK + threadIdx.x] = Zi[1][k];
       }
-      sh_cam[threadIdx.x] = cam_i;
+      sh_cam[threadIdx.x] = cl_i;
     }
     __syncthreads();
     if (active) {
-      const int off_i = cam_off[cam_i];
-      for (int j = threadIdx.x; j < seg_end; ++j) {
-        const int cam_j = sh_cam[j];
-        const int off_j = cam_off[cam_j];
+      const int row0 = sh_loff[cl_i];
+      for (int j = jb; j < je; ++j) {
+        const int cl_j = sh_cam[j];
+        const int col0 = sh_loff[cl_j];
         double Zj[2][3], Aj[2][NC];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { Zj[0][k] = sh_Z[k * CHUNK + j]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j]; }
@@ -496,8 +545,9 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b) M[a][b] = Zi[a][0] * Zj[b][0] + Zi[a][1] * Zj[b][1] + Zi[a][2] * Zj[b][2];
-        const bool same = (j == (int)threadIdx.x);
-        const int np_j = (int)cam_at(sh_tab, cam_j).nparams;
+        const bool same_obs = (j == (int)threadIdx.x);
+        const bool same_cam = (cl_j == cl_i);
+        const int np_j = (int)cam_at(sh_tab, cl_j).nparams;
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
           if (r >= np_i) continue;
@@ -507,16 +557,15 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
           for (int c = 0; c < NC; ++c) {
             if (c >= np_j) continue;
             const double val = t0 * Aj[0][c] + t1 * Aj[1][c];  // block(r, c) of W_i V'^-1 W_j^T
-            if (same) {
-              if (c >= r) lds_add(&Sdst[(long)(off_i + r) * ncp + off_i + c], val);
-            } else if (cam_i == cam_j) {
-              // two different observations of one camera: block + block^T lands on the diagonal block
+            if (same_obs) {
+              if (c >= r) lds_add(&sh_S[(row0 + r) * ld + col0 + c], val);
+            } else if (same_cam) {
+              // two observations of one camera (duplicates): block + block^T on the diagonal block
               const int lo = r < c ? r : c, hi = r < c ? c : r;
-              lds_add(&Sdst[(long)(off_i + lo) * ncp + off_i + hi], (r == c) ? 2.0 * val : val);
-            } else if (off_i < off_j) {
-              lds_add(&Sdst[(long)(off_i + r) * ncp + off_j + c], val);
+              lds_add(&sh_S[(row0 + lo) * ld + col0 + hi], (r == c) ? 2.0 * val : val);
             } else {
-              lds_add(&Sdst[(long)(off_j + c) * ncp + off_i + r], val);
+              // partners are sorted by camera, so (row camera) < (column camera): upper block triangle
+              lds_add(&sh_S[(row0 + r) * ld + col0 + c], val);
             }
           }
         }
@@ -525,12 +574,32 @@ k_schur(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     __syncthreads();
   }
   if (fail) flags[1] = 1;
-  // flush: [S (if in LDS) | b]
-  const int width = (S_IN_LDS ? ncp * ncp : 0) + lay.ncp_pad;
-  double* dst = partial + (long)blockIdx.x * width;
-  if (S_IN_LDS)
-    for (int i = threadIdx.x; i < ncp * ncp; i += BLOCK) dst[i] = sh_S[i];
-  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) dst[(S_IN_LDS ? ncp * ncp : 0) + i] = sh_b[i];
+  double* dst = partial + (long)blockIdx.x * tp.tile_elems;
+  for (int i = threadIdx.x; i < gn * gn; i += BLOCK) dst[i] = sh_S[i];
+  for (int i = threadIdx.x; i < gn; i += BLOCK) dst[gn * gn + i] = sh_b[i];
+}
+
+// Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc.
+__global__ void __launch_bounds__(BLOCK)
+k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial, int NCt, int ncp,
+              double* __restrict__ Sacc, double* __restrict__ bacc) {
+  const int t = blockIdx.y;
+  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
+  const int pa0 = tp.group_par_begin[ga], npa = tp.group_par_begin[ga + 1] - pa0;
+  const int pb0 = tp.group_par_begin[gb], npb = tp.group_par_begin[gb + 1] - pb0;
+  const int gn = tp.g * NCt;
+  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
+  if (e < npa * npb) {
+    double s = 0.0;
+    for (int w = w0; w < w1; ++w) s += partial[(long)w * tp.tile_elems + e];
+    const int r = e / npb, c = e % npb;
+    Sacc[(long)(pa0 + r) * ncp + pb0 + c] = s;
+  } else if (ga == gb && e >= gn * gn && e < gn * gn + npa) {
+    double s = 0.0;
+    for (int w = w0; w < w1; ++w) s += partial[(long)w * tp.tile_elems + e];
+    bacc[pa0 + (e - gn * gn)] = s;
+  }
 }
 
 // S = U + lam D_c^2 - Sacc (symmetric, both triangles written), rhs = -g_c + b

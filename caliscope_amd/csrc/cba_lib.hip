@@ -56,7 +56,11 @@ struct cba_problem {
   long N = 0;
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
-  bool schur_lds = false;
+  bool schur_lds = true;   // Sacc always lives in LDS tiles
+  int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
+  long tile_stream_len = 0;
+  TilePlan tp{};
+  int* tile_wg_begin = nullptr;
   int loss = 0;
   double f_scale = 1.0;
   long device_bytes = 0;
@@ -164,9 +168,21 @@ int cba_device_count(void) {
 int cba_timer_count(void) { return T_COUNT; }
 const char* cba_timer_name(int32_t i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }
 
-int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, int32_t chunk_cap, int64_t* order_out,
-                      int64_t* pt_start_out, int64_t* chunk_start_out) {
+int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
+                      int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out) {
   if (n_points < 0 || n_obs < 0 || chunk_cap <= 0 || (n_obs > 0 && !obs_pt)) return fail(CBA_ERR_INVALID, "cba_host_plan: bad arguments");
+  // optional first key: camera (stable counting sort), so that the final order is (point, camera, input order)
+  std::vector<int64_t> by_cam;
+  if (obs_cam && n_cams > 0) {
+    std::vector<int64_t> cc((size_t)n_cams + 1, 0);
+    for (int64_t i = 0; i < n_obs; ++i) {
+      if (obs_cam[i] < 0 || obs_cam[i] >= n_cams) return fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, obs_cam[i]);
+      cc[obs_cam[i] + 1]++;
+    }
+    for (int32_t c = 0; c < n_cams; ++c) cc[c + 1] += cc[c];
+    by_cam.resize((size_t)n_obs);
+    for (int64_t i = 0; i < n_obs; ++i) by_cam[cc[obs_cam[i]]++] = i;
+  }
   std::vector<int64_t> count((size_t)n_points + 1, 0);
   for (int64_t i = 0; i < n_obs; ++i) {
     const int32_t p = obs_pt[i];
@@ -181,7 +197,10 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, in
   }
   for (int32_t p = 0; p <= n_points; ++p) pt_start_out[p] = count[p];
   std::vector<int64_t> cursor(count.begin(), count.end() - 1);
-  for (int64_t i = 0; i < n_obs; ++i) order_out[cursor[obs_pt[i]]++] = i;  // stable counting sort
+  for (int64_t q = 0; q < n_obs; ++q) {  // stable counting sort by point
+    const int64_t i = by_cam.empty() ? q : by_cam[q];
+    order_out[cursor[obs_pt[i]]++] = i;
+  }
   int64_t n_chunks = 0;
   int64_t start = 0;
   chunk_start_out[0] = 0;
@@ -223,11 +242,129 @@ template <int NC> static size_t lds_build(const cba_problem* p) {
   return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
 }
 static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_LDS + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
-template <int NC> static size_t lds_schur(const cba_problem* p, bool s_lds) {
-  return ((size_t)p->C * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + p->lay.ncp_pad + (s_lds ? (size_t)p->ncp * p->ncp : 0)) * 8 +
-         CHUNK * sizeof(int);
+template <int NC> static size_t lds_schur_tile(int g) {
+  const size_t gn = (size_t)g * NC;
+  return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * gn) * 8 + ((size_t)2 * g + CHUNK) * sizeof(int);
 }
+constexpr size_t kSchurLdsBudget = 144 * 1024;
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
+
+
+// Static plan of the tiled Schur pass: camera groups, one observation stream per tile (a <= b), chunk
+// tables, partner ranges and the workgroup -> tile binding (see k_schur_tile).
+static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const std::vector<double>& hv,
+                           const std::vector<int>& hcam, const std::vector<int>& hpt, const std::vector<int>& hps,
+                           const std::vector<int>& cam_off, int max_blocks) {
+  const int G = p->G, g = p->gsz, C = p->C, P = p->P;
+  const int nT = p->n_tiles;
+  std::vector<int> gcam(G + 1), gpar(G + 1);
+  for (int a = 0; a <= G; ++a) {
+    gcam[a] = std::min(a * g, C);
+    gpar[a] = (gcam[a] < C) ? cam_off[gcam[a]] : p->ncp;
+  }
+  auto tile_id = [&](int a, int b) { return a * G - a * (a - 1) / 2 + (b - a); };  // a <= b
+  std::vector<int> ta(nT), tb(nT);
+  for (int a = 0; a < G; ++a)
+    for (int b = a; b < G; ++b) { ta[tile_id(a, b)] = a; tb[tile_id(a, b)] = b; }
+
+  struct Stream {
+    std::vector<double> u, v;
+    std::vector<int> pt;
+    std::vector<unsigned char> cl;
+    std::vector<unsigned short> jb, je;
+    std::vector<int> chunk_start;  // local offsets, starts with 0
+    int open = 0;                  // start of the currently open chunk
+  };
+  std::vector<Stream> st(nT);
+  for (auto& s : st) s.chunk_start.push_back(0);
+  std::vector<int> gbeg(G + 1);
+  for (int q = 0; q < P; ++q) {
+    const int s0 = hps[q], s1 = hps[q + 1];
+    if (s1 == s0) continue;
+    // observations of a point are sorted by camera => by group; gbeg[a]..gbeg[a+1] is group a's run
+    int cur = s0;
+    for (int a = 0; a < G; ++a) {
+      gbeg[a] = cur;
+      while (cur < s1 && hcam[cur] < gcam[a + 1]) ++cur;
+    }
+    gbeg[G] = s1;
+    for (int a = 0; a < G; ++a) {
+      const int na = gbeg[a + 1] - gbeg[a];
+      if (!na) continue;
+      for (int b = a; b < G; ++b) {
+        const int nb = (b == a) ? 0 : gbeg[b + 1] - gbeg[b];
+        if (b != a && !nb) continue;
+        Stream& s = st[tile_id(a, b)];
+        const int cnt = na + nb;
+        int len = (int)s.pt.size();
+        if (len - s.open + cnt > CHUNK) { s.chunk_start.push_back(len); s.open = len; }
+        const int base = len - s.open;  // chunk-local index of this point's first entry
+        for (int i = gbeg[a]; i < gbeg[a + 1]; ++i) {
+          const int k = i - gbeg[a];
+          s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]);
+          s.cl.push_back((unsigned char)(hcam[i] - gcam[a]));
+          if (b == a) { s.jb.push_back((unsigned short)(base + k)); s.je.push_back((unsigned short)(base + na)); }
+          else { s.jb.push_back((unsigned short)(base + na)); s.je.push_back((unsigned short)(base + cnt)); }
+        }
+        for (int i = gbeg[b]; b != a && i < gbeg[b + 1]; ++i) {
+          s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]);
+          s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b]));
+          s.jb.push_back(0); s.je.push_back(0);  // column observations have no partner loop
+        }
+      }
+    }
+  }
+  // concatenate
+  std::vector<double> U, V;
+  std::vector<int> PT, CS, TCB(nT + 1, 0);
+  std::vector<unsigned char> CL;
+  std::vector<unsigned short> JB, JE;
+  CS.push_back(0);
+  for (int t = 0; t < nT; ++t) {
+    Stream& s = st[t];
+    const int base = (int)PT.size();
+    if (!s.pt.empty()) s.chunk_start.push_back((int)s.pt.size());
+    TCB[t] = (int)CS.size() - 1;
+    for (size_t c = 1; c < s.chunk_start.size(); ++c) CS.push_back(base + s.chunk_start[c]);
+    U.insert(U.end(), s.u.begin(), s.u.end()); V.insert(V.end(), s.v.begin(), s.v.end());
+    PT.insert(PT.end(), s.pt.begin(), s.pt.end()); CL.insert(CL.end(), s.cl.begin(), s.cl.end());
+    JB.insert(JB.end(), s.jb.begin(), s.jb.end()); JE.insert(JE.end(), s.je.begin(), s.je.end());
+    s = Stream();
+  }
+  TCB[nT] = (int)CS.size() - 1;
+  p->n_tile_chunks = TCB[nT];
+  p->tile_stream_len = (long)PT.size();
+  // workgroups: proportional to the chunk count of each tile, at least one per tile
+  const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
+  std::vector<int> nwg(nT), wgb(nT + 1, 0);
+  for (int t = 0; t < nT; ++t) {
+    const long nch = TCB[t + 1] - TCB[t];
+    long w = p->n_tile_chunks > 0 ? (nch * budget + p->n_tile_chunks - 1) / p->n_tile_chunks : 1;
+    nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch, 1)));
+    wgb[t + 1] = wgb[t] + nwg[t];
+  }
+  p->tile_grid = wgb[nT];
+  std::vector<int> wt(p->tile_grid), wr(p->tile_grid);
+  for (int t = 0; t < nT; ++t)
+    for (int r = 0; r < nwg[t]; ++r) { wt[wgb[t] + r] = t; wr[wgb[t] + r] = r; }
+
+  int rc;
+  double *du = nullptr, *dv = nullptr;
+  int *dpt = nullptr, *dcs = nullptr, *dtcb = nullptr, *dwt = nullptr, *dwr = nullptr, *dnwg = nullptr, *dta = nullptr, *dtb = nullptr,
+      *dgc = nullptr, *dgp = nullptr;
+  unsigned char* dcl = nullptr;
+  unsigned short *djb = nullptr, *dje = nullptr;
+#define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
+  TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
+  TRYP(dev_upload(p, &djb, JB)); TRYP(dev_upload(p, &dje, JE)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dtcb, TCB));
+  TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwr, wr)); TRYP(dev_upload(p, &dnwg, nwg)); TRYP(dev_upload(p, &dta, ta));
+  TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
+  TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
+#undef TRYP
+  const int gn = g * p->nct;
+  p->tp = TilePlan{du, dv, dpt, dcl, djb, dje, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, gn * gn + gn};
+  return CBA_OK;
+}
 
 template <int NC>
 static int configure_kernels(cba_problem* p) {
@@ -237,9 +374,12 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 1>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
-  p->schur_lds = lds_schur<NC>(p, true) <= 150 * 1024;
-  if (p->schur_lds) { if ((rc = allow_lds(k_schur<NC, true>, lds_schur<NC>(p, true)))) return rc; }
-  else { if ((rc = allow_lds(k_schur<NC, false>, lds_schur<NC>(p, false)))) return rc; }
+  int gmax = 1;
+  while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
+  p->G = (p->C + gmax - 1) / gmax;
+  p->gsz = (p->C + p->G - 1) / p->G;
+  p->n_tiles = p->G * (p->G + 1) / 2;
+  if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_chol_solve, (size_t)p->ncp * 8))) return rc;
   return CBA_OK;
@@ -296,7 +436,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   std::vector<int64_t> order(p->N), pstart((size_t)p->P + 1), cstart((size_t)p->N + 2);
   for (int64_t i = 0; i < p->N; ++i)
     if (d->obs_cam[i] < 0 || d->obs_cam[i] >= p->C) return bail(fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, d->obs_cam[i]));
-  int64_t nch = cba_host_plan(p->P, p->N, d->obs_pt, CHUNK, order.data(), pstart.data(), cstart.data());
+  int64_t nch = cba_host_plan(p->P, p->N, d->obs_pt, d->obs_cam, p->C, CHUNK, order.data(), pstart.data(), cstart.data());
   if (nch < 0) return bail((int)nch);
   p->n_chunks = (int)nch;
   std::vector<double> hu(p->N), hv(p->N);
@@ -338,10 +478,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
+  TRY(build_tile_plan(p, hu, hv, hcam, hpt, hps, off, max_blocks));
   const long w_build = (long)p->C * ustride;
-  const long w_schur = (p->schur_lds ? (long)ncp * ncp : 0) + p->lay.ncp_pad;
-  p->partial_width = std::max(w_build, w_schur);
-  TRY(dev_alloc(p, &p->partial, (size_t)p->grid * p->partial_width));
+  p->partial_width = w_build;
+  TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
   TRY(dev_alloc(p, &p->partial4, (size_t)1024 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)1024));
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); TRY(dev_alloc(p, &p->Lbuf, (size_t)ncp * ncp));
@@ -360,7 +500,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 int cba_get_info(cba_problem* p, cba_info* o) {
   if (!p || !o) return fail(CBA_ERR_INVALID, "null argument");
   o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
-  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_lds ? 1 : 0;
+  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 1;
+  o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes;
   return CBA_OK;
 }
@@ -511,24 +652,15 @@ template <int NC>
 static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   const int ncp = p->ncp;
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
-  const long w = (p->schur_lds ? (long)ncp * ncp : 0) + p->lay.ncp_pad;
   {
     ScopedTimer t(p, T_SCHUR);
-    if (p->schur_lds) {
-      hipLaunchKernelGGL((k_schur<NC, true>), dim3(p->grid), dim3(BLOCK), lds_schur<NC>(p, true), p->stream, p->obs_u, p->obs_v,
-                         p->obs_cam, p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C,
-                         p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->Sacc, p->partial, p->flags);
-    } else {
-      HIPCHK(hipMemsetAsync(p->Sacc, 0, (size_t)ncp * ncp * sizeof(double), p->stream));
-      hipLaunchKernelGGL((k_schur<NC, false>), dim3(p->grid), dim3(BLOCK), lds_schur<NC>(p, false), p->stream, p->obs_u, p->obs_v,
-                         p->obs_cam, p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C,
-                         p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->Sacc, p->partial, p->flags);
-    }
+    hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
+                       p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags);
   }
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
-    double* dst = p->schur_lds ? p->Sacc : p->Sacc + (size_t)ncp * ncp;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((int)((w + 63) / 64)), dim3(64, 4), 0, p->stream, p->partial, p->grid, (int)w, dst);
+    hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + BLOCK - 1) / BLOCK, p->n_tiles), dim3(BLOCK), 0, p->stream, p->tp,
+                       p->tile_wg_begin, p->partial, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
                        p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs);

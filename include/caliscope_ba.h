@@ -153,9 +153,14 @@ typedef struct {
   int32_t n_cams, n_points, n_cam_params, n_params;
   int64_t n_obs;
   int32_t n_chunks, grid_blocks;
-  int32_t schur_in_lds;   /* 1: S accumulated in LDS tiles, 0: global atomics */
+  int32_t schur_in_lds;   /* always 1: the Schur complement is accumulated in LDS tiles */
   int32_t max_obs_per_point;
   int64_t device_bytes;
+  int32_t schur_groups;   /* G camera groups -> G(G+1)/2 tiles */
+  int32_t schur_tiles;
+  int32_t schur_grid;     /* workgroups of the tiled Schur kernel */
+  int32_t reserved;
+  int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
 } cba_info;
 int cba_get_info(cba_problem* p, cba_info* out);
 
@@ -167,12 +172,13 @@ int cba_get_timers(cba_problem* p, double* ms_out, int64_t* calls_out);
 int cba_reset_timers(cba_problem* p);
 int cba_enable_timers(cba_problem* p, int32_t on);
 
-/* Host-side planning only (no device needed): observation order sorted by point (stable), CSR offsets
+/* Host-side planning only (no device needed): observation order sorted by (point, camera) — obs_cam may be
+ * NULL to sort by point only — stable, CSR offsets
  * per point and the chunk table (whole points per chunk, at most `chunk_cap` observations).
  * order_out [N], pt_start_out [P+1], chunk_start_out [N+1 worst case]; returns the number of chunks
  * (>= 0) or a negative error (a point with more than chunk_cap observations is CBA_ERR_UNSUPPORTED). */
-int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, int32_t chunk_cap,
-                      int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out);
+int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
+                      int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out);
 
 const char* cba_last_error(void);
 int cba_version(void);

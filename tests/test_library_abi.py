@@ -43,13 +43,17 @@ def test_create_fails_loudly_without_device(lib):
         HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices))
 
 
-def _plan(lib, n_points, obs_pt, cap):
+def _plan(lib, n_points, obs_pt, cap, obs_cam=None, n_cams=0):
     obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
     n = len(obs_pt)
+    cam_p = None
+    if obs_cam is not None:
+        obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+        cam_p = obs_cam.ctypes.data_as(_lib.c_int32_p)
     order = np.zeros(max(n, 1), dtype=np.int64)
     pstart = np.zeros(n_points + 1, dtype=np.int64)
     cstart = np.zeros(n + 2, dtype=np.int64)
-    nch = lib.cba_host_plan(n_points, n, obs_pt.ctypes.data_as(_lib.c_int32_p), cap,
+    nch = lib.cba_host_plan(n_points, n, obs_pt.ctypes.data_as(_lib.c_int32_p), cam_p, n_cams, cap,
                             order.ctypes.data_as(_lib.c_int64_p), pstart.ctypes.data_as(_lib.c_int64_p),
                             cstart.ctypes.data_as(_lib.c_int64_p))
     return nch, order[:n], pstart, cstart[: max(nch, 0) + 1]
@@ -69,6 +73,11 @@ def test_host_plan_sorts_by_point_and_chunks_whole_points(lib):
     sizes = np.diff(cstart)
     assert sizes.min() > 0 and sizes.max() <= 256
     assert np.all(np.isin(cstart, pstart)), "chunk boundaries must coincide with point boundaries"
+    # with cameras: sorted by (point, camera), ties in input order
+    obs_cam = rng.integers(0, 7, len(obs_pt))
+    _, order2, pstart2, _ = _plan(lib, n_points, obs_pt, 256, obs_cam, 7)
+    assert np.array_equal(order2, np.lexsort((np.arange(len(obs_pt)), obs_cam, obs_pt)))
+    assert np.array_equal(pstart2, pstart)
     # greedy packing: a chunk plus the next point would overflow
     sorted_pts = obs_pt[order]
     for c in range(nch - 1):
