@@ -411,7 +411,8 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
 // triangle of Sacc into G(G+1)/2 tiles (a <= b) of (g nc)^2 doubles.  Because the sparsity pattern is
 // static, cba_create lays out one observation STREAM per tile: the observations (sorted by point, then
 // camera) whose camera is in group a or b and whose point is seen from both groups, chunked like the main
-// array, each with the [jbeg, jend) range of its pair partners inside the chunk.  A workgroup is bound to
+// array, plus the list of (i, j) observation pairs of every chunk, so that in the pair phase every lane has
+// exactly one 6x6 (9x9) block to form — no partner loops of uneven length.  A workgroup is bound to
 // one tile, keeps that tile in LDS across all of the tile's chunks, and flushes it once (per-workgroup
 // partials, reduced in fixed order).  The Jacobian blocks are recomputed per stream (G times per
 // observation) rather than stored: 24 B + ~600 flop beats 144 B of HBM traffic per use.
@@ -420,8 +421,8 @@ struct TilePlan {
   const double* v;
   const int* pt;
   const unsigned char* camloc;   // camera index inside the tile: [0,g) group a, [g,2g) group b
-  const unsigned short* jbeg;    // chunk-local partner range of each observation
-  const unsigned short* jend;
+  const unsigned short* pairs;   // (i | j << 8): chunk-local indices of every observation pair to multiply
+  const int* pair_start;         // [n_tile_chunks + 1] offsets into `pairs`
   const int* chunk_start;        // [n_tile_chunks + 1] offsets into the stream arrays
   const int* tile_chunk_begin;   // [n_tiles + 1]
   const int* wg_tile;            // [grid] tile of each workgroup
@@ -483,17 +484,14 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
     const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
     const int i = o0 + threadIdx.x;
     const bool active = i < o1;
-    double Ai[2][MAX_NC], Zi[2][3];
-    int cl_i = 0, np_i = 0, jb = 0, je = 0;
     if (active) {
+      double Ai[2][MAX_NC], Zi[2][3];
       const int pt = tp.pt[i];
-      cl_i = tp.camloc[i];
-      jb = tp.jbeg[i];
-      je = tp.jend[i];
+      const int cl_i = tp.camloc[i];
       const CamTab& ct = cam_at(sh_tab, cl_i);
       double e[2], B[2][3];
       obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], tp.u[i], tp.v[i], loss, f_scale, e, Ai, B);
-      np_i = (int)ct.nparams;
+      const int np_i = (int)ct.nparams;
       double Vd[6], L[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
@@ -530,43 +528,50 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
       sh_cam[threadIdx.x] = cl_i;
     }
     __syncthreads();
-    if (active) {
-      const int row0 = sh_loff[cl_i];
-      for (int j = jb; j < je; ++j) {
-        const int cl_j = sh_cam[j];
-        const int col0 = sh_loff[cl_j];
-        double Zj[2][3], Aj[2][NC];
+    const int q1 = tp.pair_start[ch + 1];
+    for (int q = tp.pair_start[ch] + threadIdx.x; q < q1; q += BLOCK) {
+      const unsigned pr = tp.pairs[q];
+      const int i_loc = pr & 255u, j_loc = pr >> 8;
+      const int cl_i = sh_cam[i_loc], cl_j = sh_cam[j_loc];
+      const int row0 = sh_loff[cl_i], col0 = sh_loff[cl_j];
+      const int np_i = (int)cam_at(sh_tab, cl_i).nparams, np_j = (int)cam_at(sh_tab, cl_j).nparams;
+      double Zi[2][3], Zj[2][3], Ai[2][NC], Aj[2][NC];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { Zj[0][k] = sh_Z[k * CHUNK + j]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j]; }
+      for (int k = 0; k < 3; ++k) {
+        Zi[0][k] = sh_Z[k * CHUNK + i_loc]; Zi[1][k] = sh_Z[(3 + k) * CHUNK + i_loc];
+        Zj[0][k] = sh_Z[k * CHUNK + j_loc]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j_loc];
+      }
 #pragma unroll
-        for (int k = 0; k < NC; ++k) { Aj[0][k] = sh_A[k * CHUNK + j]; Aj[1][k] = sh_A[(NC + k) * CHUNK + j]; }
-        double M[2][2];
+      for (int k = 0; k < NC; ++k) {
+        Ai[0][k] = sh_A[k * CHUNK + i_loc]; Ai[1][k] = sh_A[(NC + k) * CHUNK + i_loc];
+        Aj[0][k] = sh_A[k * CHUNK + j_loc]; Aj[1][k] = sh_A[(NC + k) * CHUNK + j_loc];
+      }
+      double M[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) M[a][b] = Zi[a][0] * Zj[b][0] + Zi[a][1] * Zj[b][1] + Zi[a][2] * Zj[b][2];
-        const bool same_obs = (j == (int)threadIdx.x);
-        const bool same_cam = (cl_j == cl_i);
-        const int np_j = (int)cam_at(sh_tab, cl_j).nparams;
+        for (int b = 0; b < 2; ++b) M[a][b] = Zi[a][0] * Zj[b][0] + Zi[a][1] * Zj[b][1] + Zi[a][2] * Zj[b][2];
+      const bool same_obs = (i_loc == j_loc);
+      const bool same_cam = (cl_j == cl_i);
+      double* Sblk = sh_S + row0 * ld + col0;
 #pragma unroll
-        for (int r = 0; r < NC; ++r) {
-          if (r >= np_i) continue;
-          const double t0 = Ai[0][r] * M[0][0] + Ai[1][r] * M[1][0];
-          const double t1 = Ai[0][r] * M[0][1] + Ai[1][r] * M[1][1];
+      for (int r = 0; r < NC; ++r) {
+        if (r >= np_i) continue;
+        const double t0 = Ai[0][r] * M[0][0] + Ai[1][r] * M[1][0];
+        const double t1 = Ai[0][r] * M[0][1] + Ai[1][r] * M[1][1];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            if (c >= np_j) continue;
-            const double val = t0 * Aj[0][c] + t1 * Aj[1][c];  // block(r, c) of W_i V'^-1 W_j^T
-            if (same_obs) {
-              if (c >= r) lds_add(&sh_S[(row0 + r) * ld + col0 + c], val);
-            } else if (same_cam) {
-              // two observations of one camera (duplicates): block + block^T on the diagonal block
-              const int lo = r < c ? r : c, hi = r < c ? c : r;
-              lds_add(&sh_S[(row0 + lo) * ld + col0 + hi], (r == c) ? 2.0 * val : val);
-            } else {
-              // partners are sorted by camera, so (row camera) < (column camera): upper block triangle
-              lds_add(&sh_S[(row0 + r) * ld + col0 + c], val);
-            }
+        for (int c = 0; c < NC; ++c) {
+          if (c >= np_j) continue;
+          const double val = t0 * Aj[0][c] + t1 * Aj[1][c];  // block(r, c) of W_i V'^-1 W_j^T
+          if (same_obs) {
+            if (c >= r) lds_add(&Sblk[r * ld + c], val);
+          } else if (same_cam) {
+            // two observations of one camera (duplicates): block + block^T on the diagonal block
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            lds_add(&Sblk[lo * ld + hi], (r == c) ? 2.0 * val : val);
+          } else {
+            // pairs are listed with (row camera) < (column camera): upper block triangle
+            lds_add(&Sblk[r * ld + c], val);
           }
         }
       }
@@ -628,44 +633,49 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
 // Dense Cholesky S = L L^T (lower triangle, row-major, in place in a copy), blocked right-looking, NB = 32.
 constexpr int NB = 32;
 
-__global__ void __launch_bounds__(NB * NB)
-k_potrf_diag(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
-  __shared__ double T[NB][NB + 1];
-  const int nb = min(NB, n - k0);
-  const int r = threadIdx.y, c = threadIdx.x;
-  if (r < nb && c < nb) T[r][c] = M[(long)(k0 + r) * n + k0 + c];
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    if (r == j && c == j) {
-      const double d = T[j][j];
-      if (!(d > 0.0) || !isfinite(d)) { flags[2] = 1; T[j][j] = 1.0; }
-      else T[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    if (c == j && r > j && r < nb) T[r][j] /= T[j][j];
-    __syncthreads();
-    if (r > j && c > j && c <= r && r < nb) T[r][c] -= T[r][j] * T[c][j];
-    __syncthreads();
-  }
-  if (r < nb && c < nb && c <= r) M[(long)(k0 + r) * n + k0 + c] = T[r][c];
-}
-
-// rows below the diagonal block:  L_ik = M_ik L_kk^-T   (one thread per row)
+// One step of the right-looking factorisation, fused: every workgroup factors the NB x NB diagonal block
+// itself (wave 0, one row per lane, in registers, column broadcasts by cross-lane reads — no barriers),
+// parks L_kk in LDS, then solves its share of the rows below:  L_ik = M_ik L_kk^-T  (one thread per row).
 __global__ void __launch_bounds__(BLOCK)
-k_trsm_panel(double* __restrict__ M, int n, int k0) {
+k_potrf_panel(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
   __shared__ double T[NB][NB + 1];
   const int nb = min(NB, n - k0);
-  for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
-    const int r = t / NB, c = t % NB;
-    T[r][c] = (r < nb && c <= r) ? M[(long)(k0 + r) * n + k0 + c] : 0.0;
+  if (threadIdx.x < WAVE) {
+    const int lane = threadIdx.x;
+    const int r = lane < NB ? lane : 0;
+    double row[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) row[c] = (lane < nb && c <= r && c < nb) ? M[(long)(k0 + r) * n + k0 + c] : (c == r ? 1.0 : 0.0);
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double d = __shfl(row[j], j, WAVE);
+      if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
+      const double ljj = sqrt(d);
+      const double lrj = (lane == j) ? ljj : row[j] / ljj;
+      row[j] = lrj;
+#pragma unroll
+      for (int c = j + 1; c < NB; ++c) {
+        const double lcj = __shfl(lrj, c, WAVE);
+        row[c] -= lrj * lcj;
+      }
+    }
+    if (bad && lane == 0) flags[2] = 1;
+    if (lane < NB) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        T[lane][c] = row[c];
+        if (blockIdx.x == 0 && lane < nb && c <= lane) M[(long)(k0 + lane) * n + k0 + c] = row[c];
+      }
+    }
   }
   __syncthreads();
   const int i = k0 + nb + blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   double x[NB];
-  double* row = M + (long)i * n + k0;
+  double* prow = M + (long)i * n + k0;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? row[j] : 0.0;
+  for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? prow[j] : 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     if (j < nb) {
@@ -678,7 +688,7 @@ k_trsm_panel(double* __restrict__ M, int n, int k0) {
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    if (j < nb) row[j] = x[j];
+    if (j < nb) prow[j] = x[j];
 }
 
 // trailing update: M_ij -= L_i,panel L_j,panel^T for tiles with i >= j beyond the panel

@@ -58,7 +58,7 @@ struct cba_problem {
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   bool schur_lds = true;   // Sacc always lives in LDS tiles
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  long tile_stream_len = 0;
+  long tile_stream_len = 0, n_pairs = 0;
   TilePlan tp{};
   int* tile_wg_begin = nullptr;
   int loss = 0;
@@ -271,12 +271,12 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     std::vector<double> u, v;
     std::vector<int> pt;
     std::vector<unsigned char> cl;
-    std::vector<unsigned short> jb, je;
-    std::vector<int> chunk_start;  // local offsets, starts with 0
-    int open = 0;                  // start of the currently open chunk
+    std::vector<unsigned short> pairs;
+    std::vector<int> chunk_start, pair_start;  // local offsets, start with 0
+    int open = 0;                              // start of the currently open chunk
   };
   std::vector<Stream> st(nT);
-  for (auto& s : st) s.chunk_start.push_back(0);
+  for (auto& s : st) { s.chunk_start.push_back(0); s.pair_start.push_back(0); }
   std::vector<int> gbeg(G + 1);
   for (int q = 0; q < P; ++q) {
     const int s0 = hps[q], s1 = hps[q + 1];
@@ -297,43 +297,47 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         Stream& s = st[tile_id(a, b)];
         const int cnt = na + nb;
         int len = (int)s.pt.size();
-        if (len - s.open + cnt > CHUNK) { s.chunk_start.push_back(len); s.open = len; }
+        if (len - s.open + cnt > CHUNK) {
+          s.chunk_start.push_back(len); s.pair_start.push_back((int)s.pairs.size()); s.open = len;
+        }
         const int base = len - s.open;  // chunk-local index of this point's first entry
         for (int i = gbeg[a]; i < gbeg[a + 1]; ++i) {
-          const int k = i - gbeg[a];
           s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]);
           s.cl.push_back((unsigned char)(hcam[i] - gcam[a]));
-          if (b == a) { s.jb.push_back((unsigned short)(base + k)); s.je.push_back((unsigned short)(base + na)); }
-          else { s.jb.push_back((unsigned short)(base + na)); s.je.push_back((unsigned short)(base + cnt)); }
         }
         for (int i = gbeg[b]; b != a && i < gbeg[b + 1]; ++i) {
           s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]);
           s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b]));
-          s.jb.push_back(0); s.je.push_back(0);  // column observations have no partner loop
+        }
+        // pairs (row observation i, column observation j), chunk-local, camera(i) <= camera(j)
+        for (int i = 0; i < na; ++i) {
+          const int j0 = (b == a) ? i : na, j1 = (b == a) ? na : cnt;
+          for (int j = j0; j < j1; ++j) s.pairs.push_back((unsigned short)((base + i) | ((base + j) << 8)));
         }
       }
     }
   }
   // concatenate
   std::vector<double> U, V;
-  std::vector<int> PT, CS, TCB(nT + 1, 0);
+  std::vector<int> PT, CS, PS, TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
-  std::vector<unsigned short> JB, JE;
-  CS.push_back(0);
+  std::vector<unsigned short> PR;
+  CS.push_back(0); PS.push_back(0);
   for (int t = 0; t < nT; ++t) {
     Stream& s = st[t];
-    const int base = (int)PT.size();
-    if (!s.pt.empty()) s.chunk_start.push_back((int)s.pt.size());
+    const int base = (int)PT.size(), pbase = (int)PR.size();
+    if (!s.pt.empty()) { s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size()); }
     TCB[t] = (int)CS.size() - 1;
-    for (size_t c = 1; c < s.chunk_start.size(); ++c) CS.push_back(base + s.chunk_start[c]);
+    for (size_t c = 1; c < s.chunk_start.size(); ++c) { CS.push_back(base + s.chunk_start[c]); PS.push_back(pbase + s.pair_start[c]); }
     U.insert(U.end(), s.u.begin(), s.u.end()); V.insert(V.end(), s.v.begin(), s.v.end());
     PT.insert(PT.end(), s.pt.begin(), s.pt.end()); CL.insert(CL.end(), s.cl.begin(), s.cl.end());
-    JB.insert(JB.end(), s.jb.begin(), s.jb.end()); JE.insert(JE.end(), s.je.begin(), s.je.end());
+    PR.insert(PR.end(), s.pairs.begin(), s.pairs.end());
     s = Stream();
   }
   TCB[nT] = (int)CS.size() - 1;
   p->n_tile_chunks = TCB[nT];
   p->tile_stream_len = (long)PT.size();
+  p->n_pairs = (long)PR.size();
   // workgroups: proportional to the chunk count of each tile, at least one per tile
   const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
   std::vector<int> nwg(nT), wgb(nT + 1, 0);
@@ -353,16 +357,17 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   int *dpt = nullptr, *dcs = nullptr, *dtcb = nullptr, *dwt = nullptr, *dwr = nullptr, *dnwg = nullptr, *dta = nullptr, *dtb = nullptr,
       *dgc = nullptr, *dgp = nullptr;
   unsigned char* dcl = nullptr;
-  unsigned short *djb = nullptr, *dje = nullptr;
+  unsigned short* dpr = nullptr;
+  int* dps = nullptr;
 #define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
   TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
-  TRYP(dev_upload(p, &djb, JB)); TRYP(dev_upload(p, &dje, JE)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dtcb, TCB));
+  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dtcb, TCB));
   TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwr, wr)); TRYP(dev_upload(p, &dnwg, nwg)); TRYP(dev_upload(p, &dta, ta));
   TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
   TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
 #undef TRYP
   const int gn = g * p->nct;
-  p->tp = TilePlan{du, dv, dpt, dcl, djb, dje, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, gn * gn + gn};
+  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, gn * gn + gn};
   return CBA_OK;
 }
 
@@ -501,7 +506,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   if (!p || !o) return fail(CBA_ERR_INVALID, "null argument");
   o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 1;
-  o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len;
+  o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes;
   return CBA_OK;
 }
@@ -636,10 +641,9 @@ static int run_cholesky(cba_problem* p) {
   const int n = p->ncp;
   HIPCHK(hipMemcpyAsync(p->Lbuf, p->S, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   for (int k0 = 0; k0 < n; k0 += NB) {
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(NB, NB), 0, p->stream, p->Lbuf, n, k0, p->flags);
     const int rest = n - (k0 + NB);
+    hipLaunchKernelGGL(k_potrf_panel, dim3(std::max(1, (rest + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0, p->flags);
     if (rest > 0) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3((rest + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0);
       const int tiles = (rest + NB - 1) / NB;
       hipLaunchKernelGGL(k_syrk_trailing, dim3(tiles, tiles), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0);
     }

@@ -161,6 +161,7 @@ typedef struct {
   int32_t schur_grid;     /* workgroups of the tiled Schur kernel */
   int32_t reserved;
   int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
+  int64_t schur_pairs;      /* observation pairs (blocks of W V^-1 W^T) formed per Schur pass */
 } cba_info;
 int cba_get_info(cba_problem* p, cba_info* out);
 
