@@ -630,15 +630,28 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense Cholesky S = L L^T (lower triangle, row-major, in place in a copy), blocked right-looking, NB = 32.
+// Dense solve of the reduced camera system  S dc = rhs  (n <= 1152) by Cholesky, blocked right-looking,
+// NB = 32.  The work matrix is (n+1) x n, row-major: rows 0..n-1 hold S (lower triangle used), row n holds
+// rhs^T.  Row n is "below" every diagonal block, so the panel solves and trailing updates of the
+// factorisation turn it into y^T = (L^-1 rhs)^T for free — the forward substitution needs no kernel of its
+// own; only L^T x = y remains (k_chol_backward).
 constexpr int NB = 32;
 
-// One step of the right-looking factorisation, fused: every workgroup factors the NB x NB diagonal block
-// itself (wave 0, one row per lane, in registers, column broadcasts by cross-lane reads — no barriers),
-// parks L_kk in LDS, then solves its share of the rows below:  L_ik = M_ik L_kk^-T  (one thread per row).
+// broadcast lane `src` (wave-uniform) of a double through SGPRs: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// One step: every workgroup factors the NB x NB diagonal block itself (wave 0: one row per lane, held in
+// registers, column broadcasts by v_readlane — no barriers, no LDS traffic), parks L_kk in LDS, then solves
+// its share of the rows below:  L_ik = M_ik L_kk^-T  (one thread per row; `nrows` = n + 1 includes rhs^T).
 __global__ void __launch_bounds__(BLOCK)
-k_potrf_panel(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
+k_potrf_panel(double* __restrict__ M, int n, int nrows, int k0, int* __restrict__ flags) {
   __shared__ double T[NB][NB + 1];
+  __shared__ double Tinv[NB];
   const int nb = min(NB, n - k0);
   if (threadIdx.x < WAVE) {
     const int lane = threadIdx.x;
@@ -649,16 +662,14 @@ k_potrf_panel(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      double d = __shfl(row[j], j, WAVE);
+      double d = readlane_f64(row[j], j);
       if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
-      const double ljj = sqrt(d);
-      const double lrj = (lane == j) ? ljj : row[j] / ljj;
+      const double inv = 1.0 / sqrt(d);
+      const double lrj = (lane == j) ? d * inv : row[j] * inv;
       row[j] = lrj;
+      if (lane == j) Tinv[j] = inv;
 #pragma unroll
-      for (int c = j + 1; c < NB; ++c) {
-        const double lcj = __shfl(lrj, c, WAVE);
-        row[c] -= lrj * lcj;
-      }
+      for (int c = j + 1; c < NB; ++c) row[c] -= lrj * readlane_f64(lrj, c);
     }
     if (bad && lane == 0) flags[2] = 1;
     if (lane < NB) {
@@ -671,7 +682,7 @@ k_potrf_panel(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
   }
   __syncthreads();
   const int i = k0 + nb + blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
+  if (i >= nrows) return;
   double x[NB];
   double* prow = M + (long)i * n + k0;
 #pragma unroll
@@ -683,7 +694,7 @@ k_potrf_panel(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
 #pragma unroll
       for (int t = 0; t < NB; ++t)
         if (t < j) v -= x[t] * T[j][t];
-      x[j] = v / T[j][j];
+      x[j] = v * Tinv[j];
     }
   }
 #pragma unroll
@@ -691,25 +702,26 @@ k_potrf_panel(double* __restrict__ M, int n, int k0, int* __restrict__ flags) {
     if (j < nb) prow[j] = x[j];
 }
 
-// trailing update: M_ij -= L_i,panel L_j,panel^T for tiles with i >= j beyond the panel
+// trailing update: M_ij -= L_i,panel L_j,panel^T for tiles with i >= j beyond the panel (rows up to nrows)
 __global__ void __launch_bounds__(BLOCK)
-k_syrk_trailing(double* __restrict__ M, int n, int k0) {
+k_syrk_trailing(double* __restrict__ M, int n, int nrows, int k0) {
   __shared__ double Li[NB][NB + 1], Lj[NB][NB + 1];
   const int nb = min(NB, n - k0);
   const int base = k0 + nb;
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
   const int i0 = base + ti * NB, j0 = base + tj * NB;
+  if (j0 >= n) return;
   for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
     const int r = t / NB, c = t % NB;
-    Li[r][c] = (i0 + r < n && c < nb) ? M[(long)(i0 + r) * n + k0 + c] : 0.0;
+    Li[r][c] = (i0 + r < nrows && c < nb) ? M[(long)(i0 + r) * n + k0 + c] : 0.0;
     Lj[r][c] = (j0 + r < n && c < nb) ? M[(long)(j0 + r) * n + k0 + c] : 0.0;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
     const int r = t / NB, c = t % NB;
     const int gi = i0 + r, gj = j0 + c;
-    if (gi < n && gj < n && gj <= gi) {
+    if (gi < nrows && gj < n && gj <= gi) {
       double acc = 0.0;
 #pragma unroll
       for (int q = 0; q < NB; ++q) acc += Li[r][q] * Lj[c][q];
@@ -718,41 +730,13 @@ k_syrk_trailing(double* __restrict__ M, int n, int k0) {
   }
 }
 
-// solve L L^T x = rhs with one workgroup; x is written to out[0..n).  The 32x32 diagonal block of each
-// step is staged in LDS so that the serial part of the substitution never waits on global memory.
+// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.
 __global__ void __launch_bounds__(BLOCK)
-k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs, double* __restrict__ out) {
+k_chol_backward(const double* __restrict__ L, int n, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double y[];  // n
   __shared__ double D[NB][NB + 1];
-  for (int i = threadIdx.x; i < n; i += BLOCK) y[i] = rhs[i];
+  for (int i = threadIdx.x; i < n; i += BLOCK) y[i] = L[(long)n * n + i];
   const int lane = threadIdx.x & (WAVE - 1);
-  // forward: L y = rhs
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = min(NB, n - k0);
-    __syncthreads();
-    for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
-      const int r = t / NB, c = t % NB;
-      D[r][c] = (r < nb && c <= r) ? L[(long)(k0 + r) * n + k0 + c] : 0.0;
-    }
-    __syncthreads();
-    if (threadIdx.x < WAVE) {
-      double yj = (lane < nb) ? y[k0 + lane] : 0.0;
-      for (int t = 0; t < nb; ++t) {
-        const double yt = __shfl(yj, t, WAVE) / D[t][t];
-        if (lane == t) yj = yt;
-        else if (lane > t && lane < nb) yj -= D[lane][t] * yt;
-      }
-      if (lane < nb) y[k0 + lane] = yj;
-    }
-    __syncthreads();
-    for (int i = k0 + nb + threadIdx.x; i < n; i += BLOCK) {
-      const double* row = L + (long)i * n + k0;
-      double acc = 0.0;
-      for (int t = 0; t < nb; ++t) acc += row[t] * y[k0 + t];
-      y[i] -= acc;
-    }
-  }
-  // backward: L^T x = y
   const int nblk = (n + NB - 1) / NB;
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * NB;
@@ -760,13 +744,14 @@ k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs
     __syncthreads();
     for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
       const int r = t / NB, c = t % NB;
-      D[r][c] = (r < nb && c <= r) ? L[(long)(k0 + r) * n + k0 + c] : 0.0;
+      D[r][c] = (r < nb && c <= r) ? L[(long)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
     }
     __syncthreads();
     if (threadIdx.x < WAVE) {
       double xj = (lane < nb) ? y[k0 + lane] : 0.0;
+      const double invd = (lane < NB) ? 1.0 / D[lane][lane] : 1.0;
       for (int t = nb - 1; t >= 0; --t) {
-        const double xt = __shfl(xj, t, WAVE) / D[t][t];
+        const double xt = readlane_f64(xj * invd, t);
         if (lane == t) xj = xt;
         else if (lane < t) xj -= D[t][lane] * xt;
       }
@@ -775,6 +760,7 @@ k_chol_solve(const double* __restrict__ L, int n, const double* __restrict__ rhs
     __syncthreads();
     for (int i = threadIdx.x; i < k0; i += BLOCK) {
       double acc = 0.0;
+#pragma unroll 8
       for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * n + i] * y[k0 + t];
       y[i] -= acc;
     }

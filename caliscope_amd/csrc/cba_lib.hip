@@ -341,11 +341,34 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   // workgroups: proportional to the chunk count of each tile, at least one per tile
   const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
   std::vector<int> nwg(nT), wgb(nT + 1, 0);
-  for (int t = 0; t < nT; ++t) {
-    const long nch = TCB[t + 1] - TCB[t];
-    long w = p->n_tile_chunks > 0 ? (nch * budget + p->n_tile_chunks - 1) / p->n_tile_chunks : 1;
-    nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch, 1)));
-    wgb[t + 1] = wgb[t] + nwg[t];
+  {
+    std::vector<long> nch(nT);
+    long used = 0;
+    for (int t = 0; t < nT; ++t) {
+      nch[t] = TCB[t + 1] - TCB[t];
+      const long w = p->n_tile_chunks > 0 ? nch[t] * budget / p->n_tile_chunks : 1;
+      nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
+      used += nwg[t];
+    }
+    // hand out what is left (or take back the excess) where the chunks-per-workgroup load is most uneven
+    while (used != budget) {
+      int best = -1;
+      double score = 0.0;
+      for (int t = 0; t < nT; ++t) {
+        if (used < budget) {
+          if (nwg[t] >= nch[t]) continue;
+          const double sc = (double)nch[t] / nwg[t];
+          if (best < 0 || sc > score) { best = t; score = sc; }
+        } else {
+          if (nwg[t] <= 1) continue;
+          const double sc = -(double)nch[t] / (nwg[t] - 1);
+          if (best < 0 || sc > score) { best = t; score = sc; }
+        }
+      }
+      if (best < 0) break;
+      if (used < budget) { nwg[best]++; used++; } else { nwg[best]--; used--; }
+    }
+    for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
   }
   p->tile_grid = wgb[nT];
   std::vector<int> wt(p->tile_grid), wr(p->tile_grid);
@@ -386,7 +409,7 @@ static int configure_kernels(cba_problem* p) {
   p->n_tiles = p->G * (p->G + 1) / 2;
   if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
-  if ((rc = allow_lds(k_chol_solve, (size_t)p->ncp * 8))) return rc;
+  if ((rc = allow_lds(k_chol_backward, (size_t)p->ncp * 8))) return rc;
   return CBA_OK;
 }
 
@@ -483,13 +506,17 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
-  TRY(build_tile_plan(p, hu, hv, hcam, hpt, hps, off, max_blocks));
+  {
+    const size_t tile_lds = (nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz);
+    const int resident = cus * std::max<int>(1, (int)((160 * 1024) / tile_lds));  // no partial last round
+    TRY(build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus))));
+  }
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
   TRY(dev_alloc(p, &p->partial4, (size_t)1024 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)1024));
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
-  TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); TRY(dev_alloc(p, &p->Lbuf, (size_t)ncp * ncp));
+  TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * ncp));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4));
   HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
@@ -638,17 +665,18 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
 
 static int run_cholesky(cba_problem* p) {
   ScopedTimer t(p, T_CHOLESKY);
-  const int n = p->ncp;
+  const int n = p->ncp, nrows = n + 1;
   HIPCHK(hipMemcpyAsync(p->Lbuf, p->S, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  HIPCHK(hipMemcpyAsync(p->Lbuf + (size_t)n * n, p->rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   for (int k0 = 0; k0 < n; k0 += NB) {
-    const int rest = n - (k0 + NB);
-    hipLaunchKernelGGL(k_potrf_panel, dim3(std::max(1, (rest + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0, p->flags);
-    if (rest > 0) {
+    const int rest = nrows - (k0 + NB);
+    hipLaunchKernelGGL(k_potrf_panel, dim3(std::max(1, (rest + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, p->stream, p->Lbuf, n, nrows, k0, p->flags);
+    if (k0 + NB < n) {
       const int tiles = (rest + NB - 1) / NB;
-      hipLaunchKernelGGL(k_syrk_trailing, dim3(tiles, tiles), dim3(BLOCK), 0, p->stream, p->Lbuf, n, k0);
+      hipLaunchKernelGGL(k_syrk_trailing, dim3(tiles, tiles), dim3(BLOCK), 0, p->stream, p->Lbuf, n, nrows, k0);
     }
   }
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(BLOCK), (size_t)n * 8, p->stream, p->Lbuf, n, p->rhs, p->s);
+  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BLOCK), (size_t)n * 8, p->stream, p->Lbuf, n, p->s);
   return CBA_OK;
 }
 
