@@ -94,6 +94,8 @@ struct cba_problem {
   double t_ms[T_COUNT] = {0};
   long t_calls[T_COUNT] = {0};
   std::vector<void*> allocs;
+  hipGraph_t chol_graph = nullptr;
+  hipGraphExec_t chol_exec = nullptr;
 };
 
 template <typename T>
@@ -221,6 +223,8 @@ void cba_destroy(cba_problem* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drain_timers(p);
   for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (p->chol_exec) (void)hipGraphExecDestroy(p->chol_exec);
+  if (p->chol_graph) (void)hipGraphDestroy(p->chol_graph);
   for (void* a : p->allocs) (void)hipFree(a);
   if (p->h_scal) (void)hipHostFree(p->h_scal);
   if (p->h_flags) (void)hipHostFree(p->h_flags);
@@ -663,8 +667,10 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
   return CBA_OK;
 }
 
-static int run_cholesky(cba_problem* p) {
-  ScopedTimer t(p, T_CHOLESKY);
+// The dense solve is ~26 small dependent launches; enqueued one by one the GPU waits on the host between
+// them (the stream was just drained by the previous primitive).  Nothing in the sequence changes from call
+// to call (same buffers, same n), so it is captured once into a hipGraph and replayed.
+static int enqueue_cholesky(cba_problem* p) {
   const int n = p->ncp, nrows = n + 1;
   HIPCHK(hipMemcpyAsync(p->Lbuf, p->S, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   HIPCHK(hipMemcpyAsync(p->Lbuf + (size_t)n * n, p->rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
@@ -677,6 +683,20 @@ static int run_cholesky(cba_problem* p) {
     }
   }
   hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BLOCK), (size_t)n * 8, p->stream, p->Lbuf, n, p->s);
+  return CBA_OK;
+}
+
+static int run_cholesky(cba_problem* p) {
+  if (!p->chol_exec) {
+    HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_cholesky(p);
+    hipError_t e = hipStreamEndCapture(p->stream, &p->chol_graph);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CBA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    HIPCHK(hipGraphInstantiate(&p->chol_exec, p->chol_graph, nullptr, nullptr, 0));
+  }
+  ScopedTimer t(p, T_CHOLESKY);
+  HIPCHK(hipGraphLaunch(p->chol_exec, p->stream));
   return CBA_OK;
 }
 
