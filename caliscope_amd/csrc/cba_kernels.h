@@ -314,19 +314,23 @@ __global__ void k_scale_update(const double* __restrict__ Upacked, const double*
 
 // scalars of the linearisation + v1 = g / scale_inv^2 (the direction of the gradient in scaled space)
 //   partial[b][0..3] = sum (g/sinv)^2, sum (x sinv)^2, sum x^2, (unused) ; partial_max[b] = max |g|
+// `cam_end` = ncp_pad; `count_cams` = 0 on ranks > 0 of a sharded solve: camera entries are replicated
+// on every rank and must enter the all-reduced sums once.
 __global__ void __launch_bounds__(BLOCK)
 k_lin_scalars(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
-              long total, double* __restrict__ v1, double* __restrict__ partial, double* __restrict__ partial_max) {
+              long total, int cam_end, int count_cams, double* __restrict__ v1, double* __restrict__ partial,
+              double* __restrict__ partial_max) {
   __shared__ double sh_red[BLOCK / WAVE];
   double s0 = 0, s1 = 0, s2 = 0, m = 0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     const double gi = g[i], si = sinv[i], xi = x[i];
     const double gh = gi / si;
+    v1[i] = gh / si;
+    m = fmax(m, fabs(gi));
+    if (i < cam_end && !count_cams) continue;
     s0 += gh * gh;
     s1 += (xi * si) * (xi * si);
     s2 += xi * xi;
-    m = fmax(m, fabs(gi));
-    v1[i] = gh / si;
   }
   double r;
   r = block_sum(s0, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
@@ -843,10 +847,10 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
 // scalars of the Newton step: partial[b][0] = sum (s sinv)^2, [1] = sum g s
 __global__ void __launch_bounds__(BLOCK)
 k_step_scalars(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s, long total,
-               double* __restrict__ partial) {
+               long first, double* __restrict__ partial) {
   __shared__ double sh_red[BLOCK / WAVE];
   double s0 = 0, s1 = 0;
-  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+  for (long i = first + (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     const double p = s[i] * sinv[i];
     s0 += p * p;
     s1 += g[i] * s[i];
@@ -859,11 +863,11 @@ k_step_scalars(const double* __restrict__ g, const double* __restrict__ sinv, co
 // w_sq = sum (s sinv - c g / sinv)^2 with c = scal[idx_gdot] / gh_sq   (device-side scalars, no host round trip)
 __global__ void __launch_bounds__(BLOCK)
 k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s, long total,
-           const double* __restrict__ scal_gdot, double gh_sq, double* __restrict__ partial) {
+           long first, const double* __restrict__ scal_gdot, double gh_sq, double* __restrict__ partial) {
   __shared__ double sh_red[BLOCK / WAVE];
   const double c = scal_gdot[0] / gh_sq;
   double s0 = 0;
-  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+  for (long i = first + (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     const double w = s[i] * sinv[i] - c * g[i] / sinv[i];
     s0 += w * w;
   }
@@ -874,15 +878,15 @@ k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const 
 // x_new = x + alpha g / sinv^2 + beta s ; partial[b] = sum step^2
 __global__ void __launch_bounds__(BLOCK)
 k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
-               const double* __restrict__ s, double alpha, double beta, long total, double* __restrict__ x_new,
-               double* __restrict__ partial) {
+               const double* __restrict__ s, double alpha, double beta, long total, int cam_end, int count_cams,
+               double* __restrict__ x_new, double* __restrict__ partial) {
   __shared__ double sh_red[BLOCK / WAVE];
   double s0 = 0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     const double si = sinv[i];
     const double st = alpha * g[i] / (si * si) + beta * s[i];
     x_new[i] = x[i] + st;
-    s0 += st * st;
+    if (i >= cam_end || count_cams) s0 += st * st;
   }
   const double r = block_sum(s0, sh_red);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;

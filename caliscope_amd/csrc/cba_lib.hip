@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/caliscope_ba.h"
 #include "cba_kernels.h"
 
@@ -94,6 +96,9 @@ struct cba_problem {
   double t_ms[T_COUNT] = {0};
   long t_calls[T_COUNT] = {0};
   std::vector<void*> allocs;
+  // sharded solve (points partitioned over ranks, cameras replicated): RCCL over xGMI
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
   hipGraph_t chol_graph = nullptr;
   hipGraphExec_t chol_exec = nullptr;
 };
@@ -152,6 +157,29 @@ static int sync_scalars(cba_problem* p, int n_scal) {
   HIPCHK(hipMemcpyAsync(p->h_scal, p->scal, n_scal * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipMemcpyAsync(p->h_flags, p->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
+  return CBA_OK;
+}
+
+#define NCCLCHK(expr)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t _r = (expr);                                                                          \
+    if (_r != ncclSuccess) return fail(CBA_ERR_COMM, "%s failed: %s", #expr, ncclGetErrorString(_r));  \
+  } while (0)
+
+// in-place sum / max over the ranks of a sharded solve, enqueued on the engine's stream (no-op for world 1)
+static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
+  if (p->world <= 1) return CBA_OK;
+  NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, p->comm, p->stream));
+  return CBA_OK;
+}
+static int allreduce_max(cba_problem* p, double* buf, size_t count) {
+  if (p->world <= 1) return CBA_OK;
+  NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclMax, p->comm, p->stream));
+  return CBA_OK;
+}
+static int allreduce_flags(cba_problem* p) {
+  if (p->world <= 1) return CBA_OK;
+  NCCLCHK(ncclAllReduce(p->flags, p->flags, 4, ncclInt, ncclMax, p->comm, p->stream));
   return CBA_OK;
 }
 
@@ -223,6 +251,7 @@ void cba_destroy(cba_problem* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drain_timers(p);
   for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (p->comm) (void)ncclCommDestroy(p->comm);
   if (p->chol_exec) (void)hipGraphExecDestroy(p->chol_exec);
   if (p->chol_graph) (void)hipGraphDestroy(p->chol_graph);
   for (void* a : p->allocs) (void)hipFree(a);
@@ -604,7 +633,9 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
   }
   ScopedTimer t(p, T_VECTOR);
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, grid, 1, p->scal + slot);
-  return CBA_OK;
+  int rc = allreduce_sum(p, p->scal + slot, 1);
+  if (rc) return rc;
+  return allreduce_flags(p);
 }
 
 template <int NC>
@@ -620,6 +651,9 @@ static int run_build(cba_problem* p) {
     const int w = p->C * UPack<NC>::STRIDE;
     hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, 4), 0, p->stream, p->partial, p->grid, w, p->Upacked);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
+    int rc = allreduce_sum(p, p->Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
+    if (!rc) rc = allreduce_sum(p, p->scal + 8, 1);
+    if (rc) return rc;
     hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->Upacked,
                        p->cam_off, p->cam_np, p->C, p->g);
   }
@@ -637,23 +671,33 @@ static int run_jv(cba_problem* p, int nv) {
     hipLaunchKernelGGL((k_jv<NC, 2>), dim3(grid), dim3(BLOCK), lds_jv(p, 2), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                        p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, grid, 4, p->scal + 12);
-  return CBA_OK;
+  return allreduce_sum(p, p->scal + 12, 4);
 }
 
 template <int NC>
 static int run_linearize(cba_problem* p, cba_linearization* out) {
-  run_build<NC>(p);
+  {
+    int rcb = run_build<NC>(p);
+    if (rcb) return rcb;
+  }
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   {
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
                        p->lay, p->first_scale ? 1 : 0, p->sinv);
-    hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->v1, p->partial4, p->partial1);
+    hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->lay.ncp_pad,
+                       p->rank == 0 ? 1 : 0, p->v1, p->partial4, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
     hipLaunchKernelGGL(k_reduce_narrow<true>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
+    int rc0 = allreduce_sum(p, p->scal + 0, 4);
+    if (!rc0) rc0 = allreduce_max(p, p->scal + 4, 1);
+    if (rc0) return rc0;
   }
-  run_jv<NC>(p, 1);
+  {
+    int rcj = run_jv<NC>(p, 1);
+    if (rcj) return rcj;
+  }
   int rc = sync_scalars(p, 16);
   if (rc) return rc;
   p->first_scale = false;
@@ -713,6 +757,10 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     ScopedTimer t(p, T_SCHUR_REDUCE);
     hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + BLOCK - 1) / BLOCK, p->n_tiles), dim3(BLOCK), 0, p->stream, p->tp,
                        p->tile_wg_begin, p->partial, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
+    {
+      int rcs = allreduce_sum(p, p->Sacc, (size_t)ncp * ncp + ncp);  // reduced camera system: the one real exchange step
+      if (rcs) return rcs;
+    }
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
                        p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs);
@@ -729,10 +777,16 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     ScopedTimer t(p, T_VECTOR);
     const long tot = p->lay.total();
     const int vg = vec_grid(tot);
-    hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, p->partial4);
+    const long first = (p->rank == 0) ? 0 : p->lay.ncp_pad;  // replicated camera entries are counted on rank 0 only
+    hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->partial4);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
-    hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, p->scal + 17, p->gh_sq, p->partial1);
+    int rcv = allreduce_sum(p, p->scal + 16, 2);
+    if (rcv) return rcv;
+    hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->scal + 17, p->gh_sq, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
+    rcv = allreduce_sum(p, p->scal + 20, 1);
+    if (!rcv) rcv = allreduce_flags(p);
+    if (rcv) return rcv;
   }
   rc = sync_scalars(p, 24);
   if (rc) return rc;
@@ -771,8 +825,9 @@ static int begin_common(cba_problem* p, double* cost_out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
-  launch_cost(p, p->x, p->tab, 24, nullptr);
-  int rc = sync_scalars(p, 32);
+  int rc = launch_cost(p, p->x, p->tab, 24, nullptr);
+  if (rc) return rc;
+  rc = sync_scalars(p, 32);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   p->first_scale = true;
@@ -831,12 +886,16 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_VECTOR);
-    hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->x_new, p->partial1);
+    hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
+                       p->rank == 0 ? 1 : 0, p->x_new, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
+    int rct = allreduce_sum(p, p->scal + 28, 1);
+    if (rct) return rct;
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
-  launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
-  int rc = sync_scalars(p, 32);
+  int rc = launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
+  if (rc) return rc;
+  rc = sync_scalars(p, 32);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   const double c = 0.5 * p->h_scal[24];
@@ -853,6 +912,29 @@ int cba_accept(cba_problem* p) {
   std::swap(p->x, p->x_new);
   std::swap(p->tab, p->tab_new);
   p->have_trial = false; p->linearized = false; p->stepped = false;
+  return CBA_OK;
+}
+
+int cba_comm_unique_id(char* out128) {
+  if (!out128) return fail(CBA_ERR_INVALID, "cba_comm_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than 128 bytes");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  std::memset(out128, 0, 128);
+  std::memcpy(out128, &id, sizeof(id));
+  return CBA_OK;
+}
+
+int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world) {
+  if (!p || !id128) return fail(CBA_ERR_INVALID, "cba_comm_init: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(CBA_ERR_INVALID, "cba_comm_init: rank %d of %d", rank, world);
+  if (p->comm) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
+  HIPCHK(hipSetDevice(p->device));
+  p->rank = rank; p->world = world;
+  if (world == 1) return CBA_OK;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  NCCLCHK(ncclCommInitRank(&p->comm, world, id, rank));
   return CBA_OK;
 }
 

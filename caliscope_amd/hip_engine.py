@@ -154,6 +154,17 @@ class HipEngine:
         self._check(self.lib.cba_reduced_system(self._h, _dp(S), _dp(rhs)), "cba_reduced_system")
         return S, rhs
 
+    # -- sharded solves: RCCL communicator inside the library -------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.cba_comm_unique_id(buf), "cba_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes produced by comm_unique_id()")
+        self._check(self.lib.cba_comm_init(self._h, unique_id, int(rank), int(world)), "cba_comm_init")
+
     def info(self) -> dict:
         o = _lib.Info()
         self._check(self.lib.cba_get_info(self._h, C.byref(o)), "cba_get_info")

@@ -75,6 +75,16 @@ typedef struct {
 int cba_create(const cba_problem_desc* desc, const cba_options* opt, cba_problem** out);
 void cba_destroy(cba_problem* p);
 
+/* ---- sharded solves (one process per GPU) --------------------------------------------------------
+ * The world points (with ALL their observations) are partitioned over the ranks by the host
+ * (caliscope_amd/sharding.py); every rank creates its problem from its own shard and the full camera set.
+ * After cba_comm_init the primitives below all-reduce — over RCCL/xGMI, on the engine's stream — exactly
+ * the camera blocks U_c, g_c, the reduced camera system (S, b) and the scalar sums; the dense solve is
+ * repeated identically on every rank.  Rank 0 calls cba_comm_unique_id and distributes the 128 bytes by any
+ * host-side channel (bench.py uses torch.distributed). */
+int cba_comm_unique_id(char* out128);
+int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world);
+
 /* ---- one trust-region iteration, as primitives (scalars out, vectors stay on the device) ------ */
 
 /* Upload x0 (reference layout, length n = sum(cam_n_params) + 3 P), evaluate the residuals there.

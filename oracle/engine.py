@@ -73,6 +73,9 @@ class OracleEngine:
         self.ncp = parameterization.n_camera_params
         P = parameterization.n_points
         self.P_global = P
+        # owned_points=None: the arrays describe a problem that is already local to this rank (the product's
+        # shard_problem did the re-indexing); current_x() then returns the local vector as the HIP engine does.
+        self._gather_on_read = owned_points is not None
         self.owned = np.arange(P) if owned_points is None else np.asarray(owned_points, dtype=np.int64)
         g2l = -np.ones(P, dtype=np.int64)
         g2l[self.owned] = np.arange(self.owned.size)
@@ -231,6 +234,8 @@ class OracleEngine:
 
     def current_x(self):
         """Full-layout x; non-owned points are filled by an all-reduce of zero-padded vectors."""
+        if not self._gather_on_read:
+            return self.x.copy()
         out = np.zeros(self.n_params)
         pts = np.zeros((self.P_global, 3))
         pts[self.owned] = self.x[self.ncp :].reshape(-1, 3)
