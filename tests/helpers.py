@@ -52,7 +52,9 @@ def aligned_difference(par, x_a, x_b):
     for A, B in zip(Ra, Rb):
         # world->cam rotation of a in b's gauge: A R^T
         rel = (A @ R.T) @ B.T
-        ang = max(ang, float(np.arccos(np.clip((np.trace(rel) - 1) / 2, -1, 1))))
+        w = np.array([rel[2, 1] - rel[1, 2], rel[0, 2] - rel[2, 0], rel[1, 0] - rel[0, 1]])
+        # atan2 form: arccos((tr-1)/2) alone has a sqrt(eps) ~ 1.5e-8 rad noise floor near zero
+        ang = max(ang, float(np.arctan2(0.5 * np.linalg.norm(w), 0.5 * (np.trace(rel) - 1.0))))
     return pos, ang, s
 
 
