@@ -50,12 +50,12 @@ def algorithmic_bytes(n_obs, n_points, n_cams, ncp, nct):
     }
 
 
-def build_problem(name, seed=42, **overrides):
+def build_problem(name, seed=42, shard=0, **overrides):
     from caliscope_amd.bundle_parameterization import BundleParameterization
     from caliscope_amd.engine import BAProblem
     from caliscope_amd.synthetic import CONFIGS, make_config
 
-    sc = make_config(name, seed=seed, **overrides)
+    sc = make_config(name, seed=seed, shard=shard, **overrides)
     par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=len(sc.points_init), refine_intrinsics=sc.refine_intrinsics)
     x0 = par.pack(sc.cameras_init, sc.points_init)
     f_scale = sc.f_scale_1px() if sc.loss != "linear" else 1.0
@@ -84,30 +84,58 @@ def rms_px(engine, par, x, cam_idx):
     return float(np.sqrt(np.mean(np.sum(e * e, axis=1))))
 
 
-def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, **overrides):
+class _Solo:
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def allreduce_sum(self, a):
+        return np.asarray(a, dtype=np.float64)
+
+    def allreduce_max(self, v):
+        return float(v)
+
+
+def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, control=None, **overrides):
+    """Weak scaling: rank r owns shard r (its own points/observations of the same cameras); the engine
+    all-reduces the camera blocks, the reduced camera system and the scalar sums over RCCL."""
     from caliscope_amd.hip_engine import HipEngine
     from caliscope_amd.trf import trf_solve
 
+    control = control or _Solo()
     solve_kw = solve_kw or {}
     t_gen = time.time()
-    sc, par, x0, prob, cfg = build_problem(name, seed=seed, **overrides)
+    sc, par, x0, prob, cfg = build_problem(name, seed=seed, shard=control.rank, **overrides)
     t_gen = time.time() - t_gen
     eng = HipEngine(prob, device_id=device_id)
+    if control.world > 1:
+        uid = control.broadcast_bytes(eng.comm_unique_id() if control.rank == 0 else None, 128)
+        eng.comm_init(uid, control.rank, control.world)
     info = eng.info()
     eng.begin(x0)
     run_iterations(eng, max(warmup, 1), solve_kw)
     if timers:
         eng.enable_timers(True)
         eng.reset_timers()
+    control.barrier()
     t0 = time.perf_counter()
-    solves, last = run_iterations(eng, steps, solve_kw)
-    elapsed = time.perf_counter() - t0
+    solves, last = run_iterations(eng, steps, solve_kw)  # every engine call ends with a stream synchronize
+    control.barrier()
+    elapsed = control.allreduce_max(time.perf_counter() - t0)
     tm = eng.timers() if timers else {}
     eng.enable_timers(False)
-    # untimed: full solve for the accuracy figure
+    # untimed: full solve for the accuracy figure (squared pixel errors summed over all shards)
     full = trf_solve(eng, None, **solve_kw)
-    rms = rms_px(eng, par, full.x, prob.camera_indices)
-    rms0 = rms_px(eng, par, x0, prob.camera_indices)
+
+    def rms_all(x):
+        r, _ = eng.residuals(x)
+        fx = np.array([b.fx_initial for b in par.blocks])[prob.camera_indices]
+        e = r.reshape(-1, 2) * fx[:, None]
+        tot = control.allreduce_sum(np.array([float(np.sum(e * e)), float(len(fx))]))
+        return float(np.sqrt(tot[0] / tot[1]))
+
+    rms, rms0 = rms_all(full.x), rms_all(x0)
     eng.close()
     return {
         "name": name, "n_obs": prob.n_obs, "n_points": par.n_points, "n_cams": len(par.blocks), "ncp": par.n_camera_params,
@@ -177,15 +205,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch multi-GPU runs with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    control = None
     if world > 1:
-        raise SystemExit("multi-GPU bench is not wired up in this revision")
+        import torch.distributed as dist
+
+        from caliscope_amd.distributed import TorchControlPlane
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")  # host-side control plane only; the data plane is RCCL inside the engine
+        control = TorchControlPlane()
 
     import __graft_entry__ as entry
 
-    entry.build()
-    m = measure(args.workload, args.steps, args.warmup, device_id=local_rank)
+    if rank == 0:
+        entry.build()
+    if control is not None:
+        control.barrier()
+    m = measure(args.workload, args.steps, args.warmup, device_id=local_rank, control=control)
     total_obs = m["n_obs"] * world
     value = total_obs * m["steps"] / m["elapsed"]
     out = {
@@ -204,7 +242,8 @@ def main():
         "config": {
             "workload": f"{args.workload}: {m['n_cams']} cams / {m['n_points']} points / {m['n_obs']} obs per GPU, "
                         f"{'extrinsics+intrinsics' if m['nct'] == 9 else 'extrinsics-only'} BA, {m['loss']} loss",
-            "n_obs_total": total_obs, "params_per_camera": m["nct"], "parallelism": f"points sharded x{world}",
+            "n_obs_total": total_obs, "params_per_camera": m["nct"],
+            "parallelism": f"points sharded x{world}; RCCL all-reduce of camera blocks + reduced camera system per iteration",
             "tolerances": "ftol=xtol=gtol=1e-8 (reference defaults)", "solves_in_timed_region": m["solves"],
         },
         "final_rms_px": round(m["final_rms_px"], 6),
@@ -237,7 +276,12 @@ def main():
     if also:
         out["also"] = also
     if rank == 0:
-        print(json.dumps(out, default=lambda o: int(o) if isinstance(o, np.integer) else float(o)))
+        print(json.dumps(out, default=lambda o: int(o) if isinstance(o, np.integer) else float(o)), flush=True)
+    if control is not None:
+        import torch.distributed as dist
+
+        control.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

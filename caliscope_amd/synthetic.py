@@ -118,12 +118,15 @@ def make_scene(
     pixel_sigma: float = 0.5,
     seed: int = 42,
     chunk: int = 131072,
+    shard: int = 0,
 ) -> SyntheticBA:
+    """``shard`` > 0 draws a different set of points / observations (and their initial perturbation) for the
+    same cameras and the same camera perturbation: rank ``shard`` of a weak-scaling run owns that set."""
     if n_obs % n_points:
         raise ValueError("n_obs must be a multiple of n_points (each point is seen by exactly n_obs/n_points cameras)")
     k = n_obs // n_points
     cams_true = ring_camera_array(n_cams)
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed if shard == 0 else [seed, shard])
     rad = 0.6 * np.sqrt(rng.uniform(0, 1, n_points))
     ang = rng.uniform(0, 2 * np.pi, n_points)
     pts = np.stack([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(0, 1.2, n_points)], axis=1)
@@ -156,7 +159,7 @@ def make_scene(
 
     outlier_rows = np.array([], dtype=np.int64)
     if outliers > 0:
-        orng = np.random.default_rng(seed + 2)
+        orng = np.random.default_rng(seed + 2 if shard == 0 else [seed + 2, shard])
         n_bad = round(outliers * n_obs)
         outlier_rows = np.sort(orng.choice(n_obs, size=n_bad, replace=False))
         mag = orng.uniform(10.0, 50.0, n_bad)
@@ -180,7 +183,8 @@ def make_scene(
             cam_id=cid, size=c.size, matrix=K, distortions=dist, rotation=rvec_to_matrix(rvec),
             translation=c.translation + irng.normal(0, 0.02, 3),
         )
-    pts_init = pts + irng.normal(0, 0.01, pts.shape)
+    prng = irng if shard == 0 else np.random.default_rng([seed + 1, shard])
+    pts_init = pts + prng.normal(0, 0.01, pts.shape)
     return SyntheticBA(
         name=name, cameras_true=cams_true, cameras_init=CameraArray(cams_init), points_true=pts, points_init=pts_init,
         camera_indices=camera_indices, image_coords=image_coords, obj_indices=obj_indices, loss=loss,
