@@ -214,27 +214,39 @@ class BundleParameterization:
 
     # -- tables for the C ABI ------------------------------------------------------------------
     def device_tables(self) -> dict[str, np.ndarray]:
-        """Flat per-camera tables consumed by ``cba_create`` (include/caliscope_ba.h).
+        return device_tables(self)
 
-        ``cam_const[c] = [fx0, fy0, cx, cy, d0..d4, 0, 0, 0]`` where ``d`` is
-        ``[k1, k2, p1, p2, k3]`` (pinhole; k1,k2 are the *initial* values, overridden by x when free)
-        or ``[k1, k2, k3, k4, 0]`` (fisheye).
-        """
-        C = len(self.blocks)
-        n_params = np.zeros(C, dtype=np.int32)
-        model = np.zeros(C, dtype=np.int32)
-        const = np.zeros((C, 12), dtype=np.float64)
-        for i, blk in enumerate(self.blocks):
-            n_params[i] = blk.n_params
-            model[i] = MODEL_FISHEYE4 if blk.fisheye else MODEL_PINHOLE_BC5
-            const[i, 0:4] = (blk.fx_initial, blk.fy_initial, blk.cx, blk.cy)
-            if blk.fisheye:
-                const[i, 4:8] = blk.dist_fixed
-            else:
-                const[i, 4:9] = (blk.k1_initial, blk.k2_initial, *blk.dist_fixed)
-        return {
-            "cam_n_params": n_params,
-            "cam_model": model,
-            "cam_const": const,
-            "cam_offsets": np.asarray(self.camera_param_offsets, dtype=np.int32),
-        }
+
+def n_params_of(parameterization) -> int:
+    """Length of the parameter vector (works for the reference's own BundleParameterization too)."""
+    return int(parameterization.n_camera_params) + 3 * int(parameterization.n_points)
+
+
+def device_tables(parameterization) -> dict[str, np.ndarray]:
+    """Flat per-camera tables consumed by ``cba_create`` (include/caliscope_ba.h).
+
+    Duck-typed on ``blocks`` / ``camera_param_offsets`` so that the reference's own
+    ``caliscope.core.bundle_parameterization.BundleParameterization`` can be passed straight through the
+    ``least_squares`` seam.  ``cam_const[c] = [fx0, fy0, cx, cy, d0..d4, 0, 0, 0]`` where ``d`` is
+    ``[k1, k2, p1, p2, k3]`` (pinhole; k1,k2 are the *initial* values, overridden by x when free) or
+    ``[k1, k2, k3, k4, 0]`` (fisheye).
+    """
+    blocks = parameterization.blocks
+    C = len(blocks)
+    n_params = np.zeros(C, dtype=np.int32)
+    model = np.zeros(C, dtype=np.int32)
+    const = np.zeros((C, 12), dtype=np.float64)
+    for i, blk in enumerate(blocks):
+        n_params[i] = blk.n_params
+        model[i] = MODEL_FISHEYE4 if blk.fisheye else MODEL_PINHOLE_BC5
+        const[i, 0:4] = (blk.fx_initial, blk.fy_initial, blk.cx, blk.cy)
+        if blk.fisheye:
+            const[i, 4:8] = blk.dist_fixed
+        else:
+            const[i, 4:9] = (blk.k1_initial, blk.k2_initial, *blk.dist_fixed)
+    return {
+        "cam_n_params": n_params,
+        "cam_model": model,
+        "cam_const": const,
+        "cam_offsets": np.asarray(parameterization.camera_param_offsets, dtype=np.int32),
+    }

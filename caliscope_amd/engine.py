@@ -55,7 +55,7 @@ class BAProblem:
 
     @property
     def n_params(self) -> int:
-        return int(self.parameterization.n_params)
+        return int(self.parameterization.n_camera_params) + 3 * int(self.parameterization.n_points)
 
 
 @dataclass

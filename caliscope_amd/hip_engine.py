@@ -13,6 +13,7 @@ import ctypes as C
 import numpy as np
 
 from caliscope_amd import _lib
+from caliscope_amd.bundle_parameterization import device_tables
 from caliscope_amd.engine import LOSS_CODES, BAProblem, Linearization, NewtonStep, Trial
 from caliscope_amd.exceptions import BackendError
 
@@ -32,7 +33,7 @@ class HipEngine:
         self.lib = _lib.load()
         self.problem = problem
         par = problem.parameterization
-        tabs = par.device_tables()
+        tabs = device_tables(par)
         self._keep = [
             np.ascontiguousarray(tabs["cam_n_params"], dtype=np.int32),
             np.ascontiguousarray(tabs["cam_model"], dtype=np.int32),
@@ -52,7 +53,7 @@ class HipEngine:
         self._h = None
         _lib.check(self.lib, self.lib.cba_create(C.byref(desc), C.byref(opt), C.byref(handle)), "cba_create")
         self._h = handle
-        self.n_params = par.n_params
+        self.n_params = problem.n_params
         self.n_cam_params = par.n_camera_params
         self.n_obs = problem.n_obs
 

@@ -26,6 +26,7 @@ import math
 
 import numpy as np
 
+from caliscope_amd.bundle_parameterization import n_params_of
 from caliscope_amd.engine import LOSS_CODES, BAProblem
 from caliscope_amd.exceptions import BackendError
 from caliscope_amd.trf import STATUS_REASONS, trf_solve
@@ -110,8 +111,9 @@ def least_squares(
     x0 = np.atleast_1d(np.asarray(x0, dtype=np.float64))
     if x0.ndim != 1:
         raise ValueError("`x0` must have at most 1 dimension.")
-    if x0.size != parameterization.n_params:
-        raise ValueError(f"x0 has {x0.size} entries, the parameterization expects {parameterization.n_params}")
+    n_expected = n_params_of(parameterization)
+    if x0.size != n_expected:
+        raise ValueError(f"x0 has {x0.size} entries, the parameterization expects {n_expected}")
     for name, tol in (("ftol", ftol), ("xtol", xtol), ("gtol", gtol)):
         if tol is None:
             raise ValueError(f"`{name}` must be a number for the MI355X backend")
