@@ -437,25 +437,33 @@ struct TilePlan {
   const int* group_cam_begin;    // [G + 1]
   const int* group_par_begin;    // [G + 1]
   int g;                         // cameras per group (max)
-  int tile_elems;                // (g nc)^2 + g nc : width of one workgroup's partial
+  int cs;                        // column stride of one camera block inside the LDS tile (odd: nc | 1)
+  int ld;                        // leading dimension of the LDS tile (odd)
+  int tile_elems;                // g nc ld + g nc : width of one workgroup's partial
 };
+// LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
+// an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
+// ld = 96 == 0 mod 32) the 64 lanes of one ds_add_f64 — same (r, c), different camera pairs — could reach
+// only 16 of the 32 bank pairs (measured: ~8-way conflicts, pair phase 830 us of a 1290 us pass on cfg4).
 
 template <int NC>
 __global__ void __launch_bounds__(BLOCK)
 k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
              const int* __restrict__ cam_off, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
              const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ partial,
-             int* __restrict__ flags) {
+             int* __restrict__ flags, int debug_skip) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int g = tp.g;
   const int gn = g * NC;
+  const int ld = tp.ld;
   double* sh_tab = sh;                          // [2g][CAMTAB_LDS]
   double* sh_A = sh_tab + 2 * g * CAMTAB_LDS;   // [2*NC][CHUNK]
   double* sh_Z = sh_A + 2 * NC * CHUNK;         // [6][CHUNK]
   double* sh_b = sh_Z + 6 * CHUNK;              // [gn]
-  double* sh_S = sh_b + gn;                     // [gn][gn]
-  int* sh_loff = reinterpret_cast<int*>(sh_S + gn * gn);  // [2g] local parameter offset of each tile camera
-  int* sh_cam = sh_loff + 2 * g;                          // [CHUNK]
+  double* sh_S = sh_b + gn;                     // [gn][ld]
+  int* sh_loff = reinterpret_cast<int*>(sh_S + gn * ld);  // [2g] row offset (packed) of each tile camera
+  int* sh_coff = sh_loff + 2 * g;                         // [2g] column offset (padded stride cs)
+  int* sh_cam = sh_coff + 2 * g;                          // [CHUNK]
 
   const int t = tp.wg_tile[blockIdx.x];
   const int ga = tp.tile_a[t], gb = tp.tile_b[t];
@@ -463,7 +471,6 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
-  const int ld = tp.group_par_begin[gb + 1] - pb0;  // columns of the tile (== rows for a diagonal tile)
 
   for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += BLOCK)
     sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)ca0 * CAMTAB_DOUBLES + i];
@@ -475,8 +482,11 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
     if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }
     else if (i - g < nb) off = cam_off[cb0 + i - g] - pb0;
     sh_loff[i] = off;
+    // column block of a tile camera: group-local camera index times the padded stride.  In a diagonal tile
+    // both roles use indices [0, g); in an off-diagonal tile the column cameras are the [g, 2g) entries.
+    sh_coff[i] = (i < g ? i : i - g) * tp.cs;
   }
-  for (int i = threadIdx.x; i < gn + gn * gn; i += BLOCK) sh_b[i] = 0.0;  // sh_b and sh_S are contiguous
+  for (int i = threadIdx.x; i < gn + gn * ld; i += BLOCK) sh_b[i] = 0.0;  // sh_b and sh_S are contiguous
   __syncthreads();
 
   const double* px = xvec + lay.ncp_pad;
@@ -488,7 +498,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
     const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
     const int i = o0 + threadIdx.x;
     const bool active = i < o1;
-    if (active) {
+    if (active && !(debug_skip & 2)) {
       double Ai[2][MAX_NC], Zi[2][3];
       const int pt = tp.pt[i];
       const int cl_i = tp.camloc[i];
@@ -532,12 +542,12 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
       sh_cam[threadIdx.x] = cl_i;
     }
     __syncthreads();
-    const int q1 = tp.pair_start[ch + 1];
+    const int q1 = (debug_skip & 1) ? 0 : tp.pair_start[ch + 1];
     for (int q = tp.pair_start[ch] + threadIdx.x; q < q1; q += BLOCK) {
       const unsigned pr = tp.pairs[q];
       const int i_loc = pr & 255u, j_loc = pr >> 8;
       const int cl_i = sh_cam[i_loc], cl_j = sh_cam[j_loc];
-      const int row0 = sh_loff[cl_i], col0 = sh_loff[cl_j];
+      const int row0 = sh_loff[cl_i], col0 = sh_coff[cl_j];
       const int np_i = (int)cam_at(sh_tab, cl_i).nparams, np_j = (int)cam_at(sh_tab, cl_j).nparams;
       double Zi[2][3], Zj[2][3], Ai[2][NC], Aj[2][NC];
 #pragma unroll
@@ -584,30 +594,34 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   }
   if (fail) flags[1] = 1;
   double* dst = partial + (long)blockIdx.x * tp.tile_elems;
-  for (int i = threadIdx.x; i < gn * gn; i += BLOCK) dst[i] = sh_S[i];
-  for (int i = threadIdx.x; i < gn; i += BLOCK) dst[gn * gn + i] = sh_b[i];
+  for (int i = threadIdx.x; i < gn * ld; i += BLOCK) dst[i] = sh_S[i];
+  for (int i = threadIdx.x; i < gn; i += BLOCK) dst[gn * ld + i] = sh_b[i];
 }
 
-// Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc.
+// Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc, undoing the
+// padded column layout of the LDS tile.
 __global__ void __launch_bounds__(BLOCK)
-k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial, int NCt, int ncp,
+k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
+              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
               double* __restrict__ Sacc, double* __restrict__ bacc) {
   const int t = blockIdx.y;
   const int ga = tp.tile_a[t], gb = tp.tile_b[t];
   const int pa0 = tp.group_par_begin[ga], npa = tp.group_par_begin[ga + 1] - pa0;
-  const int pb0 = tp.group_par_begin[gb], npb = tp.group_par_begin[gb + 1] - pb0;
-  const int gn = tp.g * NCt;
+  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+  const int gn = tp.g * NCt, ld = tp.ld;
   const int e = blockIdx.x * BLOCK + threadIdx.x;
   const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
-  if (e < npa * npb) {
+  if (e < gn * ld) {
+    const int r = e / ld, cpad = e % ld;
+    const int cj = cpad / tp.cs, within = cpad % tp.cs;
+    if (r >= npa || cj >= nb || within >= cam_np[cb0 + cj]) return;
     double s = 0.0;
     for (int w = w0; w < w1; ++w) s += partial[(long)w * tp.tile_elems + e];
-    const int r = e / npb, c = e % npb;
-    Sacc[(long)(pa0 + r) * ncp + pb0 + c] = s;
-  } else if (ga == gb && e >= gn * gn && e < gn * gn + npa) {
+    Sacc[(long)(pa0 + r) * ncp + cam_off[cb0 + cj] + within] = s;
+  } else if (ga == gb && e < gn * ld + npa) {
     double s = 0.0;
     for (int w = w0; w < w1; ++w) s += partial[(long)w * tp.tile_elems + e];
-    bacc[pa0 + (e - gn * gn)] = s;
+    bacc[pa0 + (e - gn * ld)] = s;
   }
 }
 

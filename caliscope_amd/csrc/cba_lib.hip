@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -85,6 +86,7 @@ struct cba_problem {
   int* h_flags = nullptr;
   bool first_scale = true;
   bool have_x0 = false;
+  int debug_skip = 0;  // profiling only (CBA_DEBUG_SCHUR_SKIP): 1 = skip the pair phase, 2 = skip the block recomputation
   bool begun = false, linearized = false, stepped = false, have_trial = false;
   double gh_sq = 0.0;
   std::vector<int> h_cam_off, h_cam_np;
@@ -275,9 +277,11 @@ template <int NC> static size_t lds_build(const cba_problem* p) {
   return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
 }
 static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_LDS + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
+static inline int tile_cs(int nc) { return nc | 1; }
+static inline int tile_ld(int g, int nc) { const int w = g * tile_cs(nc); return (w & 1) ? w : w + 1; }
 template <int NC> static size_t lds_schur_tile(int g) {
   const size_t gn = (size_t)g * NC;
-  return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * gn) * 8 + ((size_t)2 * g + CHUNK) * sizeof(int);
+  return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * tile_ld(g, NC)) * 8 + ((size_t)4 * g + CHUNK) * sizeof(int);
 }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
@@ -423,7 +427,8 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
 #undef TRYP
   const int gn = g * p->nct;
-  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, gn * gn + gn};
+  const int cs = tile_cs(p->nct), ld = tile_ld(g, p->nct);
+  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, cs, ld, gn * ld + gn};
   return CBA_OK;
 }
 
@@ -470,6 +475,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->device = dev;
   p->C = d->n_cams; p->P = d->n_points; p->N = d->n_obs;
   p->loss = d->loss; p->f_scale = d->f_scale;
+  if (const char* dbg = std::getenv("CBA_DEBUG_SCHUR_SKIP")) p->debug_skip = std::atoi(dbg);
   int rc = CBA_OK;
   auto bail = [&](int code) { cba_destroy(p); return code; };
 
@@ -751,12 +757,12 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   {
     ScopedTimer t(p, T_SCHUR);
     hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
-                       p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags);
+                       p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
   }
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
     hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + BLOCK - 1) / BLOCK, p->n_tiles), dim3(BLOCK), 0, p->stream, p->tp,
-                       p->tile_wg_begin, p->partial, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
+                       p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
     {
       int rcs = allreduce_sum(p, p->Sacc, (size_t)ncp * ncp + ncp);  // reduced camera system: the one real exchange step
       if (rcs) return rcs;
