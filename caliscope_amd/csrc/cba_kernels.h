@@ -446,8 +446,13 @@ struct TilePlan {
 // ld = 96 == 0 mod 32) the 64 lanes of one ds_add_f64 — same (r, c), different camera pairs — could reach
 // only 16 of the 32 bank pairs (measured: ~8-way conflicts, pair phase 830 us of a 1290 us pass on cfg4).
 
+// The pair phase is LDS-bound (36 ds_add_f64 + ~40 ds_read per pair) and the tile allows one workgroup per
+// CU, so the workgroup is 512 threads: the first 256 recompute the blocks of the chunk (one observation each),
+// then all eight waves share the chunk's pairs — twice the LDS requests in flight for the same LDS footprint.
+constexpr int SCHUR_BLOCK = 512;
+
 template <int NC>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(SCHUR_BLOCK)
 k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
              const int* __restrict__ cam_off, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
              const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ partial,
@@ -472,12 +477,12 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
 
-  for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += BLOCK)
+  for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += SCHUR_BLOCK)
     sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)ca0 * CAMTAB_DOUBLES + i];
   if (!diag)
-    for (int i = threadIdx.x; i < nb * CAMTAB_DOUBLES; i += BLOCK)
+    for (int i = threadIdx.x; i < nb * CAMTAB_DOUBLES; i += SCHUR_BLOCK)
       sh_tab[(g + i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)cb0 * CAMTAB_DOUBLES + i];
-  for (int i = threadIdx.x; i < 2 * g; i += BLOCK) {
+  for (int i = threadIdx.x; i < 2 * g; i += SCHUR_BLOCK) {
     int off = 0;
     if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }
     else if (i - g < nb) off = cam_off[cb0 + i - g] - pb0;
@@ -486,7 +491,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
     // both roles use indices [0, g); in an off-diagonal tile the column cameras are the [g, 2g) entries.
     sh_coff[i] = (i < g ? i : i - g) * tp.cs;
   }
-  for (int i = threadIdx.x; i < gn + gn * ld; i += BLOCK) sh_b[i] = 0.0;  // sh_b and sh_S are contiguous
+  for (int i = threadIdx.x; i < gn + gn * ld; i += SCHUR_BLOCK) sh_b[i] = 0.0;  // sh_b and sh_S are contiguous
   __syncthreads();
 
   const double* px = xvec + lay.ncp_pad;
@@ -497,7 +502,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   for (int ch = tp.tile_chunk_begin[t] + tp.wg_rank[blockIdx.x]; ch < ch_end; ch += tp.tile_nwg[t]) {
     const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
     const int i = o0 + threadIdx.x;
-    const bool active = i < o1;
+    const bool active = threadIdx.x < CHUNK && i < o1;  // block recomputation: one thread per observation
     if (active && !(debug_skip & 2)) {
       double Ai[2][MAX_NC], Zi[2][3];
       const int pt = tp.pt[i];
@@ -543,7 +548,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
     }
     __syncthreads();
     const int q1 = (debug_skip & 1) ? 0 : tp.pair_start[ch + 1];
-    for (int q = tp.pair_start[ch] + threadIdx.x; q < q1; q += BLOCK) {
+    for (int q = tp.pair_start[ch] + threadIdx.x; q < q1; q += SCHUR_BLOCK) {
       const unsigned pr = tp.pairs[q];
       const int i_loc = pr & 255u, j_loc = pr >> 8;
       const int cl_i = sh_cam[i_loc], cl_j = sh_cam[j_loc];
@@ -594,8 +599,8 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   }
   if (fail) flags[1] = 1;
   double* dst = partial + (long)blockIdx.x * tp.tile_elems;
-  for (int i = threadIdx.x; i < gn * ld; i += BLOCK) dst[i] = sh_S[i];
-  for (int i = threadIdx.x; i < gn; i += BLOCK) dst[gn * ld + i] = sh_b[i];
+  for (int i = threadIdx.x; i < gn * ld; i += SCHUR_BLOCK) dst[i] = sh_S[i];
+  for (int i = threadIdx.x; i < gn; i += SCHUR_BLOCK) dst[gn * ld + i] = sh_b[i];
 }
 
 // Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc, undoing the

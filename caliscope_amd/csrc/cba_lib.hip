@@ -756,7 +756,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_SCHUR);
-    hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
+    hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
                        p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
   }
   {
