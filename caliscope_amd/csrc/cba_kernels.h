@@ -604,28 +604,39 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 }
 
 // Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc, undoing the
-// padded column layout of the LDS tile.
-__global__ void __launch_bounds__(BLOCK)
+// padded column layout of the LDS tile.  blockDim = (64, 4): x walks the tile entries (coalesced), y splits
+// the workgroups of the tile four ways so that the dependent-load chain per thread stays short.
+__global__ void __launch_bounds__(256)
 k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
               const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
               double* __restrict__ Sacc, double* __restrict__ bacc) {
+  __shared__ double sh[4][64];
   const int t = blockIdx.y;
   const int ga = tp.tile_a[t], gb = tp.tile_b[t];
   const int pa0 = tp.group_par_begin[ga], npa = tp.group_par_begin[ga + 1] - pa0;
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int gn = tp.g * NCt, ld = tp.ld;
-  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  const int e = blockIdx.x * 64 + threadIdx.x;
   const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
+  double s0 = 0.0, s1 = 0.0;
+  if (e < tp.tile_elems) {
+    int w = w0 + threadIdx.y;
+    for (; w + 4 < w1; w += 8) {
+      s0 += partial[(long)w * tp.tile_elems + e];
+      s1 += partial[(long)(w + 4) * tp.tile_elems + e];
+    }
+    if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
+  }
+  sh[threadIdx.y][threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.y != 0 || e >= tp.tile_elems) return;
+  const double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
   if (e < gn * ld) {
     const int r = e / ld, cpad = e % ld;
     const int cj = cpad / tp.cs, within = cpad % tp.cs;
     if (r >= npa || cj >= nb || within >= cam_np[cb0 + cj]) return;
-    double s = 0.0;
-    for (int w = w0; w < w1; ++w) s += partial[(long)w * tp.tile_elems + e];
     Sacc[(long)(pa0 + r) * ncp + cam_off[cb0 + cj] + within] = s;
   } else if (ga == gb && e < gn * ld + npa) {
-    double s = 0.0;
-    for (int w = w0; w < w1; ++w) s += partial[(long)w * tp.tile_elems + e];
     bacc[pa0 + (e - gn * ld)] = s;
   }
 }

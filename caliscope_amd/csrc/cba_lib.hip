@@ -761,7 +761,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   }
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
-    hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + BLOCK - 1) / BLOCK, p->n_tiles), dim3(BLOCK), 0, p->stream, p->tp,
+    hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
                        p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
     {
       int rcs = allreduce_sum(p, p->Sacc, (size_t)ncp * ncp + ncp);  // reduced camera system: the one real exchange step
