@@ -679,13 +679,27 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// One step: every workgroup factors the NB x NB diagonal block itself (wave 0: one row per lane, held in
-// registers, column broadcasts by v_readlane — no barriers, no LDS traffic), parks L_kk in LDS, then solves
-// its share of the rows below:  L_ik = M_ik L_kk^-T  (one thread per row; `nrows` = n + 1 includes rhs^T).
+// 1/sqrt(d) to double precision: v_rsq_f64 seed + two Newton steps (an IEEE sqrt followed by an IEEE divide is
+// ~35 dependent FP64 instructions and sits on the serial pivot chain of the factorisation)
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
+// One step: every workgroup factors the NB x NB diagonal block itself, parks L_kk in LDS, then solves its share
+// of the rows below:  L_ik = M_ik L_kk^-T  (one thread per row; `nrows` = n + 1 includes rhs^T).
+// The diagonal block is factored by wave 0 alone, one row per lane in registers, right-looking: per pivot the
+// lanes publish their column entry through a 32-double LDS line and read the entries they need back as
+// broadcasts.  A single wave executes its DS instructions in order, so no barrier is needed inside the loop
+// (wave-scope fences keep the compiler from reordering).  A first version broadcast every entry with
+// v_readlane pairs: 6.2k instructions (1.7k readlane, 0.5k hazard s_nop), 13-19 us per block.
 __global__ void __launch_bounds__(BLOCK)
 k_potrf_panel(double* __restrict__ M, int n, int nrows, int k0, int* __restrict__ flags) {
   __shared__ double T[NB][NB + 1];
   __shared__ double Tinv[NB];
+  __shared__ double Lcol[2][NB];
   const int nb = min(NB, n - k0);
   if (threadIdx.x < WAVE) {
     const int lane = threadIdx.x;
@@ -698,12 +712,17 @@ k_potrf_panel(double* __restrict__ M, int n, int nrows, int k0, int* __restrict_
     for (int j = 0; j < NB; ++j) {
       double d = readlane_f64(row[j], j);
       if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
-      const double inv = 1.0 / sqrt(d);
+      const double inv = fast_rsqrt(d);
       const double lrj = (lane == j) ? d * inv : row[j] * inv;
       row[j] = lrj;
+      if (lane < NB) Lcol[j & 1][lane] = lrj;   // double-buffered line
       if (lane == j) Tinv[j] = inv;
+      // wave-scope ordering only: DS instructions of one wave complete in order, the fences just pin the compiler
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int c = j + 1; c < NB; ++c) row[c] -= lrj * readlane_f64(lrj, c);
+      for (int c = j + 1; c < NB; ++c) row[c] -= lrj * Lcol[j & 1][c];
     }
     if (bad && lane == 0) flags[2] = 1;
     if (lane < NB) {

@@ -146,7 +146,7 @@ def test_step_parity(name):
     hip.accept(); ora.accept()
     lh, lo = hip.linearize(), ora.linearize()  # second linearisation exercises the monotone-max scale rule
     assert abs(lh.gh_sq - lo.gh_sq) <= max(1e-7, stol) * lo.gh_sq and abs(lh.jg_sq - lo.jg_sq) <= max(1e-7, stol) * lo.jg_sq
-    assert _rel(hip.get_vector(4), ora.scale_inv) < 1e-6  # the two accepted points differ by the 1e-8 step tolerance above
+    assert _rel(hip.get_vector(4), ora.scale_inv) < (1e-6 if loss == "linear" else 1e-4)  # accepted points differ by the step tolerance
     hip.close()
 
 
