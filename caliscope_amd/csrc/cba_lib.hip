@@ -170,17 +170,17 @@ static int sync_scalars(cba_problem* p, int n_scal) {
 
 // in-place sum / max over the ranks of a sharded solve, enqueued on the engine's stream (no-op for world 1)
 static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
-  if (p->world <= 1) return CBA_OK;
+  if (!p->comm) return CBA_OK;
   NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, p->comm, p->stream));
   return CBA_OK;
 }
 static int allreduce_max(cba_problem* p, double* buf, size_t count) {
-  if (p->world <= 1) return CBA_OK;
+  if (!p->comm) return CBA_OK;
   NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclMax, p->comm, p->stream));
   return CBA_OK;
 }
 static int allreduce_flags(cba_problem* p) {
-  if (p->world <= 1) return CBA_OK;
+  if (!p->comm) return CBA_OK;
   NCCLCHK(ncclAllReduce(p->flags, p->flags, 4, ncclInt, ncclMax, p->comm, p->stream));
   return CBA_OK;
 }
@@ -937,7 +937,11 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
   if (p->comm) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
   HIPCHK(hipSetDevice(p->device));
   p->rank = rank; p->world = world;
-  if (world == 1) return CBA_OK;
+  // A one-rank communicator is pointless in production but exercises every RCCL call site on a single GPU
+  // (tests set CBA_FORCE_COMM=1); without it world == 1 stays collective-free.
+  const char* force = std::getenv("CBA_FORCE_COMM");
+  const bool forced = force && force[0] == '1';
+  if (world == 1 && !forced) return CBA_OK;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   NCCLCHK(ncclCommInitRank(&p->comm, world, id, rank));
