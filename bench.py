@@ -115,16 +115,22 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     info = eng.info()
     eng.begin(x0)
     run_iterations(eng, max(warmup, 1), solve_kw)
-    if timers:
-        eng.enable_timers(True)
-        eng.reset_timers()
+    # timed region: exactly `steps` iterations, barrier + device sync on both sides, max over ranks
     control.barrier()
     t0 = time.perf_counter()
     solves, last = run_iterations(eng, steps, solve_kw)  # every engine call ends with a stream synchronize
     control.barrier()
     elapsed = control.allreduce_max(time.perf_counter() - t0)
-    tm = eng.timers() if timers else {}
-    eng.enable_timers(False)
+    # instrumented repeat of the same `steps` iterations: HIP events around every kernel family on the engine's
+    # stream.  Kept out of the region above because recording ~40 event pairs per iteration costs 6 % (cfg4) to
+    # 50 % (cfg2) of the wall time, which would understate `value`.
+    tm = {}
+    if timers:
+        eng.enable_timers(True)
+        eng.reset_timers()
+        run_iterations(eng, steps, solve_kw)
+        tm = eng.timers()
+        eng.enable_timers(False)
     # untimed: full solve for the accuracy figure (squared pixel errors summed over all shards)
     full = trf_solve(eng, None, **solve_kw)
 
@@ -146,6 +152,22 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     }
 
 
+PMC_KERNEL = {"schur": "k_schur_tile", "build": "k_build", "jv": "k_jv", "backsub": "k_backsub", "cost": "k_cost<false>"}
+
+
+def pmc_traffic(workload, family):
+    """HBM bytes per launch of `family`'s kernel from the committed rocprofv3 PMC summary of this workload
+    (profiles/pmc_<workload>.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes); None if absent."""
+    path = ROOT / "profiles" / f"pmc_{workload}.json"
+    if not path.exists() or family not in PMC_KERNEL:
+        return None
+    rows = json.loads(path.read_text())
+    for name, row in rows.items():
+        if name.startswith(PMC_KERNEL[family]):
+            return round(row["hbm_bytes"])
+    return None
+
+
 def roofline_from(m):
     tm = m["timers"]
     if not tm:
@@ -163,7 +185,9 @@ def roofline_from(m):
              for k, v in tm.items() if v[1] > 0}
     return {
         "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg[dom],
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(m["name"], dom), "alg_bytes_per_launch": alg[dom],
+        "note": "k_schur is LDS-atomic/FP64-bound, not HBM-bound (DESIGN.md 4-5); durations from HIP events on the engine stream in an "
+                "instrumented repeat of the timed steps; traffic from profiles/pmc_*.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)",
         "avg_launch_us": round(avg_s * 1e6, 2), "kernels": table,
     }
 

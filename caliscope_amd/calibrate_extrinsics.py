@@ -1,0 +1,119 @@
+"""The solver stages of the reference's extrinsic-calibration use case, on the MI355X engine.
+
+``calibrate_extrinsics`` (reference ``core/calibrate_extrinsics.py:44-261``) is a nine-stage pipeline; stages
+1-4 (blind intrinsics, pairwise PnP / essential-matrix bootstrap, static-marker guard) need OpenCV and are
+upstream of the hot path.  Stages 5-9 — the part that calls the solver three times with a filter in between —
+are mirrored here one to one, on a volume that is already bootstrapped:
+
+  5  ``optimize(refine_intrinsics=False)``                          linear loss, reach the basin        (:206)
+     depth-ratio gate: refine intrinsics only if every camera sees p95(z)/p5(z) >= 2.0                  (:215-226)
+  6  ``optimize(refine=effective, loss="soft_l1", f_scale=1px, max_nfev=2000, ftol=1e-4, strict=False)`` (:230-238)
+  7  ``filter_by_percentile_error(filter_percentile)``              per-camera, worst 2.5 %             (:244)
+  8  ``optimize(refine_intrinsics=effective)``                      linear loss on the clean data       (:250)
+  9  ``CalibrationRun``                                             intrinsic estimates vs anchors      (:255-316)
+
+Cancellation is checked between stages only, as in the reference (``InterruptedError``); progress percentages
+are the reference's (40, 55, 75, 90, 100).
+"""
+
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from typing import Callable
+
+import numpy as np
+
+from caliscope_amd.bundle_parameterization import IntrinsicEstimate
+from caliscope_amd.capture_volume import CaptureVolume
+from caliscope_amd.point_data import STATIC_SYNC_INDEX
+
+logger = logging.getLogger(__name__)
+
+MIN_DEPTH_RATIO_FOR_INTRINSIC_REFINEMENT = 2.0  # reference calibrate_extrinsics.py:32
+
+
+@dataclass(frozen=True)
+class CalibrationRun:
+    capture_volume: CaptureVolume
+    intrinsic_estimates: tuple[IntrinsicEstimate, ...]
+    synthesized_cam_ids: frozenset = frozenset()
+    dropped_static_markers: tuple = ()
+    intrinsic_refinement_gated: bool = False
+
+
+def compute_depth_ratios(capture_volume: CaptureVolume) -> dict[int, float]:
+    """Per camera p95(z)/p5(z) of the moving world points in that camera's frame (reference
+    ``core/scale_accuracy.py:210-234``); NaN for a camera with fewer than two positive depths."""
+    world = capture_volume.world_points._df
+    moving = world[world["sync_index"] != STATIC_SYNC_INDEX]
+    cams = capture_volume.camera_array.posed_cameras
+    if moving.empty:
+        return {cam_id: float("nan") for cam_id in cams}
+    pts = moving[["x_coord", "y_coord", "z_coord"]].to_numpy()
+    out = {}
+    for cam_id, cam in cams.items():
+        z = pts @ np.asarray(cam.rotation)[2] + float(np.asarray(cam.translation).ravel()[2])
+        z = z[z > 0]
+        out[cam_id] = float(np.percentile(z, 95) / np.percentile(z, 5)) if z.size >= 2 else float("nan")
+    return out
+
+
+def refine_calibration(
+    capture_volume: CaptureVolume,
+    *,
+    refine_intrinsics: bool = True,
+    filter_percentile: float = 2.5,
+    cancellation_token=None,
+    progress: Callable[[int, str], None] | None = None,
+    _engine_factory=None,
+) -> CalibrationRun:
+    """Stages 5-9 of ``calibrate_extrinsics`` on a bootstrapped volume."""
+
+    def check_cancelled():
+        if cancellation_token is not None and getattr(cancellation_token, "is_cancelled", False):
+            raise InterruptedError("Extrinsic calibration cancelled")
+
+    def report(pct, msg):
+        if progress is not None:
+            progress(pct, msg)
+
+    anchors = {}
+    for cam_id, cam in capture_volume.camera_array.posed_cameras.items():
+        if cam.matrix is not None and cam.distortions is not None and not cam.fisheye:
+            d = np.asarray(cam.distortions).ravel()
+            anchors[cam_id] = (float(cam.matrix[0, 0]), float(d[0]), float(d[1]))
+
+    kw = {} if _engine_factory is None else {"_engine_factory": _engine_factory}
+    check_cancelled()
+    report(40, "Optimizing")
+    cv = capture_volume.optimize(refine_intrinsics=False, **kw)
+    check_cancelled()
+
+    ratios = compute_depth_ratios(cv)
+    effective = bool(refine_intrinsics and ratios and all(r >= MIN_DEPTH_RATIO_FOR_INTRINSIC_REFINEMENT for r in ratios.values()))
+    gated = bool(refine_intrinsics and not effective)
+    if gated:
+        logger.warning(f"Intrinsic refinement requested but gated off (need every camera >= "
+                       f"{MIN_DEPTH_RATIO_FOR_INTRINSIC_REFINEMENT}). Per-camera depth ratios: {ratios}")
+
+    report(55, "Robust refinement")
+    cv = cv.optimize(refine_intrinsics=effective, loss="soft_l1", f_scale=cv.pixel_f_scale(px=1.0), max_nfev=2000,
+                     ftol=1e-4, strict=False, **kw)
+    check_cancelled()
+
+    report(75, "Filtering outliers")
+    cv = cv.filter_by_percentile_error(filter_percentile, **kw)
+    check_cancelled()
+
+    report(90, "Re-optimizing")
+    cv = cv.optimize(refine_intrinsics=effective, **kw)
+
+    report(100, "Optimization complete")
+    estimates = []
+    for cam_id, cam in cv.camera_array.posed_cameras.items():
+        if cam_id in anchors and cam.matrix is not None and cam.distortions is not None:
+            f0, k10, k20 = anchors[cam_id]
+            d = np.asarray(cam.distortions).ravel()
+            estimates.append(IntrinsicEstimate(cam_id, float(cam.matrix[0, 0]), float(d[0]), float(d[1]), f0, k10, k20))
+    return CalibrationRun(cv, tuple(estimates), intrinsic_refinement_gated=gated)

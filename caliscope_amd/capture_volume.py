@@ -245,22 +245,63 @@ class CaptureVolume:
     def reprojection_report(self) -> ReprojectionReport:
         return self.compute_reprojection_report()
 
-    def filter_by_percentile_error(self, percentile: float, _engine_factory=None) -> "CaptureVolume":
-        """Drop the worst ``percentile`` percent of matched observations by pixel error (global threshold),
-        then drop world points left with fewer than two views; optimisation status is cleared."""
-        if not 0 < percentile < 100:
-            raise ValueError("percentile must be in (0, 100)")
-        report = self.compute_reprojection_report(_engine_factory)
+    # -- outlier filtering between solver passes (reference capture_volume.py:607-753) ------------------
+    def _filter_by_reprojection_thresholds(self, thresholds: dict, min_per_camera: int, _engine_factory=None) -> "CaptureVolume":
+        """Keep observations whose pixel error is <= their camera's threshold, but never fewer than
+        ``min_per_camera`` per camera (the best ones are kept); world points left without any observation
+        are pruned; the optimisation status is cleared."""
+        report = self.compute_reprojection_report(_engine_factory) if _engine_factory else self.reprojection_report
+        raw = report.raw_errors
+        err = raw["euclidean_error"].to_numpy()
+        cam = raw["cam_id"].to_numpy()
+        keep = err <= raw["cam_id"].map(thresholds).to_numpy(dtype=np.float64)
+        for cam_id in np.unique(cam):
+            idx = np.flatnonzero(cam == cam_id)
+            n_keep = int(keep[idx].sum())
+            if n_keep < min_per_camera and n_keep < idx.size:
+                n_needed = min(min_per_camera, idx.size) - n_keep
+                dropped = np.sort(err[idx][~keep[idx]])
+                if dropped.size >= n_needed:
+                    keep[idx] = err[idx] <= dropped[n_needed - 1]
         mask, *_ = self._matched_arrays()
-        e = report.raw_errors["euclidean_error"].to_numpy()
-        thr = np.percentile(e, 100.0 - percentile)
-        keep_rows = np.ones(len(mask), dtype=bool)
-        keep_rows[np.flatnonzero(mask)[e > thr]] = False
-        img_df = self.image_points._df[keep_rows]
+        keep_rows = np.zeros(len(mask), dtype=bool)  # like the reference's inner merge: unmatched rows go too
+        keep_rows[np.flatnonzero(mask)[keep]] = True
+        img_df = self.image_points._df[keep_rows].reset_index(drop=True)
         obj = self.img_to_obj_map[keep_rows]
-        views = np.bincount(obj[obj >= 0], minlength=len(self.world_points))
-        world_df = self.world_points._df[views >= 2].reset_index(drop=True)
-        return CaptureVolume(self.camera_array, ImagePoints(img_df.reset_index(drop=True)), WorldPoints(world_df), self.constraints)
+        seen = np.zeros(len(self.world_points), dtype=bool)
+        seen[obj[obj >= 0]] = True
+        world_df = self.world_points._df[seen].reset_index(drop=True)
+        return CaptureVolume(self.camera_array, ImagePoints(img_df), WorldPoints(world_df), self.constraints)
+
+    def filter_by_percentile_error(self, percentile: float, scope: str = "per_camera", min_per_camera: int = 10,
+                                   _engine_factory=None) -> "CaptureVolume":
+        """Remove the worst ``percentile`` percent of observations by reprojection error
+        (``scope``: "per_camera" thresholds, the reference's default, or one "overall" threshold)."""
+        if not (0 < percentile <= 100):
+            raise ValueError(f"percentile must be between 0 and 100, got {percentile}")
+        if min_per_camera < 1:
+            raise ValueError(f"min_per_camera must be >= 1, got {min_per_camera}")
+        if scope not in ("per_camera", "overall"):
+            raise ValueError(f"scope must be 'per_camera' or 'overall', got {scope}")
+        report = self.compute_reprojection_report(_engine_factory) if _engine_factory else self.reprojection_report
+        raw = report.raw_errors
+        keep_percentile = 100 - percentile
+        if scope == "per_camera":
+            thresholds = {}
+            for cam_id in self.camera_array.posed_cameras:
+                e = raw.loc[raw["cam_id"] == cam_id, "euclidean_error"]
+                thresholds[cam_id] = float(np.percentile(e, keep_percentile)) if len(e) else float(np.inf)
+        else:
+            thr = float(np.percentile(raw["euclidean_error"], keep_percentile))
+            thresholds = {cam_id: thr for cam_id in self.camera_array.posed_cameras}
+        return self._filter_by_reprojection_thresholds(thresholds, min_per_camera, _engine_factory)
+
+    def filter_by_absolute_error(self, max_pixels: float, min_per_camera: int = 10, _engine_factory=None) -> "CaptureVolume":
+        """Remove observations with a reprojection error above ``max_pixels`` (reference :687-707)."""
+        if max_pixels <= 0:
+            raise ValueError(f"max_pixels must be positive, got {max_pixels}")
+        thresholds = {cam_id: float(max_pixels) for cam_id in self.camera_array.posed_cameras}
+        return self._filter_by_reprojection_thresholds(thresholds, min_per_camera, _engine_factory)
 
     @classmethod
     def from_arrays(cls, camera_array: CameraArray, camera_ids, image_coords, obj_indices, points_xyz) -> "CaptureVolume":
