@@ -216,6 +216,11 @@ def cpu_baseline(budget_s=25.0):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries underneath (RCCL prints a version banner when a
+    # communicator is created, HIP/amdgpu warnings) write to fd 1 directly, so everything except the final
+    # line is sent to stderr at the file-descriptor level.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -300,7 +305,9 @@ def main():
     if also:
         out["also"] = also
     if rank == 0:
-        print(json.dumps(out, default=lambda o: int(o) if isinstance(o, np.integer) else float(o)), flush=True)
+        line = json.dumps(out, default=lambda o: int(o) if isinstance(o, np.integer) else float(o))
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
     if control is not None:
         import torch.distributed as dist
 

@@ -326,3 +326,19 @@ def test_rccl_call_sites_with_a_one_rank_communicator(monkeypatch):
     pos, ang, _ = aligned_difference(par, got.x, ref.x)
     assert pos < 1e-8 and ang < 1e-8
     assert np.all(np.isfinite(r))
+
+
+def test_stage_driver_on_device():
+    """calibrate_extrinsics stages 5-9 (optimize -> gate -> soft_l1 -> per-camera 2.5 % filter -> optimize) on the HIP engine."""
+    from caliscope_amd.calibrate_extrinsics import refine_calibration
+    from caliscope_amd.capture_volume import CaptureVolume
+
+    sc = make_scene(n_cams=8, n_points=600, n_obs=4800, outliers=0.01)
+    cv = CaptureVolume.from_arrays(sc.cameras_init, sc.camera_indices, sc.image_coords, sc.obj_indices, sc.points_init)
+    seen = []
+    run = refine_calibration(cv, progress=lambda p, m: seen.append(p))
+    assert seen == [40, 55, 75, 90, 100]
+    out = run.capture_volume
+    assert out.optimization_status.converged and run.intrinsic_refinement_gated
+    assert out.reprojection_report.overall_rmse < 1.0 < cv.reprojection_report.overall_rmse
+    assert len(out.image_points) < len(cv.image_points)
