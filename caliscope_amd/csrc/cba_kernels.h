@@ -439,7 +439,8 @@ struct TilePlan {
   int g;                         // cameras per group (max)
   int cs;                        // column stride of one camera block inside the LDS tile (odd: nc | 1)
   int ld;                        // leading dimension of the LDS tile (odd)
-  int tile_elems;                // g nc ld + g nc : width of one workgroup's partial
+  int tile_elems;                // width of one workgroup's partial (LDS-tile kernel: g nc ld + g nc)
+  const unsigned short* blk_off; // register kernel: [n_tile_chunks][g*g + 1] per-block offsets into the chunk's pairs
 };
 // LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
 // an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
@@ -601,6 +602,245 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   double* dst = partial + (long)blockIdx.x * tp.tile_elems;
   for (int i = threadIdx.x; i < gn * ld; i += SCHUR_BLOCK) dst[i] = sh_S[i];
   for (int i = threadIdx.x; i < gn; i += SCHUR_BLOCK) dst[gn * ld + i] = sh_b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Schur pass, register-accumulating variant (6-parameter cameras).
+//
+// The LDS-tile kernel above is bound by LDS throughput: 36 ds_add_f64 per pair at ~28 cycles per
+// wave-instruction (tools/lds_pattern_bench.hip), whatever the occupancy.  But a chunk of 256 observations
+// sends only ~5 pairs to each of the g^2 = 256 camera-pair blocks of a tile, so here every THREAD owns one
+// block for the whole kernel: the plan lists each chunk's pairs sorted by block, a thread walks the few
+// pairs of its block and accumulates A_i^T (Z_i Z_j^T) A_j in 36 registers — no atomics, no S tile in LDS,
+// hence ~55 KB of LDS per workgroup and three resident workgroups per CU whose block-recomputation and pair
+// phases overlap.  The (i, i) terms, which would all land on the g diagonal blocks, are added during the
+// recomputation with LDS atomics into a small g x 36 array instead.  Results leave through per-workgroup
+// partials reduced in fixed order (k_reg_reduce).
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_schur_reg(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
+            const int* __restrict__ cam_off, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
+            const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ partial,
+            int* __restrict__ flags, int debug_skip) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int g = tp.g;
+  const int gn = g * NC;
+  double* sh_tab = sh;                          // [2g][CAMTAB_LDS]
+  double* sh_A = sh_tab + 2 * g * CAMTAB_LDS;   // [2*NC][CHUNK]
+  double* sh_Z = sh_A + 2 * NC * CHUNK;         // [6][CHUNK]
+  double* sh_b = sh_Z + 6 * CHUNK;              // [gn]
+  constexpr int TRI = NC * (NC + 1) / 2;
+  double* sh_D = sh_b + gn;                     // [g][TRI]  upper triangle of sum_i A_i^T (Z_i Z_i^T) A_i per camera
+  int* sh_loff = reinterpret_cast<int*>(sh_D + g * TRI);  // [2g]
+
+  const int t = tp.wg_tile[blockIdx.x];
+  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
+  const bool diag = (ga == gb);
+  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+  const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
+
+  for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += BLOCK)
+    sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)ca0 * CAMTAB_DOUBLES + i];
+  if (!diag)
+    for (int i = threadIdx.x; i < nb * CAMTAB_DOUBLES; i += BLOCK)
+      sh_tab[(g + i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)cb0 * CAMTAB_DOUBLES + i];
+  for (int i = threadIdx.x; i < 2 * g; i += BLOCK) {
+    int off = 0;
+    if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }
+    else if (i - g < nb) off = cam_off[cb0 + i - g] - pb0;
+    sh_loff[i] = off;
+  }
+  for (int i = threadIdx.x; i < gn + g * TRI; i += BLOCK) sh_b[i] = 0.0;  // sh_b and sh_D are contiguous
+  __syncthreads();
+
+  const double* px = xvec + lay.ncp_pad;
+  const double* gp = gvec + lay.ncp_pad;
+  const double* dp = sinv + lay.ncp_pad;
+  const int nblk = g * g;
+  const bool owner = (int)threadIdx.x < nblk;  // thread <-> block (li, lj) = (tid / g, tid % g)
+  double acc[NC][NC];
+#pragma unroll
+  for (int r = 0; r < NC; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+  const bool own_diag_block = diag && owner && (threadIdx.x / g == threadIdx.x % g);
+  bool fail = false;
+  const int ch_end = tp.tile_chunk_begin[t + 1];
+  for (int ch = tp.tile_chunk_begin[t] + tp.wg_rank[blockIdx.x]; ch < ch_end; ch += tp.tile_nwg[t]) {
+    const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
+    const int i = o0 + threadIdx.x;
+    if (i < o1) {
+      double Ai[2][MAX_NC], Zi[2][3];
+      const int pt = tp.pt[i];
+      const int cl_i = tp.camloc[i];
+      const CamTab& ct = cam_at(sh_tab, cl_i);
+      double e[2], B[2][3];
+      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], tp.u[i], tp.v[i], loss, f_scale, e, Ai, B);
+      const int np_i = (int)ct.nparams;
+      double Vd[6], L[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
+      const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
+      Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+      if (!chol3(Vd, L)) {
+        fail = true;
+        L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
+      }
+      chol3_fwd(L, B[0], Zi[0]);
+      chol3_fwd(L, B[1], Zi[1]);
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k >= np_i) { Ai[0][k] = 0.0; Ai[1][k] = 0.0; }
+      if (diag && debug_skip != 2) {  // every observation lives in exactly one diagonal tile: rhs term and its own (i, i) block
+        const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
+        double y[3];
+        chol3_fwd(L, gpt, y);
+        const double zy0 = Zi[0][0] * y[0] + Zi[0][1] * y[1] + Zi[0][2] * y[2];
+        const double zy1 = Zi[1][0] * y[0] + Zi[1][1] * y[1] + Zi[1][2] * y[2];
+        double* bc = sh_b + sh_loff[cl_i];
+        const double m00 = Zi[0][0] * Zi[0][0] + Zi[0][1] * Zi[0][1] + Zi[0][2] * Zi[0][2];
+        const double m01 = Zi[0][0] * Zi[1][0] + Zi[0][1] * Zi[1][1] + Zi[0][2] * Zi[1][2];
+        const double m11 = Zi[1][0] * Zi[1][0] + Zi[1][1] * Zi[1][1] + Zi[1][2] * Zi[1][2];
+        double* Dc = sh_D + cl_i * TRI;
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+          if (r < np_i) lds_add(&bc[r], Ai[0][r] * zy0 + Ai[1][r] * zy1);
+          const double t0 = Ai[0][r] * m00 + Ai[1][r] * m01;
+          const double t1 = Ai[0][r] * m01 + Ai[1][r] * m11;
+#pragma unroll
+          for (int c = r; c < NC; ++c)
+            if (c < np_i) lds_add(&Dc[UPack<NC>::idx(r, c)], t0 * Ai[0][c] + t1 * Ai[1][c]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        sh_A[k * CHUNK + threadIdx.x] = Ai[0][k];
+        sh_A[(NC + k) * CHUNK + threadIdx.x] = Ai[1][k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sh_Z[k * CHUNK + threadIdx.x] = Zi[0][k];
+        sh_Z[(3 + k) * CHUNK + threadIdx.x] = Zi[1][k];
+      }
+    }
+    __syncthreads();
+    if (owner && debug_skip != 1) {
+      const unsigned short* bo = tp.blk_off + (long)ch * (nblk + 1) + threadIdx.x;
+      const int qb = tp.pair_start[ch];
+      for (int q = qb + bo[0], qe = qb + bo[1]; q < qe; ++q) {
+        const unsigned pr = tp.pairs[q];
+        const int i_loc = pr & 255u, j_loc = pr >> 8;
+        double Zi[2][3], Zj[2][3], Ai[2][NC], Aj[2][NC];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          Zi[0][k] = sh_Z[k * CHUNK + i_loc]; Zi[1][k] = sh_Z[(3 + k) * CHUNK + i_loc];
+          Zj[0][k] = sh_Z[k * CHUNK + j_loc]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j_loc];
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          Ai[0][k] = sh_A[k * CHUNK + i_loc]; Ai[1][k] = sh_A[(NC + k) * CHUNK + i_loc];
+          Aj[0][k] = sh_A[k * CHUNK + j_loc]; Aj[1][k] = sh_A[(NC + k) * CHUNK + j_loc];
+        }
+        const double m00 = Zi[0][0] * Zj[0][0] + Zi[0][1] * Zj[0][1] + Zi[0][2] * Zj[0][2];
+        const double m01 = Zi[0][0] * Zj[1][0] + Zi[0][1] * Zj[1][1] + Zi[0][2] * Zj[1][2];
+        const double m10 = Zi[1][0] * Zj[0][0] + Zi[1][1] * Zj[0][1] + Zi[1][2] * Zj[0][2];
+        const double m11 = Zi[1][0] * Zj[1][0] + Zi[1][1] * Zj[1][1] + Zi[1][2] * Zj[1][2];
+        if (!own_diag_block) {
+#pragma unroll
+          for (int r = 0; r < NC; ++r) {
+            const double t0 = Ai[0][r] * m00 + Ai[1][r] * m10;
+            const double t1 = Ai[0][r] * m01 + Ai[1][r] * m11;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[r][c] += t0 * Aj[0][c] + t1 * Aj[1][c];
+          }
+        } else {
+          // two different observations of ONE camera (duplicate rows): T + T^T lands on the diagonal block
+#pragma unroll
+          for (int r = 0; r < NC; ++r) {
+            const double t0 = Ai[0][r] * m00 + Ai[1][r] * m10;
+            const double t1 = Ai[0][r] * m01 + Ai[1][r] * m11;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const double val = t0 * Aj[0][c] + t1 * Aj[1][c];
+              acc[r][c] += val;
+              acc[c][r] += val;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (fail) flags[1] = 1;
+  // partial of this workgroup: [BLOCK threads][NC*NC] | sh_D [g][TRI] | sh_b [gn]
+  double* dst = partial + (long)blockIdx.x * tp.tile_elems;
+#pragma unroll
+  for (int r = 0; r < NC; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dst[(long)threadIdx.x * NC * NC + r * NC + c] = acc[r][c];
+  double* dD = dst + (long)BLOCK * NC * NC;
+  for (int i = threadIdx.x; i < g * TRI; i += BLOCK) dD[i] = sh_D[i];
+  for (int i = threadIdx.x; i < gn; i += BLOCK) dD[g * TRI + i] = sh_b[i];
+}
+
+// Reduce the partials of k_schur_reg over the workgroups of each tile and scatter into Sacc / bacc.
+// blockDim = (64, 4) as k_tile_reduce.
+__global__ void __launch_bounds__(256)
+k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
+             const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
+             double* __restrict__ Sacc, double* __restrict__ bacc) {
+  __shared__ double sh[4][64];
+  const int t = blockIdx.y;
+  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
+  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+  const int pa0 = tp.group_par_begin[ga], npa = tp.group_par_begin[ga + 1] - pa0;
+  const int g = tp.g, bsz = NCt * NCt, tri = NCt * (NCt + 1) / 2;
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
+  double s0 = 0.0, s1 = 0.0;
+  if (e < tp.tile_elems) {
+    int w = w0 + threadIdx.y;
+    for (; w + 4 < w1; w += 8) {
+      s0 += partial[(long)w * tp.tile_elems + e];
+      s1 += partial[(long)(w + 4) * tp.tile_elems + e];
+    }
+    if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
+  }
+  sh[threadIdx.y][threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.y != 0 || e >= tp.tile_elems) return;
+  const double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  const int n_thread_part = BLOCK * bsz;
+  if (e < n_thread_part) {
+    const int beta = e / bsz, rc = e % bsz;
+    if (beta >= g * g) return;
+    const int li = beta / g, lj = beta % g, r = rc / NCt, c = rc % NCt;
+    if (li >= na || lj >= nb) return;
+    if (ga == gb && lj < li) return;               // block lower triangle of a diagonal tile: not used
+    const int cam_i = ca0 + li, cam_j = cb0 + lj;
+    if (r >= cam_np[cam_i] || c >= cam_np[cam_j]) return;
+    if (ga == gb && li == lj) return;               // diagonal blocks are written from the D part below
+    Sacc[(long)(cam_off[cam_i] + r) * ncp + cam_off[cam_j] + c] = s;
+  } else if (e < n_thread_part + g * tri) {
+    if (ga != gb) return;
+    const int q = e - n_thread_part;
+    const int li = q / tri;
+    int r = 0, rem = q % tri;  // unpack idx(r, c) = r*NC - r(r-1)/2 + (c - r)
+    while (rem >= NCt - r) { rem -= NCt - r; ++r; }
+    const int c = r + rem;
+    if (li >= na) return;
+    const int cam = ca0 + li;
+    if (r >= cam_np[cam] || c >= cam_np[cam]) return;
+    // (i, i) terms (upper triangle accumulated) + duplicate-camera pairs collected by the owner of block (li, li)
+    double dup = 0.0;
+    const long e2 = (long)(li * g + li) * bsz + r * NCt + c;
+    for (int w = w0; w < w1; ++w) dup += partial[(long)w * tp.tile_elems + e2];
+    Sacc[(long)(cam_off[cam] + r) * ncp + cam_off[cam] + c] = s + dup;
+  } else if (ga == gb && e < n_thread_part + g * tri + npa) {
+    bacc[pa0 + (e - n_thread_part - g * tri)] = s;
+  }
 }
 
 // Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc, undoing the

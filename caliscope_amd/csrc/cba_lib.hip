@@ -61,6 +61,7 @@ struct cba_problem {
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   bool schur_lds = true;   // Sacc always lives in LDS tiles
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
+  bool schur_reg = false;  // register-accumulating Schur kernel (6-parameter cameras)
   long tile_stream_len = 0, n_pairs = 0;
   TilePlan tp{};
   int* tile_wg_begin = nullptr;
@@ -283,7 +284,12 @@ template <int NC> static size_t lds_schur_tile(int g) {
   const size_t gn = (size_t)g * NC;
   return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * tile_ld(g, NC)) * 8 + ((size_t)4 * g + CHUNK) * sizeof(int);
 }
+template <int NC> static size_t lds_schur_reg(int g) {
+  const size_t gn = (size_t)g * NC;
+  return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + (size_t)g * (NC * (NC + 1) / 2)) * 8 + (size_t)2 * g * sizeof(int);
+}
 constexpr size_t kSchurLdsBudget = 144 * 1024;
+constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
@@ -309,8 +315,31 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     std::vector<int> pt;
     std::vector<unsigned char> cl;
     std::vector<unsigned short> pairs;
+    std::vector<unsigned short> blk_off;       // register kernel: per chunk g*g+1 offsets of the block-sorted pairs
     std::vector<int> chunk_start, pair_start;  // local offsets, start with 0
     int open = 0;                              // start of the currently open chunk
+  };
+  const bool reg = p->schur_reg;
+  const int nblk = g * g;
+  // register kernel: the pairs of a chunk are sorted by camera-pair block (li * g + lj) and the (i, i) pairs are
+  // left out (they are accumulated during the block recomputation); blk_off gives every block its slice.
+  auto close_chunk_reg = [&](Stream& s) {
+    const size_t pb = (size_t)s.pair_start.back();
+    const size_t n = s.pairs.size() - pb;
+    std::vector<unsigned> cnt((size_t)nblk + 1, 0);
+    std::vector<unsigned short> key(n);
+    for (size_t q = 0; q < n; ++q) {
+      const unsigned pr = s.pairs[pb + q];
+      const int li = s.cl[s.open + (pr & 255u)], lj = s.cl[s.open + (pr >> 8)];
+      key[q] = (unsigned short)(li * g + (lj < g ? lj : lj - g));
+      cnt[key[q] + 1]++;
+    }
+    for (int b2 = 0; b2 < nblk; ++b2) cnt[b2 + 1] += cnt[b2];
+    for (int b2 = 0; b2 <= nblk; ++b2) s.blk_off.push_back((unsigned short)cnt[b2]);
+    std::vector<unsigned short> sorted(n);
+    std::vector<unsigned> cur(cnt.begin(), cnt.end() - 1);
+    for (size_t q = 0; q < n; ++q) sorted[cur[key[q]]++] = s.pairs[pb + q];
+    std::copy(sorted.begin(), sorted.end(), s.pairs.begin() + pb);
   };
   std::vector<Stream> st(nT);
   for (auto& s : st) { s.chunk_start.push_back(0); s.pair_start.push_back(0); }
@@ -335,6 +364,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         const int cnt = na + nb;
         int len = (int)s.pt.size();
         if (len - s.open + cnt > CHUNK) {
+          if (reg) close_chunk_reg(s);
           s.chunk_start.push_back(len); s.pair_start.push_back((int)s.pairs.size()); s.open = len;
         }
         const int base = len - s.open;  // chunk-local index of this point's first entry
@@ -348,7 +378,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         }
         // pairs (row observation i, column observation j), chunk-local, camera(i) <= camera(j)
         for (int i = 0; i < na; ++i) {
-          const int j0 = (b == a) ? i : na, j1 = (b == a) ? na : cnt;
+          const int j0 = (b == a) ? (reg ? i + 1 : i) : na, j1 = (b == a) ? na : cnt;
           for (int j = j0; j < j1; ++j) s.pairs.push_back((unsigned short)((base + i) | ((base + j) << 8)));
         }
       }
@@ -358,12 +388,16 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   std::vector<double> U, V;
   std::vector<int> PT, CS, PS, TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
-  std::vector<unsigned short> PR;
+  std::vector<unsigned short> PR, BO;
   CS.push_back(0); PS.push_back(0);
   for (int t = 0; t < nT; ++t) {
     Stream& s = st[t];
     const int base = (int)PT.size(), pbase = (int)PR.size();
-    if (!s.pt.empty()) { s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size()); }
+    if (!s.pt.empty()) {
+      if (reg) close_chunk_reg(s);
+      s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size());
+    }
+    BO.insert(BO.end(), s.blk_off.begin(), s.blk_off.end());
     TCB[t] = (int)CS.size() - 1;
     for (size_t c = 1; c < s.chunk_start.size(); ++c) { CS.push_back(base + s.chunk_start[c]); PS.push_back(pbase + s.pair_start[c]); }
     U.insert(U.end(), s.u.begin(), s.u.end()); V.insert(V.end(), s.v.begin(), s.v.end());
@@ -417,18 +451,19 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   int *dpt = nullptr, *dcs = nullptr, *dtcb = nullptr, *dwt = nullptr, *dwr = nullptr, *dnwg = nullptr, *dta = nullptr, *dtb = nullptr,
       *dgc = nullptr, *dgp = nullptr;
   unsigned char* dcl = nullptr;
-  unsigned short* dpr = nullptr;
+  unsigned short *dpr = nullptr, *dbo = nullptr;
   int* dps = nullptr;
 #define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
   TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
-  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dtcb, TCB));
+  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dbo, BO)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dtcb, TCB));
   TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwr, wr)); TRYP(dev_upload(p, &dnwg, nwg)); TRYP(dev_upload(p, &dta, ta));
   TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
   TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
 #undef TRYP
   const int gn = g * p->nct;
   const int cs = tile_cs(p->nct), ld = tile_ld(g, p->nct);
-  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, cs, ld, gn * ld + gn};
+  const int elems = reg ? BLOCK * p->nct * p->nct + g * (p->nct * (p->nct + 1) / 2) + gn : gn * ld + gn;
+  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, cs, ld, elems, dbo};
   return CBA_OK;
 }
 
@@ -441,11 +476,15 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 1>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
   int gmax = 1;
-  while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
+  const char* force_tile = std::getenv("CBA_SCHUR");
+  p->schur_reg = (NC == 6) && !(force_tile && std::strcmp(force_tile, "lds") == 0);
+  if (p->schur_reg) gmax = std::min(p->C, kSchurRegMaxGroup);
+  else while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
   p->G = (p->C + gmax - 1) / gmax;
   p->gsz = (p->C + p->G - 1) / p->G;
   p->n_tiles = p->G * (p->G + 1) / 2;
-  if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
+  if (p->schur_reg) { if ((rc = allow_lds(k_schur_reg<NC>, lds_schur_reg<NC>(p->gsz)))) return rc; }
+  else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_chol_backward, (size_t)p->ncp * 8))) return rc;
   return CBA_OK;
@@ -546,8 +585,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   {
-    const size_t tile_lds = (nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz);
-    const int resident = cus * std::max<int>(1, (int)((160 * 1024) / tile_lds));  // no partial last round
+    const size_t tile_lds = p->schur_reg ? lds_schur_reg<6>(p->gsz) : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
+    int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
+    if (p->schur_reg) per_cu = std::min(per_cu, 2);  // k_schur_reg<6>: ~220 VGPRs -> 2 waves per SIMD
+    const int resident = cus * per_cu;  // no partial last round
     TRY(build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus))));
   }
   const long w_build = (long)p->C * ustride;
@@ -571,7 +612,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 int cba_get_info(cba_problem* p, cba_info* o) {
   if (!p || !o) return fail(CBA_ERR_INVALID, "null argument");
   o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
-  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 1;
+  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_reg ? 0 : 1;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes;
   return CBA_OK;
@@ -756,13 +797,23 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_SCHUR);
-    hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
-                       p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
+    if constexpr (NC == 6) {
+      if (p->schur_reg)
+        hipLaunchKernelGGL((k_schur_reg<NC>), dim3(p->tile_grid), dim3(BLOCK), lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
+                           p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
+    }
+    if (!p->schur_reg)
+      hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
+                         p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
   }
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
-    hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
-                       p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
+    if (p->schur_reg)
+      hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
+                         p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
+    else
+      hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
+                         p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
     {
       int rcs = allreduce_sum(p, p->Sacc, (size_t)ncp * ncp + ncp);  // reduced camera system: the one real exchange step
       if (rcs) return rcs;
