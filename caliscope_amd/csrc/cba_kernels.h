@@ -428,10 +428,10 @@ struct TilePlan {
   const unsigned short* pairs;   // (i | j << 8): chunk-local indices of every observation pair to multiply
   const int* pair_start;         // [n_tile_chunks + 1] offsets into `pairs`
   const int* chunk_start;        // [n_tile_chunks + 1] offsets into the stream arrays
-  const int* tile_chunk_begin;   // [n_tiles + 1]
+  const int* wg_first;           // [grid] first chunk of the workgroup
+  const int* wg_end;             // [grid] end of the chunk range the workgroup strides through
   const int* wg_tile;            // [grid] tile of each workgroup
-  const int* wg_rank;            // [grid] rank of the workgroup inside its tile
-  const int* tile_nwg;           // [n_tiles]
+  const int* wg_stride;          // [grid] chunk stride (workgroups sharing the range)
   const int* tile_a;             // [n_tiles] group ids
   const int* tile_b;
   const int* group_cam_begin;    // [G + 1]
@@ -440,7 +440,8 @@ struct TilePlan {
   int cs;                        // column stride of one camera block inside the LDS tile (odd: nc | 1)
   int ld;                        // leading dimension of the LDS tile (odd)
   int tile_elems;                // width of one workgroup's partial (LDS-tile kernel: g nc ld + g nc)
-  const unsigned short* blk_off; // register kernel: [n_tile_chunks][g*g + 1] per-block offsets into the chunk's pairs
+  const unsigned short* blk_off; // register kernel: [n_tile_chunks][g*g + 1] per-thread offsets into the chunk's pairs
+  const int* obs;                // register kernel: stream entry -> observation (index into the T records)
 };
 // LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
 // an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
@@ -499,8 +500,8 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
   bool fail = false;
-  const int ch_end = tp.tile_chunk_begin[t + 1];
-  for (int ch = tp.tile_chunk_begin[t] + tp.wg_rank[blockIdx.x]; ch < ch_end; ch += tp.tile_nwg[t]) {
+  const int ch_end = tp.wg_end[blockIdx.x], ch_stride = tp.wg_stride[blockIdx.x];
+  for (int ch = tp.wg_first[blockIdx.x]; ch < ch_end; ch += ch_stride) {
     const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
     const int i = o0 + threadIdx.x;
     const bool active = threadIdx.x < CHUNK && i < o1;  // block recomputation: one thread per observation
@@ -605,202 +606,242 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Schur pass, register-accumulating variant (6-parameter cameras).
+// Schur pass, register-accumulating variant (6-parameter cameras): k_tprep + k_schur_reg.
 //
-// The LDS-tile kernel above is bound by LDS throughput: 36 ds_add_f64 per pair at ~28 cycles per
-// wave-instruction (tools/lds_pattern_bench.hip), whatever the occupancy.  But a chunk of 256 observations
-// sends only ~5 pairs to each of the g^2 = 256 camera-pair blocks of a tile, so here every THREAD owns one
-// block for the whole kernel: the plan lists each chunk's pairs sorted by block, a thread walks the few
-// pairs of its block and accumulates A_i^T (Z_i Z_j^T) A_j in 36 registers — no atomics, no S tile in LDS,
-// hence ~55 KB of LDS per workgroup and three resident workgroups per CU whose block-recomputation and pair
-// phases overlap.  The (i, i) terms, which would all land on the g diagonal blocks, are added during the
-// recomputation with LDS atomics into a small g x 36 array instead.  Results leave through per-workgroup
-// partials reduced in fixed order (k_reg_reduce).
+// With Z_i = B_i L^-T (L L^T = V + lam D^2 of the point) the pair term A_i^T (Z_i Z_j^T) A_j is T_i T_j^T for the
+// per-observation NC x 3 matrix T_i = A_i^T Z_i, and the rhs term is T_i y with y = L^-1 g_point.
+//
+// k_tprep evaluates every observation ONCE (the LDS-tile kernel re-linearises an observation in each of the
+// G tiles it takes part in), stores T_i as a 16-byte aligned record of REC doubles in HBM (144 B per
+// observation) and reduces the rhs per camera (LDS atomics, per-workgroup partials, k_reduce_rows).
+template <int NC> struct SchurRec { static constexpr int REC = (3 * NC + 1) & ~1; };
+constexpr int PAIRCAP = 2048;  // pairs of one chunk, staged in LDS (the plan closes a chunk before it overflows)
+
 template <int NC>
 __global__ void __launch_bounds__(BLOCK)
-k_schur_reg(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
-            const int* __restrict__ cam_off, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
-            const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ partial,
-            int* __restrict__ flags, int debug_skip) {
+k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+        const int* __restrict__ obs_pt, const int* __restrict__ chunk_start, int n_chunks,
+        const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, const int* __restrict__ cam_off,
+        int n_cams, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
+        const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
+        double* __restrict__ partial_b, int* __restrict__ flags) {
+  constexpr int REC = SchurRec<NC>::REC;
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int g = tp.g;
-  const int gn = g * NC;
-  double* sh_tab = sh;                          // [2g][CAMTAB_LDS]
-  double* sh_A = sh_tab + 2 * g * CAMTAB_LDS;   // [2*NC][CHUNK]
-  double* sh_Z = sh_A + 2 * NC * CHUNK;         // [6][CHUNK]
-  double* sh_b = sh_Z + 6 * CHUNK;              // [gn]
-  constexpr int TRI = NC * (NC + 1) / 2;
-  double* sh_D = sh_b + gn;                     // [g][TRI]  upper triangle of sum_i A_i^T (Z_i Z_i^T) A_i per camera
-  int* sh_loff = reinterpret_cast<int*>(sh_D + g * TRI);  // [2g]
-
-  const int t = tp.wg_tile[blockIdx.x];
-  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
-  const bool diag = (ga == gb);
-  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
-  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
-  const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
-
-  for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += BLOCK)
-    sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)ca0 * CAMTAB_DOUBLES + i];
-  if (!diag)
-    for (int i = threadIdx.x; i < nb * CAMTAB_DOUBLES; i += BLOCK)
-      sh_tab[(g + i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)cb0 * CAMTAB_DOUBLES + i];
-  for (int i = threadIdx.x; i < 2 * g; i += BLOCK) {
-    int off = 0;
-    if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }
-    else if (i - g < nb) off = cam_off[cb0 + i - g] - pb0;
-    sh_loff[i] = off;
-  }
-  for (int i = threadIdx.x; i < gn + g * TRI; i += BLOCK) sh_b[i] = 0.0;  // sh_b and sh_D are contiguous
+  double* sh_tab = sh;
+  double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad
+  stage_camtab(sh_tab, tab, n_cams);
+  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_b[i] = 0.0;
   __syncthreads();
-
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
-  const int nblk = g * g;
-  const bool owner = (int)threadIdx.x < nblk;  // thread <-> block (li, lj) = (tid / g, tid % g)
-  double acc[NC][NC];
+  bool fail = false;
+  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int i = chunk_start[ch] + threadIdx.x;
+    if (i >= chunk_start[ch + 1]) continue;
+    const int cam = obs_cam[i], pt = obs_pt[i];
+    const CamTab& ct = cam_at(sh_tab, cam);
+    double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
+    obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e, A, B);
+    const int np = (int)ct.nparams;
+    double Vd[6], L[6];
 #pragma unroll
-  for (int r = 0; r < NC; ++r)
+    for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
+    const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
+    Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+    if (!chol3(Vd, L)) {
+      fail = true;
+      L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
+    }
+    chol3_fwd(L, B[0], Z[0]);
+    chol3_fwd(L, B[1], Z[1]);
+    const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
+    double y[3];
+    chol3_fwd(L, gpt, y);
+    double rec[REC];
+    double* bc = sh_b + cam_off[cam];
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+      const bool live = r < np;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rec[3 * r + k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
+      if (live) lds_add(&bc[r], rec[3 * r] * y[0] + rec[3 * r + 1] * y[1] + rec[3 * r + 2] * y[2]);
+    }
+#pragma unroll
+    for (int k = 3 * NC; k < REC; ++k) rec[k] = 0.0;
+    double2* dst = reinterpret_cast<double2*>(Trec + (long)i * REC);
+#pragma unroll
+    for (int k = 0; k < REC / 2; ++k) dst[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+  }
+  if (fail) flags[1] = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) partial_b[(long)blockIdx.x * lay.ncp_pad + i] = sh_b[i];
+}
+
+// k_schur_reg: the LDS-tile kernel is bound by LDS throughput (36 ds_add_f64 per pair at ~28 cycles per
+// wave-instruction, tools/lds_pattern_bench.hip).  But a chunk of 256 observations sends only a few pairs to
+// each of the g^2 = 256 camera-pair blocks of a tile, so here every THREAD owns one block for the whole kernel:
+// the plan lists each chunk's pairs sorted by owner thread; the workgroup gathers the chunk's T records into LDS,
+// then a thread walks its few pairs and accumulates T_i T_j^T in 36 registers — no atomics, no S tile in LDS.
+// Records are read back with ds_read_b128 (REC/2 odd: the 16-byte slots of different observations spread over
+// all banks; b128 reads reach the LDS rate at this kernel's low occupancy, b64 reads do not).
+// In a diagonal tile only the blocks li < lj are real; the other g(g+1)/2 threads are "helpers": helper k serves
+// camera k mod na and receives a share of that camera's (i, i) items (and of its duplicate-row pairs, listed in
+// both orders).  The next chunk's records, pair list and slice bounds are fetched into registers while the
+// current chunk's pairs are multiplied.  Results leave through per-workgroup partials (k_reg_reduce).
+// SPLIT = 1: 256 threads, one whole block (NC x NC accumulators, ~230 VGPRs, two workgroups = 8 waves per CU).
+// SPLIT = 2: 512 threads, thread tid accumulates rows [h*NC/2, (h+1)*NC/2) of block tid % 256, h = tid / 256
+// (<= 128 VGPRs, 16 waves per CU).  Measured on cfg4: SPLIT = 2 is 15 % slower (every pair iteration's fixed cost -
+// pair decode, T_j reads - is paid twice), so SPLIT = 1 is what the library launches.
+template <int NC, int SPLIT>
+__global__ void __launch_bounds__(BLOCK * SPLIT, 2 * SPLIT)
+k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, int debug_skip) {
+  constexpr int REG_BLOCK = BLOCK * SPLIT;
+  constexpr int REC = SchurRec<NC>::REC;
+  constexpr int NP = REC / 2;                                   // 16-byte pieces per record
+  constexpr int NLD = (CHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;  // gather loads per thread
+  constexpr int NPV = PAIRCAP / REG_BLOCK;
+  constexpr int RH = (NC + SPLIT - 1) / SPLIT;                  // rows per thread
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_T = sh;                                            // [CHUNK][REC] (+ slack for the last partial load round)
+  unsigned short* sh_pairs = reinterpret_cast<unsigned short*>(sh_T + NLD * REG_BLOCK * 2);  // [PAIRCAP]
+
+  const int nblk = tp.g * tp.g;
+  const int blk = threadIdx.x % BLOCK, half = threadIdx.x / BLOCK;
+  const bool owner = blk < nblk;
+  const int r0 = half * RH;                                     // first row of this thread
+  double acc[RH][NC];
+#pragma unroll
+  for (int r = 0; r < RH; ++r)
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
-  const bool own_diag_block = diag && owner && (threadIdx.x / g == threadIdx.x % g);
-  bool fail = false;
-  const int ch_end = tp.tile_chunk_begin[t + 1];
-  for (int ch = tp.tile_chunk_begin[t] + tp.wg_rank[blockIdx.x]; ch < ch_end; ch += tp.tile_nwg[t]) {
-    const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
-    const int i = o0 + threadIdx.x;
-    if (i < o1) {
-      double Ai[2][MAX_NC], Zi[2][3];
-      const int pt = tp.pt[i];
-      const int cl_i = tp.camloc[i];
-      const CamTab& ct = cam_at(sh_tab, cl_i);
-      double e[2], B[2][3];
-      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], tp.u[i], tp.v[i], loss, f_scale, e, Ai, B);
-      const int np_i = (int)ct.nparams;
-      double Vd[6], L[6];
+
+  const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
+  double* dst = partial + (long)blockIdx.x * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
+  if (first >= ch_end) {  // more workgroups than chunks in this range
 #pragma unroll
-      for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
-      const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
-      Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
-      if (!chol3(Vd, L)) {
-        fail = true;
-        L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
-      }
-      chol3_fwd(L, B[0], Zi[0]);
-      chol3_fwd(L, B[1], Zi[1]);
+    for (int k = 0; k < RH * NC; ++k)
+      if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+    return;
+  }
+  const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
+  // Software pipeline: while the pairs of chunk `cur` are multiplied, the registers receive the records, pair list
+  // and slice bounds of the next chunk and the record indices of the one after.  Every load is unconditional (the
+  // streams are padded, the last chunk is simply fetched again): a load under a divergent branch makes the compiler
+  // drain vmcnt at the join, which would expose the whole fetch latency before each pair loop.
+  // The gather is piece-wise: element e = k * 512 + tid of a chunk is 16-byte piece e % NP of entry e / NP, so the
+  // 64 lanes of one load cover ~7 whole records (a thread fetching its own 144-byte record would touch 64 cache
+  // lines per instruction and thrash the L1), and the LDS copy is a contiguous ds_write_b128.
+  double2 rec[NLD];
+  unsigned short pv[NPV];
+  int idx[NLD];
 #pragma unroll
-      for (int k = 0; k < NC; ++k)
-        if (k >= np_i) { Ai[0][k] = 0.0; Ai[1][k] = 0.0; }
-      if (diag && debug_skip != 2) {  // every observation lives in exactly one diagonal tile: rhs term and its own (i, i) block
-        const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
-        double y[3];
-        chol3_fwd(L, gpt, y);
-        const double zy0 = Zi[0][0] * y[0] + Zi[0][1] * y[1] + Zi[0][2] * y[2];
-        const double zy1 = Zi[1][0] * y[0] + Zi[1][1] * y[1] + Zi[1][2] * y[2];
-        double* bc = sh_b + sh_loff[cl_i];
-        const double m00 = Zi[0][0] * Zi[0][0] + Zi[0][1] * Zi[0][1] + Zi[0][2] * Zi[0][2];
-        const double m01 = Zi[0][0] * Zi[1][0] + Zi[0][1] * Zi[1][1] + Zi[0][2] * Zi[1][2];
-        const double m11 = Zi[1][0] * Zi[1][0] + Zi[1][1] * Zi[1][1] + Zi[1][2] * Zi[1][2];
-        double* Dc = sh_D + cl_i * TRI;
+  for (int k = 0; k < NLD; ++k) rec[k] = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int r = 0; r < NC; ++r) {
-          if (r < np_i) lds_add(&bc[r], Ai[0][r] * zy0 + Ai[1][r] * zy1);
-          const double t0 = Ai[0][r] * m00 + Ai[1][r] * m01;
-          const double t1 = Ai[0][r] * m01 + Ai[1][r] * m11;
+  for (int k = 0; k < NPV; ++k) pv[k] = 0;
+  int q0 = 0, q1 = 0;
+  const int bo_lane = min(blk, nblk - 1);
+  {
+    const int c0 = tp.chunk_start[first];
 #pragma unroll
-          for (int c = r; c < NC; ++c)
-            if (c < np_i) lds_add(&Dc[UPack<NC>::idx(r, c)], t0 * Ai[0][c] + t1 * Ai[1][c]);
-        }
-      }
+    for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, CHUNK - 1)];
+  }
+  int nxt = first;
+  for (int cur = first - stride; cur < ch_end; cur += stride) {  // first trip: fetch only
+    int my_q0 = 0, my_q1 = 0;
+    if (cur >= first) {
+      double2* dstrec = reinterpret_cast<double2*>(sh_T);
 #pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        sh_A[k * CHUNK + threadIdx.x] = Ai[0][k];
-        sh_A[(NC + k) * CHUNK + threadIdx.x] = Ai[1][k];
-      }
+      for (int k = 0; k < NLD; ++k) dstrec[k * REG_BLOCK + threadIdx.x] = rec[k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        sh_Z[k * CHUNK + threadIdx.x] = Zi[0][k];
-        sh_Z[(3 + k) * CHUNK + threadIdx.x] = Zi[1][k];
-      }
+      for (int k = 0; k < NPV; ++k) sh_pairs[k * REG_BLOCK + threadIdx.x] = pv[k];
+      my_q0 = q0; my_q1 = q1;
+      __syncthreads();
+      nxt = min(cur + stride, last);
     }
-    __syncthreads();
-    if (owner && debug_skip != 1) {
-      const unsigned short* bo = tp.blk_off + (long)ch * (nblk + 1) + threadIdx.x;
-      const int qb = tp.pair_start[ch];
-      for (int q = qb + bo[0], qe = qb + bo[1]; q < qe; ++q) {
-        const unsigned pr = tp.pairs[q];
+    {
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int e = k * REG_BLOCK + (int)threadIdx.x;
+        rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
+      }
+      const int qb = tp.pair_start[nxt];
+#pragma unroll
+      for (int k = 0; k < NPV; ++k) pv[k] = tp.pairs[qb + k * REG_BLOCK + (int)threadIdx.x];
+      const unsigned short* bo = tp.blk_off + (long)nxt * (nblk + 1) + bo_lane;
+      const int b0 = bo[0], b1 = bo[1];
+      q0 = owner ? b0 : 0;
+      q1 = owner ? b1 : 0;
+      const int c0 = tp.chunk_start[min(nxt + stride, last)];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, CHUNK - 1)];
+    }
+    if (cur < first) continue;
+    if (debug_skip != 1) {
+      for (int q = my_q0; q < my_q1; ++q) {
+        const unsigned pr = sh_pairs[q];
         const int i_loc = pr & 255u, j_loc = pr >> 8;
-        double Zi[2][3], Zj[2][3], Ai[2][NC], Aj[2][NC];
+        const double* Ri = sh_T + i_loc * REC + 3 * r0;
+        const double2* Rj = reinterpret_cast<const double2*>(sh_T + j_loc * REC);
+        double Ti[3 * RH];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          Zi[0][k] = sh_Z[k * CHUNK + i_loc]; Zi[1][k] = sh_Z[(3 + k) * CHUNK + i_loc];
-          Zj[0][k] = sh_Z[k * CHUNK + j_loc]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j_loc];
-        }
+        for (int k = 0; k < 3 * RH; ++k) Ti[k] = Ri[k];
+        // T_j two columns (6 doubles = three 16-byte slots) at a time
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-          Ai[0][k] = sh_A[k * CHUNK + i_loc]; Ai[1][k] = sh_A[(NC + k) * CHUNK + i_loc];
-          Aj[0][k] = sh_A[k * CHUNK + j_loc]; Aj[1][k] = sh_A[(NC + k) * CHUNK + j_loc];
-        }
-        const double m00 = Zi[0][0] * Zj[0][0] + Zi[0][1] * Zj[0][1] + Zi[0][2] * Zj[0][2];
-        const double m01 = Zi[0][0] * Zj[1][0] + Zi[0][1] * Zj[1][1] + Zi[0][2] * Zj[1][2];
-        const double m10 = Zi[1][0] * Zj[0][0] + Zi[1][1] * Zj[0][1] + Zi[1][2] * Zj[0][2];
-        const double m11 = Zi[1][0] * Zj[1][0] + Zi[1][1] * Zj[1][1] + Zi[1][2] * Zj[1][2];
-        if (!own_diag_block) {
+        for (int cp = 0; cp < (NC + 1) / 2; ++cp) {
+          double Tj[6];
 #pragma unroll
-          for (int r = 0; r < NC; ++r) {
-            const double t0 = Ai[0][r] * m00 + Ai[1][r] * m10;
-            const double t1 = Ai[0][r] * m01 + Ai[1][r] * m11;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[r][c] += t0 * Aj[0][c] + t1 * Aj[1][c];
+          for (int k = 0; k < 3; ++k) {
+            const double2 b = (3 * cp + k < NP) ? Rj[3 * cp + k] : make_double2(0.0, 0.0);
+            Tj[2 * k] = b.x; Tj[2 * k + 1] = b.y;
           }
-        } else {
-          // two different observations of ONE camera (duplicate rows): T + T^T lands on the diagonal block
 #pragma unroll
-          for (int r = 0; r < NC; ++r) {
-            const double t0 = Ai[0][r] * m00 + Ai[1][r] * m10;
-            const double t1 = Ai[0][r] * m01 + Ai[1][r] * m11;
+          for (int r = 0; r < RH; ++r)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              const double val = t0 * Aj[0][c] + t1 * Aj[1][c];
-              acc[r][c] += val;
-              acc[c][r] += val;
+            for (int cc = 0; cc < 2; ++cc) {
+              const int c = 2 * cp + cc;
+              if (c < NC) acc[r][c] += Ti[3 * r] * Tj[3 * cc] + Ti[3 * r + 1] * Tj[3 * cc + 1] + Ti[3 * r + 2] * Tj[3 * cc + 2];
             }
-          }
         }
       }
     }
     __syncthreads();
   }
-  if (fail) flags[1] = 1;
-  // partial of this workgroup: [BLOCK threads][NC*NC] | sh_D [g][TRI] | sh_b [gn]
-  double* dst = partial + (long)blockIdx.x * tp.tile_elems;
+  // partial of this workgroup: [256 blocks][NC*NC]; this thread holds rows r0 .. r0 + RH - 1 of its block
 #pragma unroll
-  for (int r = 0; r < NC; ++r)
+  for (int r = 0; r < RH; ++r)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) dst[(long)threadIdx.x * NC * NC + r * NC + c] = acc[r][c];
-  double* dD = dst + (long)BLOCK * NC * NC;
-  for (int i = threadIdx.x; i < g * TRI; i += BLOCK) dD[i] = sh_D[i];
-  for (int i = threadIdx.x; i < gn; i += BLOCK) dD[g * TRI + i] = sh_b[i];
+    for (int c = 0; c < NC; ++c)
+      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
 }
 
-// Reduce the partials of k_schur_reg over the workgroups of each tile and scatter into Sacc / bacc.
-// blockDim = (64, 4) as k_tile_reduce.
+// Reduce the partials of k_schur_reg over the workgroups of each tile (fixed order).  blockDim = (64, 4) as
+// k_tile_reduce: x walks the per-thread partial entries, y splits the workgroups four ways.  Off-diagonal
+// blocks go straight into Sacc; the helper-thread entries of diagonal tiles are parked in `red` and folded per
+// camera by k_reg_fold.
 __global__ void __launch_bounds__(256)
 k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
-             double* __restrict__ Sacc, double* __restrict__ bacc) {
+             double* __restrict__ Sacc, double* __restrict__ red) {
   __shared__ double sh[4][64];
   const int t = blockIdx.y;
   const int ga = tp.tile_a[t], gb = tp.tile_b[t];
   const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
-  const int pa0 = tp.group_par_begin[ga], npa = tp.group_par_begin[ga + 1] - pa0;
-  const int g = tp.g, bsz = NCt * NCt, tri = NCt * (NCt + 1) / 2;
+  const int g = tp.g, bsz = NCt * NCt;
   const int e = blockIdx.x * 64 + threadIdx.x;
   const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
+  const bool diag = (ga == gb);
+  long dst = -1;       // >= 0: Sacc index;  -2: park in red
+  if (e < g * g * bsz) {
+    const int beta = e / bsz, rc = e % bsz;
+    const int li = beta / g, lj = beta % g, r = rc / NCt, c = rc % NCt;
+    if (diag && lj <= li) dst = -2;
+    else if (li < na && lj < nb && r < cam_np[ca0 + li] && c < cam_np[cb0 + lj])
+      dst = (long)(cam_off[ca0 + li] + r) * ncp + cam_off[cb0 + lj] + c;
+  }
   double s0 = 0.0, s1 = 0.0;
-  if (e < tp.tile_elems) {
+  if (dst != -1) {
     int w = w0 + threadIdx.y;
     for (; w + 4 < w1; w += 8) {
       s0 += partial[(long)w * tp.tile_elems + e];
@@ -810,37 +851,35 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
   }
   sh[threadIdx.y][threadIdx.x] = s0 + s1;
   __syncthreads();
-  if (threadIdx.y != 0 || e >= tp.tile_elems) return;
-  const double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-  const int n_thread_part = BLOCK * bsz;
-  if (e < n_thread_part) {
-    const int beta = e / bsz, rc = e % bsz;
-    if (beta >= g * g) return;
-    const int li = beta / g, lj = beta % g, r = rc / NCt, c = rc % NCt;
-    if (li >= na || lj >= nb) return;
-    if (ga == gb && lj < li) return;               // block lower triangle of a diagonal tile: not used
-    const int cam_i = ca0 + li, cam_j = cb0 + lj;
-    if (r >= cam_np[cam_i] || c >= cam_np[cam_j]) return;
-    if (ga == gb && li == lj) return;               // diagonal blocks are written from the D part below
-    Sacc[(long)(cam_off[cam_i] + r) * ncp + cam_off[cam_j] + c] = s;
-  } else if (e < n_thread_part + g * tri) {
-    if (ga != gb) return;
-    const int q = e - n_thread_part;
-    const int li = q / tri;
-    int r = 0, rem = q % tri;  // unpack idx(r, c) = r*NC - r(r-1)/2 + (c - r)
-    while (rem >= NCt - r) { rem -= NCt - r; ++r; }
-    const int c = r + rem;
-    if (li >= na) return;
-    const int cam = ca0 + li;
-    if (r >= cam_np[cam] || c >= cam_np[cam]) return;
-    // (i, i) terms (upper triangle accumulated) + duplicate-camera pairs collected by the owner of block (li, li)
-    double dup = 0.0;
-    const long e2 = (long)(li * g + li) * bsz + r * NCt + c;
-    for (int w = w0; w < w1; ++w) dup += partial[(long)w * tp.tile_elems + e2];
-    Sacc[(long)(cam_off[cam] + r) * ncp + cam_off[cam] + c] = s + dup;
-  } else if (ga == gb && e < n_thread_part + g * tri + npa) {
-    bacc[pa0 + (e - n_thread_part - g * tri)] = s;
+  if (threadIdx.y != 0 || dst == -1) return;
+  const double tot = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (dst >= 0) Sacc[dst] = tot;
+  else red[(long)ga * tp.tile_elems + e] = tot;
+}
+
+// Diagonal blocks of the diagonal tiles: sum the (already workgroup-reduced) accumulators of each camera's
+// helper threads.  Helper k (k-th thread with tid % g <= tid / g, in tid order) serves camera k mod na.
+// grid = (ceil(g * NC*NC / 64), G), block = 64.
+__global__ void __launch_bounds__(64)
+k_reg_fold(TilePlan tp, const double* __restrict__ red, const int* __restrict__ cam_off, const int* __restrict__ cam_np,
+           int NCt, int ncp, double* __restrict__ Sacc) {
+  const int ga = blockIdx.y;
+  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+  const int g = tp.g, bsz = NCt * NCt;
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= g * bsz) return;
+  const double* src = red + (long)ga * tp.tile_elems;
+  const int cam = q / bsz, r = (q % bsz) / NCt, c = (q % bsz) % NCt;
+  if (cam >= na || c < r || c >= cam_np[ca0 + cam]) return;
+  double s = 0.0;
+  for (int k = cam; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj
+    int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
+    while (li * (li + 1) / 2 > k) --li;
+    while ((li + 1) * (li + 2) / 2 <= k) ++li;
+    const int lj = k - li * (li + 1) / 2;
+    s += src[(long)(li * g + lj) * bsz + r * NCt + c];
   }
+  Sacc[(long)(cam_off[ca0 + cam] + r) * ncp + cam_off[ca0 + cam] + c] = s;
 }
 
 // Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc, undoing the

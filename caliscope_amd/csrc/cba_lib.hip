@@ -80,7 +80,7 @@ struct cba_problem {
   double *V = nullptr, *Upacked = nullptr;
   double *partial = nullptr, *partial4 = nullptr, *partial1 = nullptr;
   long partial_width = 0;
-  double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr;
+  double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   double* scal = nullptr;  // device scalars
   int* flags = nullptr;
   double* h_scal = nullptr;  // pinned
@@ -284,10 +284,12 @@ template <int NC> static size_t lds_schur_tile(int g) {
   const size_t gn = (size_t)g * NC;
   return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * tile_ld(g, NC)) * 8 + ((size_t)4 * g + CHUNK) * sizeof(int);
 }
-template <int NC> static size_t lds_schur_reg(int g) {
-  const size_t gn = (size_t)g * NC;
-  return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + (size_t)g * (NC * (NC + 1) / 2)) * 8 + (size_t)2 * g * sizeof(int);
+constexpr int kRegSplit = 1;  // rows of a camera-pair block per thread = NC / kRegSplit (see k_schur_reg)
+template <int NC> static size_t lds_schur_reg(int) {
+  constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * kRegSplit, NLD = (CHUNK * NP + RB - 1) / RB;
+  return (size_t)NLD * RB * 16 + (size_t)PAIRCAP * sizeof(unsigned short);
 }
+static size_t lds_tprep(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8; }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
@@ -312,17 +314,22 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
 
   struct Stream {
     std::vector<double> u, v;
-    std::vector<int> pt;
+    std::vector<int> pt, obs;
     std::vector<unsigned char> cl;
     std::vector<unsigned short> pairs;
-    std::vector<unsigned short> blk_off;       // register kernel: per chunk g*g+1 offsets of the block-sorted pairs
+    std::vector<unsigned short> blk_off;       // register kernel: per chunk g*g+1 offsets of the owner-sorted pairs
+    std::vector<std::vector<int>> helpers;     // register kernel, diagonal tile: helper threads of each camera
+    std::vector<size_t> rr;                    // rotation state per camera
+    bool diag = false;
     std::vector<int> chunk_start, pair_start;  // local offsets, start with 0
     int open = 0;                              // start of the currently open chunk
   };
   const bool reg = p->schur_reg;
   const int nblk = g * g;
-  // register kernel: the pairs of a chunk are sorted by camera-pair block (li * g + lj) and the (i, i) pairs are
-  // left out (they are accumulated during the block recomputation); blk_off gives every block its slice.
+  // register kernel: the pairs of a chunk are sorted by owner thread.  Off-diagonal tiles and li < lj: the owner
+  // of block (li, lj) is thread li * g + lj.  Diagonal tiles, li == lj ((i, i) items and duplicate-row pairs): the
+  // items of camera c rotate over that camera's helper threads (k-th thread of the lower triangle, k mod na == c).
+  // blk_off gives every thread its slice of the chunk's pair list.
   auto close_chunk_reg = [&](Stream& s) {
     const size_t pb = (size_t)s.pair_start.back();
     const size_t n = s.pairs.size() - pb;
@@ -330,9 +337,17 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     std::vector<unsigned short> key(n);
     for (size_t q = 0; q < n; ++q) {
       const unsigned pr = s.pairs[pb + q];
-      const int li = s.cl[s.open + (pr & 255u)], lj = s.cl[s.open + (pr >> 8)];
-      key[q] = (unsigned short)(li * g + (lj < g ? lj : lj - g));
-      cnt[key[q] + 1]++;
+      const int li = s.cl[s.open + (pr & 255u)], lj0 = s.cl[s.open + (pr >> 8)];
+      const int lj = lj0 < g ? lj0 : lj0 - g;
+      int k;
+      if (s.diag && li == lj) {
+        const std::vector<int>& h = s.helpers[li];
+        k = h[s.rr[li]++ % h.size()];
+      } else {
+        k = li * g + lj;
+      }
+      key[q] = (unsigned short)k;
+      cnt[k + 1]++;
     }
     for (int b2 = 0; b2 < nblk; ++b2) cnt[b2 + 1] += cnt[b2];
     for (int b2 = 0; b2 <= nblk; ++b2) s.blk_off.push_back((unsigned short)cnt[b2]);
@@ -343,6 +358,17 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   };
   std::vector<Stream> st(nT);
   for (auto& s : st) { s.chunk_start.push_back(0); s.pair_start.push_back(0); }
+  if (reg)
+    for (int a = 0; a < G; ++a) {
+      Stream& s = st[tile_id(a, a)];
+      const int na_t = gcam[a + 1] - gcam[a];
+      s.diag = true;
+      s.helpers.assign(g, {});
+      s.rr.assign(g, 0);
+      int k = 0;
+      for (int li = 0; li < g; ++li)
+        for (int lj = 0; lj <= li; ++lj, ++k) s.helpers[k % std::max(na_t, 1)].push_back(li * g + lj);
+    }
   std::vector<int> gbeg(G + 1);
   for (int q = 0; q < P; ++q) {
     const int s0 = hps[q], s1 = hps[q + 1];
@@ -363,30 +389,41 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         Stream& s = st[tile_id(a, b)];
         const int cnt = na + nb;
         int len = (int)s.pt.size();
-        if (len - s.open + cnt > CHUNK) {
+        long new_pairs = (b == a) ? (long)na * (na + 1) / 2 : (long)na * nb;
+        if (reg && b == a)
+          for (int i = gbeg[a]; i < gbeg[a + 1]; ++i)
+            for (int j = i + 1; j < gbeg[a + 1] && hcam[j] == hcam[i]; ++j) ++new_pairs;  // duplicate rows: both orders
+        if (reg && new_pairs > PAIRCAP) return CBA_ERR_UNSUPPORTED;  // caller falls back to the LDS-tile kernel
+        const bool pair_overflow = reg && (long)s.pairs.size() - s.pair_start.back() + new_pairs > PAIRCAP;
+        if (len - s.open + cnt > CHUNK || pair_overflow) {
           if (reg) close_chunk_reg(s);
           s.chunk_start.push_back(len); s.pair_start.push_back((int)s.pairs.size()); s.open = len;
         }
         const int base = len - s.open;  // chunk-local index of this point's first entry
         for (int i = gbeg[a]; i < gbeg[a + 1]; ++i) {
-          s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]);
+          s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.obs.push_back(i);
           s.cl.push_back((unsigned char)(hcam[i] - gcam[a]));
         }
         for (int i = gbeg[b]; b != a && i < gbeg[b + 1]; ++i) {
-          s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]);
+          s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.obs.push_back(i);
           s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b]));
         }
         // pairs (row observation i, column observation j), chunk-local, camera(i) <= camera(j)
         for (int i = 0; i < na; ++i) {
-          const int j0 = (b == a) ? (reg ? i + 1 : i) : na, j1 = (b == a) ? na : cnt;
-          for (int j = j0; j < j1; ++j) s.pairs.push_back((unsigned short)((base + i) | ((base + j) << 8)));
+          const int j0 = (b == a) ? i : na, j1 = (b == a) ? na : cnt;
+          for (int j = j0; j < j1; ++j) {
+            s.pairs.push_back((unsigned short)((base + i) | ((base + j) << 8)));
+            // register kernel: two rows of ONE camera contribute T + T^T, listed as (i, j) and (j, i)
+            if (reg && j != i && b == a && hcam[gbeg[a] + i] == hcam[gbeg[a] + j])
+              s.pairs.push_back((unsigned short)((base + j) | ((base + i) << 8)));
+          }
         }
       }
     }
   }
   // concatenate
   std::vector<double> U, V;
-  std::vector<int> PT, CS, PS, TCB(nT + 1, 0);
+  std::vector<int> PT, OB, CS, PS, TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
   std::vector<unsigned short> PR, BO;
   CS.push_back(0); PS.push_back(0);
@@ -402,21 +439,23 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     for (size_t c = 1; c < s.chunk_start.size(); ++c) { CS.push_back(base + s.chunk_start[c]); PS.push_back(pbase + s.pair_start[c]); }
     U.insert(U.end(), s.u.begin(), s.u.end()); V.insert(V.end(), s.v.begin(), s.v.end());
     PT.insert(PT.end(), s.pt.begin(), s.pt.end()); CL.insert(CL.end(), s.cl.begin(), s.cl.end());
+    OB.insert(OB.end(), s.obs.begin(), s.obs.end());
     PR.insert(PR.end(), s.pairs.begin(), s.pairs.end());
     s = Stream();
   }
   TCB[nT] = (int)CS.size() - 1;
+  // the register kernel fetches whole rounds without bounds checks: keep the streams readable past the end
+  if (reg) { PR.resize(PR.size() + PAIRCAP, 0); OB.resize(OB.size() + CHUNK, 0); }
   p->n_tile_chunks = TCB[nT];
   p->tile_stream_len = (long)PT.size();
-  p->n_pairs = (long)PR.size();
+  p->n_pairs = (long)PR.size() - (reg ? PAIRCAP : 0);
   // workgroups: proportional to the chunk count of each tile, at least one per tile
-  const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
-  std::vector<int> nwg(nT), wgb(nT + 1, 0);
-  {
-    std::vector<long> nch(nT);
+  std::vector<long> nch(nT);
+  for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
+  auto allocate = [&](int budget) {
+    std::vector<int> nwg(nT);
     long used = 0;
     for (int t = 0; t < nT; ++t) {
-      nch[t] = TCB[t + 1] - TCB[t];
       const long w = p->n_tile_chunks > 0 ? nch[t] * budget / p->n_tile_chunks : 1;
       nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
       used += nwg[t];
@@ -439,31 +478,50 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
       if (best < 0) break;
       if (used < budget) { nwg[best]++; used++; } else { nwg[best]--; used--; }
     }
-    for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
-  }
+    return nwg;
+  };
+  const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
+  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD gets the same share of every
+  // tile and walks one eighth of the point range, so the G tiles that gather a given T record do so through the
+  // same L2 at about the same time; HBM then serves each record once instead of G times.
+  constexpr int XCDS = 8;
+  const bool xcd_mode = reg && budget % XCDS == 0 && nT <= budget / XCDS && p->n_tile_chunks >= 4 * budget;
+  std::vector<int> nwg = allocate(xcd_mode ? budget / XCDS : budget), wgb(nT + 1, 0);
+  if (xcd_mode) for (int& w : nwg) w *= XCDS;
+  for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
   p->tile_grid = wgb[nT];
-  std::vector<int> wt(p->tile_grid), wr(p->tile_grid);
+  std::vector<int> wt(p->tile_grid), wfirst(p->tile_grid), wend(p->tile_grid), wstride(p->tile_grid);
   for (int t = 0; t < nT; ++t)
-    for (int r = 0; r < nwg[t]; ++r) { wt[wgb[t] + r] = t; wr[wgb[t] + r] = r; }
+    for (int r = 0; r < nwg[t]; ++r) {
+      const int b = wgb[t] + r;
+      wt[b] = t;
+      if (xcd_mode) {
+        const int x = r % XCDS, s = r / XCDS;
+        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
+        wfirst[b] = TCB[t] + (int)lo + s; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
+      } else {
+        wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t];
+      }
+    }
 
   int rc;
   double *du = nullptr, *dv = nullptr;
-  int *dpt = nullptr, *dcs = nullptr, *dtcb = nullptr, *dwt = nullptr, *dwr = nullptr, *dnwg = nullptr, *dta = nullptr, *dtb = nullptr,
+  int *dpt = nullptr, *dcs = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
       *dgc = nullptr, *dgp = nullptr;
   unsigned char* dcl = nullptr;
   unsigned short *dpr = nullptr, *dbo = nullptr;
-  int* dps = nullptr;
+  int *dps = nullptr, *dob = nullptr;
 #define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
   TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
-  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dbo, BO)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dtcb, TCB));
-  TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwr, wr)); TRYP(dev_upload(p, &dnwg, nwg)); TRYP(dev_upload(p, &dta, ta));
+  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dbo, BO)); TRYP(dev_upload(p, &dob, OB)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dwf, wfirst));
+  TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwe, wend)); TRYP(dev_upload(p, &dws, wstride)); TRYP(dev_upload(p, &dta, ta));
   TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
   TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
 #undef TRYP
   const int gn = g * p->nct;
   const int cs = tile_cs(p->nct), ld = tile_ld(g, p->nct);
-  const int elems = reg ? BLOCK * p->nct * p->nct + g * (p->nct * (p->nct + 1) / 2) + gn : gn * ld + gn;
-  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dtcb, dwt, dwr, dnwg, dta, dtb, dgc, dgp, g, cs, ld, elems, dbo};
+  const int elems = reg ? BLOCK * p->nct * p->nct : gn * ld + gn;
+  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dwf, dwe, dwt, dws, dta, dtb, dgc, dgp, g, cs, ld, elems, dbo, dob};
   return CBA_OK;
 }
 
@@ -483,7 +541,10 @@ static int configure_kernels(cba_problem* p) {
   p->G = (p->C + gmax - 1) / gmax;
   p->gsz = (p->C + p->G - 1) / p->G;
   p->n_tiles = p->G * (p->G + 1) / 2;
-  if (p->schur_reg) { if ((rc = allow_lds(k_schur_reg<NC>, lds_schur_reg<NC>(p->gsz)))) return rc; }
+  if (p->schur_reg) {
+    if ((rc = allow_lds(k_schur_reg<NC, kRegSplit>, lds_schur_reg<NC>(p->gsz)))) return rc;
+    if ((rc = allow_lds(k_tprep<NC>, lds_tprep(p)))) return rc;
+  }
   else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_chol_backward, (size_t)p->ncp * 8))) return rc;
@@ -584,18 +645,26 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
-  {
+  for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t tile_lds = p->schur_reg ? lds_schur_reg<6>(p->gsz) : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
-    if (p->schur_reg) per_cu = std::min(per_cu, 2);  // k_schur_reg<6>: ~220 VGPRs -> 2 waves per SIMD
+    if (p->schur_reg) per_cu = std::min(per_cu, 2);  // k_schur_reg<6>: registers allow two workgroups per CU
     const int resident = cus * per_cu;  // no partial last round
-    TRY(build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus))));
+    rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
+    if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) { p->schur_reg = false; continue; }  // a point with > PAIRCAP pairs in one tile
+    if (rc) return bail(rc);
+    break;
   }
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
   TRY(dev_alloc(p, &p->partial4, (size_t)1024 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)1024));
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
+  if (p->schur_reg) {
+    TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
+    TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * SchurRec<6>::REC));
+    TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
+  }
   TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * ncp));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4));
@@ -798,9 +867,15 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   {
     ScopedTimer t(p, T_SCHUR);
     if constexpr (NC == 6) {
-      if (p->schur_reg)
-        hipLaunchKernelGGL((k_schur_reg<NC>), dim3(p->tile_grid), dim3(BLOCK), lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
-                           p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
+      if (p->schur_reg) {
+        hipLaunchKernelGGL((k_tprep<NC>), dim3(p->grid), dim3(BLOCK), lds_tprep(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
+                           p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, p->V, p->g,
+                           p->sinv, p->Trec, p->partial_b, p->flags);
+        hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, 4), 0, p->stream, p->partial_b, p->grid,
+                           p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
+        hipLaunchKernelGGL((k_schur_reg<NC, kRegSplit>), dim3(p->tile_grid), dim3(BLOCK * kRegSplit), lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec,
+                           p->partial, p->debug_skip);
+      }
     }
     if (!p->schur_reg)
       hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
@@ -808,9 +883,12 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   }
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
-    if (p->schur_reg)
+    if (p->schur_reg) {
       hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
-                         p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
+                         p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
+      hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
+                         p->cam_off, p->cam_np, NC, ncp, p->Sacc);
+    }
     else
       hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
