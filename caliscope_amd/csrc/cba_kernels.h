@@ -926,7 +926,7 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
                                  const double* __restrict__ Upacked, const double* __restrict__ gvec,
                                  const double* __restrict__ sinv, const int* __restrict__ param_cam,
                                  const int* __restrict__ param_loc, int ncp, double lam, double* __restrict__ S,
-                                 double* __restrict__ rhs) {
+                                 double* __restrict__ rhs, double* __restrict__ W, int ldw) {
   using UP = UPack<NC>;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)ncp * ncp) return;
@@ -936,18 +936,21 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
   if (param_cam[row] == param_cam[col]) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
   if (row == col) {
     v += lam * sinv[row] * sinv[row];
-    rhs[row] = -gvec[row] + bacc[row];
+    const double rv = -gvec[row] + bacc[row];
+    rhs[row] = rv;
+    W[(long)ncp * ldw + row] = rv;  // rhs^T: last row of the Cholesky work matrix
   }
   S[(long)row * ncp + col] = v;
   S[(long)col * ncp + row] = v;
+  W[(long)row * ldw + col] = v;
+  W[(long)col * ldw + row] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense solve of the reduced camera system  S dc = rhs  (n <= 1152) by Cholesky, blocked right-looking,
-// NB = 32.  The work matrix is (n+1) x n, row-major: rows 0..n-1 hold S (lower triangle used), row n holds
-// rhs^T.  Row n is "below" every diagonal block, so the panel solves and trailing updates of the
-// factorisation turn it into y^T = (L^-1 rhs)^T for free — the forward substitution needs no kernel of its
-// own; only L^T x = y remains (k_chol_backward).
+// Dense solve of the reduced camera system  S dc = rhs  (n <= 1152) by blocked Cholesky, NB = 32.
+// The work matrix is (n+1) x ldw, row-major: rows 0..n-1 hold S, row n holds rhs^T.  Row n is "below" every
+// diagonal block, so the panel solves of the factorisation turn it into y^T = (L^-1 rhs)^T for free — the forward
+// substitution needs no kernel of its own; only L^T x = y remains (k_chol_backward).
 constexpr int NB = 32;
 
 // broadcast lane `src` (wave-uniform) of a double through SGPRs: two v_readlane_b32, no LDS round trip
@@ -967,138 +970,314 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
   return y;
 }
 
-// One step: every workgroup factors the NB x NB diagonal block itself, parks L_kk in LDS, then solves its share
-// of the rows below:  L_ik = M_ik L_kk^-T  (one thread per row; `nrows` = n + 1 includes rhs^T).
-// The diagonal block is factored by wave 0 alone, one row per lane in registers, right-looking: per pivot the
-// lanes publish their column entry through a 32-double LDS line and read the entries they need back as
-// broadcasts.  A single wave executes its DS instructions in order, so no barrier is needed inside the loop
-// (wave-scope fences keep the compiler from reordering).  A first version broadcast every entry with
-// v_readlane pairs: 6.2k instructions (1.7k readlane, 0.5k hazard s_nop), 13-19 us per block.
-__global__ void __launch_bounds__(BLOCK)
-k_potrf_panel(double* __restrict__ M, int n, int nrows, int k0, int* __restrict__ flags) {
-  __shared__ double T[NB][NB + 1];
-  __shared__ double Tinv[NB];
-  __shared__ double Lcol[2][NB];
-  const int nb = min(NB, n - k0);
-  if (threadIdx.x < WAVE) {
-    const int lane = threadIdx.x;
-    const int r = lane < NB ? lane : 0;
-    double row[NB];
+// Factor the NB x NB block parked in `D` (LDS, row stride NB + 1, `nb` live rows, identity-padded) with wave 0.
+// Left-looking by columns, lane r keeps row r in registers:  v_r = D_rj - sum_{t<j} L_rt L_jt, L_jj = sqrt(v_j),
+// L_rj = v_r / L_jj.  Row j of L is read back from LDS as broadcasts (every lane stores its new entry D[r][j] = L_rj
+// at pivot j; a wave executes its DS instructions in order, wave-scope fences only pin the compiler), prefetched one
+// pivot ahead; only the newest entry L_j,j-1 is on the critical path and travels by v_readlane instead.
+// History: a right-looking version (row[c] -= L_rj L_cj for all c > j at each pivot) needed ~20 us per block: its
+// 496 in-place updates of 32 live row registers made the register allocator spill 1.3 KB per lane.  This form has
+// one short-lived dot product per pivot: 88 VGPRs, no scratch, 2x faster (tools/chol_factor_bench).
+// The factor goes to the lower triangle of the global block at `out` (row stride ldw).
+__device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, double* __restrict__ out, int ldw,
+                                                  int* __restrict__ flags) {
+  const int lane = threadIdx.x;
+  const int r = lane & (NB - 1);
+  double row[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) row[c] = (lane < nb && c <= r && c < nb) ? M[(long)(k0 + r) * n + k0 + c] : (c == r ? 1.0 : 0.0);
-    bool bad = false;
+  for (int c = 0; c < NB; ++c) row[c] = D[r][c];
+  bool bad = false;
+  double s_prev = 0.0;
+  double pre[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      double d = readlane_f64(row[j], j);
-      if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
-      const double inv = fast_rsqrt(d);
-      const double lrj = (lane == j) ? d * inv : row[j] * inv;
-      row[j] = lrj;
-      if (lane < NB) Lcol[j & 1][lane] = lrj;   // double-buffered line
-      if (lane == j) Tinv[j] = inv;
-      // wave-scope ordering only: DS instructions of one wave complete in order, the fences just pin the compiler
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int c = j + 1; c < NB; ++c) row[c] -= lrj * Lcol[j & 1][c];
-    }
-    if (bad && lane == 0) flags[2] = 1;
-    if (lane < NB) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        T[lane][c] = row[c];
-        if (blockIdx.x == 0 && lane < nb && c <= lane) M[(long)(k0 + lane) * n + k0 + c] = row[c];
-      }
-    }
-  }
-  __syncthreads();
-  const int i = k0 + nb + blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= nrows) return;
-  double x[NB];
-  double* prow = M + (long)i * n + k0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? prow[j] : 0.0;
+  for (int t = 0; t < NB; ++t) pre[t] = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    if (j < nb) {
-      double v = x[j];
+    double nxt[NB];  // row j + 1 of L, entries t < j (final since pivot j - 1)
 #pragma unroll
-      for (int t = 0; t < NB; ++t)
-        if (t < j) v -= x[t] * T[j][t];
-      x[j] = v * Tinv[j];
-    }
+    for (int t = 0; t < NB; ++t) nxt[t] = (j + 1 < NB && t < j) ? D[(j + 1) & (NB - 1)][t] : 0.0;
+    double a[4] = {row[j], 0.0, 0.0, 0.0};  // four chains: a dependent FP64 FMA costs ~20 cycles
+#pragma unroll
+    for (int t = 0; t + 1 < j; ++t) a[t & 3] -= row[t] * pre[t];
+    double acc = (a[0] + a[1]) + (a[2] + a[3]);
+    if (j >= 1) acc -= row[j - 1] * s_prev;
+    double d = readlane_f64(acc, j);
+    if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
+    const double inv = fast_rsqrt(d);
+    const double l = (r == j) ? d * inv : (r > j ? acc * inv : 0.0);
+    row[j] = l;
+    D[r][j] = l;
+    if (j + 1 < NB) s_prev = readlane_f64(l, j + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < NB; ++t) pre[t] = nxt[t];
   }
+  if (bad && lane == 0) flags[2] = 1;
+  if (lane < nb) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
-    if (j < nb) prow[j] = x[j];
+    for (int c = 0; c < NB; ++c)
+      if (c <= lane) out[(long)lane * ldw + c] = row[c];
+  }
 }
 
-// trailing update: M_ij -= L_i,panel L_j,panel^T for tiles with i >= j beyond the panel (rows up to nrows)
-__global__ void __launch_bounds__(BLOCK)
-k_syrk_trailing(double* __restrict__ M, int n, int nrows, int k0) {
-  __shared__ double Li[NB][NB + 1], Lj[NB][NB + 1];
-  const int nb = min(NB, n - k0);
-  const int base = k0 + nb;
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (tj > ti) return;
-  const int i0 = base + ti * NB, j0 = base + tj * NB;
-  if (j0 >= n) return;
-  for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
-    const int r = t / NB, c = t % NB;
-    Li[r][c] = (i0 + r < nrows && c < nb) ? M[(long)(i0 + r) * n + k0 + c] : 0.0;
-    Lj[r][c] = (j0 + r < n && c < nb) ? M[(long)(j0 + r) * n + k0 + c] : 0.0;
+// One launch per panel (left-looking with look-ahead).  Work matrix W: (n + 1) rows, row stride ldw (multiple of 4),
+// rows 0..n-1 = S (both triangles on entry), row n = rhs^T.  Row blocks of NB rows; the rhs row is a block of its own.
+//
+// Step k >= 0 (panel columns k0 = NB k .. k0 + nbp - 1, L_kk already factored by step k - 1), workgroup w, row block
+// b = k + 1 + w:
+//   1. U   = W_bk - L_b,0:k0 L_k,0:k0^T            left-looking update of the block's panel columns.  8 waves: four
+//                                                  16 x 16 tiles x two depth slices, v_mfma_f64_16x16x4 with the
+//                                                  operands read straight from global (each lane 4 consecutive
+//                                                  doubles of a row per 16-deep slab), partial tiles summed in LDS;
+//   2. L_bk = U L_kk^-T                            one thread per row, forward substitution against L_kk in LDS;
+//   3. D_b -= L_bk L_bk^T                          the block's own diagonal block, right-looking (8 MFMAs per tile);
+//   4. b == k + 1: factor D_b (wave 0), so that the next step finds L_k+1,k+1 ready.
+// Step k = -1 is one workgroup that factors D_0.  The chain per panel is one kernel with one global round trip,
+// instead of panel-solve + trailing-update kernels (2 launches, ~28 us per panel, before).
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int CHOL_THREADS = 512;   // 1024 threads (four depth slices) measured slower: 20-25 us per step against 15-24
+constexpr int CHOL_DEPTH = CHOL_THREADS / 256;  // depth slices of the left-looking update (waves = 4 tiles x CHOL_DEPTH)
+constexpr int CHOL_BATCH = 6;      // 16-deep slabs per wave whose operand loads are in flight together
+
+__global__ void __launch_bounds__(CHOL_THREADS)
+k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace) {
+  __shared__ double sh_red[CHOL_DEPTH][4][16][17];
+  __shared__ double sh_U[NB][NB + 1], sh_L[NB][NB + 1], sh_X[NB][NB + 1], sh_D[NB][NB + 1];
+  __shared__ double sh_inv[NB];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int nbk = (n + NB - 1) / NB;
+  const int b = k + 1 + blockIdx.x;                       // row block; nbk = the rhs row
+  const int rb = (b < nbk) ? b * NB : n;                  // first row
+  const int rc = (b < nbk) ? min(NB, n - rb) : 1;         // live rows
+  constexpr int EPT = NB * NB / CHOL_THREADS, ISTEP = CHOL_THREADS / NB;  // elements of a 32 x 32 block per thread
+  const int j = tid & 31, i0 = tid >> 5;                  // (i0 + h * ISTEP, j), h < EPT
+  const bool has_diag = b < nbk;
+  double* Wb = W + (long)rb * ldw;
+  // optional phase stamps of the critical workgroup (b == k + 1), 100 MHz wall clock: CBA_CHOL_TRACE=1
+  const bool stamp = trace != nullptr && blockIdx.x == 0 && tid == 0;
+#define CHOL_STAMP(ph) do { if (stamp) trace[(k + 1) * 8 + (ph)] = wall_clock64(); } while (0)
+  CHOL_STAMP(0);
+
+  // everything this thread needs from global, in one round trip
+  double d_ij[EPT], m_ij[EPT], l_ij[EPT];
+#pragma unroll
+  for (int h = 0; h < EPT; ++h) {
+    const int i = i0 + h * ISTEP;
+    d_ij[h] = (has_diag && i < rc && j < rc) ? Wb[(long)i * ldw + rb + j] : (i == j ? 1.0 : 0.0);
+  }
+  if (k < 0) {
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) sh_D[i0 + h * ISTEP][j] = d_ij[h];
+    __syncthreads();
+    if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags);
+    return;
+  }
+  const int k0 = k * NB, nbp = min(NB, n - k0);
+#pragma unroll
+  for (int h = 0; h < EPT; ++h) {
+    const int i = i0 + h * ISTEP;
+    m_ij[h] = (i < rc && j < nbp) ? Wb[(long)i * ldw + k0 + j] : 0.0;
+    l_ij[h] = (i < nbp && j <= i) ? W[(long)(k0 + i) * ldw + k0 + j] : (i == j ? 1.0 : 0.0);
+  }
+
+  CHOL_STAMP(1);
+  // 1. left-looking update
+  {
+    const int tl = wv & 3, ti = tl >> 1, tj = tl & 1, dsl = wv >> 2;
+    const int nslab = k0 / 16;
+    const double* pa = Wb + (long)min(ti * 16 + (lane & 15), rc - 1) * ldw + 4 * (lane >> 4);
+    const double* pb = W + (long)(k0 + min(tj * 16 + (lane & 15), nbp - 1)) * ldw + 4 * (lane >> 4);
+    v4f64 c = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = dsl; s0 < nslab; s0 += CHOL_DEPTH * CHOL_BATCH) {
+      double2 a[CHOL_BATCH][2], bb[CHOL_BATCH][2];
+#pragma unroll
+      for (int u = 0; u < CHOL_BATCH; ++u) {
+        const int s = s0 + CHOL_DEPTH * u;
+        if (s < nslab) {
+          a[u][0] = *reinterpret_cast<const double2*>(pa + 16 * s);
+          a[u][1] = *reinterpret_cast<const double2*>(pa + 16 * s + 2);
+          bb[u][0] = *reinterpret_cast<const double2*>(pb + 16 * s);
+          bb[u][1] = *reinterpret_cast<const double2*>(pb + 16 * s + 2);
+        } else {
+          a[u][0] = a[u][1] = bb[u][0] = bb[u][1] = make_double2(0.0, 0.0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CHOL_BATCH; ++u) {
+        // the K index of an MFMA is lane >> 4; within a slab, step t pairs the t-th of each lane's 4 doubles:
+        // the same permutation of K on both operands, so the sum is unchanged
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][0].x, bb[u][0].x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][0].y, bb[u][0].y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][1].x, bb[u][1].x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][1].y, bb[u][1].y, c, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh_red[dsl][tl][(lane >> 4) + 4 * r][lane & 15] = c[r];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
-    const int r = t / NB, c = t % NB;
-    const int gi = i0 + r, gj = j0 + c;
-    if (gi < nrows && gj < n && gj <= gi) {
-      double acc = 0.0;
+  CHOL_STAMP(2);
 #pragma unroll
-      for (int q = 0; q < NB; ++q) acc += Li[r][q] * Lj[c][q];
-      M[(long)gi * n + gj] -= acc;
+  for (int h = 0; h < EPT; ++h) {
+    const int i = i0 + h * ISTEP;
+    const int tl = (i >> 4) * 2 + (j >> 4);
+    double upd = 0.0;
+#pragma unroll
+    for (int d = 0; d < CHOL_DEPTH; ++d) upd += sh_red[d][tl][i & 15][j & 15];
+    sh_U[i][j] = m_ij[h] - upd;
+    sh_L[i][j] = l_ij[h];
+    if (i == j) sh_inv[i] = 1.0 / l_ij[h];
+  }
+  __syncthreads();
+  CHOL_STAMP(3);
+  // 2. panel solve  x L_kk^T = u, one row of U per thread of wave 0.  The coefficients L_kk[c][t] are the same for
+  // every lane: they are read through the scalar cache (constant address space: s_load straight into SGPR operands;
+  // L_kk was written by the previous launch).  Read from LDS as broadcasts, the 528 ds_read of a lone wave took
+  // 4.6 us (a single wave gets a fifth of the LDS issue rate).  Four partial sums per entry: a dependent FP64 FMA
+  // chain runs at ~20 cycles per link.
+  if (tid < NB) {
+    typedef const __attribute__((address_space(4))) double* scalar_ptr;
+    scalar_ptr Lg = (scalar_ptr)(W + (long)k0 * ldw + k0);
+    double x[NB];
+#pragma unroll
+    for (int c2 = 0; c2 < NB; ++c2) x[c2] = sh_U[tid][c2];
+#pragma unroll
+    for (int c2 = 0; c2 < NB; ++c2) {
+      double a[4] = {x[c2], 0.0, 0.0, 0.0};
+      const long rowoff = (long)min(c2, nbp - 1) * ldw;
+#pragma unroll
+      for (int t = 0; t < c2; ++t) a[t & 3] -= x[t] * Lg[rowoff + t];
+      x[c2] = ((a[0] + a[1]) + (a[2] + a[3])) * sh_inv[c2];
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < NB; ++c2) sh_X[tid][c2] = (c2 < nbp && tid < rc) ? x[c2] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < EPT; ++h) {
+    const int i = i0 + h * ISTEP;
+    if (i < rc && j < nbp) Wb[(long)i * ldw + k0 + j] = sh_X[i][j];
+  }
+  CHOL_STAMP(4);
+  if (!has_diag) return;
+  // 3. own diagonal block, rank-NB update
+  if (wv < 4) {
+    const int ti = wv >> 1, tj = wv & 1;
+    v4f64 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NB / 4; ++t) {
+      const int q = 4 * t + (lane >> 4);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_X[ti * 16 + (lane & 15)][q], sh_X[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh_red[0][wv][(lane >> 4) + 4 * r][lane & 15] = c[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < EPT; ++h) {
+    const int i = i0 + h * ISTEP;
+    const double d_new = d_ij[h] - sh_red[0][(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
+    if (b != k + 1) {
+      if (i < rc && j < rc) Wb[(long)i * ldw + rb + j] = d_new;
+    } else {
+      sh_D[i][j] = (i < rc && j < rc) ? d_new : (i == j ? 1.0 : 0.0);
     }
   }
+  if (b != k + 1) return;
+  // 4. look-ahead: the next panel's diagonal block
+  __syncthreads();
+  CHOL_STAMP(5);
+  if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags);
+  CHOL_STAMP(6);
+#undef CHOL_STAMP
 }
 
-// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.
-__global__ void __launch_bounds__(BLOCK)
-k_chol_backward(const double* __restrict__ L, int n, double* __restrict__ out) {
+// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block (last
+// to first): wave 0 solves the NB x NB triangle, then every thread i < k0 folds the block into y_i.  The loads of
+// a block's update panel L[k0 .. k0+nb, i] and of the next diagonal block do not depend on the solution, so they
+// are issued before the triangle solve and land while it runs (the first version loaded after each barrier: 5 us
+// per block, all of it exposed latency).
+constexpr int BACK_THREADS = 512;
+__global__ void __launch_bounds__(BACK_THREADS)
+k_chol_backward(const double* __restrict__ L, int n, int ldw, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double y[];  // n
   __shared__ double D[NB][NB + 1];
-  for (int i = threadIdx.x; i < n; i += BLOCK) y[i] = L[(long)n * n + i];
+  constexpr int EPT = NB * NB / BACK_THREADS;
+  for (int i = threadIdx.x; i < n; i += BACK_THREADS) y[i] = L[(long)n * ldw + i];
   const int lane = threadIdx.x & (WAVE - 1);
   const int nblk = (n + NB - 1) / NB;
+  const int dr = threadIdx.x / NB, dc = threadIdx.x % NB;  // elements (dr + h * BACK_THREADS / NB, dc) of a diagonal block
+  double dreg[EPT];
+  // loads are unconditional (clamped addresses, select afterwards): a load under a divergent branch would make the
+  // compiler drain vmcnt at the join, i.e. before the triangle solve the loads are meant to overlap with
+  auto load_diag = [&](int kb_req) {
+    const int kb = max(kb_req, 0);
+    const int k0 = kb * NB, nb = min(NB, n - k0);
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) {
+      const int r = dr + h * (BACK_THREADS / NB);
+      const double v = L[(long)(k0 + min(r, nb - 1)) * ldw + k0 + min(dc, nb - 1)];
+      dreg[h] = (r < nb && dc <= r) ? v : (r == dc ? 1.0 : 0.0);
+    }
+  };
+  // update panel of block kb, column i: L[k0 + t][i], t < NB (rows clamped into the block, masked when used)
+  const int i = threadIdx.x;
+  double lp[NB];
+  auto load_panel = [&](int kb_req) {
+    const int kb = max(kb_req, 0);
+    const int k0 = kb * NB, nb = min(NB, n - k0);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) lp[t] = L[(long)(k0 + min(t, nb - 1)) * ldw + min(i, n - 1)];
+  };
+  load_diag(nblk - 1);
+  load_panel(nblk - 1);
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * NB;
     const int nb = min(NB, n - k0);
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) D[dr + h * (BACK_THREADS / NB)][dc] = dreg[h];
+    double lcur[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) lcur[t] = lp[t];
     __syncthreads();
-    for (int t = threadIdx.x; t < NB * NB; t += BLOCK) {
-      const int r = t / NB, c = t % NB;
-      D[r][c] = (r < nb && c <= r) ? L[(long)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
-    }
-    __syncthreads();
+    // in flight during this block's solve and update: the next block's diagonal block and update panel
+    load_diag(kb - 1);
+    load_panel(kb - 1);
     if (threadIdx.x < WAVE) {
+      // D is identity-padded to NB x NB: the triangle is solved at full size from registers (column `lane` of D)
+      const int c = lane & (NB - 1);
+      double col[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) col[t] = D[t][c];
       double xj = (lane < nb) ? y[k0 + lane] : 0.0;
-      const double invd = (lane < NB) ? 1.0 / D[lane][lane] : 1.0;
-      for (int t = nb - 1; t >= 0; --t) {
-        const double xt = readlane_f64(xj * invd, t);
+      const double dinv = 1.0 / D[c][c];
+#pragma unroll
+      for (int t = NB - 1; t >= 0; --t) {
+        const double xt = readlane_f64(xj * dinv, t);
         if (lane == t) xj = xt;
-        else if (lane < t) xj -= D[t][lane] * xt;
+        else if (lane < t) xj -= col[t] * xt;
       }
       if (lane < nb) y[k0 + lane] = xj;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < k0; i += BLOCK) {
+    if (i < k0) {
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        if (t < nb) acc += lcur[t] * y[k0 + t];
+      y[i] -= acc;
+    }
+    for (int i2 = threadIdx.x + BACK_THREADS; i2 < k0; i2 += BACK_THREADS) {  // wider systems: the rest of the panel
       double acc = 0.0;
 #pragma unroll 8
-      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * n + i] * y[k0 + t];
-      y[i] -= acc;
+      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * ldw + i2] * y[k0 + t];
+      y[i2] -= acc;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += BLOCK) out[i] = y[i];
+  for (int i = threadIdx.x; i < n; i += BACK_THREADS) out[i] = y[i];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -80,6 +80,9 @@ struct cba_problem {
   double *V = nullptr, *Upacked = nullptr;
   double *partial = nullptr, *partial4 = nullptr, *partial1 = nullptr;
   long partial_width = 0;
+  bool want_chol_trace = false;
+  long long* chol_trace = nullptr;  // CBA_CHOL_TRACE=1: phase stamps of k_chol_step (tools/chol_trace.py)
+  int ldw = 0;             // row stride of the Cholesky work matrix Lbuf (multiple of 4 doubles)
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   double* scal = nullptr;  // device scalars
   int* flags = nullptr;
@@ -576,6 +579,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->C = d->n_cams; p->P = d->n_points; p->N = d->n_obs;
   p->loss = d->loss; p->f_scale = d->f_scale;
   if (const char* dbg = std::getenv("CBA_DEBUG_SCHUR_SKIP")) p->debug_skip = std::atoi(dbg);
+  p->want_chol_trace = std::getenv("CBA_CHOL_TRACE") != nullptr;
   int rc = CBA_OK;
   auto bail = [&](int code) { cba_destroy(p); return code; };
 
@@ -665,7 +669,9 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * SchurRec<6>::REC));
     TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
   }
-  TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * ncp));
+  TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); p->ldw = (ncp + 3) & ~3;
+  if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 1) * 8));
+  TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4));
   HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
@@ -831,22 +837,31 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
 // them (the stream was just drained by the previous primitive).  Nothing in the sequence changes from call
 // to call (same buffers, same n), so it is captured once into a hipGraph and replayed.
 static int enqueue_cholesky(cba_problem* p) {
-  const int n = p->ncp, nrows = n + 1;
-  HIPCHK(hipMemcpyAsync(p->Lbuf, p->S, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  HIPCHK(hipMemcpyAsync(p->Lbuf + (size_t)n * n, p->rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int rest = nrows - (k0 + NB);
-    hipLaunchKernelGGL(k_potrf_panel, dim3(std::max(1, (rest + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, p->stream, p->Lbuf, n, nrows, k0, p->flags);
-    if (k0 + NB < n) {
-      const int tiles = (rest + NB - 1) / NB;
-      hipLaunchKernelGGL(k_syrk_trailing, dim3(tiles, tiles), dim3(BLOCK), 0, p->stream, p->Lbuf, n, nrows, k0);
-    }
-  }
-  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BLOCK), (size_t)n * 8, p->stream, p->Lbuf, n, p->s);
+  const int n = p->ncp, nbk = (n + NB - 1) / NB;
+  for (int k = -1; k < nbk; ++k)  // step k: panel k solved for the blocks below it (and the rhs row), D_k+1 factored
+    hipLaunchKernelGGL(k_chol_step, dim3(k < 0 ? 1 : nbk - k), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace);
+  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)n * 8, p->stream, p->Lbuf, n, p->ldw, p->s);
   return CBA_OK;
 }
 
 static int run_cholesky(cba_problem* p) {
+  if (p->chol_trace) {  // traced run: plain launches, then dump the stamps of the critical workgroups
+    const int nbk = (p->ncp + NB - 1) / NB;
+    HIPCHK(hipMemsetAsync(p->chol_trace, 0, (size_t)(nbk + 1) * 8 * sizeof(long long), p->stream));
+    int rc = enqueue_cholesky(p);
+    if (rc) return rc;
+    std::vector<long long> h((size_t)(nbk + 1) * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), p->chol_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (int s = 0; s <= nbk; ++s) {
+      fprintf(stderr, "chol step %2d:", s - 1);
+      for (int ph = 1; ph < 7; ++ph)
+        if (h[s * 8 + ph] && h[s * 8 + ph - 1]) fprintf(stderr, " ph%d %6.2f us", ph, (h[s * 8 + ph] - h[s * 8 + ph - 1]) * 0.01); else if (h[s * 8 + ph]) fprintf(stderr, " ph%d (%6.2f)", ph, (h[s * 8 + ph] - h[s * 8]) * 0.01);
+      if (s < nbk && h[(s + 1) * 8] && h[s * 8]) fprintf(stderr, "  | to next step start %6.2f us", (h[(s + 1) * 8] - h[s * 8]) * 0.01);
+      fprintf(stderr, "\n");
+    }
+    return CBA_OK;
+  }
   if (!p->chol_exec) {
     HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
     int rc = enqueue_cholesky(p);
@@ -898,7 +913,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     }
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
-                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs);
+                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs, p->Lbuf, p->ldw);
   }
   int rc = run_cholesky(p);
   if (rc) return rc;
