@@ -30,6 +30,19 @@ constexpr int CAM_CONST_STRIDE = 12;  // fx0 fy0 cx cy d0..d4 pad pad pad
 constexpr int MAX_NC = 9;
 constexpr double EPS_F64 = 2.220446049250313e-16;
 
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps on the device (an IEEE sqrt followed by an IEEE divide is ~35 FP64
+// instructions), the plain quotient on the host.
+CBA_HD double inv_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 enum Loss : int { LOSS_LINEAR = 0, LOSS_HUBER = 1, LOSS_SOFT_L1 = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4 };
 
 // Per-camera constants of one evaluation point (48 doubles; staged in LDS by the kernels).
@@ -101,16 +114,18 @@ struct Lens {
 
 CBA_HD void lens_pinhole(const double* d, double x, double y, Lens* L) {
   const double k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4];
-  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-  const double cd = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
-  const double dcd = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
-  const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+  // written addend-first / Horner so that every step contracts to one FMA
+  const double r2 = x * x + y * y, r4 = r2 * r2;
+  const double cd = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+  const double dcd2 = 2.0 * (k1 + r2 * (2.0 * k2 + r2 * (3.0 * k3)));  // 2 d(cd)/d(r2)
+  const double x2 = x + x, y2 = y + y;
+  const double a1 = x2 * y, a2 = r2 + x2 * x, a3 = r2 + y2 * y;
   L->xd = x * cd + p1 * a1 + p2 * a2;
   L->yd = y * cd + p1 * a3 + p2 * a1;
-  L->dxx = cd + 2.0 * x * x * dcd + 2.0 * p1 * y + 6.0 * p2 * x;
-  L->dxy = 2.0 * x * y * dcd + 2.0 * p1 * x + 2.0 * p2 * y;
+  L->dxx = cd + x * x * dcd2 + p1 * y2 + 3.0 * p2 * x2;
+  L->dxy = x * y * dcd2 + p1 * x2 + p2 * y2;
   L->dyx = L->dxy;
-  L->dyy = cd + 2.0 * y * y * dcd + 6.0 * p1 * y + 2.0 * p2 * x;
+  L->dyy = cd + y * y * dcd2 + 3.0 * p1 * y2 + p2 * x2;
   L->xr2 = x * r2; L->yr2 = y * r2; L->xr4 = x * r4; L->yr4 = y * r4;
 }
 
@@ -137,15 +152,15 @@ CBA_HD void lens_fisheye(const double* d, double x, double y, Lens* L) {
 
 // Residual only (trial evaluations).  Returns false if the projection is not finite.
 CBA_HD void project_residual(const CamTab& c, double X, double Y, double Z, double u, double v, double* e) {
-  const double Xc = c.R[0] * X + c.R[1] * Y + c.R[2] * Z + c.t[0];
-  const double Yc = c.R[3] * X + c.R[4] * Y + c.R[5] * Z + c.t[1];
-  const double Zc = c.R[6] * X + c.R[7] * Y + c.R[8] * Z + c.t[2];
+  const double Xc = c.t[0] + c.R[0] * X + c.R[1] * Y + c.R[2] * Z;  // addend first: three FMAs
+  const double Yc = c.t[1] + c.R[3] * X + c.R[4] * Y + c.R[5] * Z;
+  const double Zc = c.t[2] + c.R[6] * X + c.R[7] * Y + c.R[8] * Z;
   const double iz = 1.0 / Zc;
   const double x = Xc * iz, y = Yc * iz;
   Lens L;
   if (c.model != 0.0) lens_fisheye(c.d, x, y, &L); else lens_pinhole(c.d, x, y, &L);
-  e[0] = (c.fx * L.xd + c.cx - u) * c.inv_fx0;
-  e[1] = (c.fy * L.yd + c.cy - v) * c.inv_fx0;
+  e[0] = ((c.cx - u) + c.fx * L.xd) * c.inv_fx0;
+  e[1] = ((c.cy - v) + c.fy * L.yd) * c.inv_fx0;
 }
 
 // Residual + Jacobian blocks.  A is [2][MAX_NC] (only the first nparams columns are written),
@@ -161,8 +176,8 @@ CBA_HD void project_full(const CamTab& c, double X, double Y, double Z, double u
   Lens L;
   if (c.model != 0.0) lens_fisheye(c.d, x, y, &L); else lens_pinhole(c.d, x, y, &L);
   const double s = c.inv_fx0;
-  e[0] = (c.fx * L.xd + c.cx - u) * s;
-  e[1] = (c.fy * L.yd + c.cy - v) * s;
+  e[0] = ((c.cx - u) + c.fx * L.xd) * s;
+  e[1] = ((c.cy - v) + c.fy * L.yd) * s;
   // G = d(pixel)/dXc / fx0  (2x3)
   const double fxs = c.fx * s, fys = c.fy * s;
   const double g00 = fxs * L.dxx * iz, g01 = fxs * L.dxy * iz;
@@ -239,33 +254,35 @@ CBA_HD double robust_cost_one(int loss, double f_scale, double r) {
   }
 }
 
-// Cholesky of a symmetric 3x3 given as (xx, xy, xz, yy, yz, zz).  L = [l00; l10 l11; l20 l21 l22].
+// Cholesky of a symmetric 3x3 given as (xx, xy, xz, yy, yz, zz).  L = [l00; l10 l11; l20 l21 l22] is returned with
+// RECIPROCAL diagonal entries: out = (1/l00, l10, 1/l11, l20, l21, 1/l22) — every use below multiplies by them, so
+// the factorisation and the solves contain no division and no square root, only three inv_sqrt.
 // Returns false when a pivot is not safely positive.
 CBA_HD bool chol3(const double* v, double* L) {
   const double tiny = 16.0 * EPS_F64;
   if (!(v[0] > 0.0)) return false;
-  const double l00 = sqrt(v[0]);
-  const double l10 = v[1] / l00, l20 = v[2] / l00;
+  const double i0 = inv_sqrt(v[0]);
+  const double l10 = v[1] * i0, l20 = v[2] * i0;
   const double d1 = v[3] - l10 * l10;
   if (!(d1 > tiny * v[3])) return false;
-  const double l11 = sqrt(d1);
-  const double l21 = (v[4] - l20 * l10) / l11;
+  const double i1 = inv_sqrt(d1);
+  const double l21 = (v[4] - l20 * l10) * i1;
   const double d2 = v[5] - l20 * l20 - l21 * l21;
   if (!(d2 > tiny * v[5])) return false;
-  L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = sqrt(d2);
+  L[0] = i0; L[1] = l10; L[2] = i1; L[3] = l20; L[4] = l21; L[5] = inv_sqrt(d2);
   return true;
 }
 // y = L^{-1} b
 CBA_HD void chol3_fwd(const double* L, const double* b, double* y) {
-  y[0] = b[0] / L[0];
-  y[1] = (b[1] - L[1] * y[0]) / L[2];
-  y[2] = (b[2] - L[3] * y[0] - L[4] * y[1]) / L[5];
+  y[0] = b[0] * L[0];
+  y[1] = (b[1] - L[1] * y[0]) * L[2];
+  y[2] = (b[2] - L[3] * y[0] - L[4] * y[1]) * L[5];
 }
 // x = L^{-T} y
 CBA_HD void chol3_bwd(const double* L, const double* y, double* x) {
-  x[2] = y[2] / L[5];
-  x[1] = (y[1] - L[4] * x[2]) / L[2];
-  x[0] = (y[0] - L[1] * x[1] - L[3] * x[2]) / L[0];
+  x[2] = y[2] * L[5];
+  x[1] = (y[1] - L[4] * x[2]) * L[2];
+  x[0] = (y[0] - L[1] * x[1] - L[3] * x[2]) * L[0];
 }
 
 }  // namespace cba

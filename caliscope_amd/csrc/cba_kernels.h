@@ -800,7 +800,8 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
               const int c = 2 * cp + cc;
-              if (c < NC) acc[r][c] += Ti[3 * r] * Tj[3 * cc] + Ti[3 * r + 1] * Tj[3 * cc + 1] + Ti[3 * r + 2] * Tj[3 * cc + 2];
+              // three chained FMAs; `acc += a*b + c*d + e*f` would cost a multiply, two FMAs and an add
+              if (c < NC) acc[r][c] = fma(Ti[3 * r + 2], Tj[3 * cc + 2], fma(Ti[3 * r + 1], Tj[3 * cc + 1], fma(Ti[3 * r], Tj[3 * cc], acc[r][c])));
             }
         }
       }
