@@ -125,26 +125,31 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-// out[j] = sum_b partial[b*width + j]  (fixed order => deterministic).  Launch with blockDim = (64, 4):
-// x indexes columns (coalesced), y splits the rows four ways; partial sums meet in LDS.
-__global__ void __launch_bounds__(256)
+// out[j] = sum_b partial[b*width + j]  (fixed order => deterministic).  Launch with blockDim = (64, REDUCE_RY):
+// x indexes columns (coalesced), y splits the rows REDUCE_RY ways (two interleaved chains each) so that the chain of
+// dependent loads per thread stays short (512 rows: 16 loads deep); partial sums meet in LDS in a fixed order.
+constexpr int REDUCE_RY = 16;
+__global__ void __launch_bounds__(64 * REDUCE_RY)
 k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[REDUCE_RY][64];
   const int j = blockIdx.x * 64 + threadIdx.x;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  double s0 = 0.0, s1 = 0.0;
   if (j < width) {
     int b = threadIdx.y;
-    for (; b + 12 < nrow; b += 16) {
+    for (; b + REDUCE_RY < nrow; b += 2 * REDUCE_RY) {
       s0 += partial[(long)b * width + j];
-      s1 += partial[(long)(b + 4) * width + j];
-      s2 += partial[(long)(b + 8) * width + j];
-      s3 += partial[(long)(b + 12) * width + j];
+      s1 += partial[(long)(b + REDUCE_RY) * width + j];
     }
-    for (; b < nrow; b += 4) s0 += partial[(long)b * width + j];
+    if (b < nrow) s0 += partial[(long)b * width + j];
   }
-  sh[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  sh[threadIdx.y][threadIdx.x] = s0 + s1;
   __syncthreads();
-  if (threadIdx.y == 0 && j < width) out[j] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (threadIdx.y == 0 && j < width) {
+    double tot = 0.0;
+#pragma unroll
+    for (int y = 0; y < REDUCE_RY; ++y) tot += sh[y][threadIdx.x];
+    out[j] = tot;
+  }
 }
 // narrow case (width <= 4): one workgroup, every thread strides over the rows
 template <bool MAX>
@@ -1023,37 +1028,95 @@ __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, d
   }
 }
 
-// One launch per panel (left-looking with look-ahead).  Work matrix W: (n + 1) rows, row stride ldw (multiple of 4),
-// rows 0..n-1 = S (both triangles on entry), row n = rhs^T.  Row blocks of NB rows; the rhs row is a block of its own.
+// One launch per panel (right-looking with look-ahead).  Work matrix W: (n + 1) rows, row stride ldw (multiple of
+// 4), rows 0..n-1 = S (both triangles on entry), row n = rhs^T.  Row blocks of NB rows; the rhs row is a block of
+// its own.  Step k >= 0 (panel columns k0 = NB k .., L_kk already factored by step k - 1) has two kinds of workgroup:
 //
-// Step k >= 0 (panel columns k0 = NB k .. k0 + nbp - 1, L_kk already factored by step k - 1), workgroup w, row block
-// b = k + 1 + w:
-//   1. U   = W_bk - L_b,0:k0 L_k,0:k0^T            left-looking update of the block's panel columns.  8 waves: four
-//                                                  16 x 16 tiles x two depth slices, v_mfma_f64_16x16x4 with the
-//                                                  operands read straight from global (each lane 4 consecutive
-//                                                  doubles of a row per 16-deep slab), partial tiles summed in LDS;
-//   2. L_bk = U L_kk^-T                            one thread per row, forward substitution against L_kk in LDS;
-//   3. D_b -= L_bk L_bk^T                          the block's own diagonal block, right-looking (8 MFMAs per tile);
-//   4. b == k + 1: factor D_b (wave 0), so that the next step finds L_k+1,k+1 ready.
-// Step k = -1 is one workgroup that factors D_0.  The chain per panel is one kernel with one global round trip,
-// instead of panel-solve + trailing-update kernels (2 launches, ~28 us per panel, before).
+//   panel workgroup, row block b = k + 1 .. nbk:
+//     1. U    = W_bk - L_b,k-1 L_k,k-1^T      the one update its panel columns still miss (rank NB, FP64 MFMA);
+//     2. L_bk = U L_kk^-T                     panel solve, one thread per row;
+//     3. D_b -= L_bk L_bk^T                   its own diagonal block, kept up to date every step;
+//     4. b == k + 1: factor D_b (wave 0), so that the next step finds L_k+1,k+1 ready (look-ahead);
+//   trailing workgroup, block (i, j) with k + 1 <= j < i:
+//        W_ij -= L_i,k-1 L_j,k-1^T            the update of the previous panel, off the critical path.
+//
+// Step k = -1 is one workgroup that factors D_0.  The critical chain per panel is one launch with one global round
+// trip of three 8 KB blocks.  History: (a) panel-solve + trailing-update kernels, 2 launches and ~28 us per panel;
+// (b) one launch with a left-looking update of depth k0 - its operands (up to 160 KB) all pass through the one CU
+// that runs the critical workgroup, 6-10 us per step at the memory-level parallelism of a single CU.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int CHOL_THREADS = 512;   // 1024 threads (four depth slices) measured slower: 20-25 us per step against 15-24
-constexpr int CHOL_DEPTH = CHOL_THREADS / 256;  // depth slices of the left-looking update (waves = 4 tiles x CHOL_DEPTH)
-constexpr int CHOL_BATCH = 6;      // 16-deep slabs per wave whose operand loads are in flight together
+constexpr int CHOL_THREADS = 512;   // 8 waves; 1024 threads measured slower (register budget halves, the panel solve spills)
+
+// red[tile] = A B^T for two NB x NB panels (depth NB), four 16 x 16 tiles, one per wave 0..3 (v_mfma_f64_16x16x4:
+// eight per tile).  A, B point at element (first row, first panel column) of the operands in the work matrix; rows
+// are clamped to the live ones (callers ignore the padding rows).  A lane loads 4 consecutive doubles of row
+// (lane & 15) of its tile per 16-deep slab; the K index of an MFMA is lane >> 4, and step t pairs the t-th of each
+// lane's 4 doubles: the same permutation of K on both operands, so the sum is unchanged.
+__device__ __forceinline__ void chol_rank_nb(const double* __restrict__ A, int rcA, const double* __restrict__ B, int rcB,
+                                             int ldw, double (*red)[16][17], int wv, int lane) {
+  if (wv >= 4) return;
+  const int ti = wv >> 1, tj = wv & 1, lr = lane & 15, kq = 4 * (lane >> 4);
+  const double* pa = A + (long)min(ti * 16 + lr, rcA - 1) * ldw + kq;
+  const double* pb = B + (long)min(tj * 16 + lr, rcB - 1) * ldw + kq;
+  double2 a[NB / 16][2], b[NB / 16][2];
+#pragma unroll
+  for (int s = 0; s < NB / 16; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      a[s][h] = *reinterpret_cast<const double2*>(pa + 16 * s + 2 * h);
+      b[s][h] = *reinterpret_cast<const double2*>(pb + 16 * s + 2 * h);
+    }
+  v4f64 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NB / 16; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][h].x, b[s][h].x, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][h].y, b[s][h].y, c, 0, 0, 0);
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wv][(lane >> 4) + 4 * r][lr] = c[r];
+}
 
 __global__ void __launch_bounds__(CHOL_THREADS)
 k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace) {
-  __shared__ double sh_red[CHOL_DEPTH][4][16][17];
+  __shared__ double sh_red[4][16][17];
   __shared__ double sh_U[NB][NB + 1], sh_L[NB][NB + 1], sh_X[NB][NB + 1], sh_D[NB][NB + 1];
   __shared__ double sh_inv[NB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int nbk = (n + NB - 1) / NB;
+  constexpr int EPT = NB * NB / CHOL_THREADS, ISTEP = CHOL_THREADS / NB;  // elements of a 32 x 32 block per thread
+  const int j = tid & 31, i0 = tid >> 5;                  // (i0 + h * ISTEP, j), h < EPT
+  const int n_panel = (k < 0) ? 1 : nbk - k;
+
+  if ((int)blockIdx.x >= n_panel) {
+    // trailing role: block (bi, bj), k + 1 <= bj < bi <= nbk, takes the update of panel k - 1
+    int t = blockIdx.x - n_panel, bj = k + 1;
+    while (t >= nbk - bj) { t -= nbk - bj; ++bj; }
+    const int bi = bj + 1 + t;
+    const int ri = (bi < nbk) ? bi * NB : n, rci = (bi < nbk) ? min(NB, n - ri) : 1;
+    const int rj = bj * NB, rcj = min(NB, n - rj);
+    const int m0 = (k - 1) * NB;
+    double* Wi = W + (long)ri * ldw;
+    double w_ij[EPT];
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      w_ij[h] = (i < rci && j < rcj) ? Wi[(long)i * ldw + rj + j] : 0.0;
+    }
+    chol_rank_nb(Wi + m0, rci, W + (long)rj * ldw + m0, rcj, ldw, sh_red, wv, lane);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      if (i < rci && j < rcj) Wi[(long)i * ldw + rj + j] = w_ij[h] - sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
+    }
+    return;
+  }
+
   const int b = k + 1 + blockIdx.x;                       // row block; nbk = the rhs row
   const int rb = (b < nbk) ? b * NB : n;                  // first row
   const int rc = (b < nbk) ? min(NB, n - rb) : 1;         // live rows
-  constexpr int EPT = NB * NB / CHOL_THREADS, ISTEP = CHOL_THREADS / NB;  // elements of a 32 x 32 block per thread
-  const int j = tid & 31, i0 = tid >> 5;                  // (i0 + h * ISTEP, j), h < EPT
   const bool has_diag = b < nbk;
   double* Wb = W + (long)rb * ldw;
   // optional phase stamps of the critical workgroup (b == k + 1), 100 MHz wall clock: CBA_CHOL_TRACE=1
@@ -1084,49 +1147,15 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   }
 
   CHOL_STAMP(1);
-  // 1. left-looking update
-  {
-    const int tl = wv & 3, ti = tl >> 1, tj = tl & 1, dsl = wv >> 2;
-    const int nslab = k0 / 16;
-    const double* pa = Wb + (long)min(ti * 16 + (lane & 15), rc - 1) * ldw + 4 * (lane >> 4);
-    const double* pb = W + (long)(k0 + min(tj * 16 + (lane & 15), nbp - 1)) * ldw + 4 * (lane >> 4);
-    v4f64 c = {0.0, 0.0, 0.0, 0.0};
-    for (int s0 = dsl; s0 < nslab; s0 += CHOL_DEPTH * CHOL_BATCH) {
-      double2 a[CHOL_BATCH][2], bb[CHOL_BATCH][2];
-#pragma unroll
-      for (int u = 0; u < CHOL_BATCH; ++u) {
-        const int s = s0 + CHOL_DEPTH * u;
-        if (s < nslab) {
-          a[u][0] = *reinterpret_cast<const double2*>(pa + 16 * s);
-          a[u][1] = *reinterpret_cast<const double2*>(pa + 16 * s + 2);
-          bb[u][0] = *reinterpret_cast<const double2*>(pb + 16 * s);
-          bb[u][1] = *reinterpret_cast<const double2*>(pb + 16 * s + 2);
-        } else {
-          a[u][0] = a[u][1] = bb[u][0] = bb[u][1] = make_double2(0.0, 0.0);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < CHOL_BATCH; ++u) {
-        // the K index of an MFMA is lane >> 4; within a slab, step t pairs the t-th of each lane's 4 doubles:
-        // the same permutation of K on both operands, so the sum is unchanged
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][0].x, bb[u][0].x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][0].y, bb[u][0].y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][1].x, bb[u][1].x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][1].y, bb[u][1].y, c, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh_red[dsl][tl][(lane >> 4) + 4 * r][lane & 15] = c[r];
-  }
+  // 1. pending update of this block's panel columns by panel k - 1 (all earlier panels were applied by the trailing
+  // workgroups of earlier steps)
+  if (k >= 1) chol_rank_nb(Wb + (k0 - NB), rc, W + (long)k0 * ldw + (k0 - NB), nbp, ldw, sh_red, wv, lane);
   __syncthreads();
   CHOL_STAMP(2);
 #pragma unroll
   for (int h = 0; h < EPT; ++h) {
     const int i = i0 + h * ISTEP;
-    const int tl = (i >> 4) * 2 + (j >> 4);
-    double upd = 0.0;
-#pragma unroll
-    for (int d = 0; d < CHOL_DEPTH; ++d) upd += sh_red[d][tl][i & 15][j & 15];
+    const double upd = (k >= 1) ? sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15] : 0.0;
     sh_U[i][j] = m_ij[h] - upd;
     sh_L[i][j] = l_ij[h];
     if (i == j) sh_inv[i] = 1.0 / l_ij[h];
@@ -1173,13 +1202,13 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
       c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_X[ti * 16 + (lane & 15)][q], sh_X[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh_red[0][wv][(lane >> 4) + 4 * r][lane & 15] = c[r];
+    for (int r = 0; r < 4; ++r) sh_red[wv][(lane >> 4) + 4 * r][lane & 15] = c[r];
   }
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < EPT; ++h) {
     const int i = i0 + h * ISTEP;
-    const double d_new = d_ij[h] - sh_red[0][(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
+    const double d_new = d_ij[h] - sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
     if (b != k + 1) {
       if (i < rc && j < rc) Wb[(long)i * ldw + rb + j] = d_new;
     } else {

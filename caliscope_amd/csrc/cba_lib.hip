@@ -861,7 +861,7 @@ static int run_build(cba_problem* p) {
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
     const int w = p->C * UPack<NC>::STRIDE;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, 4), 0, p->stream, p->partial, p->grid, w, p->Upacked);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, p->Upacked);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
     int rc = allreduce_sum(p, p->Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
     if (!rc) rc = allreduce_sum(p, p->scal + 8, 1);
@@ -928,8 +928,13 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
 // to call (same buffers, same n), so it is captured once into a hipGraph and replayed.
 static int enqueue_cholesky(cba_problem* p) {
   const int n = p->ncp, nbk = (n + NB - 1) / NB;
-  for (int k = -1; k < nbk; ++k)  // step k: panel k solved for the blocks below it (and the rhs row), D_k+1 factored
-    hipLaunchKernelGGL(k_chol_step, dim3(k < 0 ? 1 : nbk - k), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace);
+  for (int k = -1; k < nbk; ++k) {
+    // step k: panel k solved for the blocks below it (and the rhs row), D_k+1 factored; extra workgroups apply the
+    // rank-NB update of panel k - 1 to the blocks right of the current panel
+    const int n_panel = k < 0 ? 1 : nbk - k;
+    const int x = nbk - k - 1, n_trailing = k < 1 ? 0 : x * (x + 1) / 2;
+    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace);
+  }
   hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)n * 8, p->stream, p->Lbuf, n, p->ldw, p->s);
   return CBA_OK;
 }
@@ -976,7 +981,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
         hipLaunchKernelGGL((k_tprep<NC>), dim3(p->grid), dim3(BLOCK), lds_tprep(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                            p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, p->V, p->g,
                            p->sinv, p->Trec, p->partial_b, p->flags);
-        hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, 4), 0, p->stream, p->partial_b, p->grid,
+        hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                            p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
         hipLaunchKernelGGL((k_schur_reg<NC, kRegSplit>), dim3(p->tile_grid), dim3(BLOCK * kRegSplit), lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec,
                            p->partial, p->debug_skip);
