@@ -152,7 +152,10 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     }
 
 
-PMC_KERNEL = {"schur": "k_schur_tile", "build": "k_build", "jv": "k_jv", "backsub": "k_backsub", "cost": "k_cost<false>"}
+# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg for 6-parameter
+# cameras, k_schur_tile for 9-parameter ones)
+PMC_KERNEL = {"schur": ("k_tprep", "k_schur_reg", "k_schur_tile"), "build": ("k_build",), "jv": ("k_jv",),
+              "backsub": ("k_backsub",), "cost": ("k_cost<false>",)}
 
 
 def pmc_traffic(workload, family):
@@ -162,10 +165,8 @@ def pmc_traffic(workload, family):
     if not path.exists() or family not in PMC_KERNEL:
         return None
     rows = json.loads(path.read_text())
-    for name, row in rows.items():
-        if name.startswith(PMC_KERNEL[family]):
-            return round(row["hbm_bytes"])
-    return None
+    found = [row["hbm_bytes"] for name, row in rows.items() if name.startswith(PMC_KERNEL[family])]
+    return round(sum(found)) if found else None
 
 
 def roofline_from(m):
@@ -186,9 +187,14 @@ def roofline_from(m):
     return {
         "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(m["name"], dom), "alg_bytes_per_launch": alg[dom],
-        "note": "k_schur is LDS-atomic/FP64-bound, not HBM-bound (DESIGN.md 4-5); durations from HIP events on the engine stream in an "
-                "instrumented repeat of the timed steps; traffic from profiles/pmc_*.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)",
+        "note": "k_schur = the Schur pass (k_tprep + k_schur_reg; k_schur_tile for 9-parameter cameras): FP64-VALU / latency "
+                "bound, not HBM-bound (DESIGN.md 4-5); durations from HIP events on the engine stream in an instrumented "
+                "repeat of the timed steps; traffic from profiles/pmc_*.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, "
+                "summed over the kernels of the pass)",
         "avg_launch_us": round(avg_s * 1e6, 2), "kernels": table,
+        # B_alg = 72 N + 312 P + 8 (nc C)^2 bytes per accepted LM iteration, over the measured step time
+        "iteration": (lambda b, t: {"alg_bytes": b, "GBps": round(b / t / 1e9, 1), "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4)})(
+            72 * m["n_obs"] + 312 * m["n_points"] + 8 * m["ncp"] ** 2, m["elapsed"] / max(m["steps"], 1)),
     }
 
 

@@ -630,9 +630,10 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         int n_cams, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
         double* __restrict__ partial_b, int* __restrict__ flags) {
-  constexpr int REC = SchurRec<NC>::REC;
+  constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* sh_tab = sh;
+  double2* sh_stage = reinterpret_cast<double2*>(sh);        // [BLOCK / WAVE][WAVE * NP]  record transpose, per wave
+  double* sh_tab = sh + (size_t)BLOCK * REC;
   double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad
   stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_b[i] = 0.0;
@@ -640,43 +641,64 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
+  const int wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  double2* stage = sh_stage + wv * WAVE * NP;
   bool fail = false;
   for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int i = chunk_start[ch] + threadIdx.x;
-    if (i >= chunk_start[ch + 1]) continue;
-    const int cam = obs_cam[i], pt = obs_pt[i];
-    const CamTab& ct = cam_at(sh_tab, cam);
-    double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
-    obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e, A, B);
-    const int np = (int)ct.nparams;
-    double Vd[6], L[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
-    const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
-    Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
-    if (!chol3(Vd, L)) {
-      fail = true;
-      L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
-    }
-    chol3_fwd(L, B[0], Z[0]);
-    chol3_fwd(L, B[1], Z[1]);
-    const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
-    double y[3];
-    chol3_fwd(L, gpt, y);
+    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+    const int i = o0 + threadIdx.x;
     double rec[REC];
-    double* bc = sh_b + cam_off[cam];
 #pragma unroll
-    for (int r = 0; r < NC; ++r) {
-      const bool live = r < np;
+    for (int k = 0; k < REC; ++k) rec[k] = 0.0;
+    if (i < o1) {
+      const int cam = obs_cam[i], pt = obs_pt[i];
+      const CamTab& ct = cam_at(sh_tab, cam);
+      double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
+      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e, A, B);
+      const int np = (int)ct.nparams;
+      double Vd[6], L[6];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) rec[3 * r + k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
-      if (live) lds_add(&bc[r], rec[3 * r] * y[0] + rec[3 * r + 1] * y[1] + rec[3 * r + 2] * y[2]);
+      for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
+      const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
+      Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+      if (!chol3(Vd, L)) {
+        fail = true;
+        L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
+      }
+      chol3_fwd(L, B[0], Z[0]);
+      chol3_fwd(L, B[1], Z[1]);
+      const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
+      double y[3];
+      chol3_fwd(L, gpt, y);
+      double* bc = sh_b + cam_off[cam];
+#pragma unroll
+      for (int r = 0; r < NC; ++r) {
+        const bool live = r < np;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rec[3 * r + k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
+        if (live) lds_add(&bc[r], rec[3 * r] * y[0] + rec[3 * r + 1] * y[1] + rec[3 * r + 2] * y[2]);
+      }
     }
+    // The 64 records of a wave are one contiguous 9216-byte run of Trec.  A lane storing its own record issues
+    // 16-byte stores 144 bytes apart (64 cache lines per instruction: the store path stalled, 45 % issue-stall
+    // cycles); so the wave transposes through LDS and every store instruction writes 1 KB contiguous.
 #pragma unroll
-    for (int k = 3 * NC; k < REC; ++k) rec[k] = 0.0;
-    double2* dst = reinterpret_cast<double2*>(Trec + (long)i * REC);
+    for (int k = 0; k < NP; ++k) stage[lane * NP + k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int w0 = o0 + wv * WAVE;                       // first observation of this wave
+    const int n_pieces = max(0, min(WAVE, o1 - w0)) * NP;  // live pieces of this wave
+    double2* dst = reinterpret_cast<double2*>(Trec + (long)w0 * REC);
 #pragma unroll
-    for (int k = 0; k < REC / 2; ++k) dst[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+    for (int k = 0; k < NP; ++k) {
+      const int e = k * WAVE + lane;
+      const double2 v = stage[e];
+      if (e < n_pieces) dst[e] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (fail) flags[1] = 1;
   __syncthreads();

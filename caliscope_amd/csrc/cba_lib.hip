@@ -293,7 +293,7 @@ template <int NC> static size_t lds_schur_reg(int) {
   constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * kRegSplit, NLD = (CHUNK * NP + RB - 1) / RB;
   return (size_t)NLD * RB * 16 + (size_t)PAIRCAP * sizeof(unsigned short);
 }
-static size_t lds_tprep(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8; }
+static size_t lds_tprep(const cba_problem* p) { return ((size_t)BLOCK * SchurRec<6>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8; }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
