@@ -1338,8 +1338,8 @@ template <int NC>
 __global__ void __launch_bounds__(BLOCK)
 k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
           const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
-          int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
-          const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
+          const int* __restrict__ chunk_pts, int n_chunks, const double* __restrict__ xvec, VecLayout lay,
+          const double* __restrict__ tab, const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
           const double* __restrict__ Vblk, const double* __restrict__ gvec, const double* __restrict__ sinv,
           double* __restrict__ svec) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -1353,9 +1353,36 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
   double* sp = svec + lay.ncp_pad;
+  // per-point solve of point p given the summed observation terms q (on top of g_p)
+  auto solve_point = [&](int p, double* q, const double* Vin, const double* din) {
+    double Vd[6], L[6], y[3], x[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Vd[k] = Vin[k];
+    Vd[0] += lam * din[0] * din[0]; Vd[3] += lam * din[1] * din[1]; Vd[5] += lam * din[2] * din[2];
+    if (chol3(Vd, L)) {
+      chol3_fwd(L, q, y);
+      chol3_bwd(L, y, x);
+    } else {
+      x[0] = x[1] = x[2] = 0.0;  // flagged by the Schur pass already
+    }
+    sp[p] = -x[0];
+    sp[lay.Ppad + p] = -x[1];
+    sp[2 * lay.Ppad + p] = -x[2];
+  };
   for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+    const int cp0 = chunk_pts[2 * ch], npts = chunk_pts[2 * ch + 1];
     const int i = o0 + threadIdx.x;
+    // Inputs of the per-point phase for point cp0 + tid: fetched now (unconditionally, clamped), consumed after the
+    // barrier.  Fetched after it, their latency - three dependent global loads - was serial time with one wave
+    // working and three parked: 45 of the kernel's 96 us.
+    const int pp = min(cp0 + (int)threadIdx.x, lay.P - 1);
+    const int pa = pt_start[pp] - o0, pb = pt_start[pp + 1] - o0;
+    double Vp[6], dpp[3], q[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Vp[k] = Vblk[(long)k * lay.Ppad + pp];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dpp[k] = dp[(long)k * lay.Ppad + pp]; q[k] = gp[(long)k * lay.Ppad + pp]; }
     double t[3] = {0.0, 0.0, 0.0};
     if (i < o1) {
       const int cam = obs_cam[i], pt = obs_pt[i];
@@ -1376,27 +1403,21 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     sh_pt[CHUNK + threadIdx.x] = t[1];
     sh_pt[2 * CHUNK + threadIdx.x] = t[2];
     __syncthreads();
-    const int cp0 = obs_pt[o0], npts = obs_pt[o1 - 1] - cp0 + 1;
-    for (int lp = threadIdx.x; lp < npts; lp += BLOCK) {
+    if ((int)threadIdx.x < npts && pb > pa) {
+      for (int j = pa; j < pb; ++j) { q[0] += sh_pt[j]; q[1] += sh_pt[CHUNK + j]; q[2] += sh_pt[2 * CHUNK + j]; }
+      solve_point(pp, q, Vp, dpp);
+    }
+    for (int lp = threadIdx.x + BLOCK; lp < npts; lp += BLOCK) {  // a range padded by unobserved points: rare
       const int p = cp0 + lp;
       const int a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
       if (b > a) {
-        double q[3] = {gp[p], gp[lay.Ppad + p], gp[2 * lay.Ppad + p]};
-        for (int j = a; j < b; ++j) { q[0] += sh_pt[j]; q[1] += sh_pt[CHUNK + j]; q[2] += sh_pt[2 * CHUNK + j]; }
-        double Vd[6], L[6], y[3], x[3];
+        double q2[3] = {gp[p], gp[lay.Ppad + p], gp[2 * lay.Ppad + p]}, V2[6], d2[3];
+        for (int j = a; j < b; ++j) { q2[0] += sh_pt[j]; q2[1] += sh_pt[CHUNK + j]; q2[2] += sh_pt[2 * CHUNK + j]; }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Vd[k] = Vblk[(long)k * lay.Ppad + p];
-        const double d0 = dp[p], d1 = dp[lay.Ppad + p], d2 = dp[2 * lay.Ppad + p];
-        Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
-        if (chol3(Vd, L)) {
-          chol3_fwd(L, q, y);
-          chol3_bwd(L, y, x);
-        } else {
-          x[0] = x[1] = x[2] = 0.0;  // flagged by the Schur pass already
-        }
-        sp[p] = -x[0];
-        sp[lay.Ppad + p] = -x[1];
-        sp[2 * lay.Ppad + p] = -x[2];
+        for (int k = 0; k < 6; ++k) V2[k] = Vblk[(long)k * lay.Ppad + p];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d2[k] = dp[(long)k * lay.Ppad + p];
+        solve_point(p, q2, V2, d2);
       }
     }
     __syncthreads();

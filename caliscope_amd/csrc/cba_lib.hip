@@ -72,6 +72,7 @@ struct cba_problem {
   // observations (sorted by point) + plan
   double *obs_u = nullptr, *obs_v = nullptr;
   int *obs_cam = nullptr, *obs_pt = nullptr, *pt_start = nullptr, *chunk_start = nullptr, *order = nullptr;
+  int* chunk_pts = nullptr;  // [n_chunks][2] first point and number of points (observed or not) in a chunk's range
   // cameras
   double* cam_const = nullptr;
   int *cam_model = nullptr, *cam_np = nullptr, *cam_off = nullptr, *param_cam = nullptr, *param_loc = nullptr;
@@ -724,6 +725,14 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_upload(p, &p->obs_u, hu)); TRY(dev_upload(p, &p->obs_v, hv));
   TRY(dev_upload(p, &p->obs_cam, hcam)); TRY(dev_upload(p, &p->obs_pt, hpt));
   TRY(dev_upload(p, &p->order, hord)); TRY(dev_upload(p, &p->pt_start, hps)); TRY(dev_upload(p, &p->chunk_start, hcs));
+  {
+    std::vector<int> hcp((size_t)std::max<int64_t>(nch, 1) * 2, 0);
+    for (int64_t q = 0; q < nch; ++q) {
+      hcp[2 * q] = hpt[hcs[q]];
+      hcp[2 * q + 1] = hpt[hcs[q + 1] - 1] - hpt[hcs[q]] + 1;
+    }
+    TRY(dev_upload(p, &p->chunk_pts, hcp));
+  }
   std::vector<double> cc(d->cam_const, d->cam_const + (size_t)p->C * 12);
   TRY(dev_upload(p, &p->cam_const, cc));
   TRY(dev_upload(p, &p->cam_model, model)); TRY(dev_upload(p, &p->cam_np, np)); TRY(dev_upload(p, &p->cam_off, off));
@@ -1015,7 +1024,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   {
     ScopedTimer t(p, T_BACKSUB);
     hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                       p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
+                       p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
                        p->f_scale, lam, p->V, p->g, p->sinv, p->s);
   }
   {
