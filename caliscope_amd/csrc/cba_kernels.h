@@ -68,6 +68,17 @@ __device__ __forceinline__ void lds_add(double* addr, double v) { unsafeAtomicAd
 // (96 dwords == 32 mod 64 banks) the lanes of a wave, each reading the same field of a different camera,
 // would land on two bank pairs (32-way conflict); an odd stride spreads 32 cameras over all bank pairs.
 constexpr int CAMTAB_LDS = CAMTAB_DOUBLES + 1;
+// The per-observation kernels walk their chunks with the NEXT chunk's observation record already in flight:
+// registers for (u, v, camera, point) of chunk n + 1 are loaded (unconditionally, index clamped) before chunk n is
+// processed, so each workgroup sees the streaming-load latency once instead of once per chunk.
+struct ObsRec { double u, v; int cam, pt; };
+__device__ __forceinline__ ObsRec load_obs(const double* __restrict__ obs_u, const double* __restrict__ obs_v,
+                                           const int* __restrict__ obs_cam, const int* __restrict__ obs_pt, int i) {
+  ObsRec r;
+  r.u = obs_u[i]; r.v = obs_v[i]; r.cam = obs_cam[i]; r.pt = obs_pt[i];
+  return r;
+}
+
 __device__ __forceinline__ void stage_camtab(double* sh_tab, const double* tab, int n_cams) {
   for (int i = threadIdx.x; i < n_cams * CAMTAB_DOUBLES; i += BLOCK)
     sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[i];
@@ -202,7 +213,7 @@ template <int NC>
 __global__ void __launch_bounds__(BLOCK)
 k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
-        int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams,
+        const int* __restrict__ chunk_pts, int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams,
         int loss, double f_scale, double* __restrict__ Vblk, double* __restrict__ gvec,
         double* __restrict__ partialU, double* __restrict__ partial_cost) {
   using UP = UPack<NC>;
@@ -217,16 +228,30 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   const double* px = xvec + lay.ncp_pad;
   double* gp = gvec + lay.ncp_pad;
   double cost = 0.0;
-  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+  const int last_obs = max(chunk_start[n_chunks] - 1, 0);
+  int ch = blockIdx.x;
+  int o0 = 0, o1 = 0;
+  ObsRec cur = {0.0, 0.0, 0, 0};
+  if (ch < n_chunks) {
+    o0 = chunk_start[ch]; o1 = chunk_start[ch + 1];
+    cur = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(o0 + (int)threadIdx.x, last_obs));
+  }
+  while (ch < n_chunks) {
+    const int nxt = ch + gridDim.x, nc = min(nxt, n_chunks - 1);
+    const int no0 = chunk_start[nc], no1 = chunk_start[nc + 1];
+    const ObsRec nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
+    // per-point phase inputs of point cp0 + tid, fetched ahead of the barrier they are used behind
+    const int cp0 = chunk_pts[2 * ch], npts = chunk_pts[2 * ch + 1];
+    const int pp = min(cp0 + (int)threadIdx.x, lay.P - 1);
+    const int pa = pt_start[pp] - o0, pb = pt_start[pp + 1] - o0;
     const int i = o0 + threadIdx.x;
     double pv[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) pv[q] = 0.0;
     if (i < o1) {
-      const int cam = obs_cam[i], pt = obs_pt[i];
+      const int cam = cur.cam, pt = cur.pt;
       double e[2], A[2][MAX_NC], B[2][3];
-      cost += obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss,
+      cost += obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss,
                                 f_scale, e, A, B);
       pv[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
       pv[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
@@ -252,26 +277,28 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
 #pragma unroll
     for (int q = 0; q < 9; ++q) sh_pt[q * CHUNK + threadIdx.x] = pv[q];
     __syncthreads();
-    const int cp0 = obs_pt[o0], npts = obs_pt[o1 - 1] - cp0 + 1;
-    for (int lp = threadIdx.x; lp < npts; lp += BLOCK) {
+    auto reduce_point = [&](int p, int a, int b) {
+      double acc[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+      for (int j = a; j < b; ++j) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] += sh_pt[q * CHUNK + j];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Vblk[(long)q * lay.Ppad + p] = acc[q];
+      gp[p] = acc[6];
+      gp[lay.Ppad + p] = acc[7];
+      gp[2 * lay.Ppad + p] = acc[8];
+    };
+    if ((int)threadIdx.x < npts && pb > pa) reduce_point(pp, pa, pb);
+    for (int lp = threadIdx.x + BLOCK; lp < npts; lp += BLOCK) {  // a range padded by unobserved points: rare
       const int p = cp0 + lp;
       const int a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
-      if (b > a) {
-        double acc[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) acc[q] = 0.0;
-        for (int j = a; j < b; ++j) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) acc[q] += sh_pt[q * CHUNK + j];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Vblk[(long)q * lay.Ppad + p] = acc[q];
-        gp[p] = acc[6];
-        gp[lay.Ppad + p] = acc[7];
-        gp[2 * lay.Ppad + p] = acc[8];
-      }
+      if (b > a) reduce_point(p, a, b);
     }
     __syncthreads();
+    cur = nx; o0 = no0; o1 = no1; ch = nxt;
   }
   double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
   for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
@@ -644,17 +671,27 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   const int wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   double2* stage = sh_stage + wv * WAVE * NP;
   bool fail = false;
-  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+  const int last_obs = max(chunk_start[n_chunks] - 1, 0);
+  int ch = blockIdx.x;
+  int o0 = 0, o1 = 0;
+  ObsRec cur = {0.0, 0.0, 0, 0};
+  if (ch < n_chunks) {
+    o0 = chunk_start[ch]; o1 = chunk_start[ch + 1];
+    cur = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(o0 + (int)threadIdx.x, last_obs));
+  }
+  while (ch < n_chunks) {
+    const int nxt = ch + gridDim.x, nc = min(nxt, n_chunks - 1);
+    const int no0 = chunk_start[nc], no1 = chunk_start[nc + 1];
+    const ObsRec nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
     const int i = o0 + threadIdx.x;
     double rec[REC];
 #pragma unroll
     for (int k = 0; k < REC; ++k) rec[k] = 0.0;
     if (i < o1) {
-      const int cam = obs_cam[i], pt = obs_pt[i];
+      const int cam = cur.cam, pt = cur.pt;
       const CamTab& ct = cam_at(sh_tab, cam);
       double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
-      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e, A, B);
+      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss, f_scale, e, A, B);
       const int np = (int)ct.nparams;
       double Vd[6], L[6];
 #pragma unroll
@@ -699,6 +736,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    cur = nx; o0 = no0; o1 = no1; ch = nxt;
   }
   if (fail) flags[1] = 1;
   __syncthreads();
@@ -1369,8 +1407,18 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     sp[lay.Ppad + p] = -x[1];
     sp[2 * lay.Ppad + p] = -x[2];
   };
-  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int o0 = chunk_start[ch], o1 = chunk_start[ch + 1];
+  const int last_obs = max(chunk_start[n_chunks] - 1, 0);
+  int ch = blockIdx.x;
+  int o0 = 0, o1 = 0;
+  ObsRec cur = {0.0, 0.0, 0, 0};
+  if (ch < n_chunks) {
+    o0 = chunk_start[ch]; o1 = chunk_start[ch + 1];
+    cur = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(o0 + (int)threadIdx.x, last_obs));
+  }
+  while (ch < n_chunks) {
+    const int nxt = ch + gridDim.x, nc = min(nxt, n_chunks - 1);
+    const int no0 = chunk_start[nc], no1 = chunk_start[nc + 1];
+    const ObsRec nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
     const int cp0 = chunk_pts[2 * ch], npts = chunk_pts[2 * ch + 1];
     const int i = o0 + threadIdx.x;
     // Inputs of the per-point phase for point cp0 + tid: fetched now (unconditionally, clamped), consumed after the
@@ -1385,9 +1433,9 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     for (int k = 0; k < 3; ++k) { dpp[k] = dp[(long)k * lay.Ppad + pp]; q[k] = gp[(long)k * lay.Ppad + pp]; }
     double t[3] = {0.0, 0.0, 0.0};
     if (i < o1) {
-      const int cam = obs_cam[i], pt = obs_pt[i];
+      const int cam = cur.cam, pt = cur.pt;
       double e[2], A[2][MAX_NC], B[2][3];
-      obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale,
+      obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss, f_scale,
                         e, A, B);
       const int np = (int)cam_at(sh_tab, cam).nparams;
       const double* dc = sh_dc + cam_off[cam];
@@ -1421,6 +1469,7 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
       }
     }
     __syncthreads();
+    cur = nx; o0 = no0; o1 = no1; ch = nxt;
   }
 }
 

@@ -864,7 +864,7 @@ static int run_build(cba_problem* p) {
   {
     ScopedTimer t(p, T_BUILD);
     hipLaunchKernelGGL(k_build<NC>, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                       p->obs_pt, p->pt_start, p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->C, p->loss, p->f_scale,
+                       p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->C, p->loss, p->f_scale,
                        p->V, p->g, p->partial, p->partial1);
   }
   {

