@@ -1421,16 +1421,20 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     const ObsRec nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
     const int cp0 = chunk_pts[2 * ch], npts = chunk_pts[2 * ch + 1];
     const int i = o0 + threadIdx.x;
-    // Inputs of the per-point phase for point cp0 + tid: fetched now (unconditionally, clamped), consumed after the
-    // barrier.  Fetched after it, their latency - three dependent global loads - was serial time with one wave
+    // Inputs of the per-point phase, fetched now and consumed after the barrier: wave 0 takes points cp0 .. cp0 + 63
+    // (a chunk of 10-observation points has ~25), unconditionally with clamped indices inside a wave-uniform branch.
+    // Fetched after the barrier, their latency - three dependent global loads - was serial time with one wave
     // working and three parked: 45 of the kernel's 96 us.
     const int pp = min(cp0 + (int)threadIdx.x, lay.P - 1);
-    const int pa = pt_start[pp] - o0, pb = pt_start[pp + 1] - o0;
-    double Vp[6], dpp[3], q[3];
+    int pa = 0, pb = 0;
+    double Vp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, dpp[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
+    if (threadIdx.x < WAVE) {
+      pa = pt_start[pp] - o0; pb = pt_start[pp + 1] - o0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Vp[k] = Vblk[(long)k * lay.Ppad + pp];
+      for (int k = 0; k < 6; ++k) Vp[k] = Vblk[(long)k * lay.Ppad + pp];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { dpp[k] = dp[(long)k * lay.Ppad + pp]; q[k] = gp[(long)k * lay.Ppad + pp]; }
+      for (int k = 0; k < 3; ++k) { dpp[k] = dp[(long)k * lay.Ppad + pp]; q[k] = gp[(long)k * lay.Ppad + pp]; }
+    }
     double t[3] = {0.0, 0.0, 0.0};
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
@@ -1451,11 +1455,11 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     sh_pt[CHUNK + threadIdx.x] = t[1];
     sh_pt[2 * CHUNK + threadIdx.x] = t[2];
     __syncthreads();
-    if ((int)threadIdx.x < npts && pb > pa) {
+    if (threadIdx.x < WAVE && (int)threadIdx.x < npts && pb > pa) {
       for (int j = pa; j < pb; ++j) { q[0] += sh_pt[j]; q[1] += sh_pt[CHUNK + j]; q[2] += sh_pt[2 * CHUNK + j]; }
       solve_point(pp, q, Vp, dpp);
     }
-    for (int lp = threadIdx.x + BLOCK; lp < npts; lp += BLOCK) {  // a range padded by unobserved points: rare
+    for (int lp = (threadIdx.x < WAVE ? threadIdx.x + BLOCK : threadIdx.x); lp < npts; lp += BLOCK) {  // points beyond the first 64
       const int p = cp0 + lp;
       const int a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
       if (b > a) {
