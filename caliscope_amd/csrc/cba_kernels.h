@@ -162,6 +162,34 @@ k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* _
     out[j] = tot;
   }
 }
+// Sharded solves: every host-visible primitive ends with ONE all-reduce of the scalars it produced.  k_xpack gathers
+// the scal slots named by `mask`, the four flags (as 0/1 doubles) and, when asked, this rank's max |g| (scal[4]) in
+// its own slot of a world-sized tail, so that a single sum-reduction carries sums, "any rank" flags and a maximum;
+// k_xunpack writes the results back where the single-rank code expects them.
+__global__ void k_xpack(const double* __restrict__ scal, const int* __restrict__ flags, unsigned long long mask, int with_max,
+                        int rank, int world, double* __restrict__ xbuf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0;
+  for (int s2 = 0; s2 < 32; ++s2)
+    if ((mask >> s2) & 1ull) xbuf[n++] = scal[s2];
+  for (int k = 0; k < 4; ++k) xbuf[n++] = flags[k] ? 1.0 : 0.0;
+  if (with_max)
+    for (int r = 0; r < world; ++r) xbuf[n++] = (r == rank) ? scal[4] : 0.0;
+}
+__global__ void k_xunpack(const double* __restrict__ xbuf, unsigned long long mask, int with_max, int world,
+                          double* __restrict__ scal, int* __restrict__ flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0;
+  for (int s2 = 0; s2 < 32; ++s2)
+    if ((mask >> s2) & 1ull) scal[s2] = xbuf[n++];
+  for (int k = 0; k < 4; ++k) flags[k] = xbuf[n++] > 0.5 ? 1 : 0;
+  if (with_max) {
+    double m = 0.0;
+    for (int r = 0; r < world; ++r) m = fmax(m, xbuf[n++]);
+    scal[4] = m;
+  }
+}
+
 // narrow case (width <= 4): one workgroup, every thread strides over the rows
 template <bool MAX>
 __global__ void __launch_bounds__(BLOCK)

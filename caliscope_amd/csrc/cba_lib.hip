@@ -87,6 +87,7 @@ struct cba_problem {
   int ldw = 0;             // row stride of the Cholesky work matrix Lbuf (multiple of 4 doubles)
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   double* scal = nullptr;  // device scalars
+  double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   int* flags = nullptr;
   double* h_scal = nullptr;  // pinned
   int* h_flags = nullptr;
@@ -180,16 +181,16 @@ static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
   NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, p->comm, p->stream));
   return CBA_OK;
 }
-static int allreduce_max(cba_problem* p, double* buf, size_t count) {
+// one all-reduce for the host-visible scalars of a primitive: scal slots in `mask`, the flags, optionally max |g|
+static int exchange(cba_problem* p, unsigned long long mask, bool with_max) {
   if (!p->comm) return CBA_OK;
-  NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclMax, p->comm, p->stream));
+  hipLaunchKernelGGL(k_xpack, dim3(1), dim3(64), 0, p->stream, p->scal, p->flags, mask, with_max ? 1 : 0, p->rank, p->world, p->xbuf);
+  const size_t n = (size_t)__builtin_popcountll(mask) + 4 + (with_max ? p->world : 0);
+  NCCLCHK(ncclAllReduce(p->xbuf, p->xbuf, n, ncclDouble, ncclSum, p->comm, p->stream));
+  hipLaunchKernelGGL(k_xunpack, dim3(1), dim3(64), 0, p->stream, p->xbuf, mask, with_max ? 1 : 0, p->world, p->scal, p->flags);
   return CBA_OK;
 }
-static int allreduce_flags(cba_problem* p) {
-  if (!p->comm) return CBA_OK;
-  NCCLCHK(ncclAllReduce(p->flags, p->flags, 4, ncclInt, ncclMax, p->comm, p->stream));
-  return CBA_OK;
-}
+#define SLOT(i) (1ull << (i))
 
 static inline int vec_grid(long total) { return (int)std::min<long>((total + BLOCK - 1) / BLOCK, 1024); }
 
@@ -772,7 +773,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 1) * 8));
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
-  TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4));
+  TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
   HIPCHK(hipMemset(p->flags, 0, 4 * sizeof(int)));
   HIPCHK(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
@@ -854,9 +855,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
   }
   ScopedTimer t(p, T_VECTOR);
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, grid, 1, p->scal + slot);
-  int rc = allreduce_sum(p, p->scal + slot, 1);
-  if (rc) return rc;
-  return allreduce_flags(p);
+  return CBA_OK;  // sharded solves: the caller's exchange() sums scal[slot] and the flags over the ranks
 }
 
 template <int NC>
@@ -873,8 +872,7 @@ static int run_build(cba_problem* p) {
     hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, p->Upacked);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
     int rc = allreduce_sum(p, p->Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
-    if (!rc) rc = allreduce_sum(p, p->scal + 8, 1);
-    if (rc) return rc;
+    if (rc) return rc;                                 // (the rho sum in scal[8] rides with the linearisation's exchange)
     hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->Upacked,
                        p->cam_off, p->cam_np, p->C, p->g);
   }
@@ -892,7 +890,7 @@ static int run_jv(cba_problem* p, int nv) {
     hipLaunchKernelGGL((k_jv<NC, 2>), dim3(grid), dim3(BLOCK), lds_jv(p, 2), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                        p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, grid, 4, p->scal + 12);
-  return allreduce_sum(p, p->scal + 12, 4);
+  return CBA_OK;  // scal[12..15] are summed over the ranks by the caller's exchange()
 }
 
 template <int NC>
@@ -911,15 +909,15 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
                        p->rank == 0 ? 1 : 0, p->v1, p->partial4, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
     hipLaunchKernelGGL(k_reduce_narrow<true>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
-    int rc0 = allreduce_sum(p, p->scal + 0, 4);
-    if (!rc0) rc0 = allreduce_max(p, p->scal + 4, 1);
-    if (rc0) return rc0;
   }
   {
     int rcj = run_jv<NC>(p, 1);
     if (rcj) return rcj;
   }
-  int rc = sync_scalars(p, 16);
+  // sums of the linearisation (scal[0..3]), rho sum (8), ||J v||^2 terms (12..15), max |g| (4): one all-reduce
+  int rc = exchange(p, SLOT(0) | SLOT(1) | SLOT(2) | SLOT(3) | SLOT(8) | SLOT(12) | SLOT(13) | SLOT(14) | SLOT(15), true);
+  if (rc) return rc;
+  rc = sync_scalars(p, 16);
   if (rc) return rc;
   p->first_scale = false;
   p->gh_sq = p->h_scal[0];
@@ -1038,8 +1036,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     if (rcv) return rcv;
     hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->scal + 17, p->gh_sq, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
-    rcv = allreduce_sum(p, p->scal + 20, 1);
-    if (!rcv) rcv = allreduce_flags(p);
+    rcv = exchange(p, SLOT(20), false);  // ||w||^2 and the flags
     if (rcv) return rcv;
   }
   rc = sync_scalars(p, 24);
@@ -1080,6 +1077,8 @@ static int begin_common(cba_problem* p, double* cost_out) {
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
   int rc = launch_cost(p, p->x, p->tab, 24, nullptr);
+  if (rc) return rc;
+  rc = exchange(p, SLOT(24), false);
   if (rc) return rc;
   rc = sync_scalars(p, 32);
   if (rc) return rc;
@@ -1124,7 +1123,8 @@ int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2
     hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a2, b2, tot, p->v2);
   }
   DISPATCH_NC(p, run_jv<6>(p, 2), run_jv<9>(p, 2));
-  int rc = sync_scalars(p, 16);
+  int rc = exchange(p, SLOT(12) | SLOT(13) | SLOT(14) | SLOT(15), false);
+  if (!rc) rc = sync_scalars(p, 16);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   gram_out[0] = p->h_scal[12]; gram_out[1] = p->h_scal[13]; gram_out[2] = p->h_scal[14];
@@ -1143,11 +1143,11 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) {
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
                        p->rank == 0 ? 1 : 0, p->x_new, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
-    int rct = allreduce_sum(p, p->scal + 28, 1);
-    if (rct) return rct;
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
   int rc = launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
+  if (rc) return rc;
+  rc = exchange(p, SLOT(24) | SLOT(28), false);  // trial cost, ||step||^2, flags
   if (rc) return rc;
   rc = sync_scalars(p, 32);
   if (rc) return rc;
@@ -1245,7 +1245,8 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
     launch_cost(p, p->v2, p->tab_new, 24, d_r);
     e = hipMemcpyAsync(r_out, d_r, (size_t)2 * p->N * sizeof(double), hipMemcpyDeviceToHost, p->stream);
   }
-  int rc = (e == hipSuccess) ? sync_scalars(p, 32) : fail(CBA_ERR_HIP, "cba_residuals: %s", hipGetErrorString(e));
+  int rc = (e == hipSuccess) ? exchange(p, SLOT(24), false) : fail(CBA_ERR_HIP, "cba_residuals: %s", hipGetErrorString(e));
+  if (!rc) rc = sync_scalars(p, 32);
   (void)hipFree(d_r);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
