@@ -674,7 +674,10 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 // k_tprep evaluates every observation ONCE (the LDS-tile kernel re-linearises an observation in each of the
 // G tiles it takes part in), stores T_i as a 16-byte aligned record of REC doubles in HBM (144 B per
 // observation) and reduces the rhs per camera (LDS atomics, per-workgroup partials, k_reduce_rows).
-template <int NC> struct SchurRec { static constexpr int REC = (3 * NC + 1) & ~1; };
+// REC doubles per record: 3 NC rounded up to an ODD number of 16-byte pieces (18 for NC = 6, 30 for NC = 9), so that
+// the pieces of different records spread over all LDS banks.
+template <int NC> struct SchurRec { static constexpr int REC = 2 * ((((3 * NC + 1) / 2) & 1) ? (3 * NC + 1) / 2 : (3 * NC + 1) / 2 + 1); };
+static_assert(SchurRec<6>::REC == 18 && SchurRec<9>::REC == 30, "record sizes");
 constexpr int PAIRCAP = 2048;  // pairs of one chunk, staged in LDS (the plan closes a chunk before it overflows)
 
 template <int NC>
@@ -782,18 +785,19 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
 // camera k mod na and receives a share of that camera's (i, i) items (and of its duplicate-row pairs, listed in
 // both orders).  The next chunk's records, pair list and slice bounds are fetched into registers while the
 // current chunk's pairs are multiplied.  Results leave through per-workgroup partials (k_reg_reduce).
+// NC = 6 runs SPLIT = 1, NC = 9 SPLIT = 3 (768 threads, 3 x 9 accumulators per thread, one workgroup = 12 waves per CU).
 // SPLIT = 1: 256 threads, one whole block (NC x NC accumulators, ~230 VGPRs, two workgroups = 8 waves per CU).
 // SPLIT = 2: 512 threads, thread tid accumulates rows [h*NC/2, (h+1)*NC/2) of block tid % 256, h = tid / 256
 // (<= 128 VGPRs, 16 waves per CU).  Measured on cfg4: SPLIT = 2 is 15 % slower (every pair iteration's fixed cost -
 // pair decode, T_j reads - is paid twice), so SPLIT = 1 is what the library launches.
-template <int NC, int SPLIT>
-__global__ void __launch_bounds__(BLOCK * SPLIT, 2 * SPLIT)
+template <int NC, int SPLIT, int MINW>
+__global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
 k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, int debug_skip) {
   constexpr int REG_BLOCK = BLOCK * SPLIT;
   constexpr int REC = SchurRec<NC>::REC;
   constexpr int NP = REC / 2;                                   // 16-byte pieces per record
   constexpr int NLD = (CHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;  // gather loads per thread
-  constexpr int NPV = PAIRCAP / REG_BLOCK;
+  constexpr int NPV = (PAIRCAP + REG_BLOCK - 1) / REG_BLOCK;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;                  // rows per thread
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_T = sh;                                            // [CHUNK][REC] (+ slack for the last partial load round)

@@ -62,7 +62,7 @@ struct cba_problem {
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   bool schur_lds = true;   // Sacc always lives in LDS tiles
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  bool schur_reg = false;  // register-accumulating Schur kernel (6-parameter cameras)
+  bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg); false: LDS-atomic tile kernel
   long tile_stream_len = 0, n_pairs = 0;
   TilePlan tp{};
   int* tile_wg_begin = nullptr;
@@ -290,12 +290,19 @@ template <int NC> static size_t lds_schur_tile(int g) {
   const size_t gn = (size_t)g * NC;
   return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * tile_ld(g, NC)) * 8 + ((size_t)4 * g + CHUNK) * sizeof(int);
 }
-constexpr int kRegSplit = 1;  // rows of a camera-pair block per thread = NC / kRegSplit (see k_schur_reg)
+// Register-accumulating Schur kernel per camera width: rows of a camera-pair block per thread = NC / SPLIT, minimum waves
+// per SIMD the kernel is compiled for, resident workgroups per CU the plan sizes its grid for (see k_schur_reg).
+template <int NC> struct RegCfg;
+template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
+template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_schur_reg(int) {
-  constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * kRegSplit, NLD = (CHUNK * NP + RB - 1) / RB;
-  return (size_t)NLD * RB * 16 + (size_t)PAIRCAP * sizeof(unsigned short);
+  constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * RegCfg<NC>::SPLIT, NLD = (CHUNK * NP + RB - 1) / RB;
+  constexpr int NPV = (PAIRCAP + RB - 1) / RB;
+  return (size_t)NLD * RB * 16 + (size_t)NPV * RB * sizeof(unsigned short);
 }
-static size_t lds_tprep(const cba_problem* p) { return ((size_t)BLOCK * SchurRec<6>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8; }
+template <int NC> static size_t lds_tprep(const cba_problem* p) {
+  return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
+}
 constexpr size_t kSchurLdsBudget = 144 * 1024;
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
@@ -540,10 +547,10 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   }
   TCB[nT] = (int)CS.size() - 1;
   // the register kernel fetches whole rounds without bounds checks: keep the streams readable past the end
-  if (reg) { PR.resize(PR.size() + PAIRCAP, 0); OB.resize(OB.size() + CHUNK, 0); }
+  if (reg) { PR.resize(PR.size() + 2 * PAIRCAP, 0); OB.resize(OB.size() + 2 * CHUNK, 0); }
   p->n_tile_chunks = TCB[nT];
   p->tile_stream_len = (long)PT.size();
-  p->n_pairs = (long)PR.size() - (reg ? PAIRCAP : 0);
+  p->n_pairs = (long)PR.size() - (reg ? 2 * PAIRCAP : 0);
   // workgroups: proportional to the chunk count of each tile, at least one per tile
   std::vector<long> nch(nT);
   for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
@@ -630,15 +637,15 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
   int gmax = 1;
   const char* force_tile = std::getenv("CBA_SCHUR");
-  p->schur_reg = (NC == 6) && !(force_tile && std::strcmp(force_tile, "lds") == 0);
+  p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
   if (p->schur_reg) gmax = std::min(p->C, kSchurRegMaxGroup);
   else while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
   p->G = (p->C + gmax - 1) / gmax;
   p->gsz = (p->C + p->G - 1) / p->G;
   p->n_tiles = p->G * (p->G + 1) / 2;
   if (p->schur_reg) {
-    if ((rc = allow_lds(k_schur_reg<NC, kRegSplit>, lds_schur_reg<NC>(p->gsz)))) return rc;
-    if ((rc = allow_lds(k_tprep<NC>, lds_tprep(p)))) return rc;
+    if ((rc = allow_lds(k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, lds_schur_reg<NC>(p->gsz)))) return rc;
+    if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   }
   else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
@@ -750,9 +757,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const size_t tile_lds = p->schur_reg ? lds_schur_reg<6>(p->gsz) : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
+    const size_t tile_lds = p->schur_reg ? ((nct == 9) ? lds_schur_reg<9>(p->gsz) : lds_schur_reg<6>(p->gsz))
+                                         : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
-    if (p->schur_reg) per_cu = std::min(per_cu, 2);  // k_schur_reg<6>: registers allow two workgroups per CU
+    if (p->schur_reg) per_cu = std::min(per_cu, (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // register budget
     const int resident = cus * per_cu;  // no partial last round
     rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
     if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) { p->schur_reg = false; continue; }  // a point with > PAIRCAP pairs in one tile
@@ -766,7 +774,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   if (p->schur_reg) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
-    TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * SchurRec<6>::REC));
+    TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * ((nct == 9) ? SchurRec<9>::REC : SchurRec<6>::REC)));
     TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
   }
   TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); p->ldw = (ncp + 3) & ~3;
@@ -983,16 +991,14 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_SCHUR);
-    if constexpr (NC == 6) {
-      if (p->schur_reg) {
-        hipLaunchKernelGGL((k_tprep<NC>), dim3(p->grid), dim3(BLOCK), lds_tprep(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
-                           p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, p->V, p->g,
-                           p->sinv, p->Trec, p->partial_b, p->flags);
-        hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
-                           p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
-        hipLaunchKernelGGL((k_schur_reg<NC, kRegSplit>), dim3(p->tile_grid), dim3(BLOCK * kRegSplit), lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec,
-                           p->partial, p->debug_skip);
-      }
+    if (p->schur_reg) {
+      hipLaunchKernelGGL((k_tprep<NC>), dim3(p->grid), dim3(BLOCK), lds_tprep<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
+                         p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, p->V, p->g,
+                         p->sinv, p->Trec, p->partial_b, p->flags);
+      hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
+                         p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
+      hipLaunchKernelGGL((k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
+                         lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
     }
     if (!p->schur_reg)
       hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,

@@ -163,8 +163,8 @@ typedef struct {
   int32_t n_cams, n_points, n_cam_params, n_params;
   int64_t n_obs;
   int32_t n_chunks, grid_blocks;
-  int32_t schur_in_lds;   /* 1: Schur tiles accumulated with LDS atomics (9-parameter cameras); 0: in registers, one
-                             thread per camera-pair block (6-parameter cameras) */
+  int32_t schur_in_lds;   /* 0: Schur blocks accumulated in registers, one thread per camera-pair block (the default);
+                             1: LDS-atomic tile kernel (CBA_SCHUR=lds, or a point with > 2048 pairs in one tile) */
   int32_t max_obs_per_point;
   int64_t device_bytes;
   int32_t schur_groups;   /* G camera groups -> G(G+1)/2 tiles */

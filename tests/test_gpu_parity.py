@@ -5,6 +5,8 @@ relative; (ii) step parity — the damped Gauss-Newton step of one (x, lam) agai
 (iii) converged parity — full solves against the reference's scipy call, gauge-aligned <= 1e-6 relative,
 cost equal to 1e-8 relative, RMS reprojection error within 1e-4 px.
 """
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -49,7 +51,7 @@ CASES = {
     "huber_outliers_C8": dict(n_cams=8, n_points=400, k=8, loss="huber", outliers=0.05),
     "softl1_outliers_C5": dict(n_cams=5, n_points=300, k=5, loss="soft_l1", outliers=0.05),
     "global_atomics_C24": dict(n_cams=24, n_points=600, k=10),
-    "refine_global_C16": dict(n_cams=16, n_points=400, k=8, refine=True),
+    "refine_global_C20": dict(n_cams=20, n_points=400, k=8, refine=True),
 }
 
 
@@ -114,8 +116,9 @@ def test_step_parity(name):
     assert _rel(hip.get_vector(4), ora.scale_inv) < (1e-12 if loss == "linear" else 1e-7)  # scale_inv (see note above)
     assert np.abs(hip.get_vector(2) - ora.g).max() < 1e-11 * np.abs(ora.g).max()
     info = hip.info()
-    assert info["schur_in_lds"] == (1 if any(b.n_params == 9 for b in par.blocks) else 0)
-    assert (info["schur_groups"] > 1) == ("global" in name), info  # the *_global_* cases need several LDS tiles
+    # register-accumulating Schur kernel for 6- and 9-parameter cameras unless the LDS-atomic fallback is forced
+    assert info["schur_in_lds"] == (1 if os.environ.get("CBA_SCHUR") == "lds" else 0)
+    assert (info["schur_groups"] > 1) == ("global" in name), info  # the *_global_* cases span several camera groups
     for lam in (1e-3, 1e-7):
         sh, so = hip.newton_step(lam), ora.newton_step(lam)
         assert sh.ok and so.ok
