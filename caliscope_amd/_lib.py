@@ -63,6 +63,20 @@ class Info(C.Structure):
     ]
 
 
+class TriangulateDesc(C.Structure):
+    _fields_ = [
+        ("n_cams", C.c_int32),
+        ("cam_model", c_int32_p),
+        ("cam_intr", c_double_p),
+        ("cam_P", c_double_p),
+        ("n_points", C.c_int64),
+        ("pt_start", c_int64_p),
+        ("obs_cam", c_int32_p),
+        ("obs_xy", c_double_p),
+        ("float32_io", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes): every symbol include/caliscope_ba.h declares
 SIGNATURES = {
     "cba_create": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(Options), C.POINTER(C.c_void_p)]),
@@ -88,6 +102,7 @@ SIGNATURES = {
     "cba_reset_timers": (C.c_int, [C.c_void_p]),
     "cba_enable_timers": (C.c_int, [C.c_void_p, C.c_int32]),
     "cba_host_plan": (C.c_int64, [C.c_int32, C.c_int64, c_int32_p, c_int32_p, C.c_int32, C.c_int32, c_int64_p, c_int64_p, c_int64_p]),
+    "cba_triangulate": (C.c_int, [C.POINTER(TriangulateDesc), C.c_int32, c_double_p, c_double_p]),
     "cba_last_error": (C.c_char_p, []),
     "cba_version": (C.c_int, []),
     "cba_device_count": (C.c_int, []),

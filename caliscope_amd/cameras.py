@@ -88,6 +88,19 @@ class CameraData:
         """Camera centre in world coordinates, ``-R^T t``."""
         return -np.asarray(self.rotation).T @ np.asarray(self.translation).ravel()
 
+    @property
+    def normalized_projection_matrix(self) -> np.ndarray:
+        """``[R | t]`` (3 x 4): projection to the normalised image plane (reference camera_array.py, same name)."""
+        if self.rotation is None or self.translation is None:
+            raise ValueError(f"Camera {self.cam_id} has no pose")
+        return np.hstack([np.asarray(self.rotation, dtype=np.float64), np.asarray(self.translation, dtype=np.float64).reshape(3, 1)])
+
+    def undistort_points(self, points, *, output="normalized"):
+        """Remove lens distortion (reference camera_array.py:135-174); runs on the device (caliscope_amd.triangulation)."""
+        from caliscope_amd.triangulation import undistort_points
+
+        return undistort_points(self, points, output=output)
+
 
 @dataclass
 class CameraArray:
@@ -110,6 +123,11 @@ class CameraArray:
     @property
     def posed_index_to_cam_id(self) -> Dict[int, int]:
         return {i: c for c, i in self.posed_cam_id_to_index.items()}
+
+    @property
+    def normalized_projection_matrices(self) -> Dict[int, np.ndarray]:
+        """cam_id -> ``[R | t]`` for the posed, non-ignored cameras (reference camera_array.py:368-375)."""
+        return {c: self.cameras[c].normalized_projection_matrix for c in self.posed_cam_id_to_index}
 
     def __getitem__(self, cam_id: int) -> CameraData:
         return self.cameras[cam_id]

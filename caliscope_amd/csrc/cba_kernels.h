@@ -1561,4 +1561,131 @@ __global__ void k_fill(double* __restrict__ p, double v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Undistortion + DLT triangulation, one thread per world point (include/caliscope_ba.h: cba_triangulate).
+// Pinhole: OpenCV's five fixed-point iterations  x <- (x0 - delta(x)) / cdist(x).  Fisheye: Newton on
+// theta_d = theta (1 + k1 theta^2 + ...), at most 10 steps, stop below 1e-8, theta_d clipped to [-pi/2, pi/2].
+__device__ __forceinline__ void undistort_one(int model, const double* __restrict__ in9, double u, double v, int f32, double* xo,
+                                              double* yo) {
+  if (f32) { u = (double)(float)u; v = (double)(float)v; }
+  const double fx = in9[0], fy = in9[1], cx = in9[2], cy = in9[3];
+  const double x0 = (u - cx) / fx, y0 = (v - cy) / fy;
+  double x = x0, y = y0;
+  if (model == 0) {
+    const double k1 = in9[4], k2 = in9[5], p1 = in9[6], p2 = in9[7], k3 = in9[8];
+    for (int it = 0; it < 5; ++it) {
+      const double r2 = x * x + y * y;
+      const double icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      const double dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+      const double dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+      x = (x0 - dx) * icd;
+      y = (y0 - dy) * icd;
+    }
+  } else {
+    const double k1 = in9[4], k2 = in9[5], k3 = in9[6], k4 = in9[7];
+    const double hp = 1.5707963267948966;
+    double td = sqrt(x0 * x0 + y0 * y0);
+    td = fmin(fmax(td, -hp), hp);
+    double scale = 1.0;
+    if (td > 1e-8) {
+      double th = td;
+      for (int it = 0; it < 10; ++it) {
+        const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+        const double fix = (th * (1.0 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8) - td) /
+                           (1.0 + 3.0 * k1 * t2 + 5.0 * k2 * t4 + 7.0 * k3 * t6 + 9.0 * k4 * t8);
+        th -= fix;
+        if (fabs(fix) < 1e-8) break;
+      }
+      scale = tan(th) / td;
+    }
+    x = x0 * scale;
+    y = y0 * scale;
+  }
+  if (f32) { x = (double)(float)x; y = (double)(float)y; }
+  *xo = x; *yo = y;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_triangulate(long n_points, const long* __restrict__ pt_start, const int* __restrict__ obs_cam, const double* __restrict__ obs_xy,
+              const int* __restrict__ cam_model, const double* __restrict__ cam_intr, const double* __restrict__ cam_P, int f32,
+              double* __restrict__ xyz, double* __restrict__ undist) {
+  const long q = (long)blockIdx.x * BLOCK + threadIdx.x;
+  if (q >= n_points) return;
+  const long a = pt_start[q], b = pt_start[q + 1];
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  double M[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) M[r][c] = 0.0;
+  for (long i = a; i < b; ++i) {
+    const int cam = obs_cam[i];
+    double x = obs_xy[2 * i], y = obs_xy[2 * i + 1];
+    if (cam_intr) undistort_one(cam_model[cam], cam_intr + 9 * cam, x, y, f32, &x, &y);
+    if (undist) { undist[2 * i] = x; undist[2 * i + 1] = y; }
+    const double* P = cam_P + 12 * cam;
+    double r0[4], r1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { r0[c] = x * P[8 + c] - P[c]; r1[c] = y * P[8 + c] - P[4 + c]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = r; c < 4; ++c) M[r][c] += r0[r] * r0[c] + r1[r] * r1[c];
+  }
+  if (b - a < 2) { xyz[3 * q] = xyz[3 * q + 1] = xyz[3 * q + 2] = nan; return; }
+#pragma unroll
+  for (int r = 1; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < r; ++c) M[r][c] = M[c][r];
+  // cyclic Jacobi on the symmetric 4 x 4; V accumulates the rotations (columns = eigenvectors)
+  double V[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int r = p + 1; r < 4; ++r) off += M[p][r] * M[p][r];
+    const double diag = M[0][0] * M[0][0] + M[1][1] * M[1][1] + M[2][2] * M[2][2] + M[3][3] * M[3][3];
+    if (off <= 1e-34 * diag) break;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int r = p + 1; r < 4; ++r) {
+        const double apq = M[p][r];
+        if (apq != 0.0) {
+          const double theta = (M[r][r] - M[p][p]) / (2.0 * apq);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // columns p, r of M and V
+            const double mkp = M[k][p], mkr = M[k][r];
+            M[k][p] = c * mkp - s * mkr; M[k][r] = s * mkp + c * mkr;
+            const double vkp = V[k][p], vkr = V[k][r];
+            V[k][p] = c * vkp - s * vkr; V[k][r] = s * vkp + c * vkr;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // rows p, r of M
+            const double mpk = M[p][k], mrk = M[r][k];
+            M[p][k] = c * mpk - s * mrk; M[r][k] = s * mpk + c * mrk;
+          }
+        }
+      }
+  }
+  int best = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (M[k][k] < M[best][best]) best = k;
+  double w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = (best == 0) ? V[k][0] : (best == 1) ? V[k][1] : (best == 2) ? V[k][2] : V[k][3];
+  xyz[3 * q] = w[0] / w[3];
+  xyz[3 * q + 1] = w[1] / w[3];
+  xyz[3 * q + 2] = w[2] / w[3];
+}
+
 }  // namespace cba

@@ -197,6 +197,51 @@ static inline int vec_grid(long total) { return (int)std::min<long>((total + BLO
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
+int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_out, double* undistorted_out) {
+  if (!d || !xyz_out) return fail(CBA_ERR_INVALID, "cba_triangulate: null argument");
+  if (d->n_cams <= 0 || d->n_points < 0 || !d->cam_P || (d->n_points > 0 && (!d->pt_start || !d->obs_cam || !d->obs_xy)))
+    return fail(CBA_ERR_INVALID, "cba_triangulate: bad descriptor");
+  if (d->cam_intr && !d->cam_model) return fail(CBA_ERR_INVALID, "cba_triangulate: cam_intr given without cam_model");
+  if (d->n_points == 0) return CBA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(CBA_ERR_NO_DEVICE, "cba_triangulate: no HIP device");
+  if (device < 0 || device >= ndev) return fail(CBA_ERR_INVALID, "cba_triangulate: device %d of %d", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  const int64_t n_obs = d->pt_start[d->n_points];
+  for (int64_t i = 0; i < n_obs; ++i)
+    if (d->obs_cam[i] < 0 || d->obs_cam[i] >= d->n_cams) return fail(CBA_ERR_INVALID, "cba_triangulate: obs_cam[%lld] out of range", (long long)i);
+  std::vector<void*> bufs;
+  auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); };
+  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, std::max<size_t>(bytes, 8)) != hipSuccess) return CBA_ERR_HIP;
+    bufs.push_back(ptr);
+    if (src && bytes && hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CBA_ERR_HIP;
+    *dst = ptr;
+    return CBA_OK;
+  };
+  void *dps = nullptr, *dcam = nullptr, *dxy = nullptr, *dmodel = nullptr, *dintr = nullptr, *dP = nullptr, *dxyz = nullptr, *dund = nullptr;
+  int rc = up(d->pt_start, (size_t)(d->n_points + 1) * sizeof(int64_t), &dps);
+  if (!rc) rc = up(d->obs_cam, (size_t)n_obs * sizeof(int32_t), &dcam);
+  if (!rc) rc = up(d->obs_xy, (size_t)n_obs * 2 * sizeof(double), &dxy);
+  if (!rc) rc = up(d->cam_P, (size_t)d->n_cams * 12 * sizeof(double), &dP);
+  if (!rc && d->cam_intr) rc = up(d->cam_intr, (size_t)d->n_cams * 9 * sizeof(double), &dintr);
+  if (!rc && d->cam_intr) rc = up(d->cam_model, (size_t)d->n_cams * sizeof(int32_t), &dmodel);
+  if (!rc) rc = up(nullptr, (size_t)d->n_points * 3 * sizeof(double), &dxyz);
+  if (!rc && undistorted_out) rc = up(nullptr, (size_t)n_obs * 2 * sizeof(double), &dund);
+  if (rc) { cleanup(); return fail(CBA_ERR_HIP, "cba_triangulate: device allocation / upload failed"); }
+  static_assert(sizeof(long) == sizeof(int64_t), "pt_start is passed as long");
+  const int grid = (int)((d->n_points + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL(k_triangulate, dim3(grid), dim3(BLOCK), 0, 0, (long)d->n_points, (const long*)dps, (const int*)dcam, (const double*)dxy,
+                     (const int*)dmodel, (const double*)dintr, (const double*)dP, d->float32_io ? 1 : 0, (double*)dxyz, (double*)dund);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(xyz_out, dxyz, (size_t)d->n_points * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && undistorted_out) e = hipMemcpy(undistorted_out, dund, (size_t)n_obs * 2 * sizeof(double), hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(CBA_ERR_HIP, "cba_triangulate: %s", hipGetErrorString(e));
+  return CBA_OK;
+}
+
 const char* cba_last_error(void) { return g_last_error.c_str(); }
 int cba_version(void) { return CBA_VERSION; }
 int cba_device_count(void) {

@@ -3,8 +3,8 @@
 Mirrors the containers the reference's ``CaptureVolume.optimize`` reads
 (``core/point_data.py:256-276`` column schemas, ``:323-373`` ImagePoints, WorldPoints):
 validated, copy-on-read pandas DataFrames with the same column names, plus the same CSV
-round-trip (``from_csv`` / ``to_csv``).  Triangulation, gap filling and smoothing are upstream
-of the path and out of scope.
+round-trip (``from_csv`` / ``to_csv``).  ``ImagePoints.triangulate`` (``:416-559``) is provided through
+``caliscope_amd.triangulation`` (device kernel); gap filling and smoothing are upstream of the path and out of scope.
 """
 
 from __future__ import annotations
@@ -72,6 +72,13 @@ class ImagePoints:
     def to_csv(self, path: str | Path) -> None:
         Path(path).parent.mkdir(parents=True, exist_ok=True)
         self._df.to_csv(path, index=False, float_format="%.6f")
+
+    def triangulate(self, camera_array, static_object_ids=frozenset()) -> "WorldPoints":
+        """Undistort + DLT-triangulate every (sync_index, object_id, keypoint_id) seen by two or more posed cameras
+        (reference ``core/point_data.py:416-559``), on the MI355X."""
+        from caliscope_amd.triangulation import triangulate
+
+        return triangulate(self, camera_array, static_object_ids)
 
 
 class WorldPoints:

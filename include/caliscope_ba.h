@@ -192,6 +192,31 @@ int cba_enable_timers(cba_problem* p, int32_t on);
 int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
                       int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out);
 
+/* ---- the step before the path: undistortion + batched DLT triangulation (x0 of the world points) ----
+ *
+ * Replaces, for one batch of 3-D points, `CameraData.undistort_points(points, output="normalized")`
+ * (reference cameras/camera_array.py:135-174: cv2.undistortPoints / cv2.fisheye.undistortPoints with P = I on
+ * float32 arrays) and `triangulate_image_points` (core/point_data.py:121-229: per point the 2k x 4 DLT matrix with
+ * rows x P[2] - P[0], y P[2] - P[1], smallest right-singular vector).  One GPU thread per point; the singular
+ * vector is the eigenvector of the smallest eigenvalue of A^T A (4 x 4, cyclic Jacobi).
+ * Observations of a point are contiguous: point q owns obs_cam/obs_xy[pt_start[q] .. pt_start[q+1]).
+ * cam_intr == NULL: obs_xy already holds undistorted normalised coordinates (the reference function's own input).
+ * Points with fewer than two observations get NaN. */
+typedef struct {
+  int32_t n_cams;
+  const int32_t* cam_model;  /* [n_cams] 0 = pinhole + Brown-Conrady 5, 1 = fisheye 4; ignored when cam_intr == NULL */
+  const double* cam_intr;    /* [n_cams][9]  fx fy cx cy d0 d1 d2 d3 d4, or NULL */
+  const double* cam_P;       /* [n_cams][12] normalised projection matrix [R | t], row-major */
+  int64_t n_points;
+  const int64_t* pt_start;   /* [n_points + 1] */
+  const int32_t* obs_cam;    /* [n_obs] camera index in [0, n_cams) */
+  const double* obs_xy;      /* [n_obs][2] */
+  int32_t float32_io;        /* 1: round the pixel input and the normalised output to float32 like the reference's cv2 calls */
+} cba_triangulate_desc;
+
+/* xyz_out [n_points][3]; undistorted_out [n_obs][2] or NULL.  device = HIP device ordinal. */
+int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_out, double* undistorted_out);
+
 const char* cba_last_error(void);
 int cba_version(void);
 int cba_device_count(void);
