@@ -135,7 +135,52 @@ class CameraArray:
     def __setitem__(self, cam_id: int, camera: CameraData) -> None:
         self.cameras[cam_id] = camera
 
-    # -- persistence (reader only; reference camera_array.py:377-441) -------------------------
+    def to_toml(self, path: Path | str) -> None:
+        """Save to ``camera_array.toml`` (reference camera_array.py:443-487): rotations as Rodrigues vectors, ``None``
+        fields omitted, atomic write."""
+        from caliscope_amd.persistence import PersistenceError, safe_write_toml
+
+        path = Path(path)
+        try:
+            path.parent.mkdir(parents=True, exist_ok=True)
+            cams = {}
+            for cam_id, cam in self.cameras.items():
+                entry = {
+                    "cam_id": cam.cam_id, "size": list(cam.size), "rotation_count": cam.rotation_count, "error": cam.error,
+                    "matrix": None if cam.matrix is None else np.asarray(cam.matrix, dtype=np.float64).tolist(),
+                    "distortions": None if cam.distortions is None else np.asarray(cam.distortions, dtype=np.float64).ravel().tolist(),
+                    "translation": None if cam.translation is None else np.asarray(cam.translation, dtype=np.float64).ravel().tolist(),
+                    "rotation": None if cam.rotation is None else matrix_to_rvec(cam.rotation).tolist(),
+                    "exposure": cam.exposure, "grid_count": cam.grid_count, "fisheye": bool(cam.fisheye),
+                }
+                cams[str(cam_id)] = {k: v for k, v in entry.items() if v is not None}
+            safe_write_toml({"cameras": cams}, path)
+        except Exception as exc:
+            raise PersistenceError(f"Failed to save CameraArray to {path}: {exc}") from exc
+
+    def to_aniposelib_toml(self, path: Path | str) -> None:
+        """aniposelib-compatible export of the posed cameras (reference camera_array.py:489-534)."""
+        from caliscope_amd.persistence import PersistenceError, safe_write_toml
+
+        path = Path(path)
+        try:
+            path.parent.mkdir(parents=True, exist_ok=True)
+            data: dict = {}
+            for cam_id, cam in self.posed_cameras.items():
+                data[f"cam_{cam_id}"] = {k: v for k, v in {
+                    "name": f"cam_{cam_id}", "size": [int(cam.size[0]), int(cam.size[1])],
+                    "matrix": None if cam.matrix is None else np.asarray(cam.matrix, dtype=np.float64).tolist(),
+                    "distortions": None if cam.distortions is None else np.asarray(cam.distortions, dtype=np.float64).ravel().tolist(),
+                    "rotation": matrix_to_rvec(cam.rotation).tolist(),
+                    "translation": np.asarray(cam.translation, dtype=np.float64).ravel().tolist(),
+                    "fisheye": bool(cam.fisheye),
+                }.items() if v is not None}
+            data["metadata"] = {"adjusted": False, "error": 0.0}
+            safe_write_toml(data, path)
+        except Exception as exc:
+            raise PersistenceError(f"Failed to save aniposelib CameraArray to {path}: {exc}") from exc
+
+    # -- persistence (reference camera_array.py:377-534) ------------------------------------------
     @classmethod
     def from_toml(cls, path: Path | str) -> "CameraArray":
         import tomli

@@ -97,6 +97,27 @@ class CaptureVolume:
         merged = self.image_points._df[_KEY].merge(world, on=_KEY, how="left")
         return merged["world_idx"].fillna(-1).to_numpy(dtype=np.int32)
 
+    # -- persistence (reference :237-267) -------------------------------------------------------------
+    def save(self, directory) -> None:
+        """Write ``camera_array.toml``, ``image_points.csv``, ``world_points.csv`` (atomic writes).  As in the reference,
+        ``optimization_status`` is not persisted; constraint sets are not supported here."""
+        from pathlib import Path
+
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        self.camera_array.to_toml(directory / "camera_array.toml")
+        self.image_points.to_csv(directory / "image_points.csv")
+        self.world_points.to_csv(directory / "world_points.csv")
+
+    @classmethod
+    def load(cls, directory) -> "CaptureVolume":
+        from pathlib import Path
+
+        directory = Path(directory)
+        return cls(camera_array=CameraArray.from_toml(directory / "camera_array.toml"),
+                   image_points=ImagePoints.from_csv(directory / "image_points.csv"),
+                   world_points=WorldPoints.from_csv(directory / "world_points.csv"))
+
     # -- marshalling (reference :346-358) ------------------------------------------------------------
     def _matched_arrays(self):
         df = self.image_points._df

@@ -70,8 +70,10 @@ class ImagePoints:
         return cls(pd.read_csv(path))
 
     def to_csv(self, path: str | Path) -> None:
+        from caliscope_amd.persistence import CSV_FLOAT_PRECISION, safe_write_csv
+
         Path(path).parent.mkdir(parents=True, exist_ok=True)
-        self._df.to_csv(path, index=False, float_format="%.6f")
+        safe_write_csv(self._df, Path(path), index=False, float_format=CSV_FLOAT_PRECISION)
 
     def triangulate(self, camera_array, static_object_ids=frozenset()) -> "WorldPoints":
         """Undistort + DLT-triangulate every (sync_index, object_id, keypoint_id) seen by two or more posed cameras
@@ -103,5 +105,7 @@ class WorldPoints:
         return cls(pd.read_csv(path))
 
     def to_csv(self, path: str | Path) -> None:
+        from caliscope_amd.persistence import CSV_FLOAT_PRECISION, safe_write_csv
+
         Path(path).parent.mkdir(parents=True, exist_ok=True)
-        self._df.to_csv(path, index=False, float_format="%.6f")
+        safe_write_csv(self._df, Path(path), index=False, float_format=CSV_FLOAT_PRECISION)
