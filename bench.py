@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: observations/sec per LM iteration (+ final RMS reprojection error, px).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--no-cpu] [--also cfg2,cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--no-cpu] [--also cfg2,cfg3,cfg5]
 
 A *step* is one trust-region (LM) iteration of the hot path over the whole observation set: trial-point
 evaluation plus — for accepted steps — linearisation (residuals, Jacobian blocks, J^T J / J^T r
@@ -13,8 +13,9 @@ resident in HBM before the timed region starts; nothing but scalars crosses PCIe
 
 Workload (``config.workload``): BASELINE.json's multi-GPU configuration cfg4 — 64 cameras / 200k points /
 2M observations, extrinsics-only, linear loss — per GPU (weak scaling: every rank owns a 200k-point shard seen
-by the same 64 cameras; the reduced camera system is all-reduced over RCCL each iteration).  The single-GPU
-configs cfg2 / cfg3 are run untimed-by-the-driver after the headline and reported under ``also``.
+by the same 64 cameras; the reduced camera system is all-reduced over RCCL each iteration).  The other configs
+(cfg2, cfg3, and cfg5 = 128 cameras / 1M points / 10M observations with joint intrinsics, on one GPU) are run
+untimed-by-the-driver after the headline and reported under ``also``.
 """
 
 from __future__ import annotations
@@ -232,7 +233,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg4")
-    ap.add_argument("--also", default="cfg2,cfg3")
+    ap.add_argument("--also", default="cfg2,cfg3,cfg5")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
