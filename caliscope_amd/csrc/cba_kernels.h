@@ -1094,6 +1094,7 @@ __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, d
     double nxt[NB];  // row j + 1 of L, entries t < j (final since pivot j - 1)
 #pragma unroll
     for (int t = 0; t < NB; ++t) nxt[t] = (j + 1 < NB && t < j) ? D[(j + 1) & (NB - 1)][t] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this pivot's arithmetic (the scheduler sinks it otherwise)
     double a[4] = {row[j], 0.0, 0.0, 0.0};  // four chains: a dependent FP64 FMA costs ~20 cycles
 #pragma unroll
     for (int t = 0; t + 1 < j; ++t) a[t & 3] -= row[t] * pre[t];
@@ -1173,7 +1174,8 @@ __device__ __forceinline__ void chol_rank_nb(const double* __restrict__ A, int r
 __global__ void __launch_bounds__(CHOL_THREADS)
 k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace) {
   __shared__ double sh_red[4][16][17];
-  __shared__ double sh_U[NB][NB + 1], sh_L[NB][NB + 1], sh_X[NB][NB + 1], sh_D[NB][NB + 1];
+  __shared__ double sh_U[NB][NB + 1], sh_X[NB][NB + 1], sh_D[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) double sh_L[NB][NB + 2];  // even row stride: pairs of coefficients are 16-byte aligned
   __shared__ double sh_inv[NB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int nbk = (n + NB - 1) / NB;
@@ -1254,24 +1256,35 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   }
   __syncthreads();
   CHOL_STAMP(3);
-  // 2. panel solve  x L_kk^T = u, one row of U per thread of wave 0.  The coefficients L_kk[c][t] are the same for
-  // every lane: they are read through the scalar cache (constant address space: s_load straight into SGPR operands;
-  // L_kk was written by the previous launch).  Read from LDS as broadcasts, the 528 ds_read of a lone wave took
-  // 4.6 us (a single wave gets a fifth of the LDS issue rate).  Four partial sums per entry: a dependent FP64 FMA
-  // chain runs at ~20 cycles per link.
+  // 2. panel solve  x L_kk^T = u, one row of U per thread of wave 0, left-looking with four partial sums per entry
+  // (a dependent FP64 FMA chain runs at ~20 cycles per link).  A lone wave is bound by its instruction count, so the
+  // coefficients L_kk[c][t] are read from LDS two at a time (16-byte aligned rows, ds_read_b128 broadcasts): 264
+  // reads instead of 528.  Measured alternatives: b64 broadcasts 4.6 us, scalar-cache loads 4.5 us (the SGPR budget
+  // exposes every s_load round trip), right-looking 6.4 us, column-per-lane with v_readlane 5.5 us.
   if (tid < NB) {
-    typedef const __attribute__((address_space(4))) double* scalar_ptr;
-    scalar_ptr Lg = (scalar_ptr)(W + (long)k0 * ldw + k0);
-    double x[NB];
+    double x[NB], inv[NB], lc[NB], ln[NB];
 #pragma unroll
-    for (int c2 = 0; c2 < NB; ++c2) x[c2] = sh_U[tid][c2];
+    for (int c2 = 0; c2 < NB; ++c2) { x[c2] = sh_U[tid][c2]; inv[c2] = sh_inv[c2]; lc[c2] = 0.0; ln[c2] = 0.0; }
 #pragma unroll
     for (int c2 = 0; c2 < NB; ++c2) {
-      double a[4] = {x[c2], 0.0, 0.0, 0.0};
-      const long rowoff = (long)min(c2, nbp - 1) * ldw;
+      // row c2 + 1 of L_kk is fetched while row c2 is consumed: left to itself the compiler issues every read right
+      // before its use and waits for it (~100 cycles each, 5.6 us for the solve)
+      if (c2 + 1 < NB) {
 #pragma unroll
-      for (int t = 0; t < c2; ++t) a[t & 3] -= x[t] * Lg[rowoff + t];
-      x[c2] = ((a[0] + a[1]) + (a[2] + a[3])) * sh_inv[c2];
+        for (int t = 0; t < c2 + 1; t += 2) {
+          const double2 l = *reinterpret_cast<const double2*>(&sh_L[c2 + 1][t]);
+          ln[t] = l.x;
+          if (t + 1 < NB) ln[t + 1] = l.y;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      double a[4] = {x[c2], 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < c2; ++t) a[t & 3] -= x[t] * lc[t];
+      x[c2] = ((a[0] + a[1]) + (a[2] + a[3])) * inv[c2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) lc[t] = ln[t];
     }
 #pragma unroll
     for (int c2 = 0; c2 < NB; ++c2) sh_X[tid][c2] = (c2 < nbp && tid < rc) ? x[c2] : 0.0;
