@@ -209,9 +209,13 @@ k_reduce_narrow(const double* __restrict__ partial, int nrow, int width, double*
 // Shared front end of the per-observation passes: project, differentiate, apply the robust-loss scaling.
 // After the call e, A, B are the rows of scipy's scaled (J, f); returns this observation's rho-sum.
 template <int NC>
-__device__ __forceinline__ double obs_linearize(const CamTab& c, double X, double Y, double Z, double u, double v,
+__device__ __forceinline__ double obs_linearize(const CamTab& c_lds, double X, double Y, double Z, double u, double v,
                                                 int loss, double f_scale, double* e, double (*A)[MAX_NC],
                                                 double (*B)[3]) {
+  // The camera row lives in LDS.  Copy it to registers in ONE batch of reads: left alone, the compiler issues each
+  // ds_read right before its first use and waits for it, ~20 exposed LDS round trips per observation.
+  const CamTab c = c_lds;
+  __builtin_amdgcn_sched_barrier(0);
   project_full(c, X, Y, Z, u, v, e, A, B);
   double rho = 0.0;
 #pragma unroll
