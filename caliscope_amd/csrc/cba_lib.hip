@@ -60,7 +60,6 @@ struct cba_problem {
   long N = 0;
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
-  bool schur_lds = true;   // Sacc always lives in LDS tiles
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
   bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg); false: LDS-atomic tile kernel
   long tile_stream_len = 0, n_pairs = 0;

@@ -99,6 +99,32 @@ def test_evaluation_parity(name):
     hip.close()
 
 
+@pytest.mark.parametrize("name", ["global_atomics_C24", "refine_global_C20"])
+def test_lds_tile_fallback_matches_register_kernel(name, monkeypatch):
+    """The LDS-atomic tile kernel (fallback for a point with > 2048 pairs in one tile, CBA_SCHUR=lds) and the
+    register-accumulating kernel solve the same damped system."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    if name not in CASES:
+        pytest.skip(f"{name} not in this case table")
+    sc, par, x0, loss, fs = _case(name)
+    steps, systems = [], []
+    for mode in ("reg", "lds"):
+        monkeypatch.setenv("CBA_SCHUR", mode)
+        eng = HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs))
+        assert eng.info()["schur_in_lds"] == (1 if mode == "lds" else 0)
+        eng.begin(x0)
+        eng.linearize()
+        assert eng.newton_step(1e-4).ok
+        steps.append(eng.get_vector(3).copy())
+        systems.append(eng.reduced_system())
+        eng.close()
+    S0, b0 = systems[0]
+    S1, b1 = systems[1]
+    assert np.abs(S0 - S1).max() <= 1e-12 * np.abs(S0).max() and np.abs(b0 - b1).max() <= 1e-11 * np.abs(b0).max()
+    assert np.abs(steps[0] - steps[1]).max() <= 1e-9 * np.abs(steps[0]).max()
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_step_parity(name):
     sc, par, x0, loss, fs = _case(name)
