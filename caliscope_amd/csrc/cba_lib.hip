@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -413,11 +414,16 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     for (size_t q = 0; q < n; ++q) sorted[cur[key[q]]++] = s.pairs[pb + q];
     std::copy(sorted.begin(), sorted.end(), s.pairs.begin() + pb);
   };
-  std::vector<Stream> st(nT);
+  // every tile's stream is built in NSEG independent pieces (contiguous point ranges), one host thread each; a piece
+  // ends with a partially filled chunk, which is all the split costs
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int NSEG = (P >= 20000) ? (int)std::max(1u, std::min(8u, hw / (unsigned)std::max(nT, 1))) : 1;
+  std::vector<Stream> st((size_t)nT * NSEG);
   for (auto& s : st) { s.chunk_start.push_back(0); s.pair_start.push_back(0); }
   if (reg)
-    for (int a = 0; a < G; ++a) {
-      Stream& s = st[tile_id(a, a)];
+    for (int a = 0; a < G; ++a)
+     for (int seg = 0; seg < NSEG; ++seg) {
+      Stream& s = st[(size_t)tile_id(a, a) * NSEG + seg];
       const int na_t = gcam[a + 1] - gcam[a];
       s.diag = true;
       s.helpers.assign(g, {});
@@ -443,9 +449,11 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   // open chunk's per-thread pair counts the least (cfg4: 30 % fewer wave iterations than the natural order).
   int window = reg ? 32 : 1;
   if (const char* w = std::getenv("CBA_PLAN_WINDOW")) window = std::max(1, std::atoi(w));
-  std::vector<int> tile_rc(nT, CBA_OK);
-  auto build_stream = [&](int t) {
-    Stream& s = st[t];
+  std::vector<int> tile_rc((size_t)nT * NSEG, CBA_OK);
+  auto build_stream = [&](int job) {
+    const int t = job / NSEG, seg = job % NSEG;
+    const int q_begin = (int)((long)P * seg / NSEG), q_end = (int)((long)P * (seg + 1) / NSEG);
+    Stream& s = st[job];
     const int a = ta[t], b = tb[t];
     const int nthr = g * g;
     std::vector<int> counts(std::max(nthr, 1), 0), wavemax((nthr + 63) / 64 + 1, 0);
@@ -489,14 +497,16 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     auto place = [&](int q, int na, int nb) {
       const int* gb = &pgb[(size_t)q * (G + 1)];
       const int cnt = na + nb;
-      const int len = (int)s.pt.size();
+      const int len = (int)s.obs.size();
       const int base = len - s.open;  // chunk-local index of this point's first entry
       for (int i = gb[a]; i < gb[a] + na; ++i) {
-        s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.obs.push_back(i);
+        if (!reg) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); }  // the register kernel reads T records by index
+        s.obs.push_back(i);
         s.cl.push_back((unsigned char)(hcam[i] - gcam[a]));
       }
       for (int i = gb[b]; b != a && i < gb[b] + nb; ++i) {
-        s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.obs.push_back(i);
+        if (!reg) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); }  // the register kernel reads T records by index
+        s.obs.push_back(i);
         s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b]));
       }
       // pairs (row observation i, column observation j), chunk-local, camera(i) <= camera(j)
@@ -518,14 +528,14 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     };
     auto close_chunk = [&]() {
       if (reg) close_chunk_reg(s);
-      const int len = (int)s.pt.size();
+      const int len = (int)s.obs.size();
       s.chunk_start.push_back(len); s.pair_start.push_back((int)s.pairs.size()); s.open = len;
       fresh_chunk();
     };
     std::vector<int> win;  // unplaced candidate points, in point order
-    int next_q = 0;
+    int next_q = q_begin;
     auto refill = [&]() {
-      while ((int)win.size() < window && next_q < P) {
+      while ((int)win.size() < window && next_q < q_end) {
         int na, nb;
         if (entries_of(next_q, na, nb)) win.push_back(next_q);
         ++next_q;
@@ -533,14 +543,14 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     };
     refill();
     while (!win.empty()) {
-      const int fill = (int)s.pt.size() - s.open;
+      const int fill = (int)s.obs.size() - s.open;
       const long open_pairs = (long)s.pairs.size() - s.pair_start.back();
       int best = -1, best_score = 0;
       for (int w = 0; w < (int)win.size(); ++w) {
         int na, nb;
         entries_of(win[w], na, nb);
         const long np = pairs_of(win[w], na, nb);
-        if (reg && np > PAIRCAP) { tile_rc[t] = CBA_ERR_UNSUPPORTED; return; }  // caller falls back to the LDS-tile kernel
+        if (reg && np > PAIRCAP) { tile_rc[job] = CBA_ERR_UNSUPPORTED; return; }  // caller falls back to the LDS-tile kernel
         if (fill + na + nb > CHUNK || (reg && open_pairs + np > PAIRCAP)) continue;
         if (window == 1) { best = w; break; }
         const int sc = score_of(win[w], na, nb);
@@ -548,7 +558,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         if (sc == 0) break;
       }
       if (best < 0) {  // nothing fits: close the chunk (any candidate fits an empty one: cba_host_plan bounds a point)
-        if (fill == 0) { tile_rc[t] = CBA_ERR_UNSUPPORTED; return; }
+        if (fill == 0) { tile_rc[job] = CBA_ERR_UNSUPPORTED; return; }
         close_chunk();
         continue;
       }
@@ -560,31 +570,34 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     }
   };
   {
+    const int n_jobs = nT * NSEG;
     std::vector<std::thread> workers;
-    for (int t = 1; t < nT; ++t) workers.emplace_back(build_stream, t);
+    for (int j = 1; j < n_jobs; ++j) workers.emplace_back(build_stream, j);
     build_stream(0);
     for (auto& w : workers) w.join();
   }
-  for (int t = 0; t < nT; ++t)
-    if (tile_rc[t]) return tile_rc[t];
+  for (int rcj : tile_rc)
+    if (rcj) return rcj;
   // concatenate
   std::vector<double> U, V;
   std::vector<int> PT, OB, CS, PS, TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
   std::vector<unsigned short> PR, BO;
   CS.push_back(0); PS.push_back(0);
-  for (int t = 0; t < nT; ++t) {
-    Stream& s = st[t];
-    const int base = (int)PT.size(), pbase = (int)PR.size();
-    if (!s.pt.empty()) {
+  for (int job = 0; job < nT * NSEG; ++job) {
+    Stream& s = st[job];
+    const int t = job / NSEG;
+    const int base = (int)OB.size(), pbase = (int)PR.size();
+    if (!s.obs.empty()) {
       if (reg) close_chunk_reg(s);
-      s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size());
+      s.chunk_start.push_back((int)s.obs.size()); s.pair_start.push_back((int)s.pairs.size());
     }
     BO.insert(BO.end(), s.blk_off.begin(), s.blk_off.end());
-    TCB[t] = (int)CS.size() - 1;
+    if (job % NSEG == 0) TCB[t] = (int)CS.size() - 1;
     for (size_t c = 1; c < s.chunk_start.size(); ++c) { CS.push_back(base + s.chunk_start[c]); PS.push_back(pbase + s.pair_start[c]); }
     U.insert(U.end(), s.u.begin(), s.u.end()); V.insert(V.end(), s.v.begin(), s.v.end());
-    PT.insert(PT.end(), s.pt.begin(), s.pt.end()); CL.insert(CL.end(), s.cl.begin(), s.cl.end());
+    PT.insert(PT.end(), s.pt.begin(), s.pt.end());
+    if (!reg) CL.insert(CL.end(), s.cl.begin(), s.cl.end());  // register kernel: camera-local ids are only needed to sort the pairs (host)
     OB.insert(OB.end(), s.obs.begin(), s.obs.end());
     PR.insert(PR.end(), s.pairs.begin(), s.pairs.end());
     s = Stream();
@@ -593,7 +606,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   // the register kernel fetches whole rounds without bounds checks: keep the streams readable past the end
   if (reg) { PR.resize(PR.size() + 2 * PAIRCAP, 0); OB.resize(OB.size() + 2 * CHUNK, 0); }
   p->n_tile_chunks = TCB[nT];
-  p->tile_stream_len = (long)PT.size();
+  p->tile_stream_len = (long)OB.size() - (reg ? 2 * CHUNK : 0);
   p->n_pairs = (long)PR.size() - (reg ? 2 * PAIRCAP : 0);
   // workgroups: proportional to the chunk count of each tile, at least one per tile
   std::vector<long> nch(nT);
@@ -746,6 +759,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   for (int c = 0; c < p->C; ++c)
     for (int r = 0; r < np[c]; ++r) { pcam[off[c] + r] = c; ploc[off[c] + r] = r; }
 
+  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = t_now();
+  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "cba_create: %-28s %.3f s\n", what, t - t_mark); t_mark = t; } };
   // plan: sort by point, chunk table
   std::vector<int64_t> order(p->N), pstart((size_t)p->P + 1), cstart((size_t)p->N + 2);
   for (int64_t i = 0; i < p->N; ++i)
@@ -753,6 +770,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   int64_t nch = cba_host_plan(p->P, p->N, d->obs_pt, d->obs_cam, p->C, CHUNK, order.data(), pstart.data(), cstart.data());
   if (nch < 0) return bail((int)nch);
   p->n_chunks = (int)nch;
+  lap("sort by point, chunk table");
   std::vector<double> hu(p->N), hv(p->N);
   std::vector<int> hcam(p->N), hpt(p->N), hord(p->N), hps((size_t)p->P + 1), hcs((size_t)nch + 1);
   for (int64_t i = 0; i < p->N; ++i) {
@@ -774,6 +792,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
+  lap("reorder on host");
   TRY(dev_upload(p, &p->obs_u, hu)); TRY(dev_upload(p, &p->obs_v, hv));
   TRY(dev_upload(p, &p->obs_cam, hcam)); TRY(dev_upload(p, &p->obs_pt, hpt));
   TRY(dev_upload(p, &p->order, hord)); TRY(dev_upload(p, &p->pt_start, hps)); TRY(dev_upload(p, &p->chunk_start, hcs));
@@ -789,6 +808,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_upload(p, &p->cam_const, cc));
   TRY(dev_upload(p, &p->cam_model, model)); TRY(dev_upload(p, &p->cam_np, np)); TRY(dev_upload(p, &p->cam_off, off));
   TRY(dev_upload(p, &p->param_cam, pcam)); TRY(dev_upload(p, &p->param_loc, ploc));
+  lap("upload observations");
   TRY(dev_alloc(p, &p->tab, (size_t)p->C * CAMTAB_DOUBLES)); TRY(dev_alloc(p, &p->tab_new, (size_t)p->C * CAMTAB_DOUBLES));
   const long tot = p->lay.total();
   for (double** v : {&p->x0, &p->x, &p->x_new, &p->g, &p->s, &p->sinv, &p->v1, &p->v2}) {
@@ -799,7 +819,9 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPCHK(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
+  lap("allocate vectors");
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
+  lap("reorder, upload, allocate");
   for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t tile_lds = p->schur_reg ? ((nct == 9) ? lds_schur_reg<9>(p->gsz) : lds_schur_reg<6>(p->gsz))
                                          : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
@@ -811,6 +833,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     if (rc) return bail(rc);
     break;
   }
+  lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
