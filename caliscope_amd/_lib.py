@@ -83,6 +83,7 @@ SIGNATURES = {
     "cba_destroy": (None, [C.c_void_p]),
     "cba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cba_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "cba_set_constraints": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p]),
     "cba_begin": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cba_restart": (C.c_int, [C.c_void_p, c_double_p]),
     "cba_linearize": (C.c_int, [C.c_void_p, C.POINTER(Linearization)]),

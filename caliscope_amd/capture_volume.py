@@ -13,8 +13,9 @@ Same public surface as the reference's ``core/capture_volume.py`` for the BA pat
 
 The marshalling of DataFrames into flat arrays follows ``:346-358`` but is vectorised (the reference uses a
 Python list comprehension over every observation, and a Python loop to build ``img_to_obj_map``).  The solver
-call goes through :func:`caliscope_amd.least_squares.least_squares`, i.e. the MI355X engine; constraints
-(rigid distances) are not handled by the engine yet and raise.
+call goes through :func:`caliscope_amd.least_squares.least_squares`, i.e. the MI355X engine; a volume's
+``ConstraintSet`` becomes the constraint rows of the solve (``_build_constraint_arrays`` <- ``:446-516``, weights
+``(pixel_sigma / f_median) / sigma`` <- ``:373-383``), ``rigidity_report`` <- ``:532-605``.
 """
 
 from __future__ import annotations
@@ -32,7 +33,8 @@ from caliscope_amd.cameras import CameraArray
 from caliscope_amd.engine import BAProblem
 from caliscope_amd.exceptions import CalibrationError
 from caliscope_amd.least_squares import least_squares
-from caliscope_amd.point_data import ImagePoints, WorldPoints
+from caliscope_amd.constraints import ConstraintSet, ConstraintViolation, DistanceConstraint, RigidityReport
+from caliscope_amd.point_data import STATIC_SYNC_INDEX, ImagePoints, WorldPoints
 from caliscope_amd.trf import STATUS_REASONS
 
 logger = logging.getLogger(__name__)
@@ -69,7 +71,7 @@ class CaptureVolume:
     camera_array: CameraArray
     image_points: ImagePoints
     world_points: WorldPoints
-    constraints: object | None = None
+    constraints: ConstraintSet | None = None
     img_to_obj_map: np.ndarray = field(init=False)
     _optimization_status: OptimizationStatus | None = field(default=None, compare=False)
 
@@ -90,17 +92,23 @@ class CaptureVolume:
             raise ValueError("No image observations have corresponding world points")
 
     def _compute_img_to_obj_map(self) -> np.ndarray:
-        """Row of ``world_points`` for every image observation, -1 when unmatched (vectorised merge)."""
+        """Row of ``world_points`` for every image observation, -1 when unmatched (vectorised merge).  Observations
+        of a static object look their point up at ``STATIC_SYNC_INDEX`` (reference :119-139)."""
         world = self.world_points._df[_KEY].copy()
         world["world_idx"] = np.arange(len(world), dtype=np.int64)
         world = world.drop_duplicates(subset=_KEY, keep="last")
-        merged = self.image_points._df[_KEY].merge(world, on=_KEY, how="left")
+        keys = self.image_points._df[_KEY]
+        static_ids = self.constraints.static_object_ids if self.constraints else frozenset()
+        if static_ids:
+            keys = keys.copy()
+            keys.loc[keys["object_id"].isin(list(static_ids)), "sync_index"] = STATIC_SYNC_INDEX
+        merged = keys.merge(world, on=_KEY, how="left")
         return merged["world_idx"].fillna(-1).to_numpy(dtype=np.int32)
 
     # -- persistence (reference :237-267) -------------------------------------------------------------
     def save(self, directory) -> None:
-        """Write ``camera_array.toml``, ``image_points.csv``, ``world_points.csv`` (atomic writes).  As in the reference,
-        ``optimization_status`` is not persisted; constraint sets are not supported here."""
+        """Write ``camera_array.toml``, ``image_points.csv``, ``world_points.csv`` and, when the volume has one,
+        ``constraints.toml`` (atomic writes).  As in the reference, ``optimization_status`` is not persisted."""
         from pathlib import Path
 
         directory = Path(directory)
@@ -108,15 +116,19 @@ class CaptureVolume:
         self.camera_array.to_toml(directory / "camera_array.toml")
         self.image_points.to_csv(directory / "image_points.csv")
         self.world_points.to_csv(directory / "world_points.csv")
+        if self.constraints is not None:
+            self.constraints.to_toml(directory / "constraints.toml")
 
     @classmethod
     def load(cls, directory) -> "CaptureVolume":
         from pathlib import Path
 
         directory = Path(directory)
+        con_path = directory / "constraints.toml"
         return cls(camera_array=CameraArray.from_toml(directory / "camera_array.toml"),
                    image_points=ImagePoints.from_csv(directory / "image_points.csv"),
-                   world_points=WorldPoints.from_csv(directory / "world_points.csv"))
+                   world_points=WorldPoints.from_csv(directory / "world_points.csv"),
+                   constraints=ConstraintSet.from_toml(con_path) if con_path.exists() else None)
 
     # -- marshalling (reference :346-358) ------------------------------------------------------------
     def _matched_arrays(self):
@@ -150,12 +162,17 @@ class CaptureVolume:
         _engine_factory=None,
     ) -> "CaptureVolume":
         """Bundle adjustment via pixel-space residuals, on the MI355X engine."""
-        if use_constraints and self.constraints is not None:
-            raise CalibrationError(
-                "This capture volume carries rigid-distance constraints, which the MI355X engine does not "
-                "implement yet.  Pass use_constraints=False (or keep the scipy path for this volume)."
-            )
         _, camera_indices, image_coords, obj_indices = self._matched_arrays()
+        con_args = (None, None, None, None)
+        if use_constraints and self.constraints is not None:
+            arrays = self._build_constraint_arrays()
+            if arrays is not None:
+                groups_a, groups_b, distances, sigmas = arrays
+                f_median = float(np.median([cam.matrix[0, 0] for cam in self.camera_array.posed_cameras.values()]))
+                # residual units are normalised image coordinates (pixels / fx): a row is 1 when the distance is off
+                # by one sigma scaled like a pixel_sigma reprojection error (reference :377-383)
+                con_args = (groups_a, groups_b, distances, (pixel_sigma / f_median) / sigmas)
+                logger.info(f"Adding {len(distances)} constraint rows (f_median={f_median:.0f}, pixel_sigma={pixel_sigma})")
         new_cameras = deepcopy(self.camera_array)
         par = BundleParameterization.from_camera_array(
             new_cameras, n_points=len(self.world_points), refine_intrinsics=refine_intrinsics
@@ -165,7 +182,7 @@ class CaptureVolume:
         result = least_squares(
             None,
             x0,
-            args=(par, camera_indices, image_coords, obj_indices, None, None, None, None),
+            args=(par, camera_indices, image_coords, obj_indices, *con_args),
             jac=None,
             verbose=verbose,
             x_scale="jac",
@@ -201,6 +218,72 @@ class CaptureVolume:
             constraints=self.constraints,
             _optimization_status=status,
         )
+
+    # -- constraint rows (reference :446-605) ----------------------------------------------------------------
+    def _constraint_instances(self):
+        """Every (constraint, sync index) at which all endpoint keypoints have a world point: yields
+        ``(constraint, sync_index, rows_a, rows_b)`` with four world-point rows per endpoint (a corner endpoint is its
+        row four times).  Static-static constraints fire once at ``STATIC_SYNC_INDEX``, mobile-mobile ones at every
+        shared sync index, mixed ones never (reference ``_firing_sync_indices`` :518-530)."""
+        con = self.constraints
+        if con is None or not (con.distances or con.centroid_distances):
+            return
+        df = self.world_points._df
+        order = np.lexsort((df["sync_index"].to_numpy(), df["keypoint_id"].to_numpy(), df["object_id"].to_numpy()))
+        obj, kp, sync = (df[c].to_numpy()[order] for c in ("object_id", "keypoint_id", "sync_index"))
+        # one slice of (sorted sync indices, world rows) per keypoint
+        start = np.flatnonzero(np.r_[True, (obj[1:] != obj[:-1]) | (kp[1:] != kp[:-1])]) if len(obj) else np.array([], dtype=np.int64)
+        end = np.r_[start[1:], len(obj)]
+        table = {(int(obj[s]), int(kp[s])): (sync[s:e], order[s:e]) for s, e in zip(start, end)}
+        empty = (np.array([], dtype=np.int64), np.array([], dtype=np.int64))
+        static_ids = con.static_object_ids
+
+        def fire(endpoints, is_static):
+            syncs = endpoints[0][0]
+            for s, _ in endpoints[1:]:
+                syncs = np.intersect1d(syncs, s)
+            syncs = syncs[syncs == STATIC_SYNC_INDEX] if is_static else syncs[syncs != STATIC_SYNC_INDEX]
+            rows = [r[np.searchsorted(s, syncs)] for s, r in endpoints]  # keys are unique per keypoint (sorted slice)
+            return syncs, rows
+
+        for dc in con.distances:
+            a_static, b_static = dc.object_id_a in static_ids, dc.object_id_b in static_ids
+            if a_static != b_static:
+                continue
+            ends = [table.get((dc.object_id_a, dc.keypoint_id_a), empty), table.get((dc.object_id_b, dc.keypoint_id_b), empty)]
+            syncs, rows = fire(ends, a_static)
+            for i, si in enumerate(syncs):
+                yield dc, int(si), [int(rows[0][i])] * 4, [int(rows[1][i])] * 4
+        for cc in con.centroid_distances:
+            a_static, b_static = cc.object_id_a in static_ids, cc.object_id_b in static_ids
+            if a_static != b_static:
+                continue
+            ends = [table.get((o, k), empty) for o in (cc.object_id_a, cc.object_id_b) for k in range(4)]
+            syncs, rows = fire(ends, a_static)
+            for i, si in enumerate(syncs):
+                yield cc, int(si), [int(rows[k][i]) for k in range(4)], [int(rows[4 + k][i]) for k in range(4)]
+
+    def _build_constraint_arrays(self):
+        """``(groups_a (n, 4) int32, groups_b (n, 4) int32, distances (n,), sigmas (n,))`` or None."""
+        ga, gb, dist, sig = [], [], [], []
+        for c, _, rows_a, rows_b in self._constraint_instances():
+            ga.append(rows_a); gb.append(rows_b); dist.append(c.distance); sig.append(c.sigma)
+        if not ga:
+            return None
+        return (np.array(ga, dtype=np.int32), np.array(gb, dtype=np.int32), np.array(dist, dtype=np.float64),
+                np.array(sig, dtype=np.float64))
+
+    def rigidity_report(self) -> RigidityReport:
+        """Measured distance of every constraint instance with the current world points (no optimisation)."""
+        xyz = self.world_points.points
+        out = []
+        for c, si, rows_a, rows_b in self._constraint_instances():
+            actual = float(np.linalg.norm(xyz[rows_a].mean(axis=0) - xyz[rows_b].mean(axis=0)))
+            if isinstance(c, DistanceConstraint):
+                out.append(ConstraintViolation(c.object_id_a, c.keypoint_id_a, c.object_id_b, c.keypoint_id_b, si, c.distance, actual))
+            else:
+                out.append(ConstraintViolation(c.object_id_a, -1, c.object_id_b, -1, si, c.distance, actual, kind="centroid"))
+        return RigidityReport(violations=tuple(out))
 
     # -- metric of record --------------------------------------------------------------------------------
     def _pixel_errors(self, camera_indices, image_coords, obj_indices, _engine_factory=None) -> np.ndarray:

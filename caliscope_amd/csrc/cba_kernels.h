@@ -354,7 +354,7 @@ __global__ void k_unpack_camera_grad(const double* __restrict__ Upacked, const i
 template <int NC>
 __global__ void k_scale_update(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
                                const int* __restrict__ param_cam, const int* __restrict__ param_loc, VecLayout lay,
-                               int first, double* __restrict__ sinv) {
+                               int first, double* __restrict__ sinv, const double* __restrict__ cdiag) {
   using UP = UPack<NC>;
   const long total = lay.total();
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -368,6 +368,7 @@ __global__ void k_scale_update(const double* __restrict__ Upacked, const double*
       if (p >= lay.P) continue;
       const int q = (k == 0) ? 0 : (k == 1 ? 3 : 5);
       v = Vblk[(long)q * lay.Ppad + p];
+      if (cdiag) v += cdiag[k * lay.Ppad + p];  // constraint rows are rows of J too (x_scale = 'jac')
     }
     v = sqrt(v);
     if (first) { if (v == 0.0) v = 1.0; }
@@ -1703,6 +1704,344 @@ k_triangulate(long n_points, const long* __restrict__ pt_start, const int* __res
   xyz[3 * q] = w[0] / w[3];
   xyz[3 * q + 1] = w[1] / w[3];
   xyz[3 * q + 2] = w[2] / w[3];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Rigid-distance constraint rows (reference core/reprojection.py:112-117 residual, :207-226 Jacobian;
+// capture_volume.py:446-531 group arrays):  r_c = w_c (|| mean X[a_c] - mean X[b_c] || - d_c), one row per constraint
+// after the 2N reprojection rows, derivative +-1/4 w_c unit_c on each of the 8 group slots (a repeated point index
+// collects its slots).  The rows touch points only, so H_pp = V~ + J_c^T J_c stops being block diagonal; the damped
+// step uses  H_pp^-1 = V~^-1 - V~^-1 J_c^T M^-1 J_c V~^-1,  M = I + J_c V~^-1 J_c^T  (Woodbury): everything the
+// unconstrained path computes stays as it is and a correction is added per CONNECTED COMPONENT of the constraint
+// graph (the corners of one board in one frame), one workgroup per component.
+struct ConPlan {
+  int n_con, n_comp;
+  const int* pt;          // [n_con][8] world point of every group slot (0-3 group a, 4-7 group b), component order
+  const int* lp;          // [n_con][8] index of that point inside its component
+  const double* dist;     // [n_con]
+  const double* weight;   // [n_con]
+  const int* order;       // [n_con] caller's row index of constraint c (residual hook)
+  const int* comp_con;    // [n_comp + 1] constraint range of a component
+  const int* comp_pt;     // [n_comp + 1] range into comp_pts
+  const int* comp_pts;    // world points of each component
+  const long* comp_m;     // [n_comp + 1] offset of the component's M (m x m) in Mbuf
+  double* f;              // [n_con] robust-scaled residual at the linearisation point
+  double* u;              // [n_con][3] robust-scaled row direction  w rs unit
+  double* z;              // [n_con][8][3]  L_p^-1 (slot coefficient)
+  double* M;              // sum m_k^2
+  double* G;              // [n_con][ncp + 1]
+  double* cdiag;          // [3][Ppad] squared column norms of the constraint rows
+  double* w;              // [n_con] scratch of k_con_backsub (J_c V~^-1 q, then M^-1 of it)
+};
+
+__device__ __forceinline__ void con_geometry(const ConPlan& cp, int c, const double* __restrict__ px, VecLayout lay, double* unit,
+                                             double* nrm) {
+  double a[3] = {0.0, 0.0, 0.0}, b[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int pa = cp.pt[c * 8 + s], pb = cp.pt[c * 8 + 4 + s];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a[k] += px[(long)k * lay.Ppad + pa]; b[k] += px[(long)k * lay.Ppad + pb]; }
+  }
+  double d[3], n2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d[k] = 0.25 * (a[k] - b[k]); n2 += d[k] * d[k]; }
+  const double n = sqrt(n2);
+  const double inv = n > 0.0 ? 1.0 / n : 0.0;  // zero subgradient at coincident endpoints (reprojection.py:213-214)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) unit[k] = d[k] * inv;
+  *nrm = n;
+}
+
+// LIN = false: cost of the rows at xvec (trial points, residual hook).  LIN = true: also f, u, and the rows' share of
+// the gradient and of the squared column norms (global FP64 atomics: a few per constraint).
+template <bool LIN>
+__global__ void __launch_bounds__(BLOCK)
+k_con_eval(ConPlan cp, const double* __restrict__ xvec, VecLayout lay, int loss, double f_scale, double* __restrict__ gvec,
+           double* __restrict__ partial, int* __restrict__ flags, double* __restrict__ r_out) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  const double* px = xvec + lay.ncp_pad;
+  double acc = 0.0;
+  bool bad = false;
+  for (int c = blockIdx.x * BLOCK + threadIdx.x; c < cp.n_con; c += gridDim.x * BLOCK) {
+    double unit[3], nrm;
+    con_geometry(cp, c, px, lay, unit, &nrm);
+    const double r = (nrm - cp.dist[c]) * cp.weight[c];
+    if (!isfinite(r)) bad = true;
+    if (r_out) r_out[cp.order[c]] = r;
+    if (!LIN) {
+      acc += robust_cost_one(loss, f_scale, r);
+    } else {
+      double rs, er;
+      acc += robust_one(loss, f_scale, r, &rs, &er);
+      cp.f[c] = er;
+      const double w = cp.weight[c] * rs;
+      const double u[3] = {unit[0] * w, unit[1] * w, unit[2] * w};
+      cp.u[c * 3] = u[0]; cp.u[c * 3 + 1] = u[1]; cp.u[c * 3 + 2] = u[2];
+      double* gp = gvec + lay.ncp_pad;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int p = cp.pt[c * 8 + s];
+        bool first = true;
+        double mult = 0.0;  // signed multiplicity of p among the slots, in quarters
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2)
+          if (cp.pt[c * 8 + s2] == p) { if (s2 < s) first = false; mult += (s2 < 4) ? 0.25 : -0.25; }
+        if (first && mult != 0.0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double jk = mult * u[k];
+            unsafeAtomicAdd(&gp[(long)k * lay.Ppad + p], jk * er);
+            unsafeAtomicAdd(&cp.cdiag[(long)k * lay.Ppad + p], jk * jk);
+          }
+        }
+      }
+    }
+  }
+  if (bad) flags[0] = 1;
+  const double tot = block_sum(acc, sh_red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// || J v ||^2 share of the constraint rows for one or two vectors: partial[b][0..2] = sum r1^2, r1 r2, r2^2
+template <int NV>
+__global__ void __launch_bounds__(BLOCK)
+k_con_jv(ConPlan cp, VecLayout lay, const double* __restrict__ v1, const double* __restrict__ v2, double* __restrict__ partial) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  double s11 = 0.0, s12 = 0.0, s22 = 0.0;
+  for (int c = blockIdx.x * BLOCK + threadIdx.x; c < cp.n_con; c += gridDim.x * BLOCK) {
+    double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int p = cp.pt[c * 8 + s];
+      const double q = (s < 4) ? 0.25 : -0.25;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double jk = q * cp.u[c * 3 + k];
+        r1 += jk * v1[lay.ncp_pad + (long)k * lay.Ppad + p];
+        if (NV == 2) r2 += jk * v2[lay.ncp_pad + (long)k * lay.Ppad + p];
+      }
+    }
+    s11 += r1 * r1; s12 += r1 * r2; s22 += r2 * r2;
+  }
+  double r;
+  r = block_sum(s11, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
+  r = block_sum(s12, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
+  r = block_sum(s22, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = r;
+  if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = 0.0;
+}
+
+constexpr int CON_MAX_POINTS = 256;  // points of one constraint component (one board in one frame)
+
+// L^T x for the 3 x 3 factor in chol3's convention (reciprocal diagonal entries)
+__device__ __forceinline__ void chol3_lt_mul(const double* L, const double* x, double* y) {
+  y[0] = x[0] / L[0] + L[1] * x[1] + L[3] * x[2];
+  y[1] = x[1] / L[2] + L[4] * x[2];
+  y[2] = x[2] / L[5];
+}
+
+__device__ __forceinline__ bool con_point_factor(const double* __restrict__ Vblk, const double* __restrict__ dp, VecLayout lay, int p,
+                                                 double lam, double* L) {
+  double Vd[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + p];
+  const double d0 = dp[p], d1 = dp[lay.Ppad + p], d2 = dp[2 * lay.Ppad + p];
+  Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+  if (chol3(Vd, L)) return true;
+  L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
+  return false;
+}
+
+// Woodbury correction of the reduced camera system, one workgroup per component:
+//   Sacc -= G^T M^-1 G,  bacc -= G^T M^-1 h,   G = J_c V~^-1 W^T (rows: sum_i (T_i z)^T),  h = J_c V~^-1 g_p,
+//   z = L_p^-1 (slot coefficient), M = I + Z Z^T factored in place (lower) and kept for k_con_backsub.
+// Runs after the T records exist (k_tprep) and after the unconstrained Sacc / bacc are in place.
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vblk, const double* __restrict__ gvec,
+            const double* __restrict__ sinv, const double* __restrict__ Trec, const int* __restrict__ pt_start,
+            const int* __restrict__ obs_cam, const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
+            double* __restrict__ Sacc, double* __restrict__ bacc, int* __restrict__ flags) {
+  constexpr int REC = SchurRec<NC>::REC;
+  __shared__ double sh_L[CON_MAX_POINTS][6];
+  __shared__ double sh_y[CON_MAX_POINTS][3];
+  __shared__ double sh_piv;
+  const int k = blockIdx.x;
+  const int c0 = cp.comp_con[k], m = cp.comp_con[k + 1] - c0;
+  const int p0 = cp.comp_pt[k], np = cp.comp_pt[k + 1] - p0;
+  double* M = cp.M + cp.comp_m[k];
+  const int gw = ncp + 1;
+  double* G = cp.G + (long)c0 * gw;
+  const double* gp = gvec + lay.ncp_pad;
+  const double* dp = sinv + lay.ncp_pad;
+  // 1. per point: factor of V~_p, y_p = L^-1 g_p
+  for (int lp = threadIdx.x; lp < np; lp += BLOCK) {
+    const int p = cp.comp_pts[p0 + lp];
+    double L[6];
+    if (!con_point_factor(Vblk, dp, lay, p, lam, L)) flags[1] = 1;
+    const double g3[3] = {gp[p], gp[lay.Ppad + p], gp[2 * lay.Ppad + p]};
+    double y[3];
+    chol3_fwd(L, g3, y);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sh_L[lp][q] = L[q];
+    sh_y[lp][0] = y[0]; sh_y[lp][1] = y[1]; sh_y[lp][2] = y[2];
+  }
+  __syncthreads();
+  // 2. z for every (constraint, slot); rows of G zeroed
+  for (int e = threadIdx.x; e < m * 8; e += BLOCK) {
+    const int c = c0 + e / 8, s = e % 8;
+    const double q = (s < 4) ? 0.25 : -0.25;
+    const double j3[3] = {q * cp.u[c * 3], q * cp.u[c * 3 + 1], q * cp.u[c * 3 + 2]};
+    double z[3];
+    chol3_fwd(sh_L[cp.lp[c * 8 + s]], j3, z);
+    cp.z[(long)(c * 8 + s) * 3] = z[0]; cp.z[(long)(c * 8 + s) * 3 + 1] = z[1]; cp.z[(long)(c * 8 + s) * 3 + 2] = z[2];
+  }
+  for (long e = threadIdx.x; e < (long)m * gw; e += BLOCK) G[e] = 0.0;
+  __syncthreads();
+  // 3. M = I + Z Z^T (lower triangle), h in the last column of G
+  for (long e = threadIdx.x; e < (long)m * m; e += BLOCK) {
+    const int a = (int)(e / m), b = (int)(e % m);
+    if (b > a) continue;
+    double acc = (a == b) ? 1.0 : 0.0;
+    for (int s = 0; s < 8; ++s) {
+      const int la = cp.lp[(c0 + a) * 8 + s];
+      const double* za = cp.z + (long)((c0 + a) * 8 + s) * 3;
+      for (int s2 = 0; s2 < 8; ++s2)
+        if (cp.lp[(c0 + b) * 8 + s2] == la) {
+          const double* zb = cp.z + (long)((c0 + b) * 8 + s2) * 3;
+          acc += za[0] * zb[0] + za[1] * zb[1] + za[2] * zb[2];
+        }
+    }
+    M[(long)a * m + b] = acc;
+  }
+  for (int c = threadIdx.x; c < m; c += BLOCK) {
+    double h = 0.0;
+    for (int s = 0; s < 8; ++s) {
+      const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
+      const double* y = sh_y[cp.lp[(c0 + c) * 8 + s]];
+      h += z[0] * y[0] + z[1] * y[1] + z[2] * y[2];
+    }
+    G[(long)c * gw + ncp] = h;
+    // 4. G rows: sum over the observations of the slot points of (T_i z)^T at the camera's columns
+    for (int s = 0; s < 8; ++s) {
+      const int p = cp.pt[(c0 + c) * 8 + s];
+      const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
+      for (int i = pt_start[p]; i < pt_start[p + 1]; ++i) {
+        const int cam = obs_cam[i];
+        const double* T = Trec + (long)i * REC;
+        const int off = cam_off[cam], npar = cam_np[cam];
+        for (int r = 0; r < npar; ++r) G[(long)c * gw + off + r] += T[3 * r] * z[0] + T[3 * r + 1] * z[1] + T[3 * r + 2] * z[2];
+      }
+    }
+  }
+  __syncthreads();
+  // 5. Cholesky of M, left-looking by columns: v_i = M_ij - sum_{t<j} L_it L_jt
+  for (int j = 0; j < m; ++j) {
+    for (int i = j + threadIdx.x; i < m; i += BLOCK) {
+      double v = M[(long)i * m + j];
+      for (int t = 0; t < j; ++t) v -= M[(long)i * m + t] * M[(long)j * m + t];
+      M[(long)i * m + j] = v;
+      if (i == j) sh_piv = v;
+    }
+    __syncthreads();
+    const double piv = sh_piv;
+    if (!(piv > 0.0)) { if (threadIdx.x == 0) flags[2] = 1; }
+    const double inv = piv > 0.0 ? 1.0 / sqrt(piv) : 1.0;
+    for (int i = j + threadIdx.x; i < m; i += BLOCK) M[(long)i * m + j] = (i == j) ? (piv > 0.0 ? sqrt(piv) : 1.0) : M[(long)i * m + j] * inv;
+    __syncthreads();
+  }
+  // 6. Y = L_M^-1 [G | h] in place, one thread per column
+  for (int col = threadIdx.x; col < gw; col += BLOCK) {
+    for (int c = 0; c < m; ++c) {
+      double v = G[(long)c * gw + col];
+      for (int t = 0; t < c; ++t) v -= M[(long)c * m + t] * G[(long)t * gw + col];
+      G[(long)c * gw + col] = v / M[(long)c * m + c];
+    }
+  }
+  __syncthreads();
+  // 7. Sacc -= Y^T Y (upper triangle), bacc -= Y^T y_h
+  for (long e = threadIdx.x; e < (long)ncp * gw; e += BLOCK) {
+    const int r = (int)(e / gw), c2 = (int)(e % gw);
+    if (c2 < r) continue;
+    double acc = 0.0;
+    for (int c = 0; c < m; ++c) acc += G[(long)c * gw + r] * G[(long)c * gw + c2];
+    if (acc != 0.0) {
+      if (c2 < ncp) unsafeAtomicAdd(&Sacc[(long)r * ncp + c2], -acc);
+      else unsafeAtomicAdd(&bacc[r], -acc);
+    }
+  }
+}
+
+// Point steps of a component:  dp += V~^-1 J_c^T M^-1 (J_c V~^-1 q)  on top of the unconstrained dp0 = -V~^-1 q
+// that k_backsub left in svec (L^-1 q = -L^T dp0 is recovered from it).
+__global__ void __launch_bounds__(BLOCK)
+k_con_backsub(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vblk, const double* __restrict__ sinv,
+              double* __restrict__ svec) {
+  __shared__ double sh_L[CON_MAX_POINTS][6];
+  __shared__ double sh_q[CON_MAX_POINTS][3];
+  __shared__ double sh_w;
+  const int k = blockIdx.x;
+  const int c0 = cp.comp_con[k], m = cp.comp_con[k + 1] - c0;
+  const int p0 = cp.comp_pt[k], np = cp.comp_pt[k + 1] - p0;
+  const double* M = cp.M + cp.comp_m[k];
+  double* u = cp.w + c0;
+  const double* dp = sinv + lay.ncp_pad;
+  double* sp = svec + lay.ncp_pad;
+  for (int lp = threadIdx.x; lp < np; lp += BLOCK) {
+    const int p = cp.comp_pts[p0 + lp];
+    double L[6];
+    con_point_factor(Vblk, dp, lay, p, lam, L);
+    const double d0[3] = {-sp[p], -sp[lay.Ppad + p], -sp[2 * lay.Ppad + p]};
+    double yq[3];
+    chol3_lt_mul(L, d0, yq);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sh_L[lp][q] = L[q];
+    sh_q[lp][0] = yq[0]; sh_q[lp][1] = yq[1]; sh_q[lp][2] = yq[2];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < m; c += BLOCK) {
+    double acc = 0.0;
+    for (int s = 0; s < 8; ++s) {
+      const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
+      const double* y = sh_q[cp.lp[(c0 + c) * 8 + s]];
+      acc += z[0] * y[0] + z[1] * y[1] + z[2] * y[2];
+    }
+    u[c] = acc;
+  }
+  __syncthreads();
+  // M w = u with the factor left by k_con_schur: forward then backward, column oriented
+  for (int j = 0; j < m; ++j) {
+    if (threadIdx.x == 0) { const double w = u[j] / M[(long)j * m + j]; u[j] = w; sh_w = w; }
+    __syncthreads();
+    const double w = sh_w;
+    for (int i = j + 1 + threadIdx.x; i < m; i += BLOCK) u[i] -= M[(long)i * m + j] * w;
+    __syncthreads();
+  }
+  for (int j = m - 1; j >= 0; --j) {
+    if (threadIdx.x == 0) { const double w = u[j] / M[(long)j * m + j]; u[j] = w; sh_w = w; }
+    __syncthreads();
+    const double w = sh_w;
+    for (int i = threadIdx.x; i < j; i += BLOCK) u[i] -= M[(long)j * m + i] * w;
+    __syncthreads();
+  }
+  // scatter: acc_p = sum_{(c, s) -> p} z w_c, then dp_p += L_p^-T acc_p
+  for (int lp = threadIdx.x; lp < np; lp += BLOCK) { sh_q[lp][0] = 0.0; sh_q[lp][1] = 0.0; sh_q[lp][2] = 0.0; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < m * 8; e += BLOCK) {
+    const int c = e / 8, s = e % 8;
+    const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
+    const double w = u[c];
+    double* a = sh_q[cp.lp[(c0 + c) * 8 + s]];
+    lds_add(&a[0], z[0] * w); lds_add(&a[1], z[1] * w); lds_add(&a[2], z[2] * w);
+  }
+  __syncthreads();
+  for (int lp = threadIdx.x; lp < np; lp += BLOCK) {
+    const int p = cp.comp_pts[p0 + lp];
+    double t[3];
+    chol3_bwd(sh_L[lp], sh_q[lp], t);
+    sp[p] += t[0]; sp[lay.Ppad + p] += t[1]; sp[2 * lay.Ppad + p] += t[2];
+  }
 }
 
 }  // namespace cba

@@ -88,6 +88,8 @@ struct cba_problem {
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
+  ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
+  int con_grid = 0;        // workgroups of the per-constraint kernels
   int* flags = nullptr;
   double* h_scal = nullptr;  // pinned
   int* h_flags = nullptr;
@@ -837,7 +839,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
-  TRY(dev_alloc(p, &p->partial4, (size_t)1024 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)1024));
+  TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   if (p->schur_reg) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
@@ -929,7 +931,13 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
                          (double*)nullptr, (const int*)nullptr);
   }
   ScopedTimer t(p, T_VECTOR);
-  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, grid, 1, p->scal + slot);
+  int rows = grid;
+  if (p->con.n_con) {  // constraint rows: their cost lands in extra partial rows (and their residuals after the 2N reprojection rows)
+    hipLaunchKernelGGL(k_con_eval<false>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, xvec, p->lay, p->loss, p->f_scale,
+                       (double*)nullptr, p->partial1 + grid, p->flags, r_out ? r_out + 2 * p->N : (double*)nullptr);
+    rows += p->con_grid;
+  }
+  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, rows, 1, p->scal + slot);
   return CBA_OK;  // sharded solves: the caller's exchange() sums scal[slot] and the flags over the ranks
 }
 
@@ -945,7 +953,14 @@ static int run_build(cba_problem* p) {
     ScopedTimer t(p, T_BUILD_REDUCE);
     const int w = p->C * UPack<NC>::STRIDE;
     hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, p->Upacked);
-    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, p->grid, 1, p->scal + 8);  // rho sum
+    int rho_rows = p->grid;
+    if (p->con.n_con) {  // constraint rows: f, u, their share of g_p and of the squared column norms
+      HIPCHK(hipMemsetAsync(p->con.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double), p->stream));
+      hipLaunchKernelGGL(k_con_eval<true>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, p->x, p->lay, p->loss, p->f_scale, p->g,
+                         p->partial1 + p->grid, p->flags, (double*)nullptr);
+      rho_rows += p->con_grid;
+    }
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, rho_rows, 1, p->scal + 8);  // rho sum
     int rc = allreduce_sum(p, p->Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
     if (rc) return rc;                                 // (the rho sum in scal[8] rides with the linearisation's exchange)
     hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->Upacked,
@@ -964,7 +979,13 @@ static int run_jv(cba_problem* p, int nv) {
   else
     hipLaunchKernelGGL((k_jv<NC, 2>), dim3(grid), dim3(BLOCK), lds_jv(p, 2), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                        p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
-  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, grid, 4, p->scal + 12);
+  int rows = grid;
+  if (p->con.n_con) {
+    if (nv == 1) hipLaunchKernelGGL(k_con_jv<1>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, p->lay, p->v1, p->v2, p->partial4 + 4 * grid);
+    else hipLaunchKernelGGL(k_con_jv<2>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, p->lay, p->v1, p->v2, p->partial4 + 4 * grid);
+    rows += p->con_grid;
+  }
+  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, rows, 4, p->scal + 12);
   return CBA_OK;  // scal[12..15] are summed over the ranks by the caller's exchange()
 }
 
@@ -979,7 +1000,7 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
   {
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
-                       p->lay, p->first_scale ? 1 : 0, p->sinv);
+                       p->lay, p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr);
     hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->lay.ncp_pad,
                        p->rank == 0 ? 1 : 0, p->v1, p->partial4, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
@@ -1078,6 +1099,9 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
       hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                          p->cam_off, p->cam_np, NC, ncp, p->Sacc);
+      if (p->con.n_con)  // Woodbury correction of S and b for the constraint rows, one workgroup per component
+        hipLaunchKernelGGL((k_con_schur<NC>), dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->g, p->sinv,
+                           p->Trec, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
     }
     else
       hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
@@ -1097,6 +1121,8 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                        p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
                        p->f_scale, lam, p->V, p->g, p->sinv, p->s);
+    if (p->con.n_con)
+      hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
   }
   {
     ScopedTimer t(p, T_VECTOR);
@@ -1127,6 +1153,92 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
 extern "C" {
 
 static int begin_common(cba_problem* p, double* cost_out);
+
+int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, const int32_t* groups_b, const double* distances,
+                        const double* weights) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_set_constraints: null problem");
+  if (p->begun) return fail(CBA_ERR_INVALID, "cba_set_constraints: call it before cba_begin");
+  if (p->con.n_con) return fail(CBA_ERR_INVALID, "cba_set_constraints: constraints are already set");
+  if (n_con <= 0) return CBA_OK;
+  if (!groups_a || !groups_b || !distances || !weights) return fail(CBA_ERR_INVALID, "cba_set_constraints: null array");
+  if (p->comm && p->world > 1) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows are not supported in sharded solves");
+  if (!p->schur_reg) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows need the T-record Schur path (CBA_SCHUR=lds is set, or a point exceeds the pair capacity)");
+  HIPCHK(hipSetDevice(p->device));
+  const int P = p->P;
+  for (long e = 0; e < (long)n_con * 4; ++e)
+    if (groups_a[e] < 0 || groups_a[e] >= P || groups_b[e] < 0 || groups_b[e] >= P)
+      return fail(CBA_ERR_INVALID, "cba_set_constraints: point index out of range in constraint %ld", e / 4);
+  // connected components of the constraint graph (union-find over world points)
+  std::vector<int> parent(P);
+  for (int q = 0; q < P; ++q) parent[q] = q;
+  auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+  for (int c = 0; c < n_con; ++c) {
+    const int r0 = find(groups_a[4 * c]);
+    for (int s = 0; s < 8; ++s) {
+      const int q = (s < 4) ? groups_a[4 * c + s] : groups_b[4 * c + s - 4];
+      const int r = find(q);
+      if (r != r0) parent[r] = r0;
+    }
+  }
+  std::vector<int> comp_of_root(P, -1), con_comp(n_con);
+  int K = 0;
+  for (int c = 0; c < n_con; ++c) {
+    const int r = find(groups_a[4 * c]);
+    if (comp_of_root[r] < 0) comp_of_root[r] = K++;
+    con_comp[c] = comp_of_root[r];
+  }
+  std::vector<int> comp_con(K + 1, 0), order(n_con);
+  for (int c = 0; c < n_con; ++c) comp_con[con_comp[c] + 1]++;
+  for (int k = 0; k < K; ++k) comp_con[k + 1] += comp_con[k];
+  {
+    std::vector<int> cur(comp_con.begin(), comp_con.end() - 1);
+    for (int c = 0; c < n_con; ++c) order[cur[con_comp[c]]++] = c;  // order[i] = caller's row of the i-th constraint here
+  }
+  std::vector<int> pt((size_t)n_con * 8), lp((size_t)n_con * 8), comp_pt(K + 1, 0), comp_pts;
+  std::vector<double> dist(n_con), wgt(n_con);
+  std::vector<long> comp_m(K + 1, 0);
+  std::vector<int> local(P, -1);
+  long max_m = 0;
+  for (int k = 0; k < K; ++k) {
+    const int first = (int)comp_pts.size();
+    for (int i = comp_con[k]; i < comp_con[k + 1]; ++i) {
+      const int c = order[i];
+      dist[i] = distances[c]; wgt[i] = weights[c];
+      for (int s = 0; s < 8; ++s) {
+        const int q = (s < 4) ? groups_a[4 * c + s] : groups_b[4 * c + s - 4];
+        if (local[q] < 0) { local[q] = (int)comp_pts.size() - first; comp_pts.push_back(q); }
+        pt[(size_t)i * 8 + s] = q; lp[(size_t)i * 8 + s] = local[q];
+      }
+    }
+    for (size_t j = first; j < comp_pts.size(); ++j) local[comp_pts[j]] = -1;
+    comp_pt[k + 1] = (int)comp_pts.size();
+    const long m = comp_con[k + 1] - comp_con[k];
+    comp_m[k + 1] = comp_m[k] + m * m;
+    max_m = std::max(max_m, m);
+    if ((int)comp_pts.size() - first > CON_MAX_POINTS)
+      return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: a constraint component couples %d points (limit %d)", (int)comp_pts.size() - first, CON_MAX_POINTS);
+  }
+  if (comp_m[K] > (1L << 28)) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint components too large (%ld entries of M)", comp_m[K]);
+  int rc;
+  int *dpt = nullptr, *dlp = nullptr, *dorder = nullptr, *dcc = nullptr, *dcp = nullptr, *dcps = nullptr;
+  long* dcm = nullptr;
+  double *ddist = nullptr, *dw = nullptr;
+#define TRYC(e) do { rc = (e); if (rc) return rc; } while (0)
+  TRYC(dev_upload(p, &dpt, pt)); TRYC(dev_upload(p, &dlp, lp)); TRYC(dev_upload(p, &dorder, order)); TRYC(dev_upload(p, &dcc, comp_con));
+  TRYC(dev_upload(p, &dcp, comp_pt)); TRYC(dev_upload(p, &dcps, comp_pts)); TRYC(dev_upload(p, &dcm, comp_m));
+  TRYC(dev_upload(p, &ddist, dist)); TRYC(dev_upload(p, &dw, wgt));
+  ConPlan cp{};
+  cp.n_con = n_con; cp.n_comp = K; cp.pt = dpt; cp.lp = dlp; cp.dist = ddist; cp.weight = dw; cp.order = dorder;
+  cp.comp_con = dcc; cp.comp_pt = dcp; cp.comp_pts = dcps; cp.comp_m = dcm;
+  TRYC(dev_alloc(p, &cp.f, (size_t)n_con)); TRYC(dev_alloc(p, &cp.u, (size_t)n_con * 3)); TRYC(dev_alloc(p, &cp.z, (size_t)n_con * 24));
+  TRYC(dev_alloc(p, &cp.M, (size_t)std::max<long>(comp_m[K], 1))); TRYC(dev_alloc(p, &cp.G, (size_t)n_con * (p->ncp + 1)));
+  TRYC(dev_alloc(p, &cp.cdiag, (size_t)3 * p->lay.Ppad)); TRYC(dev_alloc(p, &cp.w, (size_t)n_con));
+#undef TRYC
+  HIPCHK(hipMemset(cp.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double)));
+  p->con = cp;
+  p->con_grid = std::max(1, std::min((n_con + BLOCK - 1) / BLOCK, 1024));
+  return CBA_OK;
+}
 
 int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
   if (!p || !x0 || !cost_out) return fail(CBA_ERR_INVALID, "cba_begin: null argument");
@@ -1255,6 +1367,7 @@ int cba_comm_unique_id(char* out128) {
 int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world) {
   if (!p || !id128) return fail(CBA_ERR_INVALID, "cba_comm_init: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(CBA_ERR_INVALID, "cba_comm_init: rank %d of %d", rank, world);
+  if (p->con.n_con && world > 1) return fail(CBA_ERR_UNSUPPORTED, "cba_comm_init: constraint rows are not supported in sharded solves");
   if (p->comm) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
   HIPCHK(hipSetDevice(p->device));
   p->rank = rank; p->world = world;
@@ -1309,14 +1422,15 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   HIPCHK(hipSetDevice(p->device));
   // scratch: v2 holds the vector, tab_new the camera table (both are dead between solver calls)
   double* d_r = nullptr;
-  HIPCHK(hipMalloc((void**)&d_r, (size_t)2 * p->N * sizeof(double)));
+  const size_t n_rows = (size_t)2 * p->N + (size_t)p->con.n_con;  // reprojection rows, then the constraint rows
+  HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
   pack_host(p, x, p->h_vec.data(), 0.0);
   hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
   if (e == hipSuccess) e = hipMemsetAsync(p->flags, 0, sizeof(int), p->stream);
   if (e == hipSuccess) {
     launch_cam_prep(p, p->v2, p->tab_new);
     launch_cost(p, p->v2, p->tab_new, 24, d_r);
-    e = hipMemcpyAsync(r_out, d_r, (size_t)2 * p->N * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    e = hipMemcpyAsync(r_out, d_r, n_rows * sizeof(double), hipMemcpyDeviceToHost, p->stream);
   }
   int rc = (e == hipSuccess) ? exchange(p, SLOT(24), false) : fail(CBA_ERR_HIP, "cba_residuals: %s", hipGetErrorString(e));
   if (!rc) rc = sync_scalars(p, 32);

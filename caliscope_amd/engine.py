@@ -33,6 +33,12 @@ class BAProblem:
     obj_indices: np.ndarray  # (N,) int
     loss: str = "linear"
     f_scale: float = 1.0
+    # rigid-distance constraint rows (reference capture_volume.py:446-531): (n_con, 4) endpoint groups of world-point
+    # rows, target distances, row weights; None = no constraint rows
+    constraint_groups_a: np.ndarray | None = None
+    constraint_groups_b: np.ndarray | None = None
+    constraint_distances: np.ndarray | None = None
+    constraint_weights: np.ndarray | None = None
 
     def __post_init__(self):
         self.camera_indices = np.ascontiguousarray(self.camera_indices, dtype=np.int32)
@@ -48,6 +54,26 @@ class BAProblem:
                 raise ValueError("camera index out of range")
             if self.obj_indices.min() < 0 or self.obj_indices.max() >= self.parameterization.n_points:
                 raise ValueError("world-point index out of range")
+        if self.constraint_groups_a is not None:
+            self.constraint_groups_a = np.ascontiguousarray(self.constraint_groups_a, dtype=np.int32).reshape(-1, 4)
+            self.constraint_groups_b = np.ascontiguousarray(self.constraint_groups_b, dtype=np.int32).reshape(-1, 4)
+            self.constraint_distances = np.ascontiguousarray(self.constraint_distances, dtype=np.float64).ravel()
+            self.constraint_weights = np.ascontiguousarray(self.constraint_weights, dtype=np.float64).ravel()
+            m = self.constraint_groups_a.shape[0]
+            if not (self.constraint_groups_b.shape[0] == self.constraint_distances.size == self.constraint_weights.size == m):
+                raise ValueError("constraint arrays must have the same length")
+            P = self.parameterization.n_points
+            if m and (min(self.constraint_groups_a.min(), self.constraint_groups_b.min()) < 0
+                      or max(self.constraint_groups_a.max(), self.constraint_groups_b.max()) >= P):
+                raise ValueError("constraint point index out of range")
+
+    @property
+    def n_constraints(self) -> int:
+        return 0 if self.constraint_groups_a is None else int(self.constraint_groups_a.shape[0])
+
+    def constraint_args(self):
+        """The four trailing ``args`` of the reference's least_squares call (all None without constraints)."""
+        return (self.constraint_groups_a, self.constraint_groups_b, self.constraint_distances, self.constraint_weights)
 
     @property
     def n_obs(self) -> int:

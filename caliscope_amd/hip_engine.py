@@ -56,6 +56,15 @@ class HipEngine:
         self.n_params = problem.n_params
         self.n_cam_params = par.n_camera_params
         self.n_obs = problem.n_obs
+        self.n_constraints = getattr(problem, "n_constraints", 0)
+        if self.n_constraints:
+            ga, gb, dist, wgt = problem.constraint_args()
+            self._keep += [ga, gb, dist, wgt]
+            try:
+                self._check(self.lib.cba_set_constraints(self._h, self.n_constraints, _ip(ga), _ip(gb), _dp(dist), _dp(wgt)), "cba_set_constraints")
+            except Exception:
+                self.close()
+                raise
 
     # -- lifetime ------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -133,7 +142,7 @@ class HipEngine:
 
     def residuals(self, x: np.ndarray) -> tuple[np.ndarray, float]:
         x = np.ascontiguousarray(x, dtype=np.float64)
-        r = np.empty(2 * self.n_obs)
+        r = np.empty(2 * self.n_obs + self.n_constraints)  # reprojection rows, then the constraint rows
         cost = C.c_double()
         self._check(self.lib.cba_residuals(self._h, _dp(x), _dp(r), C.byref(cost)), "cba_residuals")
         return r, cost.value

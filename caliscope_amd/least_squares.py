@@ -103,11 +103,11 @@ def least_squares(
     if len(args) < 4:
         raise ValueError("args must be (parameterization, camera_indices, image_coords, obj_indices, ...) as in CaptureVolume.optimize")
     parameterization, camera_indices, image_coords, obj_indices = args[:4]
-    if any(a is not None for a in args[4:8]):
-        raise BackendError(
-            "constraint rows (rigid distances) are not implemented in the MI355X engine yet; "
-            "call optimize(use_constraints=False) or use the scipy path for constrained volumes"
-        )
+    con = tuple(args[4:8]) + (None,) * (4 - len(args[4:8]))
+    if any(a is not None for a in con) and any(a is None for a in con):
+        raise ValueError("constraint args (groups_a, groups_b, distances, weights) must be all given or all None")
+    if con[0] is not None and len(con[2]) == 0:
+        con = (None, None, None, None)
     x0 = np.atleast_1d(np.asarray(x0, dtype=np.float64))
     if x0.ndim != 1:
         raise ValueError("`x0` must have at most 1 dimension.")
@@ -133,7 +133,8 @@ def least_squares(
             raise BackendError("bounds on world points are not supported (the reference never sets them)")
         x0 = _make_strictly_feasible(x0, lb, ub)
 
-    problem = BAProblem(parameterization, camera_indices, image_coords, obj_indices, loss=loss, f_scale=float(f_scale))
+    problem = BAProblem(parameterization, camera_indices, image_coords, obj_indices, loss=loss, f_scale=float(f_scale),
+                        constraint_groups_a=con[0], constraint_groups_b=con[1], constraint_distances=con[2], constraint_weights=con[3])
     if engine_factory is None:
         from caliscope_amd.hip_engine import HipEngine
 

@@ -64,12 +64,17 @@ def _value(v: Any) -> str:
 
 
 def dumps_toml(data: dict) -> str:
-    """Serialise nested dicts of scalars / lists: top-level scalars first, then ``[a.b]`` tables depth-first."""
+    """Serialise nested dicts of scalars / lists: top-level scalars first, then ``[a.b]`` tables depth-first, then
+    ``[[a.b]]`` arrays of tables (non-empty lists of dicts)."""
     lines: list[str] = []
 
+    def is_aot(v: Any) -> bool:
+        return isinstance(v, (list, tuple)) and len(v) > 0 and all(isinstance(x, dict) for x in v)
+
     def emit(table: dict, prefix: str) -> None:
-        scalars = {k: v for k, v in table.items() if not isinstance(v, dict)}
+        scalars = {k: v for k, v in table.items() if not isinstance(v, dict) and not is_aot(v)}
         tables = {k: v for k, v in table.items() if isinstance(v, dict)}
+        arrays = {k: v for k, v in table.items() if is_aot(v)}
         if prefix and (scalars or not tables):
             lines.append(f"[{prefix}]")
         for k, v in scalars.items():
@@ -78,6 +83,15 @@ def dumps_toml(data: dict) -> str:
             lines.append("")
         for k, v in tables.items():
             emit(v, f"{prefix}.{_key(k)}" if prefix else _key(k))
+        for k, items in arrays.items():
+            name = f"{prefix}.{_key(k)}" if prefix else _key(k)
+            for item in items:
+                if any(isinstance(x, dict) or is_aot(x) for x in item.values()):
+                    raise TypeError("nested tables inside an array of tables are not supported")
+                lines.append(f"[[{name}]]")
+                for ik, iv in item.items():
+                    lines.append(f"{_key(ik)} = {_value(iv)}")
+                lines.append("")
 
     def _key(k: Any) -> str:
         k = str(k)

@@ -146,8 +146,9 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out);
  * used by the host to test trial points against the intrinsic bounds. */
 int cba_get_camera_params(cba_problem* p, int32_t which, double* out);
 
-/* joint_residuals(x) in the caller's observation order, interleaved (x0,y0,x1,y1,...) [2N], and the
- * (robust) cost.  Does not disturb the solver state. */
+/* joint_residuals(x) in the caller's observation order, interleaved (x0,y0,x1,y1,...) [2N], followed by the
+ * constraint rows [n_con] when cba_set_constraints was called, and the (robust) cost.  Does not disturb the solver
+ * state. */
 int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out);
 
 /* Blocks of J^T J and J^T f at x (robust-scaled like scipy's J, f):
@@ -191,6 +192,15 @@ int cba_enable_timers(cba_problem* p, int32_t on);
  * (>= 0) or a negative error (a point with more than chunk_cap observations is CBA_ERR_UNSUPPORTED). */
 int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
                       int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out);
+
+/* Rigid-distance constraint rows appended after the 2 n_obs reprojection rows (reference core/reprojection.py:112-117
+ * residual, :207-226 Jacobian; group arrays as built by capture_volume.py:446-531):
+ *   r_c = weights[c] * (|| mean(X[groups_a[c][0..3]]) - mean(X[groups_b[c][0..3]]) || - distances[c]).
+ * A corner endpoint repeats one point index four times.  The robust loss applies to these rows as to the others.
+ * Call once, after cba_create and before cba_begin.  Single-rank solves only; one connected component of the
+ * constraint graph (one board in one frame) may couple at most 256 points. */
+int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, const int32_t* groups_b, const double* distances,
+                        const double* weights);
 
 /* ---- the step before the path: undistortion + batched DLT triangulation (x0 of the world points) ----
  *

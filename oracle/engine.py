@@ -67,7 +67,7 @@ class _LocalParam:
 
 class OracleEngine:
     def __init__(self, parameterization, camera_indices, image_coords, obj_indices, loss="linear", f_scale=1.0,
-                 owned_points=None, allreduce=None):
+                 owned_points=None, allreduce=None, constraints=None):
         """``owned_points``: sorted global ids of the points this rank owns (None = all)."""
         self.par = parameterization
         self.ncp = parameterization.n_camera_params
@@ -87,7 +87,12 @@ class OracleEngine:
         self.n_params = parameterization.n_camera_params + 3 * P
         self.loss = loss
         self.f_scale = f_scale
-        self._loss_fn = construct_loss_function(2 * self.cam_idx.size, loss, f_scale)
+        # rigid-distance constraint rows (groups_a, groups_b, distances, weights), single-rank problems only
+        self.constraints = tuple(constraints) if constraints is not None and constraints[0] is not None else None
+        if self.constraints is not None and owned_points is not None:
+            raise ValueError("constraint rows are not supported in sharded solves")
+        n_con = 0 if self.constraints is None else len(self.constraints[0])
+        self._loss_fn = construct_loss_function(2 * self.cam_idx.size + n_con, loss, f_scale)
         self._allreduce = allreduce if allreduce is not None else (lambda a: a)
         self.scale_inv = None
         self.x = None
@@ -112,8 +117,11 @@ class OracleEngine:
         pts = x_full[self.ncp :].reshape(-1, 3)[self.owned].reshape(-1)
         return np.concatenate([x_full[: self.ncp], pts])
 
+    def _con_args(self):
+        return () if self.constraints is None else self.constraints
+
     def _residuals(self, xl):
-        return joint_residuals(xl, self.lpar, self.cam_idx, self.uv, self.obj)
+        return joint_residuals(xl, self.lpar, self.cam_idx, self.uv, self.obj, *self._con_args())
 
     def _cost(self, f) -> float:
         if not np.all(np.isfinite(f)):
@@ -132,7 +140,7 @@ class OracleEngine:
     def linearize(self):
         ncp = self.ncp
         f = self.f_raw.copy()
-        J = joint_jacobian(self.x, self.lpar, self.cam_idx, self.uv, self.obj).tocsr()
+        J = joint_jacobian(self.x, self.lpar, self.cam_idx, self.uv, self.obj, *self._con_args()).tocsr()
         if self._loss_fn is not None:
             rho = self._loss_fn(f)
             J, f = scale_for_robust_loss_function(J, f, rho)
@@ -148,9 +156,11 @@ class OracleEngine:
         Hpp = H[ncp:, ncp:].tocsr()
         V = np.zeros((nloc, 3, 3))
         coo = Hpp.tocoo()
-        V[coo.row // 3, coo.row % 3, coo.col % 3] = coo.data  # block diagonal by construction
-        assert np.all(coo.row // 3 == coo.col // 3)
+        blockdiag = coo.row // 3 == coo.col // 3  # all of it without constraint rows
+        V[coo.row[blockdiag] // 3, coo.row[blockdiag] % 3, coo.col[blockdiag] % 3] = coo.data[blockdiag]
+        assert self.constraints is not None or np.all(blockdiag)
         self.V = V
+        self.H = H if self.constraints is not None else None  # constraint rows couple points: direct solve (newton_step)
         col_sq = np.concatenate([np.diag(U), V[:, [0, 1, 2], [0, 1, 2]].reshape(-1)])
         scale_inv = np.sqrt(col_sq)
         if self.scale_inv is None:
@@ -175,9 +185,32 @@ class OracleEngine:
         fn = getattr(self, "allreduce_max", None)
         return float(fn(v)) if fn is not None else float(v)
 
+    def _finish_step(self, s):
+        self.s = s
+        p = s * self.scale_inv
+        g_h = self.g / self.scale_inv
+        gh_sq = self._norm_sq(g_h)
+        ghp = self._dot(g_h, p)
+        w = p - (ghp / gh_sq) * g_h
+        return _Step(True, self._norm_sq(p), ghp, self._norm_sq(w))
+
     def newton_step(self, lam):
         ncp = self.ncp
         D2 = self.scale_inv**2
+        if self.H is not None:
+            # with constraint rows H_pp is not block diagonal: factor the whole damped system (the device path's
+            # Woodbury correction is checked against this)
+            import scipy.sparse as sp
+            from scipy.sparse.linalg import splu
+
+            A = (self.H + lam * sp.diags(D2)).tocsc()
+            try:
+                s = splu(A).solve(-self.g)
+            except RuntimeError:
+                return _Step(False, 0.0, 0.0, 0.0)
+            if not np.all(np.isfinite(s)):
+                return _Step(False, 0.0, 0.0, 0.0)
+            return self._finish_step(s)
         g_c, g_p = self.g[:ncp], self.g[ncp:].reshape(-1, 3)
         Vd = self.V + lam * np.einsum("pi,ij->pij", D2[ncp:].reshape(-1, 3), np.eye(3))
         has_obs = np.bincount(self.obj, minlength=self.owned.size) > 0
@@ -202,14 +235,7 @@ class OracleEngine:
         dc = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
         dp = -np.einsum("pij,pj->pi", Vinv, g_p + np.einsum("cpi,c->pi", Wd, dc))
         dp[~has_obs] = 0.0
-        s = np.concatenate([dc, dp.reshape(-1)])
-        self.s = s
-        p = s * self.scale_inv
-        g_h = self.g / self.scale_inv
-        gh_sq = self._norm_sq(g_h)
-        ghp = self._dot(g_h, p)
-        w = p - (ghp / gh_sq) * g_h
-        return _Step(True, self._norm_sq(p), ghp, self._norm_sq(w))
+        return self._finish_step(np.concatenate([dc, dp.reshape(-1)]))
 
     def subspace_gram(self, a1, b1, a2, b2):
         d2g = self.g / self.scale_inv**2

@@ -14,15 +14,23 @@ from oracle.residuals import joint_jacobian, joint_residuals, reprojection_error
 
 
 def optimize_scipy(parameterization, camera_indices, image_coords, obj_indices, x0, *, ftol=1e-8, xtol=1e-8,
-                   gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, verbose=0, tr_options=None):
+                   gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, verbose=0, tr_options=None, constraints=None, tr_solver=None):
+    """``constraints`` = (groups_a, groups_b, distances, weights) or None: the four trailing ``args`` of the reference call.
+    ``tr_solver`` None is the reference's call (scipy then picks 'lsmr' for the sparse Jacobian: inexact steps that crawl
+    along weakly determined directions); tests that need the fully converged point pass 'exact' (dense SVD steps)."""
     kw = {}
+    jac = joint_jacobian
+    if tr_solver is not None:
+        kw["tr_solver"] = tr_solver
+        if tr_solver == "exact":  # scipy accepts 'exact' with a dense Jacobian only
+            jac = lambda *a: joint_jacobian(*a).toarray()  # noqa: E731
     if tr_options is not None:
         kw["tr_options"] = tr_options
     return least_squares(
         joint_residuals,
         x0,
-        args=(parameterization, camera_indices, image_coords, obj_indices, None, None, None, None),
-        jac=joint_jacobian,
+        args=(parameterization, camera_indices, image_coords, obj_indices, *(constraints if constraints is not None else (None, None, None, None))),
+        jac=jac,
         verbose=verbose,
         x_scale="jac",
         loss=loss,

@@ -73,8 +73,14 @@ def test_invalid_inputs_raise_like_scipy():
     with pytest.raises(ValueError, match="outside of provided bounds"):
         least_squares(None, x0, args=args, x_scale="jac", bounds=(lo, hi))
     ga = np.zeros((1, 4), dtype=np.int32)
-    with pytest.raises(BackendError, match="constraint rows"):
-        least_squares(None, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, ga, ga, np.ones(1), np.ones(1)),
+    with pytest.raises(ValueError, match="all given or all None"):
+        least_squares(None, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, ga, ga, None, np.ones(1)),
+                      x_scale="jac")
+    with pytest.raises(ValueError, match="same length"):
+        least_squares(None, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, ga, ga, np.ones(2), np.ones(1)),
+                      x_scale="jac")
+    with pytest.raises(ValueError, match="constraint point index"):
+        least_squares(None, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, ga + 10**6, ga, np.ones(1), np.ones(1)),
                       x_scale="jac")
     bad = x0.copy()
     bad[par.n_camera_params + 2] = np.nan
