@@ -63,6 +63,20 @@ class Info(C.Structure):
     ]
 
 
+class SolveOptions(C.Structure):
+    _fields_ = [
+        ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double), ("max_nfev", C.c_int64),
+        ("lb", c_double_p), ("ub", c_double_p), ("verbose", C.c_int32), ("max_damping_retries", C.c_int32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("reserved", C.c_int32), ("nfev", C.c_int64), ("njev", C.c_int64), ("n_iterations", C.c_int64),
+        ("cost", C.c_double), ("optimality", C.c_double), ("t_total_s", C.c_double),
+    ]
+
+
 class TriangulateDesc(C.Structure):
     _fields_ = [
         ("n_cams", C.c_int32),
@@ -91,6 +105,10 @@ SIGNATURES = {
     "cba_subspace_gram": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]),
     "cba_trial": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(TrialInfo)]),
     "cba_accept": (C.c_int, [C.c_void_p]),
+    "cba_set_camera_scaling": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(Linearization)]),
+    "cba_subspace_gram_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.c_double, C.c_double, c_double_p, c_double_p]),
+    "cba_trial_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.POINTER(TrialInfo)]),
+    "cba_solve": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(SolveOptions), c_double_p, C.POINTER(Result)]),
     "cba_get_vector": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "cba_get_camera_params": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "cba_residuals": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
@@ -105,6 +123,7 @@ SIGNATURES = {
     "cba_host_plan": (C.c_int64, [C.c_int32, C.c_int64, c_int32_p, c_int32_p, C.c_int32, C.c_int32, c_int64_p, c_int64_p, c_int64_p]),
     "cba_triangulate": (C.c_int, [C.POINTER(TriangulateDesc), C.c_int32, c_double_p, c_double_p]),
     "cba_last_error": (C.c_char_p, []),
+    "cba_set_error": (C.c_int, [C.c_int32, C.c_char_p]),
     "cba_version": (C.c_int, []),
     "cba_device_count": (C.c_int, []),
 }

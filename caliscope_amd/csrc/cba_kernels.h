@@ -381,9 +381,20 @@ __global__ void k_scale_update(const double* __restrict__ Upacked, const double*
 //   partial[b][0..3] = sum (g/sinv)^2, sum (x sinv)^2, sum x^2, (unused) ; partial_max[b] = max |g|
 // `cam_end` = ncp_pad; `count_cams` = 0 on ranks > 0 of a sharded solve: camera entries are replicated
 // on every rank and must enter the all-reduced sums once.
+
+// Coleman-Li scaling of the bounded camera parameters (cba_set_camera_scaling): effective scale of the camera block
+// sinv = state * mult, extra diagonal of the damped system in x-space = diag_h * sinv^2.
+__global__ void k_cam_rescale(const double* __restrict__ state, const double* __restrict__ mult, const double* __restrict__ diag_h,
+                              int ncp, double* __restrict__ sinv, double* __restrict__ cam_diag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncp) return;
+  const double si = state[i] * mult[i];
+  sinv[i] = si;
+  cam_diag[i] = diag_h[i] * si * si;
+}
 __global__ void __launch_bounds__(BLOCK)
 k_lin_scalars(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
-              long total, int cam_end, int count_cams, double* __restrict__ v1, double* __restrict__ partial,
+              long total, int cam_end, int count_cams, int max_from, double* __restrict__ v1, double* __restrict__ partial,
               double* __restrict__ partial_max) {
   __shared__ double sh_red[BLOCK / WAVE];
   double s0 = 0, s1 = 0, s2 = 0, m = 0;
@@ -391,7 +402,7 @@ k_lin_scalars(const double* __restrict__ x, const double* __restrict__ g, const 
     const double gi = g[i], si = sinv[i], xi = x[i];
     const double gh = gi / si;
     v1[i] = gh / si;
-    m = fmax(m, fabs(gi));
+    if (i >= max_from) m = fmax(m, fabs(gi));  // max_from = cam_end: point block only (bounded solves weigh the camera block on the host)
     if (i < cam_end && !count_cams) continue;
     s0 += gh * gh;
     s1 += (xi * si) * (xi * si);
@@ -405,12 +416,12 @@ k_lin_scalars(const double* __restrict__ x, const double* __restrict__ g, const 
   r = block_max(m, sh_red); if (threadIdx.x == 0) partial_max[blockIdx.x] = r;
 }
 
-// out = a * g / sinv^2 + b * s
+// out = a * g / sinv^2 + b * s ; entries below n_over are taken from `over` instead (camera block given by the caller)
 __global__ void k_combine(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s,
-                          double a, double b, long total, double* __restrict__ out) {
+                          double a, double b, long total, const double* __restrict__ over, int n_over, double* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const double si = sinv[i];
-    out[i] = a * g[i] / (si * si) + b * s[i];
+    out[i] = (i < n_over) ? over[i] : a * g[i] / (si * si) + b * s[i];
   }
 }
 
@@ -1023,13 +1034,13 @@ k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* 
   }
 }
 
-// S = U + lam D_c^2 - Sacc (symmetric, both triangles written), rhs = -g_c + b
+// S = U + lam D_c^2 + cam_diag - Sacc (symmetric, both triangles written), rhs = -g_c + b
 template <int NC>
 __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,
                                  const double* __restrict__ Upacked, const double* __restrict__ gvec,
                                  const double* __restrict__ sinv, const int* __restrict__ param_cam,
-                                 const int* __restrict__ param_loc, int ncp, double lam, double* __restrict__ S,
-                                 double* __restrict__ rhs, double* __restrict__ W, int ldw) {
+                                 const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ cam_diag,
+                                 double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ W, int ldw) {
   using UP = UPack<NC>;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)ncp * ncp) return;
@@ -1038,7 +1049,7 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
   double v = -Sacc[(long)row * ncp + col];
   if (param_cam[row] == param_cam[col]) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
   if (row == col) {
-    v += lam * sinv[row] * sinv[row];
+    v += lam * sinv[row] * sinv[row] + cam_diag[row];  // cam_diag: zero unless the caller set a bound scaling
     const double rv = -gvec[row] + bacc[row];
     rhs[row] = rv;
     W[(long)ncp * ldw + row] = rv;  // rhs^T: last row of the Cholesky work matrix
@@ -1558,17 +1569,19 @@ k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const 
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-// x_new = x + alpha g / sinv^2 + beta s ; partial[b] = sum step^2
+// x_new = x + alpha g / sinv^2 + beta s (entries below n_over: x_new = cam_x_new) ; partial[b] = sum step^2
 __global__ void __launch_bounds__(BLOCK)
 k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
                const double* __restrict__ s, double alpha, double beta, long total, int cam_end, int count_cams,
-               double* __restrict__ x_new, double* __restrict__ partial) {
+               const double* __restrict__ cam_x_new, int n_over, double* __restrict__ x_new, double* __restrict__ partial) {
   __shared__ double sh_red[BLOCK / WAVE];
   double s0 = 0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     const double si = sinv[i];
-    const double st = alpha * g[i] / (si * si) + beta * s[i];
-    x_new[i] = x[i] + st;
+    double st = alpha * g[i] / (si * si) + beta * s[i];
+    double xn = x[i] + st;
+    if (i < n_over) { xn = cam_x_new[i]; st = xn - x[i]; }  // camera block placed by the caller (bounded solves)
+    x_new[i] = xn;
     if (i >= cam_end || count_cams) s0 += st * st;
   }
   const double r = block_sum(s0, sh_red);

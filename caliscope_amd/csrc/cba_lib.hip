@@ -88,6 +88,8 @@ struct cba_problem {
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
+  double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
+  bool cam_scaled = false, cam_state_saved = false;
   ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
   int con_grid = 0;        // workgroups of the per-constraint kernels
   int* flags = nullptr;
@@ -243,6 +245,8 @@ int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_o
   if (e != hipSuccess) return fail(CBA_ERR_HIP, "cba_triangulate: %s", hipGetErrorString(e));
   return CBA_OK;
 }
+
+int cba_set_error(int32_t code, const char* message) { return fail(code, "%s", message ? message : ""); }
 
 const char* cba_last_error(void) { return g_last_error.c_str(); }
 int cba_version(void) { return CBA_VERSION; }
@@ -817,6 +821,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     TRY(dev_alloc(p, v, (size_t)tot));
     if (hipMemset(*v, 0, tot * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
+  for (double** v : {&p->sinv_state_c, &p->cam_diag, &p->cam_over1, &p->cam_over2}) {
+    TRY(dev_alloc(p, v, (size_t)p->lay.ncp_pad));
+    if (hipMemset(*v, 0, (size_t)p->lay.ncp_pad * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
+  }
   TRY(dev_alloc(p, &p->V, (size_t)6 * p->lay.Ppad));
   HIPCHK(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
@@ -997,12 +1005,15 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
   }
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
+  if (p->cam_scaled)  // the monotone-max rule of the Jacobi scale runs on the unmodified state of the camera block
+    HIPCHK(hipMemcpyAsync(p->sinv, p->sinv_state_c, (size_t)p->lay.ncp_pad * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  p->cam_state_saved = false;
   {
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
                        p->lay, p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr);
     hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->lay.ncp_pad,
-                       p->rank == 0 ? 1 : 0, p->v1, p->partial4, p->partial1);
+                       p->rank == 0 ? 1 : 0, 0, p->v1, p->partial4, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
     hipLaunchKernelGGL(k_reduce_narrow<true>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
   }
@@ -1112,7 +1123,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     }
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
-                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->S, p->rhs, p->Lbuf, p->ldw);
+                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw);
   }
   int rc = run_cholesky(p);
   if (rc) return rc;
@@ -1259,6 +1270,8 @@ int cba_restart(cba_problem* p, double* cost_out) {
 static int begin_common(cba_problem* p, double* cost_out) {
   HIPCHK(hipMemcpyAsync(p->x, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
+  HIPCHK(hipMemsetAsync(p->cam_diag, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream));
+  p->cam_scaled = false; p->cam_state_saved = false;
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
   int rc = launch_cost(p, p->x, p->tab, 24, nullptr);
@@ -1297,15 +1310,26 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
   return CBA_OK;
 }
 
-int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2, double* gram_out) {
+// camera-block override of a device vector: `host` [ncp] -> dev [ncp_pad] (padding stays zero)
+static int upload_cam(cba_problem* p, const double* host, double* dev) {
+  HIPCHK(hipMemcpyAsync(dev, host, (size_t)p->ncp * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  return CBA_OK;
+}
+
+int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam1, double a2, double b2, const double* cam2,
+                         double* gram_out) {
   if (!p || !gram_out) return fail(CBA_ERR_INVALID, "cba_subspace_gram: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_subspace_gram: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
   const long tot = p->lay.total();
+  if (cam1) { int rc = upload_cam(p, cam1, p->cam_over1); if (rc) return rc; }
+  if (cam2) { int rc = upload_cam(p, cam2, p->cam_over2); if (rc) return rc; }
   {
     ScopedTimer t(p, T_VECTOR);
-    hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a1, b1, tot, p->v1);
-    hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a2, b2, tot, p->v2);
+    hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a1, b1, tot,
+                       (const double*)p->cam_over1, cam1 ? p->lay.ncp_pad : 0, p->v1);
+    hipLaunchKernelGGL(k_combine, dim3(vec_grid(tot)), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, a2, b2, tot,
+                       (const double*)p->cam_over2, cam2 ? p->lay.ncp_pad : 0, p->v2);
   }
   DISPATCH_NC(p, run_jv<6>(p, 2), run_jv<9>(p, 2));
   int rc = exchange(p, SLOT(12) | SLOT(13) | SLOT(14) | SLOT(15), false);
@@ -1316,17 +1340,67 @@ int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2
   return CBA_OK;
 }
 
-int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) {
+int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2, double* gram_out) {
+  return cba_subspace_gram_ex(p, a1, b1, nullptr, a2, b2, nullptr, gram_out);
+}
+
+int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out) {
+  if (!p || !mult || !diag_h || !out) return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: null argument");
+  if (!p->linearized) return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: call cba_linearize first");
+  for (int i = 0; i < p->ncp; ++i)
+    if (!(mult[i] > 0.0) || !std::isfinite(mult[i]) || !(diag_h[i] >= 0.0) || !std::isfinite(diag_h[i]))
+      return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: entry %d: mult must be positive and diag_h non-negative (finite)", i);
+  HIPCHK(hipSetDevice(p->device));
+  const int npad = p->lay.ncp_pad;
+  if (!p->cam_state_saved) {  // first call after this linearisation: sinv still holds the Jacobi scale
+    HIPCHK(hipMemcpyAsync(p->sinv_state_c, p->sinv, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    p->cam_state_saved = true;
+  }
+  int rc = upload_cam(p, mult, p->cam_over1);
+  if (!rc) rc = upload_cam(p, diag_h, p->cam_over2);
+  if (rc) return rc;
+  const long tot = p->lay.total();
+  const int vg = vec_grid(tot);
+  {
+    ScopedTimer t(p, T_SCALE_SCALARS);
+    hipLaunchKernelGGL(k_cam_rescale, dim3((p->ncp + 255) / 256), dim3(256), 0, p->stream, p->sinv_state_c, p->cam_over1, p->cam_over2, p->ncp,
+                       p->sinv, p->cam_diag);
+    hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, npad, p->rank == 0 ? 1 : 0, npad,
+                       p->v1, p->partial4, p->partial1);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
+    hipLaunchKernelGGL(k_reduce_narrow<true>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 4);
+  }
+  rc = DISPATCH_NC(p, run_jv<6>(p, 1), run_jv<9>(p, 1));
+  if (rc) return rc;
+  rc = exchange(p, SLOT(0) | SLOT(1) | SLOT(2) | SLOT(3) | SLOT(12) | SLOT(13) | SLOT(14) | SLOT(15), true);
+  if (!rc) rc = sync_scalars(p, 16);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->cam_scaled = true; p->stepped = false;
+  p->gh_sq = p->h_scal[0];
+  out->gh_sq = p->h_scal[0];
+  out->x_scaled_norm = std::sqrt(p->h_scal[1]);
+  out->x_norm = std::sqrt(p->h_scal[2]);
+  out->g_norm_inf = p->h_scal[4];  // point block only
+  out->cost = 0.5 * p->h_scal[8];
+  out->jg_sq = p->h_scal[12];
+  return CBA_OK;
+}
+
+int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { return cba_trial_ex(p, alpha, beta, nullptr, out); }
+
+int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_new, cba_trial_info* out) {
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_trial: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_trial: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
+  if (cam_x_new) { int rcu = upload_cam(p, cam_x_new, p->cam_over1); if (rcu) return rcu; }
   HIPCHK(hipMemsetAsync(p->flags, 0, sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
-                       p->rank == 0 ? 1 : 0, p->x_new, p->partial1);
+                       p->rank == 0 ? 1 : 0, (const double*)p->cam_over1, cam_x_new ? p->ncp : 0, p->x_new, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);

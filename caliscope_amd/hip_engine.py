@@ -129,6 +129,35 @@ class HipEngine:
     def current_x(self) -> np.ndarray:
         return self.get_vector(VEC_X)
 
+    # -- the whole solve in the library (csrc/cba_solve.cpp) ---------------------------------------------
+    def solve(self, x0, *, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, lb=None, ub=None, fetch_x=True):
+        """``cba_solve``: the trust-region loop of :mod:`caliscope_amd.trf` run natively.  ``x0=None`` restarts from the
+        x0 already on the device; ``lb`` / ``ub`` bound the camera block (``n_cam_params`` entries).  Returns a
+        :class:`caliscope_amd.trf.TrfResult` (``x`` is None when ``fetch_x`` is False)."""
+        from caliscope_amd.trf import TrfResult
+
+        keep = []
+        opt = _lib.SolveOptions(ftol=float(ftol), xtol=float(xtol), gtol=float(gtol), max_nfev=0 if max_nfev is None else int(max_nfev),
+                                lb=None, ub=None, verbose=int(verbose), max_damping_retries=0)
+        if lb is not None or ub is not None:
+            for name, b in (("lb", lb), ("ub", ub)):
+                b = np.ascontiguousarray(b, dtype=np.float64)
+                if b.shape != (self.n_cam_params,):
+                    raise ValueError(f"{name} must have {self.n_cam_params} entries (the camera block of x)")
+                keep.append(b)
+                setattr(opt, name, _dp(b))
+        x_in = None
+        if x0 is not None:
+            x_in = np.ascontiguousarray(x0, dtype=np.float64)
+            if x_in.shape != (self.n_params,):
+                raise ValueError(f"x0 has shape {x_in.shape}, expected ({self.n_params},)")
+        x_out = np.empty(self.n_params) if fetch_x else None
+        res = _lib.Result()
+        self._check(self.lib.cba_solve(self._h, None if x_in is None else _dp(x_in), C.byref(opt), None if x_out is None else _dp(x_out),
+                                       C.byref(res)), "cba_solve")
+        return TrfResult(x=x_out, cost=res.cost, optimality=res.optimality, nfev=int(res.nfev), njev=int(res.njev), status=int(res.status),
+                         n_iterations=int(res.n_iterations))
+
     # -- parity hooks --------------------------------------------------------------------------------
     def get_vector(self, which: int) -> np.ndarray:
         out = np.empty(self.n_params)

@@ -23,6 +23,7 @@ filter on trial points rather than by reflective steps.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 
@@ -149,7 +150,15 @@ def least_squares(
             def feasible(cam_params):
                 return bool(np.all(cam_params > lbc) and np.all(cam_params < ubc))
 
-        res = trf_solve(engine, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
+        if hasattr(engine, "solve") and os.environ.get("CBA_HOST_LOOP", "native") != "python":
+            # the whole loop in the library (cba_solve); CBA_HOST_LOOP=python keeps the Python driver on the primitives
+            ncp = parameterization.n_camera_params
+            res = engine.solve(x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose,
+                               lb=lb[:ncp] if bounded else None, ub=ub[:ncp] if bounded else None)
+            if res.status == -1:
+                raise ValueError("Residuals are not finite in the initial point.")
+        else:
+            res = trf_solve(engine, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
     finally:
         close = getattr(engine, "close", None)
         if close is not None:

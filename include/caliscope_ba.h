@@ -39,7 +39,8 @@ enum {
   CBA_ERR_NO_DEVICE = -2,  /* no usable HIP device */
   CBA_ERR_HIP = -3,        /* a HIP runtime call failed */
   CBA_ERR_UNSUPPORTED = -4,/* valid input the engine does not handle yet */
-  CBA_ERR_COMM = -5        /* RCCL failure */
+  CBA_ERR_COMM = -5,       /* RCCL failure */
+  CBA_ERR_NUMERIC = -6     /* the damped normal equations could not be factorised */
 };
 
 enum { CBA_MODEL_PINHOLE_BC5 = 0, CBA_MODEL_FISHEYE4 = 1 };
@@ -136,6 +137,60 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out);
 /* x <- x_new (trf.py:525-526). */
 int cba_accept(cba_problem* p);
 
+/* ---- bounded camera parameters (scipy trf_bounds, trf.py:205-398) ------------------------------------
+ * With finite bounds (free intrinsics: s, k1, k2 of BundleParameterization.bounds()) scipy rescales every bounded
+ * variable by the Coleman-Li vector v (distance to the bound the gradient points at) and adds the diagonal
+ * C = diag(g * dv * scale) to the model Hessian.  Only entries of the camera block can be bounded, so the driver
+ * computes v on the host from the camera parts of x, g and scale_inv and hands two small vectors to the engine:
+ *   mult   [n_cam_params]  effective scale_inv of the camera block = Jacobi scale_inv * mult   (1 / sqrt(v) ; 1 if unbounded)
+ *   diag_h [n_cam_params]  C in the scaled space, >= 0                                           (0 if unbounded)
+ * The damped system of cba_newton_step becomes (J^T J + (lam + diag_h) * scale_inv_eff^2) s = -g, and every scaled
+ * quantity (gh_sq, jg_sq, x_scaled_norm, p_sq, w_sq, the trial step) uses the effective scale.  `out` is the
+ * linearisation in the new scaling, with g_norm_inf = max |g| over the POINT block only (the caller folds the camera
+ * block in with its v).  Call after every cba_linearize of a bounded solve; the Jacobi scale's monotone-max state is
+ * kept apart and is not disturbed. */
+int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out);
+
+/* cba_subspace_gram with the camera block of v1 / v2 replaced by cam1 / cam2 ([n_cam_params], x-space; NULL: not
+ * replaced) — the reflected direction of select_step (trf.py:129-202) differs from the trust-region step in the
+ * camera entries that hit a bound. */
+int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam1, double a2, double b2, const double* cam2,
+                         double* gram_out);
+
+/* cba_trial with the camera block of x_new given by the caller (cam_x_new [n_cam_params], NULL: as cba_trial): the
+ * driver places bounded parameters itself (truncated / reflected steps, make_strictly_feasible). */
+int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_new, cba_trial_info* out);
+
+/* ---- the whole solve behind one call ---------------------------------------------------------------
+ * Replaces the reference's `scipy.optimize.least_squares(joint_residuals, x0, args=(...), jac=joint_jacobian,
+ * x_scale="jac", loss=..., f_scale=..., ftol=..., max_nfev=..., method="trf", bounds=...)` call
+ * (core/capture_volume.py:387-411) for a problem created with cba_create (loss, f_scale and the observation arrays
+ * live in the handle; constraint rows via cba_set_constraints): the trust-region loop of scipy's trf.py:401-560 run
+ * on the primitives above (csrc/cba_solve.cpp).  What the reference consumes of scipy's result (:413-432) is in
+ * cba_result: status (-1..4, scipy's codes), x, nfev, cost. */
+typedef struct {
+  double ftol, xtol, gtol;     /* scipy's tolerances (defaults 1e-8)                                           */
+  int64_t max_nfev;            /* <= 0: 100 * n, scipy's default for max_nfev=None                             */
+  const double* lb;            /* [n_cam_params] bounds of the camera block of x (BundleParameterization.bounds */
+  const double* ub;            /*   restricted to the cameras), or NULL: iterates are kept strictly inside      */
+  int32_t verbose;             /* 2: scipy's per-iteration table on stdout                                     */
+  int32_t max_damping_retries; /* <= 0: 12                                                                     */
+} cba_solve_options;
+
+typedef struct {
+  int32_t status;              /* -1 improper input, 0 max_nfev reached, 1 gtol, 2 ftol, 3 xtol, 4 ftol and xtol */
+  int32_t reserved;
+  int64_t nfev, njev, n_iterations;
+  double cost;                 /* 0.5 * sum rho(f) at the returned x                                           */
+  double optimality;           /* ||J^T f||_inf at the returned x                                              */
+  double t_total_s;            /* wall time of the call                                                        */
+} cba_result;
+
+/* x0 [n] (NULL: restart from the x0 of the previous cba_begin / cba_solve, kept on the device), opt (NULL: defaults),
+ * x_out [n] or NULL (the solution stays on the device, cba_get_vector(CBA_VEC_X)).  In a sharded solve every rank
+ * calls it with its own handle; the scalars steering the loop are identical on all ranks. */
+int cba_solve(cba_problem* p, const double* x0, const cba_solve_options* opt, double* x_out, cba_result* out);
+
 /* ---- parity hooks / readback -------------------------------------------------------------------- */
 enum { CBA_VEC_X = 0, CBA_VEC_X_NEW = 1, CBA_VEC_GRAD = 2, CBA_VEC_STEP = 3, CBA_VEC_SCALE_INV = 4 };
 
@@ -228,6 +283,8 @@ typedef struct {
 int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_out, double* undistorted_out);
 
 const char* cba_last_error(void);
+/* Sets the calling thread's error message and returns `code` (for drivers layered on the primitives, cba_solve). */
+int cba_set_error(int32_t code, const char* message);
 int cba_version(void);
 int cba_device_count(void);
 

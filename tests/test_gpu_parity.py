@@ -374,3 +374,58 @@ def test_stage_driver_on_device():
     assert out.optimization_status.converged and run.intrinsic_refinement_gated
     assert out.reprojection_report.overall_rmse < 1.0 < cv.reprojection_report.overall_rmse
     assert len(out.image_points) < len(cv.image_points)
+
+
+@pytest.mark.parametrize("name", ["pinhole_locked_C8", "huber_outliers_C8", "pinhole_refine_C6", "global_atomics_C24"])
+def test_cba_solve_matches_python_driver(name):
+    """cba_solve (csrc/cba_solve.cpp) against the Python driver on the same device primitives: same accept/reject
+    sequence without finite bounds; with bounds (refine) the native driver runs scipy's bounded variant (Coleman-Li
+    scaling), the Python one only guards feasibility — interior solutions agree at convergence."""
+    sc, par, x0, loss, fs = _case(name)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs)
+    lb, ub = par.bounds()
+    ncp = par.n_camera_params
+    bounded = par.has_finite_bounds
+    from caliscope_amd.hip_engine import HipEngine
+
+    with HipEngine(prob) as eng:
+        feas = (lambda c: bool(np.all(c > lb[:ncp]) and np.all(c < ub[:ncp]))) if bounded else None
+        ref = trf_solve(eng, x0, feasible=feas)
+        got = eng.solve(x0, lb=lb[:ncp] if bounded else None, ub=ub[:ncp] if bounded else None)
+        assert got.status > 0 and ref.status > 0
+        if not bounded:
+            assert (got.status, got.nfev, got.njev, got.n_iterations) == (ref.status, ref.nfev, ref.njev, ref.n_iterations)
+            assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost
+            pos, ang, _ = aligned_difference(par, got.x, ref.x)  # raw x wanders along the gauge directions (lam ~ 1e-15 there)
+            assert pos < 1e-7 and ang < 1e-7
+        else:
+            assert abs(got.cost - ref.cost) <= 1e-6 * ref.cost
+            pos, ang, _ = aligned_difference(par, got.x, ref.x)
+            assert pos < 1e-4 and ang < 1e-4
+        again = eng.solve(None, lb=lb[:ncp] if bounded else None, ub=ub[:ncp] if bounded else None, fetch_x=False)  # restart from the x0 on the device
+        assert again.x is None and (again.status, again.nfev) == (got.status, got.nfev) and abs(again.cost - got.cost) <= 1e-12 * got.cost
+        capped = eng.solve(x0, max_nfev=2, ftol=1e-15, xtol=1e-15, gtol=1e-15)
+        assert capped.status == 0 and capped.nfev == 2
+
+
+def test_solution_on_an_intrinsic_bound_matches_scipy():
+    """4 cameras / 40 points with free intrinsics: k2 of one camera is driven onto its lower bound (-2).  scipy's bounded
+    TRF (Coleman-Li scaling + reflective steps, trf.py:205-398) gets there; so must the device path."""
+    from caliscope_amd.least_squares import least_squares
+    from oracle.residuals import joint_jacobian, joint_residuals
+    from oracle.solver import optimize_scipy
+
+    sc, par, x0 = small_problem(n_cams=4, n_points=40, k=4, refine=True)
+    args = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    ncp = par.n_camera_params
+    lb, ub = par.bounds()
+    ref = optimize_scipy(*args, x0)
+    got = least_squares(joint_residuals, x0, args=(*args, None, None, None, None), jac=joint_jacobian, x_scale="jac", method="trf", bounds=(lb, ub))
+    assert got.status > 0 and abs(got.cost - ref.cost) <= 1e-6 * ref.cost and got.cost <= ref.cost * (1 + 1e-9)
+    intr = got.x[:ncp].reshape(-1, 9)[:, 6:]
+    assert np.all(got.x[:ncp] > lb[:ncp]) and np.all(got.x[:ncp] < ub[:ncp]) and intr[:, 2].min() < -1.999
+    tight = dict(ftol=1e-15, xtol=1e-15, gtol=1e-11, max_nfev=100)
+    got_t = least_squares(joint_residuals, x0, args=(*args, None, None, None, None), jac=joint_jacobian, x_scale="jac", method="trf", bounds=(lb, ub), **tight)
+    ref_t = optimize_scipy(*args, x0, tr_solver="exact", **tight)
+    assert abs(got_t.cost - ref_t.cost) <= 1e-10 * ref_t.cost
+    assert np.abs(got_t.x[:ncp].reshape(-1, 9)[:, 6:] - ref_t.x[:ncp].reshape(-1, 9)[:, 6:]).max() < 1e-5
