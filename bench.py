@@ -65,12 +65,11 @@ def build_problem(name, seed=42, shard=0, **overrides):
 
 
 def run_iterations(engine, k_steps, solve_kw):
-    """Execute exactly k_steps trial iterations; returns (n_solves, last_result)."""
-    from caliscope_amd.trf import trf_solve
-
+    """Execute exactly k_steps trial iterations through cba_solve (the product's driver: the trust-region loop runs in
+    the library, restarting from the x0 kept on the device); returns (n_solves, last_result)."""
     done, solves, last = 0, 0, None
     while done < k_steps:
-        last = trf_solve(engine, None, max_nfev=(k_steps - done) + 1, fetch_x=False, **solve_kw)
+        last = engine.solve(None, max_nfev=(k_steps - done) + 1, fetch_x=False, **solve_kw)
         done += last.nfev - 1
         solves += 1
         if last.nfev <= 1:  # already converged at x0: nothing to iterate on
@@ -102,13 +101,15 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     """Weak scaling: rank r owns shard r (its own points/observations of the same cameras); the engine
     all-reduces the camera blocks, the reduced camera system and the scalar sums over RCCL."""
     from caliscope_amd.hip_engine import HipEngine
-    from caliscope_amd.trf import trf_solve
 
     control = control or _Solo()
-    solve_kw = solve_kw or {}
+    solve_kw = dict(solve_kw or {})
     t_gen = time.time()
     sc, par, x0, prob, cfg = build_problem(name, seed=seed, shard=control.rank, **overrides)
     t_gen = time.time() - t_gen
+    if par.has_finite_bounds:  # free intrinsics: the bounds of BundleParameterization.bounds(), as CaptureVolume.optimize passes them
+        lb, ub = par.bounds()
+        solve_kw.update(lb=np.ascontiguousarray(lb[: par.n_camera_params]), ub=np.ascontiguousarray(ub[: par.n_camera_params]))
     eng = HipEngine(prob, device_id=device_id)
     if control.world > 1:
         uid = control.broadcast_bytes(eng.comm_unique_id() if control.rank == 0 else None, 128)
@@ -133,7 +134,7 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         tm = eng.timers()
         eng.enable_timers(False)
     # untimed: full solve for the accuracy figure (squared pixel errors summed over all shards)
-    full = trf_solve(eng, None, **solve_kw)
+    full = eng.solve(None, **solve_kw)
 
     def rms_all(x):
         r, _ = eng.residuals(x)
