@@ -323,6 +323,14 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       gp[lay.Ppad + p] = acc[7];
       gp[2 * lay.Ppad + p] = acc[8];
     };
+    if (npts < 0 && threadIdx.x < 9) {
+      // fragment of a heavy point (more observations than a chunk holds): the whole chunk is point cp0; its sums go
+      // to V / g by atomics (zeroed by k_zero_heavy before the pass)
+      double acc = 0.0;
+      for (int j = 0; j < o1 - o0; ++j) acc += sh_pt[threadIdx.x * CHUNK + j];
+      if (threadIdx.x < 6) unsafeAtomicAdd(&Vblk[(long)threadIdx.x * lay.Ppad + cp0], acc);
+      else unsafeAtomicAdd(&gp[(long)(threadIdx.x - 6) * lay.Ppad + cp0], acc);
+    }
     if ((int)threadIdx.x < npts && pb > pa) reduce_point(pp, pa, pb);
     for (int lp = threadIdx.x + BLOCK; lp < npts; lp += BLOCK) {  // a range padded by unobserved points: rare
       const int p = cp0 + lp;
@@ -377,11 +385,6 @@ __global__ void k_scale_update(const double* __restrict__ Upacked, const double*
   }
 }
 
-// scalars of the linearisation + v1 = g / scale_inv^2 (the direction of the gradient in scaled space)
-//   partial[b][0..3] = sum (g/sinv)^2, sum (x sinv)^2, sum x^2, (unused) ; partial_max[b] = max |g|
-// `cam_end` = ncp_pad; `count_cams` = 0 on ranks > 0 of a sharded solve: camera entries are replicated
-// on every rank and must enter the all-reduced sums once.
-
 // Coleman-Li scaling of the bounded camera parameters (cba_set_camera_scaling): effective scale of the camera block
 // sinv = state * mult, extra diagonal of the damped system in x-space = diag_h * sinv^2.
 __global__ void k_cam_rescale(const double* __restrict__ state, const double* __restrict__ mult, const double* __restrict__ diag_h,
@@ -392,6 +395,11 @@ __global__ void k_cam_rescale(const double* __restrict__ state, const double* __
   sinv[i] = si;
   cam_diag[i] = diag_h[i] * si * si;
 }
+
+// scalars of the linearisation + v1 = g / scale_inv^2 (the direction of the gradient in scaled space)
+//   partial[b][0..3] = sum (g/sinv)^2, sum (x sinv)^2, sum x^2, (unused) ; partial_max[b] = max |g|
+// `cam_end` = ncp_pad; `count_cams` = 0 on ranks > 0 of a sharded solve: camera entries are replicated
+// on every rank and must enter the all-reduced sums once.
 __global__ void __launch_bounds__(BLOCK)
 k_lin_scalars(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
               long total, int cam_end, int count_cams, int max_from, double* __restrict__ v1, double* __restrict__ partial,
@@ -1516,6 +1524,11 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     sh_pt[CHUNK + threadIdx.x] = t[1];
     sh_pt[2 * CHUNK + threadIdx.x] = t[2];
     __syncthreads();
+    if (npts < 0 && threadIdx.x < 3) {  // fragment of a heavy point: partial sum of W^T dc into svec (zeroed before), k_heavy_finish solves
+      double acc = 0.0;
+      for (int j = 0; j < o1 - o0; ++j) acc += sh_pt[threadIdx.x * CHUNK + j];
+      unsafeAtomicAdd(&sp[(long)threadIdx.x * lay.Ppad + cp0], acc);
+    }
     if (threadIdx.x < WAVE && (int)threadIdx.x < npts && pb > pa) {
       for (int j = pa; j < pb; ++j) { q[0] += sh_pt[j]; q[1] += sh_pt[CHUNK + j]; q[2] += sh_pt[2 * CHUNK + j]; }
       solve_point(pp, q, Vp, dpp);
@@ -1721,6 +1734,79 @@ k_triangulate(long n_points, const long* __restrict__ pt_start, const int* __res
 
 
 // ------------------------------------------------------------------------------------------------
+// Heavy points: world points with more observations than the pair plan takes (HEAVY_OBS) — static markers seen again in
+// every frame.  Their share of the Schur complement is formed per CAMERA, not per observation pair:
+//   W_pc = sum_{i in (p, c)} T_i   (NC x 3),    Sacc += W_p W_p^T   over the cameras that see p,
+// one workgroup per heavy point; the pair plan skips them.  Points with more than CHUNK observations are also split
+// over several chunks ("fragments": chunk_pts = (point, -1)); k_build / k_backsub add a fragment's sums by atomics.
+constexpr int HEAVY_OBS = 40;  // 40 observations -> at most 40^2 = 1600 pair entries (PAIRCAP = 2048) even if they repeat a camera
+
+__global__ void k_zero_heavy(const int* __restrict__ heavy_pts, int n_heavy, VecLayout lay, double* __restrict__ a, int rows_a,
+                             double* __restrict__ b, int rows_b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_heavy) return;
+  const int p = heavy_pts[t];
+  for (int k = 0; k < rows_a; ++k) a[(long)k * lay.Ppad + p] = 0.0;
+  for (int k = 0; k < rows_b; ++k) b[(long)k * lay.Ppad + p] = 0.0;
+}
+
+// dp of the fragmented heavy points: svec holds sum_i W_i^T dc (k_backsub fragments), on top of g_p
+__global__ void k_heavy_finish(const int* __restrict__ heavy_pts, const int* __restrict__ heavy_frag, int n_heavy, VecLayout lay, double lam,
+                               const double* __restrict__ Vblk, const double* __restrict__ gvec, const double* __restrict__ sinv,
+                               double* __restrict__ svec) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_heavy || !heavy_frag[t]) return;
+  const int p = heavy_pts[t];
+  const double* gp = gvec + lay.ncp_pad;
+  const double* dp = sinv + lay.ncp_pad;
+  double* sp = svec + lay.ncp_pad;
+  double Vd[6], L[6], q[3], y[3], x[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Vd[k] = Vblk[(long)k * lay.Ppad + p];
+  const double d0 = dp[p], d1 = dp[lay.Ppad + p], d2 = dp[2 * lay.Ppad + p];
+  Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = gp[(long)k * lay.Ppad + p] + sp[(long)k * lay.Ppad + p];
+  if (chol3(Vd, L)) { chol3_fwd(L, q, y); chol3_bwd(L, y, x); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sp[(long)k * lay.Ppad + p] = -x[k];
+}
+
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_heavy_schur(const int* __restrict__ heavy_pts, const int* __restrict__ pt_start, const int* __restrict__ obs_cam,
+              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
+              const double* __restrict__ Trec, double* __restrict__ heavy_W, double* __restrict__ Sacc) {
+  constexpr int REC = SchurRec<NC>::REC;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* W = sh;                                  // [ncp][3]
+  int* seen = reinterpret_cast<int*>(W + (size_t)ncp * 3);  // [ncp] 1 if the parameter's camera sees the point
+  const int h = blockIdx.x, p = heavy_pts[h];
+  for (int e = threadIdx.x; e < ncp * 3; e += BLOCK) W[e] = 0.0;
+  for (int e = threadIdx.x; e < ncp; e += BLOCK) seen[e] = 0;
+  __syncthreads();
+  const int o0 = pt_start[p], o1 = pt_start[p + 1];
+  for (int i = o0 + threadIdx.x; i < o1; i += BLOCK) {
+    const int cam = obs_cam[i], off = cam_off[cam], np = cam_np[cam];
+    const double* T = Trec + (long)i * REC;
+    for (int r = 0; r < np; ++r) {
+      lds_add(&W[(off + r) * 3 + 0], T[3 * r]); lds_add(&W[(off + r) * 3 + 1], T[3 * r + 1]); lds_add(&W[(off + r) * 3 + 2], T[3 * r + 2]);
+      seen[off + r] = 1;
+    }
+  }
+  __syncthreads();
+  double* Wg = heavy_W + (long)h * ncp * 3;
+  for (int e = threadIdx.x; e < ncp * 3; e += BLOCK) Wg[e] = W[e];
+  // upper triangle of W W^T, rows / columns of cameras that see the point only
+  for (long e = threadIdx.x; e < (long)ncp * ncp; e += BLOCK) {
+    const int r = (int)(e / ncp), c = (int)(e % ncp);
+    if (c < r || !seen[r] || !seen[c]) continue;
+    const double acc = W[r * 3] * W[c * 3] + W[r * 3 + 1] * W[c * 3 + 1] + W[r * 3 + 2] * W[c * 3 + 2];
+    unsafeAtomicAdd(&Sacc[(long)r * ncp + c], acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rigid-distance constraint rows (reference core/reprojection.py:112-117 residual, :207-226 Jacobian;
 // capture_volume.py:446-531 group arrays):  r_c = w_c (|| mean X[a_c] - mean X[b_c] || - d_c), one row per constraint
 // after the 2N reprojection rows, derivative +-1/4 w_c unit_c on each of the 8 group slots (a repeated point index
@@ -1746,6 +1832,9 @@ struct ConPlan {
   double* G;              // [n_con][ncp + 1]
   double* cdiag;          // [3][Ppad] squared column norms of the constraint rows
   double* w;              // [n_con] scratch of k_con_backsub (J_c V~^-1 q, then M^-1 of it)
+  const int* heavy_pts;   // sorted heavy points (k_heavy_schur) and their per-camera sums W [n_heavy][ncp][3]
+  const double* heavy_W;
+  int n_heavy;
 };
 
 __device__ __forceinline__ void con_geometry(const ConPlan& cp, int c, const double* __restrict__ px, VecLayout lay, double* unit,
@@ -1940,6 +2029,17 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
     for (int s = 0; s < 8; ++s) {
       const int p = cp.pt[(c0 + c) * 8 + s];
       const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
+      int hidx = -1;  // heavy point: its per-camera sums are already formed (k_heavy_schur), binary search in the sorted list
+      for (int lo = 0, hi = cp.n_heavy - 1; lo <= hi;) {
+        const int mid = (lo + hi) >> 1, q = cp.heavy_pts[mid];
+        if (q == p) { hidx = mid; break; }
+        if (q < p) lo = mid + 1; else hi = mid - 1;
+      }
+      if (hidx >= 0) {
+        const double* Wh = cp.heavy_W + (long)hidx * ncp * 3;
+        for (int r = 0; r < ncp; ++r) G[(long)c * gw + r] += Wh[3 * r] * z[0] + Wh[3 * r + 1] * z[1] + Wh[3 * r + 2] * z[2];
+        continue;
+      }
       for (int i = pt_start[p]; i < pt_start[p + 1]; ++i) {
         const int cam = obs_cam[i];
         const double* T = Trec + (long)i * REC;

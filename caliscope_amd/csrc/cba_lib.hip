@@ -90,6 +90,8 @@ struct cba_problem {
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
   bool cam_scaled = false, cam_state_saved = false;
+  int n_heavy = 0; int* heavy_pts = nullptr; int* heavy_frag = nullptr; double* heavy_W = nullptr;  // heavy points (k_heavy_schur)
+  std::vector<int> h_heavy_pts;
   ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
   int con_grid = 0;        // workgroups of the per-constraint kernels
   int* flags = nullptr;
@@ -279,12 +281,7 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
     if (p < 0 || p >= n_points) return fail(CBA_ERR_INVALID, "observation %lld: world-point index %d out of range", (long long)i, p);
     count[p + 1]++;
   }
-  for (int32_t p = 0; p < n_points; ++p) {
-    if (count[p + 1] > chunk_cap)
-      return fail(CBA_ERR_UNSUPPORTED, "world point %d has %lld observations; this build supports at most %d per point",
-                  p, (long long)count[p + 1], chunk_cap);
-    count[p + 1] += count[p];
-  }
+  for (int32_t p = 0; p < n_points; ++p) count[p + 1] += count[p];
   for (int32_t p = 0; p <= n_points; ++p) pt_start_out[p] = count[p];
   std::vector<int64_t> cursor(count.begin(), count.end() - 1);
   for (int64_t q = 0; q < n_obs; ++q) {  // stable counting sort by point
@@ -295,10 +292,16 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
   int64_t start = 0;
   chunk_start_out[0] = 0;
   for (int32_t p = 0; p < n_points; ++p) {
-    const int64_t end = pt_start_out[p + 1];
-    if (end - start > chunk_cap) {  // close the chunk before this point
-      chunk_start_out[++n_chunks] = pt_start_out[p];
-      start = pt_start_out[p];
+    const int64_t begin = pt_start_out[p], end = pt_start_out[p + 1];
+    if (end - begin > chunk_cap) {
+      // a point that does not fit one chunk gets chunks of its own ("fragments" of at most chunk_cap observations)
+      if (begin > start) chunk_start_out[++n_chunks] = begin;
+      for (int64_t o = begin + chunk_cap; o < end; o += chunk_cap) chunk_start_out[++n_chunks] = o;
+      chunk_start_out[++n_chunks] = end;
+      start = end;
+    } else if (end - start > chunk_cap) {  // close the chunk before this point
+      chunk_start_out[++n_chunks] = begin;
+      start = begin;
     }
   }
   if (n_obs > start) chunk_start_out[++n_chunks] = n_obs;
@@ -468,6 +471,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
       const int* gb = &pgb[(size_t)q * (G + 1)];
       na = gb[a + 1] - gb[a];
       nb = (b == a) ? 0 : gb[b + 1] - gb[b];
+      if (p->n_heavy && hps[q + 1] - hps[q] > HEAVY_OBS) return false;  // heavy point: k_heavy_schur forms its share
       return na > 0 && (b == a || nb > 0);
     };
     auto pairs_of = [&](int q, int na, int nb) {  // number of pair-list entries this point adds
@@ -712,6 +716,7 @@ static int configure_kernels(cba_problem* p) {
   }
   else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
+  if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_backward, (size_t)p->ncp * 8))) return rc;
   return CBA_OK;
 }
@@ -788,6 +793,19 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   for (int q = 0; q <= p->P; ++q) { hps[q] = (int)pstart[q]; if (q) maxk = std::max<int>(maxk, (int)(pstart[q] - pstart[q - 1])); }
   for (int64_t q = 0; q <= nch; ++q) hcs[q] = (int)cstart[q];
   p->max_obs_per_point = maxk;
+  // heavy points (static markers observed again in every frame): per-camera Schur sums instead of observation pairs
+  std::vector<int> heavy, heavy_frag;
+  for (int q = 0; q < p->P && maxk > HEAVY_OBS; ++q)
+    if (hps[q + 1] - hps[q] > HEAVY_OBS) { heavy.push_back(q); heavy_frag.push_back(hps[q + 1] - hps[q] > CHUNK ? 1 : 0); }
+  if ((long)heavy.size() > std::max<long>(64, p->P / 64)) {
+    // not a few static points but a dense problem (every point seen by > HEAVY_OBS cameras): the per-point workgroup of
+    // k_heavy_schur is the wrong tool; keep the pair plan (LDS-tile fallback beyond PAIRCAP pairs per point)
+    if (maxk > CHUNK) return bail(fail(CBA_ERR_UNSUPPORTED, "%zu world points have more than %d observations (one has %d); at most %ld such points are supported",
+                                       heavy.size(), HEAVY_OBS, maxk, std::max<long>(64, p->P / 64)));
+    heavy.clear(); heavy_frag.clear();
+  }
+  p->n_heavy = (int)heavy.size();
+  p->h_heavy_pts = heavy;
 
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocDefault));
@@ -807,8 +825,13 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     for (int64_t q = 0; q < nch; ++q) {
       hcp[2 * q] = hpt[hcs[q]];
       hcp[2 * q + 1] = hpt[hcs[q + 1] - 1] - hpt[hcs[q]] + 1;
+      if (hps[hpt[hcs[q]] + 1] - hps[hpt[hcs[q]]] > CHUNK) hcp[2 * q + 1] = -1;  // fragment of a point larger than a chunk
     }
     TRY(dev_upload(p, &p->chunk_pts, hcp));
+  }
+  if (p->n_heavy) {
+    TRY(dev_upload(p, &p->heavy_pts, heavy)); TRY(dev_upload(p, &p->heavy_frag, heavy_frag));
+    TRY(dev_alloc(p, &p->heavy_W, (size_t)p->n_heavy * ncp * 3));
   }
   std::vector<double> cc(d->cam_const, d->cam_const + (size_t)p->C * 12);
   TRY(dev_upload(p, &p->cam_const, cc));
@@ -843,6 +866,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     if (rc) return bail(rc);
     break;
   }
+  if (p->n_heavy && !p->schur_reg)
+    return bail(fail(CBA_ERR_UNSUPPORTED, "%d world points have more than %d observations: they need the T-record Schur path (CBA_SCHUR=lds is set)", p->n_heavy, HEAVY_OBS));
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
@@ -874,7 +899,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_reg ? 0 : 1;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
-  o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes;
+  o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
   return CBA_OK;
 }
 
@@ -953,6 +978,9 @@ template <int NC>
 static int run_build(cba_problem* p) {
   {
     ScopedTimer t(p, T_BUILD);
+    if (p->n_heavy)  // fragments of heavy points add their sums by atomics
+      hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay, p->V, 6,
+                         p->g + p->lay.ncp_pad, 3);
     hipLaunchKernelGGL(k_build<NC>, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                        p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->C, p->loss, p->f_scale,
                        p->V, p->g, p->partial, p->partial1);
@@ -1110,6 +1138,9 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
       hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                          p->cam_off, p->cam_np, NC, ncp, p->Sacc);
+      if (p->n_heavy)  // per-camera sums of the heavy points, one workgroup each (the pair plan skips them)
+        hipLaunchKernelGGL((k_heavy_schur<NC>), dim3(p->n_heavy), dim3(BLOCK), (size_t)ncp * 3 * sizeof(double) + (size_t)ncp * sizeof(int), p->stream,
+                           p->heavy_pts, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Trec, p->heavy_W, p->Sacc);
       if (p->con.n_con)  // Woodbury correction of S and b for the constraint rows, one workgroup per component
         hipLaunchKernelGGL((k_con_schur<NC>), dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->g, p->sinv,
                            p->Trec, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
@@ -1129,9 +1160,15 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   if (rc) return rc;
   {
     ScopedTimer t(p, T_BACKSUB);
+    if (p->n_heavy)  // fragments add sum_i W_i^T dc of a heavy point into s by atomics; k_heavy_finish solves for dp
+      hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay,
+                         p->s + p->lay.ncp_pad, 3, p->s + p->lay.ncp_pad, 0);
     hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                        p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
                        p->f_scale, lam, p->V, p->g, p->sinv, p->s);
+    if (p->n_heavy)
+      hipLaunchKernelGGL(k_heavy_finish, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->heavy_frag, p->n_heavy, p->lay, lam,
+                         p->V, p->g, p->sinv, p->s);
     if (p->con.n_con)
       hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
   }
@@ -1241,6 +1278,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   ConPlan cp{};
   cp.n_con = n_con; cp.n_comp = K; cp.pt = dpt; cp.lp = dlp; cp.dist = ddist; cp.weight = dw; cp.order = dorder;
   cp.comp_con = dcc; cp.comp_pt = dcp; cp.comp_pts = dcps; cp.comp_m = dcm;
+  cp.heavy_pts = p->heavy_pts; cp.heavy_W = p->heavy_W; cp.n_heavy = p->n_heavy;
   TRYC(dev_alloc(p, &cp.f, (size_t)n_con)); TRYC(dev_alloc(p, &cp.u, (size_t)n_con * 3)); TRYC(dev_alloc(p, &cp.z, (size_t)n_con * 24));
   TRYC(dev_alloc(p, &cp.M, (size_t)std::max<long>(comp_m[K], 1))); TRYC(dev_alloc(p, &cp.G, (size_t)n_con * (p->ncp + 1)));
   TRYC(dev_alloc(p, &cp.cdiag, (size_t)3 * p->lay.Ppad)); TRYC(dev_alloc(p, &cp.w, (size_t)n_con));

@@ -226,7 +226,7 @@ typedef struct {
   int32_t schur_groups;   /* G camera groups -> G(G+1)/2 tiles */
   int32_t schur_tiles;
   int32_t schur_grid;     /* workgroups of the tiled Schur kernel */
-  int32_t reserved;
+  int32_t n_heavy_points; /* points with > 40 observations (static markers): per-camera Schur sums, split over chunks beyond 256 */
   int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
   int64_t schur_pairs;      /* observation pairs (blocks of W V^-1 W^T) formed per Schur pass */
 } cba_info;
@@ -244,7 +244,8 @@ int cba_enable_timers(cba_problem* p, int32_t on);
  * NULL to sort by point only — stable, CSR offsets
  * per point and the chunk table (whole points per chunk, at most `chunk_cap` observations).
  * order_out [N], pt_start_out [P+1], chunk_start_out [N+1 worst case]; returns the number of chunks
- * (>= 0) or a negative error (a point with more than chunk_cap observations is CBA_ERR_UNSUPPORTED). */
+ * (>= 0) or a negative error.  A point with more than chunk_cap observations gets chunks of its own (fragments of at
+ * most chunk_cap observations, no other point in them). */
 int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
                       int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out);
 

@@ -210,3 +210,47 @@ def test_capture_volume_static_markers_and_centroid_rows():
                                          par.pack(ref.camera_array, ref.world_points.points))
     assert pos < 1e-6 and ang < 1e-6 and abs(scale - 1.0) < 1e-6
     assert got.rigidity_report().rmse_mm < vol.rigidity_report().rmse_mm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_frames,with_constraints", [(30, False), (80, False), (80, True)])
+def test_heavy_static_points_step_and_solution(n_frames, with_constraints):
+    """Static marker corners are ONE world point observed again in every frame: 30 frames x 5 cameras ~ 135 rows per point
+    (heavy: per-camera Schur sums, still one chunk), 80 frames ~ 360 rows (split over chunks).  Damped step and converged
+    solution against the numpy engine."""
+    from caliscope_amd.hip_engine import HipEngine
+    from oracle.engine import OracleEngine
+    from tests.constrained_scene import marker_volume
+    from tests.helpers import aligned_difference
+
+    vol, par = marker_volume(n_frames=n_frames)
+    _, cam, uv, obj = vol._matched_arrays()
+    con = None
+    if with_constraints:
+        ga, gb, dist, sig = vol._build_constraint_arrays()
+        con = (ga, gb, dist, (1.0 / 1394.6) / sig)
+    x0 = par.pack(vol.camera_array, vol.world_points.points)
+    kw = {} if con is None else dict(constraint_groups_a=con[0], constraint_groups_b=con[1], constraint_distances=con[2], constraint_weights=con[3])
+    hip, ora = HipEngine(BAProblem(par, cam, uv, obj, **kw)), OracleEngine(par, cam, uv, obj, constraints=con)
+    info = hip.info()
+    assert info["n_heavy_points"] == 12 and info["max_obs_per_point"] > (256 if n_frames == 80 else 100) and info["schur_in_lds"] == 0
+    c_h, c_o = hip.begin(x0), ora.begin(x0)
+    assert abs(c_h - c_o) <= 1e-13 * c_o
+    hip.linearize(); ora.linearize()
+    assert np.abs(hip.get_vector(2) - ora.g).max() < 1e-11 * np.abs(ora.g).max()
+    assert np.abs(hip.get_vector(4) - ora.scale_inv).max() < 1e-12 * np.abs(ora.scale_inv).max()
+    for lam in (1e-3, 1e-8):
+        sh, so = hip.newton_step(lam), ora.newton_step(lam)
+        assert sh.ok and so.ok
+        tol = 1e-8 if lam > 1e-6 else 1e-6  # lam = 1e-8 leaves the gauge directions nearly singular: rounding is amplified there
+        assert np.abs(hip.get_vector(3) - ora.s).max() < tol * np.abs(ora.s).max(), lam
+        for fld in ("p_sq", "gh_dot_p", "w_sq"):
+            assert abs(getattr(sh, fld) - getattr(so, fld)) <= 10 * tol * abs(getattr(so, fld)), (fld, lam)
+    got = hip.solve(x0)
+    from caliscope_amd.trf import trf_solve
+
+    ref = trf_solve(ora, x0)
+    assert got.status > 0 and ref.status > 0 and abs(got.cost - ref.cost) <= 1e-9 * ref.cost
+    pos, ang, _ = aligned_difference(par, got.x, ref.x)
+    assert pos < 1e-6 and ang < 1e-6
+    hip.close()

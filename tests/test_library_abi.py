@@ -88,7 +88,9 @@ def test_host_plan_sorts_by_point_and_chunks_whole_points(lib):
 def test_host_plan_rejects_bad_input(lib):
     nch, *_ = _plan(lib, 4, np.array([0, 1, 7]), 256)
     assert nch == -1 and b"out of range" in lib.cba_last_error()
-    nch, *_ = _plan(lib, 2, np.zeros(300, dtype=np.int32), 256)
-    assert nch == -4 and b"at most 256" in lib.cba_last_error()
+    # a point larger than a chunk gets chunks of its own
+    obs_pt = np.concatenate([np.zeros(5), np.ones(700), np.full(3, 2), np.full(256, 3), np.full(257, 4)]).astype(np.int32)
+    nch, order, pstart, cstart = _plan(lib, 5, obs_pt, 256)
+    assert list(cstart) == [0, 5, 261, 517, 705, 708, 964, 1220, 1221] and nch == 8
     nch, order, pstart, cstart = _plan(lib, 3, np.array([], dtype=np.int32), 256)
     assert nch == 0
