@@ -1,10 +1,12 @@
 """The solver stages of the reference's extrinsic-calibration use case, on the MI355X engine.
 
 ``calibrate_extrinsics`` (reference ``core/calibrate_extrinsics.py:44-261``) is a nine-stage pipeline; stages
-1-4 (blind intrinsics, pairwise PnP / essential-matrix bootstrap, static-marker guard) need OpenCV and are
-upstream of the hot path.  Stages 5-9 — the part that calls the solver three times with a filter in between —
-are mirrored here one to one, on a volume that is already bootstrapped:
+1-3 (blind intrinsics, pairwise PnP / essential-matrix bootstrap) need OpenCV and are upstream of the hot path.
+Stage 4 (static-marker guard, :146-196) and stages 5-9 — the part that calls the solver three times with a filter in
+between — are mirrored here, on a volume that is already bootstrapped (a dropped marker's rows are removed from
+the volume instead of re-running the bootstrap):
 
+  4  static-marker guard: drop a static marker whose intra-marker rigidity RMSE exceeds 25 % of its size    (:146-196)
   5  ``optimize(refine_intrinsics=False)``                          linear loss, reach the basin        (:206)
      depth-ratio gate: refine intrinsics only if every camera sees p95(z)/p5(z) >= 2.0                  (:215-226)
   6  ``optimize(refine=effective, loss="soft_l1", f_scale=1px, max_nfev=2000, ftol=1e-4, strict=False)`` (:230-238)
@@ -59,6 +61,40 @@ def compute_depth_ratios(capture_volume: CaptureVolume) -> dict[int, float]:
     return out
 
 
+def apply_static_marker_guard(capture_volume: CaptureVolume) -> tuple[CaptureVolume, tuple[int, ...]]:
+    """Stage 4: a "static" marker that moved during the recording shows up as a non-rigid set of triangulated corners.
+    Markers whose intra-marker rigidity RMSE exceeds 25 % of their largest corner distance are dropped: their
+    observations, world points and every constraint that names them (reference :146-186)."""
+    from caliscope_amd.constraints import ConstraintSet, RigidityReport
+    from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+    con = capture_volume.constraints
+    if con is None or not con.static_object_ids:
+        return capture_volume, ()
+    intra = tuple(v for v in capture_volume.rigidity_report().violations if v.object_id_a == v.object_id_b)
+    rmse = RigidityReport(violations=intra).per_object_rmse_mm
+    dropped = []
+    for obj in sorted(con.static_object_ids):
+        size_mm = 1000.0 * max((d.distance for d in con.distances if d.object_id_a == obj and d.object_id_b == obj), default=0.0)
+        if size_mm > 0 and rmse.get(obj, 0.0) > 0.25 * size_mm:
+            logger.warning(f"Dropping static marker {obj}: rigidity RMSE {rmse[obj]:.1f}mm > 25% of max intra-distance {size_mm:.1f}mm")
+            dropped.append(obj)
+    if not dropped:
+        return capture_volume, ()
+    gone = set(dropped)
+    img = capture_volume.image_points.df
+    world = capture_volume.world_points.df
+    kept = ConstraintSet(
+        distances=tuple(d for d in con.distances if d.object_id_a not in gone and d.object_id_b not in gone),
+        static_object_ids=con.static_object_ids - frozenset(gone),
+        centroid_distances=tuple(c for c in con.centroid_distances if c.object_id_a not in gone and c.object_id_b not in gone),
+        point_remaps=con.point_remaps,
+    )
+    vol = CaptureVolume(capture_volume.camera_array, ImagePoints(img[~img["object_id"].isin(gone)].reset_index(drop=True)),
+                        WorldPoints(world[~world["object_id"].isin(gone)].reset_index(drop=True)), kept)
+    return vol, tuple(dropped)
+
+
 def refine_calibration(
     capture_volume: CaptureVolume,
     *,
@@ -85,6 +121,8 @@ def refine_calibration(
             anchors[cam_id] = (float(cam.matrix[0, 0]), float(d[0]), float(d[1]))
 
     kw = {} if _engine_factory is None else {"_engine_factory": _engine_factory}
+    check_cancelled()
+    capture_volume, dropped = apply_static_marker_guard(capture_volume)
     check_cancelled()
     report(40, "Optimizing")
     cv = capture_volume.optimize(refine_intrinsics=False, **kw)
@@ -116,4 +154,4 @@ def refine_calibration(
             f0, k10, k20 = anchors[cam_id]
             d = np.asarray(cam.distortions).ravel()
             estimates.append(IntrinsicEstimate(cam_id, float(cam.matrix[0, 0]), float(d[0]), float(d[1]), f0, k10, k20))
-    return CalibrationRun(cv, tuple(estimates), intrinsic_refinement_gated=gated)
+    return CalibrationRun(cv, tuple(estimates), dropped_static_markers=dropped, intrinsic_refinement_gated=gated)

@@ -86,3 +86,30 @@ def test_cancellation_between_stages():
     sc, cv = _volume(outliers=0.0, n_points=60, k=4)
     with pytest.raises(InterruptedError):
         refine_calibration(cv, cancellation_token=Token(), _engine_factory=_OracleFactory())
+
+
+def test_static_marker_guard_drops_a_marker_that_moved():
+    """Stage 4: the corners of 'static' marker 11 are triangulated as a badly non-rigid quadrilateral -> it is dropped with
+    its observations, world points and constraints; marker 10 stays."""
+    import pandas as pd
+
+    from caliscope_amd.calibrate_extrinsics import apply_static_marker_guard
+    from caliscope_amd.constraints import CentroidDistanceConstraint
+    from tests.constrained_scene import marker_volume
+
+    vol, _ = marker_volume(n_frames=4)
+    same, none = apply_static_marker_guard(vol)
+    assert same is vol and none == ()
+    world = vol.world_points.df
+    bad = (world["object_id"] == 11) & (world["keypoint_id"] == 2)
+    world.loc[bad, "x_coord"] += 0.2  # 20 cm on a 12 cm marker
+    from caliscope_amd.capture_volume import CaptureVolume
+    from caliscope_amd.point_data import WorldPoints
+
+    moved = CaptureVolume(vol.camera_array, vol.image_points, WorldPoints(world), vol.constraints)
+    out, dropped = apply_static_marker_guard(moved)
+    assert dropped == (11,) and out.constraints.static_object_ids == frozenset({10, 12})
+    assert 11 not in set(out.image_points.df["object_id"]) and 11 not in set(out.world_points.df["object_id"])
+    assert all(11 not in (d.object_id_a, d.object_id_b) for d in out.constraints.distances)
+    assert out.constraints.centroid_distances == ()  # the 11 -> 12 centre link went with marker 11
+    assert len(out._build_constraint_arrays()[2]) < len(moved._build_constraint_arrays()[2])
