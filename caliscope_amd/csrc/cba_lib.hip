@@ -1209,7 +1209,6 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   if (p->con.n_con) return fail(CBA_ERR_INVALID, "cba_set_constraints: constraints are already set");
   if (n_con <= 0) return CBA_OK;
   if (!groups_a || !groups_b || !distances || !weights) return fail(CBA_ERR_INVALID, "cba_set_constraints: null array");
-  if (p->comm && p->world > 1) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows are not supported in sharded solves");
   if (!p->schur_reg) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows need the T-record Schur path (CBA_SCHUR=lds is set, or a point exceeds the pair capacity)");
   HIPCHK(hipSetDevice(p->device));
   const int P = p->P;
@@ -1479,7 +1478,6 @@ int cba_comm_unique_id(char* out128) {
 int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world) {
   if (!p || !id128) return fail(CBA_ERR_INVALID, "cba_comm_init: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(CBA_ERR_INVALID, "cba_comm_init: rank %d of %d", rank, world);
-  if (p->con.n_con && world > 1) return fail(CBA_ERR_UNSUPPORTED, "cba_comm_init: constraint rows are not supported in sharded solves");
   if (p->comm) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
   HIPCHK(hipSetDevice(p->device));
   p->rank = rank; p->world = world;

@@ -22,10 +22,50 @@ import numpy as np
 from caliscope_amd.engine import BAProblem
 
 
-def partition_points(obj_indices: np.ndarray, n_points: int, world: int) -> list[np.ndarray]:
-    """Contiguous point ranges balanced by observation count; returns the sorted point ids of every rank."""
+def _blocked_cuts(n_points: int, groups) -> np.ndarray:
+    """blocked[c] is True when cutting between points c - 1 and c would split a connected component of the constraint
+    graph (rigid-distance rows couple the points they name: a component must live on one rank)."""
+    blocked = np.zeros(n_points + 1, dtype=bool)
+    if groups is None:
+        return blocked
+    rows = np.concatenate([np.asarray(g, dtype=np.int64).reshape(-1, 4) for g in groups], axis=1)  # (n_con, 8)
+    if rows.size == 0:
+        return blocked
+    # components by union-find over the rows, then one (min, max) point interval per component
+    parent = np.arange(n_points)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    for row in rows:
+        r0 = find(int(row[0]))
+        for q in row[1:]:
+            r = find(int(q))
+            if r != r0:
+                parent[r] = r0
+    used = np.unique(rows)
+    roots = np.array([find(int(q)) for q in used])
+    order = np.argsort(roots, kind="stable")
+    roots, used = roots[order], used[order]
+    first = np.flatnonzero(np.r_[True, roots[1:] != roots[:-1]])
+    lo = np.minimum.reduceat(used, first)
+    hi = np.maximum.reduceat(used, first)
+    delta = np.zeros(n_points + 2, dtype=np.int64)  # cuts lo < c <= hi are blocked
+    np.add.at(delta, lo + 1, 1)
+    np.add.at(delta, hi + 1, -1)
+    blocked[:] = np.cumsum(delta)[: n_points + 1] > 0
+    return blocked
+
+
+def partition_points(obj_indices: np.ndarray, n_points: int, world: int, constraint_groups=None) -> list[np.ndarray]:
+    """Contiguous point ranges balanced by observation count; returns the sorted point ids of every rank.
+    ``constraint_groups`` = (groups_a, groups_b): cuts are moved forward so that no constraint component is split."""
     if world < 1:
         raise ValueError("world must be >= 1")
+    blocked = _blocked_cuts(n_points, constraint_groups)
     counts = np.bincount(np.asarray(obj_indices, dtype=np.int64), minlength=n_points).astype(np.int64)
     cum = np.concatenate([[0], np.cumsum(counts)])
     total = int(cum[-1])
@@ -33,8 +73,10 @@ def partition_points(obj_indices: np.ndarray, n_points: int, world: int) -> list
     for r in range(1, world):
         target = total * r / world
         # first point index whose cumulative count reaches the target, never going backwards
-        cut = int(np.searchsorted(cum, target, side="left"))
-        bounds.append(min(max(cut, bounds[-1]), n_points))
+        cut = min(max(int(np.searchsorted(cum, target, side="left")), bounds[-1]), n_points)
+        while cut < n_points and blocked[cut]:
+            cut += 1
+        bounds.append(cut)
     bounds.append(n_points)
     return [np.arange(bounds[r], bounds[r + 1], dtype=np.int64) for r in range(world)]
 
@@ -60,7 +102,9 @@ class Shard:
 
 def shard_problem(problem: BAProblem, rank: int, world: int) -> Shard:
     par = problem.parameterization
-    owned = partition_points(problem.obj_indices, par.n_points, world)[rank]
+    has_con = problem.n_constraints > 0
+    groups = (problem.constraint_groups_a, problem.constraint_groups_b) if has_con else None
+    owned = partition_points(problem.obj_indices, par.n_points, world, groups)[rank]
     g2l = -np.ones(par.n_points, dtype=np.int64)
     g2l[owned] = np.arange(owned.size)
     local_obj = g2l[problem.obj_indices]
@@ -68,8 +112,16 @@ def shard_problem(problem: BAProblem, rank: int, world: int) -> Shard:
     if owned.size == 0 or not keep.any():
         raise ValueError(f"rank {rank} of {world} owns no observations; use fewer ranks for this problem")
     local_par = dataclasses.replace(par, n_points=int(owned.size))
+    con = {}
+    if has_con:  # a component is never split (partition_points), so a row is local as a whole or not at all
+        la, lb = g2l[problem.constraint_groups_a], g2l[problem.constraint_groups_b]
+        mine = la[:, 0] >= 0
+        assert np.all((la >= 0).all(axis=1) == mine) and np.all((lb >= 0).all(axis=1) == mine)
+        if mine.any():
+            con = dict(constraint_groups_a=la[mine].astype(np.int32), constraint_groups_b=lb[mine].astype(np.int32),
+                       constraint_distances=problem.constraint_distances[mine], constraint_weights=problem.constraint_weights[mine])
     local = BAProblem(
         local_par, problem.camera_indices[keep], problem.image_coords[keep], local_obj[keep].astype(np.int32),
-        loss=problem.loss, f_scale=problem.f_scale,
+        loss=problem.loss, f_scale=problem.f_scale, **con,
     )
     return Shard(local, owned, par.n_points)

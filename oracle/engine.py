@@ -198,16 +198,35 @@ class OracleEngine:
         ncp = self.ncp
         D2 = self.scale_inv**2
         if self.H is not None:
-            # with constraint rows H_pp is not block diagonal: factor the whole damped system (the device path's
-            # Woodbury correction is checked against this)
+            # with constraint rows H_pp is not block diagonal: the same Schur complement with a sparse LU of the damped
+            # H_pp in place of the 3 x 3 inverses (the device path's Woodbury correction is checked against this)
             import scipy.sparse as sp
             from scipy.sparse.linalg import splu
 
-            A = (self.H + lam * sp.diags(D2)).tocsc()
+            g_c, g_p = self.g[:ncp], self.g[ncp:]
+            Hpp = (self.H[ncp:, ncp:] + lam * sp.diags(D2[ncp:])).tolil()
+            has_obs = np.repeat(np.bincount(self.obj, minlength=self.owned.size) > 0, 3) | (np.asarray(self.H[ncp:, ncp:].diagonal()) > 0)
+            for k in np.flatnonzero(~has_obs):
+                Hpp[k, k] = 1.0
             try:
-                s = splu(A).solve(-self.g)
+                lu = splu(Hpp.tocsc())
             except RuntimeError:
                 return _Step(False, 0.0, 0.0, 0.0)
+            Wt = self.W.T.toarray()                      # (3 P_loc, ncp)
+            X = lu.solve(Wt)                             # H_pp^-1 W^T
+            S_loc = -(Wt.T @ X)
+            b_loc = X.T @ g_p
+            red = self._allreduce(np.concatenate([S_loc.reshape(-1), b_loc]))
+            S = self.U + lam * np.diag(D2[:ncp]) + red[: ncp * ncp].reshape(ncp, ncp)
+            rhs = -g_c + red[ncp * ncp :]
+            try:
+                L = np.linalg.cholesky(0.5 * (S + S.T))
+            except np.linalg.LinAlgError:
+                return _Step(False, 0.0, 0.0, 0.0)
+            dc = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+            dp = -lu.solve(g_p + Wt @ dc)
+            dp[~has_obs] = 0.0
+            s = np.concatenate([dc, dp])
             if not np.all(np.isfinite(s)):
                 return _Step(False, 0.0, 0.0, 0.0)
             return self._finish_step(s)

@@ -274,3 +274,26 @@ def test_staged_driver_with_constraints_and_static_markers():
     assert len(static) == 12
     assert out.rigidity_report().rmse_mm < 0.25 * vol.rigidity_report().rmse_mm
     assert out.reprojection_report.overall_rmse < 1.0
+
+
+@pytest.mark.gpu
+def test_constraint_rows_through_the_rccl_call_sites(monkeypatch):
+    """A one-rank RCCL communicator exercises every all-reduce of the sharded protocol with constraint rows present
+    (cost / rho sums with the rows' partials, the reduced system after the Woodbury correction); the native driver on top."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc = board_scene(n_frames=9)
+    ga, gb, dist, w = sc["constraints"]
+    prob = BAProblem(sc["par"], sc["cam"], sc["uv"], sc["obj"], constraint_groups_a=ga, constraint_groups_b=gb,
+                     constraint_distances=dist, constraint_weights=w)
+    with HipEngine(prob) as plain:
+        ref = plain.solve(sc["x0"], ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=60)
+    monkeypatch.setenv("CBA_FORCE_COMM", "1")
+    with HipEngine(prob) as eng:
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        got = eng.solve(sc["x0"], ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=60)
+    assert got.status == ref.status and got.nfev == ref.nfev and abs(got.cost - ref.cost) <= 1e-12 * ref.cost
+    from tests.helpers import aligned_difference
+
+    pos, ang, scale = aligned_difference(sc["par"], got.x, ref.x)
+    assert pos < 1e-8 and ang < 1e-8 and abs(scale - 1) < 1e-8

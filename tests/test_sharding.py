@@ -104,3 +104,81 @@ def test_two_rank_gloo_solve_matches_single_rank(tmp_path, loss):
 
     pos, ang, _ = aligned_difference(par, xs[0], single.x)
     assert pos < 1e-8 and ang < 1e-8, (pos, ang)
+
+
+def test_partition_keeps_constraint_components_together():
+    from tests.constrained_scene import board_scene
+
+    sc = board_scene(n_frames=9)
+    ga, gb, dist, w = sc["constraints"]
+    n_points, n_per = len(sc["points_true"]), sc["n_per"]
+    for world in (2, 3, 4):
+        parts = partition_points(sc["obj"], n_points, world, (ga, gb))
+        assert np.array_equal(np.concatenate(parts), np.arange(n_points))
+        for part in parts:
+            assert part.size % n_per == 0 and part[0] % n_per == 0  # whole boards only
+        prob = BAProblem(sc["par"], sc["cam"], sc["uv"], sc["obj"], constraint_groups_a=ga, constraint_groups_b=gb,
+                         constraint_distances=dist, constraint_weights=w)
+        shards = [shard_problem(prob, r, world) for r in range(world)]
+        assert sum(s.problem.n_constraints for s in shards) == len(dist)
+        for s in shards:
+            pts = sc["x0"][sc["par"].n_camera_params:].reshape(-1, 3)[s.owned_points]
+            la, lb = s.problem.constraint_groups_a, s.problem.constraint_groups_b
+            assert la.max() < s.owned_points.size and la.min() >= 0
+            # local rows measure the same distances as the global ones
+            d_loc = np.linalg.norm(pts[la].mean(axis=1) - pts[lb].mean(axis=1), axis=1)
+            assert np.all(np.abs(d_loc - s.problem.constraint_distances) < 0.05)
+    # without constraints the cuts may fall inside a board
+    free = partition_points(sc["obj"], n_points, 4)
+    assert any(part[0] % n_per for part in free[1:])
+
+
+def _con_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from caliscope_amd.distributed import TorchControlPlane, solve_sharded
+    from oracle.engine import OracleEngine
+    from tests.constrained_scene import board_scene
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = board_scene(n_frames=9)
+        ga, gb, d, w = sc["constraints"]
+        prob = BAProblem(sc["par"], sc["cam"], sc["uv"], sc["obj"], constraint_groups_a=ga, constraint_groups_b=gb,
+                         constraint_distances=d, constraint_weights=w)
+
+        def factory(shard, control):
+            sp = shard.problem
+            eng = OracleEngine(sp.parameterization, sp.camera_indices, sp.image_coords, sp.obj_indices, allreduce=control.allreduce_sum,
+                               constraints=sp.constraint_args() if sp.n_constraints else None)
+            eng.allreduce_max = control.allreduce_max
+            return eng
+
+        res = solve_sharded(prob, sc["x0"], TorchControlPlane(), engine_factory=factory, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=100)
+        np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
+        np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.cost, res.nfev, res.status], dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_solve_with_constraint_rows(tmp_path):
+    """Constraint components stay on one rank; their share of the reduced camera system rides in the same all-reduce."""
+    import torch.multiprocessing as mp
+
+    from caliscope_amd.trf import trf_solve
+    from oracle.engine import OracleEngine
+    from tests.constrained_scene import board_scene
+    from tests.helpers import aligned_difference
+
+    world = 2
+    mp.spawn(_con_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sc = board_scene(n_frames=9)
+    single = trf_solve(OracleEngine(sc["par"], sc["cam"], sc["uv"], sc["obj"], constraints=sc["constraints"]), sc["x0"],
+                       ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=100)
+    xs = [np.load(tmp_path / f"x_{r}.npy") for r in range(world)]
+    metas = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world)]
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(metas[0], metas[1])
+    assert abs(metas[0][0] - single.cost) <= 1e-10 * single.cost and int(metas[0][2]) == single.status
+    pos, ang, scale = aligned_difference(sc["par"], xs[0], single.x)
+    assert pos < 1e-8 and ang < 1e-8 and abs(scale - 1) < 1e-8
