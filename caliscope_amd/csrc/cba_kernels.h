@@ -1601,6 +1601,15 @@ k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// End of a primitive: the host-visible scalars and flags go straight to pinned host memory (mapped into the device's
+// address space) — no copy-engine round trip — and the flags are cleared for the next primitive.
+__global__ void k_publish(const double* __restrict__ scal, int n_scal, int* __restrict__ flags, double* __restrict__ host_scal,
+                          int* __restrict__ host_flags) {
+  const int t = threadIdx.x;
+  if (t < n_scal) host_scal[t] = scal[t];
+  if (t < 4) { host_flags[t] = flags[t]; flags[t] = 0; }
+}
+
 __global__ void k_fill(double* __restrict__ p, double v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }

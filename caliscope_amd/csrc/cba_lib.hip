@@ -95,8 +95,10 @@ struct cba_problem {
   ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
   int con_grid = 0;        // workgroups of the per-constraint kernels
   int* flags = nullptr;
-  double* h_scal = nullptr;  // pinned
+  double* h_scal = nullptr;  // pinned, mapped: k_publish writes it (d_hscal is the same memory seen from the device)
   int* h_flags = nullptr;
+  double* d_hscal = nullptr;
+  int* d_hflags = nullptr;
   bool first_scale = true;
   bool have_x0 = false;
   int debug_skip = 0;  // profiling only (CBA_DEBUG_SCHUR_SKIP): 1 = skip the pair phase, 2 = skip the block recomputation
@@ -169,8 +171,8 @@ static void drain_timers(cba_problem* p) {
 }
 
 static int sync_scalars(cba_problem* p, int n_scal) {
-  HIPCHK(hipMemcpyAsync(p->h_scal, p->scal, n_scal * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipMemcpyAsync(p->h_flags, p->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  // every primitive ends here: scalars and flags to the host, flags cleared for the next primitive
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags);
   HIPCHK(hipStreamSynchronize(p->stream));
   return CBA_OK;
 }
@@ -808,8 +810,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->h_heavy_pts = heavy;
 
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocMapped));
+  HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
+  HIPCHK(hipHostGetDevicePointer((void**)&p->d_hflags, p->h_flags, 0));
 
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;
@@ -1115,7 +1119,6 @@ static int run_cholesky(cba_problem* p) {
 template <int NC>
 static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
   const int ncp = p->ncp;
-  HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_SCHUR);
     if (p->schur_reg) {
@@ -1433,7 +1436,6 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   if (cam_x_new) { int rcu = upload_cam(p, cam_x_new, p->cam_over1); if (rcu) return rcu; }
-  HIPCHK(hipMemsetAsync(p->flags, 0, sizeof(int), p->stream));
   {
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
@@ -1536,7 +1538,6 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
   pack_host(p, x, p->h_vec.data(), 0.0);
   hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(p->flags, 0, sizeof(int), p->stream);
   if (e == hipSuccess) {
     launch_cam_prep(p, p->v2, p->tab_new);
     launch_cost(p, p->v2, p->tab_new, 24, d_r);
@@ -1566,6 +1567,7 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   HIPCHK(hipMemcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
   launch_cam_prep(p, p->x, p->tab);
   DISPATCH_NC(p, run_build<6>(p), run_build<9>(p));
+  HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));  // parity hook: no publish here, leave no flag behind
   HIPCHK(hipStreamSynchronize(p->stream));
   HIPCHK(hipGetLastError());
   (void)cost;
