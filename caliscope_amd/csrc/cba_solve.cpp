@@ -11,114 +11,19 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
-#include <complex>
 #include <cstdio>
 #include <vector>
 
 #include "../../include/caliscope_ba.h"
+#include "trf_math.h"
 
 namespace {
 
 // ||w||^2 / ||p||^2 below which the subspace model is built from explicit J.v products (trf.py, same constant)
 constexpr double SUBSPACE_EXPLICIT_BELOW = 1e-6;
 
-double min_quadratic_on_segment(double a, double b, double hi) {  // min over t in [0, hi] of a t^2 + b t
-  double best = std::min(0.0, hi * (a * hi + b));
-  if (a != 0.0) {
-    const double t = -0.5 * b / a;
-    if (t > 0.0 && t < hi) best = std::min(best, t * (a * t + b));
-  }
-  return best;
-}
-
-// Real roots of c[0] t^deg + ... + c[deg] (deg <= 4 after stripping leading zeros): Aberth-Ehrlich on the complex
-// roots, then the nearly real ones are polished by Newton on the real polynomial.  Callers rank the roots by a model
-// value, so a spurious extra candidate is harmless; a missed one is not — hence the generous "nearly real" band.
-int real_roots(const double* c_in, int n_coef, double* out) {
-  int lead = 0;
-  while (lead < n_coef && c_in[lead] == 0.0) ++lead;
-  const int deg = n_coef - 1 - lead;
-  if (deg <= 0) return 0;
-  const double* c = c_in + lead;
-  typedef std::complex<double> cd;
-  auto eval = [&](cd z, cd* dz) {
-    cd p = c[0], d = 0.0;
-    for (int i = 1; i <= deg; ++i) { d = d * z + p; p = p * z + c[i]; }
-    *dz = d;
-    return p;
-  };
-  double bound = 0.0;  // Cauchy bound on |root|
-  for (int i = 1; i <= deg; ++i) bound = std::max(bound, std::fabs(c[i] / c[0]));
-  bound += 1.0;
-  cd z[4];
-  for (int i = 0; i < deg; ++i) z[i] = std::polar(0.5 * bound, 0.7 + 2.0 * M_PI * i / deg);
-  for (int it = 0; it < 200; ++it) {
-    double move = 0.0;
-    for (int i = 0; i < deg; ++i) {
-      cd dp;
-      const cd p = eval(z[i], &dp);
-      if (p == cd(0.0)) continue;
-      cd ratio = (dp == cd(0.0)) ? cd(1e-3 * bound, 1e-3 * bound) : p / dp;
-      cd rep = 0.0;
-      for (int j = 0; j < deg; ++j)
-        if (j != i) {
-          const cd diff = z[i] - z[j];
-          rep += (diff == cd(0.0)) ? cd(1e6) : 1.0 / diff;
-        }
-      const cd den = 1.0 - ratio * rep;
-      const cd step = (den == cd(0.0)) ? ratio : ratio / den;
-      z[i] -= step;
-      move = std::max(move, std::abs(step) / (1.0 + std::abs(z[i])));
-    }
-    if (move < 1e-15) break;
-  }
-  int n = 0;
-  for (int i = 0; i < deg; ++i) {
-    if (std::fabs(z[i].imag()) > 1e-6 * (1.0 + std::fabs(z[i].real()))) continue;
-    double t = z[i].real();
-    for (int it = 0; it < 4; ++it) {  // Newton polish on the real line
-      double p = c[0], d = 0.0;
-      for (int k = 1; k <= deg; ++k) { d = d * t + p; p = p * t + c[k]; }
-      if (d == 0.0 || !std::isfinite(p / d)) break;
-      t -= p / d;
-    }
-    if (std::isfinite(t)) out[n++] = t;
-  }
-  return n;
-}
-
-// argmin 0.5 p^T B p + g^T p  s.t. ||p|| <= radius in two dimensions (scipy common.py:171-219 formulation: interior
-// Newton point if B is positive definite and the point is inside, else the boundary p = radius (2t, 1-t^2)/(1+t^2)
-// whose stationarity condition is a quartic in t; candidates are ranked by model value).
-void solve_subspace_2d(double b00, double b01, double b11, double g0, double g1, double radius, double* p) {
-  if (b00 > 0.0) {
-    const double schur = b11 - b01 * b01 / b00;
-    if (schur > 0.0) {
-      const double det = b00 * schur;
-      const double p0 = -(b11 * g0 - b01 * g1) / det, p1 = -(b00 * g1 - b01 * g0) / det;
-      if (p0 * p0 + p1 * p1 <= radius * radius) { p[0] = p0; p[1] = p1; return; }
-    }
-  }
-  const double r2 = radius * radius;
-  const double a = b00 * r2, b = b01 * r2, c = b11 * r2, d = g0 * radius, f = g1 * radius;
-  const double coef[5] = {-b + d, 2.0 * (a - c + f), 6.0 * b, 2.0 * (-a + c + f), -b - d};
-  double t[4];
-  const int nt = real_roots(coef, 5, t);
-  if (nt == 0) {  // degenerate quartic: steepest-descent boundary point
-    const double n = std::hypot(g0, g1);
-    p[0] = n > 0 ? -radius * g0 / n : 0.0;
-    p[1] = n > 0 ? -radius * g1 / n : 0.0;
-    return;
-  }
-  double best = INFINITY;
-  for (int i = 0; i <= nt; ++i) {  // i == nt: t -> infinity, p = (0, -radius)
-    double c0, c1;
-    if (i < nt) { const double q = 1.0 + t[i] * t[i]; c0 = radius * 2.0 * t[i] / q; c1 = radius * (1.0 - t[i] * t[i]) / q; }
-    else { c0 = 0.0; c1 = -radius; }
-    const double val = 0.5 * (c0 * (b00 * c0 + b01 * c1) + c1 * (b01 * c0 + b11 * c1)) + g0 * c0 + g1 * c1;
-    if (val < best) { best = val; p[0] = c0; p[1] = c1; }
-  }
-}
+using trf::min_quadratic_on_segment;
+using trf::solve_subspace_2d;
 
 int termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
   const bool f_ok = dF < ftol * F && ratio > 0.25;
@@ -273,10 +178,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       b00 = H_gg / gh_sq; b11 = 1.0;
     } else if (w_sq > SUBSPACE_EXPLICIT_BELOW * st.p_sq) {
       // from the step equation (H + C + lam I) p = -g_h: no further pass over the observations
-      const double H_gp = -gh_sq - lam * st.gh_dot_p, H_pp = -st.gh_dot_p - lam * st.p_sq;
-      b00 = H_gg / gh_sq;
-      b01 = (H_gp - c * H_gg) / (gh_norm * w_norm);
-      b11 = (H_pp - 2.0 * c * H_gp + c * c * H_gg) / w_sq;
+      trf::subspace_model(H_gg, gh_sq, lam, st.gh_dot_p, st.p_sq, w_sq, &b00, &b01, &b11);
     } else {
       // p nearly collinear with g_h (heavy damping): the identities cancel, form J_h q1, J_h q2 explicitly
       double gram[3];

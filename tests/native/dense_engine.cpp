@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/caliscope_ba.h"
+#include "../../caliscope_amd/csrc/trf_math.h"
 
 typedef void (*fun_cb)(const double* x, double* r);
 typedef void (*jac_cb)(const double* x, double* J);  // row-major m x n
@@ -37,6 +38,12 @@ cba_problem* de_create(int m, int n, int ncp, fun_cb fun, jac_cb jac) {
   return p;
 }
 void de_destroy(cba_problem* p) { delete p; }
+
+// the 2-D trust-region solve and the real-root finder of csrc/trf_math.h, for direct tests
+void de_subspace(double b00, double b01, double b11, double g0, double g1, double radius, double* p) {
+  trf::solve_subspace_2d(b00, b01, b11, g0, g1, radius, p);
+}
+int de_real_roots(const double* c, int n_coef, double* out) { return trf::real_roots(c, n_coef, out); }
 
 int cba_set_error(int32_t code, const char* message) { g_err = message ? message : ""; return code; }
 const char* cba_last_error(void) { return g_err.c_str(); }

@@ -121,6 +121,48 @@ def test_native_driver_on_classic_problems(native):
     assert res.status == -1 and len(evals) == 1
 
 
+def test_subspace_solver_and_root_finder(native):
+    """csrc/trf_math.h (shared by the host driver and the device-side step): the 2-D trust-region solve against brute
+    force over the disc boundary / the Python solver, the real-root finder against numpy.roots."""
+    native.de_subspace.argtypes = [C.c_double] * 6 + [_lib.c_double_p]
+    native.de_real_roots.argtypes = [_lib.c_double_p, C.c_int, _lib.c_double_p]
+    native.de_real_roots.restype = C.c_int
+    rng = np.random.default_rng(5)
+    th = np.linspace(0, 2 * np.pi, 20001)
+    model = lambda B, g, p: 0.5 * p @ B @ p + g @ p
+    for k in range(200):
+        A = rng.normal(size=(2, 2))
+        B = A @ A.T if k % 3 == 0 else A + A.T  # positive definite or indefinite
+        g = rng.normal(size=2) * (10.0 ** rng.integers(-3, 3))
+        r = float(rng.uniform(0.05, 3.0))
+        out = np.zeros(2)
+        native.de_subspace(B[0, 0], B[0, 1], B[1, 1], g[0], g[1], r, out.ctypes.data_as(_lib.c_double_p))
+        assert out @ out <= r * r * (1 + 1e-12)
+        ring = r * np.stack([np.cos(th), np.sin(th)])
+        best = min((0.5 * np.sum(ring * (B @ ring), axis=0) + g @ ring).min(), model(B, g, solve_subspace_2d(B, g, r)))
+        assert model(B, g, out) <= best + 1e-7 * (1 + abs(best)), (k, out)
+    for k in range(300):
+        deg = int(rng.integers(1, 5))
+        if k % 4 == 0:  # built from known real roots, some repeated / clustered
+            roots = rng.normal(size=deg) * (10.0 ** rng.integers(-2, 3))
+            if deg > 1 and k % 8 == 0:
+                roots[1] = roots[0] * (1 + 1e-5)
+            coef = np.poly(roots) * rng.uniform(0.5, 2)
+        else:
+            coef = rng.normal(size=deg + 1)
+        coef = np.concatenate([np.zeros(int(rng.integers(0, 2))), coef])  # leading zeros are stripped like numpy.roots
+        out = np.zeros(4)
+        n = native.de_real_roots(np.ascontiguousarray(coef).ctypes.data_as(_lib.c_double_p), len(coef), out.ctypes.data_as(_lib.c_double_p))
+        ref = np.roots(coef)
+        real = np.sort(ref[np.abs(ref.imag) < 1e-9 * (1 + np.abs(ref.real))].real)
+        scale = np.abs(np.trim_zeros(coef, "f")).max()
+        for t in out[:n]:  # every reported value is a root
+            assert abs(np.polyval(coef, t)) <= 1e-9 * scale * max(1.0, abs(t)) ** (len(np.trim_zeros(coef, "f")) - 1), (coef, t)
+        for t in real:  # every well-separated real root is reported
+            if np.min(np.abs(np.delete(ref, np.argmin(np.abs(ref - t))) - t), initial=np.inf) > 1e-3 * (1 + abs(t)):
+                assert n and np.min(np.abs(out[:n] - t)) <= 1e-7 * (1 + abs(t)), (coef, t, out[:n])
+
+
 def test_boundary_subspace_solution_matches_the_python_solver(native):
     """The quartic root finder behind solve_subspace_2d: drive it through indefinite / boundary cases by a one-iteration
     solve is indirect, so compare the Python solver against brute force here and the native one through trajectories
