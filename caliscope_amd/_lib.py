@@ -53,6 +53,14 @@ class TrialInfo(C.Structure):
     _fields_ = [("cost", C.c_double), ("step_norm", C.c_double), ("finite", C.c_int32), ("reserved", C.c_int32)]
 
 
+class StepInfo(C.Structure):
+    _fields_ = [
+        ("lin", Linearization), ("newton", NewtonInfo), ("trial", TrialInfo), ("lam", C.c_double), ("radius", C.c_double),
+        ("p_s", C.c_double * 2), ("predicted", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+        ("need_host", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class Info(C.Structure):
     _fields_ = [
         ("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_cam_params", C.c_int32), ("n_params", C.c_int32),
@@ -105,6 +113,8 @@ SIGNATURES = {
     "cba_subspace_gram": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]),
     "cba_trial": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(TrialInfo)]),
     "cba_accept": (C.c_int, [C.c_void_p]),
+    "cba_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepInfo)]),
+    "cba_step_supported": (C.c_int, [C.c_void_p]),
     "cba_set_camera_scaling": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(Linearization)]),
     "cba_subspace_gram_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.c_double, C.c_double, c_double_p, c_double_p]),
     "cba_trial_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.POINTER(TrialInfo)]),

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ba_math.h"
+#include "trf_math.h"
 
 namespace cba {
 
@@ -247,8 +248,9 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
         const int* __restrict__ chunk_pts, int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams,
         int loss, double f_scale, double* __restrict__ Vblk, double* __restrict__ gvec,
-        double* __restrict__ partialU, double* __restrict__ partial_cost) {
+        double* __restrict__ partialU, double* __restrict__ partial_cost, int* __restrict__ flags, const double* __restrict__ skip) {
   using UP = UPack<NC>;
+  if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
   double* sh_U = sh_tab + n_cams * CAMTAB_LDS;
@@ -260,6 +262,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   const double* px = xvec + lay.ncp_pad;
   double* gp = gvec + lay.ncp_pad;
   double cost = 0.0;
+  bool bad = false;
   const int last_obs = max(chunk_start[n_chunks] - 1, 0);
   int ch = blockIdx.x;
   int o0 = 0, o1 = 0;
@@ -285,6 +288,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       double e[2], A[2][MAX_NC], B[2][3];
       cost += obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss,
                                 f_scale, e, A, B);
+      if (!isfinite(e[0] + e[1])) bad = true;  // a trial point built directly by this pass (fused step): scipy's isfinite(f_new) test
       pv[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
       pv[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
       pv[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
@@ -344,6 +348,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
   const double tot = block_sum(cost, sh_red);
   if (threadIdx.x == 0) partial_cost[blockIdx.x] = tot;
+  if (bad) flags[0] = 1;
 }
 
 // unpack the reduced camera blocks: gradient -> gvec camera part
@@ -709,10 +714,11 @@ __global__ void __launch_bounds__(BLOCK)
 k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ chunk_start, int n_chunks,
         const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, const int* __restrict__ cam_off,
-        int n_cams, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
+        int n_cams, int loss, double f_scale, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
         double* __restrict__ partial_b, int* __restrict__ flags) {
   constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;
+  if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double2* sh_stage = reinterpret_cast<double2*>(sh);        // [BLOCK / WAVE][WAVE * NP]  record transpose, per wave
   double* sh_tab = sh + (size_t)BLOCK * REC;
@@ -1047,9 +1053,11 @@ template <int NC>
 __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,
                                  const double* __restrict__ Upacked, const double* __restrict__ gvec,
                                  const double* __restrict__ sinv, const int* __restrict__ param_cam,
-                                 const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ cam_diag,
-                                 double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ W, int ldw) {
+                                 const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ lam_dev,
+                                 const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
+                                 double* __restrict__ W, int ldw) {
   using UP = UPack<NC>;
+  if (lam_dev) lam = *lam_dev;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)ncp * ncp) return;
   const int row = (int)(t / ncp), col = (int)(t % ncp);
@@ -1447,9 +1455,10 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
           const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
           const int* __restrict__ chunk_pts, int n_chunks, const double* __restrict__ xvec, VecLayout lay,
           const double* __restrict__ tab, const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
-          const double* __restrict__ Vblk, const double* __restrict__ gvec, const double* __restrict__ sinv,
-          double* __restrict__ svec) {
+          const double* __restrict__ lam_dev, const double* __restrict__ Vblk, const double* __restrict__ gvec,
+          const double* __restrict__ sinv, double* __restrict__ svec) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  if (lam_dev) lam = *lam_dev;
   double* sh_tab = sh;
   double* sh_dc = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad
   double* sh_pt = sh_dc + lay.ncp_pad;               // [3][CHUNK]
@@ -1570,8 +1579,10 @@ k_step_scalars(const double* __restrict__ g, const double* __restrict__ sinv, co
 // w_sq = sum (s sinv - c g / sinv)^2 with c = scal[idx_gdot] / gh_sq   (device-side scalars, no host round trip)
 __global__ void __launch_bounds__(BLOCK)
 k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s, long total,
-           long first, const double* __restrict__ scal_gdot, double gh_sq, double* __restrict__ partial) {
+           long first, const double* __restrict__ scal_gdot, double gh_sq, const double* __restrict__ gh_sq_dev,
+           double* __restrict__ partial) {
   __shared__ double sh_red[BLOCK / WAVE];
+  if (gh_sq_dev) gh_sq = *gh_sq_dev;
   const double c = scal_gdot[0] / gh_sq;
   double s0 = 0;
   for (long i = first + (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
@@ -1586,8 +1597,10 @@ k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const 
 __global__ void __launch_bounds__(BLOCK)
 k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
                const double* __restrict__ s, double alpha, double beta, long total, int cam_end, int count_cams,
-               const double* __restrict__ cam_x_new, int n_over, double* __restrict__ x_new, double* __restrict__ partial) {
+               const double* __restrict__ cam_x_new, int n_over, const double* __restrict__ ab_dev, double* __restrict__ x_new,
+               double* __restrict__ partial) {
   __shared__ double sh_red[BLOCK / WAVE];
+  if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }  // fused step: coefficients from k_fused_subspace
   double s0 = 0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     const double si = sinv[i];
@@ -1599,6 +1612,41 @@ k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const
   }
   const double r = block_sum(s0, sh_red);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// ---- fused iteration (cba_step): the two scalar decisions of an iteration made on the device, so that one iteration
+// needs one host synchronisation instead of three.  scal slots: 0 gh_sq, 1 |x D|^2, 12 |J_h g_h|^2, 16 p_sq, 17 <g_h,p>,
+// 20 w_sq; outputs 40 lam, 41 radius, 42 need_host, 43/44 p_S, 45 predicted, 46 alpha, 47 beta.  fz: [0] lam, [2] alpha, [3] beta.
+__global__ void k_fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) {
+  const double gh_sq = scal[0], jg_sq = scal[12], xs = sqrt(scal[1]);
+  const double radius = radius_in > 0.0 ? radius_in : (xs > 0.0 ? xs : 1.0);  // first iteration: Delta = ||x0 * scale_inv||
+  const double lam = -trf::min_quadratic_on_segment(0.5 * jg_sq, -gh_sq, radius / sqrt(gh_sq)) / (radius * radius);
+  fz[0] = lam; fz[1] = radius;
+  scal[40] = lam; scal[41] = radius;
+}
+
+__global__ void k_fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
+  const double gh_sq = scal[0], jg_sq = scal[12], p_sq = scal[16], ghp = scal[17], w_sq = scal[20];
+  const double lam = fz[0], radius = fz[1], gh_norm = sqrt(gh_sq);
+  const double c = ghp / gh_sq;
+  const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * p_sq;
+  double need_host = 0.0, pS[2] = {0.0, 0.0}, alpha = 0.0, beta = 0.0, predicted = 0.0;
+  const bool ok = flags[1] == 0 && flags[2] == 0 && isfinite(p_sq) && isfinite(ghp) && isfinite(w_sq) && gh_sq > 0.0;
+  if (!ok || (two_d && !(w_sq > 1e-6 * p_sq))) {
+    need_host = 1.0;  // failed factorisation, or p nearly collinear with g_h (explicit J.v model): the host takes over
+  } else {
+    double b00, b01 = 0.0, b11;
+    const double w_norm = two_d ? sqrt(w_sq) : 1.0;
+    if (two_d) trf::subspace_model(jg_sq, gh_sq, lam, ghp, p_sq, w_sq, &b00, &b01, &b11);
+    else { b00 = jg_sq / gh_sq; b11 = 1.0; }
+    trf::solve_subspace_2d(b00, b01, b11, gh_norm, 0.0, radius, pS);
+    if (!two_d) pS[1] = 0.0;
+    predicted = -(0.5 * (pS[0] * (b00 * pS[0] + b01 * pS[1]) + pS[1] * (b01 * pS[0] + b11 * pS[1])) + gh_norm * pS[0]);
+    beta = two_d ? pS[1] / w_norm : 0.0;
+    alpha = pS[0] / gh_norm - beta * c;
+  }
+  fz[2] = alpha; fz[3] = beta;
+  scal[42] = need_host; scal[43] = pS[0]; scal[44] = pS[1]; scal[45] = predicted; scal[46] = alpha; scal[47] = beta;
 }
 
 // End of a primitive: the host-visible scalars and flags go straight to pinned host memory (mapped into the device's

@@ -90,6 +90,12 @@ struct cba_problem {
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
   bool cam_scaled = false, cam_state_saved = false;
+  // fused iteration (cba_step): device scalars [lam, radius, alpha, beta], second set of build outputs for the trial point
+  double *fz = nullptr, *V2 = nullptr, *g2 = nullptr, *U2 = nullptr;
+  bool have_build = false;   // V, g, Upacked are valid at the current x (a trial built by cba_step was accepted)
+  bool trial_built = false;  // the pending trial point carries its own build in V2, g2, U2
+  double cost_x = 0.0;       // cost at the current x
+  double trial_cost = 0.0;   // cost at the pending trial point
   int n_heavy = 0; int* heavy_pts = nullptr; int* heavy_frag = nullptr; double* heavy_W = nullptr;  // heavy points (k_heavy_schur)
   std::vector<int> h_heavy_pts;
   ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
@@ -888,6 +894,9 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
+  TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
+  TRY(dev_alloc(p, &p->U2, (size_t)p->C * ustride));
+  HIPCHK(hipMemset(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double))); HIPCHK(hipMemset(p->g2, 0, (size_t)tot * sizeof(double)));
   HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
   HIPCHK(hipMemset(p->flags, 0, 4 * sizeof(int)));
   HIPCHK(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
@@ -978,36 +987,41 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
   return CBA_OK;  // sharded solves: the caller's exchange() sums scal[slot] and the flags over the ranks
 }
 
+// Build pass at xvec (camera table tab) into the given outputs; the rho sum lands in scal[cost_slot].
 template <int NC>
-static int run_build(cba_problem* p) {
+static int run_build_into(cba_problem* p, const double* xvec, const double* tab, double* V, double* g, double* Upacked, int cost_slot,
+                          const double* skip = nullptr) {
   {
     ScopedTimer t(p, T_BUILD);
     if (p->n_heavy)  // fragments of heavy points add their sums by atomics
-      hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay, p->V, 6,
-                         p->g + p->lay.ncp_pad, 3);
+      hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay, V, 6,
+                         g + p->lay.ncp_pad, 3);
     hipLaunchKernelGGL(k_build<NC>, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                       p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->C, p->loss, p->f_scale,
-                       p->V, p->g, p->partial, p->partial1);
+                       p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
+                       V, g, p->partial, p->partial1, p->flags, skip);
   }
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
     const int w = p->C * UPack<NC>::STRIDE;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, p->Upacked);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, Upacked);
     int rho_rows = p->grid;
     if (p->con.n_con) {  // constraint rows: f, u, their share of g_p and of the squared column norms
       HIPCHK(hipMemsetAsync(p->con.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double), p->stream));
-      hipLaunchKernelGGL(k_con_eval<true>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, p->x, p->lay, p->loss, p->f_scale, p->g,
+      hipLaunchKernelGGL(k_con_eval<true>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, xvec, p->lay, p->loss, p->f_scale, g,
                          p->partial1 + p->grid, p->flags, (double*)nullptr);
       rho_rows += p->con_grid;
     }
-    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, rho_rows, 1, p->scal + 8);  // rho sum
-    int rc = allreduce_sum(p, p->Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
-    if (rc) return rc;                                 // (the rho sum in scal[8] rides with the linearisation's exchange)
-    hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->Upacked,
-                       p->cam_off, p->cam_np, p->C, p->g);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, rho_rows, 1, p->scal + cost_slot);  // rho sum
+    int rc = allreduce_sum(p, Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
+    if (rc) return rc;                               // (the rho sum rides with the caller's scalar exchange)
+    hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, Upacked,
+                       p->cam_off, p->cam_np, p->C, g);
   }
   return CBA_OK;
 }
+
+template <int NC>
+static int run_build(cba_problem* p) { return run_build_into<NC>(p, p->x, p->tab, p->V, p->g, p->Upacked, 8); }
 
 template <int NC>
 static int run_jv(cba_problem* p, int nv) {
@@ -1029,9 +1043,11 @@ static int run_jv(cba_problem* p, int nv) {
   return CBA_OK;  // scal[12..15] are summed over the ranks by the caller's exchange()
 }
 
+// device part of the linearisation (no host synchronisation): build unless the accepted trial brought its own, Jacobi
+// scale, scalars, ||J_h g_h||^2, the scalar exchange of a sharded solve
 template <int NC>
-static int run_linearize(cba_problem* p, cba_linearization* out) {
-  {
+static int run_lin_chain(cba_problem* p) {
+  if (!p->have_build) {
     int rcb = run_build<NC>(p);
     if (rcb) return rcb;
   }
@@ -1054,18 +1070,29 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
     if (rcj) return rcj;
   }
   // sums of the linearisation (scal[0..3]), rho sum (8), ||J v||^2 terms (12..15), max |g| (4): one all-reduce
-  int rc = exchange(p, SLOT(0) | SLOT(1) | SLOT(2) | SLOT(3) | SLOT(8) | SLOT(12) | SLOT(13) | SLOT(14) | SLOT(15), true);
-  if (rc) return rc;
-  rc = sync_scalars(p, 16);
-  if (rc) return rc;
+  return exchange(p, SLOT(0) | SLOT(1) | SLOT(2) | SLOT(3) | SLOT(8) | SLOT(12) | SLOT(13) | SLOT(14) | SLOT(15), true);
+}
+
+static void read_linearization(cba_problem* p, cba_linearization* out) {
+  if (!p->have_build) p->cost_x = 0.5 * p->h_scal[8];  // else: the cost of the accepted trial (cba_accept)
+  p->have_build = true;  // V, g, Upacked belong to the current x until it changes
   p->first_scale = false;
   p->gh_sq = p->h_scal[0];
   out->gh_sq = p->h_scal[0];
   out->x_scaled_norm = std::sqrt(p->h_scal[1]);
   out->x_norm = std::sqrt(p->h_scal[2]);
   out->g_norm_inf = p->h_scal[4];
-  out->cost = 0.5 * p->h_scal[8];
+  out->cost = p->cost_x;
   out->jg_sq = p->h_scal[12];
+}
+
+template <int NC>
+static int run_linearize(cba_problem* p, cba_linearization* out) {
+  int rc = run_lin_chain<NC>(p);
+  if (rc) return rc;
+  rc = sync_scalars(p, 16);
+  if (rc) return rc;
+  read_linearization(p, out);
   return CBA_OK;
 }
 
@@ -1116,14 +1143,15 @@ static int run_cholesky(cba_problem* p) {
   return CBA_OK;
 }
 
+// device part of the damped step; lam_dev != nullptr: the damping is read from device memory (fused step)
 template <int NC>
-static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
+static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev) {
   const int ncp = p->ncp;
   {
     ScopedTimer t(p, T_SCHUR);
     if (p->schur_reg) {
       hipLaunchKernelGGL((k_tprep<NC>), dim3(p->grid), dim3(BLOCK), lds_tprep<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
-                         p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, p->V, p->g,
+                         p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, lam_dev, p->V, p->g,
                          p->sinv, p->Trec, p->partial_b, p->flags);
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
@@ -1157,7 +1185,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     }
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
-                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw);
+                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw);
   }
   int rc = run_cholesky(p);
   if (rc) return rc;
@@ -1168,7 +1196,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
                          p->s + p->lay.ncp_pad, 3, p->s + p->lay.ncp_pad, 0);
     hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                        p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
-                       p->f_scale, lam, p->V, p->g, p->sinv, p->s);
+                       p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s);
     if (p->n_heavy)
       hipLaunchKernelGGL(k_heavy_finish, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->heavy_frag, p->n_heavy, p->lay, lam,
                          p->V, p->g, p->sinv, p->s);
@@ -1184,18 +1212,73 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
     int rcv = allreduce_sum(p, p->scal + 16, 2);
     if (rcv) return rcv;
-    hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->scal + 17, p->gh_sq, p->partial1);
+    hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->scal + 17, p->gh_sq,
+                       lam_dev ? (const double*)p->scal : (const double*)nullptr, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
     rcv = exchange(p, SLOT(20), false);  // ||w||^2 and the flags
     if (rcv) return rcv;
   }
-  rc = sync_scalars(p, 24);
-  if (rc) return rc;
+  return CBA_OK;
+}
+
+static void read_newton(cba_problem* p, cba_newton_info* out) {
   out->ok = (p->h_flags[1] == 0 && p->h_flags[2] == 0) ? 1 : 0;
   out->p_sq = p->h_scal[16];
   out->gh_dot_p = p->h_scal[17];
   out->w_sq = p->h_scal[20];
   if (out->ok && !(std::isfinite(out->p_sq) && std::isfinite(out->gh_dot_p) && std::isfinite(out->w_sq))) out->ok = 0;
+}
+
+template <int NC>
+static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
+  int rc = run_newton_chain<NC>(p, lam, nullptr);
+  if (rc) return rc;
+  rc = sync_scalars(p, 24);
+  if (rc) return rc;
+  read_newton(p, out);
+  return CBA_OK;
+}
+
+// One whole trust-region iteration behind a single host synchronisation: linearisation at the current x (the build is
+// skipped when the accepted trial brought its own), damping and 2-D subspace step decided on the device
+// (k_fused_lam / k_fused_subspace, the same code the host driver runs: csrc/trf_math.h), damped step, and the trial
+// point evaluated by a full build pass into the second set of buffers, so that accepting it costs nothing more.
+template <int NC>
+static int run_step(cba_problem* p, double radius, cba_step_info* out) {
+  int rc = run_lin_chain<NC>(p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_fused_lam, dim3(1), dim3(1), 0, p->stream, p->scal, radius, p->fz);
+  rc = run_newton_chain<NC>(p, 0.0, p->fz);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_fused_subspace, dim3(1), dim3(1), 0, p->stream, p->scal, p->flags, p->fz);
+  const long tot = p->lay.total();
+  const int vg = vec_grid(tot);
+  {
+    ScopedTimer t(p, T_VECTOR);
+    hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, 0.0, 0.0, tot, p->lay.ncp_pad,
+                       p->rank == 0 ? 1 : 0, (const double*)nullptr, 0, (const double*)(p->fz + 2), p->x_new, p->partial4);
+    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
+  }
+  launch_cam_prep(p, p->x_new, p->tab_new);
+  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42);  // skipped when need_host
+  if (rc) return rc;
+  rc = exchange(p, SLOT(24) | SLOT(28), false);
+  if (rc) return rc;
+  rc = sync_scalars(p, 48);
+  if (rc) return rc;
+  const int bad_residual = p->h_flags[0];
+  read_linearization(p, &out->lin);
+  read_newton(p, &out->newton);
+  out->lam = p->h_scal[40]; out->radius = p->h_scal[41];
+  out->need_host = p->h_scal[42] != 0.0 ? 1 : 0;
+  out->p_s[0] = p->h_scal[43]; out->p_s[1] = p->h_scal[44]; out->predicted = p->h_scal[45];
+  out->alpha = p->h_scal[46]; out->beta = p->h_scal[47];
+  const double c = 0.5 * p->h_scal[24];
+  out->trial.finite = (bad_residual == 0 && std::isfinite(c)) ? 1 : 0;
+  out->trial.cost = out->trial.finite ? c : NAN;
+  out->trial.step_norm = std::sqrt(p->h_scal[28]);
+  out->trial.reserved = 0;
+  p->trial_cost = c;
   return CBA_OK;
 }
 
@@ -1312,6 +1395,7 @@ static int begin_common(cba_problem* p, double* cost_out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   HIPCHK(hipMemsetAsync(p->cam_diag, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream));
   p->cam_scaled = false; p->cam_state_saved = false;
+  p->have_build = false; p->trial_built = false;
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
   int rc = launch_cost(p, p->x, p->tab, 24, nullptr);
@@ -1324,6 +1408,7 @@ static int begin_common(cba_problem* p, double* cost_out) {
   p->first_scale = true;
   p->begun = true; p->linearized = false; p->stepped = false; p->have_trial = false;
   *cost_out = p->h_flags[0] ? NAN : 0.5 * p->h_scal[24];
+  p->cost_x = *cost_out;
   return CBA_OK;
 }
 
@@ -1348,6 +1433,24 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
   HIPCHK(hipGetLastError());
   p->stepped = true;
   return CBA_OK;
+}
+
+int cba_step(cba_problem* p, double radius, cba_step_info* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_step: null argument");
+  if (!p->begun) return fail(CBA_ERR_INVALID, "cba_step: call cba_begin first");
+  if (!cba_step_supported(p)) return fail(CBA_ERR_UNSUPPORTED, "cba_step: not available for this problem (constraint rows, heavy points, bound scaling or the LDS Schur path): use the primitives");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = DISPATCH_NC(p, run_step<6>(p, radius, out), run_step<9>(p, radius, out));
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->linearized = true; p->stepped = true;
+  p->have_trial = out->need_host == 0;
+  p->trial_built = p->have_trial;
+  return CBA_OK;
+}
+
+int cba_step_supported(cba_problem* p) {
+  return (p && p->schur_reg && !p->con.n_con && !p->n_heavy && !p->cam_scaled) ? 1 : 0;
 }
 
 // camera-block override of a device vector: `host` [ncp] -> dev [ncp_pad] (padding stays zero)
@@ -1439,7 +1542,7 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
   {
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
-                       p->rank == 0 ? 1 : 0, (const double*)p->cam_over1, cam_x_new ? p->ncp : 0, p->x_new, p->partial1);
+                       p->rank == 0 ? 1 : 0, (const double*)p->cam_over1, cam_x_new ? p->ncp : 0, (const double*)nullptr, p->x_new, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
@@ -1454,7 +1557,7 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
   out->finite = (p->h_flags[0] == 0 && std::isfinite(c)) ? 1 : 0;
   out->cost = out->finite ? c : NAN;
   out->step_norm = std::sqrt(p->h_scal[28]);
-  p->have_trial = true;
+  p->have_trial = true; p->trial_built = false; p->trial_cost = c;
   return CBA_OK;
 }
 
@@ -1463,6 +1566,12 @@ int cba_accept(cba_problem* p) {
   if (!p->have_trial) return fail(CBA_ERR_INVALID, "cba_accept: no trial point");
   std::swap(p->x, p->x_new);
   std::swap(p->tab, p->tab_new);
+  if (p->trial_built) {  // the trial point came with its own build (cba_step): it becomes the linearisation point as it is
+    std::swap(p->V, p->V2); std::swap(p->g, p->g2); std::swap(p->Upacked, p->U2);
+    p->cost_x = p->trial_cost;
+  }
+  p->have_build = p->trial_built;
+  p->trial_built = false;
   p->have_trial = false; p->linearized = false; p->stepped = false;
   return CBA_OK;
 }
@@ -1557,6 +1666,7 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   if (!p || !x) return fail(CBA_ERR_INVALID, "cba_normal_blocks: null argument");
   HIPCHK(hipSetDevice(p->device));
   // Runs the real build pass on x: swap it in as the current point, then restore.
+  p->have_build = false;  // V, g, Upacked are overwritten below
   double cost;
   std::vector<double> saved((size_t)p->lay.total());
   HIPCHK(hipStreamSynchronize(p->stream));

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/caliscope_ba.h"
@@ -114,15 +115,31 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if (!(cb.x[i] > cb.lb[i] && cb.x[i] < cb.ub[i])) return cba_set_error(CBA_ERR_INVALID, "cba_solve: x0 is not strictly inside the bounds");
   }
   long nfev = 1, njev = 1, iteration = 0;
+  // Fused iterations (cba_step): linearisation, damping, damped step, subspace step and first trial behind ONE host
+  // synchronisation; the trial is evaluated by a build pass, so an accepted step needs no further pass.  A rejected
+  // first trial costs a build instead of a cost pass: after one, the next iteration goes through the primitives.
+  const char* fused_env = std::getenv("CBA_FUSED");
+  const bool fused = !bounded && cba_step_supported(p) && !(fused_env && fused_env[0] == '0');
+  bool fuse_next = fused;
   cba_linearization lin;
-  if ((rc = cba_linearize(p, &lin))) return rc;
+  cba_step_info si;
+  if (!fused && (rc = cba_linearize(p, &lin))) return rc;
+  bool lin_valid = !fused;   // `lin` describes the current x
   double radius = NAN;  // set from ||x0 * scale_inv (/ sqrt(v))|| on the first pass
   int status = -100;
-  double g_norm = lin.g_norm_inf, step_norm = NAN, actual = NAN;
+  double g_norm = NAN, step_norm = NAN, actual = NAN;
   if (opt.verbose == 2) std::printf("%15s%15s%15s%15s%15s%15s\n", "Iteration", "Total nfev", "Cost", "Cost reduction", "Step norm", "Optimality");
 
   for (;;) {
     double C_gg = 0.0;  // g_h^T C g_h, C = diag_h: the Coleman-Li term of the model Hessian (zero without bounds)
+    bool have_step = false;  // `si` holds this iteration's damped step and first trial
+    if (!lin_valid) {
+      if (status == -100 && fuse_next && nfev < max_nfev) {
+        if ((rc = cba_step(p, std::isnan(radius) ? -1.0 : radius, &si))) return rc;
+        lin = si.lin; have_step = true;
+      } else if ((rc = cba_linearize(p, &lin))) return rc;
+      lin_valid = true;
+    }
     if (bounded) {
       // Coleman-Li scaling vector of the camera block (common.py CL_scaling_vector) and what follows from it
       if ((rc = cba_get_camera_params(p, CBA_VEC_X, cb.x.data()))) return rc;
@@ -161,7 +178,9 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     // regularisation = model decrease along -g_h inside the region, per unit radius^2 (trf.py:303-309 / :477-483)
     double lam = -min_quadratic_on_segment(0.5 * H_gg, -gh_sq, radius / gh_norm) / (radius * radius);
     cba_newton_info st;
-    if ((rc = cba_newton_step(p, lam, &st))) return rc;
+    if (have_step) { lam = si.lam; st = si.newton; }
+    else if ((rc = cba_newton_step(p, lam, &st))) return rc;
+    bool first_trial_ready = have_step && st.ok && !si.need_host;
     for (int retries = 0; !st.ok;) {
       // positive definite in exact arithmetic; rounding on a gauge-singular problem can still break the factorisation
       if (++retries > max_retries) return cba_set_error(CBA_ERR_NUMERIC, "cba_solve: normal equations could not be factorised even with heavy damping");
@@ -191,10 +210,14 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     }
     actual = -1.0;
     double cost_new = cost;
+    bool first_pass = true;
     while (actual <= 0 && nfev < max_nfev) {
       double pS[2];
-      solve_subspace_2d(b00, b01, b11, gh_norm, 0.0, radius, pS);
-      if (!two_d) pS[1] = 0.0;
+      if (first_pass && first_trial_ready) { pS[0] = si.p_s[0]; pS[1] = si.p_s[1]; }  // decided on the device (same code)
+      else {
+        solve_subspace_2d(b00, b01, b11, gh_norm, 0.0, radius, pS);
+        if (!two_d) pS[1] = 0.0;
+      }
       const double quad_p = 0.5 * (pS[0] * (b00 * pS[0] + b01 * pS[1]) + pS[1] * (b01 * pS[0] + b11 * pS[1]));  // 0.5 p^T (H + C) p
       const double lin_p = gh_norm * pS[0];                                                                   // g_h^T p
       // step_h = pS0 q1 + pS1 q2 = alpha g_h + beta p;  step = alpha g / scale_inv^2 + beta s
@@ -202,7 +225,9 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       const double alpha = pS[0] / gh_norm - beta * c;
       double predicted = -(quad_p + lin_p), step_h_norm = std::hypot(pS[0], pS[1]);
       cba_trial_info tr;
-      if (!bounded) {
+      if (first_pass && first_trial_ready) {
+        tr = si.trial; predicted = si.predicted;  // the trial cba_step already evaluated
+      } else if (!bounded) {
         if ((rc = cba_trial(p, alpha, beta, &tr))) return rc;
       } else {
         // select_step (trf.py:129-202): the trust-region step if it stays inside the bounds, else the best of the step
@@ -279,9 +304,14 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         if ((rc = cba_trial_ex(p, pt_alpha, pt_beta, cb.x_new.data(), &tr))) return rc;
       }
       ++nfev;
-      if (!tr.finite) { radius = 0.25 * step_h_norm; continue; }
+      const bool was_first = first_pass;
+      first_pass = false;
+      if (!tr.finite) { radius = 0.25 * step_h_norm; if (was_first) fuse_next = false; continue; }
       cost_new = tr.cost;
       actual = cost - cost_new;
+      // speculate again only after an accepted first trial of a well-conditioned subspace (a collinear step needs the
+      // explicit J.v model, which cba_step leaves to the host)
+      if (was_first) fuse_next = fused && actual > 0 && w_sq > SUBSPACE_EXPLICIT_BELOW * st.p_sq;
       double ratio;
       if (predicted > 0) ratio = actual / predicted;
       else if (predicted == 0 && actual == 0) ratio = 1.0;
@@ -297,7 +327,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     if (actual > 0) {
       if ((rc = cba_accept(p))) return rc;
       cost = cost_new;
-      if ((rc = cba_linearize(p, &lin))) return rc;
+      lin_valid = false;  // linearised at the top of the next pass (by cba_step when fused)
       ++njev;
     } else {
       step_norm = 0.0; actual = 0.0;

@@ -137,6 +137,28 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out);
 /* x <- x_new (trf.py:525-526). */
 int cba_accept(cba_problem* p);
 
+/* ---- one iteration, one synchronisation ----------------------------------------------------------------
+ * cba_linearize + the regularisation rule + cba_newton_step + the 2-D subspace solve + cba_trial of the first trial
+ * point in ONE call: the two scalar decisions in between (reg_term of trf.py:477-483, solve_trust_region_2d of
+ * trf.py:491-493) are taken on the device by the same code the host driver uses (csrc/trf_math.h), and the trial point
+ * is evaluated by a full build pass into a second set of buffers — accepting it (cba_accept) makes it the next
+ * linearisation point without another pass.  radius <= 0: the initial Delta = ||x0 * scale_inv|| (trf.py:428-430).
+ * need_host = 1: the factorisation failed or the step is nearly collinear with the gradient (explicit J.v model): no
+ * trial was made, continue with the primitives (cba_newton_step / cba_subspace_gram / cba_trial) for this iteration.
+ * A rejected first trial is retried with cba_trial as usual.  Not available (cba_step_supported() == 0) with constraint
+ * rows, heavy points, after cba_set_camera_scaling, or on the LDS-tile Schur path. */
+typedef struct {
+  cba_linearization lin;
+  cba_newton_info newton;
+  cba_trial_info trial;
+  double lam, radius;        /* damping used, radius used                                          */
+  double p_s[2], predicted;  /* subspace step in the basis (g_h / |g_h|, w / |w|), model decrease  */
+  double alpha, beta;        /* trial step = alpha * g / scale_inv^2 + beta * s                    */
+  int32_t need_host, reserved;
+} cba_step_info;
+int cba_step(cba_problem* p, double radius, cba_step_info* out);
+int cba_step_supported(cba_problem* p);
+
 /* ---- bounded camera parameters (scipy trf_bounds, trf.py:205-398) ------------------------------------
  * With finite bounds (free intrinsics: s, k1, k2 of BundleParameterization.bounds()) scipy rescales every bounded
  * variable by the Coleman-Li vector v (distance to the bound the gradient points at) and adds the diagonal

@@ -187,6 +187,32 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
 
 int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { return cba_trial_ex(p, alpha, beta, nullptr, out); }
 
+// the fused iteration of the device engine, emulated with the primitives above and the same scalar code (trf_math.h)
+int cba_step_supported(cba_problem* p) { return p->cam_scaled ? 0 : 1; }
+int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
+  std::memset(out, 0, sizeof(*out));
+  cba_linearize(p, &out->lin);
+  const double gh_sq = out->lin.gh_sq, gh_norm = std::sqrt(gh_sq);
+  const double radius = radius_in > 0.0 ? radius_in : (out->lin.x_scaled_norm > 0.0 ? out->lin.x_scaled_norm : 1.0);
+  const double lam = -trf::min_quadratic_on_segment(0.5 * out->lin.jg_sq, -gh_sq, radius / gh_norm) / (radius * radius);
+  out->lam = lam; out->radius = radius;
+  cba_newton_step(p, lam, &out->newton);
+  const double p_sq = out->newton.p_sq, ghp = out->newton.gh_dot_p, w_sq = out->newton.w_sq;
+  const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * p_sq;
+  if (!out->newton.ok || !(gh_sq > 0.0) || (two_d && !(w_sq > 1e-6 * p_sq))) { out->need_host = 1; return CBA_OK; }
+  double b00, b01 = 0.0, b11, pS[2];
+  const double w_norm = two_d ? std::sqrt(w_sq) : 1.0, c = ghp / gh_sq;
+  if (two_d) trf::subspace_model(out->lin.jg_sq, gh_sq, lam, ghp, p_sq, w_sq, &b00, &b01, &b11);
+  else { b00 = out->lin.jg_sq / gh_sq; b11 = 1.0; }
+  trf::solve_subspace_2d(b00, b01, b11, gh_norm, 0.0, radius, pS);
+  if (!two_d) pS[1] = 0.0;
+  out->p_s[0] = pS[0]; out->p_s[1] = pS[1];
+  out->predicted = -(0.5 * (pS[0] * (b00 * pS[0] + b01 * pS[1]) + pS[1] * (b01 * pS[0] + b11 * pS[1])) + gh_norm * pS[0]);
+  out->beta = two_d ? pS[1] / w_norm : 0.0;
+  out->alpha = pS[0] / gh_norm - out->beta * c;
+  return cba_trial(p, out->alpha, out->beta, &out->trial);
+}
+
 int cba_accept(cba_problem* p) { p->x = p->x_new; p->f = p->f_new; return CBA_OK; }
 
 static const std::vector<double>& vec_of(cba_problem* p, int32_t which) {
