@@ -113,6 +113,7 @@ SIGNATURES = {
     "cba_subspace_gram": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]),
     "cba_trial": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(TrialInfo)]),
     "cba_accept": (C.c_int, [C.c_void_p]),
+    "cba_linearize_build": (C.c_int, [C.c_void_p]),
     "cba_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepInfo)]),
     "cba_step_supported": (C.c_int, [C.c_void_p]),
     "cba_set_camera_scaling": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(Linearization)]),

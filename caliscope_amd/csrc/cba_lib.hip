@@ -94,6 +94,7 @@ struct cba_problem {
   double *fz = nullptr, *V2 = nullptr, *g2 = nullptr, *U2 = nullptr;
   bool have_build = false;   // V, g, Upacked are valid at the current x (a trial built by cba_step was accepted)
   bool trial_built = false;  // the pending trial point carries its own build in V2, g2, U2
+  bool cost_pending = false; // the build of this linearisation ran here: its rho sum (scal[8]) is the cost at x
   double cost_x = 0.0;       // cost at the current x
   double trial_cost = 0.0;   // cost at the pending trial point
   int n_heavy = 0; int* heavy_pts = nullptr; int* heavy_frag = nullptr; double* heavy_W = nullptr;  // heavy points (k_heavy_schur)
@@ -1046,10 +1047,12 @@ static int run_jv(cba_problem* p, int nv) {
 // device part of the linearisation (no host synchronisation): build unless the accepted trial brought its own, Jacobi
 // scale, scalars, ||J_h g_h||^2, the scalar exchange of a sharded solve
 template <int NC>
-static int run_lin_chain(cba_problem* p) {
+static int run_lin_chain(cba_problem* p, bool scalars = true) {
   if (!p->have_build) {
     int rcb = run_build<NC>(p);
     if (rcb) return rcb;
+    p->cost_pending = true;
+    p->have_build = true;  // V, g, Upacked belong to the current x until it changes
   }
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
@@ -1060,6 +1063,8 @@ static int run_lin_chain(cba_problem* p) {
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
                        p->lay, p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr);
+    p->first_scale = false;
+    if (!scalars) return exchange(p, SLOT(8), false);  // cba_linearize_build: the caller rescales first (cba_set_camera_scaling)
     hipLaunchKernelGGL(k_lin_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, tot, p->lay.ncp_pad,
                        p->rank == 0 ? 1 : 0, 0, p->v1, p->partial4, p->partial1);
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 0);
@@ -1074,9 +1079,7 @@ static int run_lin_chain(cba_problem* p) {
 }
 
 static void read_linearization(cba_problem* p, cba_linearization* out) {
-  if (!p->have_build) p->cost_x = 0.5 * p->h_scal[8];  // else: the cost of the accepted trial (cba_accept)
-  p->have_build = true;  // V, g, Upacked belong to the current x until it changes
-  p->first_scale = false;
+  if (p->cost_pending) { p->cost_x = 0.5 * p->h_scal[8]; p->cost_pending = false; }  // else: the cost of the accepted trial
   p->gh_sq = p->h_scal[0];
   out->gh_sq = p->h_scal[0];
   out->x_scaled_norm = std::sqrt(p->h_scal[1]);
@@ -1395,7 +1398,7 @@ static int begin_common(cba_problem* p, double* cost_out) {
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   HIPCHK(hipMemsetAsync(p->cam_diag, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream));
   p->cam_scaled = false; p->cam_state_saved = false;
-  p->have_build = false; p->trial_built = false;
+  p->have_build = false; p->trial_built = false; p->cost_pending = false;
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
   int rc = launch_cost(p, p->x, p->tab, 24, nullptr);
@@ -1417,6 +1420,17 @@ int cba_linearize(cba_problem* p, cba_linearization* out) {
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize: call cba_begin first");
   HIPCHK(hipSetDevice(p->device));
   int rc = DISPATCH_NC(p, run_linearize<6>(p, out), run_linearize<9>(p, out));
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  p->linearized = true; p->stepped = false;
+  return CBA_OK;
+}
+
+int cba_linearize_build(cba_problem* p) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_linearize_build: null argument");
+  if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize_build: call cba_begin first");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = DISPATCH_NC(p, run_lin_chain<6>(p, false), run_lin_chain<9>(p, false));
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   p->linearized = true; p->stepped = false;
@@ -1520,13 +1534,7 @@ int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* dia
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   p->cam_scaled = true; p->stepped = false;
-  p->gh_sq = p->h_scal[0];
-  out->gh_sq = p->h_scal[0];
-  out->x_scaled_norm = std::sqrt(p->h_scal[1]);
-  out->x_norm = std::sqrt(p->h_scal[2]);
-  out->g_norm_inf = p->h_scal[4];  // point block only
-  out->cost = 0.5 * p->h_scal[8];
-  out->jg_sq = p->h_scal[12];
+  read_linearization(p, out);  // g_norm_inf: point block only
   return CBA_OK;
 }
 

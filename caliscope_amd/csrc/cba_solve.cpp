@@ -123,8 +123,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   bool fuse_next = fused;
   cba_linearization lin;
   cba_step_info si;
-  if (!fused && (rc = cba_linearize(p, &lin))) return rc;
-  bool lin_valid = !fused;   // `lin` describes the current x
+  bool lin_valid = false;    // `lin` describes the current x
   double radius = NAN;  // set from ||x0 * scale_inv (/ sqrt(v))|| on the first pass
   int status = -100;
   double g_norm = NAN, step_norm = NAN, actual = NAN;
@@ -137,6 +136,8 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if (status == -100 && fuse_next && nfev < max_nfev) {
         if ((rc = cba_step(p, std::isnan(radius) ? -1.0 : radius, &si))) return rc;
         lin = si.lin; have_step = true;
+      } else if (bounded) {
+        if ((rc = cba_linearize_build(p))) return rc;  // the scalars follow from cba_set_camera_scaling below
       } else if ((rc = cba_linearize(p, &lin))) return rc;
       lin_valid = true;
     }

@@ -173,6 +173,11 @@ int cba_step_supported(cba_problem* p);
  * kept apart and is not disturbed. */
 int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out);
 
+/* cba_linearize without the scalars: build pass and Jacobi scale only, no host synchronisation.  For bounded solves,
+ * which rescale the camera block before any scaled quantity is meaningful: cba_linearize_build, read the camera parts
+ * of x / g / scale_inv, cba_set_camera_scaling (which returns the linearisation). */
+int cba_linearize_build(cba_problem* p);
+
 /* cba_subspace_gram with the camera block of v1 / v2 replaced by cam1 / cam2 ([n_cam_params], x-space; NULL: not
  * replaced) — the reflected direction of select_step (trf.py:129-202) differs from the trust-region step in the
  * camera entries that hit a bound. */

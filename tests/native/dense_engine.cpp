@@ -105,6 +105,8 @@ int cba_linearize(cba_problem* p, cba_linearization* out) {
   return CBA_OK;
 }
 
+int cba_linearize_build(cba_problem* p) { cba_linearization unused; return cba_linearize(p, &unused); }
+
 int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out) {
   for (int j = 0; j < p->ncp; ++j) {
     p->sinv[j] = p->sinv_state[j] * mult[j];
