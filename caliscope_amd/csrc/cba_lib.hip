@@ -92,6 +92,7 @@ struct cba_problem {
   bool cam_scaled = false, cam_state_saved = false;
   // fused iteration (cba_step): device scalars [lam, radius, alpha, beta], second set of build outputs for the trial point
   double *fz = nullptr, *V2 = nullptr, *g2 = nullptr, *U2 = nullptr;
+  bool peer_needs_primitives = false;  // sharded solves: some rank cannot run cba_step, so none does
   bool have_build = false;   // V, g, Upacked are valid at the current x (a trial built by cba_step was accepted)
   bool trial_built = false;  // the pending trial point carries its own build in V2, g2, U2
   bool cost_pending = false; // the build of this linearisation ran here: its rho sum (scal[8]) is the cost at x
@@ -1464,7 +1465,7 @@ int cba_step(cba_problem* p, double radius, cba_step_info* out) {
 }
 
 int cba_step_supported(cba_problem* p) {
-  return (p && p->schur_reg && !p->con.n_con && !p->n_heavy && !p->cam_scaled) ? 1 : 0;
+  return (p && p->schur_reg && !p->con.n_con && !p->n_heavy && !p->cam_scaled && !p->peer_needs_primitives) ? 1 : 0;
 }
 
 // camera-block override of a device vector: `host` [ncp] -> dev [ncp_pad] (padding stays zero)
@@ -1608,6 +1609,18 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   NCCLCHK(ncclCommInitRank(&p->comm, world, id, rank));
+  // cba_step issues one collective more than the primitives (the camera blocks of the trial build): every rank must
+  // take the same route.  A rank whose shard needs the primitives (constraint rows, heavy points, LDS Schur path)
+  // switches the fused route off for all of them.
+  {
+    const double mine = cba_step_supported(p) ? 0.0 : 1.0;
+    HIPCHK(hipMemcpyAsync(p->xbuf, &mine, sizeof(double), hipMemcpyHostToDevice, p->stream));
+    NCCLCHK(ncclAllReduce(p->xbuf, p->xbuf, 1, ncclDouble, ncclSum, p->comm, p->stream));
+    double total = 0.0;
+    HIPCHK(hipMemcpyAsync(&total, p->xbuf, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->peer_needs_primitives = total > 0.0;
+  }
   return CBA_OK;
 }
 

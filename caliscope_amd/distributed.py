@@ -7,6 +7,8 @@ gathering the solution) — the data-plane collectives run inside libcaliscope_b
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from caliscope_amd.engine import BAProblem
@@ -78,7 +80,18 @@ def solve_sharded(problem: BAProblem, x0: np.ndarray, control, *, device_id: int
         shard = shard_problem(problem, control.rank, control.world)
         engine = engine_factory(shard, control)
     try:
-        res = trf_solve(engine, shard.local_x(np.asarray(x0, dtype=np.float64)), **tol)
+        par = shard.problem.parameterization
+        ncp = par.n_camera_params
+        lb, ub = par.bounds()
+        bounded = bool(np.any(np.isfinite(lb[:ncp])) or np.any(np.isfinite(ub[:ncp])))
+        x_local = shard.local_x(np.asarray(x0, dtype=np.float64))
+        if hasattr(engine, "solve") and os.environ.get("CBA_HOST_LOOP", "native") != "python":
+            # the library's driver (cba_solve) on every rank: the scalars that steer it are identical everywhere
+            res = engine.solve(x_local, lb=np.ascontiguousarray(lb[:ncp]) if bounded else None,
+                               ub=np.ascontiguousarray(ub[:ncp]) if bounded else None, **tol)
+        else:
+            feasible = (lambda c: bool(np.all(c > lb[:ncp]) and np.all(c < ub[:ncp]))) if bounded else None
+            res = trf_solve(engine, x_local, feasible=feasible, **tol)
         res.x = gather_solution(shard, res.x, control)
     finally:
         close = getattr(engine, "close", None)

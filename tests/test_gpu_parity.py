@@ -351,6 +351,10 @@ def test_rccl_call_sites_with_a_one_rank_communicator(monkeypatch):
         eng.comm_init(eng.comm_unique_id(), 0, 1)
         got = trf_solve(eng, x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=50)
         r, _ = eng.residuals(got.x)
+        # the library's own driver on the same communicator: fused iterations (cba_step) with their extra collective
+        assert eng.lib.cba_step_supported(eng._h) == 1
+        native = eng.solve(x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=50)
+        assert native.nfev == ref.nfev and native.status == ref.status and abs(native.cost - ref.cost) <= 1e-12 * ref.cost
     # not bit-identical: the FP64 LDS atomics of the build / Schur passes land in a different order on every
     # run, and the last iterations are damped only by lam ~ 1e-13 along the gauge directions
     assert got.nfev == ref.nfev and got.status == ref.status
