@@ -115,6 +115,7 @@ SIGNATURES = {
     "cba_accept": (C.c_int, [C.c_void_p]),
     "cba_linearize_build": (C.c_int, [C.c_void_p]),
     "cba_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepInfo)]),
+    "cba_refresh_step_scalars": (C.c_int, [C.c_void_p, C.POINTER(NewtonInfo)]),
     "cba_step_supported": (C.c_int, [C.c_void_p]),
     "cba_set_camera_scaling": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(Linearization)]),
     "cba_subspace_gram_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.c_double, C.c_double, c_double_p, c_double_p]),

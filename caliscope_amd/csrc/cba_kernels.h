@@ -1626,14 +1626,18 @@ __global__ void k_fused_lam(double* __restrict__ scal, double radius_in, double*
 }
 
 __global__ void k_fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
-  const double gh_sq = scal[0], jg_sq = scal[12], p_sq = scal[16], ghp = scal[17], w_sq = scal[20];
+  const double gh_sq = scal[0], jg_sq = scal[12], p_sq = scal[16], ghp = scal[17];
   const double lam = fz[0], radius = fz[1], gh_norm = sqrt(gh_sq);
   const double c = ghp / gh_sq;
-  const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * p_sq;
+  // ||w||^2 = ||p - c g_h||^2 = ||p||^2 - <g_h, p>^2 / ||g_h||^2: relative error ~ eps ||p||^2 / ||w||^2, so it is used
+  // only while w is not small against p (the primitives measure ||w||^2 by a pass of its own, k_w_scalar)
+  const double w_sq = p_sq - ghp * ghp / gh_sq;
+  scal[20] = w_sq;
+  const bool two_d = true;
   double need_host = 0.0, pS[2] = {0.0, 0.0}, alpha = 0.0, beta = 0.0, predicted = 0.0;
-  const bool ok = flags[1] == 0 && flags[2] == 0 && isfinite(p_sq) && isfinite(ghp) && isfinite(w_sq) && gh_sq > 0.0;
-  if (!ok || (two_d && !(w_sq > 1e-6 * p_sq))) {
-    need_host = 1.0;  // failed factorisation, or p nearly collinear with g_h (explicit J.v model): the host takes over
+  const bool ok = flags[1] == 0 && flags[2] == 0 && isfinite(p_sq) && isfinite(ghp) && gh_sq > 0.0;
+  if (!ok || !(w_sq > 1e-3 * p_sq)) {
+    need_host = 1.0;  // failed factorisation, or p nearly collinear with g_h: the host takes over with the primitives
   } else {
     double b00, b01 = 0.0, b11;
     const double w_norm = two_d ? sqrt(w_sq) : 1.0;

@@ -198,14 +198,17 @@ static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
   return CBA_OK;
 }
 // one all-reduce for the host-visible scalars of a primitive: scal slots in `mask`, the flags, optionally max |g|
-static int exchange(cba_problem* p, unsigned long long mask, bool with_max) {
+// `buf` / `prefix`: the packed scalars ride at the tail of a payload that needs the same sum (buf[0 .. prefix)), so
+// that payload and scalars cost one collective; buf must have room for prefix + 64 + world doubles.
+static int exchange_at(cba_problem* p, unsigned long long mask, bool with_max, double* buf, size_t prefix) {
   if (!p->comm) return CBA_OK;
-  hipLaunchKernelGGL(k_xpack, dim3(1), dim3(64), 0, p->stream, p->scal, p->flags, mask, with_max ? 1 : 0, p->rank, p->world, p->xbuf);
+  hipLaunchKernelGGL(k_xpack, dim3(1), dim3(64), 0, p->stream, p->scal, p->flags, mask, with_max ? 1 : 0, p->rank, p->world, buf + prefix);
   const size_t n = (size_t)__builtin_popcountll(mask) + 4 + (with_max ? p->world : 0);
-  NCCLCHK(ncclAllReduce(p->xbuf, p->xbuf, n, ncclDouble, ncclSum, p->comm, p->stream));
-  hipLaunchKernelGGL(k_xunpack, dim3(1), dim3(64), 0, p->stream, p->xbuf, mask, with_max ? 1 : 0, p->world, p->scal, p->flags);
+  NCCLCHK(ncclAllReduce(buf, buf, prefix + n, ncclDouble, ncclSum, p->comm, p->stream));
+  hipLaunchKernelGGL(k_xunpack, dim3(1), dim3(64), 0, p->stream, buf + prefix, mask, with_max ? 1 : 0, p->world, p->scal, p->flags);
   return CBA_OK;
 }
+static int exchange(cba_problem* p, unsigned long long mask, bool with_max) { return exchange_at(p, mask, with_max, p->xbuf, 0); }
 #define SLOT(i) (1ull << (i))
 
 static inline int vec_grid(long total) { return (int)std::min<long>((total + BLOCK - 1) / BLOCK, 1024); }
@@ -863,7 +866,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->V, (size_t)6 * p->lay.Ppad));
   HIPCHK(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
-  TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride));
+  TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride + 128));  // + room for the scalars that ride with the blocks (exchange_at)
   lap("allocate vectors");
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   lap("reorder, upload, allocate");
@@ -897,7 +900,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
-  TRY(dev_alloc(p, &p->U2, (size_t)p->C * ustride));
+  TRY(dev_alloc(p, &p->U2, (size_t)p->C * ustride + 128));
   HIPCHK(hipMemset(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double))); HIPCHK(hipMemset(p->g2, 0, (size_t)tot * sizeof(double)));
   HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
   HIPCHK(hipMemset(p->flags, 0, 4 * sizeof(int)));
@@ -992,7 +995,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
 // Build pass at xvec (camera table tab) into the given outputs; the rho sum lands in scal[cost_slot].
 template <int NC>
 static int run_build_into(cba_problem* p, const double* xvec, const double* tab, double* V, double* g, double* Upacked, int cost_slot,
-                          const double* skip = nullptr) {
+                          const double* skip = nullptr, bool defer_exchange = false) {
   {
     ScopedTimer t(p, T_BUILD);
     if (p->n_heavy)  // fragments of heavy points add their sums by atomics
@@ -1014,6 +1017,7 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
       rho_rows += p->con_grid;
     }
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, rho_rows, 1, p->scal + cost_slot);  // rho sum
+    if (defer_exchange) return CBA_OK;  // the caller sums the blocks together with its scalars and unpacks the gradient
     int rc = allreduce_sum(p, Upacked, (size_t)w);  // camera blocks U_c and g_c: sum over the point shards
     if (rc) return rc;                               // (the rho sum rides with the caller's scalar exchange)
     hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, Upacked,
@@ -1147,6 +1151,25 @@ static int run_cholesky(cba_problem* p) {
   return CBA_OK;
 }
 
+// scalars of the damped step s: ||p||^2 and <g_h, p> (scal[16], [17]) and ||w||^2, w = p - (<g_h,p> / ||g_h||^2) g_h (scal[20]).
+// formula_w: the fused step derives ||w||^2 from the first two on the device (k_fused_subspace) and spends one
+// collective; otherwise it is measured by a pass of its own, which stays accurate when w is tiny against p.
+static int run_step_scalars(cba_problem* p, bool formula_w) {
+  ScopedTimer t(p, T_VECTOR);
+  const long tot = p->lay.total();
+  const int vg = vec_grid(tot);
+  const long first = (p->rank == 0) ? 0 : p->lay.ncp_pad;  // replicated camera entries are counted on rank 0 only
+  hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->partial4);
+  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
+  if (formula_w) return exchange(p, SLOT(16) | SLOT(17), false);
+  int rcv = allreduce_sum(p, p->scal + 16, 2);
+  if (rcv) return rcv;
+  hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->scal + 17, p->gh_sq,
+                     (const double*)nullptr, p->partial1);
+  hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
+  return exchange(p, SLOT(20), false);  // ||w||^2 and the flags
+}
+
 // device part of the damped step; lam_dev != nullptr: the damping is read from device memory (fused step)
 template <int NC>
 static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev) {
@@ -1207,22 +1230,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev) {
     if (p->con.n_con)
       hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
   }
-  {
-    ScopedTimer t(p, T_VECTOR);
-    const long tot = p->lay.total();
-    const int vg = vec_grid(tot);
-    const long first = (p->rank == 0) ? 0 : p->lay.ncp_pad;  // replicated camera entries are counted on rank 0 only
-    hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->partial4);
-    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
-    int rcv = allreduce_sum(p, p->scal + 16, 2);
-    if (rcv) return rcv;
-    hipLaunchKernelGGL(k_w_scalar, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->scal + 17, p->gh_sq,
-                       lam_dev ? (const double*)p->scal : (const double*)nullptr, p->partial1);
-    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 20);
-    rcv = exchange(p, SLOT(20), false);  // ||w||^2 and the flags
-    if (rcv) return rcv;
-  }
-  return CBA_OK;
+  return run_step_scalars(p, lam_dev != nullptr);
 }
 
 static void read_newton(cba_problem* p, cba_newton_info* out) {
@@ -1264,10 +1272,12 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
     hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
-  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42);  // skipped when need_host
+  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true);  // skipped when need_host
   if (rc) return rc;
-  rc = exchange(p, SLOT(24) | SLOT(28), false);
+  // one collective for the trial's camera blocks, its cost, the step norm and the flags
+  rc = exchange_at(p, SLOT(24) | SLOT(28), false, p->U2, (size_t)p->C * UPack<NC>::STRIDE);
   if (rc) return rc;
+  hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->U2, p->cam_off, p->cam_np, p->C, p->g2);
   rc = sync_scalars(p, 48);
   if (rc) return rc;
   const int bad_residual = p->h_flags[0];
@@ -1461,6 +1471,19 @@ int cba_step(cba_problem* p, double radius, cba_step_info* out) {
   p->linearized = true; p->stepped = true;
   p->have_trial = out->need_host == 0;
   p->trial_built = p->have_trial;
+  return CBA_OK;
+}
+
+int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
+  if (!p || !out) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: null argument");
+  if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: no damped step to measure");
+  HIPCHK(hipSetDevice(p->device));
+  const int f1 = p->h_flags[1], f2 = p->h_flags[2];  // the factorisation flags of the step were published (and cleared) already
+  int rc = run_step_scalars(p, false);
+  if (!rc) rc = sync_scalars(p, 24);
+  if (rc) return rc;
+  p->h_flags[1] = f1; p->h_flags[2] = f2;
+  read_newton(p, out);
   return CBA_OK;
 }
 

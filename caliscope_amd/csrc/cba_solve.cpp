@@ -179,8 +179,11 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     // regularisation = model decrease along -g_h inside the region, per unit radius^2 (trf.py:303-309 / :477-483)
     double lam = -min_quadratic_on_segment(0.5 * H_gg, -gh_sq, radius / gh_norm) / (radius * radius);
     cba_newton_info st;
-    if (have_step) { lam = si.lam; st = si.newton; }
-    else if ((rc = cba_newton_step(p, lam, &st))) return rc;
+    if (have_step) {
+      lam = si.lam; st = si.newton;
+      // collinear step: the explicit-model branch below needs ||w||^2 measured, not derived (cba_step's shortcut)
+      if (si.need_host && st.ok && (rc = cba_refresh_step_scalars(p, &st))) return rc;
+    } else if ((rc = cba_newton_step(p, lam, &st))) return rc;
     bool first_trial_ready = have_step && st.ok && !si.need_host;
     for (int retries = 0; !st.ok;) {
       // positive definite in exact arithmetic; rounding on a gauge-singular problem can still break the factorisation
@@ -312,7 +315,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       actual = cost - cost_new;
       // speculate again only after an accepted first trial of a well-conditioned subspace (a collinear step needs the
       // explicit J.v model, which cba_step leaves to the host)
-      if (was_first) fuse_next = fused && actual > 0 && w_sq > SUBSPACE_EXPLICIT_BELOW * st.p_sq;
+      if (was_first) fuse_next = fused && actual > 0 && w_sq > 1e-2 * st.p_sq;  // (cba_step needs w_sq > 1e-3 p_sq: hysteresis)
       double ratio;
       if (predicted > 0) ratio = actual / predicted;
       else if (predicted == 0 && actual == 0) ratio = 1.0;

@@ -157,6 +157,10 @@ typedef struct {
   int32_t need_host, reserved;
 } cba_step_info;
 int cba_step(cba_problem* p, double radius, cba_step_info* out);
+/* p_sq, gh_dot_p and w_sq of the current damped step measured again, w_sq by a pass of its own: cba_step derives w_sq
+ * from the other two (one collective less), which loses accuracy when the step is nearly collinear with the gradient —
+ * exactly the need_host case, whose explicit-model branch needs it accurately. */
+int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out);
 int cba_step_supported(cba_problem* p);
 
 /* ---- bounded camera parameters (scipy trf_bounds, trf.py:205-398) ------------------------------------

@@ -199,9 +199,11 @@ int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
   const double lam = -trf::min_quadratic_on_segment(0.5 * out->lin.jg_sq, -gh_sq, radius / gh_norm) / (radius * radius);
   out->lam = lam; out->radius = radius;
   cba_newton_step(p, lam, &out->newton);
-  const double p_sq = out->newton.p_sq, ghp = out->newton.gh_dot_p, w_sq = out->newton.w_sq;
-  const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * p_sq;
-  if (!out->newton.ok || !(gh_sq > 0.0) || (two_d && !(w_sq > 1e-6 * p_sq))) { out->need_host = 1; return CBA_OK; }
+  const double p_sq = out->newton.p_sq, ghp = out->newton.gh_dot_p;
+  const double w_sq = p_sq - ghp * ghp / gh_sq;  // derived, as on the device
+  out->newton.w_sq = w_sq;
+  const bool two_d = true;
+  if (!out->newton.ok || !(gh_sq > 0.0) || !(w_sq > 1e-3 * p_sq)) { out->need_host = 1; return CBA_OK; }
   double b00, b01 = 0.0, b11, pS[2];
   const double w_norm = two_d ? std::sqrt(w_sq) : 1.0, c = ghp / gh_sq;
   if (two_d) trf::subspace_model(out->lin.jg_sq, gh_sq, lam, ghp, p_sq, w_sq, &b00, &b01, &b11);
@@ -213,6 +215,15 @@ int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
   out->beta = two_d ? pS[1] / w_norm : 0.0;
   out->alpha = pS[0] / gh_norm - out->beta * c;
   return cba_trial(p, out->alpha, out->beta, &out->trial);
+}
+
+int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
+  const int n = p->n;
+  double p_sq = 0.0, ghp = 0.0, gh_sq = 0.0, w_sq = 0.0;
+  for (int j = 0; j < n; ++j) { const double pj = p->s[j] * p->sinv[j], gh = p->g[j] / p->sinv[j]; p_sq += pj * pj; ghp += gh * pj; gh_sq += gh * gh; }
+  for (int j = 0; j < n; ++j) { const double w = p->s[j] * p->sinv[j] - (ghp / gh_sq) * p->g[j] / p->sinv[j]; w_sq += w * w; }
+  out->ok = 1; out->reserved = 0; out->p_sq = p_sq; out->gh_dot_p = ghp; out->w_sq = w_sq;
+  return CBA_OK;
 }
 
 int cba_accept(cba_problem* p) { p->x = p->x_new; p->f = p->f_new; return CBA_OK; }
