@@ -1690,6 +1690,7 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   const size_t n_rows = (size_t)2 * p->N + (size_t)p->con.n_con;  // reprojection rows, then the constraint rows
   HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
   pack_host(p, x, p->h_vec.data(), 0.0);
+  p->have_trial = false; p->trial_built = false;  // the evaluation borrows the trial point's camera table: a pending trial is gone
   hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
   if (e == hipSuccess) {
     launch_cam_prep(p, p->v2, p->tab_new);

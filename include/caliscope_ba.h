@@ -233,8 +233,8 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out);
 int cba_get_camera_params(cba_problem* p, int32_t which, double* out);
 
 /* joint_residuals(x) in the caller's observation order, interleaved (x0,y0,x1,y1,...) [2N], followed by the
- * constraint rows [n_con] when cba_set_constraints was called, and the (robust) cost.  Does not disturb the solver
- * state. */
+ * constraint rows [n_con] when cba_set_constraints was called, and the (robust) cost.  The linearisation and the damped
+ * step stay valid; a pending trial point (cba_trial without cba_accept) is discarded. */
 int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out);
 
 /* Blocks of J^T J and J^T f at x (robust-scaled like scipy's J, f):
