@@ -1656,10 +1656,14 @@ __global__ void k_fused_subspace(double* __restrict__ scal, const int* __restric
 // End of a primitive: the host-visible scalars and flags go straight to pinned host memory (mapped into the device's
 // address space) — no copy-engine round trip — and the flags are cleared for the next primitive.
 __global__ void k_publish(const double* __restrict__ scal, int n_scal, int* __restrict__ flags, double* __restrict__ host_scal,
-                          int* __restrict__ host_flags) {
+                          int* __restrict__ host_flags, unsigned long long seq) {
   const int t = threadIdx.x;
   if (t < n_scal) host_scal[t] = scal[t];
   if (t < 4) { host_flags[t] = flags[t]; flags[t] = 0; }
+  // the sequence number goes last: the host spins on it instead of sleeping in hipStreamSynchronize (host_scal[63])
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) reinterpret_cast<volatile unsigned long long*>(host_scal)[63] = seq;
 }
 
 __global__ void k_fill(double* __restrict__ p, double v, long n) {

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -106,6 +107,8 @@ struct cba_problem {
   double* h_scal = nullptr;  // pinned, mapped: k_publish writes it (d_hscal is the same memory seen from the device)
   int* h_flags = nullptr;
   double* d_hscal = nullptr;
+  unsigned long long publish_seq = 0;
+  bool spin_wait = true;  // CBA_SPIN=0: sleep in hipStreamSynchronize instead
   int* d_hflags = nullptr;
   bool first_scale = true;
   bool have_x0 = false;
@@ -180,7 +183,23 @@ static void drain_timers(cba_problem* p) {
 
 static int sync_scalars(cba_problem* p, int n_scal) {
   // every primitive ends here: scalars and flags to the host, flags cleared for the next primitive
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags);
+  const unsigned long long seq = ++p->publish_seq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, seq);
+  if (p->spin_wait) {
+    // the solver owns this host thread anyway: poll the sequence number k_publish writes last (a few hundred ns per poll of
+    // pinned memory) rather than sleep in hipStreamSynchronize and pay its wake-up latency once per iteration
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->h_scal) + 63;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *flag != seq; ++spins) {
+      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        HIPCHK(hipStreamSynchronize(p->stream));  // something is wrong or very slow: let the runtime report it
+        if (*flag != seq) return fail(CBA_ERR_HIP, "k_publish did not complete");
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return CBA_OK;
+  }
   HIPCHK(hipStreamSynchronize(p->stream));
   return CBA_OK;
 }
@@ -825,6 +844,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
   HIPCHK(hipHostGetDevicePointer((void**)&p->d_hflags, p->h_flags, 0));
+  std::memset(p->h_scal, 0, 64 * sizeof(double));
+  if (const char* sp = std::getenv("CBA_SPIN")) p->spin_wait = sp[0] != '0';
 
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;
