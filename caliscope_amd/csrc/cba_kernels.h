@@ -142,7 +142,9 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
 // dependent loads per thread stays short (512 rows: 16 loads deep); partial sums meet in LDS in a fixed order.
 constexpr int REDUCE_RY = 16;
 __global__ void __launch_bounds__(64 * REDUCE_RY)
-k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out) {
+k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out,
+              double* __restrict__ grad_out = nullptr, const int* __restrict__ cam_off = nullptr, const int* __restrict__ cam_np = nullptr,
+              int stride = 1, int tri = 0) {
   __shared__ double sh[REDUCE_RY][64];
   const int j = blockIdx.x * 64 + threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -161,6 +163,10 @@ k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* _
 #pragma unroll
     for (int y = 0; y < REDUCE_RY; ++y) tot += sh[y][threadIdx.x];
     out[j] = tot;
+    if (grad_out) {  // packed camera blocks: the gradient entries go to the vector as well (k_unpack_camera_grad, single-rank solves)
+      const int c = j / stride, r = j % stride - tri;
+      if (r >= 0 && r < cam_np[c]) grad_out[cam_off[c] + r] = tot;
+    }
   }
 }
 // Sharded solves: every host-visible primitive ends with ONE all-reduce of the scalars it produced.  k_xpack gathers
@@ -1617,7 +1623,14 @@ k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const
 // ---- fused iteration (cba_step): the two scalar decisions of an iteration made on the device, so that one iteration
 // needs one host synchronisation instead of three.  scal slots: 0 gh_sq, 1 |x D|^2, 12 |J_h g_h|^2, 16 p_sq, 17 <g_h,p>,
 // 20 w_sq; outputs 40 lam, 41 radius, 42 need_host, 43/44 p_S, 45 predicted, 46 alpha, 47 beta.  fz: [0] lam, [2] alpha, [3] beta.
-__global__ void k_fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) {
+__device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz);
+__device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz);
+__global__ void k_fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) { fused_lam(scal, radius_in, fz); }
+__global__ void k_fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
+  fused_subspace(scal, flags, fz);
+}
+
+__device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) {
   const double gh_sq = scal[0], jg_sq = scal[12], xs = sqrt(scal[1]);
   const double radius = radius_in > 0.0 ? radius_in : (xs > 0.0 ? xs : 1.0);  // first iteration: Delta = ||x0 * scale_inv||
   const double lam = -trf::min_quadratic_on_segment(0.5 * jg_sq, -gh_sq, radius / sqrt(gh_sq)) / (radius * radius);
@@ -1625,7 +1638,7 @@ __global__ void k_fused_lam(double* __restrict__ scal, double radius_in, double*
   scal[40] = lam; scal[41] = radius;
 }
 
-__global__ void k_fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
+__device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
   const double gh_sq = scal[0], jg_sq = scal[12], p_sq = scal[16], ghp = scal[17];
   const double lam = fz[0], radius = fz[1], gh_norm = sqrt(gh_sq);
   const double c = ghp / gh_sq;
@@ -1653,11 +1666,109 @@ __global__ void k_fused_subspace(double* __restrict__ scal, const int* __restric
   scal[42] = need_host; scal[43] = pS[0]; scal[44] = pS[1]; scal[45] = predicted; scal[46] = alpha; scal[47] = beta;
 }
 
+// ---- single-rank fused iterations: fewer, fatter launches (a small problem is bound by launch latency: cfg2 runs
+// ~40 kernels of a few microseconds per iteration).  Same arithmetic and summation order as the separate kernels.
+
+// k_scale_update + k_lin_scalars in one pass over the vector
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk, const int* __restrict__ param_cam,
+            const int* __restrict__ param_loc, VecLayout lay, int first, double* __restrict__ sinv, const double* __restrict__ cdiag,
+            const double* __restrict__ x, const double* __restrict__ g, double* __restrict__ v1, double* __restrict__ partial,
+            double* __restrict__ partial_max) {
+  using UP = UPack<NC>;
+  __shared__ double sh_red[BLOCK / WAVE];
+  const long total = lay.total();
+  double s0 = 0, s1 = 0, s2 = 0, m = 0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+    double si = sinv[i];
+    bool live = true;
+    double v = 0.0;
+    if (i < lay.ncp_pad) {
+      if (i >= lay.ncp) live = false;  // padding keeps scale 1
+      else { const int r = param_loc[i]; v = Upacked[param_cam[i] * UP::STRIDE + UP::idx(r, r)]; }
+    } else {
+      const long k = (i - lay.ncp_pad) / lay.Ppad, p = (i - lay.ncp_pad) % lay.Ppad;
+      if (p >= lay.P) live = false;
+      else {
+        const int q = (k == 0) ? 0 : (k == 1 ? 3 : 5);
+        v = Vblk[(long)q * lay.Ppad + p];
+        if (cdiag) v += cdiag[k * lay.Ppad + p];
+      }
+    }
+    if (live) {
+      v = sqrt(v);
+      if (first) { if (v == 0.0) v = 1.0; } else v = fmax(v, si);
+      si = v;
+      sinv[i] = si;
+    }
+    const double gi = g[i], xi = x[i];
+    const double gh = gi / si;
+    v1[i] = gh / si;
+    m = fmax(m, fabs(gi));
+    s0 += gh * gh;
+    s1 += (xi * si) * (xi * si);
+    s2 += xi * xi;
+  }
+  double r;
+  r = block_sum(s0, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
+  r = block_sum(s1, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
+  r = block_sum(s2, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = r;
+  if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = 0.0;
+  r = block_max(m, sh_red); if (threadIdx.x == 0) partial_max[blockIdx.x] = r;
+}
+
+__device__ __forceinline__ double column_sum(const double* __restrict__ partial, int nrow, int width, int col, double* sh) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nrow; b += BLOCK) s += partial[(long)b * width + col];
+  return block_sum(s, sh);
+}
+
+// the three reductions of the linearisation (sums, max |g|, ||J v||^2) and the damping in one launch
+__global__ void __launch_bounds__(BLOCK)
+k_lin_finish(const double* __restrict__ partial_lin, const double* __restrict__ partial_max, int rows_lin,
+             const double* __restrict__ partial_jv, int rows_jv, double radius, double* __restrict__ scal, double* __restrict__ fz) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  for (int j = 0; j < 4; ++j) {
+    const double r = column_sum(partial_lin, rows_lin, 4, j, sh_red);
+    if (threadIdx.x == 0) scal[j] = r;
+  }
+  {
+    double m = 0.0;
+    for (int b = threadIdx.x; b < rows_lin; b += BLOCK) m = fmax(m, partial_max[b]);
+    const double r = block_max(m, sh_red);
+    if (threadIdx.x == 0) scal[4] = r;
+  }
+  for (int j = 0; j < 4; ++j) {
+    const double r = column_sum(partial_jv, rows_jv, 4, j, sh_red);
+    if (threadIdx.x == 0) scal[12 + j] = r;
+  }
+  if (threadIdx.x == 0) fused_lam(scal, radius, fz);  // thread 0 wrote every slot it reads
+}
+
+// reduction of the step scalars and the subspace step in one launch
+__global__ void __launch_bounds__(BLOCK)
+k_step_finish(const double* __restrict__ partial, int rows, double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
+  __shared__ double sh_red[BLOCK / WAVE];
+  for (int j = 0; j < 4; ++j) {
+    const double r = column_sum(partial, rows, 4, j, sh_red);
+    if (threadIdx.x == 0) scal[16 + j] = r;
+  }
+  if (threadIdx.x == 0) fused_subspace(scal, flags, fz);
+}
+
 // End of a primitive: the host-visible scalars and flags go straight to pinned host memory (mapped into the device's
 // address space) — no copy-engine round trip — and the flags are cleared for the next primitive.
-__global__ void k_publish(const double* __restrict__ scal, int n_scal, int* __restrict__ flags, double* __restrict__ host_scal,
-                          int* __restrict__ host_flags, unsigned long long seq) {
+__global__ void __launch_bounds__(BLOCK)
+k_publish(double* __restrict__ scal, int n_scal, int* __restrict__ flags, double* __restrict__ host_scal,
+          int* __restrict__ host_flags, unsigned long long seq, const double* __restrict__ part_a, int rows_a, int slot_a,
+          const double* __restrict__ part_b, int rows_b, int slot_b) {
+  __shared__ double sh_red[BLOCK / WAVE];
   const int t = threadIdx.x;
+  // single-rank fused step: the last two per-workgroup partial columns (trial cost, step norm) are summed here
+  if (part_a) { const double r = column_sum(part_a, rows_a, 1, 0, sh_red); if (t == 0) scal[slot_a] = r; }
+  if (part_b) { const double r = column_sum(part_b, rows_b, 1, 0, sh_red); if (t == 0) scal[slot_b] = r; }
+  __syncthreads();
   if (t < n_scal) host_scal[t] = scal[t];
   if (t < 4) { host_flags[t] = flags[t]; flags[t] = 0; }
   // the sequence number goes last: the host spins on it instead of sleeping in hipStreamSynchronize (host_scal[63])

@@ -92,7 +92,7 @@ struct cba_problem {
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
   bool cam_scaled = false, cam_state_saved = false;
   // fused iteration (cba_step): device scalars [lam, radius, alpha, beta], second set of build outputs for the trial point
-  double *fz = nullptr, *V2 = nullptr, *g2 = nullptr, *U2 = nullptr;
+  double *fz = nullptr, *V2 = nullptr, *g2 = nullptr, *U2 = nullptr, *partial4b = nullptr;
   bool peer_needs_primitives = false;  // sharded solves: some rank cannot run cba_step, so none does
   bool have_build = false;   // V, g, Upacked are valid at the current x (a trial built by cba_step was accepted)
   bool trial_built = false;  // the pending trial point carries its own build in V2, g2, U2
@@ -181,10 +181,13 @@ static void drain_timers(cba_problem* p) {
   }
 }
 
-static int sync_scalars(cba_problem* p, int n_scal) {
+// part_a / part_b: per-workgroup partial columns whose sums belong to scal[slot_a] / scal[slot_b] (compact fused step)
+static int sync_scalars(cba_problem* p, int n_scal, const double* part_a = nullptr, int rows_a = 0, int slot_a = 0,
+                        const double* part_b = nullptr, int rows_b = 0, int slot_b = 0) {
   // every primitive ends here: scalars and flags to the host, flags cleared for the next primitive
   const unsigned long long seq = ++p->publish_seq;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, seq);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, seq, part_a, rows_a,
+                     slot_a, part_b, rows_b, slot_b);
   if (p->spin_wait) {
     // the solver owns this host thread anyway: poll the sequence number k_publish writes last (a few hundred ns per poll of
     // pinned memory) rather than sleep in hipStreamSynchronize and pay its wake-up latency once per iteration
@@ -908,7 +911,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
-  TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048));  // obs rows + constraint rows
+  TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   if (p->schur_reg) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
@@ -1016,7 +1019,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
 // Build pass at xvec (camera table tab) into the given outputs; the rho sum lands in scal[cost_slot].
 template <int NC>
 static int run_build_into(cba_problem* p, const double* xvec, const double* tab, double* V, double* g, double* Upacked, int cost_slot,
-                          const double* skip = nullptr, bool defer_exchange = false) {
+                          const double* skip = nullptr, bool defer_exchange = false, bool compact = false) {
   {
     ScopedTimer t(p, T_BUILD);
     if (p->n_heavy)  // fragments of heavy points add their sums by atomics
@@ -1029,7 +1032,13 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
     const int w = p->C * UPack<NC>::STRIDE;
-    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, Upacked);
+    if (compact) {  // single-rank fused step: gradient entries written by the row reduction, rho sum by k_publish
+      hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, Upacked, g,
+                         (const int*)p->cam_off, (const int*)p->cam_np, (int)UPack<NC>::STRIDE, (int)UPack<NC>::TRI);
+      return CBA_OK;
+    }
+    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, Upacked,
+                       (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
     int rho_rows = p->grid;
     if (p->con.n_con) {  // constraint rows: f, u, their share of g_p and of the squared column norms
       HIPCHK(hipMemsetAsync(p->con.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double), p->stream));
@@ -1051,7 +1060,7 @@ template <int NC>
 static int run_build(cba_problem* p) { return run_build_into<NC>(p, p->x, p->tab, p->V, p->g, p->Upacked, 8); }
 
 template <int NC>
-static int run_jv(cba_problem* p, int nv) {
+static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr) {
   ScopedTimer t(p, T_JV);
   const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
   if (nv == 1)
@@ -1066,6 +1075,7 @@ static int run_jv(cba_problem* p, int nv) {
     else hipLaunchKernelGGL(k_con_jv<2>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, p->lay, p->v1, p->v2, p->partial4 + 4 * grid);
     rows += p->con_grid;
   }
+  if (rows_out) { *rows_out = rows; return CBA_OK; }  // compact fused step: k_lin_finish sums the rows
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, rows, 4, p->scal + 12);
   return CBA_OK;  // scal[12..15] are summed over the ranks by the caller's exchange()
 }
@@ -1073,7 +1083,7 @@ static int run_jv(cba_problem* p, int nv) {
 // device part of the linearisation (no host synchronisation): build unless the accepted trial brought its own, Jacobi
 // scale, scalars, ||J_h g_h||^2, the scalar exchange of a sharded solve
 template <int NC>
-static int run_lin_chain(cba_problem* p, bool scalars = true) {
+static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = false, double radius = 0.0) {
   if (!p->have_build) {
     int rcb = run_build<NC>(p);
     if (rcb) return rcb;
@@ -1087,6 +1097,18 @@ static int run_lin_chain(cba_problem* p, bool scalars = true) {
   p->cam_state_saved = false;
   {
     ScopedTimer t(p, T_SCALE_SCALARS);
+    if (compact) {
+      // single-rank fused step: scale + scalars in one vector pass, the three reductions and the damping in one launch
+      hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc, p->lay,
+                         p->first_scale ? 1 : 0, p->sinv, (const double*)nullptr, p->x, p->g, p->v1, p->partial4b, p->partial1);
+      p->first_scale = false;
+      int rows_jv = 0;
+      int rcj = run_jv<NC>(p, 1, &rows_jv);
+      if (rcj) return rcj;
+      hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vg, p->partial4, rows_jv, radius,
+                         p->scal, p->fz);
+      return CBA_OK;
+    }
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
                        p->lay, p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr);
     p->first_scale = false;
@@ -1175,12 +1197,16 @@ static int run_cholesky(cba_problem* p) {
 // scalars of the damped step s: ||p||^2 and <g_h, p> (scal[16], [17]) and ||w||^2, w = p - (<g_h,p> / ||g_h||^2) g_h (scal[20]).
 // formula_w: the fused step derives ||w||^2 from the first two on the device (k_fused_subspace) and spends one
 // collective; otherwise it is measured by a pass of its own, which stays accurate when w is tiny against p.
-static int run_step_scalars(cba_problem* p, bool formula_w) {
+static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false) {
   ScopedTimer t(p, T_VECTOR);
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   const long first = (p->rank == 0) ? 0 : p->lay.ncp_pad;  // replicated camera entries are counted on rank 0 only
   hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->partial4);
+  if (compact) {  // single-rank fused step: the reduction and the subspace step in one launch
+    hipLaunchKernelGGL(k_step_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, p->scal, (const int*)p->flags, p->fz);
+    return CBA_OK;
+  }
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 4, p->scal + 16);
   if (formula_w) return exchange(p, SLOT(16) | SLOT(17), false);
   int rcv = allreduce_sum(p, p->scal + 16, 2);
@@ -1193,7 +1219,7 @@ static int run_step_scalars(cba_problem* p, bool formula_w) {
 
 // device part of the damped step; lam_dev != nullptr: the damping is read from device memory (fused step)
 template <int NC>
-static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev) {
+static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, bool compact = false) {
   const int ncp = p->ncp;
   {
     ScopedTimer t(p, T_SCHUR);
@@ -1202,7 +1228,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev) {
                          p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, lam_dev, p->V, p->g,
                          p->sinv, p->Trec, p->partial_b, p->flags);
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
-                         p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
+                         p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       hipLaunchKernelGGL((k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
                          lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
     }
@@ -1251,7 +1277,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev) {
     if (p->con.n_con)
       hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
   }
-  return run_step_scalars(p, lam_dev != nullptr);
+  return run_step_scalars(p, lam_dev != nullptr, compact);
 }
 
 static void read_newton(cba_problem* p, cba_newton_info* out) {
@@ -1278,28 +1304,35 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
 // point evaluated by a full build pass into the second set of buffers, so that accepting it costs nothing more.
 template <int NC>
 static int run_step(cba_problem* p, double radius, cba_step_info* out) {
-  int rc = run_lin_chain<NC>(p);
+  // single rank: no exchange steps in between, so neighbouring small kernels are folded together (k_scale_lin, k_lin_finish,
+  // k_step_finish, gradient written by k_reduce_rows, last sums taken by k_publish): 8 launches fewer per iteration
+  const bool compact = p->comm == nullptr;
+  int rc = run_lin_chain<NC>(p, true, compact, radius);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_fused_lam, dim3(1), dim3(1), 0, p->stream, p->scal, radius, p->fz);
-  rc = run_newton_chain<NC>(p, 0.0, p->fz);
+  if (!compact) hipLaunchKernelGGL(k_fused_lam, dim3(1), dim3(1), 0, p->stream, p->scal, radius, p->fz);
+  rc = run_newton_chain<NC>(p, 0.0, p->fz, compact);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_fused_subspace, dim3(1), dim3(1), 0, p->stream, p->scal, p->flags, p->fz);
+  if (!compact) hipLaunchKernelGGL(k_fused_subspace, dim3(1), dim3(1), 0, p->stream, p->scal, p->flags, p->fz);
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   {
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, 0.0, 0.0, tot, p->lay.ncp_pad,
                        p->rank == 0 ? 1 : 0, (const double*)nullptr, 0, (const double*)(p->fz + 2), p->x_new, p->partial4);
-    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
+    if (!compact) hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
-  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true);  // skipped when need_host
+  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact);  // skipped when need_host
   if (rc) return rc;
-  // one collective for the trial's camera blocks, its cost, the step norm and the flags
-  rc = exchange_at(p, SLOT(24) | SLOT(28), false, p->U2, (size_t)p->C * UPack<NC>::STRIDE);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->U2, p->cam_off, p->cam_np, p->C, p->g2);
-  rc = sync_scalars(p, 48);
+  if (compact) {
+    rc = sync_scalars(p, 48, p->partial1, p->grid, 24, p->partial4, vg, 28);
+  } else {
+    // one collective for the trial's camera blocks, its cost, the step norm and the flags
+    rc = exchange_at(p, SLOT(24) | SLOT(28), false, p->U2, (size_t)p->C * UPack<NC>::STRIDE);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_unpack_camera_grad<NC>), dim3((p->C * NC + 255) / 256), dim3(256), 0, p->stream, p->U2, p->cam_off, p->cam_np, p->C, p->g2);
+    rc = sync_scalars(p, 48);
+  }
   if (rc) return rc;
   const int bad_residual = p->h_flags[0];
   read_linearization(p, &out->lin);
