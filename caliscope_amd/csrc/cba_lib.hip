@@ -993,7 +993,7 @@ static int launch_cam_prep(cba_problem* p, const double* xvec, double* tab) {
 }
 
 // cost at (xvec, tab) -> scal[slot]; flags[0] set when a residual is not finite
-static int launch_cost(cba_problem* p, const double* xvec, const double* tab, int slot, double* r_out) {
+static int launch_cost(cba_problem* p, const double* xvec, const double* tab, int slot, double* r_out, int* rows_out = nullptr) {
   const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
   {
     ScopedTimer t(p, T_COST);
@@ -1012,6 +1012,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
                        (double*)nullptr, p->partial1 + grid, p->flags, r_out ? r_out + 2 * p->N : (double*)nullptr);
     rows += p->con_grid;
   }
+  if (rows_out) { *rows_out = rows; return CBA_OK; }  // single rank: k_publish sums the rows
   hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, rows, 1, p->scal + slot);
   return CBA_OK;  // sharded solves: the caller's exchange() sums scal[slot] and the flags over the ranks
 }
@@ -1100,7 +1101,8 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
     if (compact) {
       // single-rank fused step: scale + scalars in one vector pass, the three reductions and the damping in one launch
       hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc, p->lay,
-                         p->first_scale ? 1 : 0, p->sinv, (const double*)nullptr, p->x, p->g, p->v1, p->partial4b, p->partial1);
+                         p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr, p->x, p->g, p->v1,
+                         p->partial4b, p->partial1);
       p->first_scale = false;
       int rows_jv = 0;
       int rcj = run_jv<NC>(p, 1, &rows_jv);
@@ -1139,7 +1141,7 @@ static void read_linearization(cba_problem* p, cba_linearization* out) {
 
 template <int NC>
 static int run_linearize(cba_problem* p, cba_linearization* out) {
-  int rc = run_lin_chain<NC>(p);
+  int rc = run_lin_chain<NC>(p, true, p->comm == nullptr, 1.0);  // single rank: folded launches (the damping k_lin_finish derives is not used here)
   if (rc) return rc;
   rc = sync_scalars(p, 16);
   if (rc) return rc;
@@ -1628,15 +1630,23 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
   {
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
-                       p->rank == 0 ? 1 : 0, (const double*)p->cam_over1, cam_x_new ? p->ncp : 0, (const double*)nullptr, p->x_new, p->partial1);
-    hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial1, vg, 1, p->scal + 28);
+                       p->rank == 0 ? 1 : 0, (const double*)p->cam_over1, cam_x_new ? p->ncp : 0, (const double*)nullptr, p->x_new, p->partial4);
+    if (p->comm) hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
-  int rc = launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
-  if (rc) return rc;
-  rc = exchange(p, SLOT(24) | SLOT(28), false);  // trial cost, ||step||^2, flags
-  if (rc) return rc;
-  rc = sync_scalars(p, 32);
+  int rc;
+  if (p->comm) {
+    rc = launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
+    if (rc) return rc;
+    rc = exchange(p, SLOT(24) | SLOT(28), false);  // trial cost, ||step||^2, flags
+    if (rc) return rc;
+    rc = sync_scalars(p, 32);
+  } else {  // single rank: the cost rows and the step-norm rows are summed by k_publish
+    int cost_rows = 0;
+    rc = launch_cost(p, p->x_new, p->tab_new, 24, nullptr, &cost_rows);
+    if (rc) return rc;
+    rc = sync_scalars(p, 32, p->partial1, cost_rows, 24, p->partial4, vg, 28);
+  }
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   const double c = 0.5 * p->h_scal[24];
