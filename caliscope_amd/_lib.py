@@ -123,6 +123,7 @@ SIGNATURES = {
     "cba_solve": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(SolveOptions), c_double_p, C.POINTER(Result)]),
     "cba_get_vector": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "cba_get_camera_params": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    "cba_get_camera_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "cba_residuals": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "cba_normal_blocks": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "cba_reduced_system": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),

@@ -1777,6 +1777,19 @@ k_publish(double* __restrict__ scal, int n_scal, int* __restrict__ flags, double
   if (t == 0) reinterpret_cast<volatile unsigned long long*>(host_scal)[63] = seq;
 }
 
+// camera blocks of up to three device vectors to mapped host memory, sequence number last (as k_publish)
+__global__ void k_publish_cam(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c, int ncp,
+                              double* __restrict__ host, unsigned long long* __restrict__ host_seq, unsigned long long seq) {
+  for (int i = threadIdx.x; i < ncp; i += blockDim.x) {
+    host[i] = a[i];
+    if (b) host[ncp + i] = b[i];
+    if (c) host[2 * ncp + i] = c[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq;
+}
+
 __global__ void k_fill(double* __restrict__ p, double v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }

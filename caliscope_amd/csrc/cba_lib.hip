@@ -107,6 +107,7 @@ struct cba_problem {
   double* h_scal = nullptr;  // pinned, mapped: k_publish writes it (d_hscal is the same memory seen from the device)
   int* h_flags = nullptr;
   double* d_hscal = nullptr;
+  double *h_cam = nullptr, *d_hcam = nullptr;  // pinned, mapped: camera blocks of up to three vectors + a sequence word
   unsigned long long publish_seq = 0;
   bool spin_wait = true;  // CBA_SPIN=0: sleep in hipStreamSynchronize instead
   int* d_hflags = nullptr;
@@ -355,6 +356,7 @@ void cba_destroy(cba_problem* p) {
   for (void* a : p->allocs) (void)hipFree(a);
   if (p->h_scal) (void)hipHostFree(p->h_scal);
   if (p->h_flags) (void)hipHostFree(p->h_flags);
+  if (p->h_cam) (void)hipHostFree(p->h_cam);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -848,6 +850,9 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
   HIPCHK(hipHostGetDevicePointer((void**)&p->d_hflags, p->h_flags, 0));
   std::memset(p->h_scal, 0, 64 * sizeof(double));
+  HIPCHK(hipHostMalloc((void**)&p->h_cam, ((size_t)3 * ncp + 8) * sizeof(double), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&p->d_hcam, p->h_cam, 0));
+  std::memset(p->h_cam, 0, ((size_t)3 * ncp + 8) * sizeof(double));
   if (const char* sp = std::getenv("CBA_SPIN")) p->spin_wait = sp[0] != '0';
 
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1711,6 +1716,31 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
   return CBA_OK;
 }
 
+// camera blocks (first n_cam_params entries) of up to three device vectors in one kernel and one wait
+static int fetch_camera_blocks(cba_problem* p, const double* const* srcs, double* const* outs) {
+  const int ncp = p->ncp;
+  unsigned long long* hseq = reinterpret_cast<unsigned long long*>(p->h_cam + (size_t)3 * ncp);
+  unsigned long long* dseq = reinterpret_cast<unsigned long long*>(p->d_hcam + (size_t)3 * ncp);
+  const unsigned long long seq = ++p->publish_seq;
+  hipLaunchKernelGGL(k_publish_cam, dim3(1), dim3(BLOCK), 0, p->stream, srcs[0], srcs[1], srcs[2], ncp, p->d_hcam, dseq, seq);
+  if (p->spin_wait) {
+    volatile unsigned long long* flag = hseq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *flag != seq; ++spins)
+      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        HIPCHK(hipStreamSynchronize(p->stream));
+        if (*flag != seq) return fail(CBA_ERR_HIP, "k_publish_cam did not complete");
+        break;
+      }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    HIPCHK(hipStreamSynchronize(p->stream));
+  }
+  for (int v = 0; v < 3; ++v)
+    if (outs[v]) std::memcpy(outs[v], p->h_cam + (size_t)v * ncp, (size_t)ncp * sizeof(double));
+  return CBA_OK;
+}
+
 int cba_get_vector(cba_problem* p, int32_t which, double* out) {
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_vector: null argument");
   HIPCHK(hipSetDevice(p->device));
@@ -1741,9 +1771,17 @@ int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
     case CBA_VEC_SCALE_INV: src = p->sinv; break;
     default: return fail(CBA_ERR_INVALID, "cba_get_camera_params: unknown vector %d", which);
   }
-  HIPCHK(hipMemcpyAsync(out, src, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
-  return CBA_OK;
+  const double* srcs[3] = {src, nullptr, nullptr};
+  double* outs[3] = {out, nullptr, nullptr};
+  return fetch_camera_blocks(p, srcs, outs);
+}
+
+int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale_inv_c) {
+  if (!p || !x_c || !g_c || !scale_inv_c) return fail(CBA_ERR_INVALID, "cba_get_camera_state: null argument");
+  HIPCHK(hipSetDevice(p->device));
+  const double* srcs[3] = {p->x, p->g, p->sinv};
+  double* outs[3] = {x_c, g_c, scale_inv_c};
+  return fetch_camera_blocks(p, srcs, outs);
 }
 
 int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out) {

@@ -143,9 +143,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     }
     if (bounded) {
       // Coleman-Li scaling vector of the camera block (common.py CL_scaling_vector) and what follows from it
-      if ((rc = cba_get_camera_params(p, CBA_VEC_X, cb.x.data()))) return rc;
-      if ((rc = cba_get_camera_params(p, CBA_VEC_GRAD, cb.g.data()))) return rc;
-      if ((rc = cba_get_camera_params(p, CBA_VEC_SCALE_INV, cb.sinv.data()))) return rc;  // Jacobi scale (cba_linearize restored it)
+      if ((rc = cba_get_camera_state(p, cb.x.data(), cb.g.data(), cb.sinv.data()))) return rc;  // sinv: the Jacobi scale (restored by the linearisation)
       double gv_max = 0.0;
       for (int i = 0; i < ncp; ++i) {
         double v = 1.0, dv = 0.0;

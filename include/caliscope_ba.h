@@ -232,6 +232,10 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out);
  * used by the host to test trial points against the intrinsic bounds. */
 int cba_get_camera_params(cba_problem* p, int32_t which, double* out);
 
+/* The camera blocks of x, g and scale_inv in one call (what the Coleman-Li scaling of a bounded solve reads after every
+ * linearisation); each [n_cam_params]. */
+int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale_inv_c);
+
 /* joint_residuals(x) in the caller's observation order, interleaved (x0,y0,x1,y1,...) [2N], followed by the
  * constraint rows [n_con] when cba_set_constraints was called, and the (robust) cost.  The linearisation and the damped
  * step stay valid; a pending trial point (cba_trial without cba_accept) is discarded. */

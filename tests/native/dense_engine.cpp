@@ -235,6 +235,12 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out) {
   std::memcpy(out, vec_of(p, which).data(), sizeof(double) * p->n);
   return CBA_OK;
 }
+int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* sinv_c) {
+  std::memcpy(x_c, p->x.data(), sizeof(double) * p->ncp);
+  std::memcpy(g_c, p->g.data(), sizeof(double) * p->ncp);
+  std::memcpy(sinv_c, p->sinv.data(), sizeof(double) * p->ncp);
+  return CBA_OK;
+}
 int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
   std::memcpy(out, vec_of(p, which).data(), sizeof(double) * p->ncp);
   return CBA_OK;
