@@ -15,9 +15,12 @@ HIP kernels implement; they are never invoked).  INTEGRATION.md shows the one-li
 
 Semantics kept from scipy 1.15.3: cost definition, robust losses, ``x_scale='jac'``, termination codes,
 ``nfev`` accounting, ``max_nfev=None -> 100 n``, ``ValueError`` for bad options, infeasible ``x0`` or
-non-finite initial residuals.  Differences: the regularised Gauss-Newton step is exact
-(Schur complement) instead of LSMR at 1e-6; finite bounds (free intrinsics) are enforced as a feasibility
-filter on trial points rather than by reflective steps.
+non-finite initial residuals, constraint rows (the four trailing ``args``), finite bounds through scipy's
+bounded variant (Coleman-Li scaling, reflective steps).  Difference: the regularised
+Gauss-Newton step is exact (Schur complement) instead of LSMR at 1e-6.  The loop itself runs in the library
+(``cba_solve``); ``engine_factory`` / ``CBA_HOST_LOOP=python`` select the Python driver of
+:mod:`caliscope_amd.trf` on the engine primitives (the CPU tests plug the numpy engine in that way; that driver
+only guards bounds by rejecting infeasible trial points).
 """
 
 from __future__ import annotations

@@ -1,4 +1,7 @@
-"""Trust-region driver of the MI355X bundle-adjustment solver (host side, scalars only).
+"""Trust-region driver of the MI355X bundle-adjustment solver (host side, scalars only) — the Python twin of
+``csrc/cba_solve.cpp``, which is what the product runs (one C call per solve, fused iterations, scipy's bounded
+variant).  This module drives any :class:`~caliscope_amd.engine.BAEngine` through the primitives: the numpy engine of
+the CPU tests, or the device engine with ``CBA_HOST_LOOP=python``.
 
 The reference hands the problem to ``scipy.optimize.least_squares(method="trf",
 x_scale="jac", jac=<sparse>)`` (``core/capture_volume.py:387-411``), i.e. scipy's Trust-Region-
