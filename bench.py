@@ -194,6 +194,11 @@ def roofline_from(m):
                 "repeat of the timed steps; traffic from profiles/pmc_*.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, "
                 "summed over the kernels of the pass)",
         "avg_launch_us": round(avg_s * 1e6, 2), "kernels": table,
+        # the co-bound SURVEY.md 8(d) names: FP64 vector rate of the pair products T_i T_j^T (2 * 3 nc^2 flop per pair) over the
+        # duration of the Schur pass, against the 78.6 TFLOP/s FP64 vector peak
+        "fp64_valu": (lambda fl, t: {"flops_per_launch": fl, "achieved_tflops": round(fl / t / 1e12, 2), "peak_tflops": 78.6,
+                                     "frac": round(fl / t / 1e12 / 78.6, 4)})(
+            int(m["info"]["schur_pairs"]) * 6 * m["nct"] ** 2, tm["schur"][0] / tm["schur"][1] * 1e-3) if "schur" in tm and tm["schur"][1] else None,
         # B_alg = 72 N + 312 P + 8 (nc C)^2 bytes per accepted LM iteration, over the measured step time
         "iteration": (lambda b, t: {"alg_bytes": b, "GBps": round(b / t / 1e9, 1), "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4)})(
             72 * m["n_obs"] + 312 * m["n_points"] + 8 * m["ncp"] ** 2, m["elapsed"] / max(m["steps"], 1)),
