@@ -324,11 +324,12 @@ class CaptureVolume:
             raise ValueError("No matched observations for reprojection error calculation")
         err = self._pixel_errors(camera_indices, image_coords, obj_indices, _engine_factory)
         sq = np.sum(err * err, axis=1)
-        df = self.image_points._df[mask]
+        all_df = self.image_points._df
+        # columns as arrays: a boolean-indexed DataFrame copy of 2M rows costs more than everything else in this function
+        col = {c: all_df[c].to_numpy()[mask] for c in ("sync_index", "cam_id", "object_id", "keypoint_id")}
         raw = pd.DataFrame(
             {
-                "sync_index": df["sync_index"].to_numpy(), "cam_id": df["cam_id"].to_numpy(),
-                "object_id": df["object_id"].to_numpy(), "keypoint_id": df["keypoint_id"].to_numpy(),
+                "sync_index": col["sync_index"], "cam_id": col["cam_id"], "object_id": col["object_id"], "keypoint_id": col["keypoint_id"],
                 "error_x": err[:, 0], "error_y": err[:, 1], "euclidean_error": np.sqrt(sq),
             }
         )
@@ -339,11 +340,16 @@ class CaptureVolume:
         by_camera = {cid: 0.0 for cid in self.camera_array.posed_cameras}
         for cid, i in index_of.items():
             by_camera[cid] = float(np.sqrt(cam_sum[i] / cam_cnt[i])) if cam_cnt[i] else 0.0
-        grp = raw.assign(sq=sq).groupby(["object_id", "keypoint_id"])["sq"].mean()
-        by_point = {(int(o), int(k)): float(np.sqrt(v)) for (o, k), v in grp.items()}
-        all_df = self.image_points._df
-        total_by_cam = all_df["cam_id"].value_counts()
-        matched_by_cam = df["cam_id"].value_counts()
+        # RMS per (object_id, keypoint_id): one integer key, unique + bincount instead of a pandas group-by
+        obj_id, kp_id = col["object_id"].astype(np.int64), col["keypoint_id"].astype(np.int64)
+        kp_lo = int(kp_id.min()) if kp_id.size else 0
+        span = int(kp_id.max()) - kp_lo + 1 if kp_id.size else 1
+        keys, inv = np.unique(obj_id * span + (kp_id - kp_lo), return_inverse=True)
+        mean_sq = np.bincount(inv, weights=sq, minlength=keys.size) / np.maximum(np.bincount(inv, minlength=keys.size), 1)
+        by_point = dict(zip(zip((keys // span).tolist(), (keys % span + kp_lo).tolist()), np.sqrt(mean_sq).tolist()))
+        cams_all, n_all = np.unique(all_df["cam_id"].to_numpy(), return_counts=True)
+        cams_ok, n_ok = np.unique(col["cam_id"], return_counts=True)
+        total_by_cam, matched_by_cam = dict(zip(cams_all.tolist(), n_all.tolist())), dict(zip(cams_ok.tolist(), n_ok.tolist()))
         unmatched_by_camera = {
             int(c): int(total_by_cam.get(c, 0) - matched_by_cam.get(c, 0)) for c in self.camera_array.cameras
         }
