@@ -38,7 +38,7 @@ class ProblemDesc(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("max_blocks", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("device_id", C.c_int32), ("max_blocks", C.c_int32), ("deterministic", C.c_int32), ("evaluation_only", C.c_int32)]
 
 
 class Linearization(C.Structure):

@@ -306,8 +306,9 @@ class CaptureVolume:
         if _engine_factory is None:
             from caliscope_amd.hip_engine import HipEngine
 
-            _engine_factory = HipEngine
-        eng = _engine_factory(problem)
+            eng = HipEngine(problem, evaluation_only=True)  # the report needs residuals only: no Schur plan
+        else:
+            eng = _engine_factory(problem)
         try:
             r, _ = eng.residuals(x)
         finally:

@@ -93,6 +93,7 @@ struct cba_problem {
   bool cam_scaled = false, cam_state_saved = false;
   // fused iteration (cba_step): device scalars [lam, radius, alpha, beta], second set of build outputs for the trial point
   double *fz = nullptr, *V2 = nullptr, *g2 = nullptr, *U2 = nullptr, *partial4b = nullptr;
+  bool eval_only = false;  // cba_options.evaluation_only: no Schur plan, no solver buffers (residual hook, begin / trial costs)
   bool peer_needs_primitives = false;  // sharded solves: some rank cannot run cba_step, so none does
   bool have_build = false;   // V, g, Upacked are valid at the current x (a trial built by cba_step was accepted)
   bool trial_built = false;  // the pending trial point carries its own build in V2, g2, U2
@@ -899,7 +900,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("allocate vectors");
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   lap("reorder, upload, allocate");
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  p->eval_only = opt && opt->evaluation_only != 0;
+  for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
     const size_t tile_lds = p->schur_reg ? ((nct == 9) ? lds_schur_reg<9>(p->gsz) : lds_schur_reg<6>(p->gsz))
                                          : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
@@ -918,7 +920,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
-  if (p->schur_reg) {
+  if (p->schur_reg && !p->eval_only) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
     TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * ((nct == 9) ? SchurRec<9>::REC : SchurRec<6>::REC)));
     TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
@@ -1370,7 +1372,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   if (p->con.n_con) return fail(CBA_ERR_INVALID, "cba_set_constraints: constraints are already set");
   if (n_con <= 0) return CBA_OK;
   if (!groups_a || !groups_b || !distances || !weights) return fail(CBA_ERR_INVALID, "cba_set_constraints: null array");
-  if (!p->schur_reg) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows need the T-record Schur path (CBA_SCHUR=lds is set, or a point exceeds the pair capacity)");
+  if (!p->schur_reg && !p->eval_only) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows need the T-record Schur path (CBA_SCHUR=lds is set, or a point exceeds the pair capacity)");
   HIPCHK(hipSetDevice(p->device));
   const int P = p->P;
   for (long e = 0; e < (long)n_con * 4; ++e)
@@ -1489,6 +1491,7 @@ static int begin_common(cba_problem* p, double* cost_out) {
 
 int cba_linearize(cba_problem* p, cba_linearization* out) {
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_linearize: null argument");
+  if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_linearize: the problem was created with evaluation_only");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize: call cba_begin first");
   HIPCHK(hipSetDevice(p->device));
   int rc = DISPATCH_NC(p, run_linearize<6>(p, out), run_linearize<9>(p, out));
@@ -1501,6 +1504,7 @@ int cba_linearize(cba_problem* p, cba_linearization* out) {
 int cba_linearize_build(cba_problem* p) {
   if (!p) return fail(CBA_ERR_INVALID, "cba_linearize_build: null argument");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize_build: call cba_begin first");
+  if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_linearize_build: the problem was created with evaluation_only");
   HIPCHK(hipSetDevice(p->device));
   int rc = DISPATCH_NC(p, run_lin_chain<6>(p, false), run_lin_chain<9>(p, false));
   if (rc) return rc;
@@ -1549,7 +1553,7 @@ int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
 }
 
 int cba_step_supported(cba_problem* p) {
-  return (p && p->schur_reg && !p->con.n_con && !p->n_heavy && !p->cam_scaled && !p->peer_needs_primitives) ? 1 : 0;
+  return (p && !p->eval_only && p->schur_reg && !p->con.n_con && !p->n_heavy && !p->cam_scaled && !p->peer_needs_primitives) ? 1 : 0;
 }
 
 // camera-block override of a device vector: `host` [ncp] -> dev [ncp_pad] (padding stays zero)
@@ -1812,6 +1816,7 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
 int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, double* gc, double* gp) {
   if (!p || !x) return fail(CBA_ERR_INVALID, "cba_normal_blocks: null argument");
   HIPCHK(hipSetDevice(p->device));
+  if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_normal_blocks: the problem was created with evaluation_only");
   // Runs the real build pass on x: swap it in as the current point, then restore.
   p->have_build = false;  // V, g, Upacked are overwritten below
   double cost;

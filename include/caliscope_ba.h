@@ -69,7 +69,8 @@ typedef struct {
   int32_t device_id;     /* HIP device ordinal; -1 = current device                                  */
   int32_t max_blocks;    /* 0 = default (4 workgroups per CU); upper bound on persistent grid size   */
   int32_t deterministic; /* reserved (reductions through per-workgroup partials are already ordered) */
-  int32_t reserved;
+  int32_t evaluation_only; /* 1: residuals / costs only (cba_residuals, cba_begin): the Schur plan and the solver's buffers are
+                              not built — the reprojection report needs no more */
 } cba_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
