@@ -6,11 +6,12 @@
  *         f_scale=..., ftol=..., max_nfev=..., method="trf", bounds=...)
  * at /root/reference/src/caliscope/core/capture_volume.py:387-411.  The entry points below are what a
  * ctypes binding for that seam needs: a problem object built from exactly the arrays that call
- * receives, the evaluation primitives of one trust-region iteration (the arithmetic of
- * core/reprojection.py:75-119 `joint_residuals` and :128-234 `joint_jacobian`, of scipy's
- * `scale_for_robust_loss_function`, `compute_grad`, `compute_jac_scale` and of the regularised
- * Gauss-Newton step that scipy gets from LSMR), and parity hooks that expose intermediate results.
- * The trust-region control flow itself stays on the host (caliscope_amd/trf.py) and sees scalars only.
+ * receives, cba_solve — that whole call as one entry point —, the evaluation primitives of one trust-region
+ * iteration it is built from (the arithmetic of core/reprojection.py:75-119 `joint_residuals` and :128-234
+ * `joint_jacobian`, of scipy's `scale_for_robust_loss_function`, `compute_grad`, `compute_jac_scale` and of the
+ * regularised Gauss-Newton step that scipy gets from LSMR), and parity hooks that expose intermediate results.
+ * The trust-region control flow runs on the host inside the library (csrc/cba_solve.cpp; caliscope_amd/trf.py is the
+ * same loop in Python on the primitives) and sees scalars only.
  *
  * Conventions
  *  - all pointers are caller-owned host memory, C-contiguous, valid for the duration of the call only;
