@@ -61,6 +61,24 @@ def compute_depth_ratios(capture_volume: CaptureVolume) -> dict[int, float]:
     return out
 
 
+def _intrinsic_estimates(capture_volume: CaptureVolume, anchors: dict) -> tuple:
+    out = []
+    for cam_id, cam in capture_volume.camera_array.posed_cameras.items():
+        if cam_id in anchors and cam.matrix is not None and cam.distortions is not None:
+            f0, k10, k20 = anchors[cam_id]
+            d = np.asarray(cam.distortions).ravel()
+            out.append(IntrinsicEstimate(cam_id, float(cam.matrix[0, 0]), float(d[0]), float(d[1]), f0, k10, k20))
+    return tuple(out)
+
+
+def refresh_run(previous: CalibrationRun, capture_volume: CaptureVolume) -> CalibrationRun:
+    """Rebuild the run around a re-optimised volume (reference :263-283): the initial anchors, synthesised cameras, dropped
+    markers and the gate flag are kept, the recovered intrinsics are read again."""
+    anchors = {e.cam_id: (e.f_initial, e.k1_initial, e.k2_initial) for e in previous.intrinsic_estimates}
+    return CalibrationRun(capture_volume, _intrinsic_estimates(capture_volume, anchors), previous.synthesized_cam_ids,
+                          previous.dropped_static_markers, previous.intrinsic_refinement_gated)
+
+
 def apply_static_marker_guard(capture_volume: CaptureVolume) -> tuple[CaptureVolume, tuple[int, ...]]:
     """Stage 4: a "static" marker that moved during the recording shows up as a non-rigid set of triangulated corners.
     Markers whose intra-marker rigidity RMSE exceeds 25 % of their largest corner distance are dropped: their
@@ -148,10 +166,4 @@ def refine_calibration(
     cv = cv.optimize(refine_intrinsics=effective, **kw)
 
     report(100, "Optimization complete")
-    estimates = []
-    for cam_id, cam in cv.camera_array.posed_cameras.items():
-        if cam_id in anchors and cam.matrix is not None and cam.distortions is not None:
-            f0, k10, k20 = anchors[cam_id]
-            d = np.asarray(cam.distortions).ravel()
-            estimates.append(IntrinsicEstimate(cam_id, float(cam.matrix[0, 0]), float(d[0]), float(d[1]), f0, k10, k20))
-    return CalibrationRun(cv, tuple(estimates), dropped_static_markers=dropped, intrinsic_refinement_gated=gated)
+    return CalibrationRun(cv, _intrinsic_estimates(cv, anchors), dropped_static_markers=dropped, intrinsic_refinement_gated=gated)

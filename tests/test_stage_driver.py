@@ -113,3 +113,19 @@ def test_static_marker_guard_drops_a_marker_that_moved():
     assert all(11 not in (d.object_id_a, d.object_id_b) for d in out.constraints.distances)
     assert out.constraints.centroid_distances == ()  # the 11 -> 12 centre link went with marker 11
     assert len(out._build_constraint_arrays()[2]) < len(moved._build_constraint_arrays()[2])
+
+
+def test_refresh_run_keeps_anchors_and_flags():
+    from caliscope_amd.bundle_parameterization import IntrinsicEstimate
+    from caliscope_amd.calibrate_extrinsics import CalibrationRun, refresh_run
+    from tests.constrained_scene import marker_volume
+
+    vol, _ = marker_volume(n_frames=3)
+    prev = CalibrationRun(vol, tuple(IntrinsicEstimate(c, 1.0, 0.0, 0.0, 1400.0 + c, 0.1, -0.2) for c in vol.camera_array.cameras),
+                          frozenset({2}), (11,), True)
+    run = refresh_run(prev, vol)
+    assert run.synthesized_cam_ids == frozenset({2}) and run.dropped_static_markers == (11,) and run.intrinsic_refinement_gated
+    for e in run.intrinsic_estimates:
+        cam = vol.camera_array.cameras[e.cam_id]
+        assert (e.f_initial, e.k1_initial, e.k2_initial) == (1400.0 + e.cam_id, 0.1, -0.2)
+        assert e.f_recovered == cam.matrix[0, 0] and e.k1_recovered == cam.distortions[0]
