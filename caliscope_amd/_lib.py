@@ -108,6 +108,7 @@ SIGNATURES = {
     "cba_set_constraints": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p]),
     "cba_begin": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cba_restart": (C.c_int, [C.c_void_p, c_double_p]),
+    "cba_begin_deferred": (C.c_int, [C.c_void_p, c_double_p]),
     "cba_linearize": (C.c_int, [C.c_void_p, C.POINTER(Linearization)]),
     "cba_newton_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(NewtonInfo)]),
     "cba_subspace_gram": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]),

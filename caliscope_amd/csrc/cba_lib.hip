@@ -1027,7 +1027,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
 // Build pass at xvec (camera table tab) into the given outputs; the rho sum lands in scal[cost_slot].
 template <int NC>
 static int run_build_into(cba_problem* p, const double* xvec, const double* tab, double* V, double* g, double* Upacked, int cost_slot,
-                          const double* skip = nullptr, bool defer_exchange = false, bool compact = false) {
+                          const double* skip = nullptr, bool defer_exchange = false, bool compact = false, int flag_slot = 0) {
   {
     ScopedTimer t(p, T_BUILD);
     if (p->n_heavy)  // fragments of heavy points add their sums by atomics
@@ -1035,7 +1035,7 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
                          g + p->lay.ncp_pad, 3);
     hipLaunchKernelGGL(k_build<NC>, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                        p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
-                       V, g, p->partial, p->partial1, p->flags, skip);
+                       V, g, p->partial, p->partial1, p->flags + flag_slot, skip);
   }
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
@@ -1065,7 +1065,8 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
 }
 
 template <int NC>
-static int run_build(cba_problem* p) { return run_build_into<NC>(p, p->x, p->tab, p->V, p->g, p->Upacked, 8); }
+// the build at the current x flags a non-finite residual in flags[3] (flags[0] belongs to trial points)
+static int run_build(cba_problem* p) { return run_build_into<NC>(p, p->x, p->tab, p->V, p->g, p->Upacked, 8, nullptr, false, false, 3); }
 
 template <int NC>
 static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr) {
@@ -1136,7 +1137,7 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
 }
 
 static void read_linearization(cba_problem* p, cba_linearization* out) {
-  if (p->cost_pending) { p->cost_x = 0.5 * p->h_scal[8]; p->cost_pending = false; }  // else: the cost of the accepted trial
+  if (p->cost_pending) { p->cost_x = p->h_flags[3] ? NAN : 0.5 * p->h_scal[8]; p->cost_pending = false; }  // else: the cost of the accepted trial
   p->gh_sq = p->h_scal[0];
   out->gh_sq = p->h_scal[0];
   out->x_scaled_norm = std::sqrt(p->h_scal[1]);
@@ -1363,7 +1364,7 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
 
 extern "C" {
 
-static int begin_common(cba_problem* p, double* cost_out);
+static int begin_common(cba_problem* p, double* cost_out, bool evaluate = true);
 
 int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, const int32_t* groups_b, const double* distances,
                         const double* weights) {
@@ -1467,7 +1468,19 @@ int cba_restart(cba_problem* p, double* cost_out) {
   return begin_common(p, cost_out);
 }
 
-static int begin_common(cba_problem* p, double* cost_out) {
+int cba_begin_deferred(cba_problem* p, const double* x0) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_begin_deferred: null argument");
+  if (!x0 && !p->have_x0) return fail(CBA_ERR_INVALID, "cba_begin_deferred: no x0 on the device yet");
+  HIPCHK(hipSetDevice(p->device));
+  if (x0) {
+    pack_host(p, x0, p->h_vec.data(), 0.0);
+    HIPCHK(hipMemcpyAsync(p->x0, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    p->have_x0 = true;
+  }
+  return begin_common(p, nullptr, false);
+}
+
+static int begin_common(cba_problem* p, double* cost_out, bool evaluate) {
   HIPCHK(hipMemcpyAsync(p->x, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   HIPCHK(hipMemsetAsync(p->cam_diag, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream));
@@ -1475,6 +1488,12 @@ static int begin_common(cba_problem* p, double* cost_out) {
   p->have_build = false; p->trial_built = false; p->cost_pending = false;
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
+  p->first_scale = true;
+  p->begun = true; p->linearized = false; p->stepped = false; p->have_trial = false;
+  if (!evaluate) {  // the first linearisation (cba_step / cba_linearize) evaluates x0 with its build pass: no pass, no wait here
+    p->cost_x = NAN;
+    return CBA_OK;
+  }
   int rc = launch_cost(p, p->x, p->tab, 24, nullptr);
   if (rc) return rc;
   rc = exchange(p, SLOT(24), false);
@@ -1482,8 +1501,6 @@ static int begin_common(cba_problem* p, double* cost_out) {
   rc = sync_scalars(p, 32);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  p->first_scale = true;
-  p->begun = true; p->linearized = false; p->stepped = false; p->have_trial = false;
   *cost_out = p->h_flags[0] ? NAN : 0.5 * p->h_scal[24];
   p->cost_x = *cost_out;
   return CBA_OK;

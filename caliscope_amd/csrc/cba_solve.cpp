@@ -101,14 +101,20 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   if (bounded) { cb.resize(ncp); cb.lb = opt.lb; cb.ub = opt.ub; }
   const auto t_begin = std::chrono::steady_clock::now();
 
-  double cost = 0.0;
-  rc = x0 ? cba_begin(p, x0, &cost) : cba_restart(p, &cost);
-  if (rc) return rc;
-  if (!std::isfinite(cost)) {  // scipy raises "Residuals are not finite in the initial point": status -1, nothing solved
-    out->status = -1; out->reserved = 0; out->nfev = 1; out->njev = 0; out->n_iterations = 0; out->cost = cost; out->optimality = NAN;
+  auto not_finite_at_x0 = [&](double c) {  // scipy raises "Residuals are not finite in the initial point": status -1, nothing solved
+    out->status = -1; out->reserved = 0; out->nfev = 1; out->njev = 0; out->n_iterations = 0; out->cost = c; out->optimality = NAN;
     out->t_total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return CBA_OK;
-  }
+  };
+  double cost = NAN;
+  // Without bounds the evaluation of x0 is left to the first linearisation (its build pass computes the cost anyway): one
+  // pass over the observations and one wait less per solve.
+  const char* defer_env = std::getenv("CBA_DEFER");
+  const bool deferred = !bounded && !(defer_env && defer_env[0] == '0');
+  if (deferred) rc = cba_begin_deferred(p, x0);
+  else rc = x0 ? cba_begin(p, x0, &cost) : cba_restart(p, &cost);
+  if (rc) return rc;
+  if (!deferred && !std::isfinite(cost)) return not_finite_at_x0(cost);
   if (bounded) {  // scipy: "`x0` is infeasible." (callers nudge on-bound entries inside first, least_squares.py:820-821)
     if ((rc = cba_get_camera_params(p, CBA_VEC_X, cb.x.data()))) return rc;
     for (int i = 0; i < ncp; ++i)
@@ -140,6 +146,10 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         if ((rc = cba_linearize_build(p))) return rc;  // the scalars follow from cba_set_camera_scaling below
       } else if ((rc = cba_linearize(p, &lin))) return rc;
       lin_valid = true;
+      if (std::isnan(cost)) {  // deferred begin: this was the evaluation of x0
+        cost = lin.cost;
+        if (!std::isfinite(cost)) return not_finite_at_x0(cost);
+      }
     }
     if (bounded) {
       // Coleman-Li scaling vector of the camera block (common.py CL_scaling_vector) and what follows from it

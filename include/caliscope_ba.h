@@ -97,6 +97,10 @@ int cba_begin(cba_problem* p, const double* x0, double* cost_out);
 /* Same as cba_begin with the x0 of the last cba_begin, which is kept on the device (no host transfer). */
 int cba_restart(cba_problem* p, double* cost_out);
 
+/* cba_begin / cba_restart (x0 == NULL) without the evaluation: the first cba_step or cba_linearize evaluates x0 with the
+ * build pass it runs anyway and reports the cost (NaN if a residual is not finite) — one pass and one wait less per solve. */
+int cba_begin_deferred(cba_problem* p, const double* x0);
+
 typedef struct {
   double g_norm_inf;    /* ||J^T f||_inf                      (trf.py:459)                       */
   double gh_sq;         /* ||g_h||^2,  g_h = g / scale_inv    (trf.py:469)                       */

@@ -67,6 +67,11 @@ int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
   return begin_common(p, cost_out);
 }
 int cba_restart(cba_problem* p, double* cost_out) { return begin_common(p, cost_out); }
+int cba_begin_deferred(cba_problem* p, const double* x0) {  // the double evaluates anyway: same state as cba_begin
+  double unused;
+  if (x0) p->x0.assign(x0, x0 + p->n);
+  return begin_common(p, &unused);
+}
 
 static void lin_scalars(cba_problem* p, int max_from, cba_linearization* out) {
   const int m = p->m, n = p->n;

@@ -436,3 +436,20 @@ def test_solution_on_an_intrinsic_bound_matches_scipy():
     ref_t = optimize_scipy(*args, x0, tr_solver="exact", **tight)
     assert abs(got_t.cost - ref_t.cost) <= 1e-10 * ref_t.cost
     assert np.abs(got_t.x[:ncp].reshape(-1, 9)[:, 6:] - ref_t.x[:ncp].reshape(-1, 9)[:, 6:]).max() < 1e-5
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_non_finite_start_raises_like_scipy(refine):
+    """scipy: ValueError("Residuals are not finite in the initial point.").  Without bounds the driver leaves the evaluation
+    of x0 to the first build pass (cba_begin_deferred), with bounds to cba_begin: both routes must report it."""
+    from oracle.residuals import joint_jacobian, joint_residuals
+
+    sc, par, x0 = small_problem(n_cams=4, n_points=120, k=4, refine=refine)
+    bad = x0.copy()
+    bad[par.n_camera_params + 5] = np.nan
+    with pytest.raises(ValueError, match="not finite in the initial point"):
+        least_squares(joint_residuals, bad, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, None, None, None, None),
+                      jac=joint_jacobian, x_scale="jac", method="trf", bounds=par.bounds())
+    ok = least_squares(joint_residuals, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, None, None, None, None),
+                       jac=joint_jacobian, x_scale="jac", method="trf", bounds=par.bounds())
+    assert ok.status > 0
