@@ -453,3 +453,36 @@ def test_non_finite_start_raises_like_scipy(refine):
     ok = least_squares(joint_residuals, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices, None, None, None, None),
                        jac=joint_jacobian, x_scale="jac", method="trf", bounds=par.bounds())
     assert ok.status > 0
+
+
+def test_limits_are_reported_not_crashed():
+    """Empty input, more cameras than the LDS camera table holds, calls out of order: clean errors with a message."""
+    from caliscope_amd.exceptions import BackendError
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0 = small_problem(n_cams=4, n_points=60, k=4)
+    empty = BAProblem(par, sc.camera_indices[:0], sc.image_coords[:0], sc.obj_indices[:0])
+    with pytest.raises(BackendError, match="empty problem"):
+        HipEngine(empty)
+    big = make_scene(n_cams=320, n_points=400, n_obs=1600)
+    par_big = BundleParameterization.from_camera_array(big.cameras_init, n_points=400, refine_intrinsics=False)
+    with pytest.raises(BackendError, match="LDS|cameras|160 KiB"):
+        HipEngine(BAProblem(par_big, big.camera_indices, big.image_coords, big.obj_indices))
+    with HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)) as eng:
+        with pytest.raises(BackendError, match="cba_begin first"):
+            eng.linearize()
+        eng.begin(x0)
+        with pytest.raises(BackendError, match="cba_linearize first"):
+            eng.newton_step(1e-3)
+        eng.linearize()
+        with pytest.raises(BackendError, match="cba_newton_step first"):
+            eng.trial(0.0, 1.0)
+        with pytest.raises(BackendError, match="lam must be finite"):
+            eng.newton_step(float("nan"))
+        with pytest.raises(ValueError, match="x0 has shape"):
+            eng.begin(x0[:-1])
+    with HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices), evaluation_only=True) as ev:
+        r, cost = ev.residuals(x0)
+        assert np.isfinite(cost) and r.size == 2 * len(sc.camera_indices) and abs(ev.begin(x0) - cost) <= 1e-13 * cost
+        with pytest.raises(BackendError, match="evaluation_only"):
+            ev.linearize()
