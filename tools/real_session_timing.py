@@ -1,0 +1,37 @@
+"""Wall time of CaptureVolume.optimize() on the reference's real 4-camera ChArUco session (BASELINE cfg 1: 2 175 observations,
+660 points), with and without the board's constraint rows and free intrinsics; scipy on the oracle rows beside it.
+python tools/real_session_timing.py"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from caliscope_amd.bundle_parameterization import BundleParameterization  # noqa: E402
+from caliscope_amd.cameras import CameraArray  # noqa: E402
+from caliscope_amd.capture_volume import CaptureVolume  # noqa: E402
+from caliscope_amd.constraints import ConstraintSet  # noqa: E402
+from caliscope_amd.point_data import ImagePoints, WorldPoints  # noqa: E402
+from oracle.solver import optimize_scipy  # noqa: E402
+
+d = ROOT / "tests" / "golden" / "post_optimization"
+pitch = 0.054
+grid = np.array([[(c + 1) * pitch, (r + 1) * pitch, 0.0] for r in range(4) for c in range(3)], dtype=np.float32)
+cams, img, world = CameraArray.from_toml(d / "camera_array.toml"), ImagePoints.from_csv(d / "xy_CHARUCO.csv"), WorldPoints.from_csv(d / "xyz_CHARUCO.csv")
+plain = CaptureVolume(cams, img, world)
+board = CaptureVolume(cams, img, world, ConstraintSet.from_grid(grid, pitch))
+plain.optimize()  # HIP start-up, code paths warm
+for label, vol, kw in (("no constraints", plain, {}), ("board constraints", board, {}), ("board constraints + free intrinsics", board, {"refine_intrinsics": True})):
+    t = time.perf_counter(); out = vol.optimize(**kw); dt = time.perf_counter() - t
+    st = out.optimization_status
+    _, cam, uv, obj = vol._matched_arrays()
+    par = BundleParameterization.from_camera_array(vol.camera_array, n_points=len(vol.world_points), refine_intrinsics=kw.get("refine_intrinsics", False))
+    con = None
+    if vol.constraints is not None:
+        ga, gb, dist, sig = vol._build_constraint_arrays()
+        con = (ga, gb, dist, (1.0 / float(np.median([c.matrix[0, 0] for c in cams.cameras.values()]))) / sig)
+    t = time.perf_counter(); ref = optimize_scipy(par, cam, uv, obj, par.pack(vol.camera_array, vol.world_points.points), constraints=con); dt_ref = time.perf_counter() - t
+    print(f"{label:38s} optimize() {dt * 1e3:7.1f} ms ({st.iterations} evaluations, {st.termination_reason}, cost {st.final_cost:.6e}, "
+          f"RMS {out.reprojection_report.overall_rmse:.4f} px) | scipy call alone {dt_ref * 1e3:7.1f} ms ({ref.nfev} evaluations, cost {ref.cost:.6e})")
