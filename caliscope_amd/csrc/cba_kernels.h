@@ -515,12 +515,13 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
 // one tile, keeps that tile in LDS across all of the tile's chunks, and flushes it once (per-workgroup
 // partials, reduced in fixed order).  The Jacobian blocks are recomputed per stream (G times per
 // observation) rather than stored: 24 B + ~600 flop beats 144 B of HBM traffic per use.
+typedef unsigned int pair_t;  // two 16-bit chunk-local observation indices
 struct TilePlan {
   const double* u;
   const double* v;
   const int* pt;
   const unsigned char* camloc;   // camera index inside the tile: [0,g) group a, [g,2g) group b
-  const unsigned short* pairs;   // (i | j << 8): chunk-local indices of every observation pair to multiply
+  const pair_t* pairs;           // (i | j << 16): chunk-local indices of every observation pair to multiply
   const int* pair_start;         // [n_tile_chunks + 1] offsets into `pairs`
   const int* chunk_start;        // [n_tile_chunks + 1] offsets into the stream arrays
   const int* wg_first;           // [grid] first chunk of the workgroup
@@ -647,7 +648,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
     const int q1 = (debug_skip & 1) ? 0 : tp.pair_start[ch + 1];
     for (int q = tp.pair_start[ch] + threadIdx.x; q < q1; q += SCHUR_BLOCK) {
       const unsigned pr = tp.pairs[q];
-      const int i_loc = pr & 255u, j_loc = pr >> 8;
+      const int i_loc = pr & 0xffffu, j_loc = pr >> 16;
       const int cl_i = sh_cam[i_loc], cl_j = sh_cam[j_loc];
       const int row0 = sh_loff[cl_i], col0 = sh_coff[cl_j];
       const int np_i = (int)cam_at(sh_tab, cl_i).nparams, np_j = (int)cam_at(sh_tab, cl_j).nparams;
@@ -713,7 +714,11 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 // the pieces of different records spread over all LDS banks.
 template <int NC> struct SchurRec { static constexpr int REC = 2 * ((((3 * NC + 1) / 2) & 1) ? (3 * NC + 1) / 2 : (3 * NC + 1) / 2 + 1); };
 static_assert(SchurRec<6>::REC == 18 && SchurRec<9>::REC == 30, "record sizes");
-constexpr int PAIRCAP = 2048;  // pairs of one chunk, staged in LDS (the plan closes a chunk before it overflows)
+constexpr int PAIRCAP = 3072;  // pairs of one chunk, staged in LDS (the plan closes a chunk before it overflows)
+// Chunk of the register kernel's streams.  A thread's share of a chunk is a handful of pairs, and a wave runs at the pace of
+// its busiest lane: the more pairs per chunk, the smaller the relative spread (384 observations x 144 B = 54 KB of records,
+// two workgroups per CU still fit).  The LDS-tile kernel and the per-observation kernels keep CHUNK = 256.
+constexpr int SCHUNK = 384;
 
 template <int NC>
 __global__ void __launch_bounds__(BLOCK)
@@ -832,12 +837,12 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
   constexpr int REG_BLOCK = BLOCK * SPLIT;
   constexpr int REC = SchurRec<NC>::REC;
   constexpr int NP = REC / 2;                                   // 16-byte pieces per record
-  constexpr int NLD = (CHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;  // gather loads per thread
+  constexpr int NLD = (SCHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;  // gather loads per thread
   constexpr int NPV = (PAIRCAP + REG_BLOCK - 1) / REG_BLOCK;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;                  // rows per thread
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_T = sh;                                            // [CHUNK][REC] (+ slack for the last partial load round)
-  unsigned short* sh_pairs = reinterpret_cast<unsigned short*>(sh_T + NLD * REG_BLOCK * 2);  // [PAIRCAP]
+  pair_t* sh_pairs = reinterpret_cast<pair_t*>(sh_T + NLD * REG_BLOCK * 2);  // [PAIRCAP]
 
   const int nblk = tp.g * tp.g;
   const int blk = threadIdx.x % BLOCK, half = threadIdx.x / BLOCK;
@@ -866,7 +871,7 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
   // 64 lanes of one load cover ~7 whole records (a thread fetching its own 144-byte record would touch 64 cache
   // lines per instruction and thrash the L1), and the LDS copy is a contiguous ds_write_b128.
   double2 rec[NLD];
-  unsigned short pv[NPV];
+  pair_t pv[NPV];
   int idx[NLD];
 #pragma unroll
   for (int k = 0; k < NLD; ++k) rec[k] = make_double2(0.0, 0.0);
@@ -877,7 +882,7 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
   {
     const int c0 = tp.chunk_start[first];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, CHUNK - 1)];
+    for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, SCHUNK - 1)];
   }
   int nxt = first;
   for (int cur = first - stride; cur < ch_end; cur += stride) {  // first trip: fetch only
@@ -907,13 +912,13 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
       q1 = owner ? b1 : 0;
       const int c0 = tp.chunk_start[min(nxt + stride, last)];
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, CHUNK - 1)];
+      for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, SCHUNK - 1)];
     }
     if (cur < first) continue;
     if (debug_skip != 1) {
       for (int q = my_q0; q < my_q1; ++q) {
         const unsigned pr = sh_pairs[q];
-        const int i_loc = pr & 255u, j_loc = pr >> 8;
+        const int i_loc = pr & 0xffffu, j_loc = pr >> 16;
         const double* Ri = sh_T + i_loc * REC + 3 * r0;
         const double2* Rj = reinterpret_cast<const double2*>(sh_T + j_loc * REC);
         double Ti[3 * RH];
@@ -1928,7 +1933,7 @@ k_triangulate(long n_points, const long* __restrict__ pt_start, const int* __res
 //   W_pc = sum_{i in (p, c)} T_i   (NC x 3),    Sacc += W_p W_p^T   over the cameras that see p,
 // one workgroup per heavy point; the pair plan skips them.  Points with more than CHUNK observations are also split
 // over several chunks ("fragments": chunk_pts = (point, -1)); k_build / k_backsub add a fragment's sums by atomics.
-constexpr int HEAVY_OBS = 40;  // 40 observations -> at most 40^2 = 1600 pair entries (PAIRCAP = 2048) even if they repeat a camera
+constexpr int HEAVY_OBS = 40;  // 40 observations -> at most 40^2 = 1600 pair entries (PAIRCAP = 3072) even if they repeat a camera
 
 __global__ void k_zero_heavy(const int* __restrict__ heavy_pts, int n_heavy, VecLayout lay, double* __restrict__ a, int rows_a,
                              double* __restrict__ b, int rows_b) {

@@ -388,9 +388,9 @@ template <int NC> struct RegCfg;
 template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_schur_reg(int) {
-  constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * RegCfg<NC>::SPLIT, NLD = (CHUNK * NP + RB - 1) / RB;
+  constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * RegCfg<NC>::SPLIT, NLD = (SCHUNK * NP + RB - 1) / RB;
   constexpr int NPV = (PAIRCAP + RB - 1) / RB;
-  return (size_t)NLD * RB * 16 + (size_t)NPV * RB * sizeof(unsigned short);
+  return (size_t)NLD * RB * 16 + (size_t)NPV * RB * sizeof(pair_t);
 }
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
   return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
@@ -421,7 +421,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     std::vector<double> u, v;
     std::vector<int> pt, obs;
     std::vector<unsigned char> cl;
-    std::vector<unsigned short> pairs;
+    std::vector<pair_t> pairs;
     std::vector<unsigned short> blk_off;       // register kernel: per chunk g*g+1 offsets of the owner-sorted pairs
     std::vector<std::vector<int>> helpers;     // register kernel, diagonal tile: helper threads of each camera
     std::vector<size_t> rr;                    // rotation state per camera
@@ -430,6 +430,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     int open = 0;                              // start of the currently open chunk
   };
   const bool reg = p->schur_reg;
+  const int chunk_cap = reg ? SCHUNK : CHUNK;  // observations per chunk of a tile stream
   const int nblk = g * g;
   // register kernel: the pairs of a chunk are sorted by owner thread.  Off-diagonal tiles and li < lj: the owner
   // of block (li, lj) is thread li * g + lj.  Diagonal tiles, li == lj ((i, i) items and duplicate-row pairs): the
@@ -442,7 +443,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     std::vector<unsigned short> key(n);
     for (size_t q = 0; q < n; ++q) {
       const unsigned pr = s.pairs[pb + q];
-      const int li = s.cl[s.open + (pr & 255u)], lj0 = s.cl[s.open + (pr >> 8)];
+      const int li = s.cl[s.open + (pr & 0xffffu)], lj0 = s.cl[s.open + (pr >> 16)];
       const int lj = lj0 < g ? lj0 : lj0 - g;
       int k;
       if (s.diag && li == lj) {
@@ -456,7 +457,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     }
     for (int b2 = 0; b2 < nblk; ++b2) cnt[b2 + 1] += cnt[b2];
     for (int b2 = 0; b2 <= nblk; ++b2) s.blk_off.push_back((unsigned short)cnt[b2]);
-    std::vector<unsigned short> sorted(n);
+    std::vector<pair_t> sorted(n);
     std::vector<unsigned> cur(cnt.begin(), cnt.end() - 1);
     for (size_t q = 0; q < n; ++q) sorted[cur[key[q]]++] = s.pairs[pb + q];
     std::copy(sorted.begin(), sorted.end(), s.pairs.begin() + pb);
@@ -562,10 +563,10 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         const int li = hcam[gb[a] + i] - gcam[a];
         const int j0 = (b == a) ? i : na, j1 = (b == a) ? na : cnt;
         for (int j = j0; j < j1; ++j) {
-          s.pairs.push_back((unsigned short)((base + i) | ((base + j) << 8)));
+          s.pairs.push_back((pair_t)((base + i) | ((base + j) << 16)));
           const bool same_cam = (b == a) && hcam[gb[a] + i] == hcam[gb[a] + j];  // (i, i) items and duplicate rows
           // register kernel: two rows of ONE camera contribute T + T^T, listed as (i, j) and (j, i)
-          if (reg && same_cam && j != i) s.pairs.push_back((unsigned short)((base + j) | ((base + i) << 8)));
+          if (reg && same_cam && j != i) s.pairs.push_back((pair_t)((base + j) | ((base + i) << 16)));
           if (reg && !same_cam) {  // owner thread of block (li, lj): its load in the open chunk
             const int lj = (b == a) ? hcam[gb[a] + j] - gcam[a] : hcam[gb[b] + (j - na)] - gcam[b];
             const int key = li * g + lj;
@@ -599,7 +600,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
         entries_of(win[w], na, nb);
         const long np = pairs_of(win[w], na, nb);
         if (reg && np > PAIRCAP) { tile_rc[job] = CBA_ERR_UNSUPPORTED; return; }  // caller falls back to the LDS-tile kernel
-        if (fill + na + nb > CHUNK || (reg && open_pairs + np > PAIRCAP)) continue;
+        if (fill + na + nb > chunk_cap || (reg && open_pairs + np > PAIRCAP)) continue;
         if (window == 1) { best = w; break; }
         const int sc = score_of(win[w], na, nb);
         if (best < 0 || sc < best_score) { best = w; best_score = sc; }
@@ -630,7 +631,8 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   std::vector<double> U, V;
   std::vector<int> PT, OB, CS, PS, TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
-  std::vector<unsigned short> PR, BO;
+  std::vector<pair_t> PR;
+  std::vector<unsigned short> BO;
   CS.push_back(0); PS.push_back(0);
   for (int job = 0; job < nT * NSEG; ++job) {
     Stream& s = st[job];
@@ -652,9 +654,9 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   }
   TCB[nT] = (int)CS.size() - 1;
   // the register kernel fetches whole rounds without bounds checks: keep the streams readable past the end
-  if (reg) { PR.resize(PR.size() + 2 * PAIRCAP, 0); OB.resize(OB.size() + 2 * CHUNK, 0); }
+  if (reg) { PR.resize(PR.size() + 2 * PAIRCAP, 0); OB.resize(OB.size() + 2 * SCHUNK, 0); }
   p->n_tile_chunks = TCB[nT];
-  p->tile_stream_len = (long)OB.size() - (reg ? 2 * CHUNK : 0);
+  p->tile_stream_len = (long)OB.size() - (reg ? 2 * SCHUNK : 0);
   p->n_pairs = (long)PR.size() - (reg ? 2 * PAIRCAP : 0);
   // workgroups: proportional to the chunk count of each tile, at least one per tile
   std::vector<long> nch(nT);
@@ -716,7 +718,8 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   int *dpt = nullptr, *dcs = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
       *dgc = nullptr, *dgp = nullptr;
   unsigned char* dcl = nullptr;
-  unsigned short *dpr = nullptr, *dbo = nullptr;
+  pair_t* dpr = nullptr;
+  unsigned short* dbo = nullptr;
   int *dps = nullptr, *dob = nullptr;
 #define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
   TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
