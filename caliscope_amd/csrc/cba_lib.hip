@@ -100,6 +100,7 @@ struct cba_problem {
   bool cost_pending = false; // the build of this linearisation ran here: its rho sum (scal[8]) is the cost at x
   double cost_x = 0.0;       // cost at the current x
   double trial_cost = 0.0;   // cost at the pending trial point
+  int grid_backsub = 1;  // k_backsub keeps 34 KB of LDS (cfg4): more resident workgroups than the 57-65 KB kernels sharing p->grid
   int n_heavy = 0; int* heavy_pts = nullptr; int* heavy_frag = nullptr; double* heavy_W = nullptr;  // heavy points (k_heavy_schur)
   std::vector<int> h_heavy_pts;
   ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
@@ -862,6 +863,11 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;
   p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
+  {
+    int mult = 2;
+    if (const char* e = std::getenv("CBA_BACKSUB_WGS")) mult = std::max(1, std::atoi(e));
+    p->grid_backsub = std::max(1, std::min(p->n_chunks, mult * cus));
+  }
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
   lap("reorder on host");
@@ -1281,7 +1287,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     if (p->n_heavy)  // fragments add sum_i W_i^T dc of a heavy point into s by atomics; k_heavy_finish solves for dp
       hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay,
                          p->s + p->lay.ncp_pad, 3, p->s + p->lay.ncp_pad, 0);
-    hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+    hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid_backsub), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                        p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
                        p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s);
     if (p->n_heavy)
