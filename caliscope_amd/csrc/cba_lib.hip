@@ -408,6 +408,10 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
                            const std::vector<int>& cam_off, int max_blocks) {
   const int G = p->G, g = p->gsz, C = p->C, P = p->P;
   const int nT = p->n_tiles;
+  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = t_now();
+  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
   std::vector<int> gcam(G + 1), gpar(G + 1);
   for (int a = 0; a <= G; ++a) {
     gcam[a] = std::min(a * g, C);
@@ -618,7 +622,12 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
       win.erase(win.begin() + best);
       refill();
     }
+    if (!s.obs.empty()) {  // the piece's last, partly filled chunk
+      if (reg) close_chunk_reg(s);
+      s.chunk_start.push_back((int)s.obs.size()); s.pair_start.push_back((int)s.pairs.size());
+    }
   };
+  lap("group runs per point");
   {
     const int n_jobs = nT * NSEG;
     std::vector<std::thread> workers;
@@ -626,36 +635,54 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     build_stream(0);
     for (auto& w : workers) w.join();
   }
+  lap("streams and pairs (host threads)");
   for (int rcj : tile_rc)
     if (rcj) return rcj;
-  // concatenate
+  // concatenate: offsets of every piece first, then the copies on host threads (80 MB at cfg4; serial inserts were the
+  // largest part of the plan)
+  const int n_jobs = nT * NSEG;
+  std::vector<size_t> o_obs(n_jobs + 1, 0), o_pr(n_jobs + 1, 0), o_bo(n_jobs + 1, 0), o_ch(n_jobs + 1, 0);
+  for (int job = 0; job < n_jobs; ++job) {
+    const Stream& sj = st[job];
+    o_obs[job + 1] = o_obs[job] + sj.obs.size();
+    o_pr[job + 1] = o_pr[job] + sj.pairs.size();
+    o_bo[job + 1] = o_bo[job] + sj.blk_off.size();
+    o_ch[job + 1] = o_ch[job] + (sj.chunk_start.size() - 1);
+  }
   std::vector<double> U, V;
-  std::vector<int> PT, OB, CS, PS, TCB(nT + 1, 0);
+  // the register kernel fetches whole rounds without bounds checks: the streams stay readable past the end (zero padding)
+  const size_t pad_ob = reg ? 2 * SCHUNK : 0, pad_pr = reg ? 2 * PAIRCAP : 0;
+  std::vector<int> PT, OB(o_obs[n_jobs] + pad_ob, 0), CS(o_ch[n_jobs] + 1), PS(o_ch[n_jobs] + 1), TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
-  std::vector<pair_t> PR;
-  std::vector<unsigned short> BO;
-  CS.push_back(0); PS.push_back(0);
-  for (int job = 0; job < nT * NSEG; ++job) {
-    Stream& s = st[job];
-    const int t = job / NSEG;
-    const int base = (int)OB.size(), pbase = (int)PR.size();
-    if (!s.obs.empty()) {
-      if (reg) close_chunk_reg(s);
-      s.chunk_start.push_back((int)s.obs.size()); s.pair_start.push_back((int)s.pairs.size());
+  std::vector<pair_t> PR(o_pr[n_jobs] + pad_pr, 0);
+  std::vector<unsigned short> BO(o_bo[n_jobs]);
+  if (!reg) { U.resize(o_obs[n_jobs]); V.resize(o_obs[n_jobs]); PT.resize(o_obs[n_jobs]); CL.resize(o_obs[n_jobs]); }
+  CS[0] = 0; PS[0] = 0;
+  for (int t = 0; t < nT; ++t) TCB[t] = (int)o_ch[(size_t)t * NSEG];
+  auto copy_piece = [&](int job) {
+    Stream& sj = st[job];
+    const size_t base = o_obs[job], pbase = o_pr[job];
+    std::copy(sj.obs.begin(), sj.obs.end(), OB.begin() + base);
+    std::copy(sj.pairs.begin(), sj.pairs.end(), PR.begin() + pbase);
+    std::copy(sj.blk_off.begin(), sj.blk_off.end(), BO.begin() + o_bo[job]);
+    for (size_t c = 1; c < sj.chunk_start.size(); ++c) {
+      CS[o_ch[job] + c] = (int)(base + sj.chunk_start[c]);
+      PS[o_ch[job] + c] = (int)(pbase + sj.pair_start[c]);
     }
-    BO.insert(BO.end(), s.blk_off.begin(), s.blk_off.end());
-    if (job % NSEG == 0) TCB[t] = (int)CS.size() - 1;
-    for (size_t c = 1; c < s.chunk_start.size(); ++c) { CS.push_back(base + s.chunk_start[c]); PS.push_back(pbase + s.pair_start[c]); }
-    U.insert(U.end(), s.u.begin(), s.u.end()); V.insert(V.end(), s.v.begin(), s.v.end());
-    PT.insert(PT.end(), s.pt.begin(), s.pt.end());
-    if (!reg) CL.insert(CL.end(), s.cl.begin(), s.cl.end());  // register kernel: camera-local ids are only needed to sort the pairs (host)
-    OB.insert(OB.end(), s.obs.begin(), s.obs.end());
-    PR.insert(PR.end(), s.pairs.begin(), s.pairs.end());
-    s = Stream();
+    if (!reg) {  // the LDS-tile kernel reads the observations from its own streams
+      std::copy(sj.u.begin(), sj.u.end(), U.begin() + base); std::copy(sj.v.begin(), sj.v.end(), V.begin() + base);
+      std::copy(sj.pt.begin(), sj.pt.end(), PT.begin() + base); std::copy(sj.cl.begin(), sj.cl.end(), CL.begin() + base);
+    }
+    sj = Stream();
+  };
+  {
+    std::vector<std::thread> workers;
+    for (int j = 1; j < n_jobs; ++j) workers.emplace_back(copy_piece, j);
+    copy_piece(0);
+    for (auto& w : workers) w.join();
   }
   TCB[nT] = (int)CS.size() - 1;
-  // the register kernel fetches whole rounds without bounds checks: keep the streams readable past the end
-  if (reg) { PR.resize(PR.size() + 2 * PAIRCAP, 0); OB.resize(OB.size() + 2 * SCHUNK, 0); }
+  lap("concatenate");
   p->n_tile_chunks = TCB[nT];
   p->tile_stream_len = (long)OB.size() - (reg ? 2 * SCHUNK : 0);
   p->n_pairs = (long)PR.size() - (reg ? 2 * PAIRCAP : 0);
@@ -723,10 +750,12 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   unsigned short* dbo = nullptr;
   int *dps = nullptr, *dob = nullptr;
 #define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
+  lap("workgroup binding");
   TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
   TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dbo, BO)); TRYP(dev_upload(p, &dob, OB)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dwf, wfirst));
   TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwe, wend)); TRYP(dev_upload(p, &dws, wstride)); TRYP(dev_upload(p, &dta, ta));
   TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
+  lap("upload");
   TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
 #undef TRYP
   const int gn = g * p->nct;
