@@ -121,6 +121,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if (!(cb.x[i] > cb.lb[i] && cb.x[i] < cb.ub[i])) return cba_set_error(CBA_ERR_INVALID, "cba_solve: x0 is not strictly inside the bounds");
   }
   long nfev = 1, njev = 1, iteration = 0;
+  int n_truncated = 0, n_reflected = 0, n_gradient = 0;  // which candidate select_step took when the step left the bounds
   // Fused iterations (cba_step): linearisation, damping, damped step, subspace step and first trial behind ONE host
   // synchronisation; the trial is evaluated by a build pass, so an accepted step needs no further pass.  A rejected
   // first trial costs a build instead of a cost pass: after one, the next iteration goes through the primitives.
@@ -293,15 +294,18 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
           double ag_stride, ag_value;
           minimize_quadratic_1d(0.5 * H_gg, -gh_sq, 0.0, ag_to_bound < ag_to_tr ? theta * ag_to_bound : ag_to_tr, 0.0, &ag_stride, &ag_value);
           if (p_value < r_value && p_value < ag_value) {
+            ++n_truncated;
             pt_alpha = kappa * alpha; pt_beta = kappa * beta;
             for (int i = 0; i < ncp; ++i) cb.step[i] = kappa * cb.p[i];
             predicted = -p_value; step_h_norm = kappa * std::sqrt(p_norm2);
           } else if (r_value < p_value && r_value < ag_value) {
+            ++n_reflected;
             pt_alpha = (p_stride + r_stride) * alpha; pt_beta = (p_stride + r_stride) * beta;
             for (int i = 0; i < ncp; ++i) cb.step[i] = p_stride * cb.p[i] + r_stride * cb.r[i];
             predicted = -r_value;
             step_h_norm = std::sqrt(std::max(0.0, (p_stride * p_stride + r_stride * r_stride) * p_norm2 + 2.0 * p_stride * r_stride * ph_dot_rh));
           } else {
+            ++n_gradient;
             pt_alpha = -ag_stride; pt_beta = 0.0;
             for (int i = 0; i < ncp; ++i) cb.step[i] = ag_stride * cb.x_new[i];
             predicted = -ag_value; step_h_norm = ag_stride * gh_norm;
@@ -349,7 +353,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   if (status == -100) status = 0;
   if (x_out && (rc = cba_get_vector(p, CBA_VEC_X, x_out))) return rc;
   out->status = std::isfinite(cost) ? status : -1;
-  out->reserved = 0;
+  out->reserved = std::min(n_truncated, 1023) | (std::min(n_reflected, 1023) << 10) | (std::min(n_gradient, 1023) << 20);
   out->nfev = nfev; out->njev = njev; out->n_iterations = iteration;
   out->cost = cost; out->optimality = g_norm;
   out->t_total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

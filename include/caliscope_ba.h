@@ -216,7 +216,8 @@ typedef struct {
 
 typedef struct {
   int32_t status;              /* -1 improper input, 0 max_nfev reached, 1 gtol, 2 ftol, 3 xtol, 4 ftol and xtol */
-  int32_t reserved;
+  int32_t reserved;            /* bounded solves: trial steps that left the box and were replaced by the truncated step (bits 0-9),
+                                  its reflection (10-19), the scaled anti-gradient (20-29) — select_step's three candidates */
   int64_t nfev, njev, n_iterations;
   double cost;                 /* 0.5 * sum rho(f) at the returned x                                           */
   double optimality;           /* ||J^T f||_inf at the returned x                                              */

@@ -178,3 +178,36 @@ def test_boundary_subspace_solution_matches_the_python_solver(native):
         ring = r * np.stack([np.cos(th), np.sin(th)])
         best = (0.5 * np.sum(ring * (B @ ring), axis=0) + g @ ring).min()
         assert 0.5 * p @ B @ p + g @ p <= best + 1e-6 * (1 + abs(best))
+
+
+def test_bounded_driver_uses_all_three_candidates_of_select_step(native):
+    """Random box-constrained curve fits started near a corner: over the batch the trial steps that leave the box must have
+    been replaced by each of select_step's candidates (truncated, reflected, scaled anti-gradient) at least once, and every
+    solve must land on scipy's bounded minimiser."""
+    from scipy.optimize import least_squares
+
+    rng = np.random.default_rng(11)
+    t = np.linspace(0, 3, 40)
+    used = np.zeros(3, dtype=int)
+    for k in range(40):
+        true = np.array([rng.uniform(1, 3), rng.uniform(-2, -0.3), rng.uniform(0, 1), rng.uniform(-1, 1)])
+        y = true[0] * np.exp(true[1] * t) + true[2] + true[3] * t + 0.01 * rng.normal(size=t.size)
+        fun = lambda p: p[0] * np.exp(p[1] * t) + p[2] + p[3] * t - y
+        jac = lambda p: np.stack([np.exp(p[1] * t), p[0] * t * np.exp(p[1] * t), np.ones_like(t), t], axis=1)
+        lo = true - rng.uniform(0.05, 1.0, 4) * np.array([1, 1, 1, 1.0])
+        hi = true + rng.uniform(0.05, 1.0, 4)
+        cut = rng.integers(0, 4)  # one bound cuts the unconstrained minimiser off
+        if rng.random() < 0.5:
+            hi[cut] = true[cut] - 0.1 * abs(true[cut]) - 0.05
+            lo[cut] = hi[cut] - 1.0
+        else:
+            lo[cut] = true[cut] + 0.1 * abs(true[cut]) + 0.05
+            hi[cut] = lo[cut] + 1.0
+        p0 = lo + rng.uniform(0.02, 0.98, 4) * (hi - lo)
+        sci = least_squares(fun, p0, jac=jac, method="trf", x_scale="jac", bounds=(lo, hi), ftol=1e-12, xtol=1e-12, gtol=1e-12)
+        res, x, evals = _solve(native, fun, jac, p0, t.size, ncp=4, lb=lo, ub=hi, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=400)
+        assert all(np.all(e > lo) and np.all(e < hi) for e in evals)
+        assert res.status > 0 and abs(res.cost - sci.cost) <= 1e-6 * max(sci.cost, 1e-12), (k, res.cost, sci.cost)
+        assert np.allclose(x, sci.x, rtol=1e-4, atol=1e-5), (k, x, sci.x)
+        used += np.array([res.reserved & 1023, (res.reserved >> 10) & 1023, (res.reserved >> 20) & 1023])
+    assert np.all(used > 0), used
