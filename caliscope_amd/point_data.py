@@ -4,7 +4,8 @@ Mirrors the containers the reference's ``CaptureVolume.optimize`` reads
 (``core/point_data.py:256-276`` column schemas, ``:323-373`` ImagePoints, WorldPoints):
 validated, copy-on-read pandas DataFrames with the same column names, plus the same CSV
 round-trip (``from_csv`` / ``to_csv``).  ``ImagePoints.triangulate`` (``:416-559``) is provided through
-``caliscope_amd.triangulation`` (device kernel); gap filling and smoothing are upstream of the path and out of scope.
+``caliscope_amd.triangulation`` (device kernel).  ``fill_gaps`` / ``filter_to_objects`` / ``smooth`` (``:375-414``, ``:606-651``) are
+host-side table utilities around the path, vectorised here (the reference loops over every track with a merge).
 """
 
 from __future__ import annotations
@@ -34,6 +35,35 @@ WORLD_POINT_COLUMNS = {
     "z_coord": "float",
 }
 WORLD_POINT_OPTIONAL = ("frame_time",)
+
+
+def _fill_track_gaps(df: pd.DataFrame, track_keys: list, value_cols: list, max_gap_size: int) -> pd.DataFrame:
+    """Rows for the missing sync indices of every track (``track_keys``), as the reference fills them: inside a hole of g
+    frames the first k = min(g, max_gap_size) get a row, with values on a straight line through the k + 1 equal steps
+    between the valid frames on either side (pandas ``interpolate(method="linear")`` after the rows beyond the limit were
+    dropped: evenly spaced in ROWS, not in sync index); all other columns of the new rows are NaN."""
+    if len(df) == 0 or max_gap_size <= 0:
+        return df
+    df = df.sort_values(track_keys + ["sync_index"], kind="stable").reset_index(drop=True)
+    keys = df[track_keys].to_numpy()
+    sync = df["sync_index"].to_numpy()
+    same = np.all(keys[1:] == keys[:-1], axis=1)
+    gap = np.where(same, sync[1:] - sync[:-1] - 1, 0)
+    left = np.flatnonzero(gap > 0)                  # row before a hole
+    if left.size == 0:
+        return df
+    k = np.minimum(gap[left], max_gap_size)           # rows to insert per hole
+    src = np.repeat(left, k)
+    j = np.arange(k.sum()) - np.repeat(np.cumsum(k) - k, k) + 1   # 1..k inside each hole
+    new = pd.DataFrame({c: np.repeat(df[c].to_numpy()[left], k) for c in track_keys})
+    new["sync_index"] = sync[src] + j
+    frac = j / (np.repeat(k, k) + 1.0)
+    for c in value_cols:
+        if c in df.columns:
+            v = df[c].to_numpy(dtype=np.float64)
+            new[c] = v[src] + (v[src + 1] - v[src]) * frac
+    out = pd.concat([df, new], ignore_index=True)     # columns absent from `new` become NaN
+    return out.sort_values(track_keys + ["sync_index"], kind="stable").reset_index(drop=True)
 
 
 def _validated(df: pd.DataFrame, required: dict, optional: tuple, what: str) -> pd.DataFrame:
@@ -75,6 +105,15 @@ class ImagePoints:
         Path(path).parent.mkdir(parents=True, exist_ok=True)
         safe_write_csv(self._df, Path(path), index=False, float_format=CSV_FLOAT_PRECISION)
 
+    def fill_gaps(self, max_gap_size: int = 3) -> "ImagePoints":
+        """Fill holes of up to ``max_gap_size`` frames in every (cam_id, object_id, keypoint_id) track by linear interpolation of
+        the pixel position and the frame time (reference ``:375-402``; a longer hole gets its first ``max_gap_size`` frames)."""
+        return ImagePoints(_fill_track_gaps(self._df, ["cam_id", "object_id", "keypoint_id"], ["img_loc_x", "img_loc_y", "frame_time"], max_gap_size))
+
+    def filter_to_objects(self, object_ids) -> "ImagePoints":
+        """Only the rows whose object_id is in ``object_ids`` (reference ``:404-414``)."""
+        return ImagePoints(self._df[self._df["object_id"].isin(set(int(o) for o in object_ids))].copy())
+
     def triangulate(self, camera_array, static_object_ids=frozenset()) -> "WorldPoints":
         """Undistort + DLT-triangulate every (sync_index, object_id, keypoint_id) seen by two or more posed cameras
         (reference ``core/point_data.py:416-559``), on the MI355X."""
@@ -99,6 +138,28 @@ class WorldPoints:
 
     def __len__(self) -> int:
         return len(self._df)
+
+    def fill_gaps(self, max_gap_size: int = 3) -> "WorldPoints":
+        """Fill holes of up to ``max_gap_size`` frames in every (object_id, keypoint_id) trajectory (reference ``:606-634``)."""
+        return WorldPoints(_fill_track_gaps(self._df, ["object_id", "keypoint_id"], ["x_coord", "y_coord", "z_coord", "frame_time"], max_gap_size))
+
+    def smooth(self, fps: float, cutoff_freq: float, order: int = 2) -> "WorldPoints":
+        """Zero-phase Butterworth low-pass of every trajectory with more than ``3 * order`` samples (reference ``:636-651``;
+        samples are taken in table order, as there)."""
+        from scipy.signal import butter, filtfilt
+
+        b, a = butter(order, cutoff_freq, btype="low", fs=fps, output="ba")
+        df = self._df.copy()
+        track = df.groupby(["object_id", "keypoint_id"], sort=False).ngroup().to_numpy()
+        order_idx = np.argsort(track, kind="stable")
+        bounds = np.flatnonzero(np.r_[True, track[order_idx][1:] != track[order_idx][:-1], True])
+        xyz = df[["x_coord", "y_coord", "z_coord"]].to_numpy(dtype=np.float64)
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if hi - lo > 3 * order:
+                rows = order_idx[lo:hi]
+                xyz[rows] = filtfilt(b, a, xyz[rows], axis=0)
+        df[["x_coord", "y_coord", "z_coord"]] = xyz
+        return WorldPoints(df)
 
     @classmethod
     def from_csv(cls, path: str | Path) -> "WorldPoints":

@@ -1,0 +1,80 @@
+"""fill_gaps / filter_to_objects / smooth of the point tables against a track-by-track restatement of what the reference does
+(per track: reindex to every sync index, drop the rows beyond max_gap_size inside a hole, pandas linear interpolation)."""
+import numpy as np
+import pandas as pd
+
+from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+
+def _track_by_track(df, keys, cols, max_gap):
+    out = []
+    for vals, group in df.groupby(keys):
+        group = group.sort_values("sync_index")
+        full = pd.DataFrame({"sync_index": np.arange(group["sync_index"].min(), group["sync_index"].max() + 1)})
+        for k, v in zip(keys, vals):
+            full[k] = int(v)
+        m = pd.merge(full, group, on=keys + ["sync_index"], how="left")
+        gap = m[cols[0]].isnull().astype(int).groupby(m[cols[0]].notnull().cumsum()).cumsum()
+        m = m[gap <= max_gap]
+        for c in cols:
+            m[c] = m[c].interpolate(method="linear", limit=max_gap)
+        out.append(m)
+    return pd.concat(out).dropna(subset=[cols[0]])
+
+
+def _image_table(rng):
+    rows = []
+    for cam in range(3):
+        for kp in range(4):
+            frames = np.flatnonzero(rng.random(60) < 0.7) + 5
+            for f in frames:
+                rows.append(dict(sync_index=int(f), cam_id=cam, object_id=kp // 2, keypoint_id=kp, img_loc_x=100 + 3.0 * f + cam + rng.normal(),
+                                 img_loc_y=50 + 0.5 * f * f / 10 + kp, frame_time=f / 30.0, obj_loc_x=0.1 * kp, obj_loc_y=0.0, obj_loc_z=0.0))
+    df = pd.DataFrame(rows)
+    return df.sample(frac=1.0, random_state=1).reset_index(drop=True)
+
+
+def test_image_point_gaps_are_filled_like_the_reference_does():
+    df = _image_table(np.random.default_rng(0))
+    keys, cols = ["cam_id", "object_id", "keypoint_id"], ["img_loc_x", "img_loc_y", "frame_time"]
+    for max_gap in (1, 3, 6):
+        got = ImagePoints(df).fill_gaps(max_gap).df.sort_values(keys + ["sync_index"]).reset_index(drop=True)
+        ref = _track_by_track(ImagePoints(df).df, keys, cols, max_gap).sort_values(keys + ["sync_index"]).reset_index(drop=True)
+        assert len(got) == len(ref) > len(df)
+        for c in keys + ["sync_index"]:
+            assert np.array_equal(got[c].to_numpy(), ref[c].to_numpy()), c
+        for c in cols:
+            assert np.allclose(got[c].to_numpy(), ref[c].to_numpy(), rtol=0, atol=1e-12), c
+        assert got["obj_loc_x"].isna().sum() == len(got) - len(df)  # inserted rows carry no board coordinates
+    assert len(ImagePoints(df).fill_gaps(0)) == len(df)
+    only = ImagePoints(df).filter_to_objects([1])
+    assert set(only.df["object_id"]) == {1} and len(only) == int((df["object_id"] == 1).sum())
+
+
+def test_world_point_gaps_and_smoothing():
+    rng = np.random.default_rng(2)
+    rows = []
+    for kp in range(5):
+        frames = np.flatnonzero(rng.random(80) < 0.75)
+        for f in frames:
+            rows.append(dict(sync_index=int(f), object_id=0, keypoint_id=kp, x_coord=np.sin(f / 9.0) + 0.02 * rng.normal(), y_coord=f / 40.0,
+                             z_coord=0.1 * kp, frame_time=f / 30.0))
+    df = pd.DataFrame(rows).sample(frac=1.0, random_state=3).reset_index(drop=True)
+    keys, cols = ["object_id", "keypoint_id"], ["x_coord", "y_coord", "z_coord", "frame_time"]
+    got = WorldPoints(df).fill_gaps(3).df.sort_values(keys + ["sync_index"]).reset_index(drop=True)
+    ref = _track_by_track(WorldPoints(df).df, keys, cols, 3).sort_values(keys + ["sync_index"]).reset_index(drop=True)
+    assert len(got) == len(ref) and np.array_equal(got["sync_index"].to_numpy(), ref["sync_index"].to_numpy())
+    for c in cols:
+        assert np.allclose(got[c].to_numpy(), ref[c].to_numpy(), rtol=0, atol=1e-12), c
+    # smoothing: the reference filters every trajectory in table order with filtfilt
+    from scipy.signal import butter, filtfilt
+
+    wp = WorldPoints(df)
+    sm = wp.smooth(fps=30.0, cutoff_freq=3.0, order=2).df
+    b, a = butter(2, 3.0, btype="low", fs=30.0, output="ba")
+    base = wp.df
+    for _, group in base.groupby(["object_id", "keypoint_id"]):
+        for c in ("x_coord", "y_coord", "z_coord"):
+            assert np.allclose(sm.loc[group.index, c].to_numpy(), filtfilt(b, a, group[c].to_numpy()), atol=1e-12)
+    short = WorldPoints(df[df["keypoint_id"] == 0].head(5))
+    assert np.array_equal(short.smooth(30.0, 3.0).points, short.points)  # 5 samples <= 3 * order: untouched
