@@ -2,6 +2,7 @@
 
 import numpy as np
 import pandas as pd
+import pytest
 import tomli
 
 from caliscope_amd.cameras import CameraArray, CameraData, rvec_to_matrix
@@ -80,3 +81,33 @@ def test_capture_volume_save_load(tmp_path):
     assert np.array_equal(back.img_to_obj_map, vol.img_to_obj_map)
     a, b = wp.df[["x_coord", "y_coord", "z_coord"]].to_numpy(), back.world_points.df[["x_coord", "y_coord", "z_coord"]].to_numpy()
     assert np.abs(a - b).max() <= 5e-7  # %.6f, as the reference writes
+
+
+def test_camera_helpers_without_opencv():
+    from caliscope_amd.cameras import CameraArray, CameraData, rvec_to_matrix
+    from caliscope_amd.exceptions import CalibrationError
+
+    cam = CameraData.from_intrinsics(3, (1920, 1080), 1400.0)
+    assert cam.matrix[0, 0] == cam.matrix[1, 1] == 1400.0 and (cam.matrix[0, 2], cam.matrix[1, 2]) == (960.0, 540.0) and np.all(cam.distortions == 0)
+    cam2 = CameraData.from_intrinsics(3, (640, 480), fx=500.0, fy=510.0, cx=300.0, distortions=[0.1, 0, 0, 0, 0])
+    assert (cam2.matrix[0, 0], cam2.matrix[1, 1], cam2.matrix[0, 2], cam2.matrix[1, 2]) == (500.0, 510.0, 300.0, 240.0) and cam2.distortions[0] == 0.1
+    for bad in (dict(focal_length=1.0, fx=1.0), dict(fx=1.0), {}):
+        with pytest.raises(ValueError):
+            CameraData.from_intrinsics(0, (10, 10), **bad)
+    with pytest.raises(ValueError):
+        _ = cam.transformation
+    T = np.eye(4); T[:3, :3] = rvec_to_matrix([0.1, -0.2, 0.3]); T[:3, 3] = [1.0, 2.0, 3.0]
+    cam.transformation = T
+    assert np.allclose(cam.transformation, T) and np.allclose(cam.normalized_projection_matrix, T[:3])
+    cam.erase_calibration_data()
+    assert cam.matrix is None and cam.rotation is None and cam.translation is None
+    cam.synthesize_default_intrinsics()
+    assert cam.matrix[0, 0] == 960.0 and (cam.matrix[0, 2], cam.matrix[1, 2]) == (960.0, 540.0)
+    with pytest.raises(CalibrationError):
+        CameraData(cam_id=1, size=(10, 10), fisheye=True).synthesize_default_intrinsics()
+    arr = CameraArray.from_image_sizes({2: (1280, 720), 0: (640, 480)})
+    assert arr.all_cameras_have_resolution() and not arr.all_intrinsics_calibrated() and not arr.all_extrinsics_calibrated()
+    assert CameraArray().all_extrinsics_calibrated() and not CameraArray().all_intrinsics_calibrated() and not CameraArray().all_cameras_have_resolution()
+    for c in arr.cameras.values():
+        c.synthesize_default_intrinsics(); c.rotation = np.eye(3); c.translation = np.zeros(3)
+    assert arr.all_intrinsics_calibrated() and arr.all_extrinsics_calibrated()
