@@ -297,3 +297,33 @@ def test_constraint_rows_through_the_rccl_call_sites(monkeypatch):
 
     pos, ang, scale = aligned_difference(sc["par"], got.x, ref.x)
     assert pos < 1e-8 and ang < 1e-8 and abs(scale - 1) < 1e-8
+
+
+@pytest.mark.gpu
+def test_device_rows_on_the_reference_known_answers():
+    """The reference's own known answers for the constraint rows (tests/test_constraints.py:599-649, :770-805, :808-885) through the
+    device residual hook: rows appended after the reprojection rows, zero at the exact distance, corner and centroid values."""
+    from caliscope_amd.hip_engine import HipEngine
+    from tests.test_oracle_pins import _one_camera_two_points
+
+    cam_idx, uv, obj = np.array([0, 0], dtype=np.int32), np.array([[200.0, 200.0], [240.0, 200.0]]), np.array([0, 1], dtype=np.int32)
+
+    def rows(points, ga, gb, dist, w):
+        par, x = _one_camera_two_points(points)
+        prob = BAProblem(par, cam_idx, uv, obj, constraint_groups_a=np.array(ga, dtype=np.int32), constraint_groups_b=np.array(gb, dtype=np.int32),
+                         constraint_distances=np.array(dist), constraint_weights=np.array(w))
+        with HipEngine(prob, evaluation_only=True) as eng:
+            r, _ = eng.residuals(x)
+        with HipEngine(BAProblem(par, cam_idx, uv, obj), evaluation_only=True) as eng:
+            r0, _ = eng.residuals(x)
+        assert r.size == r0.size + len(dist) and np.array_equal(r[: r0.size], r0)
+        return r[r0.size:]
+
+    assert abs(rows([[0.0, 0, 0], [1.0, 0, 0]], [[0, 0, 0, 0]], [[1, 1, 1, 1]], [1.0], [0.5])[0]) < 1e-15
+    pts = np.array([[0.1, 0.2, 0.3], [1.4, -0.5, 0.7]])
+    got = rows(pts, [[0, 0, 0, 0]], [[1, 1, 1, 1]], [1.0], [0.5])[0]
+    assert abs(got - (np.linalg.norm(pts[0] - pts[1]) - 1.0) * 0.5) < 1e-15
+    sq = np.array([[-0.5, 0.5, 0], [0.5, 0.5, 0], [0.5, -0.5, 0], [-0.5, -0.5, 0.0]])
+    both = np.vstack([sq, sq + [2.0, 0, 0]])
+    r = rows(both, [[0, 1, 2, 3], [0, 1, 2, 3]], [[4, 5, 6, 7], [4, 5, 6, 7]], [2.0, 1.5], [3.0, 3.0])
+    assert abs(r[0]) < 1e-14 and abs(r[1] - 1.5) < 1e-14

@@ -199,3 +199,54 @@ def test_post_optimization_session_reprojects_subpixel(golden_dir):
     # 1.66 px at the stored state (1.59 px at its BA optimum, see test_trf_driver.py): a wrong sign,
     # distortion order or rotation convention would show up as tens to hundreds of pixels.
     assert 0 < rmse < 2.0, rmse
+
+
+# ---- constraint rows of joint_residuals / joint_jacobian: the reference's own known answers (tests/test_constraints.py) ----
+def _one_camera_two_points(points):
+    from caliscope_amd.cameras import CameraArray, CameraData
+
+    cam = CameraData(cam_id=0, size=(400, 400), matrix=np.array([[200.0, 0, 200], [0, 200, 200], [0, 0, 1]]), distortions=np.zeros(5),
+                     rotation=np.eye(3), translation=np.array([0.0, 0.0, 5.0]))
+    ca = CameraArray({0: cam})
+    par = BundleParameterization.from_camera_array(ca, n_points=len(points), refine_intrinsics=False)
+    return par, par.pack(ca, np.asarray(points, dtype=np.float64))
+
+
+def test_constraint_rows_follow_the_reprojection_rows_and_known_values():
+    """Reference tests/test_constraints.py:599-649 (rows appended, zero at the exact distance), :770-805 (a corner endpoint is
+    one index four times: the row equals the single-index expression EXACTLY), :808-885 (centroid rows vanish at exact geometry)."""
+    cam_idx, uv, obj = np.array([0, 0], dtype=np.int16), np.array([[200.0, 200.0], [240.0, 200.0]]), np.array([0, 1], dtype=np.int32)
+    par, x = _one_camera_two_points([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0]])
+    ga, gb = np.array([[0, 0, 0, 0]], dtype=np.int32), np.array([[1, 1, 1, 1]], dtype=np.int32)
+    r_plain = joint_residuals(x, par, cam_idx, uv, obj)
+    r_con = joint_residuals(x, par, cam_idx, uv, obj, ga, gb, np.array([1.0]), np.array([0.5]))
+    assert len(r_plain) == 4 and len(r_con) == 5 and np.array_equal(r_con[:4], r_plain) and abs(r_con[4]) < 1e-10
+    pts = np.array([[0.1, 0.2, 0.3], [1.4, -0.5, 0.7]])
+    par, x = _one_camera_two_points(pts)
+    r = joint_residuals(x, par, cam_idx, uv, obj, ga, gb, np.array([1.0]), np.array([0.5]))
+    assert r[-1] == (np.linalg.norm(pts[0] - pts[1]) - 1.0) * 0.5  # exact, not approximate
+    # centroid endpoints: two unit squares 2 m apart
+    sq = np.array([[-0.5, 0.5, 0], [0.5, 0.5, 0], [0.5, -0.5, 0], [-0.5, -0.5, 0.0]])
+    par, x = _one_camera_two_points(np.vstack([sq, sq + [2.0, 0, 0]]))
+    ga, gb = np.array([[0, 1, 2, 3]], dtype=np.int32), np.array([[4, 5, 6, 7]], dtype=np.int32)
+    r = joint_residuals(x, par, cam_idx, uv, obj, ga, gb, np.array([2.0]), np.array([3.0]))
+    assert abs(r[-1]) < 1e-12
+    r = joint_residuals(x, par, cam_idx, uv, obj, ga, gb, np.array([1.5]), np.array([3.0]))
+    assert r[-1] == pytest.approx(1.5)  # (2.0 - 1.5) * 3
+
+
+def test_constraint_rows_touch_at_most_24_columns():
+    """Reference tests/test_constraints.py:1014-1036: 3 coordinate columns per distinct endpoint point — 6 for a corner row, 24 for
+    a centroid row — and nothing in the camera block."""
+    par, x = _one_camera_two_points(np.random.default_rng(0).normal(size=(8, 3)) + [0, 0, 1.0])
+    cam_idx, uv, obj = np.zeros(2, dtype=np.int16), np.array([[200.0, 200.0], [240.0, 200.0]]), np.array([0, 1], dtype=np.int32)
+    ga = np.array([[0, 0, 0, 0], [0, 1, 2, 3]], dtype=np.int32)
+    gb = np.array([[1, 1, 1, 1], [4, 5, 6, 7]], dtype=np.int32)
+    J = joint_jacobian(x, par, cam_idx, uv, obj, ga, gb, np.array([1.0, 1.0]), np.array([1.0, 1.0])).toarray()
+    rows = J[4:]
+    assert rows.shape[0] == 2 and np.count_nonzero(rows[:, : par.n_camera_params]) == 0
+    assert np.count_nonzero(rows[0]) == 6 and np.count_nonzero(rows[1]) == 24
+    # row of the corner constraint: +unit on point 0, -unit on point 1
+    pts = x[par.n_camera_params:].reshape(-1, 3)
+    unit = (pts[0] - pts[1]) / np.linalg.norm(pts[0] - pts[1])
+    assert np.allclose(rows[0, par.n_camera_params : par.n_camera_params + 3], unit) and np.allclose(rows[0, par.n_camera_params + 3 : par.n_camera_params + 6], -unit)
