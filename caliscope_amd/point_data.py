@@ -127,6 +127,11 @@ class WorldPoints:
 
     def __init__(self, df: pd.DataFrame):
         self._df = _validated(df, WORLD_POINT_COLUMNS, WORLD_POINT_OPTIONAL, "WorldPoints")
+        # first / last sync index of the moving points; static points sit at STATIC_SYNC_INDEX (reference :586-595)
+        sync = self._df["sync_index"].to_numpy()
+        moving = sync[sync != STATIC_SYNC_INDEX]
+        self.min_index = int(moving.min()) if moving.size else 0
+        self.max_index = int(moving.max()) if moving.size else 0
 
     @property
     def df(self) -> pd.DataFrame:

@@ -78,3 +78,14 @@ def test_world_point_gaps_and_smoothing():
             assert np.allclose(sm.loc[group.index, c].to_numpy(), filtfilt(b, a, group[c].to_numpy()), atol=1e-12)
     short = WorldPoints(df[df["keypoint_id"] == 0].head(5))
     assert np.array_equal(short.smooth(30.0, 3.0).points, short.points)  # 5 samples <= 3 * order: untouched
+
+
+def test_world_point_index_range_ignores_static_rows():
+    """Reference tests/test_constraints.py:390-424."""
+    from caliscope_amd.point_data import STATIC_SYNC_INDEX
+
+    base = dict(object_id=0, keypoint_id=0, x_coord=0.0, y_coord=0.0, z_coord=0.0)
+    wp = WorldPoints(pd.DataFrame([dict(base, sync_index=STATIC_SYNC_INDEX), dict(base, sync_index=5, keypoint_id=1), dict(base, sync_index=9, keypoint_id=1)]))
+    assert (wp.min_index, wp.max_index) == (5, 9)
+    static_only = WorldPoints(pd.DataFrame([dict(base, sync_index=STATIC_SYNC_INDEX), dict(base, sync_index=STATIC_SYNC_INDEX, keypoint_id=1)]))
+    assert (static_only.min_index, static_only.max_index) == (0, 0)
