@@ -122,3 +122,39 @@ def test_device_triangulate_image_points_signature():
     assert err < 5e-6  # float32-rounded normalised coordinates: ~1e-7 relative, metres
     px = undistort_points(cams.cameras[1], df.loc[df["cam_id"] == 1, ["img_loc_x", "img_loc_y"]].to_numpy(), output="pixels")
     assert px.shape[1] == 2 and np.isfinite(px).all()
+
+
+@pytest.mark.gpu
+def test_real_session_triangulation_and_unmatched_tracking(golden_dir):
+    """The reference's session through ImagePoints.triangulate (reference tests/test_capture_volume.py:30-76: structure, no NaN, metre
+    scale) against the oracle, then the volume built from it: every observation of a triangulated point is matched, the rest
+    are counted per camera (tests/test_reprojection_report.py:92-123)."""
+    from caliscope_amd.cameras import CameraArray
+    from caliscope_amd.capture_volume import CaptureVolume
+    from caliscope_amd.point_data import ImagePoints
+
+    d = golden_dir / "post_optimization"
+    cams = CameraArray.from_toml(d / "camera_array.toml")
+    ip = ImagePoints.from_csv(d / "xy_CHARUCO.csv")
+    wp = ip.triangulate(cams)
+    df = wp.df
+    assert len(df) > 0 and not df[["x_coord", "y_coord", "z_coord"]].isna().any().any() and df[["x_coord", "y_coord", "z_coord"]].abs().max().max() < 10.0
+    s, o, k, xyz = _oracle_world_points(cams, ip, set(), float32_io=True)
+    ref = pd.DataFrame({"sync_index": s, "object_id": o, "keypoint_id": k, "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]})
+    m = df.merge(ref, on=["sync_index", "object_id", "keypoint_id"], how="outer", indicator=True)
+    assert (m["_merge"] == "both").all() and len(m) == len(ref)
+    assert np.abs(m[["x_coord", "y_coord", "z_coord"]].to_numpy() - m[["x", "y", "z"]].to_numpy()).max() < 1e-7
+    # the stored world points of the session are the same points after the reference's bundle adjustment: centimetres apart
+    stored = pd.read_csv(d / "xyz_CHARUCO.csv")
+    both = df.merge(stored, on=["sync_index", "object_id", "keypoint_id"], suffixes=("", "_ba"))
+    assert len(both) > 0.9 * len(stored)
+    assert np.median(np.linalg.norm(both[["x_coord", "y_coord", "z_coord"]].to_numpy() - both[["x_coord_ba", "y_coord_ba", "z_coord_ba"]].to_numpy(), axis=1)) < 0.05
+    vol = CaptureVolume(cams, ip, wp)
+    rep = vol.reprojection_report
+    img = vol.image_points.df
+    for cam_id in cams.cameras:
+        here = (img["cam_id"] == cam_id).to_numpy()
+        assert rep.unmatched_by_camera[cam_id] == int(here.sum() - (here & (vol.img_to_obj_map >= 0)).sum())
+    assert rep.n_unmatched_observations == len(img) - rep.n_observations_matched and 0 < rep.overall_rmse < 10.0
+    opt = vol.optimize()
+    assert opt.optimization_status.converged and opt.reprojection_report.overall_rmse < rep.overall_rmse
