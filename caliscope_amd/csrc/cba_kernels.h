@@ -538,6 +538,7 @@ struct TilePlan {
   int tile_elems;                // width of one workgroup's partial (LDS-tile kernel: g nc ld + g nc)
   const unsigned short* blk_off; // register kernel: [n_tile_chunks][g*g + 1] per-thread offsets into the chunk's pairs
   const int* obs;                // register kernel: stream entry -> observation (index into the T records)
+  int rep;                       // register kernel: threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
 };
 // LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
 // an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
@@ -845,8 +846,13 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
   pair_t* sh_pairs = reinterpret_cast<pair_t*>(sh_T + NLD * REG_BLOCK * 2);  // [PAIRCAP]
 
   const int nblk = tp.g * tp.g;
-  const int blk = threadIdx.x % BLOCK, half = threadIdx.x / BLOCK;
-  const bool owner = blk < nblk;
+  // A small camera group leaves most of the 256 threads without a block (8 cameras: 64 blocks).  Then rep = 256 / nblk threads
+  // share every block: replica `slot` takes every rep-th pair of the block's slice into its own accumulators and its own
+  // partial row (k_reg_reduce sums the rows).  rep = 1 (SPLIT > 1 or g = 16): one thread per block as before.
+  const int rep = (SPLIT == 1) ? tp.rep : 1;
+  const int blk = (rep > 1) ? (int)threadIdx.x % nblk : (int)threadIdx.x % BLOCK;
+  const int slot = (rep > 1) ? (int)threadIdx.x / nblk : 0, half = (rep > 1) ? 0 : (int)threadIdx.x / BLOCK;
+  const bool owner = blk < nblk && slot < rep;
   const int r0 = half * RH;                                     // first row of this thread
   double acc[RH][NC];
 #pragma unroll
@@ -855,11 +861,13 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
     for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
 
   const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
-  double* dst = partial + (long)blockIdx.x * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
+  double* dst = partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
   if (first >= ch_end) {  // more workgroups than chunks in this range
+    if (slot < rep) {
 #pragma unroll
-    for (int k = 0; k < RH * NC; ++k)
-      if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+      for (int k = 0; k < RH * NC; ++k)
+        if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+    }
     return;
   }
   const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
@@ -916,7 +924,7 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
     }
     if (cur < first) continue;
     if (debug_skip != 1) {
-      for (int q = my_q0; q < my_q1; ++q) {
+      for (int q = my_q0 + slot; q < my_q1; q += rep) {
         const unsigned pr = sh_pairs[q];
         const int i_loc = pr & 0xffffu, j_loc = pr >> 16;
         const double* Ri = sh_T + i_loc * REC + 3 * r0;
@@ -946,7 +954,8 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
     }
     __syncthreads();
   }
-  // partial of this workgroup: [256 blocks][NC*NC]; this thread holds rows r0 .. r0 + RH - 1 of its block
+  // partial of this workgroup: [256 blocks][NC*NC] (x rep rows); this thread holds rows r0 .. r0 + RH - 1 of its block
+  if (slot >= rep) return;
 #pragma unroll
   for (int r = 0; r < RH; ++r)
 #pragma unroll
@@ -969,7 +978,7 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int g = tp.g, bsz = NCt * NCt;
   const int e = blockIdx.x * 64 + threadIdx.x;
-  const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
+  const int w0 = tile_wg_begin[t] * tp.rep, w1 = tile_wg_begin[t + 1] * tp.rep;  // rep partial rows per workgroup
   const bool diag = (ga == gb);
   long dst = -1;       // >= 0: Sacc index;  -2: park in red
   if (e < g * g * bsz) {

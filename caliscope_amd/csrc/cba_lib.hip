@@ -761,7 +761,9 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   const int gn = g * p->nct;
   const int cs = tile_cs(p->nct), ld = tile_ld(g, p->nct);
   const int elems = reg ? BLOCK * p->nct * p->nct : gn * ld + gn;
-  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dwf, dwe, dwt, dws, dta, dtb, dgc, dgp, g, cs, ld, elems, dbo, dob};
+  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dwf, dwe, dwt, dws, dta, dtb, dgc, dgp, g, cs, ld, elems, dbo, dob, 1};
+  if (reg && p->nct == 6 && g * g <= BLOCK / 2) p->tp.rep = BLOCK / (g * g);  // small groups: several threads per block (k_schur_reg)
+  if (const char* e = std::getenv("CBA_SCHUR_REP")) p->tp.rep = std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1)));
   return CBA_OK;
 }
 
@@ -955,7 +957,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
-  TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * p->tp.tile_elems)));
+  TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems)));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   if (p->schur_reg && !p->eval_only) {
