@@ -180,6 +180,45 @@ class BundleParameterization:
             return rvec, tvec, blk._K(), np.array(blk.dist_fixed)
         return rvec, tvec, blk._K(), np.array([blk.k1_initial, blk.k2_initial, *blk.dist_fixed])
 
+    def sparsity(self, camera_indices, obj_indices, n_constraints: int = 0, constraint_groups_a=None, constraint_groups_b=None):
+        """Structure of the Jacobian as a ``scipy.sparse.lil_matrix`` of 0/1 (reference ``:188-230``): a reprojection row
+        pair touches its camera's block and its point's three columns, a constraint row the coordinates of every point of
+        both endpoint groups.  The solver here never needs it (the structure is implicit in the point-sorted records); it is
+        kept for callers that hand ``jac_sparsity`` to scipy and as the contract the kernels' Jacobian is tested against."""
+        from scipy.sparse import coo_matrix
+
+        cam = np.asarray(camera_indices, dtype=np.int64)
+        obj = np.asarray(obj_indices, dtype=np.int64)
+        n_obs = cam.shape[0]
+        n_rows = 2 * n_obs + int(n_constraints)
+        n_cols = self.n_camera_params + 3 * self.n_points
+        offsets = np.asarray(self.camera_param_offsets, dtype=np.int64)
+        widths = np.array([b.n_params for b in self.blocks], dtype=np.int64)
+        rows, cols = [], []
+        obs = np.arange(n_obs, dtype=np.int64)
+        w_obs = widths[cam] if n_obs else np.zeros(0, dtype=np.int64)
+        for p in range(int(widths.max()) if len(widths) else 0):
+            has = obs[w_obs > p]
+            for half in (0, 1):
+                rows.append(2 * has + half)
+                cols.append(offsets[cam[has]] + p)
+        for coord in range(3):
+            for half in (0, 1):
+                rows.append(2 * obs + half)
+                cols.append(self.n_camera_params + 3 * obj + coord)
+        if constraint_groups_a is not None and constraint_groups_b is not None and n_constraints > 0:
+            c_idx = 2 * n_obs + np.arange(int(n_constraints), dtype=np.int64)
+            for groups in (np.asarray(constraint_groups_a, dtype=np.int64), np.asarray(constraint_groups_b, dtype=np.int64)):
+                for col in range(groups.shape[1]):
+                    for coord in range(3):
+                        rows.append(c_idx)
+                        cols.append(self.n_camera_params + 3 * groups[:, col] + coord)
+        r = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+        c = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
+        pattern = coo_matrix((np.ones(r.size, dtype=np.int8), (r, c)), shape=(n_rows, n_cols)).tocsr()
+        pattern.data[:] = 1  # repeated endpoint rows (corner groups) mark a column once
+        return pattern.astype(int).tolil()
+
     def bound_warnings(self, x) -> tuple[BoundWarning, ...]:
         found = []
         for blk, off in zip(self.blocks, self.camera_param_offsets):

@@ -1,0 +1,109 @@
+"""Scenes for the scenario tests (tests/test_scenarios.py): the situations the reference's synthetic suite puts
+``CaptureVolume.optimize`` in (tests/synthetic/test_intrinsic_recovery.py, test_outlier_robustness.py,
+test_robust_loss.py, test_multistage_flow.py, test_large_ring.py), restated with this repo's generators.  The
+reference bootstraps the initial poses with OpenCV's PnP (out of scope here); these scenes start from
+perturbed ground truth instead, which leaves the optimum — what the assertions are about — unchanged."""
+
+import numpy as np
+import pandas as pd
+
+from caliscope_amd.cameras import CameraArray, CameraData, matrix_to_rvec, rvec_to_matrix
+from caliscope_amd.capture_volume import CaptureVolume
+from caliscope_amd.constraints import ConstraintSet
+from caliscope_amd.point_data import ImagePoints, WorldPoints
+from caliscope_amd.synthetic import WEBCAM_SIZE, project_pinhole_bc5, ring_camera_array
+
+
+def board_grid(rows, cols, spacing):
+    grid = np.array([[c * spacing, r * spacing, 0.0] for r in range(rows) for c in range(cols)])
+    return grid - grid.mean(axis=0)
+
+
+def moving_board_volume(n_cams=4, radius=1.2, n_frames=40, rows=6, cols=9, spacing=0.04, start=(0.55, -0.55, 0.15),
+                        end=(-0.55, 0.55, 0.85), tumble=2.0, stationary=False, f_scale=1.0, k1_delta=0.0, k2_delta=0.0,
+                        noise_px=0.5, outliers=0.0, seed=42, constraints=False, perturb_poses=True):
+    """A board carried (and tumbled) along a line through a camera ring: with the default path every camera sees it from
+    about 0.5 m to 1.9 m and out to the image borders, which makes focal length observable next to the poses (the
+    reference's ``intrinsic_perturbation_scene``); ``stationary`` keeps a small board in one far place (its negative
+    control).  Returns ``(volume, truth)``; the volume's cameras carry the perturbed intrinsics and poses."""
+    rng = np.random.default_rng(seed)
+    cams = ring_camera_array(n_cams, radius=radius, target=(0.0, 0.0, 0.5))
+    grid = board_grid(rows, cols, spacing)
+    n_per = len(grid)
+    axis = rng.normal(0, 1, 3)
+    axis /= np.linalg.norm(axis)
+    pts = []
+    for f in range(n_frames):
+        s = 0.0 if stationary or n_frames == 1 else f / (n_frames - 1)
+        centre = (1 - s) * np.asarray(start) + s * np.asarray(end)
+        R = rvec_to_matrix(axis * (0.3 + (0.0 if stationary else tumble * 2 * np.pi * s)))
+        pts.append(grid @ R.T + centre)
+    pts = np.vstack(pts)
+    w, h = WEBCAM_SIZE
+    cam_idx, uv, obj = [], [], []
+    for c, cam in sorted(cams.cameras.items()):
+        K = cam.matrix
+        p, z = project_pinhole_bc5(pts, cam.rotation, cam.translation, K[0, 0], K[1, 1], K[0, 2], K[1, 2], cam.distortions)
+        ok = (z > 0.1) & (p[:, 0] >= 0) & (p[:, 0] < w) & (p[:, 1] >= 0) & (p[:, 1] < h)
+        cam_idx.append(np.full(ok.sum(), c))
+        uv.append(p[ok])
+        obj.append(np.flatnonzero(ok))
+    cam_idx, uv, obj = np.concatenate(cam_idx).astype(np.int32), np.vstack(uv), np.concatenate(obj).astype(np.int32)
+    uv = uv + rng.normal(0, noise_px, uv.shape)
+    # keep points seen by at least two cameras
+    seen = np.bincount(obj, minlength=len(pts))
+    keep_pt = seen >= 2
+    keep = keep_pt[obj]
+    cam_idx, uv, obj = cam_idx[keep], uv[keep], obj[keep]
+    outlier_rows = np.zeros(0, dtype=np.int64)
+    if outliers > 0:
+        orng = np.random.default_rng(seed + 2)
+        outlier_rows = np.sort(orng.choice(len(obj), size=round(outliers * len(obj)), replace=False))
+        mag, th = orng.uniform(10.0, 50.0, len(outlier_rows)), orng.uniform(0, 2 * np.pi, len(outlier_rows))
+        uv[outlier_rows] += np.stack([mag * np.cos(th), mag * np.sin(th)], axis=1)
+    init = {}
+    for c, cam in cams.cameras.items():
+        K, dist = cam.matrix.copy(), cam.distortions.copy()
+        K[0, 0] *= f_scale
+        K[1, 1] *= f_scale
+        dist[0] += k1_delta
+        dist[1] += k2_delta
+        rvec = matrix_to_rvec(cam.rotation) + (rng.normal(0, 0.01, 3) if perturb_poses else 0)
+        init[c] = CameraData(cam_id=c, size=cam.size, matrix=K, distortions=dist, rotation=rvec_to_matrix(rvec),
+                             translation=cam.translation + (rng.normal(0, 0.01, 3) if perturb_poses else 0))
+    pts0 = pts + rng.normal(0, 0.005, pts.shape)
+    ids = np.flatnonzero(keep_pt)
+    world = pd.DataFrame({"sync_index": ids // n_per, "object_id": 0, "keypoint_id": ids % n_per, "x_coord": pts0[ids, 0],
+                          "y_coord": pts0[ids, 1], "z_coord": pts0[ids, 2], "frame_time": (ids // n_per) * 0.1})
+    img = pd.DataFrame({"sync_index": obj // n_per, "cam_id": cam_idx, "object_id": 0, "keypoint_id": obj % n_per,
+                        "img_loc_x": uv[:, 0], "img_loc_y": uv[:, 1]})
+    cs = None
+    if constraints:
+        raw = np.array([[c * spacing, r * spacing, 0.0] for r in range(rows) for c in range(cols)], dtype=np.float32)
+        cs = ConstraintSet.from_grid(raw, spacing)
+    vol = CaptureVolume(CameraArray(init), ImagePoints(img), WorldPoints(world), cs)
+    truth = dict(cameras=cams, points=pts[ids], outlier_rows=outlier_rows, n_per=n_per)
+    return vol, truth
+
+
+def pose_errors(volume, truth):
+    """Worst camera position error (m) and rotation error (deg) against the ground truth after a similarity alignment of
+    camera centres + points (what the reference's ``align_to_ground_truth`` / ``pose_error`` report,
+    tests/synthetic/assertions.py:125-168)."""
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+    from tests.helpers import camera_centres_and_rotations, umeyama
+
+    par = BundleParameterization.from_camera_array(volume.camera_array, n_points=len(truth["points"]), refine_intrinsics=False)
+    x_got = par.pack(volume.camera_array, volume.world_points.points)
+    x_true = par.pack(truth["cameras"], truth["points"])
+    ca, Ra = camera_centres_and_rotations(par, x_got)
+    cb, Rb = camera_centres_and_rotations(par, x_true)
+    pa, pb = x_got[par.n_camera_params:].reshape(-1, 3), x_true[par.n_camera_params:].reshape(-1, 3)
+    s, R, t = umeyama(np.vstack([ca, pa]), np.vstack([cb, pb]))
+    trans = float(np.linalg.norm(s * ca @ R.T + t - cb, axis=1).max())
+    ang = 0.0
+    for A, B in zip(Ra, Rb):
+        rel = (A @ R.T) @ B.T
+        w = np.array([rel[2, 1] - rel[1, 2], rel[0, 2] - rel[2, 0], rel[1, 0] - rel[0, 1]])
+        ang = max(ang, float(np.arctan2(0.5 * np.linalg.norm(w), 0.5 * (np.trace(rel) - 1.0))))
+    return trans, float(np.degrees(ang))

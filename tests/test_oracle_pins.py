@@ -250,3 +250,33 @@ def test_constraint_rows_touch_at_most_24_columns():
     pts = x[par.n_camera_params:].reshape(-1, 3)
     unit = (pts[0] - pts[1]) / np.linalg.norm(pts[0] - pts[1])
     assert np.allclose(rows[0, par.n_camera_params : par.n_camera_params + 3], unit) and np.allclose(rows[0, par.n_camera_params + 3 : par.n_camera_params + 6], -unit)
+
+
+def test_sparsity_pattern_covers_the_jacobian_and_nothing_else():
+    """Reference tests/synthetic/test_intrinsic_recovery.py:37-80 (sparsity oracle, variable-width blocks): every zero of
+    ``BundleParameterization.sparsity`` is a true zero of the Jacobian; here also the converse on generic data (each marked
+    entry is structurally reachable), with a locked fisheye camera next to a free pinhole one and both kinds of
+    constraint rows."""
+    ca, points, image_coords, cam_idx, obj_idx = _mixed_arrays()
+    par = BundleParameterization.from_camera_array(ca, n_points=len(points), refine_intrinsics=True)
+    x0 = par.pack(ca, points)
+    ga = np.array([[0, 0, 0, 0], [1, 2, 3, 4]], dtype=np.int32)
+    gb = np.array([[6, 6, 6, 6], [8, 9, 10, 11]], dtype=np.int32)
+    args = (par, cam_idx, image_coords, obj_idx, ga, gb, np.array([0.3, 0.2]), np.array([1.5, 2.5]))
+    J = joint_jacobian(x0, *args).toarray()
+    pattern = par.sparsity(cam_idx, obj_idx, 2, ga, gb)
+    from scipy.sparse import issparse
+
+    assert issparse(pattern) and pattern.format == "lil" and pattern.shape == J.shape
+    S = pattern.toarray()
+    assert set(np.unique(S)) == {0, 1}
+    assert np.abs(J[S == 0]).max() == 0.0
+    fd = _fd_jacobian(lambda x: joint_residuals(x, *args), x0)
+    assert np.abs(fd[S == 0]).max() < 1e-4  # the reference's bound on false zeros
+    n_obs = len(cam_idx)
+    per_row = S.sum(axis=1)
+    width = np.array([b.n_params for b in par.blocks])[cam_idx]
+    assert np.array_equal(per_row[: 2 * n_obs], np.repeat(width + 3, 2))
+    assert list(per_row[2 * n_obs:]) == [6, 24]  # corner endpoints mark one point each, centroid endpoints four
+    # without constraint arguments only the reprojection rows exist
+    assert par.sparsity(cam_idx, obj_idx, 0, None, None).shape == (2 * n_obs, par.n_params)
