@@ -4,7 +4,9 @@
 1-3 (blind intrinsics, pairwise PnP / essential-matrix bootstrap) need OpenCV and are upstream of the hot path.
 Stage 4 (static-marker guard, :146-196) and stages 5-9 — the part that calls the solver three times with a filter in
 between — are mirrored here, on a volume that is already bootstrapped (a dropped marker's rows are removed from
-the volume instead of re-running the bootstrap):
+the volume instead of re-running the bootstrap).  :func:`calibrate_extrinsics` keeps the reference's entry point and its
+input guards (stages 1-2, :70-143) for cameras that already carry pose estimates; stage 3 is then only the
+triangulation (``CaptureVolume.bootstrap``):
 
   4  static-marker guard: drop a static marker whose intra-marker rigidity RMSE exceeds 25 % of its size    (:146-196)
   5  ``optimize(refine_intrinsics=False)``                          linear loss, reach the basin        (:206)
@@ -111,6 +113,120 @@ def apply_static_marker_guard(capture_volume: CaptureVolume) -> tuple[CaptureVol
     vol = CaptureVolume(capture_volume.camera_array, ImagePoints(img[~img["object_id"].isin(gone)].reset_index(drop=True)),
                         WorldPoints(world[~world["object_id"].isin(gone)].reset_index(drop=True)), kept)
     return vol, tuple(dropped)
+
+
+def _validate_two_sided_extraction(image_points, thickness_m: float) -> None:
+    """The identity scheme of a two-sided board is frozen into the extraction (object 1 = back face, ``obj_loc_z`` =
+    thickness) while the constraints are compiled from the current configuration: a mismatch would silently drop every
+    cross-face row, so it is an error (reference :328-370)."""
+    from caliscope_amd.exceptions import CalibrationError
+
+    df = image_points.df
+    observed = {int(o) for o in df["object_id"].unique()}
+    expected = {0, 1} if thickness_m > 0 else {0}
+    if observed != expected:
+        if thickness_m > 0 and 1 not in observed:
+            detail = ("board thickness is set but the extraction has no back-face observations (object_id 1): re-extract, or "
+                      "set thickness to 0 if only one face was filmed.")
+        elif thickness_m == 0 and 1 in observed:
+            detail = ("the extraction contains back-face observations (object_id 1) but board thickness is 0: re-extract, or "
+                      "restore the thickness the extraction was made with.")
+        else:
+            detail = "re-extract with the current board configuration."
+        raise CalibrationError(f"Extraction/config identity mismatch: observed object_ids {sorted(observed)}, configured "
+                               f"thickness implies {sorted(expected)} — {detail}")
+    if thickness_m > 0:
+        extracted = float(df.loc[df["object_id"] == 1, "obj_loc_z"].iloc[0])
+        if abs(extracted - thickness_m) > 1e-9:
+            raise CalibrationError(f"Board thickness changed since extraction: extraction carries back-face obj_loc "
+                                   f"z={extracted * 100:.2f}cm but configured thickness is {thickness_m * 100:.2f}cm. Re-extract, "
+                                   f"or restore the original thickness.")
+
+
+def _count_firing_cross_face_rows(world_df, distances) -> int:
+    """Cross-object distance rows whose two endpoints are triangulated at one common sync index at least — the join
+    ``_build_constraint_arrays`` performs (reference :373-391), on integer keys instead of per-row Python sets."""
+    cross = [d for d in distances if d.object_id_a != d.object_id_b]
+    if not cross or len(world_df) == 0:
+        return 0
+    triples = set(zip(world_df["object_id"].astype(int).tolist(), world_df["keypoint_id"].astype(int).tolist(),
+                      world_df["sync_index"].astype(int).tolist()))
+    by_point: dict = {}
+    for o, k, s in triples:
+        by_point.setdefault((o, k), set()).add(s)
+    return sum(1 for d in cross if by_point.get((d.object_id_a, d.keypoint_id_a), set()) & by_point.get((d.object_id_b, d.keypoint_id_b), set()))
+
+
+def calibrate_extrinsics(
+    image_points,
+    camera_array,
+    constraints,
+    *,
+    refine_intrinsics: bool = True,
+    filter_percentile: float = 2.5,
+    cancellation_token=None,
+    progress: Callable[[int, str], None] | None = None,
+    _engine_factory=None,
+    _triangulate=None,
+) -> CalibrationRun:
+    """The reference's entry point (``calibrate_extrinsics.py:44-261``, same arguments, progress marks and errors) for
+    cameras that carry pose estimates: blind intrinsics for uncalibrated cameras, the extraction guards, triangulation
+    on the device, static-marker guard, the three solver passes with the filter in between."""
+    from copy import deepcopy
+
+    from caliscope_amd.exceptions import CalibrationError
+
+    def report(pct, msg):
+        if progress is not None:
+            progress(pct, msg)
+
+    def check_cancelled():
+        if cancellation_token is not None and getattr(cancellation_token, "is_cancelled", False):
+            raise InterruptedError("Calibration cancelled")
+
+    report(5, "Preparing cameras")
+    cameras = deepcopy(camera_array)
+    synthesized = set()
+    for cam in cameras.cameras.values():
+        if not cam.ignore and (cam.matrix is None or cam.distortions is None):
+            synthesized.add(cam.cam_id)
+            cam.synthesize_default_intrinsics()
+    df = image_points.df
+    if synthesized and df[["obj_loc_x", "obj_loc_y", "obj_loc_z"]].isna().all().all():
+        raise CalibrationError(
+            f"Epipolar bootstrap requires calibrated intrinsics, but cameras {sorted(synthesized)} have none and fell back to "
+            f"blind defaults (f=width/2). Without object geometry there is no anchor to absorb the focal-length error: "
+            f"supply real intrinsics first, then re-run extrinsic calibration."
+        )
+    anchors = {}
+    for cam in cameras.cameras.values():
+        if not cam.ignore and cam.matrix is not None and cam.distortions is not None:
+            d = np.asarray(cam.distortions).ravel()
+            anchors[cam.cam_id] = (float(cam.matrix[0, 0]), float(d[0]), float(d[1]))
+    if constraints is not None and constraints.back_face_thickness_m is not None:
+        _validate_two_sided_extraction(image_points, constraints.back_face_thickness_m)
+    if constraints is not None:
+        image_points = constraints.remap_image_points(image_points)
+    check_cancelled()
+
+    report(15, "Bootstrapping poses")
+    volume = CaptureVolume.bootstrap(image_points, cameras, constraints=constraints, _triangulate=_triangulate)
+    if constraints is not None and (constraints.back_face_thickness_m or 0) > 0:
+        firing = _count_firing_cross_face_rows(volume.world_points.df, constraints.distances)
+        total = sum(1 for d in constraints.distances if d.object_id_a != d.object_id_b)
+        logger.info(f"Cross-face constraints firing: {firing}/{total} rows across all sync indices")
+        if firing == 0:
+            raise CalibrationError(
+                "No cross-face constraint fires: no sync index has both the front and the mirrored face triangulated (each "
+                "face needs >= 2 cameras simultaneously). The front-viewing and back-viewing camera groups have no rigid "
+                "link, so calibration would be arbitrary."
+            )
+    check_cancelled()
+    run = refine_calibration(volume, refine_intrinsics=refine_intrinsics, filter_percentile=filter_percentile,
+                             cancellation_token=cancellation_token, progress=progress, _engine_factory=_engine_factory)
+    estimates = _intrinsic_estimates(run.capture_volume, anchors)
+    return CalibrationRun(run.capture_volume, estimates, frozenset(synthesized), run.dropped_static_markers,
+                          run.intrinsic_refinement_gated)
 
 
 def refine_calibration(

@@ -424,6 +424,39 @@ class CaptureVolume:
         return self._filter_by_reprojection_thresholds(thresholds, min_per_camera, _engine_factory)
 
     @classmethod
+    def bootstrap(cls, image_points: ImagePoints, camera_array: CameraArray, constraints=None, *, _triangulate=None) -> "CaptureVolume":
+        """Starting volume for ``optimize`` from 2-D observations (reference ``:268-320``): copy the cameras, triangulate
+        every point seen by two or more posed cameras (on the device), keep the input untouched.
+
+        The reference first estimates the poses from pairwise PnP / essential-matrix decompositions (OpenCV, upstream of
+        the solver path and not rebuilt here): this ``bootstrap`` takes the poses the cameras already carry — a previous
+        calibration, a rig description, another tool's estimate — and raises ``CalibrationError`` for cameras that have
+        observations but no pose.  Validation and errors otherwise follow the reference (``:288-307``)."""
+        point_cams = set(int(c) for c in image_points.df["cam_id"].unique())
+        missing = point_cams - set(camera_array.cameras)
+        if missing:
+            raise CalibrationError(f"ImagePoints reference cameras {missing} not in the CameraArray.")
+        uncalibrated = [cid for cid, cam in camera_array.cameras.items() if cam.matrix is None or cam.distortions is None]
+        if uncalibrated:
+            raise CalibrationError(
+                f"Cannot run extrinsic calibration -- cameras {uncalibrated} have no intrinsic calibration.\n\n"
+                f"Run calibrate_intrinsics() for each camera first."
+            )
+        unposed = sorted(cid for cid in point_cams
+                         if not camera_array.cameras[cid].ignore
+                         and (camera_array.cameras[cid].rotation is None or camera_array.cameras[cid].translation is None))
+        if unposed:
+            raise CalibrationError(
+                f"Cameras {unposed} have observations but no pose estimate. This backend refines poses; the initial pose "
+                f"network (PnP / essential matrix) is upstream of it: load a previous calibration or supply estimates."
+            )
+        cameras = deepcopy(camera_array)
+        static_ids = constraints.static_object_ids if constraints else frozenset()
+        triangulate = _triangulate or (lambda ip, cams, static: ip.triangulate(cams, static_object_ids=static))
+        world_points = triangulate(image_points, cameras, static_ids)
+        return cls(camera_array=cameras, image_points=image_points, world_points=world_points, constraints=constraints)
+
+    @classmethod
     def from_arrays(cls, camera_array: CameraArray, camera_ids, image_coords, obj_indices, points_xyz) -> "CaptureVolume":
         """Build a volume from flat arrays (synthetic scenes): observation i is keypoint 0 of object
         ``obj_indices[i]`` at sync_index 0 — one world point per object."""

@@ -129,3 +129,139 @@ def test_refresh_run_keeps_anchors_and_flags():
         cam = vol.camera_array.cameras[e.cam_id]
         assert (e.f_initial, e.k1_initial, e.k2_initial) == (1400.0 + e.cam_id, 0.1, -0.2)
         assert e.f_recovered == cam.matrix[0, 0] and e.k1_recovered == cam.distortions[0]
+
+
+# -- the reference's entry point: guards + triangulation + stages 4-9 (reference tests/test_calibrate_extrinsics.py) ------------
+def _oracle_triangulate(image_points, cameras, static_ids):
+    import pandas as pd
+
+    from caliscope_amd.point_data import WorldPoints
+    from tests.test_triangulation import _oracle_world_points
+
+    s, o, k, xyz = _oracle_world_points(cameras, image_points, set(static_ids), float32_io=True)
+    return WorldPoints(pd.DataFrame({"sync_index": s, "object_id": o, "keypoint_id": k, "x_coord": xyz[:, 0], "y_coord": xyz[:, 1],
+                                     "z_coord": xyz[:, 2]}))
+
+
+def _board_session(strip=False, with_obj_loc=True):
+    """Observations + posed cameras + the board's constraints, as ``calibrate_extrinsics`` receives them."""
+    from copy import deepcopy
+
+    from caliscope_amd.point_data import ImagePoints
+    from tests.scenario_scenes import moving_board_volume
+
+    vol, truth = moving_board_volume(constraints=True)
+    df = vol.image_points.df
+    if with_obj_loc:
+        grid = np.array([[c * 0.04, r * 0.04, 0.0] for r in range(6) for c in range(9)])
+        df[["obj_loc_x", "obj_loc_y", "obj_loc_z"]] = grid[df["keypoint_id"].to_numpy()]
+    cameras = deepcopy(vol.camera_array)
+    if strip:
+        for cam in cameras.cameras.values():
+            cam.matrix = cam.distortions = None
+    return ImagePoints(df), cameras, vol.constraints, truth
+
+
+def _engine_kwargs(kind):
+    from tests.test_scenarios import _numpy_factory
+
+    return dict(_engine_factory=_numpy_factory, _triangulate=_oracle_triangulate) if kind == "numpy" else {}
+
+
+@pytest.mark.parametrize("kind", ["numpy", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_calibrate_extrinsics_entry_point_with_provided_intrinsics(kind):
+    from caliscope_amd.calibrate_extrinsics import CalibrationRun, calibrate_extrinsics
+    from tests.scenario_scenes import pose_errors
+
+    image_points, cameras, constraints, truth = _board_session()
+    before = {c: (cam.matrix.copy(), cam.rotation.copy()) for c, cam in cameras.cameras.items()}
+    seen = []
+    run = calibrate_extrinsics(image_points, cameras, constraints, progress=lambda p, m: seen.append(p), **_engine_kwargs(kind))
+    assert isinstance(run, CalibrationRun) and run.synthesized_cam_ids == frozenset() and run.dropped_static_markers == ()
+    assert seen == sorted(seen) and seen[0] == 5 and seen[-1] == 100
+    assert run.capture_volume.optimization_status.converged and not run.intrinsic_refinement_gated
+    for est in run.intrinsic_estimates:
+        true = truth["cameras"].cameras[est.cam_id]
+        assert abs(est.f_initial - true.matrix[0, 0]) < 1e-6 and abs(est.f_recovered - true.matrix[0, 0]) < 0.01 * true.matrix[0, 0]
+    assert run.capture_volume.rigidity_report().rmse_mm < 1.0
+    # the caller's cameras are untouched
+    assert all(np.array_equal(cam.matrix, before[c][0]) and np.array_equal(cam.rotation, before[c][1]) for c, cam in cameras.cameras.items())
+    vol = run.capture_volume
+    if len(vol.world_points) == len(truth["points"]):
+        trans, rot = pose_errors(vol, truth)
+        assert trans < 0.01 and rot < 0.5, (trans, rot)
+
+
+@pytest.mark.parametrize("kind", ["numpy", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_calibrate_extrinsics_blind_intrinsics(kind):
+    """Cameras without intrinsics start from f = width / 2 and no distortion (the product workflow, reference
+    TestEndToEndBlind): the pipeline converges, reports every camera as synthesised and recovers the focal length (3 % here:
+    the blind model has p1 = p2 = k3 = 0, the true lens does not) and the board's rigidity."""
+    from caliscope_amd.calibrate_extrinsics import calibrate_extrinsics
+
+    image_points, cameras, constraints, truth = _board_session(strip=True)
+    run = calibrate_extrinsics(image_points, cameras, constraints, **_engine_kwargs(kind))
+    assert run.capture_volume.optimization_status.converged
+    assert run.synthesized_cam_ids == frozenset(cameras.cameras)
+    for est in run.intrinsic_estimates:
+        f_true = truth["cameras"].cameras[est.cam_id].matrix[0, 0]
+        assert est.f_initial == 960.0 and est.k1_initial == 0.0
+        assert abs(est.f_recovered - f_true) < 0.03 * f_true, (est.cam_id, est.f_recovered)
+    assert run.capture_volume.rigidity_report().rmse_mm < 2.0
+
+
+def test_calibrate_extrinsics_input_guards():
+    from copy import deepcopy
+
+    from caliscope_amd.calibrate_extrinsics import calibrate_extrinsics
+    from caliscope_amd.exceptions import CalibrationError
+
+    image_points, cameras, constraints, _ = _board_session(strip=True, with_obj_loc=False)
+    with pytest.raises(CalibrationError, match="Epipolar bootstrap requires calibrated intrinsics"):
+        calibrate_extrinsics(image_points, cameras, constraints, _triangulate=_oracle_triangulate)
+
+    class Token:
+        is_cancelled = True
+
+    image_points, cameras, constraints, _ = _board_session()
+    with pytest.raises(InterruptedError):
+        calibrate_extrinsics(image_points, cameras, constraints, cancellation_token=Token(), _triangulate=_oracle_triangulate)
+    unposed = deepcopy(cameras)
+    unposed.cameras[2].rotation = unposed.cameras[2].translation = None
+    with pytest.raises(CalibrationError, match=r"Cameras \[2\] have observations but no pose"):
+        calibrate_extrinsics(image_points, unposed, constraints, _triangulate=_oracle_triangulate)
+    fewer = deepcopy(cameras)
+    del fewer.cameras[3]
+    with pytest.raises(CalibrationError, match="not in the CameraArray"):
+        calibrate_extrinsics(image_points, fewer, constraints, _triangulate=_oracle_triangulate)
+
+
+def test_two_sided_extraction_guard_and_cross_face_count():
+    """Reference tests/test_calibrate_extrinsics.py:182-232."""
+    import pandas as pd
+
+    from caliscope_amd.calibrate_extrinsics import _count_firing_cross_face_rows, _validate_two_sided_extraction
+    from caliscope_amd.constraints import DistanceConstraint
+    from caliscope_amd.exceptions import CalibrationError
+    from caliscope_amd.point_data import ImagePoints
+
+    def points(object_ids, back_z=0.006):
+        return ImagePoints(pd.DataFrame([dict(sync_index=0, cam_id=0, object_id=o, keypoint_id=k, img_loc_x=100.0, img_loc_y=100.0,
+                                              obj_loc_x=0.05 * k, obj_loc_y=0.0, obj_loc_z=back_z if o == 1 else 0.0)
+                                         for o in object_ids for k in (0, 1)]))
+
+    _validate_two_sided_extraction(points([0]), thickness_m=0.0)
+    _validate_two_sided_extraction(points([0, 1]), thickness_m=0.006)
+    with pytest.raises(CalibrationError, match="no back-face observations"):
+        _validate_two_sided_extraction(points([0]), thickness_m=0.006)
+    with pytest.raises(CalibrationError, match="thickness is 0"):
+        _validate_two_sided_extraction(points([0, 1]), thickness_m=0.0)
+    with pytest.raises(CalibrationError, match="thickness changed"):
+        _validate_two_sided_extraction(points([0, 1], back_z=0.006), thickness_m=0.012)
+
+    cross = lambda a, b: DistanceConstraint(object_id_a=0, keypoint_id_a=a, object_id_b=1, keypoint_id_b=b, distance=0.006, sigma=0.0005)
+    world = pd.DataFrame([dict(sync_index=5, object_id=0, keypoint_id=0), dict(sync_index=5, object_id=1, keypoint_id=0),
+                          dict(sync_index=6, object_id=0, keypoint_id=1), dict(sync_index=7, object_id=1, keypoint_id=1)])
+    assert _count_firing_cross_face_rows(world, (cross(0, 0), cross(1, 1))) == 1
+    intra = DistanceConstraint(object_id_a=0, keypoint_id_a=0, object_id_b=0, keypoint_id_b=1, distance=0.05, sigma=0.002)
+    assert _count_firing_cross_face_rows(world.iloc[:1], (intra,)) == 0
