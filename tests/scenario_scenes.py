@@ -107,3 +107,45 @@ def pose_errors(volume, truth):
         w = np.array([rel[2, 1] - rel[1, 2], rel[0, 2] - rel[2, 0], rel[1, 0] - rel[0, 1]])
         ang = max(ang, float(np.arctan2(0.5 * np.linalg.norm(w), 0.5 * (np.trace(rel) - 1.0))))
     return trans, float(np.degrees(ang))
+
+
+def chain_volume(n_cams=6, spacing=1.0, n_points=600, noise_px=0.5, seed=42):
+    """Cameras in a row looking the same way; every point is seen by one pair of neighbours only, so the co-visibility
+    graph is a chain (tridiagonal coverage, the reference's ``chain_scene``): errors accumulate towards the ends and the
+    reduced camera system is block-tridiagonal."""
+    from caliscope_amd.synthetic import WEBCAM_DIST, WEBCAM_FOCAL
+
+    rng = np.random.default_rng(seed)
+    w, h = WEBCAM_SIZE
+    K = np.array([[WEBCAM_FOCAL, 0, w / 2.0], [0, WEBCAM_FOCAL, h / 2.0], [0, 0, 1.0]])
+    R = np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])  # camera z = world y (looking along +y), image y = world -z
+    cams = {c: CameraData(cam_id=c, size=WEBCAM_SIZE, matrix=K.copy(), distortions=np.array(WEBCAM_DIST), rotation=R.copy(),
+                          translation=-R @ np.array([c * spacing, 0.0, 0.0])) for c in range(n_cams)}
+    truth_cams = CameraArray(cams)
+    per_pair = n_points // (n_cams - 1)
+    pts, cam_idx, uv, obj = [], [], [], []
+    for pair in range(n_cams - 1):
+        got = 0
+        while got < per_pair:
+            X = np.c_[rng.uniform(pair * spacing - 0.3, (pair + 1) * spacing + 0.3, 64), rng.uniform(2.0, 4.0, 64), rng.uniform(-0.7, 0.7, 64)]
+            ok = np.ones(len(X), dtype=bool)
+            proj = []
+            for c in (pair, pair + 1):
+                cam = cams[c]
+                p, z = project_pinhole_bc5(X, cam.rotation, cam.translation, K[0, 0], K[1, 1], K[0, 2], K[1, 2], cam.distortions)
+                ok &= (z > 0.1) & (p[:, 0] >= 0) & (p[:, 0] < w) & (p[:, 1] >= 0) & (p[:, 1] < h)
+                proj.append(p)
+            for i in np.flatnonzero(ok)[: per_pair - got]:
+                for c, p in zip((pair, pair + 1), proj):
+                    cam_idx.append(c)
+                    uv.append(p[i])
+                    obj.append(len(pts))
+                pts.append(X[i])
+                got += 1
+    pts, uv = np.array(pts), np.array(uv) + rng.normal(0, noise_px, (len(uv), 2))
+    init = CameraArray({c: CameraData(cam_id=c, size=cam.size, matrix=cam.matrix.copy(), distortions=cam.distortions.copy(),
+                                      rotation=rvec_to_matrix(matrix_to_rvec(cam.rotation) + rng.normal(0, 0.01, 3)),
+                                      translation=cam.translation + rng.normal(0, 0.02, 3)) for c, cam in cams.items()})
+    vol = CaptureVolume.from_arrays(init, np.array(cam_idx, dtype=np.int32), uv, np.array(obj, dtype=np.int32),
+                                    pts + rng.normal(0, 0.01, pts.shape))
+    return vol, dict(cameras=truth_cams, points=pts)

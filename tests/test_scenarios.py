@@ -176,3 +176,35 @@ def test_large_ring(factory):
     assert opt.optimization_status.converged and _report(opt, factory).overall_rmse < 2.0
     trans, rot = pose_errors(opt, truth)
     assert rot < 0.5 and trans < 0.005, (trans, rot)
+
+
+def test_stationary_planar_board(factory):
+    """Globally coplanar, redundant frames (reference tests/synthetic/test_planar_degeneracy.py:46-76): with fixed
+    intrinsics there is no extra degeneracy — valid poses at 4x the ring tolerances."""
+    vol, truth = moving_board_volume(radius=2.0, rows=4, cols=6, spacing=0.05, n_frames=10, stationary=True, start=(0.0, 0.0, 0.5))
+    opt = vol.optimize(strict=False, _engine_factory=factory)
+    assert _report(opt, factory).overall_rmse < 5.0
+    trans, rot = pose_errors(opt, truth)
+    assert rot < 2.0 and trans < 0.020, (trans, rot)
+
+
+def test_chain_linked_cameras(factory):
+    """Every point is shared by one pair of neighbouring cameras only (reference tests/synthetic/test_chain_linked.py:52-97):
+    the solve may stop on max_nfev, poses stay within the reference's ceilings and the scale stays metric."""
+    from tests.helpers import camera_centres_and_rotations, umeyama
+    from tests.scenario_scenes import chain_volume
+
+    vol, truth = chain_volume()
+    df = vol.image_points.df
+    pairs = df.groupby("object_id")["cam_id"].agg(lambda c: tuple(sorted(c)))
+    assert all(b - a == 1 for a, b in pairs)  # tridiagonal coverage
+    opt = vol.optimize(strict=False, max_nfev=5000, _engine_factory=factory)
+    trans, rot = pose_errors(opt, truth)
+    assert rot < 10.0 and trans < 1.0, (trans, rot)
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+
+    par = BundleParameterization.from_camera_array(opt.camera_array, n_points=len(truth["points"]), refine_intrinsics=False)
+    got, _ = camera_centres_and_rotations(par, par.pack(opt.camera_array, opt.world_points.points))
+    ref, _ = camera_centres_and_rotations(par, par.pack(truth["cameras"], truth["points"]))
+    scale, _, _ = umeyama(got, ref)
+    assert abs(scale - 1.0) < 0.02, scale
