@@ -51,6 +51,23 @@ class OptimizationStatus:
     bound_warnings: tuple = ()
 
 
+def _group_index(keys: np.ndarray):
+    """``(unique_sorted_keys, inverse)`` like ``np.unique(keys, return_inverse=True)`` for integer keys.  Ids here
+    (cameras, points, keypoints) are small and dense, so a presence table + prefix sum replaces the sort of every
+    observation; widely spread keys fall back to ``np.unique``."""
+    keys = np.asarray(keys, dtype=np.int64)
+    if keys.size == 0:
+        return keys, np.zeros(0, dtype=np.int64)
+    lo, hi = int(keys.min()), int(keys.max())
+    if hi - lo > 4 * keys.size + 1024:
+        return np.unique(keys, return_inverse=True)
+    shifted = keys - lo
+    present = np.zeros(hi - lo + 1, dtype=bool)
+    present[shifted] = True
+    rank = np.cumsum(present, dtype=np.int64) - 1
+    return np.flatnonzero(present) + lo, rank[shifted]
+
+
 @dataclass(frozen=True)
 class ReprojectionReport:
     overall_rmse: float
@@ -140,13 +157,25 @@ class CaptureVolume:
 
     # -- marshalling (reference :346-358) ------------------------------------------------------------
     def _matched_arrays(self):
-        df = self.image_points._df
+        col = self.image_points.arrays()
         index_of = self.camera_array.posed_cam_id_to_index
-        cam_lookup = pd.Series(index_of, dtype="float64")
-        cam_idx = df["cam_id"].map(cam_lookup)
-        mask = (self.img_to_obj_map >= 0) & cam_idx.notna().to_numpy()
-        camera_indices = cam_idx.to_numpy()[mask].astype(np.int32)
-        image_coords = df[["img_loc_x", "img_loc_y"]].to_numpy(dtype=np.float64)[mask]
+        cam_id = col["cam_id"]
+        # cam_id -> position among the posed cameras through a dense table (ids are small non-negative integers)
+        lo = min(int(cam_id.min()), min(index_of, default=0)) if cam_id.size else 0
+        hi = max(int(cam_id.max()), max(index_of, default=0)) if cam_id.size else 0
+        if hi - lo < (1 << 20):
+            table = np.full(hi - lo + 1, -1, dtype=np.int32)
+            for cid, i in index_of.items():
+                table[cid - lo] = i
+            cam_idx = table[cam_id - lo]
+        else:  # sparse ids: binary search in the sorted posed ids
+            ids = np.array(sorted(index_of), dtype=np.int64)
+            pos = np.array([index_of[c] for c in ids], dtype=np.int32)
+            at = np.minimum(np.searchsorted(ids, cam_id), len(ids) - 1) if len(ids) else np.zeros(cam_id.shape, dtype=np.int64)
+            cam_idx = np.where(ids[at] == cam_id, pos[at], -1).astype(np.int32) if len(ids) else np.full(cam_id.shape, -1, dtype=np.int32)
+        mask = (self.img_to_obj_map >= 0) & (cam_idx >= 0)
+        camera_indices = cam_idx[mask]
+        image_coords = np.stack([col["img_loc_x"][mask], col["img_loc_y"][mask]], axis=1)
         obj_indices = self.img_to_obj_map[mask].astype(np.int32)
         return mask, camera_indices, image_coords, obj_indices
 
@@ -217,12 +246,10 @@ class CaptureVolume:
             final_cost=float(result.cost),
             bound_warnings=par.bound_warnings(result.x),
         )
-        world_df = self.world_points.df
-        world_df[["x_coord", "y_coord", "z_coord"]] = new_points
         return CaptureVolume(
             camera_array=new_cameras,
             image_points=self.image_points,
-            world_points=WorldPoints(world_df),
+            world_points=self.world_points.with_points(new_points),
             constraints=self.constraints,
             _optimization_status=status,
             _known_map=self.img_to_obj_map,
@@ -345,11 +372,12 @@ class CaptureVolume:
         obj_id, kp_id = col["object_id"].astype(np.int64), col["keypoint_id"].astype(np.int64)
         kp_lo = int(kp_id.min()) if kp_id.size else 0
         span = int(kp_id.max()) - kp_lo + 1 if kp_id.size else 1
-        keys, inv = np.unique(obj_id * span + (kp_id - kp_lo), return_inverse=True)
+        keys, inv = _group_index(obj_id * span + (kp_id - kp_lo))
         mean_sq = np.bincount(inv, weights=sq, minlength=keys.size) / np.maximum(np.bincount(inv, minlength=keys.size), 1)
         by_point = dict(zip(zip((keys // span).tolist(), (keys % span + kp_lo).tolist()), np.sqrt(mean_sq).tolist()))
-        cams_all, n_all = np.unique(all_df["cam_id"].to_numpy(), return_counts=True)
-        cams_ok, n_ok = np.unique(col["cam_id"], return_counts=True)
+        cams_all, inv_all = _group_index(all_df["cam_id"].to_numpy())
+        cams_ok, inv_ok = _group_index(col["cam_id"])
+        n_all, n_ok = np.bincount(inv_all, minlength=cams_all.size), np.bincount(inv_ok, minlength=cams_ok.size)
         total_by_cam, matched_by_cam = dict(zip(cams_all.tolist(), n_all.tolist())), dict(zip(cams_ok.tolist(), n_ok.tolist()))
         unmatched_by_camera = {
             int(c): int(total_by_cam.get(c, 0) - matched_by_cam.get(c, 0)) for c in self.camera_array.cameras
@@ -374,24 +402,27 @@ class CaptureVolume:
         raw = report.raw_errors
         err = raw["euclidean_error"].to_numpy()
         cam = raw["cam_id"].to_numpy()
-        keep = err <= raw["cam_id"].map(thresholds).to_numpy(dtype=np.float64)
-        for cam_id in np.unique(cam):
-            idx = np.flatnonzero(cam == cam_id)
-            n_keep = int(keep[idx].sum())
-            if n_keep < min_per_camera and n_keep < idx.size:
-                n_needed = min(min_per_camera, idx.size) - n_keep
-                dropped = np.sort(err[idx][~keep[idx]])
-                if dropped.size >= n_needed:
-                    keep[idx] = err[idx] <= dropped[n_needed - 1]
+        cams, inv = _group_index(cam)
+        keep = err <= np.array([thresholds[int(c)] for c in cams], dtype=np.float64)[inv]
+        kept_per_cam = np.bincount(inv, weights=keep, minlength=len(cams)).astype(np.int64)
+        rows_per_cam = np.bincount(inv, minlength=len(cams))
+        for k in np.flatnonzero((kept_per_cam < min_per_camera) & (kept_per_cam < rows_per_cam)):  # safety floor: rarely any
+            idx = np.flatnonzero(inv == k)
+            n_needed = min(min_per_camera, idx.size) - int(kept_per_cam[k])
+            dropped = np.sort(err[idx][~keep[idx]])
+            if dropped.size >= n_needed:
+                keep[idx] = err[idx] <= dropped[n_needed - 1]
         mask, *_ = self._matched_arrays()
         keep_rows = np.zeros(len(mask), dtype=bool)  # like the reference's inner merge: unmatched rows go too
         keep_rows[np.flatnonzero(mask)[keep]] = True
-        img_df = self.image_points._df[keep_rows].reset_index(drop=True)
-        obj = self.img_to_obj_map[keep_rows]
+        obj = self.img_to_obj_map[keep_rows]  # all >= 0: kept rows are matched rows
         seen = np.zeros(len(self.world_points), dtype=bool)
-        seen[obj[obj >= 0]] = True
-        world_df = self.world_points._df[seen].reset_index(drop=True)
-        return CaptureVolume(self.camera_array, ImagePoints(img_df), WorldPoints(world_df), self.constraints)
+        seen[obj] = True
+        # the surviving observations keep their world point, whose row number drops by the pruned rows before it: the new
+        # volume gets its observation -> point map from the old one instead of a merge over every observation
+        new_row = np.cumsum(seen, dtype=np.int64) - 1
+        return CaptureVolume(self.camera_array, self.image_points.take(keep_rows), self.world_points.take(seen), self.constraints,
+                             _known_map=new_row[obj].astype(np.int32))
 
     def filter_by_percentile_error(self, percentile: float, scope: str = "per_camera", min_per_camera: int = 10,
                                    _engine_factory=None) -> "CaptureVolume":
@@ -407,10 +438,17 @@ class CaptureVolume:
         raw = report.raw_errors
         keep_percentile = 100 - percentile
         if scope == "per_camera":
-            thresholds = {}
-            for cam_id in self.camera_array.posed_cameras:
-                e = raw.loc[raw["cam_id"] == cam_id, "euclidean_error"]
-                thresholds[cam_id] = float(np.percentile(e, keep_percentile)) if len(e) else float(np.inf)
+            # one stable sort by camera instead of a boolean selection over every observation per camera
+            err, cam = raw["euclidean_error"].to_numpy(), raw["cam_id"].to_numpy()
+            cams, inv = _group_index(cam)
+            # numpy's stable sort of 16-bit keys is a radix sort
+            order = np.argsort(inv.astype(np.int16) if cams.size < 32768 else inv, kind="stable")
+            start = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=cams.size))[:-1]]).astype(np.int64)
+            stop = np.append(start[1:], len(order))
+            thresholds = {cam_id: float(np.inf) for cam_id in self.camera_array.posed_cameras}
+            for c, a, b in zip(cams.tolist(), start.tolist(), stop.tolist()):
+                if c in thresholds:
+                    thresholds[c] = float(np.percentile(err[order[a:b]], keep_percentile))
         else:
             thr = float(np.percentile(raw["euclidean_error"], keep_percentile))
             thresholds = {cam_id: thr for cam_id in self.camera_array.posed_cameras}

@@ -87,6 +87,25 @@ class ImagePoints:
 
     def __init__(self, df: pd.DataFrame):
         self._df = _validated(df, IMAGE_POINT_COLUMNS, IMAGE_POINT_OPTIONAL, "ImagePoints")
+        self._arrays = None
+
+    def take(self, rows) -> "ImagePoints":
+        """The rows selected by a boolean mask or an index array, re-indexed from 0.  A subset of a validated table is
+        valid, so nothing is re-checked (the filters between solver passes use this)."""
+        out = object.__new__(ImagePoints)
+        out._df = self._df[rows].reset_index(drop=True) if np.asarray(rows).dtype == bool else self._df.iloc[rows].reset_index(drop=True)
+        out._arrays = None
+        return out
+
+    def arrays(self) -> dict:
+        """The required columns as numpy arrays (read-only, built once: the table is immutable) — the marshalling of
+        ``CaptureVolume.optimize`` and the report work on these instead of going through pandas on every call."""
+        if self._arrays is None:
+            cols = {c: self._df[c].to_numpy() for c in IMAGE_POINT_COLUMNS}
+            for a in cols.values():
+                a.setflags(write=False)
+            self._arrays = cols
+        return self._arrays
 
     @property
     def df(self) -> pd.DataFrame:
@@ -139,7 +158,35 @@ class WorldPoints:
 
     @property
     def points(self) -> np.ndarray:
-        return self._df[["x_coord", "y_coord", "z_coord"]].to_numpy(dtype=np.float64)
+        xyz = getattr(self, "_xyz", None)
+        if xyz is None:
+            xyz = self._xyz = self._df[["x_coord", "y_coord", "z_coord"]].to_numpy(dtype=np.float64)
+        return xyz.copy()
+
+    def take(self, rows) -> "WorldPoints":
+        """Row subset (boolean mask or index array) of a validated table, re-indexed from 0, without re-validation."""
+        out = object.__new__(WorldPoints)
+        out._df = self._df[rows].reset_index(drop=True) if np.asarray(rows).dtype == bool else self._df.iloc[rows].reset_index(drop=True)
+        sync = out._df["sync_index"].to_numpy()
+        moving = sync[sync != STATIC_SYNC_INDEX]
+        out.min_index = int(moving.min()) if moving.size else 0
+        out.max_index = int(moving.max()) if moving.size else 0
+        return out
+
+    def with_points(self, xyz) -> "WorldPoints":
+        """The same keys with new coordinates — what ``CaptureVolume.optimize`` returns its points in.  The table was
+        validated when this object was built, so only the new block is checked (finite ``(P, 3)`` floats) instead of
+        re-validating every column, which costs more than a small solve."""
+        xyz = np.asarray(xyz, dtype=np.float64)
+        if xyz.shape != (len(self._df), 3):
+            raise ValueError(f"expected {(len(self._df), 3)} coordinates, got {xyz.shape}")
+        if not np.isfinite(xyz).all():
+            raise ValueError("WorldPoints validation failed: non-finite coordinates")
+        out = object.__new__(WorldPoints)
+        df = self._df.copy()
+        df[["x_coord", "y_coord", "z_coord"]] = xyz
+        out._df, out.min_index, out.max_index, out._xyz = df, self.min_index, self.max_index, xyz.copy()
+        return out
 
     def __len__(self) -> int:
         return len(self._df)

@@ -89,3 +89,62 @@ def test_world_point_index_range_ignores_static_rows():
     assert (wp.min_index, wp.max_index) == (5, 9)
     static_only = WorldPoints(pd.DataFrame([dict(base, sync_index=STATIC_SYNC_INDEX), dict(base, sync_index=STATIC_SYNC_INDEX, keypoint_id=1)]))
     assert (static_only.min_index, static_only.max_index) == (0, 0)
+
+
+def test_world_points_with_points_and_cached_columns():
+    """The fast paths of ``CaptureVolume.optimize``: new coordinates on validated keys, numpy views of the observation table."""
+    import pandas as pd
+    import pytest
+
+    from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+    world = WorldPoints(pd.DataFrame({"sync_index": [0, 0, 1], "object_id": 0, "keypoint_id": [0, 1, 0], "x_coord": [0.0, 1.0, 2.0],
+                                      "y_coord": 0.5, "z_coord": [1.0, 1.0, 1.5], "frame_time": [0.0, 0.0, 0.1]}))
+    xyz = np.arange(9.0).reshape(3, 3)
+    moved = world.with_points(xyz)
+    assert np.array_equal(moved.points, xyz) and np.array_equal(moved.df[["x_coord", "y_coord", "z_coord"]].to_numpy(), xyz)
+    assert np.array_equal(world.points[:, 0], [0.0, 1.0, 2.0])  # the source table is untouched
+    assert moved.df[["sync_index", "object_id", "keypoint_id", "frame_time"]].equals(world.df[["sync_index", "object_id", "keypoint_id", "frame_time"]])
+    assert (moved.min_index, moved.max_index) == (world.min_index, world.max_index) == (0, 1)
+    pts = moved.points
+    pts[:] = -1.0
+    assert np.array_equal(moved.points, xyz)  # `points` hands out copies
+    with pytest.raises(ValueError):
+        world.with_points(np.zeros((2, 3)))
+    with pytest.raises(ValueError, match="non-finite"):
+        world.with_points(np.full((3, 3), np.nan))
+
+    img = ImagePoints(pd.DataFrame({"sync_index": [0, 0], "cam_id": [1, 2], "object_id": 0, "keypoint_id": [0, 0], "img_loc_x": [10.0, 20.0],
+                                    "img_loc_y": [1.0, 2.0]}))
+    cols = img.arrays()
+    assert cols is img.arrays() and set(cols) == {"sync_index", "cam_id", "object_id", "keypoint_id", "img_loc_x", "img_loc_y"}
+    assert cols["cam_id"].dtype == np.int64 and cols["img_loc_x"].dtype == np.float64
+    with pytest.raises(ValueError):
+        cols["img_loc_x"][0] = 0.0
+
+
+def test_marshalling_with_sparse_and_unposed_camera_ids():
+    """Observation -> camera-position mapping: cameras without a pose and ids that do not appear in the array drop out, ids
+    far apart take the search path instead of the dense table."""
+    import pandas as pd
+
+    from caliscope_amd.cameras import CameraArray, CameraData
+    from caliscope_amd.capture_volume import CaptureVolume
+    from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+    K = np.array([[800.0, 0, 320], [0, 800.0, 240], [0, 0, 1]])
+
+    def cam(cid, posed=True):
+        return CameraData(cam_id=cid, size=(640, 480), matrix=K.copy(), distortions=np.zeros(5), rotation=np.eye(3) if posed else None,
+                          translation=np.array([0.0, 0.0, 2.0]) if posed else None)
+
+    for ids in ((3, 5, 9), (3, 5, 4_000_000)):
+        array = CameraArray({ids[0]: cam(ids[0]), ids[1]: cam(ids[1], posed=False), ids[2]: cam(ids[2])})
+        img = ImagePoints(pd.DataFrame({"sync_index": 0, "cam_id": [ids[0], ids[1], ids[2], ids[2], 77], "object_id": 0,
+                                        "keypoint_id": [0, 0, 0, 1, 0], "img_loc_x": [1.0, 2.0, 3.0, 4.0, 5.0], "img_loc_y": 0.0}))
+        world = WorldPoints(pd.DataFrame({"sync_index": 0, "object_id": 0, "keypoint_id": [0, 1], "x_coord": 0.0, "y_coord": 0.0, "z_coord": 0.0}))
+        vol = CaptureVolume(array, img, world)
+        mask, cam_idx, uv, obj = vol._matched_arrays()
+        assert mask.tolist() == [True, False, True, True, False]
+        assert cam_idx.tolist() == [0, 1, 1] and obj.tolist() == [0, 0, 1] and uv[:, 0].tolist() == [1.0, 3.0, 4.0]
+        assert cam_idx.dtype == np.int32 and obj.dtype == np.int32

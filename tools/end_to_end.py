@@ -44,3 +44,5 @@ print(f"optimize(): {t_opt:.3f} s total, status {st.termination_reason}, {st.ite
 print(f"  marshalling DataFrames -> arrays {t_marshal:.3f} s | engine set-up (sort, plan, upload) {t_create:.3f} s | "
       f"solve {t_solve:.3f} s ({res.nfev} evaluations) | rest (deepcopy, unpack, new volume) {max(t_opt - t_marshal - t_create - t_solve, 0):.3f} s")
 print(f"reprojection_report (device residuals + group-bys): {t_rep:.3f} s, RMS {rep.overall_rmse:.4f} px")
+t = time.perf_counter(); flt = out.filter_by_percentile_error(2.5); t_flt = time.perf_counter() - t
+print(f"filter_by_percentile_error(2.5) on the cached report: {t_flt:.3f} s ({len(out.image_points) - len(flt.image_points)} observations removed)")
