@@ -149,3 +149,71 @@ def chain_volume(n_cams=6, spacing=1.0, n_points=600, noise_px=0.5, seed=42):
     vol = CaptureVolume.from_arrays(init, np.array(cam_idx, dtype=np.int32), uv, np.array(obj, dtype=np.int32),
                                     pts + rng.normal(0, 0.01, pts.shape))
     return vol, dict(cameras=truth_cams, points=pts)
+
+
+def two_sided_board_session(n_cams=6, radius=2.0, n_frames=30, rows=4, cols=6, spacing=0.05, thickness=0.006, noise_px=0.5, seed=42,
+                            fused=False):
+    """A thick board filmed from all around: a camera on the +z side of the board sees the back face (object 1, corners at
+    board z = +thickness), a camera on the -z side the front face (object 0, z = 0) — never both in one frame (the reference's
+    ``two_sided_charuco_scene``).  ``fused`` relabels everything as object 0 at z = 0, the pre-thickness treatment.
+    Returns ``(image_points, cameras_init, constraints, truth)`` as ``calibrate_extrinsics`` takes them."""
+    rng = np.random.default_rng(seed)
+    cams = ring_camera_array(n_cams, radius=radius, target=(0.0, 0.0, 0.5))
+    grid = np.array([[c * spacing, r * spacing, 0.0] for r in range(rows) for c in range(cols)])
+    centre_off = grid.mean(axis=0)
+    w, h = WEBCAM_SIZE
+    rows_out, truth_pts = [], {}
+    for f in range(n_frames):
+        s = f / max(n_frames - 1, 1)
+        # the board stands upright and turns about the vertical axis while drifting through the volume
+        yaw = 2 * np.pi * 1.5 * s + 0.3
+        R = rvec_to_matrix(np.array([0.0, 0.0, yaw])) @ rvec_to_matrix(np.array([np.pi / 2 + 0.2 * np.sin(5 * s), 0.0, 0.0]))
+        centre = np.array([0.3 * np.cos(3 * s), 0.3 * np.sin(2 * s), 0.5 + 0.1 * np.sin(4 * s)])
+        normal = R[:, 2]
+        faces = {0: (grid - centre_off) @ R.T + centre, 1: (grid - centre_off + [0, 0, thickness]) @ R.T + centre}
+        for c, cam in sorted(cams.cameras.items()):
+            cam_centre = -cam.rotation.T @ cam.translation
+            view = cam_centre - centre
+            cosang = float(normal @ view / np.linalg.norm(view))
+            if abs(cosang) < 0.25:
+                continue  # grazing view: the tracker would not detect the board
+            face = 1 if cosang > 0 else 0
+            X = faces[face]
+            K = cam.matrix
+            p, z = project_pinhole_bc5(X, cam.rotation, cam.translation, K[0, 0], K[1, 1], K[0, 2], K[1, 2], cam.distortions)
+            ok = (z > 0.1) & (p[:, 0] >= 0) & (p[:, 0] < w) & (p[:, 1] >= 0) & (p[:, 1] < h)
+            p = p + rng.normal(0, noise_px, p.shape)
+            for k in np.flatnonzero(ok):
+                rows_out.append(dict(sync_index=f, cam_id=c, object_id=0 if fused else face, keypoint_id=int(k), img_loc_x=p[k, 0], img_loc_y=p[k, 1],
+                                     obj_loc_x=grid[k, 0], obj_loc_y=grid[k, 1], obj_loc_z=0.0 if fused or face == 0 else thickness))
+                truth_pts[(f, face, int(k))] = X[k]
+    init = CameraArray({c: CameraData(cam_id=c, size=cam.size, matrix=cam.matrix.copy(), distortions=cam.distortions.copy(),
+                                      rotation=rvec_to_matrix(matrix_to_rvec(cam.rotation) + rng.normal(0, 0.01, 3)),
+                                      translation=cam.translation + rng.normal(0, 0.01, 3)) for c, cam in cams.cameras.items()})
+    cs = ConstraintSet.from_grid(grid.astype(np.float32), spacing, thickness_m=0.0 if fused else thickness)
+    return ImagePoints(pd.DataFrame(rows_out)), init, cs, dict(cameras=cams, points=truth_pts)
+
+
+def keyed_errors(volume, truth):
+    """Worst camera position error (m), rotation error (deg) and world-point RMSE (m) against a ground truth keyed by
+    ``(sync_index, object_id, keypoint_id)``, after a similarity alignment on cameras + matched points."""
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+    from tests.helpers import camera_centres_and_rotations, umeyama
+
+    df = volume.world_points.df
+    keys = list(zip(df["sync_index"].tolist(), df["object_id"].tolist(), df["keypoint_id"].tolist()))
+    has = np.array([k in truth["points"] for k in keys])
+    got_pts = df[["x_coord", "y_coord", "z_coord"]].to_numpy()[has]
+    true_pts = np.array([truth["points"][k] for k, ok in zip(keys, has) if ok])
+    par = BundleParameterization.from_camera_array(volume.camera_array, n_points=1, refine_intrinsics=False)
+    ca, Ra = camera_centres_and_rotations(par, par.pack(volume.camera_array, np.zeros((1, 3))))
+    cb, Rb = camera_centres_and_rotations(par, par.pack(truth["cameras"], np.zeros((1, 3))))
+    s, R, t = umeyama(np.vstack([ca, got_pts]), np.vstack([cb, true_pts]))
+    trans = float(np.linalg.norm(s * ca @ R.T + t - cb, axis=1).max())
+    ang = 0.0
+    for A, B in zip(Ra, Rb):
+        rel = (A @ R.T) @ B.T
+        wv = np.array([rel[2, 1] - rel[1, 2], rel[0, 2] - rel[2, 0], rel[1, 0] - rel[0, 1]])
+        ang = max(ang, float(np.arctan2(0.5 * np.linalg.norm(wv), 0.5 * (np.trace(rel) - 1.0))))
+    rmse = float(np.sqrt(np.mean(np.sum((s * got_pts @ R.T + t - true_pts) ** 2, axis=1))))
+    return trans, float(np.degrees(ang)), rmse

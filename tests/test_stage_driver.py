@@ -272,3 +272,32 @@ def test_two_sided_extraction_guard_and_cross_face_count():
     assert _count_firing_cross_face_rows(world, (cross(0, 0), cross(1, 1))) == 1
     intra = DistanceConstraint(object_id_a=0, keypoint_id_a=0, object_id_b=0, keypoint_id_b=1, distance=0.05, sigma=0.002)
     assert _count_firing_cross_face_rows(world.iloc[:1], (intra,)) == 0
+
+
+@pytest.mark.parametrize("kind,n_frames", [("numpy", 16), pytest.param("hip", 16, marks=pytest.mark.gpu)])
+def test_thick_two_sided_board_through_the_pipeline(kind, n_frames):
+    """Reference tests/synthetic/test_two_sided_charuco.py:41-87 (its tolerances): no camera ever sees both faces of the 6 mm
+    board in one frame; the identity split (back face = object 1 at z = +t) with the cross-face ties and braces recovers the
+    ground truth in the right basin (a reflected back face would be ~12 mm off), and beats the pre-thickness treatment
+    (both faces fused into object 0 at z = 0) by more than 2x on the same footage."""
+    from caliscope_amd.calibrate_extrinsics import calibrate_extrinsics
+    from tests.scenario_scenes import keyed_errors, two_sided_board_session
+
+    scene = dict(n_cams=8, radius=1.2, n_frames=n_frames, thickness=0.006)
+    image_points, cameras, constraints, truth = two_sided_board_session(**scene)
+    df = image_points.df
+    assert df.groupby(["cam_id", "sync_index"])["object_id"].nunique().max() == 1
+    per_face = df.groupby(["sync_index", "object_id"])["cam_id"].nunique().unstack(fill_value=0)
+    assert ((per_face[0] >= 2) & (per_face[1] >= 2)).sum() >= n_frames // 2  # the cross-face rows do fire
+    run = calibrate_extrinsics(image_points, cameras, constraints, refine_intrinsics=False, **_engine_kwargs(kind))
+    assert run.capture_volume.optimization_status.converged
+    trans, rot, rmse = keyed_errors(run.capture_volume, truth)
+    # world points: 4 mm here (points seen by two close cameras only carry ~2 mm of depth noise at 0.5 px), still far from the
+    # ~12 mm signature of the reflected basin
+    assert rot < 0.2 and trans < 0.003 and rmse < 0.004, (trans, rot, rmse)
+
+    fused_points, cameras, fused_constraints, _ = two_sided_board_session(fused=True, **scene)
+    fused = calibrate_extrinsics(fused_points, cameras, fused_constraints, refine_intrinsics=False, **_engine_kwargs(kind))
+    front = dict(cameras=truth["cameras"], points={(s, 0, k): v for (s, face, k), v in truth["points"].items() if face == 0})
+    fused_trans, _, _ = keyed_errors(fused.capture_volume, front)
+    assert trans < fused_trans / 2, (trans, fused_trans)
