@@ -113,8 +113,14 @@ class CaptureVolume:
             raise ValueError("No world points provided")
         if len(self.camera_array.posed_cameras) == 0:
             raise ValueError("No posed cameras in array")
-        if int(np.sum(self.img_to_obj_map >= 0)) == 0:
+        n_matched = int(np.sum(self.img_to_obj_map >= 0))
+        if n_matched == 0:
             raise ValueError("No image observations have corresponding world points")
+        if n_matched < 2 * n_world:
+            logger.warning(f"Suspicious geometry: {n_matched} matched observations for {n_world} world points. "
+                           f"Expected at least {n_world * 2} for multi-view geometry.")
+        if int(self.img_to_obj_map.max()) >= n_world:
+            raise ValueError(f"obj_indices contains out-of-bounds index: {int(self.img_to_obj_map.max())} >= {n_world}")
 
     def _compute_img_to_obj_map(self) -> np.ndarray:
         """Row of ``world_points`` for every image observation, -1 when unmatched (vectorised merge).  Observations
