@@ -14,8 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -134,11 +138,35 @@ struct cba_problem {
   hipGraphExec_t chol_exec = nullptr;
 };
 
+// Stream capture and other threads: while one thread records the Cholesky graph, this runtime rejects allocation,
+// memset and synchronous-copy calls of every other thread (they fail, and the capture is invalidated), thread-local capture
+// mode notwithstanding.  The recording takes this lock exclusively; every entry point that talks to the device holds it
+// shared, so handles run concurrently across threads and only wait while another thread records its graph (once per handle).
+static std::shared_mutex g_capture_mu;
+static thread_local int tl_capture_safe_depth = 0;
+struct CaptureSafe {  // shared side; nests within a thread (entry point -> helper)
+  explicit CaptureSafe(std::shared_mutex&) { if (tl_capture_safe_depth++ == 0) g_capture_mu.lock_shared(); }
+  ~CaptureSafe() { if (--tl_capture_safe_depth == 0) g_capture_mu.unlock_shared(); }
+  CaptureSafe(const CaptureSafe&) = delete;
+  CaptureSafe& operator=(const CaptureSafe&) = delete;
+};
+struct CaptureRecording {  // exclusive side; gives the thread's shared hold back for the duration (no upgrade deadlock)
+  bool held = tl_capture_safe_depth > 0;
+  CaptureRecording() { if (held) g_capture_mu.unlock_shared(); g_capture_mu.lock(); }
+  ~CaptureRecording() { g_capture_mu.unlock(); if (held) g_capture_mu.lock_shared(); }
+};
+static hipError_t guarded_malloc(void** ptr, size_t bytes) { CaptureSafe g(g_capture_mu); return hipMalloc(ptr, bytes); }
+static hipError_t guarded_free(void* ptr) { CaptureSafe g(g_capture_mu); return hipFree(ptr); }
+static hipError_t guarded_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  CaptureSafe g(g_capture_mu);
+  return hipMemcpy(dst, src, bytes, kind);
+}
+
 template <typename T>
 static int dev_alloc(cba_problem* p, T** out, size_t count) {
   void* ptr = nullptr;
   size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-  HIPCHK(hipMalloc(&ptr, bytes));
+  HIPCHK(guarded_malloc(&ptr, bytes));
   p->allocs.push_back(ptr);
   p->device_bytes += (long)bytes;
   *out = static_cast<T*>(ptr);
@@ -148,7 +176,7 @@ template <typename T>
 static int dev_upload(cba_problem* p, T** out, const std::vector<T>& h) {
   int rc = dev_alloc(p, out, h.size());
   if (rc) return rc;
-  if (!h.empty()) HIPCHK(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!h.empty()) HIPCHK(guarded_memcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return CBA_OK;
 }
 
@@ -242,6 +270,7 @@ static inline int vec_grid(long total) { return (int)std::min<long>((total + BLO
 extern "C" {
 
 int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_out, double* undistorted_out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!d || !xyz_out) return fail(CBA_ERR_INVALID, "cba_triangulate: null argument");
   if (d->n_cams <= 0 || d->n_points < 0 || !d->cam_P || (d->n_points > 0 && (!d->pt_start || !d->obs_cam || !d->obs_xy)))
     return fail(CBA_ERR_INVALID, "cba_triangulate: bad descriptor");
@@ -255,12 +284,12 @@ int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_o
   for (int64_t i = 0; i < n_obs; ++i)
     if (d->obs_cam[i] < 0 || d->obs_cam[i] >= d->n_cams) return fail(CBA_ERR_INVALID, "cba_triangulate: obs_cam[%lld] out of range", (long long)i);
   std::vector<void*> bufs;
-  auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); };
+  auto cleanup = [&]() { for (void* b : bufs) (void)guarded_free(b); };
   auto up = [&](const void* src, size_t bytes, void** dst) -> int {
     void* ptr = nullptr;
-    if (hipMalloc(&ptr, std::max<size_t>(bytes, 8)) != hipSuccess) return CBA_ERR_HIP;
+    if (guarded_malloc(&ptr, std::max<size_t>(bytes, 8)) != hipSuccess) return CBA_ERR_HIP;
     bufs.push_back(ptr);
-    if (src && bytes && hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CBA_ERR_HIP;
+    if (src && bytes && guarded_memcpy(ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CBA_ERR_HIP;
     *dst = ptr;
     return CBA_OK;
   };
@@ -279,8 +308,8 @@ int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_o
   hipLaunchKernelGGL(k_triangulate, dim3(grid), dim3(BLOCK), 0, 0, (long)d->n_points, (const long*)dps, (const int*)dcam, (const double*)dxy,
                      (const int*)dmodel, (const double*)dintr, (const double*)dP, d->float32_io ? 1 : 0, (double*)dxyz, (double*)dund);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpy(xyz_out, dxyz, (size_t)d->n_points * 3 * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && undistorted_out) e = hipMemcpy(undistorted_out, dund, (size_t)n_obs * 2 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = guarded_memcpy(xyz_out, dxyz, (size_t)d->n_points * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && undistorted_out) e = guarded_memcpy(undistorted_out, dund, (size_t)n_obs * 2 * sizeof(double), hipMemcpyDeviceToHost);
   cleanup();
   if (e != hipSuccess) return fail(CBA_ERR_HIP, "cba_triangulate: %s", hipGetErrorString(e));
   return CBA_OK;
@@ -347,6 +376,7 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
 }
 
 void cba_destroy(cba_problem* p) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
@@ -355,21 +385,39 @@ void cba_destroy(cba_problem* p) {
   if (p->comm) (void)ncclCommDestroy(p->comm);
   if (p->chol_exec) (void)hipGraphExecDestroy(p->chol_exec);
   if (p->chol_graph) (void)hipGraphDestroy(p->chol_graph);
-  for (void* a : p->allocs) (void)hipFree(a);
-  if (p->h_scal) (void)hipHostFree(p->h_scal);
-  if (p->h_flags) (void)hipHostFree(p->h_flags);
-  if (p->h_cam) (void)hipHostFree(p->h_cam);
+  {
+    CaptureSafe g(g_capture_mu);
+    for (void* a : p->allocs) (void)hipFree(a);
+    if (p->h_scal) (void)hipHostFree(p->h_scal);
+    if (p->h_flags) (void)hipHostFree(p->h_flags);
+    if (p->h_cam) (void)hipHostFree(p->h_cam);
+  }
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
 
 }  // extern "C"
 
+// The dynamic-LDS ceiling of a kernel is an attribute of the function, shared by every handle of the process: it only ever
+// grows, so that a handle created later for a smaller problem (fewer cameras) cannot lower it under a live handle that
+// launches the same kernel with more LDS (two CaptureVolumes of different rigs, a worker thread next to the main thread).
+static int raise_lds_ceiling(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> ceiling;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = ceiling[{dev, fn}];
+  if (bytes <= have) return CBA_OK;
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return CBA_OK;
+}
+
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return fail(CBA_ERR_UNSUPPORTED, "kernel needs %zu bytes of LDS (> 160 KiB)", bytes);
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return CBA_OK;
+  return raise_lds_ceiling(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + 8) * 8; }
@@ -797,6 +845,7 @@ static int configure_kernels(cba_problem* p) {
 extern "C" {
 
 int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!d || !out) return fail(CBA_ERR_INVALID, "cba_create: null argument");
   *out = nullptr;
   if (d->n_cams <= 0 || d->n_points <= 0 || d->n_obs <= 0) return fail(CBA_ERR_INVALID, "cba_create: empty problem (cams=%d points=%d obs=%lld)", d->n_cams, d->n_points, (long long)d->n_obs);
@@ -880,14 +929,17 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->n_heavy = (int)heavy.size();
   p->h_heavy_pts = heavy;
 
-  HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocMapped));
-  HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocMapped));
-  HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
-  HIPCHK(hipHostGetDevicePointer((void**)&p->d_hflags, p->h_flags, 0));
+  {
+    CaptureSafe not_while_recording(g_capture_mu);
+    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
+    HIPCHK(hipHostGetDevicePointer((void**)&p->d_hflags, p->h_flags, 0));
+    HIPCHK(hipHostMalloc((void**)&p->h_cam, ((size_t)3 * ncp + 8) * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&p->d_hcam, p->h_cam, 0));
+  }
   std::memset(p->h_scal, 0, 64 * sizeof(double));
-  HIPCHK(hipHostMalloc((void**)&p->h_cam, ((size_t)3 * ncp + 8) * sizeof(double), hipHostMallocMapped));
-  HIPCHK(hipHostGetDevicePointer((void**)&p->d_hcam, p->h_cam, 0));
   std::memset(p->h_cam, 0, ((size_t)3 * ncp + 8) * sizeof(double));
   if (const char* sp = std::getenv("CBA_SPIN")) p->spin_wait = sp[0] != '0';
 
@@ -994,6 +1046,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
 
 int cba_enable_timers(cba_problem* p, int32_t on) { if (!p) return fail(CBA_ERR_INVALID, "null"); p->timers_on = on != 0; return CBA_OK; }
 int cba_reset_timers(cba_problem* p) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "null");
   (void)hipSetDevice(p->device);
   drain_timers(p);
@@ -1001,6 +1054,7 @@ int cba_reset_timers(cba_problem* p) {
   return CBA_OK;
 }
 int cba_get_timers(cba_problem* p, double* ms, int64_t* calls) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "null");
   (void)hipSetDevice(p->device);
   drain_timers(p);
@@ -1232,6 +1286,7 @@ static int run_cholesky(cba_problem* p) {
     return CBA_OK;
   }
   if (!p->chol_exec) {
+    CaptureRecording recording;
     HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
     int rc = enqueue_cholesky(p);
     hipError_t e = hipStreamEndCapture(p->stream, &p->chol_graph);
@@ -1408,6 +1463,7 @@ static int begin_common(cba_problem* p, double* cost_out, bool evaluate = true);
 
 int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, const int32_t* groups_b, const double* distances,
                         const double* weights) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_set_constraints: null problem");
   if (p->begun) return fail(CBA_ERR_INVALID, "cba_set_constraints: call it before cba_begin");
   if (p->con.n_con) return fail(CBA_ERR_INVALID, "cba_set_constraints: constraints are already set");
@@ -1493,6 +1549,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
 }
 
 int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x0 || !cost_out) return fail(CBA_ERR_INVALID, "cba_begin: null argument");
   HIPCHK(hipSetDevice(p->device));
   pack_host(p, x0, p->h_vec.data(), 0.0);
@@ -1502,6 +1559,7 @@ int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
 }
 
 int cba_restart(cba_problem* p, double* cost_out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !cost_out) return fail(CBA_ERR_INVALID, "cba_restart: null argument");
   if (!p->have_x0) return fail(CBA_ERR_INVALID, "cba_restart: call cba_begin first");
   HIPCHK(hipSetDevice(p->device));
@@ -1509,6 +1567,7 @@ int cba_restart(cba_problem* p, double* cost_out) {
 }
 
 int cba_begin_deferred(cba_problem* p, const double* x0) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_begin_deferred: null argument");
   if (!x0 && !p->have_x0) return fail(CBA_ERR_INVALID, "cba_begin_deferred: no x0 on the device yet");
   HIPCHK(hipSetDevice(p->device));
@@ -1547,6 +1606,7 @@ static int begin_common(cba_problem* p, double* cost_out, bool evaluate) {
 }
 
 int cba_linearize(cba_problem* p, cba_linearization* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_linearize: null argument");
   if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_linearize: the problem was created with evaluation_only");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize: call cba_begin first");
@@ -1559,6 +1619,7 @@ int cba_linearize(cba_problem* p, cba_linearization* out) {
 }
 
 int cba_linearize_build(cba_problem* p) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_linearize_build: null argument");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize_build: call cba_begin first");
   if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_linearize_build: the problem was created with evaluation_only");
@@ -1571,6 +1632,7 @@ int cba_linearize_build(cba_problem* p) {
 }
 
 int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_newton_step: null argument");
   if (!p->linearized) return fail(CBA_ERR_INVALID, "cba_newton_step: call cba_linearize first");
   if (!(lam >= 0.0) || !std::isfinite(lam)) return fail(CBA_ERR_INVALID, "cba_newton_step: lam must be finite and >= 0");
@@ -1583,6 +1645,7 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
 }
 
 int cba_step(cba_problem* p, double radius, cba_step_info* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_step: null argument");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_step: call cba_begin first");
   if (!cba_step_supported(p)) return fail(CBA_ERR_UNSUPPORTED, "cba_step: not available for this problem (constraint rows, heavy points, bound scaling or the LDS Schur path): use the primitives");
@@ -1597,6 +1660,7 @@ int cba_step(cba_problem* p, double radius, cba_step_info* out) {
 }
 
 int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: no damped step to measure");
   HIPCHK(hipSetDevice(p->device));
@@ -1621,6 +1685,7 @@ static int upload_cam(cba_problem* p, const double* host, double* dev) {
 
 int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam1, double a2, double b2, const double* cam2,
                          double* gram_out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !gram_out) return fail(CBA_ERR_INVALID, "cba_subspace_gram: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_subspace_gram: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
@@ -1648,6 +1713,7 @@ int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2
 }
 
 int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !mult || !diag_h || !out) return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: null argument");
   if (!p->linearized) return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: call cba_linearize first");
   for (int i = 0; i < p->ncp; ++i)
@@ -1687,6 +1753,7 @@ int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* dia
 int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { return cba_trial_ex(p, alpha, beta, nullptr, out); }
 
 int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_new, cba_trial_info* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_trial: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_trial: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
@@ -1724,6 +1791,7 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
 }
 
 int cba_accept(cba_problem* p) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_accept: null argument");
   if (!p->have_trial) return fail(CBA_ERR_INVALID, "cba_accept: no trial point");
   std::swap(p->x, p->x_new);
@@ -1749,6 +1817,7 @@ int cba_comm_unique_id(char* out128) {
 }
 
 int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !id128) return fail(CBA_ERR_INVALID, "cba_comm_init: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(CBA_ERR_INVALID, "cba_comm_init: rank %d of %d", rank, world);
   if (p->comm) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
@@ -1803,6 +1872,7 @@ static int fetch_camera_blocks(cba_problem* p, const double* const* srcs, double
 }
 
 int cba_get_vector(cba_problem* p, int32_t which, double* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_vector: null argument");
   HIPCHK(hipSetDevice(p->device));
   const double* src = nullptr;
@@ -1815,12 +1885,13 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out) {
     default: return fail(CBA_ERR_INVALID, "cba_get_vector: unknown vector %d", which);
   }
   HIPCHK(hipStreamSynchronize(p->stream));
-  HIPCHK(hipMemcpy(p->h_vec.data(), src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(guarded_memcpy(p->h_vec.data(), src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
   unpack_host(p, p->h_vec.data(), out);
   return CBA_OK;
 }
 
 int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_camera_params: null argument");
   HIPCHK(hipSetDevice(p->device));
   const double* src = nullptr;
@@ -1838,6 +1909,7 @@ int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
 }
 
 int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale_inv_c) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x_c || !g_c || !scale_inv_c) return fail(CBA_ERR_INVALID, "cba_get_camera_state: null argument");
   HIPCHK(hipSetDevice(p->device));
   const double* srcs[3] = {p->x, p->g, p->sinv};
@@ -1846,12 +1918,13 @@ int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale
 }
 
 int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x || !r_out) return fail(CBA_ERR_INVALID, "cba_residuals: null argument");
   HIPCHK(hipSetDevice(p->device));
   // scratch: v2 holds the vector, tab_new the camera table (both are dead between solver calls)
   double* d_r = nullptr;
   const size_t n_rows = (size_t)2 * p->N + (size_t)p->con.n_con;  // reprojection rows, then the constraint rows
-  HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
+  HIPCHK(guarded_malloc((void**)&d_r, n_rows * sizeof(double)));
   pack_host(p, x, p->h_vec.data(), 0.0);
   p->have_trial = false; p->trial_built = false;  // the evaluation borrows the trial point's camera table: a pending trial is gone
   hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
@@ -1862,7 +1935,7 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   }
   int rc = (e == hipSuccess) ? exchange(p, SLOT(24), false) : fail(CBA_ERR_HIP, "cba_residuals: %s", hipGetErrorString(e));
   if (!rc) rc = sync_scalars(p, 32);
-  (void)hipFree(d_r);
+  (void)guarded_free(d_r);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   p->have_trial = false;  // tab_new was overwritten
@@ -1871,6 +1944,7 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
 }
 
 int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, double* gc, double* gp) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x) return fail(CBA_ERR_INVALID, "cba_normal_blocks: null argument");
   HIPCHK(hipSetDevice(p->device));
   if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_normal_blocks: the problem was created with evaluation_only");
@@ -1879,11 +1953,11 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   double cost;
   std::vector<double> saved((size_t)p->lay.total());
   HIPCHK(hipStreamSynchronize(p->stream));
-  HIPCHK(hipMemcpy(saved.data(), p->x, saved.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(guarded_memcpy(saved.data(), p->x, saved.size() * sizeof(double), hipMemcpyDeviceToHost));
   const bool was_begun = p->begun;
   const bool first = p->first_scale;
   pack_host(p, x, p->h_vec.data(), 0.0);
-  HIPCHK(hipMemcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(guarded_memcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
   launch_cam_prep(p, p->x, p->tab);
   DISPATCH_NC(p, run_build<6>(p), run_build<9>(p));
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));  // parity hook: no publish here, leave no flag behind
@@ -1893,7 +1967,7 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   const int ustride = (p->nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   const int tri = (p->nct == 9) ? UPack<9>::TRI : UPack<6>::TRI;
   std::vector<double> hU((size_t)p->C * ustride);
-  HIPCHK(hipMemcpy(hU.data(), p->Upacked, hU.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(guarded_memcpy(hU.data(), p->Upacked, hU.size() * sizeof(double), hipMemcpyDeviceToHost));
   if (U) {
     std::fill(U, U + (size_t)p->C * 81, 0.0);
     for (int c = 0; c < p->C; ++c) {
@@ -1912,19 +1986,19 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
       for (int r = 0; r < p->h_cam_np[c]; ++r) gc[p->h_cam_off[c] + r] = hU[(size_t)c * ustride + tri + r];
   if (V) {
     std::vector<double> hV((size_t)6 * p->lay.Ppad);
-    HIPCHK(hipMemcpy(hV.data(), p->V, hV.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(guarded_memcpy(hV.data(), p->V, hV.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int q = 0; q < p->P; ++q)
       for (int k = 0; k < 6; ++k) V[(size_t)q * 6 + k] = hV[(size_t)k * p->lay.Ppad + q];
   }
   if (gp) {
-    HIPCHK(hipMemcpy(p->h_vec.data(), p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(guarded_memcpy(p->h_vec.data(), p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
     const double* vx = p->h_vec.data() + p->lay.ncp_pad;
     for (int q = 0; q < p->P; ++q) {
       gp[3 * q] = vx[q]; gp[3 * q + 1] = vx[p->lay.Ppad + q]; gp[3 * q + 2] = vx[2 * p->lay.Ppad + q];
     }
   }
   // restore the solver's current point (its blocks must be rebuilt by the next cba_linearize)
-  HIPCHK(hipMemcpy(p->x, saved.data(), saved.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(guarded_memcpy(p->x, saved.data(), saved.size() * sizeof(double), hipMemcpyHostToDevice));
   launch_cam_prep(p, p->x, p->tab);
   HIPCHK(hipStreamSynchronize(p->stream));
   p->begun = was_begun; p->first_scale = first; p->linearized = false; p->stepped = false;
@@ -1932,12 +2006,13 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
 }
 
 int cba_reduced_system(cba_problem* p, double* S, double* rhs) {
+  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_reduced_system: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_reduced_system: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipStreamSynchronize(p->stream));
-  if (S) HIPCHK(hipMemcpy(S, p->S, (size_t)p->ncp * p->ncp * sizeof(double), hipMemcpyDeviceToHost));
-  if (rhs) HIPCHK(hipMemcpy(rhs, p->rhs, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost));
+  if (S) HIPCHK(guarded_memcpy(S, p->S, (size_t)p->ncp * p->ncp * sizeof(double), hipMemcpyDeviceToHost));
+  if (rhs) HIPCHK(guarded_memcpy(rhs, p->rhs, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost));
   return CBA_OK;
 }
 

@@ -488,3 +488,56 @@ def test_limits_are_reported_not_crashed():
         assert np.isfinite(cost) and r.size == 2 * len(sc.camera_indices) and abs(ev.begin(x0) - cost) <= 1e-13 * cost
         with pytest.raises(BackendError, match="evaluation_only"):
             ev.linearize()
+
+
+@pytest.mark.gpu
+def test_live_handles_of_different_size_and_worker_threads():
+    """The reference solves from the main thread or a QThread worker (task_manager.py:18-48), and nothing stops a caller
+    from holding two volumes of different rigs.  (1) The dynamic-LDS ceiling of a kernel is per function, not per handle: a
+    small handle created while a large one is alive must not lower it.  (2) Handles are independent across threads (ctypes
+    releases the GIL; every entry point selects its device; the last error is thread-local)."""
+    import threading
+
+    from caliscope_amd.hip_engine import HipEngine
+
+    big, par_big, x_big = small_problem(n_cams=96, n_points=1500, k=8, refine=True, seed=5)
+    prob_big = BAProblem(par_big, big.camera_indices, big.image_coords, big.obj_indices)
+    lb, ub = par_big.bounds()
+    ncp = par_big.n_camera_params
+    with HipEngine(prob_big) as eng:
+        first = eng.solve(x_big, lb=lb[:ncp], ub=ub[:ncp], max_nfev=6)
+        tiny, par_tiny, x_tiny = small_problem(n_cams=3, n_points=40, k=3, refine=True, seed=6)
+        with HipEngine(BAProblem(par_tiny, tiny.camera_indices, tiny.image_coords, tiny.obj_indices)) as small:
+            lt, ut = par_tiny.bounds()
+            assert small.solve(x_tiny, lb=lt[: par_tiny.n_camera_params], ub=ut[: par_tiny.n_camera_params]).status > 0
+            again = eng.solve(x_big, lb=lb[:ncp], ub=ub[:ncp], max_nfev=6)  # the large handle still launches
+        assert again.nfev == first.nfev and abs(again.cost - first.cost) <= 1e-9 * first.cost
+
+    cases = [small_problem(n_cams=4 + i, n_points=200 + 50 * i, k=4, seed=10 + i) for i in range(4)]
+
+    def solve(case):
+        sc, par, x0 = case
+        return least_squares(None, x0, args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), x_scale="jac", method="trf")
+
+    serial = [solve(c) for c in cases]
+    results, errors = [None] * len(cases), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                results[i] = solve(cases[i])
+            if i == 0:  # an error in one thread stays in that thread
+                with pytest.raises(ValueError):
+                    least_squares(None, np.full(cases[0][2].shape, np.nan), args=(cases[0][1], cases[0][0].camera_indices,
+                                  cases[0][0].image_coords, cases[0][0].obj_indices), x_scale="jac", method="trf")
+        except BaseException as exc:  # noqa: BLE001 - reported below with the thread index
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, ref in zip(results, serial):
+        assert got.status == ref.status and abs(got.nfev - ref.nfev) <= 1 and abs(got.cost - ref.cost) <= 1e-9 * ref.cost
