@@ -539,6 +539,11 @@ struct TilePlan {
   const unsigned short* blk_off; // register kernel: [n_tile_chunks][g*g + 1] per-thread offsets into the chunk's pairs
   const int* obs;                // register kernel: stream entry -> observation (index into the T records)
   int rep;                       // register kernel: threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
+  // k_schur_reg2 (schur_plan.h): transposed pair codes
+  const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_loc | j_loc << 16)
+  const int* code_start;         // [n_tile_chunks + 1] offsets into `codes`
+  const unsigned* nit;           // [n_tile_chunks] iterations of waves 0..3, one byte each
+  int zero_loc;                  // chunk-local index of the all-zero record (idle lanes multiply it)
 };
 // LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
 // an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
@@ -955,6 +960,161 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
     __syncthreads();
   }
   // partial of this workgroup: [256 blocks][NC*NC] (x rep rows); this thread holds rows r0 .. r0 + RH - 1 of its block
+  if (slot >= rep) return;
+#pragma unroll
+  for (int r = 0; r < RH; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
+}
+
+// k_schur_reg2: the same ownership (one camera-pair block per thread, accumulators in registers, T records of a chunk in
+// LDS), driven by the dealt plan of schur_plan.h.  What changed against k_schur_reg:
+//   * the plan equalises the pairs per block of every chunk (cap t, first-fit dealing over a region of ~128 chunks), so
+//     a wave spends ~80 % of its lane-iterations on real pairs instead of ~45 %;
+//   * the pair list is transposed: iteration `it` of wave w reads 64 consecutive codes, one per lane, idle lanes get the
+//     code of an all-zero record.  No per-thread slice table, no pair list in LDS, no divergence: the trip count is
+//     wave-uniform and the body is straight-line code;
+//   * the first four codes of the next chunk travel in registers like its records do, and the gather of the next
+//     chunk's records is issued in two halves around the first pair iteration instead of in one burst in front of the
+//     loop (the burst kept a wave ~1 us in the issue stage per chunk: the texture path takes one 16-byte quad per clock).
+template <int NC> struct Reg2Cfg {
+  static constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;
+  static constexpr int SPLIT = (NC == 9) ? 3 : 1;
+  static constexpr int REG_BLOCK = BLOCK * SPLIT;
+  static constexpr int NLD = (SCHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;            // gather loads per thread
+  static constexpr int ZERO_LOC = (NLD * REG_BLOCK * 2 + REC - 1) / REC;           // first record slot behind the staged chunk
+  static constexpr size_t LDS_BYTES = (size_t)(ZERO_LOC + 1) * REC * sizeof(double);
+};
+
+template <int NC, int SPLIT, int MINW>
+__global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
+k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, int debug_skip) {
+  using Cfg = Reg2Cfg<NC>;
+  static_assert(SPLIT == Cfg::SPLIT, "split");
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NP = Cfg::NP, NLD = Cfg::NLD;
+  constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
+  constexpr int NCD = 4;                        // codes of a chunk that travel in registers
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_T = sh;
+
+  const int nblk = tp.g * tp.g;
+  const int rep = (SPLIT == 1) ? tp.rep : 1;
+  const int tid = (int)threadIdx.x;
+  const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
+  const int cw = ct / WAVE, lane = ct % WAVE;
+  const int blk = (rep > 1) ? tid % nblk : ct;
+  const int slot = (rep > 1) ? tid / nblk : 0, half = (rep > 1) ? 0 : tid / BLOCK;
+  const int r0 = half * RH;
+  double acc[RH][NC];
+#pragma unroll
+  for (int r = 0; r < RH; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+
+  const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
+  double* dst = partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
+  if (first >= ch_end) {  // more workgroups than chunks in this range
+    if (slot < rep) {
+#pragma unroll
+      for (int k = 0; k < RH * NC; ++k)
+        if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+    }
+    return;
+  }
+  for (int k = tid; k < REC; k += REG_BLOCK) sh_T[Cfg::ZERO_LOC * REC + k] = 0.0;
+  const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
+  const unsigned zero_code = (unsigned)Cfg::ZERO_LOC | ((unsigned)Cfg::ZERO_LOC << 16);
+
+  double2 rec[NLD];
+  int idx[NLD];
+  unsigned cd[NCD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) rec[k] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int k = 0; k < NCD; ++k) cd[k] = zero_code;
+  int n_nx = 0;          // iterations of this wave in the fetched chunk
+  long code_nx = 0;      // offset of this lane's first code of the fetched chunk
+  {
+    const int c0 = tp.chunk_start[first];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
+  }
+  auto gather = [&](int k) {
+    const int e = k * REG_BLOCK + tid;
+    rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
+  };
+  auto pair = [&](unsigned code) {
+    const int i_loc = code & 0xffffu, j_loc = code >> 16;
+    const double* Ri = sh_T + i_loc * REC + 3 * r0;
+    const double2* Rj = reinterpret_cast<const double2*>(sh_T + j_loc * REC);
+    double Ti[3 * RH];
+#pragma unroll
+    for (int k = 0; k < 3 * RH; ++k) Ti[k] = Ri[k];
+#pragma unroll
+    for (int cp = 0; cp < (NC + 1) / 2; ++cp) {  // T_j two columns (three 16-byte slots) at a time
+      double Tj[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 b = (3 * cp + k < NP) ? Rj[3 * cp + k] : make_double2(0.0, 0.0);
+        Tj[2 * k] = b.x; Tj[2 * k + 1] = b.y;
+      }
+#pragma unroll
+      for (int r = 0; r < RH; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c = 2 * cp + cc;
+          if (c < NC) acc[r][c] = fma(Ti[3 * r + 2], Tj[3 * cc + 2], fma(Ti[3 * r + 1], Tj[3 * cc + 1], fma(Ti[3 * r], Tj[3 * cc], acc[r][c])));
+        }
+    }
+  };
+
+  int nxt = first;
+  for (int cur = first - stride; cur < ch_end; cur += stride) {  // first trip: fetch only
+    int n_cur = 0;
+    long code_cur = 0;
+    unsigned cc[NCD];
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
+    if (cur >= first) {
+      double2* dstrec = reinterpret_cast<double2*>(sh_T);
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) dstrec[k * REG_BLOCK + tid] = rec[k];
+      n_cur = n_nx; code_cur = code_nx;
+      __syncthreads();
+      nxt = min(cur + stride, last);
+    }
+    // first half of the next chunk's gather (every load unconditional: see k_schur_reg)
+#pragma unroll
+    for (int k = 0; k < NLD / 2; ++k) gather(k);
+    __builtin_amdgcn_sched_barrier(0);
+    if (cur >= first && debug_skip != 1 && n_cur > 0) pair(cc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = NLD / 2; k < NLD; ++k) gather(k);
+    {
+      const unsigned packed = tp.nit[nxt];
+      int pre = 0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) pre += (w < cw) ? (int)((packed >> (8 * w)) & 0xffu) : 0;
+      n_nx = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * cw)) & 0xffu));
+      code_nx = (long)tp.code_start[nxt] + (long)pre * WAVE + lane;
+#pragma unroll
+      for (int k = 0; k < NCD; ++k) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+      const int c0 = tp.chunk_start[min(nxt + stride, last)];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (cur < first) continue;
+    if (debug_skip != 1) {
+#pragma unroll
+      for (int it = 1; it < NCD; ++it)
+        if (it < n_cur) pair(cc[it]);
+      for (int it = NCD; it < n_cur; ++it) pair(tp.codes[code_cur + (long)it * WAVE]);  // rare: more than four pairs of one block in a chunk
+    }
+    __syncthreads();
+  }
   if (slot >= rep) return;
 #pragma unroll
   for (int r = 0; r < RH; ++r)

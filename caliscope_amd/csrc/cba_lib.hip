@@ -26,6 +26,7 @@
 
 #include "../../include/caliscope_ba.h"
 #include "cba_kernels.h"
+#include "schur_plan.h"
 
 using namespace cba;
 
@@ -67,7 +68,9 @@ struct cba_problem {
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg); false: LDS-atomic tile kernel
+  bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg / k_schur_reg2); false: LDS-atomic tile kernel
+  bool schur_v2 = false;   // dealt plan + k_schur_reg2 (default); CBA_SCHUR=reg1 keeps round 1's greedy plan and k_schur_reg
+  double plan_lane_util = 0.0;  // schur_v2: share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
   TilePlan tp{};
   int* tile_wg_begin = nullptr;
@@ -449,6 +452,70 @@ constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
+// Workgroup -> tile binding shared by the tile plans: workgroups proportional to the chunk count of each tile (at least
+// one per tile), XCD-aware for the register kernels.  TCB = first chunk of every tile.
+struct WgBinding { std::vector<int> wgb, wt, wfirst, wend, wstride; };
+static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, bool reg) {
+  WgBinding out;
+  // workgroups: proportional to the chunk count of each tile, at least one per tile
+  std::vector<long> nch(nT);
+  for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
+  auto allocate = [&](int budget) {
+    std::vector<int> nwg(nT);
+    long used = 0;
+    for (int t = 0; t < nT; ++t) {
+      const long w = p->n_tile_chunks > 0 ? nch[t] * budget / p->n_tile_chunks : 1;
+      nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
+      used += nwg[t];
+    }
+    // hand out what is left (or take back the excess) where the chunks-per-workgroup load is most uneven
+    while (used != budget) {
+      int best = -1;
+      double score = 0.0;
+      for (int t = 0; t < nT; ++t) {
+        if (used < budget) {
+          if (nwg[t] >= nch[t]) continue;
+          const double sc = (double)nch[t] / nwg[t];
+          if (best < 0 || sc > score) { best = t; score = sc; }
+        } else {
+          if (nwg[t] <= 1) continue;
+          const double sc = -(double)nch[t] / (nwg[t] - 1);
+          if (best < 0 || sc > score) { best = t; score = sc; }
+        }
+      }
+      if (best < 0) break;
+      if (used < budget) { nwg[best]++; used++; } else { nwg[best]--; used--; }
+    }
+    return nwg;
+  };
+  const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
+  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD gets the same share of every
+  // tile and walks one eighth of the point range, so the G tiles that gather a given T record do so through the
+  // same L2 at about the same time; HBM then serves each record once instead of G times.
+  constexpr int XCDS = 8;
+  const bool xcd_mode = reg && budget % XCDS == 0 && nT <= budget / XCDS && p->n_tile_chunks >= 4 * budget;
+  std::vector<int> nwg = allocate(xcd_mode ? budget / XCDS : budget), wgb(nT + 1, 0);
+  if (xcd_mode) for (int& w : nwg) w *= XCDS;
+  for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
+  p->tile_grid = wgb[nT];
+  std::vector<int> wt(p->tile_grid), wfirst(p->tile_grid), wend(p->tile_grid), wstride(p->tile_grid);
+  for (int t = 0; t < nT; ++t)
+    for (int r = 0; r < nwg[t]; ++r) {
+      const int b = wgb[t] + r;
+      wt[b] = t;
+      if (xcd_mode) {
+        const int x = r % XCDS, s = r / XCDS;
+        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
+        wfirst[b] = TCB[t] + (int)lo + s; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
+      } else {
+        wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t];
+      }
+    }
+
+  out.wgb = std::move(wgb); out.wt = std::move(wt); out.wfirst = std::move(wfirst); out.wend = std::move(wend); out.wstride = std::move(wstride);
+  return out;
+}
+
 // Static plan of the tiled Schur pass: camera groups, one observation stream per tile (a <= b), chunk
 // tables, partner ranges and the workgroup -> tile binding (see k_schur_tile).
 static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const std::vector<double>& hv,
@@ -734,60 +801,8 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   p->n_tile_chunks = TCB[nT];
   p->tile_stream_len = (long)OB.size() - (reg ? 2 * SCHUNK : 0);
   p->n_pairs = (long)PR.size() - (reg ? 2 * PAIRCAP : 0);
-  // workgroups: proportional to the chunk count of each tile, at least one per tile
-  std::vector<long> nch(nT);
-  for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
-  auto allocate = [&](int budget) {
-    std::vector<int> nwg(nT);
-    long used = 0;
-    for (int t = 0; t < nT; ++t) {
-      const long w = p->n_tile_chunks > 0 ? nch[t] * budget / p->n_tile_chunks : 1;
-      nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
-      used += nwg[t];
-    }
-    // hand out what is left (or take back the excess) where the chunks-per-workgroup load is most uneven
-    while (used != budget) {
-      int best = -1;
-      double score = 0.0;
-      for (int t = 0; t < nT; ++t) {
-        if (used < budget) {
-          if (nwg[t] >= nch[t]) continue;
-          const double sc = (double)nch[t] / nwg[t];
-          if (best < 0 || sc > score) { best = t; score = sc; }
-        } else {
-          if (nwg[t] <= 1) continue;
-          const double sc = -(double)nch[t] / (nwg[t] - 1);
-          if (best < 0 || sc > score) { best = t; score = sc; }
-        }
-      }
-      if (best < 0) break;
-      if (used < budget) { nwg[best]++; used++; } else { nwg[best]--; used--; }
-    }
-    return nwg;
-  };
-  const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
-  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD gets the same share of every
-  // tile and walks one eighth of the point range, so the G tiles that gather a given T record do so through the
-  // same L2 at about the same time; HBM then serves each record once instead of G times.
-  constexpr int XCDS = 8;
-  const bool xcd_mode = reg && budget % XCDS == 0 && nT <= budget / XCDS && p->n_tile_chunks >= 4 * budget;
-  std::vector<int> nwg = allocate(xcd_mode ? budget / XCDS : budget), wgb(nT + 1, 0);
-  if (xcd_mode) for (int& w : nwg) w *= XCDS;
-  for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
-  p->tile_grid = wgb[nT];
-  std::vector<int> wt(p->tile_grid), wfirst(p->tile_grid), wend(p->tile_grid), wstride(p->tile_grid);
-  for (int t = 0; t < nT; ++t)
-    for (int r = 0; r < nwg[t]; ++r) {
-      const int b = wgb[t] + r;
-      wt[b] = t;
-      if (xcd_mode) {
-        const int x = r % XCDS, s = r / XCDS;
-        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
-        wfirst[b] = TCB[t] + (int)lo + s; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
-      } else {
-        wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t];
-      }
-    }
+  const WgBinding bind = bind_workgroups(p, TCB, nT, max_blocks, reg);
+  const std::vector<int>&wgb = bind.wgb, &wt = bind.wt, &wfirst = bind.wfirst, &wend = bind.wend, &wstride = bind.wstride;
 
   int rc;
   double *du = nullptr, *dv = nullptr;
@@ -815,6 +830,67 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   return CBA_OK;
 }
 
+// Plan of k_schur_reg2 (schur_plan.h builds it on the host; here: workgroup binding and upload).
+template <int NC>
+static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, const std::vector<int>& hps,
+                                const std::vector<int>& cam_off, int max_blocks) {
+  const int G = p->G, g = p->gsz, C = p->C;
+  const int nT = p->n_tiles;
+  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = t_now();
+  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
+  Reg2Params prm;
+  prm.C = C; prm.P = p->P; prm.G = G; prm.g = g;
+  prm.rep = (NC == 6 && g * g <= BLOCK / 2) ? BLOCK / (g * g) : 1;  // small groups: several threads per block
+  if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1))) : 1;
+  prm.chunk_cap = SCHUNK;
+  prm.zero_loc = Reg2Cfg<NC>::ZERO_LOC;
+  if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
+  prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
+  Reg2Plan plan;
+  if (build_reg2_plan(prm, hcam, hps, plan)) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
+  lap("dealt streams and codes (host threads)");
+  p->n_tile_chunks = plan.tile_chunk_begin[nT];
+  p->tile_stream_len = (long)plan.obs.size() - 2 * SCHUNK;
+  p->n_pairs = plan.n_pairs;
+  p->plan_lane_util = plan.lane_iters > 0 ? (double)plan.n_pairs / (double)plan.lane_iters : 0.0;
+  if (plan_timing)
+    fprintf(stderr, "  plan: %d tiles x %d regions, %d chunks (%.1f records each), %ld pairs, lane utilisation %.3f\n", nT, plan.n_regions,
+            p->n_tile_chunks, p->n_tile_chunks ? (double)p->tile_stream_len / p->n_tile_chunks : 0.0, plan.n_pairs, p->plan_lane_util);
+  const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, true);
+  lap("workgroup binding");
+  std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
+  for (int a = 0; a <= G; ++a) {
+    gcam[a] = std::min(a * g, C);
+    gpar[a] = (gcam[a] < C) ? cam_off[gcam[a]] : p->ncp;
+  }
+  {
+    int t = 0;
+    for (int a = 0; a < G; ++a)
+      for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
+  }
+  int rc;
+  int *dob = nullptr, *dcs = nullptr, *dcode = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
+      *dgc = nullptr, *dgp = nullptr;
+  unsigned *dcodes = nullptr, *dnit = nullptr;
+#define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
+  TRYP(dev_upload(p, &dob, plan.obs)); TRYP(dev_upload(p, &dcs, plan.chunk_start)); TRYP(dev_upload(p, &dcode, plan.code_start));
+  TRYP(dev_upload(p, &dcodes, plan.codes)); TRYP(dev_upload(p, &dnit, plan.nit));
+  TRYP(dev_upload(p, &dwf, bind.wfirst)); TRYP(dev_upload(p, &dwt, bind.wt)); TRYP(dev_upload(p, &dwe, bind.wend)); TRYP(dev_upload(p, &dws, bind.wstride));
+  TRYP(dev_upload(p, &dta, ta)); TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
+  TRYP(dev_upload(p, &p->tile_wg_begin, bind.wgb));
+#undef TRYP
+  lap("upload");
+  TilePlan tp{};
+  tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
+  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
+  tp.tile_elems = BLOCK * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;
+  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit; tp.zero_loc = prm.zero_loc;
+  p->tp = tp;
+  return CBA_OK;
+}
+
 template <int NC>
 static int configure_kernels(cba_problem* p) {
   int rc;
@@ -826,6 +902,7 @@ static int configure_kernels(cba_problem* p) {
   int gmax = 1;
   const char* force_tile = std::getenv("CBA_SCHUR");
   p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
+  p->schur_v2 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg1") == 0);
   if (p->schur_reg) gmax = std::min(p->C, kSchurRegMaxGroup);
   else while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
   p->G = (p->C + gmax - 1) / gmax;
@@ -833,6 +910,7 @@ static int configure_kernels(cba_problem* p) {
   p->n_tiles = p->G * (p->G + 1) / 2;
   if (p->schur_reg) {
     if ((rc = allow_lds(k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, lds_schur_reg<NC>(p->gsz)))) return rc;
+    if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
     if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   }
   else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
@@ -994,13 +1072,18 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("reorder, upload, allocate");
   p->eval_only = opt && opt->evaluation_only != 0;
   for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
-    const size_t tile_lds = p->schur_reg ? ((nct == 9) ? lds_schur_reg<9>(p->gsz) : lds_schur_reg<6>(p->gsz))
+    const size_t tile_lds = p->schur_v2 ? ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES)
+                          : p->schur_reg ? ((nct == 9) ? lds_schur_reg<9>(p->gsz) : lds_schur_reg<6>(p->gsz))
                                          : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
     if (p->schur_reg) per_cu = std::min(per_cu, (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // register budget
     const int resident = cus * per_cu;  // no partial last round
-    rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
-    if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) { p->schur_reg = false; continue; }  // a point with > PAIRCAP pairs in one tile
+    if (p->schur_reg && p->schur_v2)
+      rc = (nct == 9) ? build_reg2_tile_plan<9>(p, hcam, hps, off, std::min(resident, std::max(max_blocks, cus)))
+                      : build_reg2_tile_plan<6>(p, hcam, hps, off, std::min(resident, std::max(max_blocks, cus)));
+    else
+      rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
+    if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) { p->schur_reg = false; p->schur_v2 = false; continue; }  // a point too large for the pair plan
     if (rc) return bail(rc);
     break;
   }
@@ -1334,8 +1417,12 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
                          p->sinv, p->Trec, p->partial_b, p->flags);
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
-      hipLaunchKernelGGL((k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
-                         lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
+      if (p->schur_v2)
+        hipLaunchKernelGGL((k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
+                           Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
+      else
+        hipLaunchKernelGGL((k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
+                           lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
     }
     if (!p->schur_reg)
       hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,

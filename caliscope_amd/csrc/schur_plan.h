@@ -1,0 +1,345 @@
+// Static plan of the register-accumulating Schur kernel (k_schur_reg2), host side only: plain C++, no HIP, so that the
+// CPU suite can build it with g++ and replay it against a direct sum (tests/native/plan_harness.cpp).
+//
+// The kernel (cba_kernels.h) binds a 256-thread workgroup to one tile (camera group a x camera group b) of the reduced
+// camera system.  Every thread owns one camera-pair block of the tile and keeps its nc x nc accumulators in registers.  A
+// tile's work is a stream of T records (one per observation whose camera is in group a or b), cut into CHUNKS that fit
+// LDS; per chunk every thread multiplies the record pairs (T_i, T_j) that belong to its block.  A wave runs at the pace
+// of its busiest lane, so what the plan decides is the time the pass takes: the chunks must hold the same number of
+// pairs for every block.
+//
+// Round 1 filled one open chunk greedily from a window of 32 points (48 % of the lane-iterations did work on cfg4).
+// Here a REGION of ~128 chunks is open at once and the points of the region are DEALT: heaviest first, each to the
+// first chunk (first fit) that has room for its records and where none of its blocks has reached the cap `t` (pairs per
+// thread per chunk); what fits nowhere is dealt again with t + 1.  With 384 records per chunk a thread sees 1.8 pairs
+// per chunk on cfg4 and the cap is 2: 82 % of the lane-iterations do work (tools/plan_sim.py).
+//
+// The pair list leaves the plan TRANSPOSED: for chunk c and wave w, nit[c].w iterations of 64 codes each, code =
+// (i_loc | j_loc << 16) of the pair lane `l` multiplies in that iteration, or ZERO (both halves point at an all-zero
+// record kept behind the chunk in LDS) when the lane has nothing left.  The kernel's pair loop is therefore branch-free
+// with a wave-uniform trip count, and a lane fetches its code with one coalesced load.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace cba {
+
+struct Reg2Params {
+  int C = 0, P = 0;       // cameras, world points
+  int G = 1, g = 1;       // camera groups, cameras per group (max)
+  int rep = 1;            // threads per camera-pair block (small groups: 256 / g^2)
+  int chunk_cap = 384;    // records per chunk
+  int zero_loc = 0;       // chunk-local index of the all-zero record
+  int region_chunks = 128;
+  int heavy_obs = 0;      // > 0: points with more observations are left out (k_heavy_schur forms their share)
+  int threads = 0;        // host threads (0: hardware concurrency)
+};
+
+struct Reg2Plan {
+  std::vector<int> obs;               // stream entry -> observation (index into the T records); padded with 2 * chunk_cap zeros
+  std::vector<int> chunk_start;       // [n_chunks + 1] offsets into obs
+  std::vector<int> code_start;        // [n_chunks + 1] offsets into codes
+  std::vector<unsigned> nit;          // [n_chunks] iterations of waves 0..3, one byte each
+  std::vector<unsigned> codes;        // transposed pair codes; padded with 4 * 256 ZERO codes
+  std::vector<int> tile_chunk_begin;  // [n_tiles + 1]
+  long n_pairs = 0;                   // pair codes that do work
+  long lane_iters = 0;                // 64 x wave-iterations (n_pairs / lane_iters = lane utilisation)
+  int n_regions = 1;
+};
+
+namespace reg2_detail {
+
+struct Cand { int q; int n_rec; int key_begin, key_end; };
+
+struct Job {
+  int tile = 0, q_begin = 0, q_end = 0;
+  std::vector<int> obs, chunk_start, code_start;
+  std::vector<unsigned> nit, codes;
+  long n_pairs = 0, lane_iters = 0;
+  int rc = 0;
+};
+
+}  // namespace reg2_detail
+
+// hcam / hps: cameras of the observations sorted by (point, camera) and the first observation of every point.
+// Returns 0, or -1 when a single point does not fit a chunk.
+inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, const std::vector<int>& hps, Reg2Plan& out) {
+  using namespace reg2_detail;
+  const int G = prm.G, g = prm.g, C = prm.C, P = prm.P, rep = std::max(1, prm.rep);
+  const int nT = G * (G + 1) / 2, nblk = g * g, R = prm.chunk_cap;
+  const unsigned ZERO = (unsigned)prm.zero_loc | ((unsigned)prm.zero_loc << 16);
+  std::vector<int> gcam(G + 1);
+  for (int a = 0; a <= G; ++a) gcam[a] = std::min(a * g, C);
+  std::vector<int> ta(nT), tb(nT);
+  {
+    int t = 0;
+    for (int a = 0; a < G; ++a)
+      for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
+  }
+  // observations of a point are sorted by camera => by group; pgb[q*(G+1) + a] .. [a+1] is group a's run
+  std::vector<int> pgb((size_t)P * (G + 1));
+  long stream_total = 0;
+  for (int q = 0; q < P; ++q) {
+    int cur = hps[q];
+    const int s1 = hps[q + 1];
+    for (int a = 0; a < G; ++a) {
+      pgb[(size_t)q * (G + 1) + a] = cur;
+      while (cur < s1 && hcam[cur] < gcam[a + 1]) ++cur;
+    }
+    pgb[(size_t)q * (G + 1) + G] = s1;
+    stream_total += (long)(s1 - hps[q]) * G;  // an observation takes part in the G tiles of its group (upper bound)
+  }
+  // regions: the same point ranges for every tile, about region_chunks chunks of an average tile each
+  const long per_tile = std::max<long>(1, stream_total / std::max(nT, 1));
+  int n_regions = (int)std::max<long>(1, (per_tile + (long)R * prm.region_chunks / 2) / ((long)R * std::max(prm.region_chunks, 1)));
+  n_regions = std::min(n_regions, std::max(1, P));
+  out.n_regions = n_regions;
+
+  std::vector<Job> jobs((size_t)nT * n_regions);
+  for (int t = 0; t < nT; ++t)
+    for (int r = 0; r < n_regions; ++r) {
+      Job& j = jobs[(size_t)t * n_regions + r];
+      j.tile = t;
+      j.q_begin = (int)((long)P * r / n_regions);
+      j.q_end = (int)((long)P * (r + 1) / n_regions);
+    }
+
+  auto run_job = [&](Job& job) {
+    const int a = ta[job.tile], b = tb[job.tile];
+    const bool diag = (a == b);
+    const int na_t = gcam[a + 1] - gcam[a];
+    const int min_rec = diag ? 1 : 2;  // records of the smallest point of this tile
+    // key space of the load counters: [0, nblk) real camera-pair blocks, [nblk, nblk + g) the (i, i) items of a camera
+    // (diagonal tiles), which its helper threads share
+    std::vector<std::vector<int>> helpers;
+    if (diag) {
+      helpers.assign(g, {});
+      int k = 0;
+      for (int li = 0; li < g; ++li)
+        for (int lj = 0; lj <= li; ++lj, ++k) helpers[k % std::max(na_t, 1)].push_back(li * g + lj);
+    }
+    std::vector<Cand> cand;
+    std::vector<unsigned short> keys;
+    long tot_rec = 0, tot_pairs = 0;
+    std::vector<long> key_tot((size_t)nblk + g, 0);
+    for (int q = job.q_begin; q < job.q_end; ++q) {
+      const int* gb = &pgb[(size_t)q * (G + 1)];
+      const int na = gb[a + 1] - gb[a], nb = diag ? 0 : gb[b + 1] - gb[b];
+      if (prm.heavy_obs > 0 && hps[q + 1] - hps[q] > prm.heavy_obs) continue;
+      if (na <= 0 || (!diag && nb <= 0)) continue;
+      if (na + nb > R) { job.rc = -1; return; }
+      Cand c{q, na + nb, (int)keys.size(), 0};
+      for (int i = gb[a]; i < gb[a] + na; ++i) {
+        const int li = hcam[i] - gcam[a];
+        const int j0 = diag ? i : gb[b], j1 = diag ? gb[a] + na : gb[b] + nb;
+        for (int j = j0; j < j1; ++j) {
+          const int lj = hcam[j] - gcam[b];
+          if (diag && lj == li) {  // (i, i) item, or two rows of one camera: T_i T_j^T + T_j T_i^T, two codes
+            keys.push_back((unsigned short)(nblk + li));
+            if (j != i) keys.push_back((unsigned short)(nblk + li));
+          } else {
+            keys.push_back((unsigned short)(li * g + lj));
+          }
+        }
+      }
+      c.key_end = (int)keys.size();
+      for (int k = c.key_begin; k < c.key_end; ++k) key_tot[keys[k]]++;
+      tot_rec += c.n_rec;
+      tot_pairs += c.key_end - c.key_begin;
+      cand.push_back(c);
+    }
+    job.chunk_start.push_back(0);
+    job.code_start.push_back(0);
+    if (cand.empty()) return;
+    // capacity of a key per unit of the cap t: rep thread slots per block, all helper slots of a camera
+    std::vector<int> unit((size_t)nblk + g, rep);
+    int active_slots = 0;
+    for (int k = 0; k < nblk + g; ++k) {
+      if (k >= nblk) unit[k] = diag ? rep * (int)helpers[k - nblk].size() : 0;
+      if (key_tot[k] > 0) active_slots += unit[k];
+    }
+    active_slots = std::max(active_slots, 1);
+    // heaviest first (counting sort by pair count, stable in point order)
+    std::vector<int> order(cand.size());
+    {
+      int maxp = 0;
+      for (const Cand& c : cand) maxp = std::max(maxp, c.key_end - c.key_begin);
+      std::vector<int> start((size_t)maxp + 2, 0);
+      for (const Cand& c : cand) start[(size_t)maxp - (c.key_end - c.key_begin) + 1]++;
+      for (int i = 0; i <= maxp; ++i) start[i + 1] += start[i];
+      for (int i = 0; i < (int)cand.size(); ++i) order[start[(size_t)maxp - (cand[i].key_end - cand[i].key_begin)]++] = i;
+    }
+
+    struct Deal {
+      std::vector<std::vector<int>> members;  // candidates of every chunk, in placement order
+      long cost = 0;
+    };
+    const double mean = (double)tot_pairs / active_slots / std::max(1.0, (double)tot_rec / R);  // pairs per thread slot per full chunk
+    auto deal = [&](int t0, int r_eff, Deal& d) {
+      const int want = (int)((tot_rec + r_eff - 1) / r_eff);
+      const int max_chunks = want + std::max(2, want / 12);
+      std::vector<unsigned short> cnt;  // [chunk][nblk + g]
+      std::vector<int> fill;
+      const int W = nblk + g;
+      auto open_chunk = [&]() { cnt.resize(cnt.size() + W, 0); fill.push_back(0); d.members.emplace_back(); };
+      std::vector<int> todo(order), left;
+      for (int t = t0; !todo.empty(); ++t) {
+        left.clear();
+        int first = 0;
+        for (int ci : todo) {
+          const Cand& c = cand[ci];
+          while (first < (int)fill.size() && fill[first] + min_rec > r_eff) ++first;
+          bool placed = false;
+          for (int ch = first; ch <= (int)fill.size() && !placed; ++ch) {
+            if (ch == (int)fill.size()) {
+              if (ch >= max_chunks && t < t0 + 6) break;  // the region is full at this cap: try again with t + 1
+              open_chunk();
+            }
+            if (fill[ch] + c.n_rec > r_eff) continue;
+            unsigned short* cc = &cnt[(size_t)ch * W];
+            int k = c.key_begin;
+            for (; k < c.key_end; ++k)
+              if (++cc[keys[k]] > t * unit[keys[k]]) break;
+            if (k < c.key_end) {  // over the cap: take the increments back
+              for (int k2 = c.key_begin; k2 <= k; ++k2) --cc[keys[k2]];
+              if (fill[ch] == 0 && ch + 1 == (int)fill.size()) break;  // does not even fit an empty chunk at this cap
+              continue;
+            }
+            fill[ch] += c.n_rec;
+            d.members[ch].push_back(ci);
+            placed = true;
+          }
+          if (!placed) left.push_back(ci);
+        }
+        todo.swap(left);
+      }
+      // cost model: wave-iterations (four waves, each at the pace of its busiest slot) + a fixed share per chunk
+      d.cost = 0;
+      for (size_t ch = 0; ch < fill.size(); ++ch) {
+        if (!fill[ch]) continue;
+        const unsigned short* cc = &cnt[ch * W];
+        int mx = 0;
+        for (int k = 0; k < W; ++k)
+          if (unit[k] > 0) mx = std::max(mx, (cc[k] + unit[k] - 1) / unit[k]);
+        d.cost += 4 * mx + 6;
+      }
+    };
+    Deal best;
+    {
+      int t_hi = std::max(1, (int)std::ceil(mean - 1e-9));
+      int r_hi = R;
+      if (mean / t_hi > 0.93) r_hi = std::max(R / 2, (int)(R * 0.93 * t_hi / mean));
+      deal(t_hi, r_hi, best);
+      if (t_hi > 1 && mean / (t_hi - 1) < 1.35) {
+        Deal alt;
+        deal(t_hi - 1, std::max(R / 2, (int)(R * 0.93 * (t_hi - 1) / mean)), alt);
+        if (alt.cost < best.cost) best = std::move(alt);
+      }
+    }
+    // emit: stream entries, transposed codes
+    std::vector<std::vector<unsigned>> lists(256);
+    std::vector<unsigned> rr((size_t)nblk, 0), rrc((size_t)g, 0);
+    for (const std::vector<int>& mem : best.members) {
+      if (mem.empty()) continue;
+      for (auto& l : lists) l.clear();
+      std::fill(rr.begin(), rr.end(), 0u);
+      std::fill(rrc.begin(), rrc.end(), 0u);
+      const int open = (int)job.obs.size();
+      for (int ci : mem) {
+        const int q = cand[ci].q;
+        const int* gb = &pgb[(size_t)q * (G + 1)];
+        const int na = gb[a + 1] - gb[a], nb = diag ? 0 : gb[b + 1] - gb[b];
+        const int base = (int)job.obs.size() - open;
+        for (int i = gb[a]; i < gb[a] + na; ++i) job.obs.push_back(i);
+        for (int i = gb[b]; !diag && i < gb[b] + nb; ++i) job.obs.push_back(i);
+        auto emit = [&](int blk, unsigned code) {
+          const int slot = (int)(rr[blk]++ % (unsigned)rep);
+          lists[(size_t)slot * nblk + blk].push_back(code);
+        };
+        for (int i = 0; i < na; ++i) {
+          const int li = hcam[gb[a] + i] - gcam[a];
+          const int j0 = diag ? i : na, j1 = diag ? na : na + nb;
+          for (int j = j0; j < j1; ++j) {
+            const int lj = diag ? hcam[gb[a] + j] - gcam[a] : hcam[gb[b] + (j - na)] - gcam[b];
+            const unsigned code = (unsigned)(base + i) | ((unsigned)(base + j) << 16);
+            if (diag && lj == li) {
+              const std::vector<int>& h = helpers[li];
+              emit(h[rrc[li]++ % h.size()], code);
+              if (j != i) emit(h[rrc[li]++ % h.size()], (unsigned)(base + j) | ((unsigned)(base + i) << 16));
+            } else {
+              emit(li * g + lj, code);
+            }
+          }
+        }
+      }
+      unsigned packed = 0;
+      for (int w = 0; w < 4; ++w) {
+        size_t mx = 0;
+        for (int l = 0; l < 64; ++l) mx = std::max(mx, lists[(size_t)w * 64 + l].size());
+        mx = std::min<size_t>(mx, 255);  // a byte per wave; 255 pairs of one block in one chunk cannot happen (chunk_cap records)
+        packed |= (unsigned)mx << (8 * w);
+        for (size_t it = 0; it < mx; ++it)
+          for (int l = 0; l < 64; ++l) {
+            const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
+            job.codes.push_back(it < li.size() ? li[it] : ZERO);
+          }
+        job.lane_iters += (long)mx * 64;
+      }
+      for (auto& l : lists) job.n_pairs += (long)l.size();
+      job.nit.push_back(packed);
+      job.chunk_start.push_back((int)job.obs.size());
+      job.code_start.push_back((int)job.codes.size());
+    }
+  };
+
+  {
+    unsigned hw = prm.threads > 0 ? (unsigned)prm.threads : std::max(1u, std::thread::hardware_concurrency());
+    hw = std::min<unsigned>(hw, (unsigned)jobs.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (size_t j = next++; j < jobs.size(); j = next++) run_job(jobs[j]);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < hw; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
+  for (const Job& j : jobs)
+    if (j.rc) return j.rc;
+
+  // concatenate in (tile, region) order
+  size_t n_obs = 0, n_codes = 0, n_chunks = 0;
+  for (const Job& j : jobs) { n_obs += j.obs.size(); n_codes += j.codes.size(); n_chunks += j.nit.size(); }
+  out.obs.assign(n_obs + 2 * (size_t)R, 0);
+  out.codes.assign(n_codes + 4 * 256, ZERO);
+  out.chunk_start.assign(n_chunks + 1, 0);
+  out.code_start.assign(n_chunks + 1, 0);
+  out.nit.assign(n_chunks, 0);
+  out.tile_chunk_begin.assign(nT + 1, 0);
+  out.n_pairs = 0; out.lane_iters = 0;
+  size_t o = 0, cpos = 0, ch = 0;
+  for (int t = 0; t < nT; ++t) {
+    out.tile_chunk_begin[t] = (int)ch;
+    for (int r = 0; r < n_regions; ++r) {
+      const Job& j = jobs[(size_t)t * n_regions + r];
+      std::copy(j.obs.begin(), j.obs.end(), out.obs.begin() + o);
+      std::copy(j.codes.begin(), j.codes.end(), out.codes.begin() + cpos);
+      for (size_t c = 0; c < j.nit.size(); ++c) {
+        out.nit[ch + c] = j.nit[c];
+        out.chunk_start[ch + c + 1] = (int)(o + j.chunk_start[c + 1]);
+        out.code_start[ch + c + 1] = (int)(cpos + j.code_start[c + 1]);
+      }
+      o += j.obs.size(); cpos += j.codes.size(); ch += j.nit.size();
+      out.n_pairs += j.n_pairs; out.lane_iters += j.lane_iters;
+    }
+  }
+  out.tile_chunk_begin[nT] = (int)ch;
+  return 0;
+}
+
+}  // namespace cba

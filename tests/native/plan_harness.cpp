@@ -1,0 +1,51 @@
+// CPU replay of the dealt Schur plan (caliscope_amd/csrc/schur_plan.h): walks the transposed pair codes exactly as
+// k_schur_reg2 does (chunk by chunk, wave by wave, iteration by iteration, lane by lane) and accumulates T_i T_j^T per
+// owner thread, so that tests/test_schur_plan.py can compare the per-block sums with a direct sum over the points.
+#include <cstdio>
+#include <vector>
+
+#include "../../caliscope_amd/csrc/schur_plan.h"
+
+extern "C" {
+
+// acc_out: [n_tiles][256][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
+int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int zero_loc, int region_chunks, int heavy_obs,
+                int threads, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
+  cba::Reg2Params prm;
+  prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap; prm.zero_loc = zero_loc;
+  prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads;
+  const long N = hps[P];
+  std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
+  cba::Reg2Plan plan;
+  const int rc = cba::build_reg2_plan(prm, vcam, vps, plan);
+  if (rc) return rc;
+  const int nT = G * (G + 1) / 2, bsz = nc * nc;
+  const int n_chunks = plan.tile_chunk_begin[nT];
+  for (int t = 0; t < nT; ++t)
+    for (int ch = plan.tile_chunk_begin[t]; ch < plan.tile_chunk_begin[t + 1]; ++ch) {
+      const int c0 = plan.chunk_start[ch], len = plan.chunk_start[ch + 1] - c0;
+      if (len <= 0 || len > chunk_cap) return -10;
+      long code = plan.code_start[ch];
+      const unsigned packed = plan.nit[ch];
+      for (int w = 0; w < 4; ++w) {
+        const int n = (packed >> (8 * w)) & 0xff;
+        for (int it = 0; it < n; ++it)
+          for (int lane = 0; lane < 64; ++lane, ++code) {
+            const unsigned cd = plan.codes[code];
+            const int il = cd & 0xffff, jl = cd >> 16;
+            if (il == zero_loc && jl == zero_loc) continue;
+            if (il >= len || jl >= len) return -11;
+            const double* Ti = T + (long)plan.obs[c0 + il] * rec;
+            const double* Tj = T + (long)plan.obs[c0 + jl] * rec;
+            double* a = acc_out + ((long)t * 256 + w * 64 + lane) * bsz;
+            for (int r = 0; r < nc; ++r)
+              for (int c = 0; c < nc; ++c) a[r * nc + c] += Ti[3 * r] * Tj[3 * c] + Ti[3 * r + 1] * Tj[3 * c + 1] + Ti[3 * r + 2] * Tj[3 * c + 2];
+          }
+      }
+      if (code != plan.code_start[ch + 1]) return -12;
+    }
+  stats_out[0] = n_chunks; stats_out[1] = plan.n_pairs; stats_out[2] = plan.lane_iters; stats_out[3] = plan.n_regions;
+  stats_out[4] = (long)plan.obs.size() - 2L * chunk_cap;
+  return 0;
+}
+}
