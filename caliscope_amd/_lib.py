@@ -105,6 +105,10 @@ SIGNATURES = {
     "cba_destroy": (None, [C.c_void_p]),
     "cba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cba_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "cba_group_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "cba_group_join": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "cba_group_abort": (None, [C.c_void_p]),
+    "cba_group_destroy": (None, [C.c_void_p]),
     "cba_set_constraints": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p]),
     "cba_begin": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cba_restart": (C.c_int, [C.c_void_p, c_double_p]),

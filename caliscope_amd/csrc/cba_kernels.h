@@ -1040,9 +1040,11 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
   }
+  // debug_skip (profiling only, results are garbage): 1 no pair loop, 2 no record gather, 4 no LDS stores, 8 no index / code loads
+  const bool dbg_pairs = !(debug_skip & 1), dbg_gather = !(debug_skip & 2), dbg_store = !(debug_skip & 4), dbg_index = !(debug_skip & 8);
   auto gather = [&](int k) {
     const int e = k * REG_BLOCK + tid;
-    rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
+    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
   };
   auto pair = [&](unsigned code) {
     const int i_loc = code & 0xffffu, j_loc = code >> 16;
@@ -1079,7 +1081,8 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     if (cur >= first) {
       double2* dstrec = reinterpret_cast<double2*>(sh_T);
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) dstrec[k * REG_BLOCK + tid] = rec[k];
+      for (int k = 0; k < NLD; ++k)
+        if (dbg_store) dstrec[k * REG_BLOCK + tid] = rec[k];
       n_cur = n_nx; code_cur = code_nx;
       __syncthreads();
       nxt = min(cur + stride, last);
@@ -1088,7 +1091,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < NLD / 2; ++k) gather(k);
     __builtin_amdgcn_sched_barrier(0);
-    if (cur >= first && debug_skip != 1 && n_cur > 0) pair(cc[0]);
+    if (cur >= first && dbg_pairs && n_cur > 0) pair(cc[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = NLD / 2; k < NLD; ++k) gather(k);
@@ -1100,14 +1103,16 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
       n_nx = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * cw)) & 0xffu));
       code_nx = (long)tp.code_start[nxt] + (long)pre * WAVE + lane;
 #pragma unroll
-      for (int k = 0; k < NCD; ++k) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+      for (int k = 0; k < NCD; ++k)
+        if (dbg_index) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
       const int c0 = tp.chunk_start[min(nxt + stride, last)];
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
+      for (int k = 0; k < NLD; ++k)
+        if (dbg_index) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
     }
     __builtin_amdgcn_sched_barrier(0);
     if (cur < first) continue;
-    if (debug_skip != 1) {
+    if (dbg_pairs) {
 #pragma unroll
       for (int it = 1; it < NCD; ++it)
         if (it < n_cur) pair(cc[it]);

@@ -52,13 +52,14 @@ static int fail(int code, const char* fmt, ...) {
 
 enum TimerId {
   T_CAM_PREP = 0, T_COST, T_BUILD, T_BUILD_REDUCE, T_SCALE_SCALARS, T_JV, T_SCHUR, T_SCHUR_REDUCE, T_CHOLESKY,
-  T_BACKSUB, T_VECTOR, T_COUNT
+  T_BACKSUB, T_VECTOR, T_SCHUR_PAIRS, T_COUNT
 };
 static const char* kTimerNames[T_COUNT] = {
     "cam_prep", "cost", "build", "build_reduce", "scale_scalars", "jv", "schur", "schur_reduce_finalize",
-    "cholesky_solve", "backsub", "vector_ops"};
+    "cholesky_solve", "backsub", "vector_ops", "schur_pairs"};
 
 struct EventPair { hipEvent_t a, b; };
+struct cba_group;
 
 struct cba_problem {
   int device = 0;
@@ -136,7 +137,10 @@ struct cba_problem {
   std::vector<void*> allocs;
   // sharded solve (points partitioned over ranks, cameras replicated): RCCL over xGMI
   ncclComm_t comm = nullptr;
+  cba_group* group = nullptr;  // in-process device group (cba_group_join): direct peer-to-peer exchange instead of RCCL
   int rank = 0, world = 1;
+  unsigned long long group_generation = 0;
+  bool sharded() const { return comm != nullptr || group != nullptr; }
   hipGraph_t chol_graph = nullptr;
   hipGraphExec_t chol_exec = nullptr;
 };
@@ -247,8 +251,80 @@ static int sync_scalars(cba_problem* p, int n_scal, const double* part_a = nullp
     if (_r != ncclSuccess) return fail(CBA_ERR_COMM, "%s failed: %s", #expr, ncclGetErrorString(_r));  \
   } while (0)
 
-// in-place sum / max over the ranks of a sharded solve, enqueued on the engine's stream (no-op for world 1)
+// In-process device group: the ranks are handles of ONE process, one host thread each (cba_group_join).  The exchange is
+// direct: every rank parks its contribution in a staging buffer of its own device, then sums the staging buffers of all
+// ranks in rank order — its own and, through peer access over xGMI, everybody else's — so all ranks end with the same
+// bits and no ring is involved ("direct ... over the 7 xGMI links, never a ring for these sizes").
+// Ordering across the streams: events.  Collective g uses staging buffer g & 1:
+//   rank r, stream r:  wait done_q[g & 1] of all q (their reads of generation g - 2)  ->  copy  ->  record ready_r[g & 1]
+//   host:              barrier (every rank has recorded its ready event)
+//   rank r, stream r:  wait ready_q[g & 1] of all q  ->  sum kernel  ->  record done_r[g & 1]
+// The one host barrier per collective also orders generation g + 2's waits behind generation g's records.
+struct cba_group {
+  int world = 0;
+  std::atomic<int> arrived{0};
+  std::atomic<unsigned> phase{0};
+  std::atomic<int> joined{0}, failed{0}, aborted{0};
+  std::vector<cba_problem*> member;
+  std::vector<double*> stage[2];
+  std::vector<hipEvent_t> ready[2], done[2];
+  size_t capacity = 0;  // doubles per staging buffer
+  unsigned long long generation = 0;  // advanced by rank 0 behind the barrier; every rank keeps its own copy in step
+  const double** d_src[2] = {nullptr, nullptr};  // per rank (device memory of that rank): the `world` staging pointers of a parity
+  std::vector<const double**> src_tab[2];
+  // sense-reversing spin barrier: the member threads are dedicated to their devices and meet every few hundred microseconds
+  // returns false when the group was aborted (cba_group_abort: a member failed and will never arrive)
+  bool barrier() {
+    const unsigned ph = phase.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == world) {
+      arrived.store(0, std::memory_order_relaxed);
+      phase.store(ph + 1, std::memory_order_release);
+    } else {
+      int spins = 0;
+      while (phase.load(std::memory_order_acquire) == ph) {
+        if (aborted.load(std::memory_order_acquire)) return false;
+        if (++spins > 2000) { std::this_thread::yield(); }
+      }
+    }
+    return !aborted.load(std::memory_order_acquire);
+  }
+};
+constexpr int GROUP_MAX = 16;
+
+struct GroupSrc { const double* p[GROUP_MAX]; };
+__global__ void __launch_bounds__(256)
+k_group_sum(GroupSrc src, int world, size_t count, double* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    double s = src.p[0][i];
+    for (int q = 1; q < world; ++q) s += src.p[q][i];  // rank order: identical bits on every rank
+    out[i] = s;
+  }
+}
+
+static int group_allreduce(cba_problem* p, double* buf, size_t count) {
+  cba_group* g = p->group;
+  if (count > g->capacity) return fail(CBA_ERR_INVALID, "group exchange of %zu doubles exceeds the staging capacity %zu", count, g->capacity);
+  const int r = p->rank, par = (int)(p->group_generation & 1ull);
+  for (int q = 0; q < g->world; ++q)
+    if (q != r) HIPCHK(hipStreamWaitEvent(p->stream, g->done[par][q], 0));
+  HIPCHK(hipMemcpyAsync(g->stage[par][r], buf, count * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  HIPCHK(hipEventRecord(g->ready[par][r], p->stream));
+  if (!g->barrier()) return fail(CBA_ERR_INVALID, "device group aborted: another rank failed");
+  GroupSrc src;
+  for (int q = 0; q < g->world; ++q) {
+    src.p[q] = g->stage[par][q];
+    if (q != r) HIPCHK(hipStreamWaitEvent(p->stream, g->ready[par][q], 0));
+  }
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 256));
+  hipLaunchKernelGGL(k_group_sum, dim3(grid), dim3(256), 0, p->stream, src, g->world, count, buf);
+  HIPCHK(hipEventRecord(g->done[par][r], p->stream));
+  p->group_generation++;
+  return CBA_OK;
+}
+
+// in-place sum over the ranks of a sharded solve, enqueued on the engine's stream (no-op for world 1)
 static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
+  if (p->group) return group_allreduce(p, buf, count);
   if (!p->comm) return CBA_OK;
   NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, p->comm, p->stream));
   return CBA_OK;
@@ -257,10 +333,11 @@ static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
 // `buf` / `prefix`: the packed scalars ride at the tail of a payload that needs the same sum (buf[0 .. prefix)), so
 // that payload and scalars cost one collective; buf must have room for prefix + 64 + world doubles.
 static int exchange_at(cba_problem* p, unsigned long long mask, bool with_max, double* buf, size_t prefix) {
-  if (!p->comm) return CBA_OK;
+  if (!p->sharded()) return CBA_OK;
   hipLaunchKernelGGL(k_xpack, dim3(1), dim3(64), 0, p->stream, p->scal, p->flags, mask, with_max ? 1 : 0, p->rank, p->world, buf + prefix);
   const size_t n = (size_t)__builtin_popcountll(mask) + 4 + (with_max ? p->world : 0);
-  NCCLCHK(ncclAllReduce(buf, buf, prefix + n, ncclDouble, ncclSum, p->comm, p->stream));
+  const int rc = allreduce_sum(p, buf, prefix + n);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_xunpack, dim3(1), dim3(64), 0, p->stream, buf + prefix, mask, with_max ? 1 : 0, p->world, p->scal, p->flags);
   return CBA_OK;
 }
@@ -1326,7 +1403,7 @@ static void read_linearization(cba_problem* p, cba_linearization* out) {
 
 template <int NC>
 static int run_linearize(cba_problem* p, cba_linearization* out) {
-  int rc = run_lin_chain<NC>(p, true, p->comm == nullptr, 1.0);  // single rank: folded launches (the damping k_lin_finish derives is not used here)
+  int rc = run_lin_chain<NC>(p, true, !p->sharded(), 1.0);  // single rank: folded launches (the damping k_lin_finish derives is not used here)
   if (rc) return rc;
   rc = sync_scalars(p, 16);
   if (rc) return rc;
@@ -1417,6 +1494,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
                          p->sinv, p->Trec, p->partial_b, p->flags);
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
+      ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
       if (p->schur_v2)
         hipLaunchKernelGGL((k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
                            Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
@@ -1498,7 +1576,7 @@ template <int NC>
 static int run_step(cba_problem* p, double radius, cba_step_info* out) {
   // single rank: no exchange steps in between, so neighbouring small kernels are folded together (k_scale_lin, k_lin_finish,
   // k_step_finish, gradient written by k_reduce_rows, last sums taken by k_publish): 8 launches fewer per iteration
-  const bool compact = p->comm == nullptr;
+  const bool compact = !p->sharded();
   int rc = run_lin_chain<NC>(p, true, compact, radius);
   if (rc) return rc;
   if (!compact) hipLaunchKernelGGL(k_fused_lam, dim3(1), dim3(1), 0, p->stream, p->scal, radius, p->fz);
@@ -1851,11 +1929,11 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
     ScopedTimer t(p, T_VECTOR);
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, alpha, beta, tot, p->lay.ncp_pad,
                        p->rank == 0 ? 1 : 0, (const double*)p->cam_over1, cam_x_new ? p->ncp : 0, (const double*)nullptr, p->x_new, p->partial4);
-    if (p->comm) hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
+    if (p->sharded()) hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
   }
   launch_cam_prep(p, p->x_new, p->tab_new);
   int rc;
-  if (p->comm) {
+  if (p->sharded()) {
     rc = launch_cost(p, p->x_new, p->tab_new, 24, nullptr);
     if (rc) return rc;
     rc = exchange(p, SLOT(24) | SLOT(28), false);  // trial cost, ||step||^2, flags
@@ -1931,6 +2009,96 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
     p->peer_needs_primitives = total > 0.0;
   }
   return CBA_OK;
+}
+
+int cba_group_create(int32_t world, cba_group** out) {
+  if (!out) return fail(CBA_ERR_INVALID, "cba_group_create: null argument");
+  *out = nullptr;
+  if (world < 1 || world > GROUP_MAX) return fail(CBA_ERR_INVALID, "cba_group_create: world %d (1..%d)", world, GROUP_MAX);
+  cba_group* g = new cba_group();
+  g->world = world;
+  g->member.assign(world, nullptr);
+  for (int par = 0; par < 2; ++par) {
+    g->stage[par].assign(world, nullptr);
+    g->ready[par].assign(world, nullptr);
+    g->done[par].assign(world, nullptr);
+  }
+  *out = g;
+  return CBA_OK;
+}
+
+// Called concurrently by the `world` member threads (one per handle); returns when every rank has joined.
+int cba_group_join(cba_problem* p, cba_group* g, int32_t rank) {
+  if (!p || !g) return fail(CBA_ERR_INVALID, "cba_group_join: null argument");
+  if (rank < 0 || rank >= g->world) return fail(CBA_ERR_INVALID, "cba_group_join: rank %d of %d", rank, g->world);
+  if (p->comm || p->group) return fail(CBA_ERR_INVALID, "cba_group_join: the handle already belongs to a communicator");
+  int rc = CBA_OK;
+  {
+    CaptureSafe api_guard(g_capture_mu);
+    if (hipSetDevice(p->device) != hipSuccess) rc = fail(CBA_ERR_HIP, "hipSetDevice(%d) failed", p->device);
+    // staging: the largest payload is the reduced camera system with its right-hand side, or the camera blocks with the
+    // packed scalars behind them
+    const size_t ustride = (p->nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
+    const size_t cap = std::max<size_t>((size_t)p->ncp * p->ncp + p->lay.ncp_pad, (size_t)p->C * ustride + 128) + 128;
+    for (int par = 0; par < 2 && !rc; ++par) {
+      if (guarded_malloc((void**)&g->stage[par][rank], cap * sizeof(double)) != hipSuccess) { rc = fail(CBA_ERR_HIP, "staging allocation failed"); break; }
+      if (hipEventCreateWithFlags(&g->ready[par][rank], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&g->done[par][rank], hipEventDisableTiming) != hipSuccess) { rc = fail(CBA_ERR_HIP, "hipEventCreate failed"); break; }
+      // a first record, so that the waits of the first two collectives find completed events
+      (void)hipEventRecord(g->ready[par][rank], p->stream);
+      (void)hipEventRecord(g->done[par][rank], p->stream);
+    }
+    if (rank == 0) g->capacity = cap;
+    g->member[rank] = p;
+  }
+  if (rc) g->failed.store(1);
+  if (!g->barrier()) return fail(CBA_ERR_INVALID, "cba_group_join: the group was aborted (another rank failed before joining)");  // every rank has allocated and published its staging buffers
+  if (g->failed.load()) return rc ? rc : fail(CBA_ERR_HIP, "cba_group_join: another rank failed to join");
+  {
+    CaptureSafe api_guard(g_capture_mu);
+    for (int q = 0; q < g->world && !rc; ++q) {
+      const int dq = g->member[q]->device;
+      if (dq == p->device) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, p->device, dq) != hipSuccess || !can) { rc = fail(CBA_ERR_HIP, "device %d cannot access device %d", p->device, dq); break; }
+      const hipError_t e = hipDeviceEnablePeerAccess(dq, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { rc = fail(CBA_ERR_HIP, "hipDeviceEnablePeerAccess(%d) failed: %s", dq, hipGetErrorString(e)); break; }
+      (void)hipGetLastError();
+    }
+  }
+  if (rc) g->failed.store(1);
+  if (!g->barrier()) return fail(CBA_ERR_INVALID, "cba_group_join: the group was aborted");  // peer access settled on every rank
+  if (g->failed.load()) return rc ? rc : fail(CBA_ERR_HIP, "cba_group_join: another rank failed to join");
+  p->group = g; p->rank = rank; p->world = g->world; p->group_generation = 0;
+  // every rank must take the same route through an iteration (see cba_comm_init)
+  {
+    const double mine = cba_step_supported(p) ? 0.0 : 1.0;
+    double total = 0.0;
+    HIPCHK(hipMemcpyAsync(p->xbuf, &mine, sizeof(double), hipMemcpyHostToDevice, p->stream));
+    int rca = allreduce_sum(p, p->xbuf, 1);
+    if (rca) return rca;
+    HIPCHK(hipMemcpyAsync(&total, p->xbuf, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->peer_needs_primitives = total > 0.0;
+  }
+  if (p->world == 1) { p->group = nullptr; }  // nothing to exchange; keep the single-rank fast paths
+  return CBA_OK;
+}
+
+// A member that failed outside the library releases the ranks spinning in a group barrier; their calls return an error.
+void cba_group_abort(cba_group* g) { if (g) g->aborted.store(1, std::memory_order_release); }
+
+// After the member handles are destroyed (or at least idle).
+void cba_group_destroy(cba_group* g) {
+  if (!g) return;
+  CaptureSafe api_guard(g_capture_mu);
+  for (int par = 0; par < 2; ++par)
+    for (int q = 0; q < g->world; ++q) {
+      if (g->stage[par][q]) (void)hipFree(g->stage[par][q]);
+      if (g->ready[par][q]) (void)hipEventDestroy(g->ready[par][q]);
+      if (g->done[par][q]) (void)hipEventDestroy(g->done[par][q]);
+    }
+  delete g;
 }
 
 // camera blocks (first n_cam_params entries) of up to three device vectors in one kernel and one wait

@@ -205,6 +205,10 @@ class HipEngine:
             raise ValueError("unique_id must be the 128 bytes produced by comm_unique_id()")
         self._check(self.lib.cba_comm_init(self._h, unique_id, int(rank), int(world)), "cba_comm_init")
 
+    def group_join(self, group: "DeviceGroup", rank: int) -> None:
+        """Join an in-process device group (one host thread per member; returns when all have joined)."""
+        self._check(self.lib.cba_group_join(self._h, group.handle, int(rank)), "cba_group_join")
+
     def info(self) -> dict:
         o = _lib.Info()
         self._check(self.lib.cba_get_info(self._h, C.byref(o)), "cba_get_info")
@@ -223,6 +227,25 @@ class HipEngine:
         calls = np.zeros(n, dtype=np.int64)
         self._check(self.lib.cba_get_timers(self._h, _dp(ms), calls.ctypes.data_as(_lib.c_int64_p)), "cba_get_timers")
         return {self.lib.cba_timer_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
+
+
+class DeviceGroup:
+    """``cba_group``: the handles of one process exchange directly over peer access (caliscope_amd.distributed)."""
+
+    def __init__(self, world: int):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib, self.lib.cba_group_create(int(world), C.byref(h)), "cba_group_create")
+        self.handle, self.world = h, int(world)
+
+    def abort(self) -> None:
+        if self.handle is not None:
+            self.lib.cba_group_abort(self.handle)
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self.lib.cba_group_destroy(self.handle)
+            self.handle = None
 
 
 def device_count() -> int:

@@ -89,10 +89,14 @@ def least_squares(
     kwargs=None,
     *,
     engine_factory=None,
+    devices=None,
 ):
     """Solve the bundle-adjustment problem described by ``args`` on the MI355X.
 
-    ``engine_factory(problem) -> BAEngine`` is a test hook (defaults to the HIP engine).
+    ``engine_factory(problem) -> BAEngine`` is a test hook (defaults to the HIP engine).  ``devices`` (or the
+    environment variable ``CALISCOPE_HIP_DEVICES=0,1,...``) names the GPUs of this node the solve is sharded over — by
+    world point, one host thread per device inside this call (:func:`caliscope_amd.distributed.solve_multi_device`); the
+    reference's call site needs no launcher and no change for it.
     """
     if method != "trf":
         raise ValueError("the MI355X backend implements method='trf' only (what the reference uses)")
@@ -140,9 +144,21 @@ def least_squares(
     problem = BAProblem(parameterization, camera_indices, image_coords, obj_indices, loss=loss, f_scale=float(f_scale),
                         constraint_groups_a=con[0], constraint_groups_b=con[1], constraint_distances=con[2], constraint_weights=con[3])
     if engine_factory is None:
+        from caliscope_amd.distributed import devices_from_env, solve_multi_device
         from caliscope_amd.hip_engine import HipEngine
 
-        engine_factory = HipEngine
+        if devices is None:
+            devices = devices_from_env()
+        if devices is not None and len(devices) > 1:
+            if os.environ.get("CBA_HOST_LOOP", "native") == "python":
+                raise BackendError("CBA_HOST_LOOP=python drives one device; unset it to shard over several")
+            ncp = parameterization.n_camera_params
+            res = solve_multi_device(problem, x0, devices, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose,
+                                     cam_bounds=(lb[:ncp], ub[:ncp]) if bounded else None)
+            if res.status == -1:
+                raise ValueError("Residuals are not finite in the initial point.")
+            return _result_of(res, verbose)
+        engine_factory = (lambda prob: HipEngine(prob, device_id=int(devices[0]))) if devices else HipEngine
     engine = engine_factory(problem)
     try:
         feasible = None
@@ -161,12 +177,20 @@ def least_squares(
             if res.status == -1:
                 raise ValueError("Residuals are not finite in the initial point.")
         else:
+            if bounded and hasattr(engine, "solve"):
+                # the Python driver only rejects infeasible trial points; on the device that silently changes bounded behaviour
+                # (it stalls where scipy's Coleman-Li iteration converges)
+                raise BackendError("CBA_HOST_LOOP=python has no bounded (Coleman-Li) variant: solves with free intrinsics need the native driver")
             res = trf_solve(engine, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
     finally:
         close = getattr(engine, "close", None)
         if close is not None:
             close()
 
+    return _result_of(res, verbose)
+
+
+def _result_of(res, verbose):
     out = OptimizeResult(
         x=res.x, cost=res.cost, optimality=res.optimality, nfev=res.nfev, njev=res.njev, status=res.status,
         message=TERMINATION_MESSAGES.get(res.status, STATUS_REASONS.get(res.status, "")), success=res.status > 0,

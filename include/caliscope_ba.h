@@ -88,6 +88,21 @@ void cba_destroy(cba_problem* p);
 int cba_comm_unique_id(char* out128);
 int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world);
 
+/* ---- sharded solves inside ONE process (one host thread per GPU) ----------------------------------
+ * `CaptureVolume.optimize()` is a single in-process call in the reference (core/capture_volume.py:322-334), so a
+ * caller cannot be asked for a launcher: caliscope_amd.distributed.solve_multi_device starts one thread per device,
+ * each creates the handle of its shard, and the handles join a group.  With RCCL the threads call cba_comm_init with a
+ * shared unique id; cba_group_* is the direct alternative: every rank stages its contribution on its own device and sums
+ * the staging buffers of all ranks in rank order through peer access over xGMI (bit-identical replicas, no ring).  The
+ * group also accepts several handles on the SAME device, which is how a 1-GPU box runs the multi-rank protocol in the tests.
+ * cba_group_join is called concurrently by the `world` member threads and returns when all have joined; destroy the
+ * member handles before the group. */
+typedef struct cba_group cba_group;
+int cba_group_create(int32_t world, cba_group** out);
+int cba_group_join(cba_problem* p, cba_group* g, int32_t rank);
+void cba_group_abort(cba_group* g);   /* a member failed: ranks waiting in the group's barrier return an error instead of spinning */
+void cba_group_destroy(cba_group* g);
+
 /* ---- one trust-region iteration, as primitives (scalars out, vectors stay on the device) ------ */
 
 /* Upload x0 (reference layout, length n = sum(cam_n_params) + 3 P), evaluate the residuals there.

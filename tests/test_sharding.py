@@ -1,5 +1,6 @@
-"""Point sharding and the multi-rank protocol on CPU: world_size 2 over gloo, with the numpy oracle engine
-standing in for the HIP engine (same BAEngine protocol, same set of all-reduced quantities)."""
+"""Point sharding and the multi-rank protocol on CPU: world_size 2 — two processes over the stdlib TCP control plane and
+two threads over the in-process one — with the numpy oracle engine standing in for the HIP engine (same BAEngine protocol,
+same set of all-reduced quantities).  tests/test_multi_device.py runs the same protocol on the device."""
 import os
 import socket
 
@@ -49,19 +50,27 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, loss, out_dir):
-    import torch.distributed as dist
+def _spawn(target, world, *args):
+    import multiprocessing as mp
 
-    from caliscope_amd.distributed import TorchControlPlane, solve_sharded
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=target, args=(r, world) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def _worker(rank, world, port, loss, out_dir):
+    from caliscope_amd.distributed import SocketControlPlane, solve_sharded
     from oracle.engine import OracleEngine
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = SocketControlPlane(rank, world, port)
     try:
         sc, par, x0 = small_problem(n_cams=6, n_points=240, k=6, loss=loss, outliers=0.05 if loss != "linear" else 0.0)
         fs = sc.f_scale_1px() * 2.0 if loss != "linear" else 1.0
         prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs)
-        ctl = TorchControlPlane()
 
         def factory(shard, control):
             sp = shard.problem
@@ -76,18 +85,16 @@ def _worker(rank, world, port, loss, out_dir):
         np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
         np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.cost, res.nfev, res.status], dtype=np.float64))
     finally:
-        dist.destroy_process_group()
+        ctl.close()
 
 
 @pytest.mark.parametrize("loss", ["linear", "soft_l1"])
-def test_two_rank_gloo_solve_matches_single_rank(tmp_path, loss):
-    import torch.multiprocessing as mp
-
+def test_two_rank_socket_solve_matches_single_rank(tmp_path, loss):
     from caliscope_amd.trf import trf_solve
     from oracle.engine import OracleEngine
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), loss, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, world, _free_port(), loss, str(tmp_path))
     sc, par, x0 = small_problem(n_cams=6, n_points=240, k=6, loss=loss, outliers=0.05 if loss != "linear" else 0.0)
     fs = sc.f_scale_1px() * 2.0 if loss != "linear" else 1.0
     single = trf_solve(OracleEngine(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs), x0,
@@ -134,14 +141,11 @@ def test_partition_keeps_constraint_components_together():
 
 
 def _con_worker(rank, world, port, out_dir):
-    import torch.distributed as dist
-
-    from caliscope_amd.distributed import TorchControlPlane, solve_sharded
+    from caliscope_amd.distributed import SocketControlPlane, solve_sharded
     from oracle.engine import OracleEngine
     from tests.constrained_scene import board_scene
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = SocketControlPlane(rank, world, port)
     try:
         sc = board_scene(n_frames=9)
         ga, gb, d, w = sc["constraints"]
@@ -155,24 +159,22 @@ def _con_worker(rank, world, port, out_dir):
             eng.allreduce_max = control.allreduce_max
             return eng
 
-        res = solve_sharded(prob, sc["x0"], TorchControlPlane(), engine_factory=factory, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=100)
+        res = solve_sharded(prob, sc["x0"], ctl, engine_factory=factory, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=100)
         np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
         np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.cost, res.nfev, res.status], dtype=np.float64))
     finally:
-        dist.destroy_process_group()
+        ctl.close()
 
 
-def test_two_rank_gloo_solve_with_constraint_rows(tmp_path):
+def test_two_rank_socket_solve_with_constraint_rows(tmp_path):
     """Constraint components stay on one rank; their share of the reduced camera system rides in the same all-reduce."""
-    import torch.multiprocessing as mp
-
     from caliscope_amd.trf import trf_solve
     from oracle.engine import OracleEngine
     from tests.constrained_scene import board_scene
     from tests.helpers import aligned_difference
 
     world = 2
-    mp.spawn(_con_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _spawn(_con_worker, world, _free_port(), str(tmp_path))
     sc = board_scene(n_frames=9)
     single = trf_solve(OracleEngine(sc["par"], sc["cam"], sc["uv"], sc["obj"], constraints=sc["constraints"]), sc["x0"],
                        ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=100)
@@ -182,3 +184,65 @@ def test_two_rank_gloo_solve_with_constraint_rows(tmp_path):
     assert abs(metas[0][0] - single.cost) <= 1e-10 * single.cost and int(metas[0][2]) == single.status
     pos, ang, scale = aligned_difference(sc["par"], xs[0], single.x)
     assert pos < 1e-8 and ang < 1e-8 and abs(scale - 1) < 1e-8
+
+
+def test_three_rank_thread_control_plane_matches_single_rank():
+    """The in-process control plane of solve_multi_device (one thread per rank) on the numpy engine."""
+    import threading
+
+    from caliscope_amd.distributed import ThreadControlPlane, _ThreadGroupState, solve_sharded
+    from caliscope_amd.trf import trf_solve
+    from oracle.engine import OracleEngine
+    from tests.helpers import aligned_difference
+
+    sc, par, x0 = small_problem(n_cams=6, n_points=240, k=6)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    world = 3
+    state = _ThreadGroupState(world)
+    out = [None] * world
+
+    def factory(shard, control):
+        sp = shard.problem
+        eng = OracleEngine(sp.parameterization, sp.camera_indices, sp.image_coords, sp.obj_indices, allreduce=control.allreduce_sum)
+        eng.allreduce_max = control.allreduce_max
+        return eng
+
+    def member(r):
+        out[r] = solve_sharded(prob, x0, ThreadControlPlane(state, r), engine_factory=factory, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)
+
+    threads = [threading.Thread(target=member, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert all(o is not None for o in out)
+    single = trf_solve(OracleEngine(par, sc.camera_indices, sc.image_coords, sc.obj_indices), x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)
+    for o in out[1:]:
+        assert np.array_equal(o.x, out[0].x) and o.nfev == out[0].nfev and o.cost == out[0].cost
+    assert abs(out[0].cost - single.cost) <= 1e-10 * single.cost and out[0].nfev == single.nfev
+    pos, ang, _ = aligned_difference(par, out[0].x, single.x)
+    assert pos < 1e-8 and ang < 1e-8
+
+
+def test_socket_control_plane_rendezvous_from_env(tmp_path):
+    """``SocketControlPlane.from_env``: the ranks of one launch meet through the rendezvous file keyed by their parent."""
+    _spawn(_env_worker, 3, str(tmp_path))
+    got = [np.load(tmp_path / f"s_{r}.npy") for r in range(3)]
+    for g in got:
+        assert np.array_equal(g, np.array([0.0 + 1.0 + 2.0, 2.0, 7.0]))
+
+
+def _env_worker(rank, world, out_dir):
+    from caliscope_amd.distributed import SocketControlPlane
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_PORT="29555")
+    os.environ.pop("CBA_CONTROL_PORT", None)
+    ctl = SocketControlPlane.from_env(timeout=60)
+    try:
+        s = ctl.allreduce_sum(np.array([float(rank)]))[0]
+        m = ctl.allreduce_max(float(rank))
+        b = ctl.broadcast_bytes(bytes([7]) * 4 if rank == 0 else None, 4)
+        ctl.barrier()
+        np.save(os.path.join(out_dir, f"s_{rank}.npy"), np.array([s, m, float(b[0])]))
+    finally:
+        ctl.close()
