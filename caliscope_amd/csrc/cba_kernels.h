@@ -987,9 +987,12 @@ template <int NC> struct Reg2Cfg {
   static constexpr size_t LDS_BYTES = (size_t)(ZERO_LOC + 1) * REC * sizeof(double);
 };
 
-template <int NC, int SPLIT, int MINW>
+// DBG (profiling builds of the NC = 6 kernel only, tools/schur_split.py; the results are garbage): 1 no pair loop, 2 no record
+// gather, 4 no LDS stores, 8 no index / code loads.  Compile-time: a run-time switch in front of the loads made the
+// compiler drain vmcnt behind every one of them and doubled the kernel's time.
+template <int NC, int SPLIT, int MINW, int DBG = 0>
 __global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
-k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, int debug_skip) {
+k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ dbg_times = nullptr) {
   using Cfg = Reg2Cfg<NC>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
   constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NP = Cfg::NP, NLD = Cfg::NLD;
@@ -1040,8 +1043,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
   }
-  // debug_skip (profiling only, results are garbage): 1 no pair loop, 2 no record gather, 4 no LDS stores, 8 no index / code loads
-  const bool dbg_pairs = !(debug_skip & 1), dbg_gather = !(debug_skip & 2), dbg_store = !(debug_skip & 4), dbg_index = !(debug_skip & 8);
+  constexpr bool dbg_pairs = !(DBG & 1), dbg_gather = !(DBG & 2), dbg_store = !(DBG & 4), dbg_index = !(DBG & 8);
   auto gather = [&](int k) {
     const int e = k * REG_BLOCK + tid;
     if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
@@ -1071,6 +1073,13 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     }
   };
 
+  // DBG & 16: shader-clock time of every phase of a trip, summed per wave (tools/schur_split.py prints them)
+  constexpr bool dbg_time = (DBG & 16) != 0;
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int ph) {
+    if (dbg_time) { const long long t = clock64(); tacc[ph] += t - tlast; tlast = t; }
+  };
+  if (dbg_time) tlast = clock64();
   int nxt = first;
   for (int cur = first - stride; cur < ch_end; cur += stride) {  // first trip: fetch only
     int n_cur = 0;
@@ -1079,20 +1088,25 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
     if (cur >= first) {
+      if (dbg_time) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }  // 0: waiting for the gathered records
       double2* dstrec = reinterpret_cast<double2*>(sh_T);
 #pragma unroll
       for (int k = 0; k < NLD; ++k)
         if (dbg_store) dstrec[k * REG_BLOCK + tid] = rec[k];
       n_cur = n_nx; code_cur = code_nx;
+      if (dbg_time) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }  // 1: LDS stores
       __syncthreads();
+      stamp(2);                                                                           // 2: barrier A
       nxt = min(cur + stride, last);
     }
     // first half of the next chunk's gather (every load unconditional: see k_schur_reg)
 #pragma unroll
     for (int k = 0; k < NLD / 2; ++k) gather(k);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(3);                                                                             // 3: first half of the gather issued
     if (cur >= first && dbg_pairs && n_cur > 0) pair(cc[0]);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(4);                                                                             // 4: first pair
 #pragma unroll
     for (int k = NLD / 2; k < NLD; ++k) gather(k);
     {
@@ -1111,6 +1125,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
         if (dbg_index) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(5);                                                                             // 5: second half, codes, indices issued
     if (cur < first) continue;
     if (dbg_pairs) {
 #pragma unroll
@@ -1118,7 +1133,13 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
         if (it < n_cur) pair(cc[it]);
       for (int it = NCD; it < n_cur; ++it) pair(tp.codes[code_cur + (long)it * WAVE]);  // rare: more than four pairs of one block in a chunk
     }
+    stamp(6);                                                                             // 6: remaining pairs
     __syncthreads();
+    stamp(7);                                                                             // 7: barrier B
+  }
+  if (dbg_time && dbg_times && lane == 0 && half == 0) {
+#pragma unroll
+    for (int ph = 0; ph < 8; ++ph) dbg_times[((long)blockIdx.x * 4 + cw) * 8 + ph] = tacc[ph];
   }
   if (slot >= rep) return;
 #pragma unroll

@@ -149,6 +149,7 @@ struct cba_problem {
 // memset and synchronous-copy calls of every other thread (they fail, and the capture is invalidated), thread-local capture
 // mode notwithstanding.  The recording takes this lock exclusively; every entry point that talks to the device holds it
 // shared, so handles run concurrently across threads and only wait while another thread records its graph (once per handle).
+static int ensure_cholesky_graph(cba_problem* p);
 static std::shared_mutex g_capture_mu;
 static thread_local int tl_capture_safe_depth = 0;
 struct CaptureSafe {  // shared side; nests within a thread (entry point -> helper)
@@ -269,6 +270,7 @@ struct cba_group {
   std::vector<double*> stage[2];
   std::vector<hipEvent_t> ready[2], done[2];
   size_t capacity = 0;  // doubles per staging buffer
+  int timeout_s = 120;  // CBA_GROUP_TIMEOUT_S
   unsigned long long generation = 0;  // advanced by rank 0 behind the barrier; every rank keeps its own copy in step
   const double** d_src[2] = {nullptr, nullptr};  // per rank (device memory of that rank): the `world` staging pointers of a parity
   std::vector<const double**> src_tab[2];
@@ -280,10 +282,20 @@ struct cba_group {
       arrived.store(0, std::memory_order_relaxed);
       phase.store(ph + 1, std::memory_order_release);
     } else {
-      int spins = 0;
+      long spins = 0;
+      std::chrono::steady_clock::time_point t0;
       while (phase.load(std::memory_order_acquire) == ph) {
         if (aborted.load(std::memory_order_acquire)) return false;
-        if (++spins > 2000) { std::this_thread::yield(); }
+        if (++spins > 2000) {
+          std::this_thread::yield();
+          // watchdog: a rank that never arrives (it failed, or the ranks disagree about the next collective) must not
+          // leave the others spinning for ever
+          if (spins == 2001) t0 = std::chrono::steady_clock::now();
+          else if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) {
+            aborted.store(1, std::memory_order_release);
+            return false;
+          }
+        }
       }
     }
     return !aborted.load(std::memory_order_acquire);
@@ -309,7 +321,9 @@ static int group_allreduce(cba_problem* p, double* buf, size_t count) {
     if (q != r) HIPCHK(hipStreamWaitEvent(p->stream, g->done[par][q], 0));
   HIPCHK(hipMemcpyAsync(g->stage[par][r], buf, count * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   HIPCHK(hipEventRecord(g->ready[par][r], p->stream));
-  if (!g->barrier()) return fail(CBA_ERR_INVALID, "device group aborted: another rank failed");
+  if (!g->barrier())
+    return fail(CBA_ERR_INVALID, "device group aborted at collective %llu of rank %d (%zu doubles): another rank failed or never arrived",
+                p->group_generation, r, count);
   GroupSrc src;
   for (int q = 0; q < g->world; ++q) {
     src.p[q] = g->stage[par][q];
@@ -987,7 +1001,15 @@ static int configure_kernels(cba_problem* p) {
   p->n_tiles = p->G * (p->G + 1) / 2;
   if (p->schur_reg) {
     if ((rc = allow_lds(k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, lds_schur_reg<NC>(p->gsz)))) return rc;
-    if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
+    if (NC == 6 && p->debug_skip) {
+      constexpr int D6 = (NC == 6);
+      for (const void* fn : {(const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 2 * D6>,
+                             (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 4 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 8 * D6>,
+                             (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 10 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 15 * D6>,
+                             (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 16 * D6>})
+        if ((rc = raise_lds_ceiling(fn, Reg2Cfg<NC>::LDS_BYTES))) return rc;
+    }
     if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   }
   else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
@@ -1190,6 +1212,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPCHK(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
 #undef TRY
   p->h_vec.resize((size_t)tot);
+  if (!p->eval_only && !p->want_chol_trace) {
+    rc = ensure_cholesky_graph(p);
+    if (rc) return bail(rc);
+  }
   HIPCHK(hipDeviceSynchronize());
   *out = p;
   return CBA_OK;
@@ -1427,6 +1453,21 @@ static int enqueue_cholesky(cba_problem* p) {
   return CBA_OK;
 }
 
+// Recording takes the capture lock exclusively, i.e. waits until no other thread is inside an entry point.  cba_create
+// records the graph up front: inside a sharded solve a rank waiting for that lock while its peers wait for it in a
+// collective (holding the lock shared) would never get it.
+static int ensure_cholesky_graph(cba_problem* p) {
+  if (p->chol_exec) return CBA_OK;
+  CaptureRecording recording;
+  HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_cholesky(p);
+  hipError_t e = hipStreamEndCapture(p->stream, &p->chol_graph);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(CBA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  HIPCHK(hipGraphInstantiate(&p->chol_exec, p->chol_graph, nullptr, nullptr, 0));
+  return CBA_OK;
+}
+
 static int run_cholesky(cba_problem* p) {
   if (p->chol_trace) {  // traced run: plain launches, then dump the stamps of the critical workgroups
     const int nbk = (p->ncp + NB - 1) / NB;
@@ -1445,15 +1486,8 @@ static int run_cholesky(cba_problem* p) {
     }
     return CBA_OK;
   }
-  if (!p->chol_exec) {
-    CaptureRecording recording;
-    HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_cholesky(p);
-    hipError_t e = hipStreamEndCapture(p->stream, &p->chol_graph);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(CBA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    HIPCHK(hipGraphInstantiate(&p->chol_exec, p->chol_graph, nullptr, nullptr, 0));
-  }
+  int rcg = ensure_cholesky_graph(p);
+  if (rcg) return rcg;
   ScopedTimer t(p, T_CHOLESKY);
   HIPCHK(hipGraphLaunch(p->chol_exec, p->stream));
   return CBA_OK;
@@ -1495,9 +1529,40 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
-      if (p->schur_v2)
-        hipLaunchKernelGGL((k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
-                           Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
+      if (p->schur_v2) {
+        auto launch = [&](auto kernel) {
+          hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);
+        };
+        constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
+        switch (NC == 6 ? p->debug_skip : 0) {  // profiling variants (CBA_DEBUG_SCHUR_SKIP, tools/schur_split.py)
+          case 1: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 1 : 0)>); break;
+          case 2: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 2 : 0)>); break;
+          case 4: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 4 : 0)>); break;
+          case 8: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 8 : 0)>); break;
+          case 10: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 10 : 0)>); break;
+          case 15: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 15 : 0)>); break;
+          case 16: {  // phase clock of every wave (profiling): printed per launch
+            long long* d = nullptr;
+            const size_t n = (size_t)p->tile_grid * 4 * 8;
+            if (guarded_malloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
+            (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
+            hipLaunchKernelGGL((k_schur_reg2<NC, SP, MW, (NC == 6 ? 16 : 0)>), dim3(p->tile_grid), dim3(BLOCK * SP), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp,
+                               p->Trec, p->partial, d);
+            std::vector<long long> h(n);
+            (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
+            (void)hipStreamSynchronize(p->stream);
+            (void)guarded_free(d);
+            static const char* names[8] = {"wait records", "LDS stores", "barrier A", "gather 1 issue", "pair 0", "gather 2 + idx issue", "pairs 1..", "barrier B"};
+            double tot = 0.0, sum[8] = {0};
+            for (size_t w = 0; w < n / 8; ++w)
+              for (int ph = 0; ph < 8; ++ph) { sum[ph] += (double)h[w * 8 + ph]; tot += (double)h[w * 8 + ph]; }
+            fprintf(stderr, "k_schur_reg2 phases, mean shader clocks per wave (%zu waves):", n / 8);
+            for (int ph = 0; ph < 8; ++ph) fprintf(stderr, "  %s %.0f (%.1f%%)", names[ph], sum[ph] / (n / 8), 100.0 * sum[ph] / std::max(tot, 1.0));
+            fprintf(stderr, "  | total %.0f\n", tot / (n / 8));
+          } break;
+          default: launch(k_schur_reg2<NC, SP, MW, 0>); break;
+        }
+      }
       else
         hipLaunchKernelGGL((k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
                            lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
@@ -2017,6 +2082,7 @@ int cba_group_create(int32_t world, cba_group** out) {
   if (world < 1 || world > GROUP_MAX) return fail(CBA_ERR_INVALID, "cba_group_create: world %d (1..%d)", world, GROUP_MAX);
   cba_group* g = new cba_group();
   g->world = world;
+  if (const char* e = std::getenv("CBA_GROUP_TIMEOUT_S")) g->timeout_s = std::max(1, std::atoi(e));
   g->member.assign(world, nullptr);
   for (int par = 0; par < 2; ++par) {
     g->stage[par].assign(world, nullptr);
