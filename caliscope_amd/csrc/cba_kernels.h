@@ -979,23 +979,28 @@ k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ p
 //     chunk's records is issued in two halves around the first pair iteration instead of in one burst in front of the
 //     loop (the burst kept a wave ~1 us in the issue stage per chunk: the texture path takes one 16-byte quad per clock).
 template <int NC> struct Reg2Cfg {
-  static constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;
+  static constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;                      // doubles / 16-byte pieces per record
   static constexpr int SPLIT = (NC == 9) ? 3 : 1;
-  static constexpr int REG_BLOCK = BLOCK * SPLIT;
-  static constexpr int NLD = (SCHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;            // gather loads per thread
-  static constexpr int ZERO_LOC = (NLD * REG_BLOCK * 2 + REC - 1) / REC;           // first record slot behind the staged chunk
-  static constexpr size_t LDS_BYTES = (size_t)(ZERO_LOC + 1) * REC * sizeof(double);
+  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;
+  // staging: every wave gathers its own run of EPW chunk slots, NLD load instructions of 64 pieces each; its LDS region is
+  // padded to whole instructions (the tail lanes of the last one land in the padding)
+  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots per wave (96 / 32)
+  static constexpr int NLD = (EPW * NP + WAVE - 1) / WAVE;                         // gather loads per thread (14 / 8)
+  static constexpr int WAVE_PIECES = NLD * WAVE;
+  static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // the all-zero record sits behind the staged chunk
+  static constexpr size_t LDS_BYTES = (size_t)(ZERO_PIECE + NP) * 16;
+  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (NP & 1) == 1, "staging layout");
 };
 
 // DBG (profiling builds of the NC = 6 kernel only, tools/schur_split.py; the results are garbage): 1 no pair loop, 2 no record
-// gather, 4 no LDS stores, 8 no index / code loads.  Compile-time: a run-time switch in front of the loads made the
-// compiler drain vmcnt behind every one of them and doubled the kernel's time.
+// gather, 4 no LDS stores, 8 no index / code loads, 16 phase clock.  Compile-time: a run-time switch in front of the loads made
+// the compiler drain vmcnt behind every one of them and doubled the kernel's time.
 template <int NC, int SPLIT, int MINW, int DBG = 0>
 __global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
 k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ dbg_times = nullptr) {
   using Cfg = Reg2Cfg<NC>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NP = Cfg::NP, NLD = Cfg::NLD;
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NP = Cfg::NP, NLD = Cfg::NLD, EPW = Cfg::EPW;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
   constexpr int NCD = 4;                        // codes of a chunk that travel in registers
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -1006,6 +1011,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
   const int tid = (int)threadIdx.x;
   const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
   const int cw = ct / WAVE, lane = ct % WAVE;
+  const int sw = tid / WAVE;                    // staging wave
   const int blk = (rep > 1) ? tid % nblk : ct;
   const int slot = (rep > 1) ? tid / nblk : 0, half = (rep > 1) ? 0 : tid / BLOCK;
   const int r0 = half * RH;
@@ -1025,12 +1031,21 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     }
     return;
   }
-  for (int k = tid; k < REC; k += REG_BLOCK) sh_T[Cfg::ZERO_LOC * REC + k] = 0.0;
+  for (int k = tid; k < REC; k += REG_BLOCK) sh_T[Cfg::ZERO_PIECE * 2 + k] = 0.0;
   const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
-  const unsigned zero_code = (unsigned)Cfg::ZERO_LOC | ((unsigned)Cfg::ZERO_LOC << 16);
+  const unsigned zero_code = (unsigned)Cfg::ZERO_PIECE | ((unsigned)Cfg::ZERO_PIECE << 16);
+  constexpr bool dbg_pairs = !(DBG & 1), dbg_gather = !(DBG & 2), dbg_store = !(DBG & 4), dbg_index = !(DBG & 8);
 
+  // Software pipeline (as k_schur_reg): while the pairs of chunk `cur` are multiplied, the registers receive the records
+  // and the first codes of the next chunk and the record indices of the one after.  Every load is unconditional (the
+  // streams are padded, the last chunk is simply fetched again).
+  // Gather: load k of a lane is 16-byte piece (k * 64 + lane) % NP of wave slot (k * 64 + lane) / NP, so the 64 lanes of a
+  // load cover ~7 whole records and the LDS copy is one contiguous ds_write_b128.  The record index of a slot comes from
+  // two coalesced loads per wave (slots 0..63 and 64..EPW-1 of the wave's run) and a ds_bpermute per load: load k only
+  // needs slots [k * 64 / NP, (k * 64 + 63) / NP], which lie entirely in one of the two registers.  Slot and piece advance
+  // by constants from one load to the next (64 = q NP + r), so there is no division in the loop.
   double2 rec[NLD];
-  int idx[NLD];
+  int idxA = 0, idxB = 0;
   unsigned cd[NCD];
 #pragma unroll
   for (int k = 0; k < NLD; ++k) rec[k] = make_double2(0.0, 0.0);
@@ -1038,20 +1053,28 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
   for (int k = 0; k < NCD; ++k) cd[k] = zero_code;
   int n_nx = 0;          // iterations of this wave in the fetched chunk
   long code_nx = 0;      // offset of this lane's first code of the fetched chunk
-  {
-    const int c0 = tp.chunk_start[first];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
-  }
-  constexpr bool dbg_pairs = !(DBG & 1), dbg_gather = !(DBG & 2), dbg_store = !(DBG & 4), dbg_index = !(DBG & 8);
-  auto gather = [&](int k) {
-    const int e = k * REG_BLOCK + tid;
-    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
+  auto load_indices = [&](int chunk) {
+    if (!dbg_index) return;
+    const int* src = tp.obs + tp.chunk_start[chunk] + sw * EPW;
+    idxA = src[lane];
+    if (EPW > WAVE) idxB = src[WAVE + (lane & (EPW - WAVE - 1))];  // EPW - 64 is a power of two (32)
   };
+  static_assert(EPW <= WAVE || ((EPW - WAVE) & (EPW - WAVE - 1)) == 0, "second index register");
+  load_indices(first);
+  auto gather = [&](int k) {
+    // compile-time per k: which index register; per lane: slot and piece of this load
+    constexpr int Q = WAVE / NP, RM = WAVE % NP;
+    int piece = (k * RM + lane % NP), el = k * Q + lane / NP;   // (k * 64 + lane) = (k Q + lane / NP) NP + (k RM + lane % NP)
+    el += piece / NP; piece %= NP;                               // k RM + lane % NP < NLD NP: the compiler folds these for constant k
+    el = min(el, EPW - 1);
+    const bool useB = (k * WAVE) / NP >= WAVE;                   // whole load in the second register (slots >= 64)
+    const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
+    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * REC)[piece];
+  };
+  // (no load straddles the two index registers: loads k < NP end at slot (64 k + 63) / NP <= 63, loads k >= NP start at slot >= 64)
   auto pair = [&](unsigned code) {
-    const int i_loc = code & 0xffffu, j_loc = code >> 16;
-    const double* Ri = sh_T + i_loc * REC + 3 * r0;
-    const double2* Rj = reinterpret_cast<const double2*>(sh_T + j_loc * REC);
+    const double* Ri = sh_T + (code & 0xffffu) * 2 + 3 * r0;
+    const double2* Rj = reinterpret_cast<const double2*>(sh_T) + (code >> 16);
     double Ti[3 * RH];
 #pragma unroll
     for (int k = 0; k < 3 * RH; ++k) Ti[k] = Ri[k];
@@ -1089,17 +1112,17 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
     if (cur >= first) {
       if (dbg_time) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }  // 0: waiting for the gathered records
-      double2* dstrec = reinterpret_cast<double2*>(sh_T);
+      double2* dstrec = reinterpret_cast<double2*>(sh_T) + sw * Cfg::WAVE_PIECES + (tid % WAVE);
 #pragma unroll
       for (int k = 0; k < NLD; ++k)
-        if (dbg_store) dstrec[k * REG_BLOCK + tid] = rec[k];
+        if (dbg_store) dstrec[k * WAVE] = rec[k];
       n_cur = n_nx; code_cur = code_nx;
       if (dbg_time) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }  // 1: LDS stores
       __syncthreads();
       stamp(2);                                                                           // 2: barrier A
       nxt = min(cur + stride, last);
     }
-    // first half of the next chunk's gather (every load unconditional: see k_schur_reg)
+    // first half of the next chunk's gather
 #pragma unroll
     for (int k = 0; k < NLD / 2; ++k) gather(k);
     __builtin_amdgcn_sched_barrier(0);
@@ -1119,10 +1142,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
       for (int k = 0; k < NCD; ++k)
         if (dbg_index) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
-      const int c0 = tp.chunk_start[min(nxt + stride, last)];
-#pragma unroll
-      for (int k = 0; k < NLD; ++k)
-        if (dbg_index) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + tid) / NP, SCHUNK - 1)];
+      load_indices(min(nxt + stride, last));
     }
     __builtin_amdgcn_sched_barrier(0);
     stamp(5);                                                                             // 5: second half, codes, indices issued

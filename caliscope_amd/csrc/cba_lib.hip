@@ -936,7 +936,8 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   prm.rep = (NC == 6 && g * g <= BLOCK / 2) ? BLOCK / (g * g) : 1;  // small groups: several threads per block
   if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1))) : 1;
   prm.chunk_cap = SCHUNK;
-  prm.zero_loc = Reg2Cfg<NC>::ZERO_LOC;
+  prm.slots_per_wave = Reg2Cfg<NC>::EPW; prm.wave_pieces = Reg2Cfg<NC>::WAVE_PIECES; prm.rec_pieces = Reg2Cfg<NC>::NP;
+  prm.zero_piece = Reg2Cfg<NC>::ZERO_PIECE;
   if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
   Reg2Plan plan;
@@ -947,8 +948,9 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   p->n_pairs = plan.n_pairs;
   p->plan_lane_util = plan.lane_iters > 0 ? (double)plan.n_pairs / (double)plan.lane_iters : 0.0;
   if (plan_timing)
-    fprintf(stderr, "  plan: %d tiles x %d regions, %d chunks (%.1f records each), %ld pairs, lane utilisation %.3f\n", nT, plan.n_regions,
-            p->n_tile_chunks, p->n_tile_chunks ? (double)p->tile_stream_len / p->n_tile_chunks : 0.0, plan.n_pairs, p->plan_lane_util);
+    fprintf(stderr, "  plan: %d tiles x %d regions, %d chunks (%.1f slots each), %ld pairs, lane utilisation %.3f, LDS cycles per 16-lane read group %.2f (arrival order %.2f)\n",
+            nT, plan.n_regions, p->n_tile_chunks, p->n_tile_chunks ? (double)p->tile_stream_len / p->n_tile_chunks : 0.0, plan.n_pairs, p->plan_lane_util,
+            plan.lds_groups ? (double)plan.lds_cycles / plan.lds_groups : 0.0, plan.lds_groups ? (double)plan.lds_cycles_arrival / plan.lds_groups : 0.0);
   const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, true);
   lap("workgroup binding");
   std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
@@ -977,7 +979,7 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
   tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
   tp.tile_elems = BLOCK * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;
-  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit; tp.zero_loc = prm.zero_loc;
+  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit; tp.zero_loc = prm.zero_piece;
   p->tp = tp;
   return CBA_OK;
 }

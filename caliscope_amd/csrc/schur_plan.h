@@ -15,9 +15,19 @@
 // per chunk on cfg4 and the cap is 2: 82 % of the lane-iterations do work (tools/plan_sim.py).
 //
 // The pair list leaves the plan TRANSPOSED: for chunk c and wave w, nit[c].w iterations of 64 codes each, code =
-// (i_loc | j_loc << 16) of the pair lane `l` multiplies in that iteration, or ZERO (both halves point at an all-zero
+// (i_addr | j_addr << 16) of the pair lane `l` multiplies in that iteration (LDS addresses of the two records in 16-byte
+// units), or ZERO (both halves point at an all-zero
 // record kept behind the chunk in LDS) when the lane has nothing left.  The kernel's pair loop is therefore branch-free
 // with a wave-uniform trip count, and a lane fetches its code with one coalesced load.
+//
+// LDS bank conflicts.  A lane reads its two records with ds_read_b128; the LDS serves a wave's b128 read in four fixed
+// groups of 16 lanes, one cycle per group when the 16 addresses fall into 16 different 16-byte bank groups
+// ((address / 16) mod 16, /opt/skills/guides/MI355X_MICROARCH.md, LDS).  A record starts at slot * stride with an odd
+// stride in 16-byte units, so the bank group of piece m is (m + c * slot) mod 16 with c odd: what matters is the slot's
+// residue mod 16.  With the records of a chunk in arrival order the residues of the 16 records a lane group reads are
+// random (3.1 cycles per group instead of 1: the pair loop was LDS-bound on exactly that).  The order of the records
+// inside a chunk is free, so the plan COLOURS them: every (iteration, lane group, operand) is a clique of up to 16
+// records that want 16 different residues; a greedy pass plus two refinement sweeps assign residues, then slots.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -33,8 +43,13 @@ struct Reg2Params {
   int C = 0, P = 0;       // cameras, world points
   int G = 1, g = 1;       // camera groups, cameras per group (max)
   int rep = 1;            // threads per camera-pair block (small groups: 256 / g^2)
-  int chunk_cap = 384;    // records per chunk
-  int zero_loc = 0;       // chunk-local index of the all-zero record
+  int chunk_cap = 384;    // records (slots) per chunk
+  // LDS layout of a staged chunk, in 16-byte pieces: slot s lives at (s / slots_per_wave) * wave_pieces + (s % slots_per_wave) *
+  // rec_pieces (every wave of the kernel stages its own run of slots, padded to whole load instructions); the codes carry
+  // these piece addresses, so the pair loop does no index arithmetic.  slots_per_wave must be a multiple of 16 and
+  // rec_pieces odd (then the bank group of a record is decided by slot mod 16, see below).
+  int slots_per_wave = 96, wave_pieces = 896, rec_pieces = 9;
+  int zero_piece = 0;     // piece address of the all-zero record
   int region_chunks = 128;
   int heavy_obs = 0;      // > 0: points with more observations are left out (k_heavy_schur forms their share)
   int threads = 0;        // host threads (0: hardware concurrency)
@@ -49,6 +64,9 @@ struct Reg2Plan {
   std::vector<int> tile_chunk_begin;  // [n_tiles + 1]
   long n_pairs = 0;                   // pair codes that do work
   long lane_iters = 0;                // 64 x wave-iterations (n_pairs / lane_iters = lane utilisation)
+  long lds_groups = 0;                // (iteration, lane group, operand) read groups
+  long lds_cycles = 0;                // LDS cycles they take with the plan's slots (1 per group when conflict-free)
+  long lds_cycles_arrival = 0;        // ... and with the records in arrival order, for comparison
   int n_regions = 1;
 };
 
@@ -60,9 +78,16 @@ struct Job {
   int tile = 0, q_begin = 0, q_end = 0;
   std::vector<int> obs, chunk_start, code_start;
   std::vector<unsigned> nit, codes;
-  long n_pairs = 0, lane_iters = 0;
+  long n_pairs = 0, lane_iters = 0, lds_groups = 0, lds_cycles = 0, lds_cycles_arrival = 0;
   int rc = 0;
 };
+
+// lane groups of ds_read_b128 (wave64): group of lane l
+inline int b128_group(int lane) {
+  const int l = lane & 31, hi = (lane >> 5) * 2;
+  const bool g0 = (l < 4) || (l >= 12 && l < 16) || (l >= 20 && l < 28);
+  return hi + (g0 ? 0 : 1);
+}
 
 }  // namespace reg2_detail
 
@@ -72,7 +97,8 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
   using namespace reg2_detail;
   const int G = prm.G, g = prm.g, C = prm.C, P = prm.P, rep = std::max(1, prm.rep);
   const int nT = G * (G + 1) / 2, nblk = g * g, R = prm.chunk_cap;
-  const unsigned ZERO = (unsigned)prm.zero_loc | ((unsigned)prm.zero_loc << 16);
+  const unsigned ZERO = (unsigned)prm.zero_piece | ((unsigned)prm.zero_piece << 16);
+  auto piece_of = [&](int slot) { return (unsigned)((slot / prm.slots_per_wave) * prm.wave_pieces + (slot % prm.slots_per_wave) * prm.rec_pieces); };
   std::vector<int> gcam(G + 1);
   for (int a = 0; a <= G; ++a) gcam[a] = std::min(a * g, C);
   std::vector<int> ta(nT), tb(nT);
@@ -241,22 +267,28 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
         if (alt.cost < best.cost) best = std::move(alt);
       }
     }
-    // emit: stream entries, transposed codes
+    // emit: stream entries (in slot order), transposed codes
     std::vector<std::vector<unsigned>> lists(256);
     std::vector<unsigned> rr((size_t)nblk, 0), rrc((size_t)g, 0);
+    std::vector<int> rec_obs;                 // chunk record id (arrival order) -> observation
+    std::vector<int> slot_of, residue;        // record id -> slot / residue
+    std::vector<std::vector<int>> cliques;    // distinct record ids a lane group reads in one instruction
+    std::vector<std::vector<int>> rec_cl;     // record id -> cliques it belongs to
+    std::vector<int> clq_cnt;                 // [clique][16] members per residue
+    std::vector<int> mark;
     for (const std::vector<int>& mem : best.members) {
       if (mem.empty()) continue;
       for (auto& l : lists) l.clear();
       std::fill(rr.begin(), rr.end(), 0u);
       std::fill(rrc.begin(), rrc.end(), 0u);
-      const int open = (int)job.obs.size();
+      rec_obs.clear();
       for (int ci : mem) {
         const int q = cand[ci].q;
         const int* gb = &pgb[(size_t)q * (G + 1)];
         const int na = gb[a + 1] - gb[a], nb = diag ? 0 : gb[b + 1] - gb[b];
-        const int base = (int)job.obs.size() - open;
-        for (int i = gb[a]; i < gb[a] + na; ++i) job.obs.push_back(i);
-        for (int i = gb[b]; !diag && i < gb[b] + nb; ++i) job.obs.push_back(i);
+        const int base = (int)rec_obs.size();
+        for (int i = gb[a]; i < gb[a] + na; ++i) rec_obs.push_back(i);
+        for (int i = gb[b]; !diag && i < gb[b] + nb; ++i) rec_obs.push_back(i);
         auto emit = [&](int blk, unsigned code) {
           const int slot = (int)(rr[blk]++ % (unsigned)rep);
           lists[(size_t)slot * nblk + blk].push_back(code);
@@ -277,16 +309,105 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
           }
         }
       }
-      unsigned packed = 0;
+      const int n_rec = (int)rec_obs.size();
+      size_t nit_w[4];
       for (int w = 0; w < 4; ++w) {
         size_t mx = 0;
         for (int l = 0; l < 64; ++l) mx = std::max(mx, lists[(size_t)w * 64 + l].size());
-        mx = std::min<size_t>(mx, 255);  // a byte per wave; 255 pairs of one block in one chunk cannot happen (chunk_cap records)
+        nit_w[w] = std::min<size_t>(mx, 255);  // a byte per wave; 255 pairs of one block in one chunk cannot happen (chunk_cap records)
+      }
+      // cliques of the LDS reads: per wave, iteration, lane group and operand the distinct records read together
+      cliques.clear();
+      mark.assign((size_t)n_rec, -1);
+      for (int w = 0; w < 4; ++w)
+        for (size_t it = 0; it < nit_w[w]; ++it)
+          for (int side = 0; side < 2; ++side) {
+            const size_t c0 = cliques.size();
+            cliques.resize(c0 + 4);
+            for (int l = 0; l < 64; ++l) {
+              const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
+              if (it >= li.size()) continue;
+              const int r = side ? (int)(li[it] >> 16) : (int)(li[it] & 0xffffu);
+              const int cq = (int)c0 + b128_group(l);
+              if (mark[r] == cq) continue;  // the same record twice in a group: one address, a broadcast
+              mark[r] = cq;
+              cliques[cq].push_back(r);
+            }
+          }
+      auto clique_cost = [&](const std::vector<int>& res) {
+        long cyc = 0;
+        int cnt[16];
+        for (const std::vector<int>& cq : cliques) {
+          if (cq.empty()) continue;
+          std::fill(cnt, cnt + 16, 0);
+          int mx = 0;
+          for (int r : cq) mx = std::max(mx, ++cnt[res[r] & 15]);
+          cyc += mx;
+        }
+        return cyc;
+      };
+      residue.resize((size_t)n_rec);
+      for (int r = 0; r < n_rec; ++r) residue[r] = r & 15;
+      long groups = 0;
+      for (const std::vector<int>& cq : cliques) groups += cq.empty() ? 0 : 1;
+      job.lds_groups += groups;
+      job.lds_cycles_arrival += clique_cost(residue);
+      // colouring
+      const int cap_class = (R + 15) / 16;
+      rec_cl.assign((size_t)n_rec, {});
+      for (size_t cq = 0; cq < cliques.size(); ++cq)
+        for (int r : cliques[cq]) rec_cl[r].push_back((int)cq);
+      clq_cnt.assign(cliques.size() * 16, 0);
+      std::vector<int> class_size(16, 0), order_r((size_t)n_rec);
+      for (int r = 0; r < n_rec; ++r) order_r[r] = r;
+      std::stable_sort(order_r.begin(), order_r.end(), [&](int x, int y) { return rec_cl[x].size() > rec_cl[y].size(); });
+      std::fill(residue.begin(), residue.end(), -1);
+      auto best_residue = [&](int r) {
+        int best_rho = -1;
+        long best_cost = 0;
+        for (int rho = 0; rho < 16; ++rho) {
+          if (class_size[rho] >= cap_class) continue;
+          long cost = 0;
+          for (int cq : rec_cl[r]) cost += clq_cnt[(size_t)cq * 16 + rho];
+          cost = cost * 64 + class_size[rho];
+          if (best_rho < 0 || cost < best_cost) { best_rho = rho; best_cost = cost; }
+        }
+        return best_rho;
+      };
+      auto put = [&](int r, int rho, int d) {
+        residue[r] = d > 0 ? rho : -1;
+        class_size[rho] += d;
+        for (int cq : rec_cl[r]) clq_cnt[(size_t)cq * 16 + rho] += d;
+      };
+      for (int r : order_r) put(r, best_residue(r), +1);
+      for (int sweep = 0; sweep < 2; ++sweep)
+        for (int r : order_r) {
+          const int old = residue[r];
+          put(r, old, -1);
+          put(r, best_residue(r), +1);
+        }
+      job.lds_cycles += clique_cost(residue);
+      // slots: residue rho takes rho, rho + 16, rho + 32, ...
+      slot_of.assign((size_t)n_rec, 0);
+      {
+        int next_k[16] = {0};
+        for (int r = 0; r < n_rec; ++r) slot_of[r] = residue[r] + 16 * next_k[residue[r]]++;
+      }
+      int n_slots = 0;
+      for (int r = 0; r < n_rec; ++r) n_slots = std::max(n_slots, slot_of[r] + 1);
+      const size_t open = job.obs.size();
+      job.obs.resize(open + n_slots, 0);  // holes point at observation 0: loaded, never referenced
+      for (int r = 0; r < n_rec; ++r) job.obs[open + slot_of[r]] = rec_obs[r];
+      unsigned packed = 0;
+      for (int w = 0; w < 4; ++w) {
+        const size_t mx = nit_w[w];
         packed |= (unsigned)mx << (8 * w);
         for (size_t it = 0; it < mx; ++it)
           for (int l = 0; l < 64; ++l) {
             const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
-            job.codes.push_back(it < li.size() ? li[it] : ZERO);
+            unsigned code = ZERO;
+            if (it < li.size()) code = piece_of(slot_of[li[it] & 0xffffu]) | (piece_of(slot_of[li[it] >> 16]) << 16);
+            job.codes.push_back(code);
           }
         job.lane_iters += (long)mx * 64;
       }
@@ -321,7 +442,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
   out.code_start.assign(n_chunks + 1, 0);
   out.nit.assign(n_chunks, 0);
   out.tile_chunk_begin.assign(nT + 1, 0);
-  out.n_pairs = 0; out.lane_iters = 0;
+  out.n_pairs = 0; out.lane_iters = 0; out.lds_groups = 0; out.lds_cycles = 0; out.lds_cycles_arrival = 0;
   size_t o = 0, cpos = 0, ch = 0;
   for (int t = 0; t < nT; ++t) {
     out.tile_chunk_begin[t] = (int)ch;
@@ -336,6 +457,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       }
       o += j.obs.size(); cpos += j.codes.size(); ch += j.nit.size();
       out.n_pairs += j.n_pairs; out.lane_iters += j.lane_iters;
+      out.lds_groups += j.lds_groups; out.lds_cycles += j.lds_cycles; out.lds_cycles_arrival += j.lds_cycles_arrival;
     }
   }
   out.tile_chunk_begin[nT] = (int)ch;

@@ -9,10 +9,11 @@
 extern "C" {
 
 // acc_out: [n_tiles][256][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
-int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int zero_loc, int region_chunks, int heavy_obs,
+int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int zero_piece, int region_chunks, int heavy_obs,
                 int threads, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
   cba::Reg2Params prm;
-  prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap; prm.zero_loc = zero_loc;
+  prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap; prm.zero_piece = zero_piece;
+  prm.rec_pieces = rec / 2; prm.slots_per_wave = 96; prm.wave_pieces = (96 * prm.rec_pieces + 63) / 64 * 64;
   prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads;
   const long N = hps[P];
   std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
@@ -32,9 +33,15 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
         for (int it = 0; it < n; ++it)
           for (int lane = 0; lane < 64; ++lane, ++code) {
             const unsigned cd = plan.codes[code];
-            const int il = cd & 0xffff, jl = cd >> 16;
-            if (il == zero_loc && jl == zero_loc) continue;
-            if (il >= len || jl >= len) return -11;
+            const int ia = cd & 0xffff, ja = cd >> 16;
+            if (ia == zero_piece && ja == zero_piece) continue;
+            // piece address -> slot (the inverse of the kernel's staging layout)
+            auto slot_at = [&](int addr) {
+              const int w = addr / prm.wave_pieces, off = addr % prm.wave_pieces;
+              return (off % prm.rec_pieces) ? -1 : w * prm.slots_per_wave + off / prm.rec_pieces;
+            };
+            const int il = slot_at(ia), jl = slot_at(ja);
+            if (il < 0 || jl < 0 || il >= len || jl >= len) return -11;
             const double* Ti = T + (long)plan.obs[c0 + il] * rec;
             const double* Tj = T + (long)plan.obs[c0 + jl] * rec;
             double* a = acc_out + ((long)t * 256 + w * 64 + lane) * bsz;
@@ -46,6 +53,7 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
     }
   stats_out[0] = n_chunks; stats_out[1] = plan.n_pairs; stats_out[2] = plan.lane_iters; stats_out[3] = plan.n_regions;
   stats_out[4] = (long)plan.obs.size() - 2L * chunk_cap;
+  stats_out[5] = plan.lds_groups; stats_out[6] = plan.lds_cycles; stats_out[7] = plan.lds_cycles_arrival;
   return 0;
 }
 }
