@@ -708,23 +708,50 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Schur pass, register-accumulating variant (6-parameter cameras): k_tprep + k_schur_reg.
+// Schur pass, register-accumulating variant: k_tprep + k_schur_reg2 (+ k_reg_reduce, k_reg_fold, k_unprime).
 //
 // With Z_i = B_i L^-T (L L^T = V + lam D^2 of the point) the pair term A_i^T (Z_i Z_j^T) A_j is T_i T_j^T for the
 // per-observation NC x 3 matrix T_i = A_i^T Z_i, and the rhs term is T_i y with y = L^-1 g_point.
 //
-// k_tprep evaluates every observation ONCE (the LDS-tile kernel re-linearises an observation in each of the
-// G tiles it takes part in), stores T_i as a 16-byte aligned record of REC doubles in HBM (144 B per
-// observation) and reduces the rhs per camera (LDS atomics, per-workgroup partials, k_reduce_rows).
-// REC doubles per record: 3 NC rounded up to an ODD number of 16-byte pieces (18 for NC = 6, 30 for NC = 9), so that
-// the pieces of different records spread over all LDS banks.
-template <int NC> struct SchurRec { static constexpr int REC = 2 * ((((3 * NC + 1) / 2) & 1) ? (3 * NC + 1) / 2 : (3 * NC + 1) / 2 + 1); };
-static_assert(SchurRec<6>::REC == 18 && SchurRec<9>::REC == 30, "record sizes");
-constexpr int PAIRCAP = 3072;  // pairs of one chunk, staged in LDS (the plan closes a chunk before it overflows)
-// Chunk of the register kernel's streams.  A thread's share of a chunk is a handful of pairs, and a wave runs at the pace of
-// its busiest lane: the more pairs per chunk, the smaller the relative spread (384 observations x 144 B = 54 KB of records,
-// two workgroups per CU still fit).  The LDS-tile kernel and the per-observation kernels keep CHUNK = 256.
-constexpr int SCHUNK = 384;
+// k_tprep evaluates every observation ONCE (the LDS-tile kernel re-linearises an observation in each of the G tiles it
+// takes part in), stores a record per observation in HBM and reduces the rhs per camera (LDS atomics, per-workgroup
+// partials, k_reduce_rows).
+//
+// The record is COMPACT.  The camera block factors (ba_math.h, project_full): A = G [C | I | A_intr] with G = d(pixel)/dX_c
+// (2 x 3), C = -[Y]x J_l the derivative of the rotated point Y = R X by the rotation vector, so
+//     T = [ J_l^T [Y]x Q ;  Q ;  T_intr ],     Q = G^T Z  (3 x 3: rows 3..5 of T),   T_intr = A_intr^T Z  (rows 6..8, NC = 9).
+// The record holds Y (3), Q (9) and T_intr (9): 12 doubles = 96 B (NC = 6) or 21 -> 22 doubles = 176 B (NC = 9) instead of
+// 144 / 240 B; the pair kernel gathers, stages and reads a third less, and it never forms the top rows: with D = Q_i Q_j^T
+//     [Y_i]x D [Y_j]x^T | [Y_i]x D | D [Y_j]x^T | D
+// are the four 3 x 3 quarters of the PRIMED block T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr] (99 FP64 operations per pair
+// instead of 108 on 18 + 18 doubles).  The per-camera factor J_l^T is applied once per block at the end (k_unprime).
+// The rhs needs the true rows 0..2, which k_tprep has in registers anyway.
+template <int NC> struct SchurRec {
+  static constexpr int NVAL = (NC == 9) ? 21 : 12;        // doubles that carry data
+  static constexpr int NPH = (NVAL + 1) / 2;              // 16-byte pieces of a record in HBM: 6 / 11
+  static constexpr int REC = 2 * NPH;                     // record stride in HBM, doubles: 12 / 22
+  static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride in LDS, 16-byte pieces, odd: 7 / 11 (bank spread)
+};
+static_assert(SchurRec<6>::REC == 12 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");
+
+// true T (NC x 3, row-major) from a compact record and the camera's J_l (row-major): k_heavy_schur, k_con_schur
+template <int NC>
+__device__ __forceinline__ void expand_record(const double* __restrict__ rec, const double* __restrict__ Jl, double* __restrict__ T) {
+  const double Y0 = rec[0], Y1 = rec[1], Y2 = rec[2];
+  const double* Q = rec + 3;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const double q0 = Q[m], q1 = Q[3 + m], q2 = Q[6 + m];
+    const double c0 = Y1 * q2 - Y2 * q1, c1 = Y2 * q0 - Y0 * q2, c2 = Y0 * q1 - Y1 * q0;  // Y x Q[:, m]
+#pragma unroll
+    for (int r = 0; r < 3; ++r) T[3 * r + m] = Jl[r] * c0 + Jl[3 + r] * c1 + Jl[6 + r] * c2;  // (J_l^T c)_r
+    T[9 + m] = q0; T[12 + m] = q1; T[15 + m] = q2;
+  }
+  if (NC == 9) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) T[18 + k] = rec[12 + k];
+  }
+}
 
 template <int NC>
 __global__ void __launch_bounds__(BLOCK)
@@ -768,8 +795,9 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
       const CamTab& ct = cam_at(sh_tab, cam);
+      const double X = px[pt], Yw = px[lay.Ppad + pt], Zw = px[2 * lay.Ppad + pt];
       double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
-      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss, f_scale, e, A, B);
+      obs_linearize<NC>(ct, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);
       const int np = (int)ct.nparams;
       double Vd[6], L[6];
 #pragma unroll
@@ -786,17 +814,23 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       double y[3];
       chol3_fwd(L, gpt, y);
       double* bc = sh_b + cam_off[cam];
+      // rotated point Y = R X (the record's first three entries)
+      rec[0] = fma(ct.R[2], Zw, fma(ct.R[1], Yw, ct.R[0] * X));
+      rec[1] = fma(ct.R[5], Zw, fma(ct.R[4], Yw, ct.R[3] * X));
+      rec[2] = fma(ct.R[8], Zw, fma(ct.R[7], Yw, ct.R[6] * X));
 #pragma unroll
       for (int r = 0; r < NC; ++r) {
         const bool live = r < np;
+        double t[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rec[3 * r + k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
-        if (live) lds_add(&bc[r], rec[3 * r] * y[0] + rec[3 * r + 1] * y[1] + rec[3 * r + 2] * y[2]);
+        for (int k = 0; k < 3; ++k) t[k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
+        if (live) lds_add(&bc[r], t[0] * y[0] + t[1] * y[1] + t[2] * y[2]);
+        if (r >= 3) { rec[3 * r - 6] = t[0]; rec[3 * r - 5] = t[1]; rec[3 * r - 4] = t[2]; }  // rows 3.. : Q, then T_intr
       }
     }
-    // The 64 records of a wave are one contiguous 9216-byte run of Trec.  A lane storing its own record issues
-    // 16-byte stores 144 bytes apart (64 cache lines per instruction: the store path stalled, 45 % issue-stall
-    // cycles); so the wave transposes through LDS and every store instruction writes 1 KB contiguous.
+    // The 64 records of a wave are one contiguous run of Trec.  A lane storing its own record issues 16-byte stores one
+    // record apart (64 cache lines per instruction: the store path stalled, 45 % issue-stall cycles); so the wave transposes
+    // through LDS and every store instruction writes 1 KB contiguous.
 #pragma unroll
     for (int k = 0; k < NP; ++k) stage[lane * NP + k] = make_double2(rec[2 * k], rec[2 * k + 1]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -821,176 +855,79 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) partial_b[(long)blockIdx.x * lay.ncp_pad + i] = sh_b[i];
 }
 
-// k_schur_reg: the LDS-tile kernel is bound by LDS throughput (36 ds_add_f64 per pair at ~28 cycles per
-// wave-instruction, tools/lds_pattern_bench.hip).  But a chunk of 256 observations sends only a few pairs to
-// each of the g^2 = 256 camera-pair blocks of a tile, so here every THREAD owns one block for the whole kernel:
-// the plan lists each chunk's pairs sorted by owner thread; the workgroup gathers the chunk's T records into LDS,
-// then a thread walks its few pairs and accumulates T_i T_j^T in 36 registers — no atomics, no S tile in LDS.
-// Records are read back with ds_read_b128 (REC/2 odd: the 16-byte slots of different observations spread over
-// all banks; b128 reads reach the LDS rate at this kernel's low occupancy, b64 reads do not).
-// In a diagonal tile only the blocks li < lj are real; the other g(g+1)/2 threads are "helpers": helper k serves
-// camera k mod na and receives a share of that camera's (i, i) items (and of its duplicate-row pairs, listed in
-// both orders).  The next chunk's records, pair list and slice bounds are fetched into registers while the
-// current chunk's pairs are multiplied.  Results leave through per-workgroup partials (k_reg_reduce).
-// NC = 6 runs SPLIT = 1, NC = 9 SPLIT = 3 (768 threads, 3 x 9 accumulators per thread, one workgroup = 12 waves per CU).
-// SPLIT = 1: 256 threads, one whole block (NC x NC accumulators, ~230 VGPRs, two workgroups = 8 waves per CU).
-// SPLIT = 2: 512 threads, thread tid accumulates rows [h*NC/2, (h+1)*NC/2) of block tid % 256, h = tid / 256
-// (<= 128 VGPRs, 16 waves per CU).  Measured on cfg4: SPLIT = 2 is 15 % slower (every pair iteration's fixed cost -
-// pair decode, T_j reads - is paid twice), so SPLIT = 1 is what the library launches.
-template <int NC, int SPLIT, int MINW>
-__global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
-k_schur_reg(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, int debug_skip) {
-  constexpr int REG_BLOCK = BLOCK * SPLIT;
-  constexpr int REC = SchurRec<NC>::REC;
-  constexpr int NP = REC / 2;                                   // 16-byte pieces per record
-  constexpr int NLD = (SCHUNK * NP + REG_BLOCK - 1) / REG_BLOCK;  // gather loads per thread
-  constexpr int NPV = (PAIRCAP + REG_BLOCK - 1) / REG_BLOCK;
-  constexpr int RH = (NC + SPLIT - 1) / SPLIT;                  // rows per thread
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* sh_T = sh;                                            // [CHUNK][REC] (+ slack for the last partial load round)
-  pair_t* sh_pairs = reinterpret_cast<pair_t*>(sh_T + NLD * REG_BLOCK * 2);  // [PAIRCAP]
-
-  const int nblk = tp.g * tp.g;
-  // A small camera group leaves most of the 256 threads without a block (8 cameras: 64 blocks).  Then rep = 256 / nblk threads
-  // share every block: replica `slot` takes every rep-th pair of the block's slice into its own accumulators and its own
-  // partial row (k_reg_reduce sums the rows).  rep = 1 (SPLIT > 1 or g = 16): one thread per block as before.
-  const int rep = (SPLIT == 1) ? tp.rep : 1;
-  const int blk = (rep > 1) ? (int)threadIdx.x % nblk : (int)threadIdx.x % BLOCK;
-  const int slot = (rep > 1) ? (int)threadIdx.x / nblk : 0, half = (rep > 1) ? 0 : (int)threadIdx.x / BLOCK;
-  const bool owner = blk < nblk && slot < rep;
-  const int r0 = half * RH;                                     // first row of this thread
-  double acc[RH][NC];
-#pragma unroll
-  for (int r = 0; r < RH; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
-
-  const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
-  double* dst = partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
-  if (first >= ch_end) {  // more workgroups than chunks in this range
-    if (slot < rep) {
-#pragma unroll
-      for (int k = 0; k < RH * NC; ++k)
-        if (r0 * NC + k < NC * NC) dst[k] = 0.0;
-    }
-    return;
-  }
-  const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
-  // Software pipeline: while the pairs of chunk `cur` are multiplied, the registers receive the records, pair list
-  // and slice bounds of the next chunk and the record indices of the one after.  Every load is unconditional (the
-  // streams are padded, the last chunk is simply fetched again): a load under a divergent branch makes the compiler
-  // drain vmcnt at the join, which would expose the whole fetch latency before each pair loop.
-  // The gather is piece-wise: element e = k * 512 + tid of a chunk is 16-byte piece e % NP of entry e / NP, so the
-  // 64 lanes of one load cover ~7 whole records (a thread fetching its own 144-byte record would touch 64 cache
-  // lines per instruction and thrash the L1), and the LDS copy is a contiguous ds_write_b128.
-  double2 rec[NLD];
-  pair_t pv[NPV];
-  int idx[NLD];
-#pragma unroll
-  for (int k = 0; k < NLD; ++k) rec[k] = make_double2(0.0, 0.0);
-#pragma unroll
-  for (int k = 0; k < NPV; ++k) pv[k] = 0;
-  int q0 = 0, q1 = 0;
-  const int bo_lane = min(blk, nblk - 1);
-  {
-    const int c0 = tp.chunk_start[first];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, SCHUNK - 1)];
-  }
-  int nxt = first;
-  for (int cur = first - stride; cur < ch_end; cur += stride) {  // first trip: fetch only
-    int my_q0 = 0, my_q1 = 0;
-    if (cur >= first) {
-      double2* dstrec = reinterpret_cast<double2*>(sh_T);
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) dstrec[k * REG_BLOCK + threadIdx.x] = rec[k];
-#pragma unroll
-      for (int k = 0; k < NPV; ++k) sh_pairs[k * REG_BLOCK + threadIdx.x] = pv[k];
-      my_q0 = q0; my_q1 = q1;
-      __syncthreads();
-      nxt = min(cur + stride, last);
-    }
-    {
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int e = k * REG_BLOCK + (int)threadIdx.x;
-        rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx[k] * REC)[e % NP];
-      }
-      const int qb = tp.pair_start[nxt];
-#pragma unroll
-      for (int k = 0; k < NPV; ++k) pv[k] = tp.pairs[qb + k * REG_BLOCK + (int)threadIdx.x];
-      const unsigned short* bo = tp.blk_off + (long)nxt * (nblk + 1) + bo_lane;
-      const int b0 = bo[0], b1 = bo[1];
-      q0 = owner ? b0 : 0;
-      q1 = owner ? b1 : 0;
-      const int c0 = tp.chunk_start[min(nxt + stride, last)];
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) idx[k] = tp.obs[c0 + min((k * REG_BLOCK + (int)threadIdx.x) / NP, SCHUNK - 1)];
-    }
-    if (cur < first) continue;
-    if (debug_skip != 1) {
-      for (int q = my_q0 + slot; q < my_q1; q += rep) {
-        const unsigned pr = sh_pairs[q];
-        const int i_loc = pr & 0xffffu, j_loc = pr >> 16;
-        const double* Ri = sh_T + i_loc * REC + 3 * r0;
-        const double2* Rj = reinterpret_cast<const double2*>(sh_T + j_loc * REC);
-        double Ti[3 * RH];
-#pragma unroll
-        for (int k = 0; k < 3 * RH; ++k) Ti[k] = Ri[k];
-        // T_j two columns (6 doubles = three 16-byte slots) at a time
-#pragma unroll
-        for (int cp = 0; cp < (NC + 1) / 2; ++cp) {
-          double Tj[6];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const double2 b = (3 * cp + k < NP) ? Rj[3 * cp + k] : make_double2(0.0, 0.0);
-            Tj[2 * k] = b.x; Tj[2 * k + 1] = b.y;
-          }
-#pragma unroll
-          for (int r = 0; r < RH; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-              const int c = 2 * cp + cc;
-              // three chained FMAs; `acc += a*b + c*d + e*f` would cost a multiply, two FMAs and an add
-              if (c < NC) acc[r][c] = fma(Ti[3 * r + 2], Tj[3 * cc + 2], fma(Ti[3 * r + 1], Tj[3 * cc + 1], fma(Ti[3 * r], Tj[3 * cc], acc[r][c])));
-            }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // partial of this workgroup: [256 blocks][NC*NC] (x rep rows); this thread holds rows r0 .. r0 + RH - 1 of its block
-  if (slot >= rep) return;
-#pragma unroll
-  for (int r = 0; r < RH; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
-}
-
-// k_schur_reg2: the same ownership (one camera-pair block per thread, accumulators in registers, T records of a chunk in
-// LDS), driven by the dealt plan of schur_plan.h.  What changed against k_schur_reg:
-//   * the plan equalises the pairs per block of every chunk (cap t, first-fit dealing over a region of ~128 chunks), so
-//     a wave spends ~80 % of its lane-iterations on real pairs instead of ~45 %;
-//   * the pair list is transposed: iteration `it` of wave w reads 64 consecutive codes, one per lane, idle lanes get the
-//     code of an all-zero record.  No per-thread slice table, no pair list in LDS, no divergence: the trip count is
-//     wave-uniform and the body is straight-line code;
-//   * the first four codes of the next chunk travel in registers like its records do, and the gather of the next
-//     chunk's records is issued in two halves around the first pair iteration instead of in one burst in front of the
-//     loop (the burst kept a wave ~1 us in the issue stage per chunk: the texture path takes one 16-byte quad per clock).
+// k_schur_reg2.  A 256-thread workgroup is bound to one tile (camera group a x camera group b) of the reduced camera
+// system; every THREAD owns one camera-pair block of the tile for the whole kernel and keeps its NC x NC accumulators in
+// registers (NC = 9: three threads per block, three rows each) — no atomics, no S tile in LDS, a fixed summation order.
+// A tile's work is a stream of chunks (schur_plan.h): the workgroup gathers the chunk's compact records into LDS, then
+// every thread multiplies the record pairs that belong to its block.
+//   * the plan equalises the pairs per block of every chunk (cap t, first-fit dealing over a region of chunks), so a wave
+//     spends ~80 % of its lane-iterations on real pairs (round 1's greedy window: ~45 %);
+//   * the pair list is transposed: iteration `it` of wave w reads 64 consecutive codes, one per lane; a code holds the
+//     LDS addresses of the two records, idle lanes get the address of an all-zero record.  No per-thread slice table, no
+//     pair list in LDS, no divergence: the trip count is wave-uniform and the body is straight-line code;
+//   * the plan also picks the slot of every record inside the chunk so that the 16 lanes the LDS serves together read
+//     from 16 different bank groups (schur_plan.h, "LDS bank conflicts");
+//   * records are gathered piece-wise (lane e of a wave loads 16-byte piece e % NPH of slot e / NPH of the wave's run of
+//     slots: ~10 whole records per load instruction; a thread fetching its own record would touch 64 cache lines per
+//     instruction), through registers, one chunk ahead; the first four codes of the next chunk travel the same way.
 template <int NC> struct Reg2Cfg {
-  static constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;                      // doubles / 16-byte pieces per record
+  static constexpr int REC = SchurRec<NC>::REC, NPH = SchurRec<NC>::NPH, LST = SchurRec<NC>::LST;
   static constexpr int SPLIT = (NC == 9) ? 3 : 1;
   static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;
-  // staging: every wave gathers its own run of EPW chunk slots, NLD load instructions of 64 pieces each; its LDS region is
-  // padded to whole instructions (the tail lanes of the last one land in the padding)
-  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots per wave (96 / 32)
-  static constexpr int NLD = (EPW * NP + WAVE - 1) / WAVE;                         // gather loads per thread (14 / 8)
-  static constexpr int WAVE_PIECES = NLD * WAVE;
+  // slots (records) per chunk: 512 x 7 pieces = 56 KB (two workgroups per CU) / 384 x 11 pieces = 66 KB (one 12-wave workgroup;
+  // its 168-register budget leaves room for six staging registers per thread, not eleven)
+  static constexpr int SCHUNK = (NC == 9) ? 384 : 512;
+  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots staged by one wave (128 / 32)
+  static constexpr int NLD = (EPW * NPH + WAVE - 1) / WAVE;                        // gather loads per thread (12 / 6; the tail lanes of
+                                                                                   // a last, partial load repeat the wave's last slot)
+  static constexpr int WAVE_PIECES = EPW * LST;                                    // LDS pieces of one wave's run
   static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // the all-zero record sits behind the staged chunk
-  static constexpr size_t LDS_BYTES = (size_t)(ZERO_PIECE + NP) * 16;
-  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (NP & 1) == 1, "staging layout");
+  static constexpr size_t LDS_BYTES = (size_t)(ZERO_PIECE + LST) * 16;
+  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
+  static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
 };
+
+// Primed pair product of a thread that owns three rows (NC = 9): with Rm = Q_i (or T_intr,i) the three rows are
+//   Rm T'_j^T = [ (Rm Q_j^T) [Y_j]x^T | Rm Q_j^T | Rm T_intr,j^T ],   and [Y_i]x times that for the rows of [Y_i]x Q_i.
+// Column group by column group, so that few values are live at a time (the kernel has 168 registers per thread).
+template <int NC, bool CROSS_I>
+__device__ __forceinline__ void pair_rows(double (*acc)[NC], const double* Rm, const double* Yi, const double2* __restrict__ Rj) {
+  auto put = [&](int c, double m0, double m1, double m2) {
+    if (CROSS_I) {  // ([Y_i]x M)[r][c] = (Y_i x M[:, c])_r, two FMAs each
+      acc[0][c] = fma(Yi[1], m2, fma(-Yi[2], m1, acc[0][c]));
+      acc[1][c] = fma(Yi[2], m0, fma(-Yi[0], m2, acc[1][c]));
+      acc[2][c] = fma(Yi[0], m1, fma(-Yi[1], m0, acc[2][c]));
+    } else {
+      acc[0][c] += m0; acc[1][c] += m1; acc[2][c] += m2;
+    }
+  };
+  double D[3][3];
+  double Yj[3];
+  {
+    const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
+    Yj[0] = j0.x; Yj[1] = j0.y; Yj[2] = j1.x;
+    const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 3; ++b2) D[a][b2] = fma(Rm[3 * a + 2], Qj[3 * b2 + 2], fma(Rm[3 * a + 1], Qj[3 * b2 + 1], Rm[3 * a] * Qj[3 * b2]));
+  }
+#pragma unroll
+  for (int b2 = 0; b2 < 3; ++b2) put(3 + b2, D[0][b2], D[1][b2], D[2][b2]);
+  // (D [Y_j]x^T)[a][c] = (Y_j x D[a, :])_c
+  put(0, fma(Yj[1], D[0][2], -(Yj[2] * D[0][1])), fma(Yj[1], D[1][2], -(Yj[2] * D[1][1])), fma(Yj[1], D[2][2], -(Yj[2] * D[2][1])));
+  put(1, fma(Yj[2], D[0][0], -(Yj[0] * D[0][2])), fma(Yj[2], D[1][0], -(Yj[0] * D[1][2])), fma(Yj[2], D[2][0], -(Yj[0] * D[2][2])));
+  put(2, fma(Yj[0], D[0][1], -(Yj[1] * D[0][0])), fma(Yj[0], D[1][1], -(Yj[1] * D[1][0])), fma(Yj[0], D[2][1], -(Yj[1] * D[2][0])));
+  if constexpr (NC == 9) {
+    const double2 j6 = Rj[6], j7 = Rj[7], j8 = Rj[8], j9 = Rj[9], j10 = Rj[10];
+    const double Ij[9] = {j6.x, j6.y, j7.x, j7.y, j8.x, j8.y, j9.x, j9.y, j10.x};
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2)
+      put(6 + b2, fma(Rm[2], Ij[3 * b2 + 2], fma(Rm[1], Ij[3 * b2 + 1], Rm[0] * Ij[3 * b2])),
+          fma(Rm[5], Ij[3 * b2 + 2], fma(Rm[4], Ij[3 * b2 + 1], Rm[3] * Ij[3 * b2])),
+          fma(Rm[8], Ij[3 * b2 + 2], fma(Rm[7], Ij[3 * b2 + 1], Rm[6] * Ij[3 * b2])));
+  }
+}
 
 // DBG (profiling builds of the NC = 6 kernel only, tools/schur_split.py; the results are garbage): 1 no pair loop, 2 no record
 // gather, 4 no LDS stores, 8 no index / code loads, 16 phase clock.  Compile-time: a run-time switch in front of the loads made
@@ -1000,11 +937,11 @@ __global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
 k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ dbg_times = nullptr) {
   using Cfg = Reg2Cfg<NC>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NP = Cfg::NP, NLD = Cfg::NLD, EPW = Cfg::EPW;
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NPH = Cfg::NPH, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
   constexpr int NCD = 4;                        // codes of a chunk that travel in registers
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* sh_T = sh;
+  double2* sh_p = reinterpret_cast<double2*>(sh);  // the staged chunk, in 16-byte pieces
 
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
@@ -1031,19 +968,17 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     }
     return;
   }
-  for (int k = tid; k < REC; k += REG_BLOCK) sh_T[Cfg::ZERO_PIECE * 2 + k] = 0.0;
+  for (int k = tid; k < LST; k += REG_BLOCK) sh_p[Cfg::ZERO_PIECE + k] = make_double2(0.0, 0.0);
   const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
   const unsigned zero_code = (unsigned)Cfg::ZERO_PIECE | ((unsigned)Cfg::ZERO_PIECE << 16);
   constexpr bool dbg_pairs = !(DBG & 1), dbg_gather = !(DBG & 2), dbg_store = !(DBG & 4), dbg_index = !(DBG & 8);
 
-  // Software pipeline (as k_schur_reg): while the pairs of chunk `cur` are multiplied, the registers receive the records
-  // and the first codes of the next chunk and the record indices of the one after.  Every load is unconditional (the
-  // streams are padded, the last chunk is simply fetched again).
-  // Gather: load k of a lane is 16-byte piece (k * 64 + lane) % NP of wave slot (k * 64 + lane) / NP, so the 64 lanes of a
-  // load cover ~7 whole records and the LDS copy is one contiguous ds_write_b128.  The record index of a slot comes from
-  // two coalesced loads per wave (slots 0..63 and 64..EPW-1 of the wave's run) and a ds_bpermute per load: load k only
-  // needs slots [k * 64 / NP, (k * 64 + 63) / NP], which lie entirely in one of the two registers.  Slot and piece advance
-  // by constants from one load to the next (64 = q NP + r), so there is no division in the loop.
+  // Software pipeline: while the pairs of chunk `cur` are multiplied, the registers receive the records and the first
+  // codes of the next chunk and the record indices of the one after.  Every load is unconditional (the streams are padded,
+  // the last chunk is simply fetched again): a load under a divergent branch makes the compiler drain vmcnt at the join.
+  // The record index of a slot comes from two coalesced loads per wave (slots 0..63 and 64..EPW-1 of the wave's run) and a
+  // ds_bpermute per gather: load k covers slots [64 k / NPH, (64 k + 63) / NPH], which lie entirely in one of the two
+  // registers (64 slots are a whole number of loads).
   double2 rec[NLD];
   int idxA = 0, idxB = 0;
   unsigned cd[NCD];
@@ -1057,42 +992,64 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     if (!dbg_index) return;
     const int* src = tp.obs + tp.chunk_start[chunk] + sw * EPW;
     idxA = src[lane];
-    if (EPW > WAVE) idxB = src[WAVE + (lane & (EPW - WAVE - 1))];  // EPW - 64 is a power of two (32)
+    if (EPW > WAVE) idxB = src[WAVE + lane];
   };
-  static_assert(EPW <= WAVE || ((EPW - WAVE) & (EPW - WAVE - 1)) == 0, "second index register");
   load_indices(first);
-  auto gather = [&](int k) {
-    // compile-time per k: which index register; per lane: slot and piece of this load
-    constexpr int Q = WAVE / NP, RM = WAVE % NP;
-    int piece = (k * RM + lane % NP), el = k * Q + lane / NP;   // (k * 64 + lane) = (k Q + lane / NP) NP + (k RM + lane % NP)
-    el += piece / NP; piece %= NP;                               // k RM + lane % NP < NLD NP: the compiler folds these for constant k
+  // slot (inside the wave's run) and piece of load k of this lane: k * 64 + lane = el * NPH + piece
+  auto slot_piece = [&](int k, int& el, int& piece) {
+    constexpr int Q = WAVE / NPH, RM = WAVE % NPH;
+    piece = k * RM + lane % NPH;
+    el = k * Q + lane / NPH + piece / NPH;
+    piece %= NPH;
     el = min(el, EPW - 1);
-    const bool useB = (k * WAVE) / NP >= WAVE;                   // whole load in the second register (slots >= 64)
+  };
+  auto gather = [&](int k) {
+    int el, piece;
+    slot_piece(k, el, piece);
+    const bool useB = EPW > WAVE && k * WAVE >= WAVE * NPH;  // slots >= 64: the second index register
     const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
     if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * REC)[piece];
   };
-  // (no load straddles the two index registers: loads k < NP end at slot (64 k + 63) / NP <= 63, loads k >= NP start at slot >= 64)
   auto pair = [&](unsigned code) {
-    const double* Ri = sh_T + (code & 0xffffu) * 2 + 3 * r0;
-    const double2* Rj = reinterpret_cast<const double2*>(sh_T) + (code >> 16);
-    double Ti[3 * RH];
+    const double2* Ri = sh_p + (code & 0xffffu);
+    const double2* Rj = sh_p + (code >> 16);
+    // record: [Y0 Y1][Y2 Q00][Q01 Q02][Q10 Q11][Q12 Q20][Q21 Q22] ([I00 I01] .. [I22 -])
+    if constexpr (NC == 6) {  // the thread owns all six rows: rows 3..5 are Q_i T'_j^T, rows 0..2 [Y_i]x times the same products
+      const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
+      const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
+      const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
+      const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
+      const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
+      double M[3][NC];
 #pragma unroll
-    for (int k = 0; k < 3 * RH; ++k) Ti[k] = Ri[k];
+      for (int a = 0; a < 3; ++a) {
 #pragma unroll
-    for (int cp = 0; cp < (NC + 1) / 2; ++cp) {  // T_j two columns (three 16-byte slots) at a time
-      double Tj[6];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double2 b = (3 * cp + k < NP) ? Rj[3 * cp + k] : make_double2(0.0, 0.0);
-        Tj[2 * k] = b.x; Tj[2 * k + 1] = b.y;
+        for (int b2 = 0; b2 < 3; ++b2)
+          M[a][3 + b2] = fma(Qi[3 * a + 2], Qj[3 * b2 + 2], fma(Qi[3 * a + 1], Qj[3 * b2 + 1], Qi[3 * a] * Qj[3 * b2]));
+        // (D [Y_j]x^T)[a][c] = (Y_j x D[a, :])_c
+        M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
+        M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
+        M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
       }
 #pragma unroll
-      for (int r = 0; r < RH; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const int c = 2 * cp + cc;
-          if (c < NC) acc[r][c] = fma(Ti[3 * r + 2], Tj[3 * cc + 2], fma(Ti[3 * r + 1], Tj[3 * cc + 1], fma(Ti[3 * r], Tj[3 * cc], acc[r][c])));
-        }
+      for (int c = 0; c < NC; ++c) {
+        acc[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], acc[0][c]));
+        acc[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], acc[1][c]));
+        acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
+        acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
+      }
+    } else {
+      double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
+      if (half == 2) {  // rows of T_intr,i
+        const double2 i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
+        Rm[0] = i6.x; Rm[1] = i6.y; Rm[2] = i7.x; Rm[3] = i7.y; Rm[4] = i8.x; Rm[5] = i8.y; Rm[6] = i9.x; Rm[7] = i9.y; Rm[8] = i10.x;
+      } else {
+        const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
+        Yi[0] = i0.x; Yi[1] = i0.y; Yi[2] = i1.x;
+        Rm[0] = i1.y; Rm[1] = i2.x; Rm[2] = i2.y; Rm[3] = i3.x; Rm[4] = i3.y; Rm[5] = i4.x; Rm[6] = i4.y; Rm[7] = i5.x; Rm[8] = i5.y;
+      }
+      if (half == 0) pair_rows<NC, true>(acc, Rm, Yi, Rj);
+      else pair_rows<NC, false>(acc, Rm, Yi, Rj);
     }
   };
 
@@ -1112,10 +1069,13 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
     if (cur >= first) {
       if (dbg_time) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }  // 0: waiting for the gathered records
-      double2* dstrec = reinterpret_cast<double2*>(sh_T) + sw * Cfg::WAVE_PIECES + (tid % WAVE);
+      double2* dstrec = sh_p + sw * Cfg::WAVE_PIECES;
 #pragma unroll
-      for (int k = 0; k < NLD; ++k)
-        if (dbg_store) dstrec[k * WAVE] = rec[k];
+      for (int k = 0; k < NLD; ++k) {
+        int el, piece;
+        slot_piece(k, el, piece);
+        if (dbg_store) dstrec[el * LST + piece] = rec[k];
+      }
       n_cur = n_nx; code_cur = code_nx;
       if (dbg_time) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }  // 1: LDS stores
       __syncthreads();
@@ -1167,6 +1127,56 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int c = 0; c < NC; ++c)
       if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
+}
+
+// The pair kernel accumulates PRIMED blocks T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr]; the true rows 0..2 are J_l^T times the primed
+// ones, so block (ci, cj) of Sacc becomes P_i^T block P_j with P = blockdiag(J_l, I).  One thread per camera pair ci <= cj,
+// after k_reg_reduce / k_reg_fold and before anything else adds to Sacc (heavy points, constraint rows, the all-reduce).
+template <int NC>
+__global__ void k_unprime(double* __restrict__ Sacc, const double* __restrict__ tab, const int* __restrict__ cam_off,
+                          const int* __restrict__ cam_np, int n_cams, int ncp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ci = t / n_cams, cj = t % n_cams;
+  if (ci >= n_cams || cj < ci) return;
+  const int npi = cam_np[ci], npj = cam_np[cj];
+  double* base = Sacc + (long)cam_off[ci] * ncp + cam_off[cj];
+  const double* Ji = tab + (long)ci * CAMTAB_DOUBLES + 12;  // CamTab::Jl, row-major
+  const double* Jj = tab + (long)cj * CAMTAB_DOUBLES + 12;
+  // rows 0..2:  J_i^T B (all columns);  for the diagonal block only the upper triangle is stored: mirror what is missing
+  auto at = [&](int r, int c) -> double { return (ci == cj && c < r) ? base[(long)c * ncp + r] : base[(long)r * ncp + c]; };
+  double B[3][NC], Cc[NC][3], TL[3][3];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double b0 = c < npj ? at(0, c) : 0.0, b1 = c < npj ? at(1, c) : 0.0, b2 = c < npj ? at(2, c) : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) B[r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
+  }
+  // columns 0..2 of rows 3..: B J_j
+#pragma unroll
+  for (int r = 3; r < NC; ++r) {
+    const double a0 = r < npi ? at(r, 0) : 0.0, a1 = r < npi ? at(r, 1) : 0.0, a2 = r < npi ? at(r, 2) : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Cc[r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
+  }
+  // top-left 3 x 3: J_i^T B J_j
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) TL[r][c] = B[r][0] * Jj[c] + B[r][1] * Jj[3 + c] + B[r][2] * Jj[6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c >= npj || (ci == cj && c < r)) continue;
+      base[(long)r * ncp + c] = (c < 3) ? TL[r][c] : B[r][c];
+    }
+  if (ci != cj) {  // (below the diagonal of a diagonal block: the mirror image of rows 0..2, not stored)
+#pragma unroll
+    for (int r = 3; r < NC; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (r < npi) base[(long)r * ncp + c] = Cc[r][c];
+  }
 }
 
 // Reduce the partials of k_schur_reg over the workgroups of each tile (fixed order).  blockDim = (64, 4) as
@@ -2148,7 +2158,7 @@ k_triangulate(long n_points, const long* __restrict__ pt_start, const int* __res
 //   W_pc = sum_{i in (p, c)} T_i   (NC x 3),    Sacc += W_p W_p^T   over the cameras that see p,
 // one workgroup per heavy point; the pair plan skips them.  Points with more than CHUNK observations are also split
 // over several chunks ("fragments": chunk_pts = (point, -1)); k_build / k_backsub add a fragment's sums by atomics.
-constexpr int HEAVY_OBS = 40;  // 40 observations -> at most 40^2 = 1600 pair entries (PAIRCAP = 3072) even if they repeat a camera
+constexpr int HEAVY_OBS = 40;  // more observations than this: per-camera sums (k_heavy_schur) instead of 40^2 / 2 pair codes per point
 
 __global__ void k_zero_heavy(const int* __restrict__ heavy_pts, int n_heavy, VecLayout lay, double* __restrict__ a, int rows_a,
                              double* __restrict__ b, int rows_b) {
@@ -2185,7 +2195,7 @@ template <int NC>
 __global__ void __launch_bounds__(BLOCK)
 k_heavy_schur(const int* __restrict__ heavy_pts, const int* __restrict__ pt_start, const int* __restrict__ obs_cam,
               const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
-              const double* __restrict__ Trec, double* __restrict__ heavy_W, double* __restrict__ Sacc) {
+              const double* __restrict__ Trec, const double* __restrict__ tab, double* __restrict__ heavy_W, double* __restrict__ Sacc) {
   constexpr int REC = SchurRec<NC>::REC;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* W = sh;                                  // [ncp][3]
@@ -2197,7 +2207,8 @@ k_heavy_schur(const int* __restrict__ heavy_pts, const int* __restrict__ pt_star
   const int o0 = pt_start[p], o1 = pt_start[p + 1];
   for (int i = o0 + threadIdx.x; i < o1; i += BLOCK) {
     const int cam = obs_cam[i], off = cam_off[cam], np = cam_np[cam];
-    const double* T = Trec + (long)i * REC;
+    double T[3 * NC];
+    expand_record<NC>(Trec + (long)i * REC, tab + (long)cam * CAMTAB_DOUBLES + 12, T);  // compact record -> true T (J_l of the camera)
     for (int r = 0; r < np; ++r) {
       lds_add(&W[(off + r) * 3 + 0], T[3 * r]); lds_add(&W[(off + r) * 3 + 1], T[3 * r + 1]); lds_add(&W[(off + r) * 3 + 2], T[3 * r + 2]);
       seen[off + r] = 1;
@@ -2371,7 +2382,7 @@ __device__ __forceinline__ bool con_point_factor(const double* __restrict__ Vblk
 template <int NC>
 __global__ void __launch_bounds__(BLOCK)
 k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vblk, const double* __restrict__ gvec,
-            const double* __restrict__ sinv, const double* __restrict__ Trec, const int* __restrict__ pt_start,
+            const double* __restrict__ sinv, const double* __restrict__ Trec, const double* __restrict__ tab, const int* __restrict__ pt_start,
             const int* __restrict__ obs_cam, const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
             double* __restrict__ Sacc, double* __restrict__ bacc, int* __restrict__ flags) {
   constexpr int REC = SchurRec<NC>::REC;
@@ -2451,7 +2462,8 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
       }
       for (int i = pt_start[p]; i < pt_start[p + 1]; ++i) {
         const int cam = obs_cam[i];
-        const double* T = Trec + (long)i * REC;
+        double T[3 * NC];
+        expand_record<NC>(Trec + (long)i * REC, tab + (long)cam * CAMTAB_DOUBLES + 12, T);
         const int off = cam_off[cam], npar = cam_np[cam];
         for (int r = 0; r < npar; ++r) G[(long)c * gw + off + r] += T[3 * r] * z[0] + T[3 * r + 1] * z[1] + T[3 * r + 2] * z[2];
       }

@@ -530,11 +530,6 @@ template <int NC> static size_t lds_schur_tile(int g) {
 template <int NC> struct RegCfg;
 template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
-template <int NC> static size_t lds_schur_reg(int) {
-  constexpr int NP = SchurRec<NC>::REC / 2, RB = BLOCK * RegCfg<NC>::SPLIT, NLD = (SCHUNK * NP + RB - 1) / RB;
-  constexpr int NPV = (PAIRCAP + RB - 1) / RB;
-  return (size_t)NLD * RB * 16 + (size_t)NPV * RB * sizeof(pair_t);
-}
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
   return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
 }
@@ -640,8 +635,8 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     std::vector<int> chunk_start, pair_start;  // local offsets, start with 0
     int open = 0;                              // start of the currently open chunk
   };
-  const bool reg = p->schur_reg;
-  const int chunk_cap = reg ? SCHUNK : CHUNK;  // observations per chunk of a tile stream
+  const bool reg = false;  // the register kernel has its own plan (build_reg2_tile_plan); this one serves the LDS-tile kernel
+  const int chunk_cap = CHUNK;  // observations per chunk of a tile stream
   const int nblk = g * g;
   // register kernel: the pairs of a chunk are sorted by owner thread.  Off-diagonal tiles and li < lj: the owner
   // of block (li, lj) is thread li * g + lj.  Diagonal tiles, li == lj ((i, i) items and duplicate-row pairs): the
@@ -804,14 +799,11 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
     refill();
     while (!win.empty()) {
       const int fill = (int)s.obs.size() - s.open;
-      const long open_pairs = (long)s.pairs.size() - s.pair_start.back();
       int best = -1, best_score = 0;
       for (int w = 0; w < (int)win.size(); ++w) {
         int na, nb;
         entries_of(win[w], na, nb);
-        const long np = pairs_of(win[w], na, nb);
-        if (reg && np > PAIRCAP) { tile_rc[job] = CBA_ERR_UNSUPPORTED; return; }  // caller falls back to the LDS-tile kernel
-        if (fill + na + nb > chunk_cap || (reg && open_pairs + np > PAIRCAP)) continue;
+        if (fill + na + nb > chunk_cap) continue;
         if (window == 1) { best = w; break; }
         const int sc = score_of(win[w], na, nb);
         if (best < 0 || sc < best_score) { best = w; best_score = sc; }
@@ -857,7 +849,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   }
   std::vector<double> U, V;
   // the register kernel fetches whole rounds without bounds checks: the streams stay readable past the end (zero padding)
-  const size_t pad_ob = reg ? 2 * SCHUNK : 0, pad_pr = reg ? 2 * PAIRCAP : 0;
+  const size_t pad_ob = 0, pad_pr = 0;
   std::vector<int> PT, OB(o_obs[n_jobs] + pad_ob, 0), CS(o_ch[n_jobs] + 1), PS(o_ch[n_jobs] + 1), TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
   std::vector<pair_t> PR(o_pr[n_jobs] + pad_pr, 0);
@@ -890,8 +882,8 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   TCB[nT] = (int)CS.size() - 1;
   lap("concatenate");
   p->n_tile_chunks = TCB[nT];
-  p->tile_stream_len = (long)OB.size() - (reg ? 2 * SCHUNK : 0);
-  p->n_pairs = (long)PR.size() - (reg ? 2 * PAIRCAP : 0);
+  p->tile_stream_len = (long)OB.size();
+  p->n_pairs = (long)PR.size();
   const WgBinding bind = bind_workgroups(p, TCB, nT, max_blocks, reg);
   const std::vector<int>&wgb = bind.wgb, &wt = bind.wt, &wfirst = bind.wfirst, &wend = bind.wend, &wstride = bind.wstride;
 
@@ -935,8 +927,8 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   prm.C = C; prm.P = p->P; prm.G = G; prm.g = g;
   prm.rep = (NC == 6 && g * g <= BLOCK / 2) ? BLOCK / (g * g) : 1;  // small groups: several threads per block
   if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1))) : 1;
-  prm.chunk_cap = SCHUNK;
-  prm.slots_per_wave = Reg2Cfg<NC>::EPW; prm.wave_pieces = Reg2Cfg<NC>::WAVE_PIECES; prm.rec_pieces = Reg2Cfg<NC>::NP;
+  prm.chunk_cap = Reg2Cfg<NC>::SCHUNK;
+  prm.slots_per_wave = Reg2Cfg<NC>::EPW; prm.wave_pieces = Reg2Cfg<NC>::WAVE_PIECES; prm.rec_pieces = Reg2Cfg<NC>::LST;
   prm.zero_piece = Reg2Cfg<NC>::ZERO_PIECE;
   if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
@@ -944,7 +936,7 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   if (build_reg2_plan(prm, hcam, hps, plan)) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
   lap("dealt streams and codes (host threads)");
   p->n_tile_chunks = plan.tile_chunk_begin[nT];
-  p->tile_stream_len = (long)plan.obs.size() - 2 * SCHUNK;
+  p->tile_stream_len = (long)plan.obs.size() - 2 * Reg2Cfg<NC>::SCHUNK;
   p->n_pairs = plan.n_pairs;
   p->plan_lane_util = plan.lane_iters > 0 ? (double)plan.n_pairs / (double)plan.lane_iters : 0.0;
   if (plan_timing)
@@ -995,14 +987,13 @@ static int configure_kernels(cba_problem* p) {
   int gmax = 1;
   const char* force_tile = std::getenv("CBA_SCHUR");
   p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
-  p->schur_v2 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg1") == 0);
+  p->schur_v2 = p->schur_reg;
   if (p->schur_reg) gmax = std::min(p->C, kSchurRegMaxGroup);
   else while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
   p->G = (p->C + gmax - 1) / gmax;
   p->gsz = (p->C + p->G - 1) / p->G;
   p->n_tiles = p->G * (p->G + 1) / 2;
   if (p->schur_reg) {
-    if ((rc = allow_lds(k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, lds_schur_reg<NC>(p->gsz)))) return rc;
     if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
     if (NC == 6 && p->debug_skip) {
       constexpr int D6 = (NC == 6);
@@ -1173,8 +1164,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("reorder, upload, allocate");
   p->eval_only = opt && opt->evaluation_only != 0;
   for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
-    const size_t tile_lds = p->schur_v2 ? ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES)
-                          : p->schur_reg ? ((nct == 9) ? lds_schur_reg<9>(p->gsz) : lds_schur_reg<6>(p->gsz))
+    const size_t tile_lds = p->schur_reg ? ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES)
                                          : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
     if (p->schur_reg) per_cu = std::min(per_cu, (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // register budget
@@ -1531,7 +1521,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
-      if (p->schur_v2) {
+      {
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);
         };
@@ -1565,9 +1555,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
           default: launch(k_schur_reg2<NC, SP, MW, 0>); break;
         }
       }
-      else
-        hipLaunchKernelGGL((k_schur_reg<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT),
-                           lds_schur_reg<NC>(p->gsz), p->stream, p->tp, p->Trec, p->partial, p->debug_skip);
+
     }
     if (!p->schur_reg)
       hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
@@ -1580,12 +1568,13 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
       hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                          p->cam_off, p->cam_np, NC, ncp, p->Sacc);
+      hipLaunchKernelGGL((k_unprime<NC>), dim3((p->C * p->C + 255) / 256), dim3(256), 0, p->stream, p->Sacc, p->tab, p->cam_off, p->cam_np, p->C, ncp);
       if (p->n_heavy)  // per-camera sums of the heavy points, one workgroup each (the pair plan skips them)
         hipLaunchKernelGGL((k_heavy_schur<NC>), dim3(p->n_heavy), dim3(BLOCK), (size_t)ncp * 3 * sizeof(double) + (size_t)ncp * sizeof(int), p->stream,
-                           p->heavy_pts, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Trec, p->heavy_W, p->Sacc);
+                           p->heavy_pts, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Trec, p->tab, p->heavy_W, p->Sacc);
       if (p->con.n_con)  // Woodbury correction of S and b for the constraint rows, one workgroup per component
         hipLaunchKernelGGL((k_con_schur<NC>), dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->g, p->sinv,
-                           p->Trec, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
+                           p->Trec, p->tab, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
     }
     else
       hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,

@@ -9,11 +9,14 @@
 extern "C" {
 
 // acc_out: [n_tiles][256][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
-int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int zero_piece, int region_chunks, int heavy_obs,
-                int threads, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
+int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int slots_per_wave, int lds_stride, int region_chunks,
+                int heavy_obs, int threads, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
   cba::Reg2Params prm;
-  prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap; prm.zero_piece = zero_piece;
-  prm.rec_pieces = rec / 2; prm.slots_per_wave = 96; prm.wave_pieces = (96 * prm.rec_pieces + 63) / 64 * 64;
+  prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap;
+  // the kernel's staging layout (cba_kernels.h, Reg2Cfg): a wave stages slots_per_wave slots, lds_stride pieces apart
+  prm.rec_pieces = lds_stride; prm.slots_per_wave = slots_per_wave; prm.wave_pieces = slots_per_wave * lds_stride;
+  const int zero_piece = (chunk_cap + slots_per_wave - 1) / slots_per_wave * prm.wave_pieces;
+  prm.zero_piece = zero_piece;
   prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads;
   const long N = hps[P];
   std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
