@@ -337,7 +337,7 @@ def solve_multi_device(problem: BAProblem, x0: np.ndarray, devices, *, backend: 
         try:
             results[rank] = solve_sharded(problem, x0, ctl, device_id=devices[rank], group=group, **dict(tol))
         except BaseException as exc:  # noqa: BLE001 - re-raised in the caller's thread
-            errors[rank] = exc
+            errors[rank] = (time.monotonic(), exc)
             ctl.abort()  # peers waiting in a host-side exchange fail instead of hanging
             if group is not None:
                 group.abort()  # ... and so do peers spinning in the library's group barrier
@@ -349,8 +349,7 @@ def solve_multi_device(problem: BAProblem, x0: np.ndarray, devices, *, backend: 
         t.join()
     if group is not None:
         group.close()
-    first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or next(
-        (e for e in errors if e is not None), None)
-    if first is not None:
-        raise first
+    failed = sorted((e for e in errors if e is not None), key=lambda te: te[0])
+    if failed:
+        raise failed[0][1]  # the rank that failed first; the others only report that the group was aborted
     return results[0]

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp PYTHONUNBUFFERED=1 CBA_GROUP_TIMEOUT_S=15
+O=gpurun_out/r2g; mkdir -p $O
+timeout 300 python -m pytest tests/test_multi_device.py tests/test_gpu_parity.py -m gpu -x -q --timeout=120 > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log
+timeout 200 python tools/schur_split.py cfg4 0,16 > $O/split_cfg4.log 2>&1
+CBA_PLAN_TIMING=1 timeout 300 python bench.py --no-cpu --also cfg5 --steps 20 --warmup 4 > $O/bench.json 2> $O/bench.err
+tail -4 $O/tests.log; grep -v "^k_schur" $O/split_cfg4.log; grep "^k_schur" $O/split_cfg4.log | tail -1; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2g/bench.json').read().strip().splitlines()[-1])
+print('ms/step',d['ms_per_step'],{n:v['avg_us'] for n,v in d['roofline']['kernels'].items()})
+print(d.get('also'))
+PY
+grep "plan:" $O/bench.err | head
