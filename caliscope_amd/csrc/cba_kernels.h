@@ -12,8 +12,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "ba_math.h"
 #include "trf_math.h"
 
@@ -1012,18 +1010,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
     if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * REC)[piece];
   };
-  // `pair` multiplies one record pair; K0..K1-1 are gathers of the next chunk to issue on the way, one at a time between
-  // pieces of arithmetic: issued in a burst, the four waves of the workgroup queue up behind one another at the texture
-  // addresser (~200 clocks per load instruction, a third of the kernel's time in the issue stage; tools/schur_split.py 16)
-  auto pair = [&](unsigned code, auto K0c, auto K1c) {
-    constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value;
-    auto spill = [&](int n) {  // n-th interleaving point of this pair (compile-time n): gather K0 + n if it is in the range
-      if (K0 + n < K1) {
-        __builtin_amdgcn_sched_barrier(0);
-        gather(K0 + n);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
+  auto pair = [&](unsigned code) {
     const double2* Ri = sh_p + (code & 0xffffu);
     const double2* Rj = sh_p + (code >> 16);
     // record: [Y0 Y1][Y2 Q00][Q01 Q02][Q10 Q11][Q12 Q20][Q21 Q22] ([I00 I01] .. [I22 -])
@@ -1034,7 +1021,6 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
       const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
       const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
       double M[3][NC];
-      spill(0);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -1044,7 +1030,6 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
         M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
         M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
         M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
-        if (a == 1) spill(1);
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
@@ -1052,15 +1037,8 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
         acc[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], acc[1][c]));
         acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
         acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
-        if (c == 0) spill(2);
-        if (c == 2) spill(3);
-        if (c == 4) spill(4);
       }
-#pragma unroll
-      for (int n = 5; n < K1 - K0; ++n) spill(n);
     } else {
-#pragma unroll
-      for (int n = 0; n < K1 - K0; ++n) spill(n);
       double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
       if (half == 2) {  // rows of T_intr,i
         const double2 i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
@@ -1104,30 +1082,17 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
       stamp(2);                                                                           // 2: barrier A
       nxt = min(cur + stride, last);
     }
-    // the next chunk's gather rides inside the first three pairs (NLD / 3 loads each); what does not find a pair is issued plainly
+    // first half of the next chunk's gather
+#pragma unroll
+    for (int k = 0; k < NLD / 2; ++k) gather(k);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(3);                                                                             // 3: first half of the gather issued
+    if (cur >= first && dbg_pairs && n_cur > 0) pair(cc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(4);                                                                             // 4: first pair
+#pragma unroll
+    for (int k = NLD / 2; k < NLD; ++k) gather(k);
     {
-      constexpr int G1 = (NLD + 2) / 3, G2 = 2 * G1 < NLD ? 2 * G1 : NLD;
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, G1>; using I2 = std::integral_constant<int, G2>;
-      using I3 = std::integral_constant<int, NLD>;
-      const bool live = cur >= first && dbg_pairs;
-      if (live && n_cur > 0) pair(cc[0], I0{}, I1{});
-      else {
-#pragma unroll
-        for (int k = 0; k < G1; ++k) gather(k);
-      }
-      stamp(3);                                                                           // 3: first pair + a third of the gather
-      if (live && n_cur > 1) pair(cc[1], I1{}, I2{});
-      else {
-#pragma unroll
-        for (int k = G1; k < G2; ++k) gather(k);
-      }
-      stamp(4);                                                                           // 4: second pair + a third of the gather
-      if (live && n_cur > 2) pair(cc[2], I2{}, I3{});
-      else {
-#pragma unroll
-        for (int k = G2; k < NLD; ++k) gather(k);
-      }
-      stamp(5);                                                                           // 5: third pair + the rest of the gather
       const unsigned packed = tp.nit[nxt];
       int pre = 0;
 #pragma unroll
@@ -1138,12 +1103,15 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
       for (int k = 0; k < NCD; ++k)
         if (dbg_index) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
       load_indices(min(nxt + stride, last));
-      if (cur < first) continue;
-      if (dbg_pairs) {
-        using IN = std::integral_constant<int, 0>;
-        if (3 < n_cur) pair(cc[3], IN{}, IN{});
-        for (int it = NCD; it < n_cur; ++it) pair(tp.codes[code_cur + (long)it * WAVE], IN{}, IN{});  // rare: more than four pairs of one block in a chunk
-      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(5);                                                                             // 5: second half, codes, indices issued
+    if (cur < first) continue;
+    if (dbg_pairs) {
+#pragma unroll
+      for (int it = 1; it < NCD; ++it)
+        if (it < n_cur) pair(cc[it]);
+      for (int it = NCD; it < n_cur; ++it) pair(tp.codes[code_cur + (long)it * WAVE]);  // rare: more than four pairs of one block in a chunk
     }
     stamp(6);                                                                             // 6: remaining pairs
     __syncthreads();

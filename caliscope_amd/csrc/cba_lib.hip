@@ -1544,7 +1544,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
             (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
             (void)hipStreamSynchronize(p->stream);
             (void)guarded_free(d);
-            static const char* names[8] = {"wait records", "LDS stores", "barrier A", "pair 0 + gather/3", "pair 1 + gather/3", "pair 2 + gather/3", "codes, idx, pairs 3..", "barrier B"};
+            static const char* names[8] = {"wait records", "LDS stores", "barrier A", "gather 1 issue", "pair 0", "gather 2 + idx issue", "pairs 1..", "barrier B"};
             double tot = 0.0, sum[8] = {0};
             for (size_t w = 0; w < n / 8; ++w)
               for (int ph = 0; ph < 8; ++ph) { sum[ph] += (double)h[w * 8 + ph]; tot += (double)h[w * 8 + ph]; }
