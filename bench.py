@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: observations/sec per LM iteration (+ final RMS reprojection error, px).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--no-cpu] [--also cfg2,cfg3,cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--scaling strong|weak] [--no-cpu] [--also cfg2,cfg3,cfg5]
 
 A *step* is one trust-region (LM) iteration of the hot path over the whole observation set: trial-point
 evaluation plus — for accepted steps — linearisation (residuals, Jacobian blocks, J^T J / J^T r
@@ -12,10 +12,15 @@ exactly K trial iterations have been executed (this is the reference's own norma
 resident in HBM before the timed region starts; nothing but scalars crosses PCIe inside it.
 
 Workload (``config.workload``): BASELINE.json's multi-GPU configuration cfg4 — 64 cameras / 200k points /
-2M observations, extrinsics-only, linear loss — per GPU (weak scaling: every rank owns a 200k-point shard seen
-by the same 64 cameras; the reduced camera system is all-reduced over RCCL each iteration).  The other configs
-(cfg2, cfg3, and cfg5 = 128 cameras / 1M points / 10M observations with joint intrinsics, on one GPU) are run
-untimed-by-the-driver after the headline and reported under ``also``.
+2M observations, extrinsics-only, linear loss.  With ``--gpus N`` the default is STRONG scaling, as BASELINE.json
+words it ("2M obs sharded across 8 x MI355X"): the same 2M observations, their points partitioned over the N ranks
+(caliscope_amd/sharding.py), the camera blocks and the reduced camera system all-reduced over RCCL each iteration;
+``--scaling weak`` gives every rank its own 200k-point shard of the same 64 cameras instead.  The other configs (cfg2,
+cfg3, and cfg5 = 128 cameras / 1M points / 10M observations with joint intrinsics, on one GPU) are run
+untimed-by-the-driver after the headline and reported under ``also`` (cfg5 with its full roofline block).
+
+``cpu_baseline`` is the reference's scipy call on a bounded sample of the workload, and the SAME sample is then solved
+on the GPU: ``parity`` holds the differences (RMS px, cost, gauge-aligned poses / points) of the two solutions.
 """
 
 from __future__ import annotations
@@ -97,15 +102,26 @@ class _Solo:
         return float(v)
 
 
-def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, control=None, **overrides):
-    """Weak scaling: rank r owns shard r (its own points/observations of the same cameras); the engine
-    all-reduces the camera blocks, the reduced camera system and the scalar sums over RCCL."""
+def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, control=None, scaling="strong", **overrides):
+    """Strong scaling: every rank generates the same scene and keeps the shard of points ``shard_problem`` gives it.
+    Weak scaling: rank r draws its own points/observations of the same cameras.  Either way the engine all-reduces the
+    camera blocks, the reduced camera system and the scalar sums over RCCL."""
     from caliscope_amd.hip_engine import HipEngine
+    from caliscope_amd.sharding import shard_problem
 
     control = control or _Solo()
     solve_kw = dict(solve_kw or {})
     t_gen = time.time()
-    sc, par, x0, prob, cfg = build_problem(name, seed=seed, shard=control.rank, **overrides)
+    n_total, n_params_global = None, None
+    if scaling == "strong" and control.world > 1:
+        sc, par, x0, prob, cfg = build_problem(name, seed=seed, shard=0, **overrides)
+        n_total = prob.n_obs
+        shard = shard_problem(prob, control.rank, control.world)
+        x0 = shard.local_x(x0)
+        n_params_global = int(prob.n_params)
+        prob, par = shard.problem, shard.problem.parameterization
+    else:
+        sc, par, x0, prob, cfg = build_problem(name, seed=seed, shard=control.rank, **overrides)
     t_gen = time.time() - t_gen
     if par.has_finite_bounds:  # free intrinsics: the bounds of BundleParameterization.bounds(), as CaptureVolume.optimize passes them
         lb, ub = par.bounds()
@@ -134,7 +150,8 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         tm = eng.timers()
         eng.enable_timers(False)
     # untimed: full solve for the accuracy figure (squared pixel errors summed over all shards)
-    full = eng.solve(None, **solve_kw)
+    # (sharded: scipy's default evaluation cap 100 n refers to the whole problem, and every rank must use the same one)
+    full = eng.solve(None, **solve_kw, **({"max_nfev": 100 * n_params_global} if n_params_global else {}))
 
     def rms_all(x):
         r, _ = eng.residuals(x)
@@ -146,7 +163,8 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     rms, rms0 = rms_all(full.x), rms_all(x0)
     eng.close()
     return {
-        "name": name, "n_obs": prob.n_obs, "n_points": par.n_points, "n_cams": len(par.blocks), "ncp": par.n_camera_params,
+        "name": name, "n_obs": prob.n_obs, "n_obs_total": n_total if n_total is not None else prob.n_obs * control.world,
+        "n_points": par.n_points, "n_cams": len(par.blocks), "ncp": par.n_camera_params, "full_njev": full.njev,
         "nct": 9 if any(b.n_params == 9 for b in par.blocks) else 6, "loss": prob.loss, "elapsed": elapsed, "steps": steps,
         "solves": solves, "timers": tm, "final_rms_px": rms, "initial_rms_px": rms0, "full_nfev": full.nfev,
         "full_status": full.status, "full_cost": full.cost, "info": info, "t_generate_s": t_gen,
@@ -154,9 +172,9 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     }
 
 
-# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg for 6-parameter
-# cameras, k_schur_tile for 9-parameter ones)
-PMC_KERNEL = {"schur": ("k_tprep", "k_schur_reg", "k_schur_tile"), "build": ("k_build",), "jv": ("k_jv",),
+# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg2; k_schur_tile is the
+# LDS-atomic fallback)
+PMC_KERNEL = {"schur": ("k_tprep", "k_schur_reg2", "k_reg_reduce", "k_reg_fold", "k_unprime", "k_schur_tile"), "build": ("k_build",), "jv": ("k_jv",),
               "backsub": ("k_backsub",), "cost": ("k_cost<false>",)}
 
 
@@ -189,8 +207,8 @@ def roofline_from(m):
     return {
         "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(m["name"], dom), "alg_bytes_per_launch": alg[dom],
-        "note": "k_schur = the Schur pass (k_tprep + k_schur_reg; k_schur_tile for 9-parameter cameras): FP64-VALU / latency "
-                "bound, not HBM-bound (DESIGN.md 4-5); durations from HIP events on the engine stream in an instrumented "
+        "note": "k_schur = the Schur pass (k_tprep writes one compact record per observation, k_schur_reg2 gathers them per "
+                "camera-group tile and multiplies the pairs: DESIGN.md 4-5); durations from HIP events on the engine stream in an instrumented "
                 "repeat of the timed steps; traffic from profiles/pmc_*.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, "
                 "summed over the kernels of the pass)",
         "avg_launch_us": round(avg_s * 1e6, 2), "kernels": table,
@@ -205,12 +223,57 @@ def roofline_from(m):
     }
 
 
-def cpu_baseline(budget_s=25.0):
-    """The reference's scipy call on the oracle callables, one host core, on a bounded sample of the workload:
-    cfg4's cameras and visibility recipe at half the points (64 cams / 100k points / 1M obs), full solve with
-    the reference's default tolerances."""
+def _similarity(src, dst):
+    """Least-squares similarity (s, R, t), dst ~ s R src + t (Umeyama; the reference aligns solutions the same way,
+    core/alignment.py:84-150) — BA leaves a 7-DoF gauge free, so two solvers' results are compared after alignment."""
+    mu_s, mu_d = src.mean(0), dst.mean(0)
+    a, b = src - mu_s, dst - mu_d
+    U, sv, Vt = np.linalg.svd(b.T @ a / len(src))
+    sign = np.ones(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        sign[2] = -1
+    R = U @ np.diag(sign) @ Vt
+    sc = float((sv * sign).sum() / (a * a).sum() * len(src))
+    return sc, R, mu_d - sc * R @ mu_s
+
+
+def solution_parity(par, x_a, x_b):
+    """Gauge-aligned difference of two solutions: (max relative position difference of camera centres and points, max
+    rotation angle between corresponding cameras [rad])."""
+    from caliscope_amd.cameras import rvec_to_matrix
+
+    def cams(x):
+        cen, rot = [], []
+        for off in par.camera_param_offsets:
+            R = rvec_to_matrix(x[off:off + 3])
+            rot.append(R)
+            cen.append(-R.T @ x[off + 3:off + 6])
+        return np.array(cen), np.array(rot)
+
+    ca, Ra = cams(x_a)
+    cb, Rb = cams(x_b)
+    pa, pb = x_a[par.n_camera_params:].reshape(-1, 3), x_b[par.n_camera_params:].reshape(-1, 3)
+    sc, R, t = _similarity(np.vstack([ca, pa]), np.vstack([cb, pb]))
+    extent = np.abs(np.vstack([cb, pb])).max()
+    pos = max(np.abs(sc * ca @ R.T + t - cb).max(), np.abs(sc * pa @ R.T + t - pb).max()) / extent
+    ang = 0.0
+    for A, B in zip(Ra, Rb):
+        rel = (A @ R.T) @ B.T
+        w = np.array([rel[2, 1] - rel[1, 2], rel[0, 2] - rel[2, 0], rel[1, 0] - rel[0, 1]])
+        ang = max(ang, float(np.arctan2(0.5 * np.linalg.norm(w), 0.5 * (np.trace(rel) - 1.0))))
+    return float(pos), float(ang)
+
+
+def cpu_baseline(device_id=0):
+    """The reference's scipy call on the oracle callables, one host core, on a bounded sample of the workload: cfg4's
+    cameras and visibility recipe at half the points (64 cams / 100k points / 1M obs), full solve with the reference's
+    default tolerances.  The same arrays and the same x0 then go through the product's solver on the GPU; `parity` is the
+    difference of the two solutions (north star: RMS within 1e-4 px, poses / points within 1e-6 relative after gauge
+    alignment — at default tolerances both solvers stop at ftol, so the alignment figure shows their stopping distance)."""
     from caliscope_amd.bundle_parameterization import BundleParameterization
+    from caliscope_amd.least_squares import least_squares
     from caliscope_amd.synthetic import make_scene
+    from oracle.residuals import joint_residuals
     from oracle.solver import optimize_scipy
 
     sc = make_scene("cfg4-sample", n_cams=64, n_points=100_000, n_obs=1_000_000)
@@ -220,12 +283,33 @@ def cpu_baseline(budget_s=25.0):
     res = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0)
     dt = time.perf_counter() - t0
     iters = max(res.nfev - 1, 1)
-    return {
+    t1 = time.perf_counter()
+    gpu = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", method="trf",
+                        args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), devices=[device_id])
+    dt_gpu = time.perf_counter() - t1
+    fx = np.array([b.fx_initial for b in par.blocks])[sc.camera_indices]
+
+    def rms(x):  # the oracle's residuals for both solutions: independent of the device code
+        e = joint_residuals(x, par, sc.camera_indices, sc.image_coords, sc.obj_indices).reshape(-1, 2) * fx[:, None]
+        return float(np.sqrt(np.mean(np.sum(e * e, axis=1))))
+
+    rms_cpu, rms_gpu = rms(res.x), rms(gpu.x)
+    pos, ang = solution_parity(par, gpu.x, res.x)
+    base = {
         "value": round(sc.n_obs * iters / dt, 1), "unit": "obs/s", "cores": 1, "kind": "port",
         "sample": f"64 cams / 100k points / 1M obs (half of cfg4), scipy least_squares trf+lsmr, default tolerances: "
                   f"{res.nfev} evaluations in {dt:.1f} s; host has {os.cpu_count()} cores, the scipy path is single-threaded",
-        "seconds": round(dt, 2),
+        "seconds": round(dt, 2), "nfev": int(res.nfev), "status": int(res.status), "cost": float(res.cost), "final_rms_px": round(rms_cpu, 6),
     }
+    parity = {
+        "sample": "the cpu_baseline sample: same arrays, same x0, default tolerances on both sides",
+        "gpu": {"nfev": int(gpu.nfev), "status": int(gpu.status), "cost": float(gpu.cost), "final_rms_px": round(rms_gpu, 6),
+                "seconds_end_to_end": round(dt_gpu, 3)},
+        "d_rms_px": rms_gpu - rms_cpu, "rel_cost": (float(gpu.cost) - float(res.cost)) / float(res.cost),
+        "aligned_pos": pos, "aligned_ang_rad": ang,
+        "value_ratio_gpu_end_to_end_over_cpu": round(sc.n_obs * max(gpu.nfev - 1, 1) / dt_gpu / (sc.n_obs * iters / dt), 1),
+    }
+    return base, parity
 
 
 def main():
@@ -241,6 +325,7 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--also", default="cfg2,cfg3,cfg5")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -251,13 +336,9 @@ def main():
                          f"python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     control = None
     if world > 1:
-        import torch.distributed as dist
+        from caliscope_amd.distributed import SocketControlPlane
 
-        from caliscope_amd.distributed import TorchControlPlane
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")  # host-side control plane only; the data plane is RCCL inside the engine
-        control = TorchControlPlane()
+        control = SocketControlPlane.from_env()  # host-side control plane only (TCP on the loopback); the data plane is RCCL inside the engine
 
     import __graft_entry__ as entry
 
@@ -265,8 +346,8 @@ def main():
         entry.build()
     if control is not None:
         control.barrier()
-    m = measure(args.workload, args.steps, args.warmup, device_id=local_rank, control=control)
-    total_obs = m["n_obs"] * world
+    m = measure(args.workload, args.steps, args.warmup, device_id=local_rank, control=control, scaling=args.scaling)
+    total_obs = m["n_obs_total"]
     value = total_obs * m["steps"] / m["elapsed"]
     out = {
         "metric": "observations/sec per LM iteration",
@@ -277,26 +358,28 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(m["elapsed"] / m["steps"] * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {m['n_cams']} cams / {m['n_points']} points / {m['n_obs']} obs per GPU, "
+            "workload": f"{args.workload}: {m['n_cams']} cams / {total_obs} obs in total ({m['n_points']} points / {m['n_obs']} obs on rank 0), "
                         f"{'extrinsics+intrinsics' if m['nct'] == 9 else 'extrinsics-only'} BA, {m['loss']} loss",
             "n_obs_total": total_obs, "params_per_camera": m["nct"],
-            "parallelism": f"points sharded x{world}; RCCL all-reduce of camera blocks + reduced camera system per iteration",
+            "parallelism": f"points sharded x{world} ({args.scaling if world > 1 else 'single GPU'}); RCCL all-reduce of camera blocks + reduced camera system per iteration",
             "tolerances": "ftol=xtol=gtol=1e-8 (reference defaults)", "solves_in_timed_region": m["solves"],
         },
         "final_rms_px": round(m["final_rms_px"], 6),
         "initial_rms_px": round(m["initial_rms_px"], 4),
-        "solve": {"nfev": m["full_nfev"], "status": m["full_status"], "cost": m["full_cost"]},
+        # accepted iterations re-linearise (njev - 1 of them after x0); the other trial points were rejected
+        "solve": {"nfev": m["full_nfev"], "njev": m["full_njev"], "accepted_steps": m["full_njev"] - 1,
+                  "rejected_trials": m["full_nfev"] - m["full_njev"], "status": m["full_status"], "cost": m["full_cost"]},
         "roofline": roofline_from(m),
         "engine": m["info"],
     }
     if not args.no_cpu and rank == 0 and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], out["parity"] = cpu_baseline(device_id=local_rank)
         except Exception as exc:  # the baseline must never break the bench line
             out["cpu_baseline"] = {"value": None, "unit": "obs/s", "cores": 1, "kind": "port", "sample": f"failed: {exc}"}
     also = {}
@@ -310,8 +393,10 @@ def main():
                     "value": round(a["n_obs"] * a["steps"] / a["elapsed"], 1), "unit": "obs/s",
                     "ms_per_step": round(a["elapsed"] / a["steps"] * 1e3, 4), "final_rms_px": round(a["final_rms_px"], 6),
                     "workload": f"{a['n_cams']} cams / {a['n_points']} points / {a['n_obs']} obs, {a['loss']} loss",
-                    "nfev": a["full_nfev"], "status": a["full_status"],
-                    "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us")},
+                    "nfev": a["full_nfev"], "status": a["full_status"], "accepted_steps": a["full_njev"] - 1,
+                    "rejected_trials": a["full_nfev"] - a["full_njev"], "initial_rms_px": round(a["initial_rms_px"], 4),
+                    # cfg5 is the largest single-GPU configuration of BASELINE.json: its full roofline block, not a digest
+                    "roofline": rf if (rf is None or name == "cfg5") else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic")},
                 }
             except Exception as exc:
                 also[name] = {"error": str(exc)}
@@ -322,10 +407,8 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (line + "\n").encode())
     if control is not None:
-        import torch.distributed as dist
-
         control.barrier()
-        dist.destroy_process_group()
+        control.close()
 
 
 if __name__ == "__main__":

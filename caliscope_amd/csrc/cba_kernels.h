@@ -1346,12 +1346,18 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 // one short-lived dot product per pivot: 88 VGPRs, no scratch, 2x faster (tools/chol_factor_bench).
 // The factor goes to the lower triangle of the global block at `out` (row stride ldw).
 __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, double* __restrict__ out, int ldw,
-                                                  int* __restrict__ flags) {
+                                                  int* __restrict__ flags, double* __restrict__ xinv) {
+  // Lanes 0..31 factor: lane r keeps row r of L.  Lanes 32..63 run the SAME instruction stream on a column of X = L^-1
+  // (lane 32 + c keeps column c):  X_jc = (delta_jc - sum_{t<j} L_jt X_tc) / L_jj  is the row recurrence
+  // v_r = D_rj - sum_{t<j} L_rt L_jt with the lane's own values X_tc in the place of L_rt and delta_jc in the place of D_rj;
+  // the broadcast row L_j,: and the pivot are shared.  The inverse costs nothing (the lanes were idle) and turns the panel
+  // solves of the next step and the backward substitution into matrix products (k_chol_step, k_chol_backward).
   const int lane = threadIdx.x;
   const int r = lane & (NB - 1);
+  const bool isX = lane >= NB;
   double row[NB];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) row[c] = D[r][c];
+  for (int c = 0; c < NB; ++c) row[c] = isX ? (c == r ? 1.0 : 0.0) : D[r][c];
   bool bad = false;
   double s_prev = 0.0;
   double pre[NB];
@@ -1371,9 +1377,9 @@ __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, d
     double d = readlane_f64(acc, j);
     if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
     const double inv = fast_rsqrt(d);
-    const double l = (r == j) ? d * inv : (r > j ? acc * inv : 0.0);
+    const double l = isX ? acc * inv : ((r == j) ? d * inv : (r > j ? acc * inv : 0.0));
     row[j] = l;
-    D[r][j] = l;
+    if (!isX) D[r][j] = l;
     if (j + 1 < NB) s_prev = readlane_f64(l, j + 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1382,10 +1388,15 @@ __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, d
     for (int t = 0; t < NB; ++t) pre[t] = nxt[t];
   }
   if (bad && lane == 0) flags[2] = 1;
-  if (lane < nb) {
+  if (!isX) {
+    if (lane < nb) {
 #pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c <= lane) out[(long)lane * ldw + c] = row[c];
+      for (int c = 0; c < NB; ++c)
+        if (c <= lane) out[(long)lane * ldw + c] = row[c];
+    }
+  } else {  // X (NB x NB, row-major, identity-padded beyond nb): lane 32 + c holds column c
+#pragma unroll
+    for (int t = 0; t < NB; ++t) xinv[t * NB + r] = row[t];
   }
 }
 
@@ -1440,11 +1451,10 @@ __device__ __forceinline__ void chol_rank_nb(const double* __restrict__ A, int r
 }
 
 __global__ void __launch_bounds__(CHOL_THREADS)
-k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace) {
+k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace, double* __restrict__ Xinv) {
   __shared__ double sh_red[4][16][17];
   __shared__ double sh_U[NB][NB + 1], sh_X[NB][NB + 1], sh_D[NB][NB + 1];
   __shared__ __attribute__((aligned(16))) double sh_L[NB][NB + 2];  // even row stride: pairs of coefficients are 16-byte aligned
-  __shared__ double sh_inv[NB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int nbk = (n + NB - 1) / NB;
   constexpr int EPT = NB * NB / CHOL_THREADS, ISTEP = CHOL_THREADS / NB;  // elements of a 32 x 32 block per thread
@@ -1497,7 +1507,7 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
 #pragma unroll
     for (int h = 0; h < EPT; ++h) sh_D[i0 + h * ISTEP][j] = d_ij[h];
     __syncthreads();
-    if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags);
+    if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags, Xinv);  // X_0
     return;
   }
   const int k0 = k * NB, nbp = min(NB, n - k0);
@@ -1505,7 +1515,7 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   for (int h = 0; h < EPT; ++h) {
     const int i = i0 + h * ISTEP;
     m_ij[h] = (i < rc && j < nbp) ? Wb[(long)i * ldw + k0 + j] : 0.0;
-    l_ij[h] = (i < nbp && j <= i) ? W[(long)(k0 + i) * ldw + k0 + j] : (i == j ? 1.0 : 0.0);
+    l_ij[h] = Xinv[(long)k * NB * NB + i * NB + j];  // X_k = L_kk^-1 (identity-padded), written by the factorisation of D_k
   }
 
   CHOL_STAMP(1);
@@ -1520,42 +1530,24 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
     const double upd = (k >= 1) ? sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15] : 0.0;
     sh_U[i][j] = m_ij[h] - upd;
     sh_L[i][j] = l_ij[h];
-    if (i == j) sh_inv[i] = 1.0 / l_ij[h];
   }
   __syncthreads();
   CHOL_STAMP(3);
-  // 2. panel solve  x L_kk^T = u, one row of U per thread of wave 0, left-looking with four partial sums per entry
-  // (a dependent FP64 FMA chain runs at ~20 cycles per link).  A lone wave is bound by its instruction count, so the
-  // coefficients L_kk[c][t] are read from LDS two at a time (16-byte aligned rows, ds_read_b128 broadcasts): 264
-  // reads instead of 528.  Measured alternatives: b64 broadcasts 4.6 us, scalar-cache loads 4.5 us (the SGPR budget
-  // exposes every s_load round trip), right-looking 6.4 us, column-per-lane with v_readlane 5.5 us.
-  if (tid < NB) {
-    double x[NB], inv[NB], lc[NB], ln[NB];
+  // 2. panel solve  L_bk = U L_kk^-T = U X_k^T: a 32 x 32 x 32 product on the matrix cores (four 16 x 16 tiles, one per
+  // wave 0..3).  History: a triangular solve by wave 0, one row of U per thread, was 2.8 us of the 13 us of a step.
+  if (wv < 4) {
+    const int ti = wv >> 1, tj = wv & 1;
+    v4f64 c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int c2 = 0; c2 < NB; ++c2) { x[c2] = sh_U[tid][c2]; inv[c2] = sh_inv[c2]; lc[c2] = 0.0; ln[c2] = 0.0; }
-#pragma unroll
-    for (int c2 = 0; c2 < NB; ++c2) {
-      // row c2 + 1 of L_kk is fetched while row c2 is consumed: left to itself the compiler issues every read right
-      // before its use and waits for it (~100 cycles each, 5.6 us for the solve)
-      if (c2 + 1 < NB) {
-#pragma unroll
-        for (int t = 0; t < c2 + 1; t += 2) {
-          const double2 l = *reinterpret_cast<const double2*>(&sh_L[c2 + 1][t]);
-          ln[t] = l.x;
-          if (t + 1 < NB) ln[t + 1] = l.y;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      double a[4] = {x[c2], 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int t = 0; t < c2; ++t) a[t & 3] -= x[t] * lc[t];
-      x[c2] = ((a[0] + a[1]) + (a[2] + a[3])) * inv[c2];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < NB; ++t) lc[t] = ln[t];
+    for (int t = 0; t < NB / 4; ++t) {
+      const int q = 4 * t + (lane >> 4);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_U[ti * 16 + (lane & 15)][q], sh_L[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
     }
 #pragma unroll
-    for (int c2 = 0; c2 < NB; ++c2) sh_X[tid][c2] = (c2 < nbp && tid < rc) ? x[c2] : 0.0;
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + (lane >> 4) + 4 * r, jj = tj * 16 + (lane & 15);
+      sh_X[i][jj] = (jj < nbp && i < rc) ? c[r] : 0.0;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -1592,7 +1584,7 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   // 4. look-ahead: the next panel's diagonal block
   __syncthreads();
   CHOL_STAMP(5);
-  if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags);
+  if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags, Xinv + (long)(k + 1) * NB * NB);
   CHOL_STAMP(6);
 #undef CHOL_STAMP
 }

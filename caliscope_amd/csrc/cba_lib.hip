@@ -95,6 +95,7 @@ struct cba_problem {
   long long* chol_trace = nullptr;  // CBA_CHOL_TRACE=1: phase stamps of k_chol_step (tools/chol_trace.py)
   int ldw = 0;             // row stride of the Cholesky work matrix Lbuf (multiple of 4 doubles)
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
+  double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
@@ -1194,6 +1195,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); p->ldw = (ncp + 3) & ~3;
   if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 1) * 8));
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
+  TRY(dev_alloc(p, &p->Xinv, (size_t)((ncp + NB - 1) / NB + 1) * NB * NB));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
@@ -1439,7 +1441,7 @@ static int enqueue_cholesky(cba_problem* p) {
     // rank-NB update of panel k - 1 to the blocks right of the current panel
     const int n_panel = k < 0 ? 1 : nbk - k;
     const int x = nbk - k - 1, n_trailing = k < 1 ? 0 : x * (x + 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace);
+    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace, p->Xinv);
   }
   hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)n * 8, p->stream, p->Lbuf, n, p->ldw, p->s);
   return CBA_OK;

@@ -337,6 +337,27 @@ def test_full_size_cfg2_properties():
         assert abs((c_plus - c_minus) / (2 * t) - lin.gh_sq) <= 1e-5 * lin.gh_sq
 
 
+def test_full_size_cfg2_converged_parity_with_scipy():
+    """BASELINE.json configs[1] at its full size (8 cams / 5 000 points / 40 000 obs, extrinsics-only): the product's solve
+    against the reference's scipy call on the same arrays and x0 — north star: poses / points within 1e-6 relative after
+    gauge alignment, RMS reprojection error within 1e-4 px (tolerances of both solvers tightened so that both reach the
+    minimum instead of their ftol stopping points; ~3 s of scipy)."""
+    from oracle.solver import rms_reprojection_px
+
+    sc = make_scene("cfg2", n_cams=8, n_points=5000, n_obs=40000)
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=5000, refine_intrinsics=False)
+    x0 = par.pack(sc.cameras_init, sc.points_init)
+    tol = dict(ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=400)
+    ref, got = _solve_both(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, **tol)
+    assert got.status > 0
+    assert abs(got.cost - ref.cost) <= 1e-8 * ref.cost
+    args = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    r_got, r_ref = rms_reprojection_px(*args, got.x), rms_reprojection_px(*args, ref.x)
+    assert abs(r_got - r_ref) < 1e-4 and 0.55 < r_got < 0.75
+    pos, ang, _ = aligned_difference(par, got.x, ref.x)
+    assert pos < 1e-6 and ang < 1e-6, (pos, ang)
+
+
 def test_rccl_call_sites_with_a_one_rank_communicator(monkeypatch):
     """Every all-reduce the sharded protocol issues (camera blocks, reduced system, scalar sums, flags) runs
     through RCCL on the engine's stream; with one rank the result must equal the plain path."""
