@@ -253,36 +253,48 @@ class CameraArray:
 
         path = Path(path)
         if not path.exists():
-            raise FileNotFoundError(f"CameraArray file not found: {path}")
-        with open(path, "rb") as fh:
-            doc = tomli.load(fh)
+            raise PersistenceError(f"CameraArray file not found: {path}")
+        try:
+            with open(path, "rb") as fh:
+                doc = tomli.load(fh)
+        except Exception as exc:
+            raise PersistenceError(f"Failed to load CameraArray from {path}: {exc}") from exc
+        if not doc or "cameras" not in doc:
+            return cls({})
+
+        def scalar(v):  # legacy files hold the string "null" where a value is missing (reference toml_helpers._clean_scalar)
+            return None if v is None or v == "null" else v
+
         out: Dict[int, CameraData] = {}
         for key, entry in (doc.get("cameras") or {}).items():
-            def arr(name):
-                v = entry.get(name)
-                return None if v is None or v == "null" else np.asarray(v, dtype=np.float64)
+            try:
+                def arr(name):
+                    v = entry.get(name)
+                    return None if v is None or v == "null" else np.asarray(v, dtype=np.float64)
 
-            rot = arr("rotation")
-            if rot is not None:
-                if rot.shape == (3, 3):
-                    pass  # legacy files store the matrix
-                elif rot.size == 3:
-                    rot = rvec_to_matrix(rot.ravel())
-                else:
-                    raise ValueError(f"Camera {key}: invalid rotation shape {rot.shape}")
-            size = entry["size"]
-            out[int(key)] = CameraData(
-                cam_id=int(key),
-                size=(int(size[0]), int(size[1])),
-                rotation_count=int(entry.get("rotation_count", 0)),
-                error=entry.get("error"),
-                matrix=arr("matrix"),
-                distortions=arr("distortions"),
-                exposure=entry.get("exposure"),
-                grid_count=entry.get("grid_count"),
-                ignore=bool(entry.get("ignore", False)),
-                translation=arr("translation"),
-                rotation=rot,
-                fisheye=bool(entry.get("fisheye", False)),
-            )
+                rot = arr("rotation")
+                if rot is not None:
+                    if rot.shape == (3, 3):
+                        pass  # legacy files store the matrix
+                    elif rot.size == 3:
+                        rot = rvec_to_matrix(rot.ravel())
+                    else:
+                        raise ValueError(f"invalid rotation shape {rot.shape}")
+                size = entry["size"]
+                out[int(key)] = CameraData(
+                    cam_id=int(key),
+                    size=(int(size[0]), int(size[1])),
+                    rotation_count=int(entry.get("rotation_count", 0)),
+                    error=scalar(entry.get("error")),
+                    matrix=arr("matrix"),
+                    distortions=arr("distortions"),
+                    exposure=scalar(entry.get("exposure")),
+                    grid_count=scalar(entry.get("grid_count")),
+                    ignore=bool(entry.get("ignore", False)),
+                    translation=arr("translation"),
+                    rotation=rot,
+                    fisheye=bool(entry.get("fisheye", False)),
+                )
+            except Exception as exc:
+                raise PersistenceError(f"Failed to parse camera {key}: {exc}") from exc
         return cls(out)

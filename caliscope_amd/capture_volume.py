@@ -400,11 +400,11 @@ class CaptureVolume:
         return self.compute_reprojection_report()
 
     # -- outlier filtering between solver passes (reference capture_volume.py:607-753) ------------------
-    def _filter_by_reprojection_thresholds(self, thresholds: dict, min_per_camera: int, _engine_factory=None) -> "CaptureVolume":
+    def _filter_by_reprojection_thresholds(self, thresholds: dict, min_per_camera: int, _engine_factory=None, _report=None) -> "CaptureVolume":
         """Keep observations whose pixel error is <= their camera's threshold, but never fewer than
         ``min_per_camera`` per camera (the best ones are kept); world points left without any observation
         are pruned; the optimisation status is cleared."""
-        report = self.compute_reprojection_report(_engine_factory) if _engine_factory else self.reprojection_report
+        report = _report if _report is not None else (self.compute_reprojection_report(_engine_factory) if _engine_factory else self.reprojection_report)
         raw = report.raw_errors
         err = raw["euclidean_error"].to_numpy()
         cam = raw["cam_id"].to_numpy()
@@ -458,12 +458,14 @@ class CaptureVolume:
         else:
             thr = float(np.percentile(raw["euclidean_error"], keep_percentile))
             thresholds = {cam_id: thr for cam_id in self.camera_array.posed_cameras}
-        return self._filter_by_reprojection_thresholds(thresholds, min_per_camera, _engine_factory)
+        return self._filter_by_reprojection_thresholds(thresholds, min_per_camera, _engine_factory, _report=report)  # one report for both steps
 
     def filter_by_absolute_error(self, max_pixels: float, min_per_camera: int = 10, _engine_factory=None) -> "CaptureVolume":
         """Remove observations with a reprojection error above ``max_pixels`` (reference :687-707)."""
         if max_pixels <= 0:
             raise ValueError(f"max_pixels must be positive, got {max_pixels}")
+        if min_per_camera < 1:
+            raise ValueError(f"min_per_camera must be >= 1, got {min_per_camera}")
         thresholds = {cam_id: float(max_pixels) for cam_id in self.camera_array.posed_cameras}
         return self._filter_by_reprojection_thresholds(thresholds, min_per_camera, _engine_factory)
 

@@ -1748,7 +1748,11 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
     if ((int)comp_pts.size() - first > CON_MAX_POINTS)
       return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: a constraint component couples %d points (limit %d)", (int)comp_pts.size() - first, CON_MAX_POINTS);
   }
-  if (comp_m[K] > (1L << 28)) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint components too large (%ld entries of M)", comp_m[K]);
+  // memory of the Woodbury correction: M (sum of m^2 over the components) and G (n_con x (ncp + 1)), doubles
+  if (comp_m[K] > (1L << 28) || (long)n_con * (p->ncp + 1) > (1L << 29))
+    return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: the constraint rows need %.1f GB for the per-component matrices (sum of m^2 = %ld) and %.1f GB for their "
+                "camera coupling (%d rows x %d camera parameters); the limits are 2 GB and 4 GB - use fewer rows per object and frame (DESIGN.md 2.2)",
+                comp_m[K] * 8e-9, comp_m[K], (double)n_con * (p->ncp + 1) * 8e-9, n_con, p->ncp);
   int rc;
   int *dpt = nullptr, *dlp = nullptr, *dorder = nullptr, *dcc = nullptr, *dcp = nullptr, *dcps = nullptr;
   long* dcm = nullptr;
