@@ -1347,7 +1347,7 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 // The factor goes to the lower triangle of the global block at `out` (row stride ldw).
 __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, double* __restrict__ out, int ldw,
                                                   int* __restrict__ flags, double* __restrict__ xinv) {
-  // Lanes 0..31 factor: lane r keeps row r of L.  Lanes 32..63 run the SAME instruction stream on a column of X = L^-1
+  // D has 2 NB rows (rows NB.. are scratch).  Lanes 0..31 factor: lane r keeps row r of L.  Lanes 32..63 run the SAME instruction stream on a column of X = L^-1
   // (lane 32 + c keeps column c):  X_jc = (delta_jc - sum_{t<j} L_jt X_tc) / L_jj  is the row recurrence
   // v_r = D_rj - sum_{t<j} L_rt L_jt with the lane's own values X_tc in the place of L_rt and delta_jc in the place of D_rj;
   // the broadcast row L_j,: and the pivot are shared.  The inverse costs nothing (the lanes were idle) and turns the panel
@@ -1377,9 +1377,13 @@ __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, d
     double d = readlane_f64(acc, j);
     if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
     const double inv = fast_rsqrt(d);
-    const double l = isX ? acc * inv : ((r == j) ? d * inv : (r > j ? acc * inv : 0.0));
+    // selects on values, one multiply: written as nested products the compiler put divergent branches on the pivot chain
+    double v = acc;
+    v = (!isX && r == j) ? d : v;
+    v = (!isX && r < j) ? 0.0 : v;
+    const double l = v * inv;
     row[j] = l;
-    if (!isX) D[r][j] = l;
+    D[lane][j] = l;  // rows NB.. of D take the X lanes' values (never read): no divergent store inside the pivot chain
     if (j + 1 < NB) s_prev = readlane_f64(l, j + 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1453,7 +1457,7 @@ __device__ __forceinline__ void chol_rank_nb(const double* __restrict__ A, int r
 __global__ void __launch_bounds__(CHOL_THREADS)
 k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace, double* __restrict__ Xinv) {
   __shared__ double sh_red[4][16][17];
-  __shared__ double sh_U[NB][NB + 1], sh_X[NB][NB + 1], sh_D[NB][NB + 1];
+  __shared__ double sh_U[NB][NB + 1], sh_X[NB][NB + 1], sh_D[2 * NB][NB + 1];
   __shared__ __attribute__((aligned(16))) double sh_L[NB][NB + 2];  // even row stride: pairs of coefficients are 16-byte aligned
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int nbk = (n + NB - 1) / NB;
