@@ -720,19 +720,20 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 // The record is COMPACT.  The camera block factors (ba_math.h, project_full): A = G [C | I | A_intr] with G = d(pixel)/dX_c
 // (2 x 3), C = -[Y]x J_l the derivative of the rotated point Y = R X by the rotation vector, so
 //     T = [ J_l^T [Y]x Q ;  Q ;  T_intr ],     Q = G^T Z  (3 x 3: rows 3..5 of T),   T_intr = A_intr^T Z  (rows 6..8, NC = 9).
-// The record holds Y (3), Q (9) and T_intr (9): 12 doubles = 96 B (NC = 6) or 21 -> 22 doubles = 176 B (NC = 9) instead of
-// 144 / 240 B; the pair kernel gathers, stages and reads a third less, and it never forms the top rows: with D = Q_i Q_j^T
+// The record holds Y (3), Q (9) and T_intr (9): 12 doubles, stored 112 B apart (NC = 6), or 21 -> 22 doubles = 176 B (NC = 9)
+// instead of 144 / 240 B; the pair kernel gathers, stages and reads a third less, and it never forms the top rows: with D = Q_i Q_j^T
 //     [Y_i]x D [Y_j]x^T | [Y_i]x D | D [Y_j]x^T | D
 // are the four 3 x 3 quarters of the PRIMED block T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr] (99 FP64 operations per pair
 // instead of 108 on 18 + 18 doubles).  The per-camera factor J_l^T is applied once per block at the end (k_unprime).
 // The rhs needs the true rows 0..2, which k_tprep has in registers anyway.
 template <int NC> struct SchurRec {
   static constexpr int NVAL = (NC == 9) ? 21 : 12;        // doubles that carry data
-  static constexpr int NPH = (NVAL + 1) / 2;              // 16-byte pieces of a record in HBM: 6 / 11
-  static constexpr int REC = 2 * NPH;                     // record stride in HBM, doubles: 12 / 22
-  static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride in LDS, 16-byte pieces, odd: 7 / 11 (bank spread)
+  static constexpr int NPH = (NVAL + 1) / 2;              // 16-byte pieces that carry data: 6 / 11
+  static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride, 16-byte pieces, odd: 7 / 11 (LDS bank spread; the same
+                                                          // stride in HBM lets k_schur_reg3 load records straight into LDS)
+  static constexpr int REC = 2 * LST;                     // record stride, doubles: 14 / 22
 };
-static_assert(SchurRec<6>::REC == 12 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");
+static_assert(SchurRec<6>::REC == 14 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");
 
 // true T (NC x 3, row-major) from a compact record and the camera's J_l (row-major): k_heavy_schur, k_con_schur
 template <int NC>
@@ -1121,6 +1122,184 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int ph = 0; ph < 8; ++ph) dbg_times[((long)blockIdx.x * 4 + cw) * 8 + ph] = tacc[ph];
   }
+  if (slot >= rep) return;
+#pragma unroll
+  for (int r = 0; r < RH; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
+}
+
+// k_schur_reg3: the same ownership, plan format and pair arithmetic as k_schur_reg2 with another data path.  k_schur_reg2 moves
+// a chunk HBM -> registers -> LDS: per trip every wave waits for its loads, issues NLD ds_write_b128 (13 cycles each and
+// serialised with the other waves' reads), and two barriers fence the single LDS copy; tools/schur_split.py puts 80 % of the
+// kernel's time into that skeleton, and with one 12-wave workgroup per CU (NC = 9) nothing overlaps it.  Here the records go
+// straight from HBM into LDS (global_load_lds_dwordx4: 64 lanes, 64 consecutive 16-byte pieces of LDS, any global addresses)
+// into the buffer that is NOT being read (two buffers of half the size), so a trip is: wait for the loads issued a trip ago,
+// one barrier, issue the next chunk's loads, multiply.  No staging registers (the 168-register NC = 9 kernel no longer spills).
+template <int NC> struct Reg3Cfg {
+  static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
+  static constexpr int SPLIT = (NC == 9) ? 3 : 1;
+  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;
+  static constexpr int SCHUNK = (NC == 9) ? 384 : 320;                             // slots per chunk (per LDS buffer)
+  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots loaded by one wave (80 / 32)
+  static constexpr int NLD = (EPW * LST + WAVE - 1) / WAVE;                        // load instructions per wave and chunk (9 / 6)
+  static constexpr int WAVE_PIECES = NLD * WAVE;                                   // LDS pieces of one wave's run, padded to whole loads
+  static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // all-zero record behind the chunk, in each buffer
+  static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                          // (+1: keeps the second buffer 32-byte aligned)
+  static constexpr size_t LDS_BYTES = (size_t)2 * BUF_PIECES * 16;
+  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
+  static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
+};
+
+template <int NC, int SPLIT, int MINW>
+__global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
+k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial) {
+  using Cfg = Reg3Cfg<NC>;
+  static_assert(SPLIT == Cfg::SPLIT, "split");
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
+  constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
+  constexpr int NCD = 4;                        // codes of a chunk that travel in registers
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double2* sh_p = reinterpret_cast<double2*>(sh);  // two chunk buffers, in 16-byte pieces
+
+  const int nblk = tp.g * tp.g;
+  const int rep = (SPLIT == 1) ? tp.rep : 1;
+  const int tid = (int)threadIdx.x;
+  const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
+  const int cw = ct / WAVE, lane = ct % WAVE;
+  const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave
+  const int blk = (rep > 1) ? tid % nblk : ct;
+  const int slot = (rep > 1) ? tid / nblk : 0, half = (rep > 1) ? 0 : tid / BLOCK;
+  const int r0 = half * RH;
+  double acc[RH][NC];
+#pragma unroll
+  for (int r = 0; r < RH; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+
+  const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
+  double* dst = partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
+  if (first >= ch_end) {  // more workgroups than chunks in this range
+    if (slot < rep) {
+#pragma unroll
+      for (int k = 0; k < RH * NC; ++k)
+        if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+    }
+    return;
+  }
+  for (int k = tid; k < 2 * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
+  const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
+  const unsigned zero_code = (unsigned)Cfg::ZERO_PIECE | ((unsigned)Cfg::ZERO_PIECE << 16);
+
+  int idxA = 0, idxB = 0;
+  unsigned cd[NCD];
+#pragma unroll
+  for (int k = 0; k < NCD; ++k) cd[k] = zero_code;
+  int n_nx = 0;
+  long code_nx = 0;
+  auto load_indices = [&](int chunk) {
+    const int* src = tp.obs + tp.chunk_start[chunk] + sw * EPW;
+    idxA = src[lane];
+    if (EPW > WAVE) idxB = src[WAVE + (lane & (EPW - WAVE - 1))];
+  };
+  static_assert(EPW <= WAVE || ((EPW - WAVE) & (EPW - WAVE - 1)) == 0, "second index register");
+  auto load_codes = [&](int chunk) {
+    const unsigned packed = tp.nit[chunk];
+    int pre = 0;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) pre += (w < cw) ? (int)((packed >> (8 * w)) & 0xffu) : 0;
+    n_nx = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * cw)) & 0xffu));
+    code_nx = (long)tp.code_start[chunk] + (long)pre * WAVE + lane;
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+  };
+  // load k of this wave fills LDS pieces [k * 64, k * 64 + 64) of the wave's run: piece (k * 64 + lane) % LST of slot
+  // (k * 64 + lane) / LST; the record index of the slot comes from the wave's index registers (ds_bpermute)
+  auto issue = [&](int buf) {
+    constexpr int Q = WAVE / LST, RM = WAVE % LST;
+    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      int piece = k * RM + lane % LST;
+      int el = k * Q + lane / LST + piece / LST;
+      piece %= LST;
+      el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
+      const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
+      const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
+      const double2* g = reinterpret_cast<const double2*>(Trec + (long)idx * REC) + piece;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                       (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
+    }
+  };
+  auto pair = [&](const double2* bufp, unsigned code) {
+    const double2* Ri = bufp + (code & 0xffffu);
+    const double2* Rj = bufp + (code >> 16);
+    if constexpr (NC == 6) {
+      const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
+      const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
+      const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
+      const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
+      const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
+      double M[3][NC];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2)
+          M[a][3 + b2] = fma(Qi[3 * a + 2], Qj[3 * b2 + 2], fma(Qi[3 * a + 1], Qj[3 * b2 + 1], Qi[3 * a] * Qj[3 * b2]));
+        M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
+        M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
+        M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        acc[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], acc[0][c]));
+        acc[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], acc[1][c]));
+        acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
+        acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
+      }
+    } else {
+      double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
+      if (half == 2) {  // rows of T_intr,i
+        const double2 i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
+        Rm[0] = i6.x; Rm[1] = i6.y; Rm[2] = i7.x; Rm[3] = i7.y; Rm[4] = i8.x; Rm[5] = i8.y; Rm[6] = i9.x; Rm[7] = i9.y; Rm[8] = i10.x;
+      } else {
+        const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
+        Yi[0] = i0.x; Yi[1] = i0.y; Yi[2] = i1.x;
+        Rm[0] = i1.y; Rm[1] = i2.x; Rm[2] = i2.y; Rm[3] = i3.x; Rm[4] = i3.y; Rm[5] = i4.x; Rm[6] = i4.y; Rm[7] = i5.x; Rm[8] = i5.y;
+      }
+      if (half == 0) pair_rows<NC, true>(acc, Rm, Yi, Rj);
+      else pair_rows<NC, false>(acc, Rm, Yi, Rj);
+    }
+  };
+
+  load_indices(first);
+  issue(0);
+  load_codes(first);
+  load_indices(min(first + stride, last));
+  int buf = 0;
+  for (int cur = first; cur < ch_end; cur += stride) {
+    unsigned cc[NCD];
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
+    const int n_cur = n_nx;
+    const long code_cur = code_nx;
+    // the loads into `buf` (issued a trip ago) have landed, and every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nxt = min(cur + stride, last);
+    issue(buf ^ 1);                         // idxA / idxB hold nxt's indices
+    load_codes(nxt);
+    load_indices(min(nxt + stride, last));
+    __builtin_amdgcn_sched_barrier(0);
+    const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
+#pragma unroll
+    for (int it = 0; it < NCD; ++it)
+      if (it < n_cur) pair(bufp, cc[it]);
+    for (int it = NCD; it < n_cur; ++it) pair(bufp, tp.codes[code_cur + (long)it * WAVE]);  // rare: more than four pairs of one block in a chunk
+    buf ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last trip's loads target LDS: let them land before the workgroup retires
   if (slot >= rep) return;
 #pragma unroll
   for (int r = 0; r < RH; ++r)

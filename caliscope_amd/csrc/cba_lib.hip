@@ -70,7 +70,8 @@ struct cba_problem {
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
   bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg / k_schur_reg2); false: LDS-atomic tile kernel
-  bool schur_v2 = false;   // dealt plan + k_schur_reg2 (default); CBA_SCHUR=reg1 keeps round 1's greedy plan and k_schur_reg
+  bool schur_v2 = false;   // dealt plan + register kernel (always with schur_reg)
+  bool schur_v3 = true;    // k_schur_reg3 (records loaded straight into a double-buffered LDS chunk); CBA_SCHUR=reg2: k_schur_reg2 (register-staged)
   double plan_lane_util = 0.0;  // schur_v2: share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
   TilePlan tp{};
@@ -915,7 +916,7 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
 }
 
 // Plan of k_schur_reg2 (schur_plan.h builds it on the host; here: workgroup binding and upload).
-template <int NC>
+template <int NC, typename KCfg>
 static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, const std::vector<int>& hps,
                                 const std::vector<int>& cam_off, int max_blocks) {
   const int G = p->G, g = p->gsz, C = p->C;
@@ -928,16 +929,16 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   prm.C = C; prm.P = p->P; prm.G = G; prm.g = g;
   prm.rep = (NC == 6 && g * g <= BLOCK / 2) ? BLOCK / (g * g) : 1;  // small groups: several threads per block
   if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1))) : 1;
-  prm.chunk_cap = Reg2Cfg<NC>::SCHUNK;
-  prm.slots_per_wave = Reg2Cfg<NC>::EPW; prm.wave_pieces = Reg2Cfg<NC>::WAVE_PIECES; prm.rec_pieces = Reg2Cfg<NC>::LST;
-  prm.zero_piece = Reg2Cfg<NC>::ZERO_PIECE;
+  prm.chunk_cap = KCfg::SCHUNK;
+  prm.slots_per_wave = KCfg::EPW; prm.wave_pieces = KCfg::WAVE_PIECES; prm.rec_pieces = KCfg::LST;
+  prm.zero_piece = KCfg::ZERO_PIECE;
   if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
   Reg2Plan plan;
   if (build_reg2_plan(prm, hcam, hps, plan)) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
   lap("dealt streams and codes (host threads)");
   p->n_tile_chunks = plan.tile_chunk_begin[nT];
-  p->tile_stream_len = (long)plan.obs.size() - 2 * Reg2Cfg<NC>::SCHUNK;
+  p->tile_stream_len = (long)plan.obs.size() - 2 * KCfg::SCHUNK;
   p->n_pairs = plan.n_pairs;
   p->plan_lane_util = plan.lane_iters > 0 ? (double)plan.n_pairs / (double)plan.lane_iters : 0.0;
   if (plan_timing)
@@ -989,6 +990,7 @@ static int configure_kernels(cba_problem* p) {
   const char* force_tile = std::getenv("CBA_SCHUR");
   p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
   p->schur_v2 = p->schur_reg;
+  p->schur_v3 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg2") == 0) && !p->debug_skip;  // the profiling variants are k_schur_reg2's
   if (p->schur_reg) gmax = std::min(p->C, kSchurRegMaxGroup);
   else while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
   p->G = (p->C + gmax - 1) / gmax;
@@ -996,6 +998,7 @@ static int configure_kernels(cba_problem* p) {
   p->n_tiles = p->G * (p->G + 1) / 2;
   if (p->schur_reg) {
     if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
     if (NC == 6 && p->debug_skip) {
       constexpr int D6 = (NC == 6);
       for (const void* fn : {(const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 2 * D6>,
@@ -1165,14 +1168,16 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("reorder, upload, allocate");
   p->eval_only = opt && opt->evaluation_only != 0;
   for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
-    const size_t tile_lds = p->schur_reg ? ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES)
+    const size_t tile_lds = p->schur_reg ? (p->schur_v3 ? ((nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES) : ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES))
                                          : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
     if (p->schur_reg) per_cu = std::min(per_cu, (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // register budget
     const int resident = cus * per_cu;  // no partial last round
-    if (p->schur_reg && p->schur_v2)
-      rc = (nct == 9) ? build_reg2_tile_plan<9>(p, hcam, hps, off, std::min(resident, std::max(max_blocks, cus)))
-                      : build_reg2_tile_plan<6>(p, hcam, hps, off, std::min(resident, std::max(max_blocks, cus)));
+    if (p->schur_reg && p->schur_v2) {
+      const int mb = std::min(resident, std::max(max_blocks, cus));
+      if (p->schur_v3) rc = (nct == 9) ? build_reg2_tile_plan<9, Reg3Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg3Cfg<6>>(p, hcam, hps, off, mb);
+      else rc = (nct == 9) ? build_reg2_tile_plan<9, Reg2Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg2Cfg<6>>(p, hcam, hps, off, mb);
+    }
     else
       rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
     if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) { p->schur_reg = false; p->schur_v2 = false; continue; }  // a point too large for the pair plan
@@ -1523,7 +1528,10 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
-      {
+      if (p->schur_v3) {
+        hipLaunchKernelGGL((k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg3Cfg<NC>::LDS_BYTES,
+                           p->stream, p->tp, p->Trec, p->partial);
+      } else {
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);
         };

@@ -9,12 +9,12 @@
 extern "C" {
 
 // acc_out: [n_tiles][256][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
-int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int slots_per_wave, int lds_stride, int region_chunks,
+int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int slots_per_wave, int lds_stride, int wave_pieces, int region_chunks,
                 int heavy_obs, int threads, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
   cba::Reg2Params prm;
   prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap;
-  // the kernel's staging layout (cba_kernels.h, Reg2Cfg): a wave stages slots_per_wave slots, lds_stride pieces apart
-  prm.rec_pieces = lds_stride; prm.slots_per_wave = slots_per_wave; prm.wave_pieces = slots_per_wave * lds_stride;
+  // the kernel's staging layout (cba_kernels.h, Reg2Cfg): a wave stages slots_per_wave slots, lds_stride pieces apart, in a run of wave_pieces pieces (k_schur_reg3 pads it to whole loads)
+  prm.rec_pieces = lds_stride; prm.slots_per_wave = slots_per_wave; prm.wave_pieces = wave_pieces;
   const int zero_piece = (chunk_cap + slots_per_wave - 1) / slots_per_wave * prm.wave_pieces;
   prm.zero_piece = zero_piece;
   prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads;

@@ -50,6 +50,8 @@ CASES = {
     "pinhole_refine_C6": dict(n_cams=6, n_points=300, k=6, refine=True),
     "huber_outliers_C8": dict(n_cams=8, n_points=400, k=8, loss="huber", outliers=0.05),
     "softl1_outliers_C5": dict(n_cams=5, n_points=300, k=5, loss="soft_l1", outliers=0.05),
+    "cauchy_outliers_C6": dict(n_cams=6, n_points=300, k=6, loss="cauchy", outliers=0.05),
+    "arctan_outliers_C6": dict(n_cams=6, n_points=300, k=6, loss="arctan", outliers=0.05),
     "global_atomics_C24": dict(n_cams=24, n_points=600, k=10),
     "refine_global_C20": dict(n_cams=20, n_points=400, k=8, refine=True),
 }
@@ -161,6 +163,21 @@ def test_step_parity(name):
         # the reduced camera system itself
         S, rhs = hip.reduced_system()
         assert np.allclose(S, S.T, rtol=0, atol=1e-14 * np.abs(S).max())
+        if loss == "linear":
+            # Independent of any Schur code (protocol ii): the damped normal equations of the oracle's sparse J
+            # solved as ONE system, and the reduced system formed from its blocks — the latter checks the camera-point cross
+            # blocks W (the pair products T_i T_j^T of the Schur pass) entry by entry instead of through the step.
+            import scipy.sparse as sp
+            from scipy.sparse.linalg import splu
+
+            ncp = par.n_camera_params
+            D2 = sp.diags(ora.scale_inv ** 2)
+            H = (ora.J.T @ ora.J + lam * D2).tocsc()
+            s_full = splu(H).solve(-ora.g)
+            assert np.abs(s_h - s_full).max() < 1e-8 * np.abs(s_full).max(), lam
+            Hcc, Hcp, Hpp = H[:ncp, :ncp].toarray(), H[:ncp, ncp:], H[ncp:, ncp:].tocsc()
+            S_ref = Hcc - Hcp @ splu(Hpp).solve(Hcp.T.toarray())
+            assert np.abs(S - S_ref).max() < 1e-9 * np.abs(S_ref).max(), lam
         assert np.linalg.norm(S @ s_h[: par.n_camera_params] - rhs) < 1e-7 * np.linalg.norm(rhs)
         gh, go = hip.subspace_gram(0.3, -1.2, 1.1, 0.4), ora.subspace_gram(0.3, -1.2, 1.1, 0.4)
         assert np.allclose(gh, go, rtol=max(1e-7, stol))

@@ -20,7 +20,7 @@ def harness(tmp_path_factory):
                    check=True)
     lib = C.CDLL(str(out))
     lib.plan_replay.restype = C.c_int
-    lib.plan_replay.argtypes = [C.c_int] * 13 + [I32P, I32P, F64P, F64P, I64P]
+    lib.plan_replay.argtypes = [C.c_int] * 14 + [I32P, I32P, F64P, F64P, I64P]
     return lib
 
 
@@ -39,20 +39,24 @@ def _visibility(rng, n_cams, n_points, k_lo, k_hi, duplicates=0.0, unobserved=0.
     return np.concatenate(cams).astype(np.int32), np.asarray(starts, dtype=np.int32)
 
 
-def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_chunks=64, heavy_obs=0):
+def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_chunks=64, heavy_obs=0, layout="reg3"):
     P = len(hps) - 1
     G = -(-n_cams // gmax)
     g = -(-n_cams // G)
     rep = 256 // (g * g) if (nc == 6 and g * g <= 128) else 1
     rec = T.shape[1]
-    # staging layout of k_schur_reg2 (Reg2Cfg): 512 slots, 4 waves x 128, 7 pieces apart (nc = 6); 384 slots, 12 x 32, 11 apart (nc = 9)
-    epw, lst = (128, 7) if nc == 6 else (32, 11)
+    # LDS layout of k_schur_reg3 (Reg3Cfg): 320 slots, 4 waves x 80, 7 pieces apart in runs of 576 (nc = 6); 384 slots, 12 x 32, 11
+    # apart in runs of 384 (nc = 9).  `layout` = "reg2": k_schur_reg2's 512 = 4 x 128 slots, unpadded runs.
+    if layout == "reg2":
+        epw, lst, wp, cap = (128, 7, 896, 512) if nc == 6 else (32, 11, 352, 384)
+    else:
+        epw, lst, wp, cap = (80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384)
     if chunk_cap is None:
-        chunk_cap = 512 if nc == 6 else 384
+        chunk_cap = cap
     nT = G * (G + 1) // 2
     acc = np.zeros((nT, 256, nc * nc))
     stats = np.zeros(8, dtype=np.int64)
-    rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, region_chunks, heavy_obs, 4, hcam.ctypes.data_as(I32P),
+    rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, hcam.ctypes.data_as(I32P),
                          hps.ctypes.data_as(I32P), T.ctypes.data_as(F64P), acc.ctypes.data_as(F64P), stats.ctypes.data_as(I64P))
     assert rc == 0, rc
     return acc, stats, (G, g, rep)
@@ -124,7 +128,9 @@ def test_pairs_reach_their_blocks_random_visibility(harness):
     _check(harness, rng, 64, 900, 2, 10, 6)           # four groups of 16, ten tiles
     _check(harness, rng, 8, 300, 2, 8, 6)             # one small group: rep = 4 threads per block
     _check(harness, rng, 20, 400, 1, 6, 6)            # ragged: two groups of 10, single-view points, rep = 2
-    _check(harness, rng, 40, 500, 3, 9, 9)            # nine-parameter cameras (30-double records)
+    _check(harness, rng, 40, 500, 3, 9, 9)            # nine-parameter cameras
+    _check(harness, rng, 64, 600, 2, 10, 6, layout="reg2")
+    _check(harness, rng, 24, 300, 3, 9, 9, layout="reg2")
 
 
 def test_duplicate_rows_and_unobserved_points(harness):
@@ -162,7 +168,7 @@ def test_lane_utilisation_at_the_bench_shape(harness):
     stats = _check(harness, rng, 64, 10000, 10, 10, 6)
     n_pairs, lane_iters = stats[1], stats[2]
     assert n_pairs == 10000 * 55
-    assert n_pairs / lane_iters > 0.70, n_pairs / lane_iters
+    assert n_pairs / lane_iters > 0.68, n_pairs / lane_iters
     # LDS bank conflicts of the record reads (ds_read_b128: four groups of 16 lanes, one cycle per group when the 16 records sit
     # in 16 different bank groups): the coloured slots stay below 1.6 cycles per group, the arrival order needs ~2.5
     groups, cycles, arrival = stats[5], stats[6], stats[7]
