@@ -536,14 +536,12 @@ struct TilePlan {
   int cs;                        // column stride of one camera block inside the LDS tile (odd: nc | 1)
   int ld;                        // leading dimension of the LDS tile (odd)
   int tile_elems;                // width of one workgroup's partial (LDS-tile kernel: g nc ld + g nc)
-  const unsigned short* blk_off; // register kernel: [n_tile_chunks][g*g + 1] per-thread offsets into the chunk's pairs
-  const int* obs;                // register kernel: stream entry -> observation (index into the T records)
-  int rep;                       // register kernel: threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
-  // k_schur_reg2 (schur_plan.h): transposed pair codes
-  const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_loc | j_loc << 16)
+  // register kernels (k_schur_reg2 / k_schur_reg3, plan: schur_plan.h)
+  const int* obs;                // chunk slot -> observation (index into the T records)
+  int rep;                       // threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
+  const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_addr | j_addr << 16), LDS addresses in 16-byte pieces
   const int* code_start;         // [n_tile_chunks + 1] offsets into `codes`
   const unsigned* nit;           // [n_tile_chunks] iterations of waves 0..3, one byte each
-  int zero_loc;                  // chunk-local index of the all-zero record (idle lanes multiply it)
 };
 // LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
 // an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
@@ -1788,7 +1786,9 @@ k_chol_backward(const double* __restrict__ L, int n, int ldw, double* __restrict
   const int i = threadIdx.x;
   // column c of X_kb for thread c < NB (X is identity-padded beyond the live rows)
   double xc[NB], lp[NB];
+  const int wave_i0 = __builtin_amdgcn_readfirstlane(i & ~(WAVE - 1));  // first thread of this wave: the branches below are wave-uniform
   auto load_x = [&](int kb_req) {
+    if (wave_i0 != 0) return;  // only wave 0 multiplies by X
     const int kb = max(kb_req, 0);
 #pragma unroll
     for (int t = 0; t < NB; ++t) xc[t] = Xinv[(long)kb * NB * NB + t * NB + (i & (NB - 1))];
@@ -1798,6 +1798,7 @@ k_chol_backward(const double* __restrict__ L, int n, int ldw, double* __restrict
   auto load_panel = [&](int kb_req) {
     const int kb = max(kb_req, 0);
     const int k0 = kb * NB, nb = min(NB, n - k0);
+    if (wave_i0 >= k0) return;  // no column of this wave takes part in the fold of block kb
     const int col = min(i, max(k0 - 1, 0));
 #pragma unroll
     for (int t = 0; t < NB; ++t) lp[t] = L[(long)(k0 + min(t, nb - 1)) * ldw + col];

