@@ -1770,75 +1770,91 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
 #undef CHOL_STAMP
 }
 
-// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block (last to
-// first): x_k = X_k^T y_k with X_k = L_kk^-1 from the factorisation (a 32 x 32 product by 32 threads; the serial triangle
-// solve it replaces took a third of a block's time), then every thread i < k0 folds the block into y_i.  The loads of a
-// block's update panel L[k0 .. k0+nb, i] and of the next X do not depend on the solution, so they are issued a block ahead.
-// The workgroup's memory path moves ~16 bytes per clock, so only the columns i < k0 that the fold uses are loaded (loading
-// all n columns of every panel, as the first version did, was two thirds of its 47 us).
+// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block (last
+// to first): wave 0 solves the NB x NB triangle, then every thread i < k0 folds the block into y_i.  The loads of
+// a block's update panel L[k0 .. k0+nb, i] and of the next diagonal block do not depend on the solution, so they
+// are issued before the triangle solve and land while it runs (the first version loaded after each barrier: 5 us
+// per block, all of it exposed latency).
 constexpr int BACK_THREADS = 512;
 __global__ void __launch_bounds__(BACK_THREADS)
-k_chol_backward(const double* __restrict__ L, int n, int ldw, double* __restrict__ out, const double* __restrict__ Xinv) {
+k_chol_backward(const double* __restrict__ L, int n, int ldw, double* __restrict__ out) {  // (a variant that multiplies by the stored
+  // inverses X_k instead of solving the triangles and loads only the columns the fold uses measured 15 us slower: reverted)
   extern __shared__ __attribute__((aligned(16))) double y[];  // n
-  __shared__ double xs[NB];
+  __shared__ double D[NB][NB + 1];
+  constexpr int EPT = NB * NB / BACK_THREADS;
   for (int i = threadIdx.x; i < n; i += BACK_THREADS) y[i] = L[(long)n * ldw + i];
+  const int lane = threadIdx.x & (WAVE - 1);
   const int nblk = (n + NB - 1) / NB;
-  const int i = threadIdx.x;
-  // column c of X_kb for thread c < NB (X is identity-padded beyond the live rows)
-  double xc[NB], lp[NB];
-  const int wave_i0 = __builtin_amdgcn_readfirstlane(i & ~(WAVE - 1));  // first thread of this wave: the branches below are wave-uniform
-  auto load_x = [&](int kb_req) {
-    if (wave_i0 != 0) return;  // only wave 0 multiplies by X
+  const int dr = threadIdx.x / NB, dc = threadIdx.x % NB;  // elements (dr + h * BACK_THREADS / NB, dc) of a diagonal block
+  double dreg[EPT];
+  // loads are unconditional (clamped addresses, select afterwards): a load under a divergent branch would make the
+  // compiler drain vmcnt at the join, i.e. before the triangle solve the loads are meant to overlap with
+  auto load_diag = [&](int kb_req) {
     const int kb = max(kb_req, 0);
+    const int k0 = kb * NB, nb = min(NB, n - k0);
 #pragma unroll
-    for (int t = 0; t < NB; ++t) xc[t] = Xinv[(long)kb * NB * NB + t * NB + (i & (NB - 1))];
+    for (int h = 0; h < EPT; ++h) {
+      const int r = dr + h * (BACK_THREADS / NB);
+      const double v = L[(long)(k0 + min(r, nb - 1)) * ldw + k0 + min(dc, nb - 1)];
+      dreg[h] = (r < nb && dc <= r) ? v : (r == dc ? 1.0 : 0.0);
+    }
   };
-  // update panel of block kb, column i: L[k0 + t][i], t < NB (rows clamped into the block, masked when used); columns >= k0
-  // all read column k0 - 1: one address per row, no extra traffic
+  // update panel of block kb, column i: L[k0 + t][i], t < NB (rows clamped into the block, masked when used)
+  const int i = threadIdx.x;
+  double lp[NB];
   auto load_panel = [&](int kb_req) {
     const int kb = max(kb_req, 0);
     const int k0 = kb * NB, nb = min(NB, n - k0);
-    if (wave_i0 >= k0) return;  // no column of this wave takes part in the fold of block kb
-    const int col = min(i, max(k0 - 1, 0));
 #pragma unroll
-    for (int t = 0; t < NB; ++t) lp[t] = L[(long)(k0 + min(t, nb - 1)) * ldw + col];
+    for (int t = 0; t < NB; ++t) lp[t] = L[(long)(k0 + min(t, nb - 1)) * ldw + min(i, n - 1)];
   };
-  load_x(nblk - 1);
+  load_diag(nblk - 1);
   load_panel(nblk - 1);
-  __syncthreads();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * NB;
     const int nb = min(NB, n - k0);
-    double xcur[NB], lcur[NB];
 #pragma unroll
-    for (int t = 0; t < NB; ++t) { xcur[t] = xc[t]; lcur[t] = lp[t]; }
-    // in flight during this block: the next block's X and update panel
-    load_x(kb - 1);
+    for (int h = 0; h < EPT; ++h) D[dr + h * (BACK_THREADS / NB)][dc] = dreg[h];
+    double lcur[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) lcur[t] = lp[t];
+    __syncthreads();
+    // in flight during this block's solve and update: the next block's diagonal block and update panel
+    load_diag(kb - 1);
     load_panel(kb - 1);
-    if (i < NB) {  // x_c = sum_t X[t][c] y[k0 + t]
-      double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (threadIdx.x < WAVE) {
+      // D is identity-padded to NB x NB: the triangle is solved at full size from registers (column `lane` of D)
+      const int c = lane & (NB - 1);
+      double col[NB];
 #pragma unroll
-      for (int t = 0; t < NB; ++t) a[t & 3] = fma(xcur[t], (t < nb) ? y[k0 + t] : 0.0, a[t & 3]);
-      xs[i] = (a[0] + a[1]) + (a[2] + a[3]);
+      for (int t = 0; t < NB; ++t) col[t] = D[t][c];
+      double xj = (lane < nb) ? y[k0 + lane] : 0.0;
+      const double dinv = 1.0 / D[c][c];
+#pragma unroll
+      for (int t = NB - 1; t >= 0; --t) {
+        const double xt = readlane_f64(xj * dinv, t);
+        if (lane == t) xj = xt;
+        else if (lane < t) xj -= col[t] * xt;
+      }
+      if (lane < nb) y[k0 + lane] = xj;
     }
     __syncthreads();
-    if (i < nb) y[k0 + i] = xs[i];
     if (i < k0) {
       double acc = 0.0;
 #pragma unroll
       for (int t = 0; t < NB; ++t)
-        if (t < nb) acc += lcur[t] * xs[t];
+        if (t < nb) acc += lcur[t] * y[k0 + t];
       y[i] -= acc;
     }
-    for (int i2 = i + BACK_THREADS; i2 < k0; i2 += BACK_THREADS) {  // wider systems: the rest of the panel
+    for (int i2 = threadIdx.x + BACK_THREADS; i2 < k0; i2 += BACK_THREADS) {  // wider systems: the rest of the panel
       double acc = 0.0;
 #pragma unroll 8
-      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * ldw + i2] * xs[t];
+      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * ldw + i2] * y[k0 + t];
       y[i2] -= acc;
     }
-    __syncthreads();
   }
-  for (int i3 = threadIdx.x; i3 < n; i3 += BACK_THREADS) out[i3] = y[i3];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += BACK_THREADS) out[i] = y[i];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1250,7 +1250,7 @@ static int enqueue_cholesky(cba_problem* p) {
     const int x = nbk - k - 1, n_trailing = k < 1 ? 0 : x * (x + 1) / 2;
     hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace, p->Xinv);
   }
-  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)n * 8, p->stream, p->Lbuf, n, p->ldw, p->s, p->Xinv);
+  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)n * 8, p->stream, p->Lbuf, n, p->ldw, p->s);
   return CBA_OK;
 }
 
