@@ -246,24 +246,86 @@ template <int NC> struct UPack {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Deterministic per-camera sums (cba_options.deterministic).  The default kernels add an observation's share of U_c, g_c
+// (k_build) and of the rhs (k_tprep) with FP64 LDS atomics, whose order — and with it the last bits of the sums, and now
+// and then the evaluation count of a solve — changes from run to run; the reference is bit-reproducible (single-threaded
+// scipy, capture_volume.py:387).  Here a chunk's values are parked in LDS, nine per observation and round, and summed per
+// camera in the chunk's FIXED camera-sorted order (cba_create lays out, per chunk, the observation order by camera and the
+// camera offsets); every thread owns the running sums of its (camera, value) tasks for the whole kernel, so the
+// per-workgroup partials and everything downstream (k_reduce_rows, fixed order) are reproducible bit for bit.
+constexpr int DET_ROUND = 9;              // values per observation and round
+constexpr int DET_LD = CHUNK + 1;         // row stride of the parking area (odd: the nine rows of a task group hit nine banks)
+struct DetPlan {
+  const unsigned char* perm;    // [n_chunks][CHUNK] chunk-local observation indices, sorted by camera
+  const unsigned short* cstart; // [n_chunks][C + 1] offsets into perm
+};
+// one round: `val[q]` of this thread's observation (zeros when it has none) -> per-camera sums into acc[m], task = tid + BLOCK * m,
+// camera = task / DET_ROUND, value = task % DET_ROUND.  sh_cv: DET_ROUND * DET_LD doubles; sh_perm / sh_cs: the chunk's tables.
+template <int M>
+__device__ __forceinline__ void det_round(const double* val, double* sh_cv, const int* sh_perm, const int* sh_cs, int n_cams, double* acc) {
+#pragma unroll
+  for (int q = 0; q < DET_ROUND; ++q) sh_cv[q * DET_LD + threadIdx.x] = val[q];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int task = (int)threadIdx.x + BLOCK * m;
+    if (task < n_cams * DET_ROUND) {
+      const int c = task / DET_ROUND, q = task % DET_ROUND;
+      double s = 0.0;
+      for (int j = sh_cs[c]; j < sh_cs[c + 1]; ++j) s += sh_cv[q * DET_LD + sh_perm[j]];
+      acc[m] += s;
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
 // build pass: residuals + Jacobian blocks -> per-point V_p, g_p (segmented sums through LDS), per-camera
 // U_c, g_c (LDS atomics, flushed as per-workgroup partials), cost partials.
+// value v (position in the packed camera block: upper triangle row by row, then the gradient) of one observation
 template <int NC>
+__device__ __forceinline__ double cam_block_value(int v, const double (*A)[MAX_NC], const double* e, int np) {
+  using UP = UPack<NC>;
+  int idx = 0;
+#pragma unroll
+  for (int r = 0; r < NC; ++r)
+#pragma unroll
+    for (int c = r; c < NC; ++c, ++idx)
+      if (idx == v) return (r < np && c < np) ? A[0][r] * A[0][c] + A[1][r] * A[1][c] : 0.0;
+#pragma unroll
+  for (int r = 0; r < NC; ++r)
+    if (UP::TRI + r == v) return (r < np) ? A[0][r] * e[0] + A[1][r] * e[1] : 0.0;
+  return 0.0;
+}
+
+template <int NC, int DETM = 0>  // DETM > 0: deterministic variant, DETM tasks per thread and round (cameras <= DETM * 256 / 9)
 __global__ void __launch_bounds__(BLOCK)
 k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
         const int* __restrict__ chunk_pts, int n_chunks, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams,
         int loss, double f_scale, double* __restrict__ Vblk, double* __restrict__ gvec,
-        double* __restrict__ partialU, double* __restrict__ partial_cost, int* __restrict__ flags, const double* __restrict__ skip) {
+        double* __restrict__ partialU, double* __restrict__ partial_cost, int* __restrict__ flags, const double* __restrict__ skip,
+        DetPlan det = DetPlan{nullptr, nullptr}) {
   using UP = UPack<NC>;
+  constexpr bool DET = DETM > 0;
   if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_U = sh_tab + n_cams * CAMTAB_LDS;
-  double* sh_pt = sh_U + n_cams * UP::STRIDE;
+  double* sh_U = sh_tab + n_cams * CAMTAB_LDS;                         // DET: the parking area of det_round instead
+  double* sh_pt = sh_U + (DET ? DET_ROUND * DET_LD : n_cams * UP::STRIDE);
   double* sh_red = sh_pt + 9 * CHUNK;
+  int* sh_perm = reinterpret_cast<int*>(sh_red + 8);                   // DET: [CHUNK] + [n_cams + 1]
+  int* sh_cs = sh_perm + CHUNK;
+  constexpr int DROUNDS = (UP::STRIDE + DET_ROUND - 1) / DET_ROUND;    // 3 / 6
+  constexpr int DM = DET ? DETM : 1;                                   // tasks per thread and round: ceil(C * 9 / 256)
+  double dacc[DROUNDS][DM];
+#pragma unroll
+  for (int r = 0; r < DROUNDS; ++r)
+#pragma unroll
+    for (int m = 0; m < DM; ++m) dacc[r][m] = 0.0;
   stage_camtab(sh_tab, tab, n_cams);
-  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
+  if (!DET)
+    for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
   __syncthreads();
   const double* px = xvec + lay.ncp_pad;
   double* gp = gvec + lay.ncp_pad;
@@ -289,9 +351,17 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     double pv[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) pv[q] = 0.0;
+    double e[2] = {0.0, 0.0}, A[2][MAX_NC];
+    int np_det = 0;
+    if (DET) {
+#pragma unroll
+      for (int k = 0; k < MAX_NC; ++k) { A[0][k] = 0.0; A[1][k] = 0.0; }
+      sh_perm[threadIdx.x] = det.perm[(long)ch * CHUNK + threadIdx.x];
+      if ((int)threadIdx.x <= n_cams) sh_cs[threadIdx.x] = det.cstart[(long)ch * (n_cams + 1) + threadIdx.x];
+    }
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
-      double e[2], A[2][MAX_NC], B[2][3];
+      double B[2][3];
       cost += obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss,
                                 f_scale, e, A, B);
       if (!isfinite(e[0] + e[1])) bad = true;  // a trial point built directly by this pass (fused step): scipy's isfinite(f_new) test
@@ -305,14 +375,17 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       pv[7] = B[0][1] * e[0] + B[1][1] * e[1];
       pv[8] = B[0][2] * e[0] + B[1][2] * e[1];
       const int np = (int)cam_at(sh_tab, cam).nparams;
-      double* Uc = sh_U + cam * UP::STRIDE;
+      np_det = np;
+      if (!DET) {
+        double* Uc = sh_U + cam * UP::STRIDE;
 #pragma unroll
-      for (int r = 0; r < NC; ++r) {
-        if (r < np) {
+        for (int r = 0; r < NC; ++r) {
+          if (r < np) {
 #pragma unroll
-          for (int c = r; c < NC; ++c)
-            if (c < np) lds_add(&Uc[UP::idx(r, c)], A[0][r] * A[0][c] + A[1][r] * A[1][c]);
-          lds_add(&Uc[UP::TRI + r], A[0][r] * e[0] + A[1][r] * e[1]);
+            for (int c = r; c < NC; ++c)
+              if (c < np) lds_add(&Uc[UP::idx(r, c)], A[0][r] * A[0][c] + A[1][r] * A[1][c]);
+            lds_add(&Uc[UP::TRI + r], A[0][r] * e[0] + A[1][r] * e[1]);
+          }
         }
       }
     }
@@ -348,10 +421,30 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       if (b > a) reduce_point(p, a, b);
     }
     __syncthreads();
+    if (DET) {  // camera blocks: fixed-order sums, nine values per round (np_det == 0: no observation, all values zero)
+#pragma unroll
+      for (int rd = 0; rd < DROUNDS; ++rd) {
+        double val[DET_ROUND];
+#pragma unroll
+        for (int q = 0; q < DET_ROUND; ++q) val[q] = cam_block_value<NC>(rd * DET_ROUND + q, A, e, np_det);
+        det_round<DM>(val, sh_U, sh_perm, sh_cs, n_cams, dacc[rd]);
+      }
+    }
     cur = nx; o0 = no0; o1 = no1; ch = nxt;
   }
   double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
-  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
+  if (DET) {
+#pragma unroll
+    for (int rd = 0; rd < DROUNDS; ++rd)
+#pragma unroll
+      for (int m = 0; m < DM; ++m) {
+        const int task = (int)threadIdx.x + BLOCK * m;
+        const int c = task / DET_ROUND, v = rd * DET_ROUND + task % DET_ROUND;
+        if (task < n_cams * DET_ROUND && v < UP::STRIDE) dst[c * UP::STRIDE + v] = dacc[rd][m];
+      }
+  } else {
+    for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
+  }
   const double tot = block_sum(cost, sh_red);
   if (threadIdx.x == 0) partial_cost[blockIdx.x] = tot;
   if (bad) flags[0] = 1;
@@ -752,22 +845,30 @@ __device__ __forceinline__ void expand_record(const double* __restrict__ rec, co
   }
 }
 
-template <int NC>
+template <int NC, int DETM = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ chunk_start, int n_chunks,
         const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, const int* __restrict__ cam_off,
         int n_cams, int loss, double f_scale, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
-        double* __restrict__ partial_b, int* __restrict__ flags) {
+        double* __restrict__ partial_b, int* __restrict__ flags, DetPlan det = DetPlan{nullptr, nullptr}) {
   constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;
+  constexpr bool DET = DETM > 0;
   if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double2* sh_stage = reinterpret_cast<double2*>(sh);        // [BLOCK / WAVE][WAVE * NP]  record transpose, per wave
   double* sh_tab = sh + (size_t)BLOCK * REC;
-  double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad
+  double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad (DET: the parking area of det_round, then the chunk's camera order)
+  int* sh_perm = reinterpret_cast<int*>(sh_b + DET_ROUND * DET_LD);
+  int* sh_cs = sh_perm + CHUNK;
+  constexpr int DM = DET ? DETM : 1;
+  double dacc[DM];
+#pragma unroll
+  for (int m = 0; m < DM; ++m) dacc[m] = 0.0;
   stage_camtab(sh_tab, tab, n_cams);
-  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_b[i] = 0.0;
+  if (!DET)
+    for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_b[i] = 0.0;
   __syncthreads();
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
@@ -791,6 +892,13 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     double rec[REC];
 #pragma unroll
     for (int k = 0; k < REC; ++k) rec[k] = 0.0;
+    double bval[DET_ROUND];
+#pragma unroll
+    for (int q = 0; q < DET_ROUND; ++q) bval[q] = 0.0;
+    if (DET) {
+      sh_perm[threadIdx.x] = det.perm[(long)ch * CHUNK + threadIdx.x];
+      if ((int)threadIdx.x <= n_cams) sh_cs[threadIdx.x] = det.cstart[(long)ch * (n_cams + 1) + threadIdx.x];
+    }
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
       const CamTab& ct = cam_at(sh_tab, cam);
@@ -823,7 +931,8 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         double t[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) t[k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
-        if (live) lds_add(&bc[r], t[0] * y[0] + t[1] * y[1] + t[2] * y[2]);
+        if (DET) bval[r] = live ? t[0] * y[0] + t[1] * y[1] + t[2] * y[2] : 0.0;
+        else if (live) lds_add(&bc[r], t[0] * y[0] + t[1] * y[1] + t[2] * y[2]);
         if (r >= 3) { rec[3 * r - 6] = t[0]; rec[3 * r - 5] = t[1]; rec[3 * r - 4] = t[2]; }  // rows 3.. : Q, then T_intr
       }
     }
@@ -847,11 +956,26 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (DET) {  // rhs terms: fixed-order sums per camera (one round: NC <= DET_ROUND values per observation)
+      __syncthreads();
+      det_round<DM>(bval, sh_b, sh_perm, sh_cs, n_cams, dacc);
+    }
     cur = nx; o0 = no0; o1 = no1; ch = nxt;
   }
   if (fail) flags[1] = 1;
   __syncthreads();
-  for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) partial_b[(long)blockIdx.x * lay.ncp_pad + i] = sh_b[i];
+  double* brow = partial_b + (long)blockIdx.x * lay.ncp_pad;
+  if (DET) {
+    for (int i = lay.ncp + threadIdx.x; i < lay.ncp_pad; i += BLOCK) brow[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < DM; ++m) {
+      const int task = (int)threadIdx.x + BLOCK * m;
+      const int c = task / DET_ROUND, q = task % DET_ROUND;
+      if (task < n_cams * DET_ROUND && q < (int)cam_at(sh_tab, c).nparams) brow[cam_off[c] + q] = dacc[m];
+    }
+  } else {
+    for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) brow[i] = sh_b[i];
+  }
 }
 
 // k_schur_reg2.  A 256-thread workgroup is bound to one tile (camera group a x camera group b) of the reduced camera

@@ -96,6 +96,8 @@ struct cba_problem {
   long long* chol_trace = nullptr;  // CBA_CHOL_TRACE=1: phase stamps of k_chol_step (tools/chol_trace.py)
   int ldw = 0;             // row stride of the Cholesky work matrix Lbuf (multiple of 4 doubles)
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
+  int det_m = 0;  // cba_options.deterministic: tasks per thread of the fixed-order camera sums (3, 5 or 8; 0: atomics)
+  DetPlan det{nullptr, nullptr};
   double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
@@ -518,6 +520,8 @@ static int allow_lds(K kernel, size_t bytes) {
 
 static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + 8) * 8; }
 template <int NC> static size_t lds_build(const cba_problem* p) {
+  if (p->det_m)  // parking area of the fixed-order sums instead of the packed blocks, + the chunk's camera order (ints)
+    return ((size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD + 9 * CHUNK + 8) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
   return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
 }
 static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_LDS + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
@@ -533,6 +537,7 @@ template <int NC> struct RegCfg;
 template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
+  if (p->det_m) return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
   return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
 }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
@@ -786,6 +791,14 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_cost<false>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
+  if (p->det_m) {
+    if ((rc = allow_lds(k_build<NC, 3>, lds_build<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_build<NC, 5>, lds_build<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_build<NC, 8>, lds_build<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_tprep<NC, 3>, lds_tprep<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_tprep<NC, 5>, lds_tprep<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_tprep<NC, 8>, lds_tprep<NC>(p)))) return rc;
+  }
   if ((rc = allow_lds(k_jv<NC, 1>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
   int gmax = 1;
@@ -933,6 +946,25 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_upload(p, &p->obs_u, hu)); TRY(dev_upload(p, &p->obs_v, hv));
   TRY(dev_upload(p, &p->obs_cam, hcam)); TRY(dev_upload(p, &p->obs_pt, hpt));
   TRY(dev_upload(p, &p->order, hord)); TRY(dev_upload(p, &p->pt_start, hps)); TRY(dev_upload(p, &p->chunk_start, hcs));
+  if (opt && opt->deterministic) {
+    // fixed-order per-camera sums (k_build / k_tprep, det_round): per chunk the observation order by camera and the camera offsets
+    const int need = (p->C * DET_ROUND + BLOCK - 1) / BLOCK;
+    p->det_m = need <= 3 ? 3 : need <= 5 ? 5 : need <= 8 ? 8 : -1;
+    if (p->det_m < 0) return bail(fail(CBA_ERR_UNSUPPORTED, "deterministic sums support up to %d cameras, the problem has %d", 8 * BLOCK / DET_ROUND, p->C));
+    std::vector<unsigned char> perm((size_t)std::max<int64_t>(nch, 1) * CHUNK, 0);
+    std::vector<unsigned short> cst((size_t)std::max<int64_t>(nch, 1) * (p->C + 1), 0);
+    for (int64_t c = 0; c < nch; ++c) {
+      const int o0 = hcs[c], n = hcs[c + 1] - o0;
+      unsigned short* cs = &cst[(size_t)c * (p->C + 1)];
+      for (int k = 0; k < n; ++k) cs[hcam[o0 + k] + 1]++;
+      for (int q = 0; q < p->C; ++q) cs[q + 1] += cs[q];
+      std::vector<unsigned short> cur(cs, cs + p->C);
+      for (int k = 0; k < n; ++k) perm[(size_t)c * CHUNK + cur[hcam[o0 + k]]++] = (unsigned char)k;  // stable: observation order inside a camera
+    }
+    unsigned char* dperm = nullptr; unsigned short* dcst = nullptr;
+    TRY(dev_upload(p, &dperm, perm)); TRY(dev_upload(p, &dcst, cst));
+    p->det = DetPlan{dperm, dcst};
+  }
   {
     std::vector<int> hcp((size_t)std::max<int64_t>(nch, 1) * 2, 0);
     for (int64_t q = 0; q < nch; ++q) {
@@ -1114,9 +1146,17 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
     if (p->n_heavy)  // fragments of heavy points add their sums by atomics
       hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay, V, 6,
                          g + p->lay.ncp_pad, 3);
-    hipLaunchKernelGGL(k_build<NC>, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                       p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
-                       V, g, p->partial, p->partial1, p->flags + flag_slot, skip);
+    auto launch_build = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds_build<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                         p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
+                         V, g, p->partial, p->partial1, p->flags + flag_slot, skip, p->det);
+    };
+    switch (p->det_m) {  // deterministic: fixed-order camera sums (k_build<NC, tasks per thread>)
+      case 3: launch_build(k_build<NC, 3>); break;
+      case 5: launch_build(k_build<NC, 5>); break;
+      case 8: launch_build(k_build<NC, 8>); break;
+      default: launch_build(k_build<NC, 0>); break;
+    }
   }
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
@@ -1324,9 +1364,17 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
   {
     ScopedTimer t(p, T_SCHUR);
     if (p->schur_reg) {
-      hipLaunchKernelGGL((k_tprep<NC>), dim3(p->grid), dim3(BLOCK), lds_tprep<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
-                         p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, lam_dev, p->V, p->g,
-                         p->sinv, p->Trec, p->partial_b, p->flags);
+      auto launch_tprep = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds_tprep<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
+                           p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, lam_dev, p->V, p->g,
+                           p->sinv, p->Trec, p->partial_b, p->flags, p->det);
+      };
+      switch (p->det_m) {
+        case 3: launch_tprep(k_tprep<NC, 3>); break;
+        case 5: launch_tprep(k_tprep<NC, 5>); break;
+        case 8: launch_tprep(k_tprep<NC, 8>); break;
+        default: launch_tprep(k_tprep<NC, 0>); break;
+      }
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone

@@ -29,8 +29,15 @@ def _ip(a: np.ndarray):
 
 
 class HipEngine:
-    def __init__(self, problem: BAProblem, device_id: int = -1, max_blocks: int = 0, evaluation_only: bool = False):
-        """``evaluation_only``: residuals / costs only (``residuals``, ``begin``) — skips the Schur plan and the solver buffers."""
+    def __init__(self, problem: BAProblem, device_id: int = -1, max_blocks: int = 0, evaluation_only: bool = False,
+                 deterministic: bool | None = None):
+        """``evaluation_only``: residuals / costs only (``residuals``, ``begin``) — skips the Schur plan and the solver buffers.
+        ``deterministic`` (default: the environment variable ``CBA_DETERMINISTIC=1``): fixed-order sums everywhere, two solves
+        of the same problem return the same bits (as the reference's single-threaded scipy does); a few percent slower."""
+        import os
+
+        if deterministic is None:
+            deterministic = os.environ.get("CBA_DETERMINISTIC", "0") not in ("", "0")
         self.lib = _lib.load()
         self.problem = problem
         par = problem.parameterization
@@ -49,7 +56,7 @@ class HipEngine:
             obs_cam=_ip(self._keep[3]), obs_pt=_ip(self._keep[4]), obs_uv=_dp(self._keep[5]),
             loss=LOSS_CODES[problem.loss], f_scale=float(problem.f_scale),
         )
-        opt = _lib.Options(device_id=device_id, max_blocks=max_blocks, deterministic=0, evaluation_only=1 if evaluation_only else 0)
+        opt = _lib.Options(device_id=device_id, max_blocks=max_blocks, deterministic=1 if deterministic else 0, evaluation_only=1 if evaluation_only else 0)
         handle = C.c_void_p()
         self._h = None
         _lib.check(self.lib, self.lib.cba_create(C.byref(desc), C.byref(opt), C.byref(handle)), "cba_create")

@@ -69,7 +69,10 @@ typedef struct {
 typedef struct {
   int32_t device_id;     /* HIP device ordinal; -1 = current device                                  */
   int32_t max_blocks;    /* 0 = default (4 workgroups per CU); upper bound on persistent grid size   */
-  int32_t deterministic; /* reserved (reductions through per-workgroup partials are already ordered) */
+  int32_t deterministic; /* 1: the per-camera sums of the build and Schur passes are formed in a fixed order (parked in LDS, summed per
+                            camera in the chunk's camera-sorted order) instead of by FP64 LDS atomics: two solves of one problem return
+                            identical bits, as the reference's single-threaded scipy does (capture_volume.py:387).  Constraint rows and
+                            heavy points still add their few sums atomically. */
   int32_t evaluation_only; /* 1: residuals / costs only (cba_residuals, cba_begin): the Schur plan and the solver's buffers are
                               not built — the reprojection report needs no more */
 } cba_options;

@@ -378,6 +378,31 @@ def test_full_size_cfg2_converged_parity_with_scipy():
     assert pos < 1e-6 and ang < 1e-6, (pos, ang)
 
 
+@pytest.mark.parametrize("name", ["pinhole_locked_C8", "global_atomics_C24", "refine_global_C20", "huber_outliers_C8"])
+def test_deterministic_mode_is_bit_reproducible(name):
+    """cba_options.deterministic: two solves of one problem return identical bits (the reference's scipy call is
+    single-threaded and bit-reproducible, core/capture_volume.py:387); the sums agree with the default (atomic) path to rounding."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0, loss, fs = _case(name)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs)
+    lb, ub = par.bounds()
+    ncp = par.n_camera_params
+    kw = dict(lb=lb[:ncp], ub=ub[:ncp]) if par.has_finite_bounds else {}
+    runs = []
+    for _ in range(3):
+        with HipEngine(prob, deterministic=True) as eng:
+            res = eng.solve(x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200, **kw)
+            U, V, gc, gp = eng.normal_blocks(x0)
+            runs.append((res, U, gc))
+    for res, U, gc in runs[1:]:
+        assert np.array_equal(res.x, runs[0][0].x) and res.nfev == runs[0][0].nfev and res.cost == runs[0][0].cost
+        assert np.array_equal(U, runs[0][1]) and np.array_equal(gc, runs[0][2])
+    with HipEngine(prob) as eng:  # default path: same sums up to the order of the additions
+        U0, V0, gc0, gp0 = eng.normal_blocks(x0)
+    assert _rel(runs[0][1], U0) < 1e-12 and _rel(runs[0][2], gc0) < 1e-11
+
+
 def test_rccl_call_sites_with_a_one_rank_communicator(monkeypatch):
     """Every all-reduce the sharded protocol issues (camera blocks, reduced system, scalar sums, flags) runs
     through RCCL on the engine's stream; with one rank the result must equal the plain path."""
