@@ -138,7 +138,8 @@ struct cba_problem {
   std::vector<EventPair> free_events;
   double t_ms[T_COUNT] = {0};
   long t_calls[T_COUNT] = {0};
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;   // arena chunks (dev_alloc)
+  char* arena_cur = nullptr; size_t arena_left = 0, arena_next = (size_t)4 << 20;
   // sharded solve (points partitioned over ranks, cameras replicated): RCCL over xGMI
   ncclComm_t comm = nullptr;
   cba_group* group = nullptr;  // in-process device group (cba_group_join): direct peer-to-peer exchange instead of RCCL
@@ -174,14 +175,31 @@ static hipError_t guarded_memcpy(void* dst, const void* src, size_t bytes, hipMe
   return hipMemcpy(dst, src, bytes, kind);
 }
 
+// Device memory of a handle comes from an arena: a handle has ~60 buffers, and on the reference's own 4-camera session
+// creating and freeing them one hipMalloc / hipFree at a time was more than half of an optimize() call (the solve itself takes
+// 1 ms).  Buffers are carved out of chunks (the first 4 MB, then doubling; a large buffer gets a chunk of its own), 256-byte
+// aligned; cba_destroy frees the chunks.
 template <typename T>
 static int dev_alloc(cba_problem* p, T** out, size_t count) {
-  void* ptr = nullptr;
-  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-  HIPCHK(guarded_malloc(&ptr, bytes));
-  p->allocs.push_back(ptr);
+  const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+  if (bytes > p->arena_left) {
+    const size_t chunk = std::max(bytes, p->arena_next);
+    void* ptr = nullptr;
+    HIPCHK(guarded_malloc(&ptr, chunk));
+    p->allocs.push_back(ptr);
+    if (bytes >= p->arena_next) {  // a buffer of its own: the open chunk stays open
+      p->device_bytes += (long)bytes;
+      *out = static_cast<T*>(ptr);
+      return CBA_OK;
+    }
+    p->arena_cur = static_cast<char*>(ptr);
+    p->arena_left = chunk;
+    p->arena_next = std::min<size_t>(p->arena_next * 2, (size_t)256 << 20);
+  }
+  *out = reinterpret_cast<T*>(p->arena_cur);
+  p->arena_cur += bytes;
+  p->arena_left -= bytes;
   p->device_bytes += (long)bytes;
-  *out = static_cast<T*>(ptr);
   return CBA_OK;
 }
 template <typename T>

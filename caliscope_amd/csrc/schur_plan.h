@@ -50,7 +50,8 @@ struct Reg2Params {
   // rec_pieces odd (then the bank group of a record is decided by slot mod 16, see below).
   int slots_per_wave = 96, wave_pieces = 896, rec_pieces = 9;
   int zero_piece = 0;     // piece address of the all-zero record
-  int region_chunks = 128;
+  int region_chunks = 32;   // chunks dealt together: larger regions pack better (lane utilisation 0.77 at 128, 0.71 at 32 on cfg4) but the tiles that
+                            // gather one record then do so further apart in time: at 32 half of those gathers hit the L2 (PMC FETCH_SIZE 0.59 vs 0.90 GB)
   int heavy_obs = 0;      // > 0: points with more observations are left out (k_heavy_schur forms their share)
   int threads = 0;        // host threads (0: hardware concurrency)
 };
