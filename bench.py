@@ -172,9 +172,9 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     }
 
 
-# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg2; k_schur_tile is the
-# LDS-atomic fallback)
-PMC_KERNEL = {"schur": ("k_tprep", "k_schur_reg2", "k_reg_reduce", "k_reg_fold", "k_unprime", "k_schur_tile"), "build": ("k_build",), "jv": ("k_jv",),
+# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg3; k_schur_reg2 and
+# k_schur_tile are the fallbacks)
+PMC_KERNEL = {"schur": ("k_tprep", "k_schur_reg3", "k_schur_reg2", "k_schur_tile"), "build": ("k_build",), "jv": ("k_jv",),
               "backsub": ("k_backsub",), "cost": ("k_cost<false>",)}
 
 
@@ -207,7 +207,7 @@ def roofline_from(m):
     return {
         "bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(m["name"], dom), "alg_bytes_per_launch": alg[dom],
-        "note": "k_schur = the Schur pass (k_tprep writes one compact record per observation, k_schur_reg2 gathers them per "
+        "note": "k_schur = the Schur pass (k_tprep writes one compact record per observation, k_schur_reg3 gathers them per "
                 "camera-group tile and multiplies the pairs: DESIGN.md 4-5); durations from HIP events on the engine stream in an instrumented "
                 "repeat of the timed steps; traffic from profiles/pmc_*.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, "
                 "summed over the kernels of the pass)",
