@@ -13,6 +13,7 @@
 // The file is compiled by hipcc into the kernels and by g++ into the CPU math harness that the
 // non-GPU tests compare with the oracle (tests/native/).
 #pragma once
+#include <cstddef>
 #include <cmath>
 #include <cstdint>
 
@@ -58,6 +59,7 @@ struct CamTab {
   double pad[13];
 };
 static_assert(sizeof(CamTab) == 48 * sizeof(double), "CamTab must be 48 doubles");
+static_assert(offsetof(CamTab, pad) == 35 * sizeof(double), "35 live doubles (CAMTAB_LIVE in cba_kernels.h)");
 constexpr int CAMTAB_DOUBLES = 48;
 
 // x_cam: this camera's slice of the parameter vector (6 or 9 entries); cconst: cam_const row.

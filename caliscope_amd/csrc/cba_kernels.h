@@ -68,7 +68,8 @@ __device__ __forceinline__ void lds_add(double* addr, double v) { unsafeAtomicAd
 // LDS copy of the camera table.  Rows are padded to 49 doubles: with the natural stride of 48 doubles
 // (96 dwords == 32 mod 64 banks) the lanes of a wave, each reading the same field of a different camera,
 // would land on two bank pairs (32-way conflict); an odd stride spreads 32 cameras over all bank pairs.
-constexpr int CAMTAB_LDS = CAMTAB_DOUBLES + 1;
+constexpr int CAMTAB_LIVE = 35;               // doubles of a CamTab row in use (everything before the padding)
+constexpr int CAMTAB_LDS = CAMTAB_LIVE + 2;    // 37: the padding stays in HBM (49 doubles per camera cost k_build / k_tprep their third workgroup per CU)
 // The per-observation kernels walk their chunks with the NEXT chunk's observation record already in flight:
 // registers for (u, v, camera, point) of chunk n + 1 are loaded (unconditionally, index clamped) before chunk n is
 // processed, so each workgroup sees the streaming-load latency once instead of once per chunk.
@@ -81,8 +82,8 @@ __device__ __forceinline__ ObsRec load_obs(const double* __restrict__ obs_u, con
 }
 
 __device__ __forceinline__ void stage_camtab(double* sh_tab, const double* tab, int n_cams) {
-  for (int i = threadIdx.x; i < n_cams * CAMTAB_DOUBLES; i += BLOCK)
-    sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[i];
+  for (int i = threadIdx.x; i < n_cams * CAMTAB_LIVE; i += BLOCK)
+    sh_tab[(i / CAMTAB_LIVE) * CAMTAB_LDS + (i % CAMTAB_LIVE)] = tab[(i / CAMTAB_LIVE) * CAMTAB_DOUBLES + (i % CAMTAB_LIVE)];
 }
 __device__ __forceinline__ const CamTab& cam_at(const double* sh_tab, int cam) {
   return *reinterpret_cast<const CamTab*>(sh_tab + cam * CAMTAB_LDS);
@@ -672,11 +673,11 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
 
-  for (int i = threadIdx.x; i < na * CAMTAB_DOUBLES; i += SCHUR_BLOCK)
-    sh_tab[(i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)ca0 * CAMTAB_DOUBLES + i];
+  for (int i = threadIdx.x; i < na * CAMTAB_LIVE; i += SCHUR_BLOCK)
+    sh_tab[(i / CAMTAB_LIVE) * CAMTAB_LDS + (i % CAMTAB_LIVE)] = tab[(long)(ca0 + i / CAMTAB_LIVE) * CAMTAB_DOUBLES + (i % CAMTAB_LIVE)];
   if (!diag)
-    for (int i = threadIdx.x; i < nb * CAMTAB_DOUBLES; i += SCHUR_BLOCK)
-      sh_tab[(g + i / CAMTAB_DOUBLES) * CAMTAB_LDS + (i % CAMTAB_DOUBLES)] = tab[(long)cb0 * CAMTAB_DOUBLES + i];
+    for (int i = threadIdx.x; i < nb * CAMTAB_LIVE; i += SCHUR_BLOCK)
+      sh_tab[(g + i / CAMTAB_LIVE) * CAMTAB_LDS + (i % CAMTAB_LIVE)] = tab[(long)(cb0 + i / CAMTAB_LIVE) * CAMTAB_DOUBLES + (i % CAMTAB_LIVE)];
   for (int i = threadIdx.x; i < 2 * g; i += SCHUR_BLOCK) {
     int off = 0;
     if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }

@@ -951,7 +951,9 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (const char* sp = std::getenv("CBA_SPIN")) p->spin_wait = sp[0] != '0';
 
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;
+  int grid_mult = 2;  // persistent workgroups per CU of the per-observation kernels
+  if (const char* e = std::getenv("CBA_GRID_MULT")) grid_mult = std::max(1, std::atoi(e));
+  int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : grid_mult * cus;
   p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
   {
     int mult = 2;
