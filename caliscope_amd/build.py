@@ -38,7 +38,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return OUT
     cmd = [
         hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
-        "-Wall", "-Wno-unused-function", *map(str, SOURCES), "-o", str(OUT), "-pthread", "-lrccl",
+        "-Wall", "-Wno-unused-function", *map(str, SOURCES), "-o", str(OUT), "-pthread", "-lrccl", "-lrocprofiler-sdk-roctx",
     ]
     if verbose:
         print("[caliscope_amd.build]", " ".join(cmd), flush=True)

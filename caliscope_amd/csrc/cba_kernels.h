@@ -1586,6 +1586,24 @@ k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* 
   }
 }
 
+// Sharded solves exchange the reduced camera system: only the upper triangle of Sacc carries data, so the all-reduce moves
+// ncp (ncp + 1) / 2 + ncp doubles (0.59 MB for cfg4) instead of ncp^2 + ncp.  dir = 0 packs [triangle | b], dir = 1 unpacks.
+__global__ void __launch_bounds__(256)
+k_tri_pack(double* __restrict__ Sacc, double* __restrict__ tri, int ncp, int dir) {
+  const long ntri = (long)ncp * (ncp + 1) / 2;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < (long)ncp * ncp + ncp; t += (long)gridDim.x * 256) {
+    if (t >= (long)ncp * ncp) {  // b
+      const long k = t - (long)ncp * ncp;
+      if (dir == 0) tri[ntri + k] = Sacc[t]; else Sacc[t] = tri[ntri + k];
+      continue;
+    }
+    const int row = (int)(t / ncp), col = (int)(t % ncp);
+    if (col < row) continue;
+    const long q = (long)row * ncp - (long)row * (row - 1) / 2 + (col - row);
+    if (dir == 0) tri[q] = Sacc[t]; else Sacc[t] = tri[q];
+  }
+}
+
 // S = U + lam D_c^2 + cam_diag - Sacc (symmetric, both triangles written), rhs = -g_c + b
 template <int NC>
 __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,

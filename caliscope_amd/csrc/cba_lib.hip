@@ -23,6 +23,7 @@
 #include <vector>
 
 #include <rccl/rccl.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include "../../include/caliscope_ba.h"
 #include "cba_kernels.h"
@@ -98,6 +99,7 @@ struct cba_problem {
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   int det_m = 0;  // cba_options.deterministic: tasks per thread of the fixed-order camera sums (3, 5 or 8; 0: atomics)
   DetPlan det{nullptr, nullptr};
+  double* tri = nullptr;   // packed upper triangle of Sacc + b for the exchange of a sharded solve
   double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
@@ -209,6 +211,13 @@ static int dev_upload(cba_problem* p, T** out, const std::vector<T>& h) {
   if (!h.empty()) HIPCHK(guarded_memcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return CBA_OK;
 }
+
+// roctx range around the host-side enqueue of a phase: `rocprofv3 --marker-trace --kernel-trace` shows the kernels of an
+// iteration under build / linearize / schur / cholesky / backsub / trial (free when no profiler is attached)
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+  ~RoctxRange() { roctxRangePop(); }
+};
 
 struct ScopedTimer {
   cba_problem* p;
@@ -1046,6 +1055,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems)));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
+  TRY(dev_alloc(p, &p->tri, (size_t)ncp * (ncp + 1) / 2 + p->lay.ncp_pad));
   if (p->schur_reg && !p->eval_only) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
     TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * ((nct == 9) ? SchurRec<9>::REC : SchurRec<6>::REC)));
@@ -1161,6 +1171,7 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
 template <int NC>
 static int run_build_into(cba_problem* p, const double* xvec, const double* tab, double* V, double* g, double* Upacked, int cost_slot,
                           const double* skip = nullptr, bool defer_exchange = false, bool compact = false, int flag_slot = 0) {
+  RoctxRange range("cba:build");
   {
     ScopedTimer t(p, T_BUILD);
     if (p->n_heavy)  // fragments of heavy points add their sums by atomics
@@ -1234,6 +1245,7 @@ static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr) {
 // scale, scalars, ||J_h g_h||^2, the scalar exchange of a sharded solve
 template <int NC>
 static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = false, double radius = 0.0) {
+  RoctxRange range("cba:linearize");
   if (!p->have_build) {
     int rcb = run_build<NC>(p);
     if (rcb) return rcb;
@@ -1381,7 +1393,9 @@ static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false
 template <int NC>
 static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, bool compact = false) {
   const int ncp = p->ncp;
+  RoctxRange range("cba:damped_step");
   {
+    RoctxRange r2("cba:schur");
     ScopedTimer t(p, T_SCHUR);
     if (p->schur_reg) {
       auto launch_tprep = [&](auto kernel) {
@@ -1459,17 +1473,26 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     else
       hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
-    {
-      int rcs = allreduce_sum(p, p->Sacc, (size_t)ncp * ncp + ncp);  // reduced camera system: the one real exchange step
+    if (p->sharded()) {  // reduced camera system: the one real exchange step — upper triangle and b, packed
+      const size_t ntri = (size_t)ncp * (ncp + 1) / 2 + ncp;
+      const int tg = (int)std::min<size_t>(((size_t)ncp * ncp + ncp + 255) / 256, 1024);
+      hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 0);
+      int rcs = allreduce_sum(p, p->tri, ntri);
       if (rcs) return rcs;
+      hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 1);
     }
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
                        p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw);
   }
-  int rc = run_cholesky(p);
+  int rc;
+  {
+    RoctxRange r2("cba:cholesky");
+    rc = run_cholesky(p);
+  }
   if (rc) return rc;
   {
+    RoctxRange r2("cba:backsub");
     ScopedTimer t(p, T_BACKSUB);
     if (p->n_heavy)  // fragments add sum_i W_i^T dc of a heavy point into s by atomics; k_heavy_finish solves for dp
       hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay,
@@ -1510,6 +1533,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
 // point evaluated by a full build pass into the second set of buffers, so that accepting it costs nothing more.
 template <int NC>
 static int run_step(cba_problem* p, double radius, cba_step_info* out) {
+  RoctxRange range("cba:step");  // one fused trust-region iteration
   // single rank: no exchange steps in between, so neighbouring small kernels are folded together (k_scale_lin, k_lin_finish,
   // k_step_finish, gradient written by k_reduce_rows, last sums taken by k_publish): 8 launches fewer per iteration
   const bool compact = !p->sharded();
