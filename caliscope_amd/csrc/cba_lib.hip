@@ -28,6 +28,7 @@
 #include "../../include/caliscope_ba.h"
 #include "cba_kernels.h"
 #include "schur_plan.h"
+#include "host_plan.h"
 
 using namespace cba;
 
@@ -454,50 +455,8 @@ const char* cba_timer_name(int32_t i) { return (i >= 0 && i < T_COUNT) ? kTimerN
 
 int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
                       int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out) {
-  if (n_points < 0 || n_obs < 0 || chunk_cap <= 0 || (n_obs > 0 && !obs_pt)) return fail(CBA_ERR_INVALID, "cba_host_plan: bad arguments");
-  // optional first key: camera (stable counting sort), so that the final order is (point, camera, input order)
-  std::vector<int64_t> by_cam;
-  if (obs_cam && n_cams > 0) {
-    std::vector<int64_t> cc((size_t)n_cams + 1, 0);
-    for (int64_t i = 0; i < n_obs; ++i) {
-      if (obs_cam[i] < 0 || obs_cam[i] >= n_cams) return fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, obs_cam[i]);
-      cc[obs_cam[i] + 1]++;
-    }
-    for (int32_t c = 0; c < n_cams; ++c) cc[c + 1] += cc[c];
-    by_cam.resize((size_t)n_obs);
-    for (int64_t i = 0; i < n_obs; ++i) by_cam[cc[obs_cam[i]]++] = i;
-  }
-  std::vector<int64_t> count((size_t)n_points + 1, 0);
-  for (int64_t i = 0; i < n_obs; ++i) {
-    const int32_t p = obs_pt[i];
-    if (p < 0 || p >= n_points) return fail(CBA_ERR_INVALID, "observation %lld: world-point index %d out of range", (long long)i, p);
-    count[p + 1]++;
-  }
-  for (int32_t p = 0; p < n_points; ++p) count[p + 1] += count[p];
-  for (int32_t p = 0; p <= n_points; ++p) pt_start_out[p] = count[p];
-  std::vector<int64_t> cursor(count.begin(), count.end() - 1);
-  for (int64_t q = 0; q < n_obs; ++q) {  // stable counting sort by point
-    const int64_t i = by_cam.empty() ? q : by_cam[q];
-    order_out[cursor[obs_pt[i]]++] = i;
-  }
-  int64_t n_chunks = 0;
-  int64_t start = 0;
-  chunk_start_out[0] = 0;
-  for (int32_t p = 0; p < n_points; ++p) {
-    const int64_t begin = pt_start_out[p], end = pt_start_out[p + 1];
-    if (end - begin > chunk_cap) {
-      // a point that does not fit one chunk gets chunks of its own ("fragments" of at most chunk_cap observations)
-      if (begin > start) chunk_start_out[++n_chunks] = begin;
-      for (int64_t o = begin + chunk_cap; o < end; o += chunk_cap) chunk_start_out[++n_chunks] = o;
-      chunk_start_out[++n_chunks] = end;
-      start = end;
-    } else if (end - start > chunk_cap) {  // close the chunk before this point
-      chunk_start_out[++n_chunks] = begin;
-      start = begin;
-    }
-  }
-  if (n_obs > start) chunk_start_out[++n_chunks] = n_obs;
-  return n_chunks;
+  return host_plan_impl([](int code, const char* fmt, auto... args) { return fail(code, fmt, args...); }, n_points, n_obs, obs_pt, obs_cam, n_cams, chunk_cap,
+                        order_out, pt_start_out, chunk_start_out);
 }
 
 void cba_destroy(cba_problem* p) {

@@ -1,8 +1,11 @@
 // Test double of the device engine: the primitives cba_solve drives (include/caliscope_ba.h), implemented for a small
-// DENSE least-squares problem whose residuals and Jacobian come from the test through callbacks.  It lets the CPU
-// suite run csrc/cba_solve.cpp (compiled by g++ together with this file) without a GPU; linear loss only.
+// DENSE least-squares problem.  The (robust-scaled) residual rows, their Jacobian and the cost come from a pluggable model:
+// callbacks of the test (de_create: linear loss, cost = 0.5 |f|^2) or the bundle-adjustment model of cpu_library.cpp, which
+// includes this file and adds the rest of the C ABI.  It lets the CPU suite run csrc/cba_solve.cpp (compiled by g++ together
+// with this file) without a GPU.
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -12,30 +15,33 @@
 typedef void (*fun_cb)(const double* x, double* r);
 typedef void (*jac_cb)(const double* x, double* J);  // row-major m x n
 
+struct BaModel;  // cpu_library.cpp
 struct cba_problem {
   int m = 0, n = 0, ncp = 0;
-  fun_cb fun = nullptr;
-  jac_cb jac = nullptr;
+  std::function<double(const double* x, double* f)> fun;   // fills the scaled residual rows, returns the cost 0.5 sum rho
+  std::function<void(const double* x, double* J)> jac;     // scaled rows, row-major m x n
   std::vector<double> x0, x, x_new, f, f_new, J, g, s, sinv, sinv_state, cam_diag;
+  double cost = 0.0, cost_new = 0.0, last_lam = 0.0;
   bool first_scale = true, cam_scaled = false;
+  BaModel* model = nullptr;
 };
 
 static thread_local std::string g_err;
 
-static double cost_of(const std::vector<double>& f) {
-  double c = 0.0;
-  for (double v : f) c += v * v;
-  return 0.5 * c;
-}
-
 extern "C" {
 
+static void de_size(cba_problem* p, int m, int n, int ncp);
 cba_problem* de_create(int m, int n, int ncp, fun_cb fun, jac_cb jac) {
   cba_problem* p = new cba_problem;
-  p->m = m; p->n = n; p->ncp = ncp; p->fun = fun; p->jac = jac;
+  p->fun = [fun, m](const double* x, double* f) { fun(x, f); double c = 0.0; for (int i = 0; i < m; ++i) c += f[i] * f[i]; return 0.5 * c; };
+  p->jac = [jac](const double* x, double* J) { jac(x, J); };
+  de_size(p, m, n, ncp);
+  return p;
+}
+static void de_size(cba_problem* p, int m, int n, int ncp) {
+  p->m = m; p->n = n; p->ncp = ncp;
   p->x0.assign(n, 0.0); p->x.assign(n, 0.0); p->x_new.assign(n, 0.0); p->f.assign(m, 0.0); p->f_new.assign(m, 0.0);
   p->J.assign((size_t)m * n, 0.0); p->g.assign(n, 0.0); p->s.assign(n, 0.0); p->sinv.assign(n, 1.0); p->sinv_state.assign(n, 1.0); p->cam_diag.assign(n, 0.0);
-  return p;
 }
 void de_destroy(cba_problem* p) { delete p; }
 
@@ -48,18 +54,20 @@ int de_real_roots(const double* c, int n_coef, double* out) { return trf::real_r
 int cba_set_error(int32_t code, const char* message) { g_err = message ? message : ""; return code; }
 const char* cba_last_error(void) { return g_err.c_str(); }
 
+#ifndef CBA_CPU_LIBRARY  // cpu_library.cpp has its own
 int cba_get_info(cba_problem* p, cba_info* out) {
   std::memset(out, 0, sizeof(*out));
   out->n_params = p->n; out->n_cam_params = p->ncp;
   return CBA_OK;
 }
+#endif
 
 static int begin_common(cba_problem* p, double* cost_out) {
   p->x = p->x0;
-  p->fun(p->x.data(), p->f.data());
+  p->cost = p->fun(p->x.data(), p->f.data());
   p->first_scale = true; p->cam_scaled = false;
   p->cam_diag.assign(p->n, 0.0);
-  *cost_out = cost_of(p->f);
+  *cost_out = p->cost;
   return CBA_OK;
 }
 int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
@@ -90,7 +98,7 @@ static void lin_scalars(cba_problem* p, int max_from, cba_linearization* out) {
     jg_sq += r * r;
   }
   out->g_norm_inf = ginf; out->gh_sq = gh_sq; out->jg_sq = jg_sq; out->x_scaled_norm = std::sqrt(xs); out->x_norm = std::sqrt(xn);
-  out->cost = cost_of(p->f);
+  out->cost = p->cost;
 }
 
 int cba_linearize(cba_problem* p, cba_linearization* out) {
@@ -124,6 +132,7 @@ int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* dia
 
 int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
   const int m = p->m, n = p->n;
+  p->last_lam = lam;
   std::vector<double> A((size_t)n * n, 0.0), b(n);
   for (int a = 0; a < n; ++a) {
     for (int c = a; c < n; ++c) {
@@ -186,8 +195,8 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
     if (cam_x_new && j < p->ncp) { p->x_new[j] = cam_x_new[j]; step = p->x_new[j] - p->x[j]; }
     sn += step * step;
   }
-  p->fun(p->x_new.data(), p->f_new.data());
-  out->cost = cost_of(p->f_new); out->step_norm = std::sqrt(sn); out->finite = std::isfinite(out->cost) ? 1 : 0; out->reserved = 0;
+  p->cost_new = p->fun(p->x_new.data(), p->f_new.data());
+  out->cost = p->cost_new; out->step_norm = std::sqrt(sn); out->finite = std::isfinite(out->cost) ? 1 : 0; out->reserved = 0;
   if (!out->finite) out->cost = NAN;
   return CBA_OK;
 }
@@ -231,7 +240,7 @@ int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
   return CBA_OK;
 }
 
-int cba_accept(cba_problem* p) { p->x = p->x_new; p->f = p->f_new; return CBA_OK; }
+int cba_accept(cba_problem* p) { p->x = p->x_new; p->f = p->f_new; p->cost = p->cost_new; return CBA_OK; }
 
 static const std::vector<double>& vec_of(cba_problem* p, int32_t which) {
   return which == CBA_VEC_X ? p->x : which == CBA_VEC_X_NEW ? p->x_new : which == CBA_VEC_GRAD ? p->g : which == CBA_VEC_STEP ? p->s : p->sinv;
