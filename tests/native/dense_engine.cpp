@@ -3,6 +3,7 @@
 // callbacks of the test (de_create: linear loss, cost = 0.5 |f|^2) or the bundle-adjustment model of cpu_library.cpp, which
 // includes this file and adds the rest of the C ABI.  It lets the CPU suite run csrc/cba_solve.cpp (compiled by g++ together
 // with this file) without a GPU.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -130,34 +131,48 @@ int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* dia
   return CBA_OK;
 }
 
+// Damped normal equations (J^T J + lam D^2 + cam_diag) s = -g by an envelope ("skyline") Cholesky in REVERSED parameter order:
+// bundle-adjustment rows touch one camera and a few points, so with the points first the factor of the arrow matrix has no
+// fill outside the camera rows and a few-thousand-parameter session factors in milliseconds; a dense test problem simply has a
+// full envelope.  The rows of J are scanned for their nonzeros once.
 int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
   const int m = p->m, n = p->n;
   p->last_lam = lam;
   std::vector<double> A((size_t)n * n, 0.0), b(n);
-  for (int a = 0; a < n; ++a) {
-    for (int c = a; c < n; ++c) {
-      double v = 0.0;
-      for (int i = 0; i < m; ++i) v += p->J[(size_t)i * n + a] * p->J[(size_t)i * n + c];
-      A[(size_t)c * n + a] = v;  // lower triangle
+  std::vector<int> first(n), nz;
+  for (int a = 0; a < n; ++a) first[a] = a;
+  auto q = [n](int j) { return n - 1 - j; };  // position of parameter j in the factorisation order
+  for (int i = 0; i < m; ++i) {
+    const double* row = &p->J[(size_t)i * n];
+    nz.clear();
+    for (int j = n - 1; j >= 0; --j) if (row[j] != 0.0) nz.push_back(j);  // q() ascending
+    for (size_t u = 0; u < nz.size(); ++u) {
+      const int r = q(nz[u]);
+      first[r] = std::min(first[r], q(nz[0]));
+      for (size_t v = 0; v <= u; ++v) A[(size_t)r * n + q(nz[v])] += row[nz[u]] * row[nz[v]];
     }
-    A[(size_t)a * n + a] += lam * p->sinv[a] * p->sinv[a] + p->cam_diag[a];
-    b[a] = -p->g[a];
+  }
+  for (int a = 0; a < n; ++a) {
+    A[(size_t)q(a) * n + q(a)] += lam * p->sinv[a] * p->sinv[a] + p->cam_diag[a];
+    b[q(a)] = -p->g[a];
   }
   out->ok = 1; out->reserved = 0;
-  for (int j = 0; j < n; ++j) {  // Cholesky, lower
-    double d = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(d > 0.0)) { out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
-    d = std::sqrt(d);
-    A[(size_t)j * n + j] = d;
-    for (int i = j + 1; i < n; ++i) {
-      double v = A[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-      A[(size_t)i * n + j] = v / d;
+  for (int i = 0; i < n; ++i) {  // row-oriented Cholesky inside the envelope
+    double* Li = &A[(size_t)i * n];
+    for (int j = first[i]; j <= i; ++j) {
+      const double* Lj = &A[(size_t)j * n];
+      double v = Li[j];
+      for (int k = std::max(first[i], first[j]); k < j; ++k) v -= Li[k] * Lj[k];
+      if (j < i) Li[j] = v / Lj[j];
+      else {
+        if (!(v > 0.0)) { out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
+        Li[i] = std::sqrt(v);
+      }
     }
   }
-  for (int i = 0; i < n; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
-  for (int i = n - 1; i >= 0; --i) { double v = b[i]; for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
+  for (int i = 0; i < n; ++i) { double v = b[i]; for (int k = first[i]; k < i; ++k) v -= A[(size_t)i * n + k] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { b[i] /= A[(size_t)i * n + i]; for (int k = first[i]; k < i; ++k) b[k] -= A[(size_t)i * n + k] * b[i]; }
+  for (int a = 0; a < n / 2; ++a) std::swap(b[a], b[q(a)]);  // back to parameter order
   p->s = b;
   double p_sq = 0.0, ghp = 0.0, gh_sq = 0.0;
   for (int j = 0; j < n; ++j) { const double pj = b[j] * p->sinv[j], gh = p->g[j] / p->sinv[j]; p_sq += pj * pj; ghp += gh * pj; gh_sq += gh * gh; }

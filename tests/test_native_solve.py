@@ -101,7 +101,9 @@ def test_native_driver_on_classic_problems(native):
 
     rosen = (lambda x: np.array([10.0 * (x[1] - x[0] ** 2), 1.0 - x[0]]), lambda x: np.array([[-20.0 * x[0], 10.0], [-1.0, 0.0]]))
     res, x, evals = _solve(native, *rosen, np.array([-1.2, 1.0]), 2)
-    assert res.status > 0 and np.allclose(x, [1.0, 1.0], atol=1e-6) and res.nfev == len(evals)
+    # the fused iteration evaluates its first trial before the host sees the gradient: when that iteration ends on gtol the
+    # trial is discarded and — like scipy, which never makes it — not counted
+    assert res.status > 0 and np.allclose(x, [1.0, 1.0], atol=1e-6) and len(evals) - res.nfev in (0, 1)
     t = np.linspace(0, 4, 30)
     y = 2.5 * np.exp(-1.3 * t) + 0.5 + 0.01 * np.cos(37 * t)
     fit = (lambda p: p[0] * np.exp(p[1] * t) + p[2] - y, lambda p: np.stack([np.exp(p[1] * t), p[0] * t * np.exp(p[1] * t), np.ones_like(t)], axis=1))
