@@ -823,7 +823,11 @@ template <int NC> struct SchurRec {
   static constexpr int NPH = (NVAL + 1) / 2;              // 16-byte pieces that carry data: 6 / 11
   static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride, 16-byte pieces, odd: 7 / 11 (LDS bank spread; the same
                                                           // stride in HBM lets k_schur_reg3 load records straight into LDS)
-  static constexpr int REC = 2 * LST;                     // record stride, doubles: 14 / 22
+  static constexpr int REC = 2 * LST;                     // record stride in LDS, doubles: 14 / 22
+  // record stride in HBM, doubles.  NC = 6: 16, one 128-byte line per record (at 112 bytes seven of eight records straddle two lines, and the
+  // pair kernel's gather is bound by the lines an instruction touches: 17 instead of 10 per load of 64 pieces)
+  static constexpr int HREC = (NC == 6) ? 16 : REC;
+  static constexpr int STAGE = (HREC / 2) | 1;            // k_tprep's transposing LDS stage: record stride in pieces, odd (bank spread)
 };
 static_assert(SchurRec<6>::REC == 14 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");
 
@@ -854,12 +858,12 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         int n_cams, int loss, double f_scale, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
         double* __restrict__ partial_b, int* __restrict__ flags, DetPlan det = DetPlan{nullptr, nullptr}) {
-  constexpr int REC = SchurRec<NC>::REC, NP = REC / 2;
+  constexpr int REC = SchurRec<NC>::HREC, NP = REC / 2, SP = SchurRec<NC>::STAGE;  // the records as they lie in HBM
   constexpr bool DET = DETM > 0;
   if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam)
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double2* sh_stage = reinterpret_cast<double2*>(sh);        // [BLOCK / WAVE][WAVE * NP]  record transpose, per wave
-  double* sh_tab = sh + (size_t)BLOCK * REC;
+  double2* sh_stage = reinterpret_cast<double2*>(sh);        // [BLOCK / WAVE][WAVE * SP]  record transpose, per wave
+  double* sh_tab = sh + (size_t)BLOCK * SP * 2;
   double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad (DET: the parking area of det_round, then the chunk's camera order)
   int* sh_perm = reinterpret_cast<int*>(sh_b + DET_ROUND * DET_LD);
   int* sh_cs = sh_perm + CHUNK;
@@ -875,7 +879,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
   const int wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  double2* stage = sh_stage + wv * WAVE * NP;
+  double2* stage = sh_stage + wv * WAVE * SP;
   bool fail = false;
   const int last_obs = max(chunk_start[n_chunks] - 1, 0);
   int ch = blockIdx.x;
@@ -941,7 +945,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     // record apart (64 cache lines per instruction: the store path stalled, 45 % issue-stall cycles); so the wave transposes
     // through LDS and every store instruction writes 1 KB contiguous.
 #pragma unroll
-    for (int k = 0; k < NP; ++k) stage[lane * NP + k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+    for (int k = 0; k < NP; ++k) stage[lane * SP + k] = make_double2(rec[2 * k], rec[2 * k + 1]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -951,7 +955,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const int e = k * WAVE + lane;
-      const double2 v = stage[e];
+      const double2 v = stage[(e / NP) * SP + e % NP];
       if (e < n_pieces) dst[e] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -998,6 +1002,7 @@ template <int NC> struct Reg2Cfg {
   static constexpr int REC = SchurRec<NC>::REC, NPH = SchurRec<NC>::NPH, LST = SchurRec<NC>::LST;
   static constexpr int SPLIT = (NC == 9) ? 3 : 1;
   static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;
+  static constexpr int CODE_THREADS = BLOCK, CODE_WAVES = BLOCK / WAVE, GROUP = 16, PAIR_CAP = 0;
   // slots (records) per chunk: 512 x 7 pieces = 56 KB (two workgroups per CU) / 384 x 11 pieces = 66 KB (one 12-wave workgroup;
   // its 168-register budget leaves room for six staging registers per thread, not eleven)
   static constexpr int SCHUNK = (NC == 9) ? 384 : 512;
@@ -1132,7 +1137,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     slot_piece(k, el, piece);
     const bool useB = EPW > WAVE && k * WAVE >= WAVE * NPH;  // slots >= 64: the second index register
     const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * REC)[piece];
+    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC)[piece];
   };
   auto pair = [&](unsigned code) {
     const double2* Ri = sh_p + (code & 0xffffu);
@@ -1260,88 +1265,149 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 // straight from HBM into LDS (global_load_lds_dwordx4: 64 lanes, 64 consecutive 16-byte pieces of LDS, any global addresses)
 // into the buffer that is NOT being read (two buffers of half the size), so a trip is: wait for the loads issued a trip ago,
 // one barrier, issue the next chunk's loads, multiply.  No staging registers (the 168-register NC = 9 kernel no longer spills).
-template <int NC> struct Reg3Cfg {
+// WIDE (NC = 6, more than 16 cameras): a workgroup owns a 32 x 32 camera tile, so a record is gathered by half as many tiles
+// (cfg4: 2 instead of 4 — the kernel's time follows the bytes it gathers, 5.3).  1024 threads with a block each would have 128
+// registers (the 36 accumulators and one pair in flight need ~176: it spilled); so 512 threads own TWO blocks each: the plan is
+// made for 16 "virtual" waves of 64 blocks, physical wave w runs the pair codes of virtual waves w and w + 8 one after the other
+// into two sets of accumulators.  One workgroup per CU (8 waves, as two narrow workgroups), every wave loads 64 slots of a
+// 512-slot chunk: seven full load instructions.
+template <int NC, bool WIDE = false> struct Reg3Cfg {
+  static_assert(!WIDE || NC == 6, "the wide tile is the one-thread-per-block kernel");
   static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
   static constexpr int SPLIT = (NC == 9) ? 3 : 1;
-  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;
-  static constexpr int SCHUNK = (NC == 9) ? 384 : 320;                             // slots per chunk (per LDS buffer)
-  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots loaded by one wave (80 / 32)
-  static constexpr int NLD = (EPW * LST + WAVE - 1) / WAVE;                        // load instructions per wave and chunk (9 / 6)
+  static constexpr int VB = WIDE ? 2 : 1;                                          // blocks per thread
+  static constexpr int PHYS_THREADS = WIDE ? 2 * BLOCK : BLOCK;                    // threads that own blocks (x SPLIT row parts)
+  static constexpr int CODE_THREADS = PHYS_THREADS * VB;                           // blocks of a tile = pair-code streams
+  static constexpr int REG_BLOCK = PHYS_THREADS * SPLIT, NWAVES = REG_BLOCK / WAVE, CODE_WAVES = CODE_THREADS / WAVE;
+  static constexpr int GROUP = WIDE ? 32 : 16;                                     // cameras per group: GROUP^2 blocks <= CODE_THREADS
+  // pair codes per block and chunk that travel in registers (a code beyond them is loaded inside the pair loop: a vmcnt(0) behind the record loads
+  // in flight).  The wide kernel's register file is full at two; its plan caps the pairs of a block per chunk there and opens more chunks instead.
+  static constexpr int NCD = WIDE ? 2 : (NC == 6) ? 8 : 4;
+  static constexpr int PAIR_CAP = WIDE ? NCD : 0;
+  static constexpr int SCHUNK = WIDE ? 512 : (NC == 9) ? 384 : 320;                // slots per chunk (per LDS buffer)
+  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots loaded by one wave (80 / 32; wide: 64)
+  static constexpr int NLD = (EPW * LST + WAVE - 1) / WAVE;                        // load instructions per wave and chunk (9 / 6; wide: 7)
   static constexpr int WAVE_PIECES = NLD * WAVE;                                   // LDS pieces of one wave's run, padded to whole loads
   static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // all-zero record behind the chunk, in each buffer
   static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                          // (+1: keeps the second buffer 32-byte aligned)
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF_PIECES * 16;
   static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
   static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
+  static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
 };
 
-template <int NC, int SPLIT, int MINW>
-__global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
-k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial) {
-  using Cfg = Reg3Cfg<NC>;
+// The body is a function of its own with `Trec` as a __restrict__ PARAMETER: inlined into the kernel, every access in it carries
+// alias-scope metadata, and only with that does the compiler's wait-count insertion let a ds_read pass a pending LDS-DMA load (with
+// the body written directly in the kernel it put a vmcnt(0) in front of the first record read of every trip: the wave sat out the
+// gather it had just issued).
+// CLK (profiling build, CBA_SCHUR_CLOCK=1): per wave the shader clocks spent waiting for loads, in the barrier, issuing and multiplying.
+template <int NC, int SPLIT, bool WIDE, bool CLK = false>
+__device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
+                                                const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
+                                                const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr) {
+  using Cfg = Reg3Cfg<NC, WIDE>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
+  constexpr int VB = Cfg::VB, PT = Cfg::PHYS_THREADS, PW = PT / WAVE, NWORD = Cfg::CODE_WAVES / 4;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
-  constexpr int NCD = 4;                        // codes of a chunk that travel in registers
-  extern __shared__ __attribute__((aligned(16))) double sh[];
+  constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
   double2* sh_p = reinterpret_cast<double2*>(sh);  // two chunk buffers, in 16-byte pieces
 
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
   const int tid = (int)threadIdx.x;
-  const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
-  const int cw = ct / WAVE, lane = ct % WAVE;
+  const int ct = tid % PT;                      // code thread: the SPLIT parts of a block multiply the same pairs
+  const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
   const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave
-  const int blk = (rep > 1) ? tid % nblk : ct;
-  const int slot = (rep > 1) ? tid / nblk : 0, half = (rep > 1) ? 0 : tid / BLOCK;
+  const int half = (rep > 1) ? 0 : tid / PT;
   const int r0 = half * RH;
-  double acc[RH][NC];
+  double acc[VB][RH][NC];
 #pragma unroll
-  for (int r = 0; r < RH; ++r)
+  for (int v = 0; v < VB; ++v)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+    for (int r = 0; r < RH; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[v][r][c] = 0.0;
 
+  // block v of this thread: virtual thread vt = v * PT + ct of the plan; rep > 1: vt = slot * nblk + block
+  auto out_of = [&](int v, bool* owner) -> double* {
+    const int vt = (SPLIT == 1) ? v * PT + tid : ct;
+    const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
+    *owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
+    return partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
+  };
   const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
-  double* dst = partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
   if (first >= ch_end) {  // more workgroups than chunks in this range
-    if (slot < rep) {
 #pragma unroll
-      for (int k = 0; k < RH * NC; ++k)
-        if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+    for (int v = 0; v < VB; ++v) {
+      bool owner;
+      double* dst = out_of(v, &owner);
+      if (owner) {
+#pragma unroll
+        for (int k = 0; k < RH * NC; ++k)
+          if (r0 * NC + k < NC * NC) dst[k] = 0.0;
+      }
     }
     return;
   }
   for (int k = tid; k < 2 * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
   const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
-  const unsigned zero_code = (unsigned)Cfg::ZERO_PIECE | ((unsigned)Cfg::ZERO_PIECE << 16);
-
-  int idxA = 0, idxB = 0;
-  unsigned cd[NCD];
+  // Per trip every wave issues, in this order and WITHOUT waiting in between: the codes of the next chunk and the record indices
+  // of the chunk after next (their addresses come from the iteration counts / offsets loaded a trip earlier), the counts and
+  // offsets of the chunks behind those, the records of the next chunk; then it multiplies the current chunk while all of that
+  // is in flight.  (Until round 2's last revision addresses were computed from values loaded in the same trip: the wait for them
+  // was a vmcnt(0) behind the record loads, i.e. every wave sat out its own gather before it multiplied; only the second
+  // workgroup of the CU overlapped.)
+  struct Raw { unsigned nit[NWORD]; int code_start; int obs_start; };  // counts / code offset of one chunk, stream offset of its successor
+  auto load_raw = [&](int chunk, int successor) {
+    Raw r;
 #pragma unroll
-  for (int k = 0; k < NCD; ++k) cd[k] = zero_code;
-  int n_nx = 0;
-  long code_nx = 0;
-  auto load_indices = [&](int chunk) {
-    const int* src = tp.obs + tp.chunk_start[chunk] + sw * EPW;
-    idxA = src[lane];
-    if (EPW > WAVE) idxB = src[WAVE + (lane & (EPW - WAVE - 1))];
+    for (int q = 0; q < NWORD; ++q) r.nit[q] = p_nit[(long)chunk * NWORD + q];
+    r.code_start = p_code_start[chunk];
+    r.obs_start = p_chunk_start[successor];
+    return r;
+  };
+  auto load_indices = [&](int obs_start, int* iA, int* iB) {
+    const int* src = p_obs + obs_start + sw * EPW;
+    *iA = src[lane];
+    if (EPW > WAVE) *iB = src[WAVE + (lane & (EPW - WAVE - 1))];
   };
   static_assert(EPW <= WAVE || ((EPW - WAVE) & (EPW - WAVE - 1)) == 0, "second index register");
-  auto load_codes = [&](int chunk) {
-    const unsigned packed = tp.nit[chunk];
-    int pre = 0;
+  unsigned cd[VB][NCD];
+  int n_nx[VB];
+  long code_nx[VB];
+  auto load_codes = [&](const Raw& r) {
+    int pre[VB], mine[VB];
 #pragma unroll
-    for (int w = 0; w < 3; ++w) pre += (w < cw) ? (int)((packed >> (8 * w)) & 0xffu) : 0;
-    n_nx = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * cw)) & 0xffu));
-    code_nx = (long)tp.code_start[chunk] + (long)pre * WAVE + lane;
+    for (int v = 0; v < VB; ++v) { pre[v] = 0; mine[v] = 0; }
 #pragma unroll
-    for (int k = 0; k < NCD; ++k) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+    for (int q = 0; q < NWORD; ++q) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int n = (int)((r.nit[q] >> (8 * w)) & 0xffu);
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {  // virtual wave of block v: v * PW + pw
+          pre[v] += (4 * q + w < v * PW + pw) ? n : 0;
+          mine[v] = (4 * q + w == v * PW + pw) ? n : mine[v];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      n_nx[v] = __builtin_amdgcn_readfirstlane(mine[v]);
+      code_nx[v] = (long)r.code_start + (long)pre[v] * WAVE + lane;
+#pragma unroll
+      for (int k = 0; k < NCD; ++k) cd[v][k] = p_codes[code_nx[v] + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+    }
   };
   // load k of this wave fills LDS pieces [k * 64, k * 64 + 64) of the wave's run: piece (k * 64 + lane) % LST of slot
   // (k * 64 + lane) / LST; the record index of the slot comes from the wave's index registers (ds_bpermute)
-  auto issue = [&](int buf) {
+  auto issue = [&](int buf, int idxA, int idxB) {
     constexpr int Q = WAVE / LST, RM = WAVE % LST;
     double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
+    // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
+    // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
+    const double2* g[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       int piece = k * RM + lane % LST;
@@ -1350,12 +1416,14 @@ k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
       el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
       const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
       const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-      const double2* g = reinterpret_cast<const double2*>(Trec + (long)idx * REC) + piece;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
-                                       (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
+      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + piece;
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
   };
-  auto pair = [&](const double2* bufp, unsigned code) {
+  auto pair = [&](double (&A)[RH][NC], const double2* bufp, unsigned code) {
     const double2* Ri = bufp + (code & 0xffffu);
     const double2* Rj = bufp + (code >> 16);
     if constexpr (NC == 6) {
@@ -1376,10 +1444,10 @@ k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        acc[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], acc[0][c]));
-        acc[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], acc[1][c]));
-        acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
-        acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
+        A[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], A[0][c]));
+        A[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], A[1][c]));
+        A[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], A[2][c]));
+        A[3][c] += M[0][c]; A[4][c] += M[1][c]; A[5][c] += M[2][c];
       }
     } else {
       double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
@@ -1391,44 +1459,116 @@ k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
         Yi[0] = i0.x; Yi[1] = i0.y; Yi[2] = i1.x;
         Rm[0] = i1.y; Rm[1] = i2.x; Rm[2] = i2.y; Rm[3] = i3.x; Rm[4] = i3.y; Rm[5] = i4.x; Rm[6] = i4.y; Rm[7] = i5.x; Rm[8] = i5.y;
       }
-      if (half == 0) pair_rows<NC, true>(acc, Rm, Yi, Rj);
-      else pair_rows<NC, false>(acc, Rm, Yi, Rj);
+      if (half == 0) pair_rows<NC, true>(A, Rm, Yi, Rj);
+      else pair_rows<NC, false>(A, Rm, Yi, Rj);
     }
   };
 
-  load_indices(first);
-  issue(0);
-  load_codes(first);
-  load_indices(min(first + stride, last));
+  long long clk_sum[6] = {0, 0, 0, 0, 0, 0};
+  const long long t_start = CLK ? clock64() : 0;
+  int idxA = 0, idxB = 0;
+  const int second = min(first + stride, last);
+  Raw raw = load_raw(first, second);
+  load_indices(p_chunk_start[first], &idxA, &idxB);
+  issue(0, idxA, idxB);
+  load_codes(raw);                           // the first chunk's codes
+  load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
+  raw = load_raw(second, min(second + stride, last));
   int buf = 0;
   for (int cur = first; cur < ch_end; cur += stride) {
-    unsigned cc[NCD];
-#pragma unroll
-    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
-    const int n_cur = n_nx;
-    const long code_cur = code_nx;
-    // the loads into `buf` (issued a trip ago) have landed, and every wave is done reading the other buffer
+    // everything issued a trip ago has landed (the records of `cur` in `buf`, its codes, the counts and indices of the next
+    // chunk), and every wave is done reading the other buffer
+    long long tA = 0, tB = 0, tC = 0, tD = 0;
+    if (CLK) tA = clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int nxt = min(cur + stride, last);
-    issue(buf ^ 1);                         // idxA / idxB hold nxt's indices
-    load_codes(nxt);
-    load_indices(min(nxt + stride, last));
-    __builtin_amdgcn_sched_barrier(0);
-    const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
+    if (CLK) tB = clock64();
+    // The values loaded a trip ago pass through an empty asm: to the compiler they are no longer results of loads that are
+    // still pending (it cannot see the wait above, and for registers whose load sits behind the loop's back edge it inserted
+    // its own vmcnt(0) at their first use — in the middle of the pair loop, behind the record loads just issued).
 #pragma unroll
-    for (int it = 0; it < NCD; ++it)
-      if (it < n_cur) pair(bufp, cc[it]);
-    for (int it = NCD; it < n_cur; ++it) pair(bufp, tp.codes[code_cur + (long)it * WAVE]);  // rare: more than four pairs of one block in a chunk
+    for (int v = 0; v < VB; ++v)
+#pragma unroll
+      for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[v][k]));
+    // (raw is wave-uniform: left alone the compiler moves it to SGPRs right behind its load — v_readfirstlane, i.e. a wait in the
+    // middle of the issue sequence; scalar loads are not used inside the loop, the LDS-DMA intrinsic counts as a clobber)
+#pragma unroll
+    for (int q = 0; q < NWORD; ++q) asm volatile("" : "+v"(raw.nit[q]));
+    asm volatile("" : "+v"(raw.code_start));
+    asm volatile("" : "+v"(raw.obs_start));
+    asm volatile("" : "+v"(idxA));
+    if (EPW > WAVE) asm volatile("" : "+v"(idxB));
+    __syncthreads();
+    if (CLK) tC = clock64();
+    unsigned cc[VB][NCD];
+    int n_cur[VB];
+    long code_cur[VB];
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+#pragma unroll
+      for (int k = 0; k < NCD; ++k) cc[v][k] = cd[v][k];
+      n_cur[v] = n_nx[v];
+      code_cur[v] = code_nx[v];
+    }
+    const int nxt2 = min(min(cur + stride, last) + stride, last);
+    load_codes(raw);                        // codes of the next chunk: addresses from registers, no wait
+    int idxA_n = 0, idxB_n = 0;
+    load_indices(raw.obs_start, &idxA_n, &idxB_n);  // indices of the chunk after next
+    const Raw raw_n = load_raw(nxt2, min(nxt2 + stride, last));
+    issue(buf ^ 1, idxA, idxB);             // records of the next chunk
+    __builtin_amdgcn_sched_barrier(0);
+    if (CLK) { tD = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
+    // (reading the records of pair it + 1 while pair it is multiplied — there would be registers for it in the narrow NC = 6 kernel — measured
+    // slower: 112k instead of 98k clocks per wave in the pair phase)
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+#pragma unroll
+      for (int it = 0; it < NCD; ++it)
+        if (it < n_cur[v]) pair(acc[v], bufp, cc[v][it]);
+      for (int it = NCD; it < n_cur[v]; ++it) pair(acc[v], bufp, p_codes[code_cur[v] + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
+    }
+    if (CLK) {
+      __builtin_amdgcn_sched_barrier(0);
+      const long long tE = clock64();
+      clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[3] += tE - tD; clk_sum[4] += 1;
+#pragma unroll
+      for (int v = 0; v < VB; ++v) clk_sum[5] += n_cur[v];
+    }
+    raw = raw_n; idxA = idxA_n; idxB = idxB_n;
     buf ^= 1;
   }
+  if (CLK && lane == 0 && clk) {
+    long long* o = clk + ((long)blockIdx.x * Cfg::NWAVES + sw) * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
+    o[6] = clock64() - t_start;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last trip's loads target LDS: let them land before the workgroup retires
-  if (slot >= rep) return;
 #pragma unroll
-  for (int r = 0; r < RH; ++r)
+  for (int v = 0; v < VB; ++v) {
+    bool owner;
+    double* dst = out_of(v, &owner);
+    if (!owner) continue;
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
+    for (int r = 0; r < RH; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (r0 + r < NC) dst[r * NC + c] = acc[v][r][c];
+  }
+}
+
+template <int NC, int SPLIT, int MINW, bool WIDE = false>
+__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::REG_BLOCK), MINW)
+k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  schur_reg3_body<NC, SPLIT, WIDE>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh);
+}
+
+template <int NC, int SPLIT, int MINW, bool WIDE = false>
+__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::REG_BLOCK), MINW)
+k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  schur_reg3_body<NC, SPLIT, WIDE, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk);
 }
 
 // The pair kernel accumulates PRIMED blocks T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr]; the true rows 0..2 are J_l^T times the primed
@@ -2513,7 +2653,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_heavy_schur(const int* __restrict__ heavy_pts, const int* __restrict__ pt_start, const int* __restrict__ obs_cam,
               const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
               const double* __restrict__ Trec, const double* __restrict__ tab, double* __restrict__ heavy_W, double* __restrict__ Sacc) {
-  constexpr int REC = SchurRec<NC>::REC;
+  constexpr int REC = SchurRec<NC>::HREC;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* W = sh;                                  // [ncp][3]
   int* seen = reinterpret_cast<int*>(W + (size_t)ncp * 3);  // [ncp] 1 if the parameter's camera sees the point
@@ -2702,7 +2842,7 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
             const double* __restrict__ sinv, const double* __restrict__ Trec, const double* __restrict__ tab, const int* __restrict__ pt_start,
             const int* __restrict__ obs_cam, const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
             double* __restrict__ Sacc, double* __restrict__ bacc, int* __restrict__ flags) {
-  constexpr int REC = SchurRec<NC>::REC;
+  constexpr int REC = SchurRec<NC>::HREC;
   __shared__ double sh_L[CON_MAX_POINTS][6];
   __shared__ double sh_y[CON_MAX_POINTS][3];
   __shared__ double sh_piv;

@@ -73,6 +73,7 @@ struct cba_problem {
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
   bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg / k_schur_reg2); false: LDS-atomic tile kernel
   bool schur_v2 = false;   // dealt plan + register kernel (always with schur_reg)
+  bool schur_wide = false; // k_schur_reg3<6, ..., WIDE>: 32 x 32 camera tiles, 512 threads with two blocks each (CBA_SCHUR_WIDE=1; six-parameter cameras, more than 16)
   bool schur_v3 = true;    // k_schur_reg3 (records loaded straight into a double-buffered LDS chunk); CBA_SCHUR=reg2: k_schur_reg2 (register-staged)
   double plan_lane_util = 0.0;  // schur_v2: share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
@@ -130,6 +131,7 @@ struct cba_problem {
   int* d_hflags = nullptr;
   bool first_scale = true;
   bool have_x0 = false;
+  bool schur_clock = false;  // profiling only (CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
   int debug_skip = 0;  // profiling only (CBA_DEBUG_SCHUR_SKIP): 1 = skip the pair phase, 2 = skip the block recomputation
   bool begun = false, linearized = false, stepped = false, have_trial = false;
   double gh_sq = 0.0;
@@ -523,11 +525,11 @@ template <int NC> struct RegCfg;
 template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
-  if (p->det_m) return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
-  return ((size_t)BLOCK * SchurRec<NC>::REC + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
+  if (p->det_m) return ((size_t)BLOCK * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
+  return ((size_t)BLOCK * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
 }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
-constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
+constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads (the wide kernel: Reg3Cfg<6, true>::GROUP)
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
@@ -720,11 +722,16 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
   Reg2Params prm;
   prm.C = C; prm.P = p->P; prm.G = G; prm.g = g;
-  prm.rep = (NC == 6 && g * g <= BLOCK / 2) ? BLOCK / (g * g) : 1;  // small groups: several threads per block
-  if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), BLOCK / std::max(g * g, 1))) : 1;
+  constexpr int CT = KCfg::CODE_THREADS;
+  prm.rep = (NC == 6 && g * g <= CT / 2) ? CT / (g * g) : 1;  // small groups: several threads per block
+  if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), CT / std::max(g * g, 1))) : 1;
+  prm.n_waves = KCfg::CODE_WAVES;
+  prm.pair_cap = KCfg::PAIR_CAP;
+  if (const char* e = std::getenv("CBA_PLAN_PAIR_CAP")) prm.pair_cap = std::atoi(e);
   prm.chunk_cap = KCfg::SCHUNK;
   prm.slots_per_wave = KCfg::EPW; prm.wave_pieces = KCfg::WAVE_PIECES; prm.rec_pieces = KCfg::LST;
   prm.zero_piece = KCfg::ZERO_PIECE;
+  if (KCfg::CODE_WAVES > 4) prm.region_chunks = 128;  // wide tiles: ~1 pair per block and chunk, the dealing needs room (lane utilisation 0.44 at 32, 0.50 at 128); only two tiles gather a record
   if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
   Reg2Plan plan;
@@ -765,10 +772,21 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   TilePlan tp{};
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
   tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
-  tp.tile_elems = BLOCK * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;
+  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
   tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
   p->tp = tp;
   return CBA_OK;
+}
+
+// camera groups of the LDS-tile kernel (k_schur_tile): the widest group whose tile fits the LDS budget
+template <int NC>
+static int regroup_for_lds_tile(cba_problem* p) {
+  int gmax = 1;
+  while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
+  p->G = (p->C + gmax - 1) / gmax;
+  p->gsz = (p->C + p->G - 1) / p->G;
+  p->n_tiles = p->G * (p->G + 1) / 2;
+  return allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz));
 }
 
 template <int NC>
@@ -792,14 +810,24 @@ static int configure_kernels(cba_problem* p) {
   p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
   p->schur_v2 = p->schur_reg;
   p->schur_v3 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg2") == 0) && !p->debug_skip;  // the profiling variants are k_schur_reg2's
-  if (p->schur_reg) gmax = std::min(p->C, kSchurRegMaxGroup);
-  else while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
-  p->G = (p->C + gmax - 1) / gmax;
-  p->gsz = (p->C + p->G - 1) / p->G;
-  p->n_tiles = p->G * (p->G + 1) / 2;
+  {
+    const char* wide_env = std::getenv("CBA_SCHUR_WIDE");
+    // opt-in (CBA_SCHUR_WIDE=1, more than 16 cameras): measured on cfg4 the wide kernel gathers half the bytes and takes the same time
+    // as the narrow one (the pair kernel is bound by issue, barrier and pair arithmetic in equal parts, not by the bytes)
+    p->schur_wide = NC == 6 && p->schur_v3 && wide_env && std::atoi(wide_env) == 1 && p->C > kSchurRegMaxGroup;
+  }
+  if (p->schur_reg) {
+    gmax = std::min(p->C, p->schur_wide ? Reg3Cfg<6, true>::GROUP : kSchurRegMaxGroup);
+    p->G = (p->C + gmax - 1) / gmax;
+    p->gsz = (p->C + p->G - 1) / p->G;
+    p->n_tiles = p->G * (p->G + 1) / 2;
+  } else if ((rc = regroup_for_lds_tile<NC>(p))) return rc;
   if (p->schur_reg) {
     if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
     if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
+    if constexpr (NC == 6) {
+      if (p->schur_wide && (rc = allow_lds(k_schur_reg3<6, 1, 2, true>, Reg3Cfg<6, true>::LDS_BYTES))) return rc;
+    }
     if (NC == 6 && p->debug_skip) {
       constexpr int D6 = (NC == 6);
       for (const void* fn : {(const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 2 * D6>,
@@ -810,7 +838,6 @@ static int configure_kernels(cba_problem* p) {
     }
     if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   }
-  else if ((rc = allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_backward, (size_t)p->ncp * 8))) return rc;
@@ -843,6 +870,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->C = d->n_cams; p->P = d->n_points; p->N = d->n_obs;
   p->loss = d->loss; p->f_scale = d->f_scale;
   if (const char* dbg = std::getenv("CBA_DEBUG_SCHUR_SKIP")) p->debug_skip = std::atoi(dbg);
+  p->schur_clock = std::getenv("CBA_SCHUR_CLOCK") != nullptr;
   p->want_chol_trace = std::getenv("CBA_CHOL_TRACE") != nullptr;
   int rc = CBA_OK;
   auto bail = [&](int code) { cba_destroy(p); return code; };
@@ -990,19 +1018,25 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("reorder, upload, allocate");
   p->eval_only = opt && opt->evaluation_only != 0;
   for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
-    const size_t tile_lds = p->schur_reg ? (p->schur_v3 ? ((nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES) : ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES))
+    const size_t tile_lds = p->schur_reg ? (p->schur_wide ? Reg3Cfg<6, true>::LDS_BYTES
+                                            : p->schur_v3 ? ((nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES) : ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES))
                                          : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
     int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
     if (p->schur_reg) per_cu = std::min(per_cu, (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // register budget
     const int resident = cus * per_cu;  // no partial last round
     if (p->schur_reg && p->schur_v2) {
       const int mb = std::min(resident, std::max(max_blocks, cus));
-      if (p->schur_v3) rc = (nct == 9) ? build_reg2_tile_plan<9, Reg3Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg3Cfg<6>>(p, hcam, hps, off, mb);
+      if (p->schur_wide) rc = build_reg2_tile_plan<6, Reg3Cfg<6, true>>(p, hcam, hps, off, mb);
+      else if (p->schur_v3) rc = (nct == 9) ? build_reg2_tile_plan<9, Reg3Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg3Cfg<6>>(p, hcam, hps, off, mb);
       else rc = (nct == 9) ? build_reg2_tile_plan<9, Reg2Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg2Cfg<6>>(p, hcam, hps, off, mb);
     }
     else
       rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
-    if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) { p->schur_reg = false; p->schur_v2 = false; continue; }  // a point too large for the pair plan
+    if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) {  // a point too large for the pair plan: the LDS-tile kernel, with the groups that fit its tile
+      p->schur_reg = false; p->schur_v2 = false; p->schur_v3 = false; p->schur_wide = false;
+      if ((rc = (nct == 9) ? regroup_for_lds_tile<9>(p) : regroup_for_lds_tile<6>(p))) return bail(rc);
+      continue;
+    }
     if (rc) return bail(rc);
     break;
   }
@@ -1017,7 +1051,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->tri, (size_t)ncp * (ncp + 1) / 2 + p->lay.ncp_pad));
   if (p->schur_reg && !p->eval_only) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
-    TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * ((nct == 9) ? SchurRec<9>::REC : SchurRec<6>::REC)));
+    TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * ((nct == 9) ? SchurRec<9>::HREC : SchurRec<6>::HREC)));
     TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
   }
   TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); p->ldw = (ncp + 3) & ~3;
@@ -1049,6 +1083,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_reg ? 0 : 1;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
+  o->schur_wide = (p->schur_reg && p->schur_wide) ? 1 : 0; o->reserved = 0;
   return CBA_OK;
 }
 
@@ -1371,7 +1406,46 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
-      if (p->schur_v3) {
+      if (p->schur_v3 && NC == 6 && p->schur_clock) {  // profiling build of the pair kernel: phase clocks per wave, printed per launch (tools/schur_split.py)
+        if constexpr (NC == 6) {
+          const int nw = p->schur_wide ? Reg3Cfg<6, true>::NWAVES : Reg3Cfg<6>::NWAVES;
+          const size_t n = (size_t)p->tile_grid * nw * 8;
+          long long* d = nullptr;
+          if (guarded_malloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
+          (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
+          if (p->schur_wide) {
+            using Wide = Reg3Cfg<6, true>;
+            if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, true>, Wide::LDS_BYTES)) return CBA_ERR_HIP;
+            hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d);
+          } else {
+            if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, false>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
+            hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, false>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::REG_BLOCK), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d);
+          }
+          std::vector<long long> h(n);
+          (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
+          (void)hipStreamSynchronize(p->stream);
+          (void)guarded_free(d);
+          static const char* names[4] = {"wait for loads", "barrier", "issue", "pairs"};
+          double sum[8] = {0};
+          double tmax = 0.0;
+          size_t waves = 0;
+          for (size_t w = 0; w < n / 8; ++w) {
+            if (!h[w * 8 + 4]) continue;
+            ++waves;
+            for (int k = 0; k < 7; ++k) sum[k] += (double)h[w * 8 + k];
+            tmax = std::max(tmax, (double)h[w * 8 + 6]);
+          }
+          const double wv = (double)std::max<size_t>(waves, 1);
+          fprintf(stderr, "k_schur_reg3%s phases, mean clocks per wave (%zu waves, %.1f trips, %.1f pair iterations each):", p->schur_wide ? " (wide)" : "", waves, sum[4] / wv, sum[5] / wv);
+          for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
+          fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
+        }
+      } else if (p->schur_wide) {
+        if constexpr (NC == 6) {
+          using Wide = Reg3Cfg<6, true>;
+          hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
+        }
+      } else if (p->schur_v3) {
         hipLaunchKernelGGL((k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg3Cfg<NC>::LDS_BYTES,
                            p->stream, p->tp, p->Trec, p->partial);
       } else {

@@ -54,14 +54,17 @@ struct Reg2Params {
                             // gather one record then do so further apart in time: at 32 half of those gathers hit the L2 (PMC FETCH_SIZE 0.59 vs 0.90 GB)
   int heavy_obs = 0;      // > 0: points with more observations are left out (k_heavy_schur forms their share)
   int threads = 0;        // host threads (0: hardware concurrency)
+  int pair_cap = 0;       // > 0: pairs of one block per chunk the kernel takes without an extra load; the dealing opens new chunks rather than going beyond
+                          // (a single point with more pairs of one block than this still gets its chunk)
+  int n_waves = 4;        // waves of a workgroup that multiply pairs (4: 256 threads, 16: the 1024-thread kernel of 32 x 32 tiles)
 };
 
 struct Reg2Plan {
   std::vector<int> obs;               // stream entry -> observation (index into the T records); padded with 2 * chunk_cap zeros
   std::vector<int> chunk_start;       // [n_chunks + 1] offsets into obs
   std::vector<int> code_start;        // [n_chunks + 1] offsets into codes
-  std::vector<unsigned> nit;          // [n_chunks] iterations of waves 0..3, one byte each
-  std::vector<unsigned> codes;        // transposed pair codes; padded with 4 * 256 ZERO codes
+  std::vector<unsigned> nit;          // [n_chunks][n_waves / 4] iterations of the waves, one byte each
+  std::vector<unsigned> codes;        // transposed pair codes; padded with 4 * 64 n_waves ZERO codes
   std::vector<int> tile_chunk_begin;  // [n_tiles + 1]
   long n_pairs = 0;                   // pair codes that do work
   long lane_iters = 0;                // 64 x wave-iterations (n_pairs / lane_iters = lane utilisation)
@@ -98,6 +101,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
   using namespace reg2_detail;
   const int G = prm.G, g = prm.g, C = prm.C, P = prm.P, rep = std::max(1, prm.rep);
   const int nT = G * (G + 1) / 2, nblk = g * g, R = prm.chunk_cap;
+  const int NW = std::max(4, prm.n_waves / 4 * 4), NWORD = NW / 4;
   const unsigned ZERO = (unsigned)prm.zero_piece | ((unsigned)prm.zero_piece << 16);
   auto piece_of = [&](int slot) { return (unsigned)((slot / prm.slots_per_wave) * prm.wave_pieces + (slot % prm.slots_per_wave) * prm.rec_pieces); };
   std::vector<int> gcam(G + 1);
@@ -224,7 +228,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
           bool placed = false;
           for (int ch = first; ch <= (int)fill.size() && !placed; ++ch) {
             if (ch == (int)fill.size()) {
-              if (ch >= max_chunks && t < t0 + 6) break;  // the region is full at this cap: try again with t + 1
+              if (ch >= max_chunks && t < t0 + 6 && (prm.pair_cap <= 0 || t < prm.pair_cap)) break;  // the region is full at this cap: try again with t + 1
               open_chunk();
             }
             if (fill[ch] + c.n_rec > r_eff) continue;
@@ -253,12 +257,13 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
         int mx = 0;
         for (int k = 0; k < W; ++k)
           if (unit[k] > 0) mx = std::max(mx, (cc[k] + unit[k] - 1) / unit[k]);
-        d.cost += 4 * mx + 6;
+        d.cost += NW * mx + 6;
       }
     };
     Deal best;
     {
       int t_hi = std::max(1, (int)std::ceil(mean - 1e-9));
+      if (prm.pair_cap > 0) t_hi = std::min(t_hi, prm.pair_cap);
       int r_hi = R;
       if (mean / t_hi > 0.93) r_hi = std::max(R / 2, (int)(R * 0.93 * t_hi / mean));
       deal(t_hi, r_hi, best);
@@ -269,7 +274,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       }
     }
     // emit: stream entries (in slot order), transposed codes
-    std::vector<std::vector<unsigned>> lists(256);
+    std::vector<std::vector<unsigned>> lists((size_t)NW * 64);
     std::vector<unsigned> rr((size_t)nblk, 0), rrc((size_t)g, 0);
     std::vector<int> rec_obs;                 // chunk record id (arrival order) -> observation
     std::vector<int> slot_of, residue;        // record id -> slot / residue
@@ -311,8 +316,8 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
         }
       }
       const int n_rec = (int)rec_obs.size();
-      size_t nit_w[4];
-      for (int w = 0; w < 4; ++w) {
+      std::vector<size_t> nit_w((size_t)NW);
+      for (int w = 0; w < NW; ++w) {
         size_t mx = 0;
         for (int l = 0; l < 64; ++l) mx = std::max(mx, lists[(size_t)w * 64 + l].size());
         nit_w[w] = std::min<size_t>(mx, 255);  // a byte per wave; 255 pairs of one block in one chunk cannot happen (chunk_cap records)
@@ -320,7 +325,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       // cliques of the LDS reads: per wave, iteration, lane group and operand the distinct records read together
       cliques.clear();
       mark.assign((size_t)n_rec, -1);
-      for (int w = 0; w < 4; ++w)
+      for (int w = 0; w < NW; ++w)
         for (size_t it = 0; it < nit_w[w]; ++it)
           for (int side = 0; side < 2; ++side) {
             const size_t c0 = cliques.size();
@@ -399,10 +404,10 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       const size_t open = job.obs.size();
       job.obs.resize(open + n_slots, 0);  // holes point at observation 0: loaded, never referenced
       for (int r = 0; r < n_rec; ++r) job.obs[open + slot_of[r]] = rec_obs[r];
-      unsigned packed = 0;
-      for (int w = 0; w < 4; ++w) {
+      std::vector<unsigned> packed((size_t)NWORD, 0u);
+      for (int w = 0; w < NW; ++w) {
         const size_t mx = nit_w[w];
-        packed |= (unsigned)mx << (8 * w);
+        packed[w / 4] |= (unsigned)mx << (8 * (w % 4));
         for (size_t it = 0; it < mx; ++it)
           for (int l = 0; l < 64; ++l) {
             const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
@@ -413,7 +418,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
         job.lane_iters += (long)mx * 64;
       }
       for (auto& l : lists) job.n_pairs += (long)l.size();
-      job.nit.push_back(packed);
+      job.nit.insert(job.nit.end(), packed.begin(), packed.end());
       job.chunk_start.push_back((int)job.obs.size());
       job.code_start.push_back((int)job.codes.size());
     }
@@ -436,12 +441,12 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
 
   // concatenate in (tile, region) order
   size_t n_obs = 0, n_codes = 0, n_chunks = 0;
-  for (const Job& j : jobs) { n_obs += j.obs.size(); n_codes += j.codes.size(); n_chunks += j.nit.size(); }
+  for (const Job& j : jobs) { n_obs += j.obs.size(); n_codes += j.codes.size(); n_chunks += j.nit.size() / NWORD; }
   out.obs.assign(n_obs + 2 * (size_t)R, 0);
-  out.codes.assign(n_codes + 4 * 256, ZERO);
+  out.codes.assign(n_codes + (size_t)4 * 64 * NW, ZERO);
   out.chunk_start.assign(n_chunks + 1, 0);
   out.code_start.assign(n_chunks + 1, 0);
-  out.nit.assign(n_chunks, 0);
+  out.nit.assign(n_chunks * NWORD, 0);
   out.tile_chunk_begin.assign(nT + 1, 0);
   out.n_pairs = 0; out.lane_iters = 0; out.lds_groups = 0; out.lds_cycles = 0; out.lds_cycles_arrival = 0;
   size_t o = 0, cpos = 0, ch = 0;
@@ -451,12 +456,13 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       const Job& j = jobs[(size_t)t * n_regions + r];
       std::copy(j.obs.begin(), j.obs.end(), out.obs.begin() + o);
       std::copy(j.codes.begin(), j.codes.end(), out.codes.begin() + cpos);
-      for (size_t c = 0; c < j.nit.size(); ++c) {
-        out.nit[ch + c] = j.nit[c];
+      const size_t jch = j.nit.size() / NWORD;
+      std::copy(j.nit.begin(), j.nit.end(), out.nit.begin() + ch * NWORD);
+      for (size_t c = 0; c < jch; ++c) {
         out.chunk_start[ch + c + 1] = (int)(o + j.chunk_start[c + 1]);
         out.code_start[ch + c + 1] = (int)(cpos + j.code_start[c + 1]);
       }
-      o += j.obs.size(); cpos += j.codes.size(); ch += j.nit.size();
+      o += j.obs.size(); cpos += j.codes.size(); ch += jch;
       out.n_pairs += j.n_pairs; out.lane_iters += j.lane_iters;
       out.lds_groups += j.lds_groups; out.lds_cycles += j.lds_cycles; out.lds_cycles_arrival += j.lds_cycles_arrival;
     }

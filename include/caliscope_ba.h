@@ -289,6 +289,8 @@ typedef struct {
   int32_t n_heavy_points; /* points with > 40 observations (static markers): per-camera Schur sums, split over chunks beyond 256 */
   int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
   int64_t schur_pairs;      /* observation pairs (blocks of W V^-1 W^T) formed per Schur pass */
+  int32_t schur_wide;       /* 1: 32 x 32 camera tiles, two blocks per thread (opt-in: CBA_SCHUR_WIDE=1) */
+  int32_t reserved;
 } cba_info;
 int cba_get_info(cba_problem* p, cba_info* out);
 

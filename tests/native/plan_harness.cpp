@@ -2,22 +2,23 @@
 // k_schur_reg2 does (chunk by chunk, wave by wave, iteration by iteration, lane by lane) and accumulates T_i T_j^T per
 // owner thread, so that tests/test_schur_plan.py can compare the per-block sums with a direct sum over the points.
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../caliscope_amd/csrc/schur_plan.h"
 
 extern "C" {
 
-// acc_out: [n_tiles][256][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
+// acc_out: [n_tiles][64 n_waves][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
 int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int slots_per_wave, int lds_stride, int wave_pieces, int region_chunks,
-                int heavy_obs, int threads, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
+                int heavy_obs, int threads, int n_waves, int pair_cap, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
   cba::Reg2Params prm;
   prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap;
   // the kernel's staging layout (cba_kernels.h, Reg2Cfg): a wave stages slots_per_wave slots, lds_stride pieces apart, in a run of wave_pieces pieces (k_schur_reg3 pads it to whole loads)
   prm.rec_pieces = lds_stride; prm.slots_per_wave = slots_per_wave; prm.wave_pieces = wave_pieces;
   const int zero_piece = (chunk_cap + slots_per_wave - 1) / slots_per_wave * prm.wave_pieces;
   prm.zero_piece = zero_piece;
-  prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads;
+  prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads; prm.n_waves = n_waves; prm.pair_cap = pair_cap;
   const long N = hps[P];
   std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
   cba::Reg2Plan plan;
@@ -30,9 +31,8 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
       const int c0 = plan.chunk_start[ch], len = plan.chunk_start[ch + 1] - c0;
       if (len <= 0 || len > chunk_cap) return -10;
       long code = plan.code_start[ch];
-      const unsigned packed = plan.nit[ch];
-      for (int w = 0; w < 4; ++w) {
-        const int n = (packed >> (8 * w)) & 0xff;
+      for (int w = 0; w < n_waves; ++w) {
+        const int n = (plan.nit[(size_t)ch * (n_waves / 4) + w / 4] >> (8 * (w % 4))) & 0xff;
         for (int it = 0; it < n; ++it)
           for (int lane = 0; lane < 64; ++lane, ++code) {
             const unsigned cd = plan.codes[code];
@@ -47,15 +47,36 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
             if (il < 0 || jl < 0 || il >= len || jl >= len) return -11;
             const double* Ti = T + (long)plan.obs[c0 + il] * rec;
             const double* Tj = T + (long)plan.obs[c0 + jl] * rec;
-            double* a = acc_out + ((long)t * 256 + w * 64 + lane) * bsz;
+            double* a = acc_out + ((long)t * 64 * n_waves + w * 64 + lane) * bsz;
             for (int r = 0; r < nc; ++r)
               for (int c = 0; c < nc; ++c) a[r * nc + c] += Ti[3 * r] * Tj[3 * c] + Ti[3 * r + 1] * Tj[3 * c + 1] + Ti[3 * r + 2] * Tj[3 * c + 2];
           }
       }
       if (code != plan.code_start[ch + 1]) return -12;
     }
+  if (std::getenv("PLAN_TILE_STATS"))
+    for (int t = 0; t < nT; ++t) {
+      long its = 0, slots = 0, pairs = 0;
+      for (int ch = plan.tile_chunk_begin[t]; ch < plan.tile_chunk_begin[t + 1]; ++ch) {
+        slots += plan.chunk_start[ch + 1] - plan.chunk_start[ch];
+        for (int w = 0; w < n_waves; ++w) its += (plan.nit[(size_t)ch * (n_waves / 4) + w / 4] >> (8 * (w % 4))) & 0xff;
+        for (long c = plan.code_start[ch]; c < plan.code_start[ch + 1]; ++c) pairs += plan.codes[c] != ((unsigned)zero_piece | ((unsigned)zero_piece << 16));
+      }
+      const int nch = plan.tile_chunk_begin[t + 1] - plan.tile_chunk_begin[t];
+      std::fprintf(stderr, "tile %d: %d chunks, %.1f slots/chunk, %.2f wave-iterations per chunk and wave, utilisation %.3f\n", t, nch, (double)slots / std::max(nch, 1),
+                   (double)its / std::max(nch, 1) / n_waves, (double)pairs / std::max(1L, its * 64));
+    }
   stats_out[0] = n_chunks; stats_out[1] = plan.n_pairs; stats_out[2] = plan.lane_iters; stats_out[3] = plan.n_regions;
   stats_out[4] = (long)plan.obs.size() - 2L * chunk_cap;
+  {  // wave-iterations beyond the cap (codes the kernel loads inside its pair loop)
+    long over = 0;
+    for (int ch = 0; ch < n_chunks; ++ch)
+      for (int w = 0; w < n_waves; ++w) {
+        const int n = (plan.nit[(size_t)ch * (n_waves / 4) + w / 4] >> (8 * (w % 4))) & 0xff;
+        if (pair_cap > 0 && n > pair_cap) over += n - pair_cap;
+      }
+    stats_out[8] = over;
+  }
   stats_out[5] = plan.lds_groups; stats_out[6] = plan.lds_cycles; stats_out[7] = plan.lds_cycles_arrival;
   return 0;
 }

@@ -20,7 +20,7 @@ def harness(tmp_path_factory):
                    check=True)
     lib = C.CDLL(str(out))
     lib.plan_replay.restype = C.c_int
-    lib.plan_replay.argtypes = [C.c_int] * 14 + [I32P, I32P, F64P, F64P, I64P]
+    lib.plan_replay.argtypes = [C.c_int] * 16 + [I32P, I32P, F64P, F64P, I64P]
     return lib
 
 
@@ -39,24 +39,30 @@ def _visibility(rng, n_cams, n_points, k_lo, k_hi, duplicates=0.0, unobserved=0.
     return np.concatenate(cams).astype(np.int32), np.asarray(starts, dtype=np.int32)
 
 
-def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_chunks=64, heavy_obs=0, layout="reg3"):
+def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_chunks=64, heavy_obs=0, layout="reg3", pair_cap=None):
     P = len(hps) - 1
     G = -(-n_cams // gmax)
     g = -(-n_cams // G)
-    rep = 256 // (g * g) if (nc == 6 and g * g <= 128) else 1
+    threads = 1024 if layout == "wide" else 256
+    rep = threads // (g * g) if (nc == 6 and g * g <= threads // 2) else 1
     rec = T.shape[1]
     # LDS layout of k_schur_reg3 (Reg3Cfg): 320 slots, 4 waves x 80, 7 pieces apart in runs of 576 (nc = 6); 384 slots, 12 x 32, 11
     # apart in runs of 384 (nc = 9).  `layout` = "reg2": k_schur_reg2's 512 = 4 x 128 slots, unpadded runs.
     if layout == "reg2":
         epw, lst, wp, cap = (128, 7, 896, 512) if nc == 6 else (32, 11, 352, 384)
+    elif layout == "wide":  # Reg3Cfg<6, true>: 1024 blocks (16 code waves), 512 slots = 8 loading waves x 64, runs of 448 pieces
+        assert nc == 6
+        epw, lst, wp, cap = 64, 7, 448, 512
     else:
         epw, lst, wp, cap = (80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384)
     if chunk_cap is None:
         chunk_cap = cap
     nT = G * (G + 1) // 2
-    acc = np.zeros((nT, 256, nc * nc))
-    stats = np.zeros(8, dtype=np.int64)
-    rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, hcam.ctypes.data_as(I32P),
+    acc = np.zeros((nT, threads, nc * nc))
+    stats = np.zeros(9, dtype=np.int64)
+    if pair_cap is None:  # Reg3Cfg::PAIR_CAP
+        pair_cap = 2 if layout == "wide" else 0
+    rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, threads // 64, pair_cap, hcam.ctypes.data_as(I32P),
                          hps.ctypes.data_as(I32P), T.ctypes.data_as(F64P), acc.ctypes.data_as(F64P), stats.ctypes.data_as(I64P))
     assert rc == 0, rc
     return acc, stats, (G, g, rep)
@@ -131,6 +137,18 @@ def test_pairs_reach_their_blocks_random_visibility(harness):
     _check(harness, rng, 40, 500, 3, 9, 9)            # nine-parameter cameras
     _check(harness, rng, 64, 600, 2, 10, 6, layout="reg2")
     _check(harness, rng, 24, 300, 3, 9, 9, layout="reg2")
+
+
+def test_wide_tiles_of_the_1024_thread_kernel(harness):
+    """32 x 32 camera tiles, 16 waves (k_schur_reg3<6, ..., WIDE>): the same plan code with n_waves = 16."""
+    rng = np.random.default_rng(11)
+    _check(harness, rng, 64, 900, 2, 10, 6, gmax=32, layout="wide")     # two groups of 32: three tiles
+    _check(harness, rng, 32, 500, 2, 9, 6, gmax=32, layout="wide")      # one diagonal tile, 496 real blocks + 528 helpers
+    _check(harness, rng, 20, 400, 1, 6, 6, gmax=32, layout="wide")      # one group of 20: rep = 2 threads per block
+    _check(harness, rng, 100, 800, 3, 12, 6, gmax=32, layout="wide", duplicates=0.1, unobserved=0.05)  # four groups of 25
+    stats = _check(harness, rng, 64, 10000, 10, 10, 6, gmax=32, layout="wide")
+    print("wide: lane utilisation", stats[1] / stats[2], "LDS cycles per group", stats[6] / stats[5], "chunks", stats[0], "stream", stats[4])
+    assert stats[1] == 10000 * 55 and stats[1] / stats[2] > 0.42   # ~1 pair per block and chunk: the cap of 2 leaves half of the lane-iterations idle
 
 
 def test_duplicate_rows_and_unobserved_points(harness):
