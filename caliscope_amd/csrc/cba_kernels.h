@@ -1316,6 +1316,14 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
   const int tid = (int)threadIdx.x;
+  // workgroup id: groups of eight consecutive ids (one per XCD) alternate between the two halves of the grid.  With two workgroups per CU the ones
+  // dispatched later run slower (phase clocks: the time per trip grows by a third from the first to the last quarter of the grid); spread like this
+  // every tile gets the same mix, and the cost model of the binding (cba_lib.hip, bind_workgroups) holds for all of them
+  int wg = (int)blockIdx.x;
+  if ((gridDim.x & 15u) == 0) {
+    const int gh = wg >> 3, halfg = (int)(gridDim.x >> 4);
+    wg = ((gh < halfg ? 2 * gh : 2 * (gh - halfg) + 1) << 3) | (wg & 7);
+  }
   const int ct = tid % PT;                      // code thread: the SPLIT parts of a block multiply the same pairs
   const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
   const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave
@@ -1334,9 +1342,9 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     const int vt = (SPLIT == 1) ? v * PT + tid : ct;
     const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
     *owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
-    return partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
+    return partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
   };
-  const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
+  const int first = tp.wg_first[wg], ch_end = tp.wg_end[wg], stride = tp.wg_stride[wg];
   if (first >= ch_end) {  // more workgroups than chunks in this range
 #pragma unroll
     for (int v = 0; v < VB; ++v) {
@@ -1538,10 +1546,11 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     buf ^= 1;
   }
   if (CLK && lane == 0 && clk) {
-    long long* o = clk + ((long)blockIdx.x * Cfg::NWAVES + sw) * 8;
+    long long* o = clk + ((long)wg * Cfg::NWAVES + sw) * 8;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
     o[6] = clock64() - t_start;
+    o[7] = ((long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 40) | (wall_clock64() & 0xffffffffffLL);  // HW_ID, start stamp (100 MHz)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last trip's loads target LDS: let them land before the workgroup retires
 #pragma unroll
@@ -1561,7 +1570,7 @@ template <int NC, int SPLIT, int MINW, bool WIDE = false>
 __global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::REG_BLOCK), MINW)
 k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, WIDE>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh);
+  schur_reg3_body<NC, SPLIT, WIDE, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh);
 }
 
 template <int NC, int SPLIT, int MINW, bool WIDE = false>

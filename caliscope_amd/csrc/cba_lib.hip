@@ -131,6 +131,7 @@ struct cba_problem {
   int* d_hflags = nullptr;
   bool first_scale = true;
   bool have_x0 = false;
+  std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
   bool schur_clock = false;  // profiling only (CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
   int debug_skip = 0;  // profiling only (CBA_DEBUG_SCHUR_SKIP): 1 = skip the pair phase, 2 = skip the block recomputation
   bool begun = false, linearized = false, stepped = false, have_trial = false;
@@ -536,16 +537,22 @@ static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_
 // Workgroup -> tile binding shared by the tile plans: workgroups proportional to the chunk count of each tile (at least
 // one per tile), XCD-aware for the register kernels.  TCB = first chunk of every tile.
 struct WgBinding { std::vector<int> wgb, wt, wfirst, wend, wstride; };
-static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, bool reg) {
+// `tile_cost` (optional): estimated time of every tile's chunks; workgroups are then handed out in proportion to it instead of the chunk counts (a
+// diagonal tile's chunks hold 3 pair iterations per wave where an off-diagonal tile's hold 2: with equal chunk counts per workgroup the
+// diagonal tiles' workgroups ran 30 % longer than the rest, and the kernel lasts as long as its slowest workgroup).
+static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, bool reg, const std::vector<double>* tile_cost = nullptr) {
   WgBinding out;
-  // workgroups: proportional to the chunk count of each tile, at least one per tile
+  // workgroups: proportional to the chunk count (or the cost) of each tile, at least one per tile
   std::vector<long> nch(nT);
   for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
+  std::vector<double> wt_cost(nT);
+  double cost_total = 0.0;
+  for (int t = 0; t < nT; ++t) { wt_cost[t] = tile_cost ? (*tile_cost)[t] : (double)nch[t]; cost_total += wt_cost[t]; }
   auto allocate = [&](int budget) {
     std::vector<int> nwg(nT);
     long used = 0;
     for (int t = 0; t < nT; ++t) {
-      const long w = p->n_tile_chunks > 0 ? nch[t] * budget / p->n_tile_chunks : 1;
+      const long w = cost_total > 0.0 ? (long)(wt_cost[t] * budget / cost_total) : 1;
       nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
       used += nwg[t];
     }
@@ -556,11 +563,11 @@ static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, in
       for (int t = 0; t < nT; ++t) {
         if (used < budget) {
           if (nwg[t] >= nch[t]) continue;
-          const double sc = (double)nch[t] / nwg[t];
+          const double sc = wt_cost[t] / nwg[t];
           if (best < 0 || sc > score) { best = t; score = sc; }
         } else {
           if (nwg[t] <= 1) continue;
-          const double sc = -(double)nch[t] / (nwg[t] - 1);
+          const double sc = -wt_cost[t] / (nwg[t] - 1);
           if (best < 0 || sc > score) { best = t; score = sc; }
         }
       }
@@ -745,7 +752,26 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
     fprintf(stderr, "  plan: %d tiles x %d regions, %d chunks (%.1f slots each), %ld pairs, lane utilisation %.3f, LDS cycles per 16-lane read group %.2f (arrival order %.2f)\n",
             nT, plan.n_regions, p->n_tile_chunks, p->n_tile_chunks ? (double)p->tile_stream_len / p->n_tile_chunks : 0.0, plan.n_pairs, p->plan_lane_util,
             plan.lds_groups ? (double)plan.lds_cycles / plan.lds_groups : 0.0, plan.lds_groups ? (double)plan.lds_cycles_arrival / plan.lds_groups : 0.0);
-  const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, true);
+  // cost of a chunk: gather + barrier (in units of one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its
+  // slowest wave
+  double cost_a = 2.0;
+  if (const char* e = std::getenv("CBA_PLAN_COST_A")) cost_a = std::atof(e);
+  std::vector<double> tile_cost(nT, 0.0);
+  {
+    const int nword = KCfg::CODE_WAVES / 4, vb = KCfg::CODE_WAVES / (KCfg::REG_BLOCK / KCfg::SPLIT / WAVE);  // blocks per thread: their iterations add up
+    const int pwaves = KCfg::CODE_WAVES / vb;
+    for (int t = 0; t < nT; ++t)
+      for (int ch = plan.tile_chunk_begin[t]; ch < plan.tile_chunk_begin[t + 1]; ++ch) {
+        int mx = 0;
+        for (int w = 0; w < pwaves; ++w) {
+          int its = 0;
+          for (int v = 0; v < vb; ++v) { const int vw = v * pwaves + w; its += (int)((plan.nit[(size_t)ch * nword + vw / 4] >> (8 * (vw % 4))) & 0xffu); }
+          mx = std::max(mx, its);
+        }
+        tile_cost[t] += cost_a + mx;
+      }
+  }
+  const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, true, cost_a >= 0.0 ? &tile_cost : nullptr);
   lap("workgroup binding");
   std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
   for (int a = 0; a <= G; ++a) {
@@ -768,6 +794,7 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   TRYP(dev_upload(p, &dta, ta)); TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
   TRYP(dev_upload(p, &p->tile_wg_begin, bind.wgb));
 #undef TRYP
+  p->h_tile_wg_begin = bind.wgb;
   lap("upload");
   TilePlan tp{};
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
@@ -824,7 +851,7 @@ static int configure_kernels(cba_problem* p) {
   } else if ((rc = regroup_for_lds_tile<NC>(p))) return rc;
   if (p->schur_reg) {
     if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, false>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
     if constexpr (NC == 6) {
       if (p->schur_wide && (rc = allow_lds(k_schur_reg3<6, 1, 2, true>, Reg3Cfg<6, true>::LDS_BYTES))) return rc;
     }
@@ -1413,14 +1440,17 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
           long long* d = nullptr;
           if (guarded_malloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
           (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
-          if (p->schur_wide) {
-            using Wide = Reg3Cfg<6, true>;
-            if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, true>, Wide::LDS_BYTES)) return CBA_ERR_HIP;
-            hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d);
-          } else {
-            if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, false>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
-            hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, false>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::REG_BLOCK), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d);
-          }
+          auto launch_clk = [&](auto kernel, int threads, size_t lds) {
+            if (raise_lds_ceiling((const void*)kernel, lds)) return CBA_ERR_HIP;
+            hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(threads), lds, p->stream, p->tp, p->Trec, p->partial, d);
+            return CBA_OK;
+          };
+          using Wide = Reg3Cfg<6, true>;
+          using Narrow = Reg3Cfg<6>;
+          int rcl;
+          if (p->schur_wide) rcl = launch_clk(k_schur_reg3_clk<6, 1, 2, true>, Wide::REG_BLOCK, Wide::LDS_BYTES);
+          else rcl = launch_clk(k_schur_reg3_clk<6, 1, 2, false>, Narrow::REG_BLOCK, Narrow::LDS_BYTES);
+          if (rcl) return rcl;
           std::vector<long long> h(n);
           (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
           (void)hipStreamSynchronize(p->stream);
@@ -1439,6 +1469,21 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
           fprintf(stderr, "k_schur_reg3%s phases, mean clocks per wave (%zu waves, %.1f trips, %.1f pair iterations each):", p->schur_wide ? " (wide)" : "", waves, sum[4] / wv, sum[5] / wv);
           for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
           fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
+          if (const char* e = std::getenv("CBA_SCHUR_CLOCK"); e && std::atoi(e) == 2)  // per workgroup: lifetime of wave 0, its HW_ID register, its end stamp
+            for (int b = 0; b < p->tile_grid; ++b)
+              fprintf(stderr, "wg %d life %lld hwid %llx end100MHz %lld trips %lld\n", b, h[(size_t)b * nw * 8 + 6], (unsigned long long)h[(size_t)b * nw * 8 + 7] >> 40,
+                      h[(size_t)b * nw * 8 + 7] & 0xffffffffffLL, h[(size_t)b * nw * 8 + 4]);
+          for (int t = 0; t + 1 < (int)p->h_tile_wg_begin.size(); ++t) {  // the kernel lasts as long as its slowest workgroup
+            double mean = 0.0, mx = 0.0, trips = 0.0, its = 0.0;
+            const int b0 = p->h_tile_wg_begin[t], b1 = p->h_tile_wg_begin[t + 1];
+            for (int b = b0; b < b1; ++b) {
+              double life = 0.0;
+              for (int w = 0; w < nw; ++w) life = std::max(life, (double)h[((size_t)b * nw + w) * 8 + 6]);
+              mean += life; mx = std::max(mx, life); trips += (double)h[(size_t)b * nw * 8 + 4]; its += (double)h[(size_t)b * nw * 8 + 5];
+            }
+            const double nb = std::max(1, b1 - b0);
+            fprintf(stderr, "    tile %2d: %3d workgroups, %.1f trips and %.1f pair iterations (wave 0) each, lifetime mean %.0f max %.0f clocks\n", t, b1 - b0, trips / nb, its / nb, mean / nb, mx);
+          }
         }
       } else if (p->schur_wide) {
         if constexpr (NC == 6) {
@@ -1446,8 +1491,8 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
           hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
         }
       } else if (p->schur_v3) {
-        hipLaunchKernelGGL((k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>), dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg3Cfg<NC>::LDS_BYTES,
-                           p->stream, p->tp, p->Trec, p->partial);
+        constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
+        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, false>), dim3(p->tile_grid), dim3(BLOCK * SP), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
       } else {
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);

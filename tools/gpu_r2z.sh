@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+O=$GRAFT_REPO_ROOT/gpurun_out/r2z; mkdir -p $O
+CBA_SCHUR_CLOCK=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/clock.log
+grep -A12 -h 'k_schur_reg3' $O/clock.log | tail -12
