@@ -824,9 +824,9 @@ template <int NC> struct SchurRec {
   static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride, 16-byte pieces, odd: 7 / 11 (LDS bank spread; the same
                                                           // stride in HBM lets k_schur_reg3 load records straight into LDS)
   static constexpr int REC = 2 * LST;                     // record stride in LDS, doubles: 14 / 22
-  // record stride in HBM, doubles.  NC = 6: 16, one 128-byte line per record (at 112 bytes seven of eight records straddle two lines, and the
-  // pair kernel's gather is bound by the lines an instruction touches: 17 instead of 10 per load of 64 pieces)
-  static constexpr int HREC = (NC == 6) ? 16 : REC;
+  // record stride in HBM, doubles: the LDS stride.  (16 doubles = one 128-byte line per record for NC = 6 was measured: the pair kernel's issue phase
+  // shrank by 7 %, k_tprep grew by as much, and the pass moved 1.15 GB instead of 0.93 GB through HBM.)
+  static constexpr int HREC = REC;
   static constexpr int STAGE = (HREC / 2) | 1;            // k_tprep's transposing LDS stage: record stride in pieces, odd (bank spread)
 };
 static_assert(SchurRec<6>::REC == 14 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");

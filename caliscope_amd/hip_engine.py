@@ -216,6 +216,11 @@ class HipEngine:
         """Join an in-process device group (one host thread per member; returns when all have joined)."""
         self._check(self.lib.cba_group_join(self._h, group.handle, int(rank)), "cba_group_join")
 
+    def set_loss(self, loss: str, f_scale: float) -> None:
+        """Another robust loss on the same observations (``cba_set_loss``): the Schur plan and the device buffers stay."""
+        self._check(self.lib.cba_set_loss(self._h, LOSS_CODES[loss], float(f_scale)), "cba_set_loss")
+        self.problem.loss, self.problem.f_scale = loss, float(f_scale)
+
     def info(self) -> dict:
         o = _lib.Info()
         self._check(self.lib.cba_get_info(self._h, C.byref(o)), "cba_get_info")

@@ -145,8 +145,6 @@ def least_squares(
                         constraint_groups_a=con[0], constraint_groups_b=con[1], constraint_distances=con[2], constraint_weights=con[3])
     if engine_factory is None:
         from caliscope_amd.distributed import devices_from_env, solve_multi_device
-        from caliscope_amd.hip_engine import HipEngine
-
         if devices is None:
             devices = devices_from_env()
         if devices is not None and len(devices) > 1:
@@ -158,8 +156,16 @@ def least_squares(
             if res.status == -1:
                 raise ValueError("Residuals are not finite in the initial point.")
             return _result_of(res, verbose)
-        engine_factory = (lambda prob: HipEngine(prob, device_id=int(devices[0]))) if devices else HipEngine
-    engine = engine_factory(problem)
+        # the default path: a handle built for the same observations by the previous call is reused (engine_cache)
+        from caliscope_amd import engine_cache
+
+        cache_key = None
+        engine, cache_key = engine_cache.checkout(problem, device_id=int(devices[0]) if devices else -1)
+        cached = True
+    else:
+        engine = engine_factory(problem)
+        cached = False
+    solved = False
     try:
         feasible = None
         if bounded:
@@ -182,10 +188,14 @@ def least_squares(
                 # (it stalls where scipy's Coleman-Li iteration converges)
                 raise BackendError("CBA_HOST_LOOP=python has no bounded (Coleman-Li) variant: solves with free intrinsics need the native driver")
             res = trf_solve(engine, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
+        solved = True
     finally:
-        close = getattr(engine, "close", None)
-        if close is not None:
-            close()
+        if cached and solved:
+            engine_cache.checkin(cache_key, engine)
+        else:  # a handle that raised is not kept
+            close = getattr(engine, "close", None)
+            if close is not None:
+                close()
 
     return _result_of(res, verbose)
 

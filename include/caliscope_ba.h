@@ -274,6 +274,11 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
 /* The reduced camera system of the LAST cba_newton_step: S [ncp][ncp] symmetric (full), rhs [ncp]. */
 int cba_reduced_system(cba_problem* p, double* S, double* rhs);
 
+/* Change the robust loss of an existing problem (same observations, same camera tables): what a caller does between the stages of
+ * calibrate_extrinsics (linear, then soft_l1 on the same data: reference core/calibrate_extrinsics.py:206,230-238) without paying for the
+ * Schur plan again.  The next cba_begin / cba_solve starts from scratch with the new loss. */
+int cba_set_loss(cba_problem* p, int32_t loss, double f_scale);
+
 /* ---- introspection ------------------------------------------------------------------------------ */
 typedef struct {
   int32_t n_cams, n_points, n_cam_params, n_params;

@@ -178,6 +178,13 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   return CBA_OK;
 }
 
+int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
+  if (!p || !p->model) return failf(CBA_ERR_INVALID, "cba_set_loss: null problem");
+  if (loss < CBA_LOSS_LINEAR || loss > CBA_LOSS_ARCTAN || (loss != CBA_LOSS_LINEAR && !(f_scale > 0.0))) return failf(CBA_ERR_INVALID, "cba_set_loss: bad loss / f_scale");
+  p->model->loss = loss; p->model->f_scale = f_scale;
+  return CBA_OK;
+}
+
 int cba_get_info(cba_problem* p, cba_info* out) {
   std::memset(out, 0, sizeof(*out));
   const BaModel* md = p->model;

@@ -196,6 +196,29 @@ def test_constraint_rows_through_the_cpu_build(cpu_lib):
     assert out["status"] > 0 and out["rel_cost"] < 1e-8 and out["pos"] < 1e-6 and out["ang"] < 1e-6 and abs(out["scale"] - 1) < 1e-6, out
 
 
+def test_engine_cache_and_set_loss_on_the_cpu_build(cpu_lib):
+    """Two least_squares calls on the same observations: the second reuses the first call's handle and only changes the loss."""
+    out = _run(cpu_lib, """
+        import json
+        import numpy as np
+        from caliscope_amd import engine_cache
+        from caliscope_amd.least_squares import least_squares
+        from oracle.solver import optimize_scipy
+        from tests.helpers import small_problem
+        sc, par, x0 = small_problem(n_cams=4, n_points=80, k=4, loss="huber", outliers=0.05)
+        a = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+        fs = sc.f_scale_1px() * 2.0
+        kw = dict(x_scale="jac", bounds=par.bounds(), method="trf")
+        first = least_squares(None, x0, args=a + (None,) * 4, **kw)
+        robust = least_squares(None, first.x, args=a + (None,) * 4, loss="huber", f_scale=fs, **kw)
+        ref = optimize_scipy(*a, first.x, loss="huber", f_scale=fs)
+        keep = np.arange(len(sc.camera_indices)) % 5 != 0
+        sub = least_squares(None, x0, args=(par, sc.camera_indices[keep], sc.image_coords[keep], sc.obj_indices[keep]) + (None,) * 4, **kw)
+        print(json.dumps(dict(stats=engine_cache.stats, rel=float(abs(robust.cost - ref.cost) / ref.cost), ok=bool(first.status > 0 and robust.status > 0 and sub.status > 0))))
+    """)
+    assert out["ok"] and out["stats"] == {"hits": 1, "misses": 2} and out["rel"] < 1e-6, out
+
+
 def test_unsupported_entries_fail_loudly(cpu_lib):
     out = _run(cpu_lib, """
         import json

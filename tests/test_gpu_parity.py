@@ -341,6 +341,32 @@ def test_capture_volume_optimize_real_session(golden_dir):
     assert r3 <= r2 < r1
 
 
+def test_handle_is_reused_for_the_same_observations_with_another_loss():
+    """The stages of calibrate_extrinsics solve the same observations with a linear and then a robust loss: the second call finds the
+    first call's handle (engine_cache), changes the loss (cba_set_loss) and returns what a fresh handle returns; other observations miss."""
+    from caliscope_amd import engine_cache
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0 = small_problem(n_cams=6, n_points=300, k=6, loss="huber", outliers=0.05)
+    a = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    fs = sc.f_scale_1px() * 2.0
+    engine_cache.clear()
+    h0, m0 = engine_cache.stats["hits"], engine_cache.stats["misses"]
+    kw = dict(x_scale="jac", bounds=par.bounds(), method="trf")
+    first = least_squares(None, x0, args=a + (None,) * 4, **kw)
+    robust = least_squares(None, first.x, args=a + (None,) * 4, loss="huber", f_scale=fs, **kw)
+    assert (engine_cache.stats["hits"] - h0, engine_cache.stats["misses"] - m0) == (1, 1)
+    with HipEngine(BAProblem(*a, loss="huber", f_scale=fs)) as fresh:
+        ref = fresh.solve(first.x)
+    assert robust.status == ref.status and abs(robust.nfev - ref.nfev) <= 1 and abs(robust.cost - ref.cost) <= 1e-7 * ref.cost
+    again = least_squares(None, x0, args=a + (None,) * 4, **kw)  # back to the linear loss on the kept handle
+    assert engine_cache.stats["hits"] - h0 == 2 and abs(again.cost - first.cost) <= 1e-7 * first.cost
+    keep = np.arange(len(sc.camera_indices)) % 7 != 0  # a filtered observation set: another problem
+    sub = least_squares(None, x0, args=(par, sc.camera_indices[keep], sc.image_coords[keep], sc.obj_indices[keep]) + (None,) * 4, **kw)
+    assert sub.status > 0 and engine_cache.stats["misses"] - m0 == 2
+    engine_cache.clear()
+
+
 def test_strict_raises_when_not_converged_and_soft_l1_stage():
     from caliscope_amd.capture_volume import CaptureVolume
     from caliscope_amd.exceptions import CalibrationError
@@ -501,9 +527,9 @@ def test_cba_solve_matches_python_driver(name):
             pos, ang, _ = aligned_difference(par, got.x, ref.x)
             assert pos < 1e-4 and ang < 1e-4
         again = eng.solve(None, lb=lb[:ncp] if bounded else None, ub=ub[:ncp] if bounded else None, fetch_x=False)  # restart from the x0 on the device
-        # two runs of one problem differ by the order of the FP64 atomics: a gradient norm that lands on either side of gtol
-        # moves the stop by one evaluation
-        assert again.x is None and again.status > 0 and abs(again.nfev - got.nfev) <= 1 and abs(again.cost - got.cost) <= 1e-9 * got.cost
+        # two runs of one problem differ by the order of the FP64 atomics: a cost reduction or a gradient norm that lands on either side of
+        # ftol / gtol moves the stop by one evaluation, and the cost by what that evaluation still gains (~ftol = 1e-8 relative)
+        assert again.x is None and again.status > 0 and abs(again.nfev - got.nfev) <= 1 and abs(again.cost - got.cost) <= 1e-7 * got.cost
         capped = eng.solve(x0, max_nfev=2, ftol=1e-15, xtol=1e-15, gtol=1e-15)
         assert capped.status == 0 and capped.nfev == 2
 
