@@ -824,9 +824,10 @@ template <int NC> struct SchurRec {
   static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride, 16-byte pieces, odd: 7 / 11 (LDS bank spread; the same
                                                           // stride in HBM lets k_schur_reg3 load records straight into LDS)
   static constexpr int REC = 2 * LST;                     // record stride in LDS, doubles: 14 / 22
-  // record stride in HBM, doubles: the LDS stride.  (16 doubles = one 128-byte line per record for NC = 6 was measured: the pair kernel's issue phase
-  // shrank by 7 %, k_tprep grew by as much, and the pass moved 1.15 GB instead of 0.93 GB through HBM.)
-  static constexpr int HREC = REC;
+  // record stride in HBM, doubles: the pieces that carry data, 12 / 22 (96 / 176 bytes).  NC = 6: the seventh piece of the LDS stride is padding
+  // for the bank spread only; the pair kernel's load lanes that land on it fetch the sixth piece again.  (128-byte records, one line each, were
+  // measured: the pair kernel's issue phase shrank by 7 %, k_tprep grew by as much, and the pass moved 1.15 GB instead of 0.93 GB through HBM.)
+  static constexpr int HREC = 2 * NPH;
   static constexpr int STAGE = (HREC / 2) | 1;            // k_tprep's transposing LDS stage: record stride in pieces, odd (bank spread)
 };
 static_assert(SchurRec<6>::REC == 14 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");
@@ -1137,7 +1138,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     slot_piece(k, el, piece);
     const bool useB = EPW > WAVE && k * WAVE >= WAVE * NPH;  // slots >= 64: the second index register
     const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC)[piece];
+    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC)[piece];  // (piece < NPH here)
   };
   auto pair = [&](unsigned code) {
     const double2* Ri = sh_p + (code & 0xffffu);
@@ -1424,7 +1425,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
       el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
       const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
       const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + piece;
+      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
