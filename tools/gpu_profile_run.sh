@@ -1,8 +1,9 @@
 #!/bin/bash
-# round 2 validation + profiles (after the pair-kernel work)
+# the validation + profile run whose outputs are summarised under profiles/ (gpurun -- bash tools/gpu_profile_run.sh): full GPU suite, smoke, bench with
+# the CPU baseline, rocprofv3 kernel traces (cfg4, cfg5, cfg2+3), HBM counters (cfg4, cfg5), roctx markers, phase clocks of the pair kernel, Cholesky trace
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp PYTHONUNBUFFERED=1 CBA_GROUP_TIMEOUT_S=15
-O=$GRAFT_REPO_ROOT/gpurun_out/r3f; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/profile_run; mkdir -p $O
 timeout 700 python -m pytest tests -m gpu -x -q --timeout=150 > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log
 timeout 60 python __graft_entry__.py --smoke > $O/smoke.log 2>&1
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
