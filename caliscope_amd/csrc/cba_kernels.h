@@ -829,6 +829,9 @@ template <int NC> struct SchurRec {
   // measured: the pair kernel's issue phase shrank by 7 %, k_tprep grew by as much, and the pass moved 1.15 GB instead of 0.93 GB through HBM.)
   static constexpr int HREC = 2 * NPH;
   static constexpr int STAGE = (HREC / 2) | 1;            // k_tprep's transposing LDS stage: record stride in pieces, odd (bank spread)
+  // waves of a k_tprep workgroup that stage at the same time.  NC = 9: two, in two turns — with a stage for all four (45 KB) next to the camera
+  // table the kernel had 92 KB of LDS and ran one workgroup per CU
+  static constexpr int STAGE_WAVES = (NC == 9) ? 2 : 4;
 };
 static_assert(SchurRec<6>::REC == 14 && SchurRec<6>::LST == 7 && SchurRec<9>::REC == 22 && SchurRec<9>::LST == 11, "record sizes");
 
@@ -859,12 +862,13 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         int n_cams, int loss, double f_scale, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
         double* __restrict__ partial_b, int* __restrict__ flags, DetPlan det = DetPlan{nullptr, nullptr}) {
-  constexpr int REC = SchurRec<NC>::HREC, NP = REC / 2, SP = SchurRec<NC>::STAGE;  // the records as they lie in HBM
+  constexpr int REC = SchurRec<NC>::HREC, NP = REC / 2, SP = SchurRec<NC>::STAGE, SW = SchurRec<NC>::STAGE_WAVES;  // the records as they lie in HBM
+  static_assert((BLOCK / WAVE) % SW == 0, "stage turns");
   constexpr bool DET = DETM > 0;
   if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam)
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double2* sh_stage = reinterpret_cast<double2*>(sh);        // [BLOCK / WAVE][WAVE * SP]  record transpose, per wave
-  double* sh_tab = sh + (size_t)BLOCK * SP * 2;
+  double2* sh_stage = reinterpret_cast<double2*>(sh);        // [SW][WAVE * SP]  record transpose, per wave (of a turn)
+  double* sh_tab = sh + (size_t)SW * WAVE * SP * 2;
   double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad (DET: the parking area of det_round, then the chunk's camera order)
   int* sh_perm = reinterpret_cast<int*>(sh_b + DET_ROUND * DET_LD);
   int* sh_cs = sh_perm + CHUNK;
@@ -880,7 +884,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
   const int wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  double2* stage = sh_stage + wv * WAVE * SP;
+  double2* stage = sh_stage + (wv % SW) * WAVE * SP;
   bool fail = false;
   const int last_obs = max(chunk_start[n_chunks] - 1, 0);
   int ch = blockIdx.x;
@@ -945,23 +949,29 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     // The 64 records of a wave are one contiguous run of Trec.  A lane storing its own record issues 16-byte stores one
     // record apart (64 cache lines per instruction: the store path stalled, 45 % issue-stall cycles); so the wave transposes
     // through LDS and every store instruction writes 1 KB contiguous.
-#pragma unroll
-    for (int k = 0; k < NP; ++k) stage[lane * SP + k] = make_double2(rec[2 * k], rec[2 * k + 1]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int w0 = o0 + wv * WAVE;                       // first observation of this wave
     const int n_pieces = max(0, min(WAVE, o1 - w0)) * NP;  // live pieces of this wave
     double2* dst = reinterpret_cast<double2*>(Trec + (long)w0 * REC);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const int e = k * WAVE + lane;
-      const double2 v = stage[(e / NP) * SP + e % NP];
-      if (e < n_pieces) dst[e] = v;
+    for (int turn = 0; turn < (BLOCK / WAVE) / SW; ++turn) {
+      if (wv / SW == turn) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) stage[lane * SP + k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int e = k * WAVE + lane;
+          const double2 v = stage[(e / NP) * SP + e % NP];
+          if (e < n_pieces) dst[e] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (SW < BLOCK / WAVE) __syncthreads();  // the next turn's waves reuse the stage
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (DET) {  // rhs terms: fixed-order sums per camera (one round: NC <= DET_ROUND values per observation)
       __syncthreads();
       det_round<DM>(bval, sh_b, sh_perm, sh_cs, n_cams, dacc);
@@ -2425,33 +2435,64 @@ __device__ __forceinline__ double column_sum(const double* __restrict__ partial,
 __global__ void __launch_bounds__(BLOCK)
 k_lin_finish(const double* __restrict__ partial_lin, const double* __restrict__ partial_max, int rows_lin,
              const double* __restrict__ partial_jv, int rows_jv, double radius, double* __restrict__ scal, double* __restrict__ fz) {
-  __shared__ double sh_red[BLOCK / WAVE];
-  for (int j = 0; j < 4; ++j) {
-    const double r = column_sum(partial_lin, rows_lin, 4, j, sh_red);
-    if (threadIdx.x == 0) scal[j] = r;
+  // nine sums and a maximum in ONE pass and one barrier (column by column — ten block reductions in a row — the kernel took 10.6 us);
+  // per value the order of the additions is the one of column_sum / block_sum
+  __shared__ double sh_red[10][BLOCK / WAVE];
+  double v[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) v[q] = 0.0;
+  for (int b = threadIdx.x; b < rows_lin; b += BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += partial_lin[(long)b * 4 + j];
+    v[4] = fmax(v[4], partial_max[b]);
   }
-  {
-    double m = 0.0;
-    for (int b = threadIdx.x; b < rows_lin; b += BLOCK) m = fmax(m, partial_max[b]);
-    const double r = block_max(m, sh_red);
-    if (threadIdx.x == 0) scal[4] = r;
+  for (int b = threadIdx.x; b < rows_jv; b += BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[5 + j] += partial_jv[(long)b * 4 + j];
   }
-  for (int j = 0; j < 4; ++j) {
-    const double r = column_sum(partial_jv, rows_jv, 4, j, sh_red);
-    if (threadIdx.x == 0) scal[12 + j] = r;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double r = (q == 4) ? wave_max(v[q]) : wave_sum(v[q]);
+    if (lane == 0) sh_red[q][w] = r;
   }
-  if (threadIdx.x == 0) fused_lam(scal, radius, fz);  // thread 0 wrote every slot it reads
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      double r = 0.0;
+      for (int i = 0; i < BLOCK / WAVE; ++i) r = (q == 4) ? fmax(r, sh_red[q][i]) : r + sh_red[q][i];
+      scal[q < 5 ? q : 12 + (q - 5)] = r;
+    }
+    fused_lam(scal, radius, fz);
+  }
 }
 
 // reduction of the step scalars and the subspace step in one launch
 __global__ void __launch_bounds__(BLOCK)
 k_step_finish(const double* __restrict__ partial, int rows, double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
-  __shared__ double sh_red[BLOCK / WAVE];
-  for (int j = 0; j < 4; ++j) {
-    const double r = column_sum(partial, rows, 4, j, sh_red);
-    if (threadIdx.x == 0) scal[16 + j] = r;
+  __shared__ double sh_red[4][BLOCK / WAVE];  // four sums, one pass, one barrier (as k_lin_finish)
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < rows; b += BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += partial[(long)b * 4 + j];
   }
-  if (threadIdx.x == 0) fused_subspace(scal, flags, fz);
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double r = wave_sum(v[j]);
+    if (lane == 0) sh_red[j][w] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double r = 0.0;
+      for (int i = 0; i < BLOCK / WAVE; ++i) r += sh_red[j][i];
+      scal[16 + j] = r;
+    }
+    fused_subspace(scal, flags, fz);
+  }
 }
 
 // End of a primitive: the host-visible scalars and flags go straight to pinned host memory (mapped into the device's

@@ -526,8 +526,8 @@ template <int NC> struct RegCfg;
 template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
-  if (p->det_m) return ((size_t)BLOCK * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
-  return ((size_t)BLOCK * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
+  if (p->det_m) return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
+  return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
 }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads (the wide kernel: Reg3Cfg<6, true>::GROUP)
