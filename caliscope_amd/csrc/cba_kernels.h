@@ -299,7 +299,10 @@ __device__ __forceinline__ double cam_block_value(int v, const double (*A)[MAX_N
   return 0.0;
 }
 
-template <int NC, int DETM = 0>  // DETM > 0: deterministic variant, DETM tasks per thread and round (cameras <= DETM * 256 / 9)
+// CAMG: the camera table stays in global memory (48 doubles per camera, read through the vector cache) instead of LDS: for nine-parameter cameras
+// and more than ~64 of them the table, the per-camera accumulators and the point stage together exceed half of the LDS, and the kernel ran one
+// workgroup per CU.
+template <int NC, int DETM = 0, bool CAMG = false>  // DETM > 0: deterministic variant, DETM tasks per thread and round (cameras <= DETM * 256 / 9)
 __global__ void __launch_bounds__(BLOCK)
 k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
@@ -312,7 +315,10 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_U = sh_tab + n_cams * CAMTAB_LDS;                         // DET: the parking area of det_round instead
+  double* sh_U = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);            // DET: the parking area of det_round instead
+  auto cam_of = [&](int cam) -> const CamTab& {
+    return CAMG ? *reinterpret_cast<const CamTab*>(tab + (long)cam * CAMTAB_DOUBLES) : cam_at(sh_tab, cam);
+  };
   double* sh_pt = sh_U + (DET ? DET_ROUND * DET_LD : n_cams * UP::STRIDE);
   double* sh_red = sh_pt + 9 * CHUNK;
   int* sh_perm = reinterpret_cast<int*>(sh_red + 8);                   // DET: [CHUNK] + [n_cams + 1]
@@ -324,7 +330,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   for (int r = 0; r < DROUNDS; ++r)
 #pragma unroll
     for (int m = 0; m < DM; ++m) dacc[r][m] = 0.0;
-  stage_camtab(sh_tab, tab, n_cams);
+  if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
   if (!DET)
     for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
   __syncthreads();
@@ -363,7 +369,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
       double B[2][3];
-      cost += obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss,
+      cost += obs_linearize<NC>(cam_of(cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss,
                                 f_scale, e, A, B);
       if (!isfinite(e[0] + e[1])) bad = true;  // a trial point built directly by this pass (fused step): scipy's isfinite(f_new) test
       pv[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
@@ -375,7 +381,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       pv[6] = B[0][0] * e[0] + B[1][0] * e[1];
       pv[7] = B[0][1] * e[0] + B[1][1] * e[1];
       pv[8] = B[0][2] * e[0] + B[1][2] * e[1];
-      const int np = (int)cam_at(sh_tab, cam).nparams;
+      const int np = (int)cam_of(cam).nparams;
       np_det = np;
       if (!DET) {
         double* Uc = sh_U + cam * UP::STRIDE;

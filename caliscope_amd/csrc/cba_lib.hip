@@ -508,7 +508,15 @@ static int allow_lds(K kernel, size_t bytes) {
 }
 
 static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + 8) * 8; }
+// k_build<NC, 0, true> reads the camera table from global memory: chosen when the table is what keeps a second workgroup off the CU
+template <int NC> static size_t lds_build_camg(const cba_problem* p) { return ((size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8; }
+template <int NC> static bool build_camg(const cba_problem* p) {
+  const size_t with_tab = ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
+  if (const char* e = std::getenv("CBA_BUILD_CAMG")) return std::atoi(e) != 0 && !p->det_m;
+  return !p->det_m && with_tab > 80 * 1024 && lds_build_camg<NC>(p) <= 80 * 1024;
+}
 template <int NC> static size_t lds_build(const cba_problem* p) {
+  if (build_camg<NC>(p)) return lds_build_camg<NC>(p);
   if (p->det_m)  // parking area of the fixed-order sums instead of the packed blocks, + the chunk's camera order (ints)
     return ((size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD + 9 * CHUNK + 8) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
   return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
@@ -822,6 +830,7 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_cost<false>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
+  if ((rc = allow_lds(k_build<NC, 0, true>, lds_build<NC>(p)))) return rc;
   if (p->det_m) {
     if ((rc = allow_lds(k_build<NC, 3>, lds_build<NC>(p)))) return rc;
     if ((rc = allow_lds(k_build<NC, 5>, lds_build<NC>(p)))) return rc;
@@ -1217,7 +1226,9 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
       case 3: launch_build(k_build<NC, 3>); break;
       case 5: launch_build(k_build<NC, 5>); break;
       case 8: launch_build(k_build<NC, 8>); break;
-      default: launch_build(k_build<NC, 0>); break;
+      default:
+        if (build_camg<NC>(p)) launch_build(k_build<NC, 0, true>); else launch_build(k_build<NC, 0>);
+        break;
     }
   }
   {
