@@ -818,8 +818,8 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 // The record is COMPACT.  The camera block factors (ba_math.h, project_full): A = G [C | I | A_intr] with G = d(pixel)/dX_c
 // (2 x 3), C = -[Y]x J_l the derivative of the rotated point Y = R X by the rotation vector, so
 //     T = [ J_l^T [Y]x Q ;  Q ;  T_intr ],     Q = G^T Z  (3 x 3: rows 3..5 of T),   T_intr = A_intr^T Z  (rows 6..8, NC = 9).
-// The record holds Y (3), Q (9) and T_intr (9): 12 doubles, stored 112 B apart (NC = 6), or 21 -> 22 doubles = 176 B (NC = 9)
-// instead of 144 / 240 B; the pair kernel gathers, stages and reads a third less, and it never forms the top rows: with D = Q_i Q_j^T
+// The record holds Y (3), Q (9) and T_intr (9): 12 doubles = 96 B (NC = 6), or 21 -> 22 doubles = 176 B (NC = 9) instead of 144 / 240 B
+// (in LDS: 112 / 176 B apart, an odd stride in 16-byte pieces); the pair kernel gathers, stages and reads a third less, and it never forms the top rows: with D = Q_i Q_j^T
 //     [Y_i]x D [Y_j]x^T | [Y_i]x D | D [Y_j]x^T | D
 // are the four 3 x 3 quarters of the PRIMED block T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr] (99 FP64 operations per pair
 // instead of 108 on 18 + 18 doubles).  The per-camera factor J_l^T is applied once per block at the end (k_unprime).
@@ -827,8 +827,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 template <int NC> struct SchurRec {
   static constexpr int NVAL = (NC == 9) ? 21 : 12;        // doubles that carry data
   static constexpr int NPH = (NVAL + 1) / 2;              // 16-byte pieces that carry data: 6 / 11
-  static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride, 16-byte pieces, odd: 7 / 11 (LDS bank spread; the same
-                                                          // stride in HBM lets k_schur_reg3 load records straight into LDS)
+  static constexpr int LST = (NPH & 1) ? NPH : NPH + 1;   // record stride in LDS, 16-byte pieces, odd: 7 / 11 (bank spread)
   static constexpr int REC = 2 * LST;                     // record stride in LDS, doubles: 14 / 22
   // record stride in HBM, doubles: the pieces that carry data, 12 / 22 (96 / 176 bytes).  NC = 6: the seventh piece of the LDS stride is padding
   // for the bank spread only; the pair kernel's load lanes that land on it fetch the sixth piece again.  (128-byte records, one line each, were
