@@ -2078,91 +2078,133 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
 #undef CHOL_STAMP
 }
 
-// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block (last
-// to first): wave 0 solves the NB x NB triangle, then every thread i < k0 folds the block into y_i.  The loads of
-// a block's update panel L[k0 .. k0+nb, i] and of the next diagonal block do not depend on the solution, so they
-// are issued before the triangle solve and land while it runs (the first version loaded after each barrier: 5 us
-// per block, all of it exposed latency).
+// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block kb (last to first):
+//   x_kb = X_kb^T y_kb     with the stored inverse X_kb = L_kb,kb^-1 (a 32-term dot product per lane of half a wave; the triangle solve it
+//                          replaces was 32 dependent readlane steps, 0.9 us per block),
+//   y_i -= sum_t L[k0 + t][i] x_t  for every i < k0 (one thread per column, the block's update panel in registers).
+// Everything a block needs from global memory is loaded TWO blocks ahead: its update panel into one of two register sets, its inverse
+// into registers and from there, a block ahead, into one of two LDS copies.  History: loads issued one block ahead landed behind the
+// 0.9 us triangle solve they were meant to overlap with: 3.9 us per block, 47 us for ncp = 384, of which ~2 us per block were exposed
+// load latency; a first inverse-based variant without the deeper prefetch was slower still.
 constexpr int BACK_THREADS = 512;
 __global__ void __launch_bounds__(BACK_THREADS)
-k_chol_backward(const double* __restrict__ L, int n, int ldw, double* __restrict__ out) {  // (a variant that multiplies by the stored
-  // inverses X_k instead of solving the triangles and loads only the columns the fold uses measured 15 us slower: reverted)
-  extern __shared__ __attribute__((aligned(16))) double y[];  // n
-  __shared__ double D[NB][NB + 1];
-  constexpr int EPT = NB * NB / BACK_THREADS;
-  for (int i = threadIdx.x; i < n; i += BACK_THREADS) y[i] = L[(long)n * ldw + i];
-  const int lane = threadIdx.x & (WAVE - 1);
+k_chol_backward(const double* __restrict__ L, int n, int ldw, const double* __restrict__ Xinv, double* __restrict__ out,
+                long long* __restrict__ trace = nullptr) {  // trace (CBA_CHOL_TRACE=1): eight 100 MHz stamps
+  extern __shared__ __attribute__((aligned(16))) double y[];  // n + NB
+  __shared__ double sh_X[2][NB][NB + 1];
+  __shared__ double sh_x[NB];
+  constexpr int EPT = NB * NB / BACK_THREADS;  // elements of an inverse per thread
+  const int tid = threadIdx.x;
   const int nblk = (n + NB - 1) / NB;
-  const int dr = threadIdx.x / NB, dc = threadIdx.x % NB;  // elements (dr + h * BACK_THREADS / NB, dc) of a diagonal block
-  double dreg[EPT];
-  // loads are unconditional (clamped addresses, select afterwards): a load under a divergent branch would make the
-  // compiler drain vmcnt at the join, i.e. before the triangle solve the loads are meant to overlap with
-  auto load_diag = [&](int kb_req) {
+  const bool stamp = trace != nullptr && tid == 0;
+  if (stamp) trace[0] = wall_clock64();
+  for (int i = tid; i < n + NB; i += BACK_THREADS) y[i] = (i < n) ? L[(long)n * ldw + i] : 0.0;  // NB zeros behind y: the last block may be partial
+  // loads are unconditional (clamped block index, results of a block < 0 are never used): a load under a branch makes the compiler
+  // drain vmcnt at the join
+  // The prefetching loads are inline asm: the compiler does not track them, so it inserts no waits of its own for them (for a register
+  // loaded behind the loop's back edge that is a vmcnt(0) at the first use, i.e. a wait for the NEXT block's loads too); the one wait they
+  // need is the explicit s_waitcnt at the top of a step.  (Its own loads stay correct: vmcnt counts in order, extra loads in flight only make
+  // a compiler-inserted wait stricter.)
+  auto asm_load = [](const double* ptr) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+  };
+  auto load_x = [&](int kb_req, double (&xr)[EPT]) {
     const int kb = max(kb_req, 0);
-    const int k0 = kb * NB, nb = min(NB, n - k0);
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) xr[h] = asm_load(Xinv + (long)kb * NB * NB + tid + h * BACK_THREADS);
+  };
+  auto store_x = [&](int kb, const double (&xr)[EPT]) {
 #pragma unroll
     for (int h = 0; h < EPT; ++h) {
-      const int r = dr + h * (BACK_THREADS / NB);
-      const double v = L[(long)(k0 + min(r, nb - 1)) * ldw + k0 + min(dc, nb - 1)];
-      dreg[h] = (r < nb && dc <= r) ? v : (r == dc ? 1.0 : 0.0);
+      const int e = tid + h * BACK_THREADS;
+      sh_X[kb & 1][e / NB][e % NB] = xr[h];
     }
   };
-  // update panel of block kb, column i: L[k0 + t][i], t < NB (rows clamped into the block, masked when used)
-  const int i = threadIdx.x;
-  double lp[NB];
-  auto load_panel = [&](int kb_req) {
+  auto load_panel = [&](int kb_req, double (&lp)[NB]) {  // column min(tid, n - 1) of rows k0 .. k0 + NB (clamped into the block)
     const int kb = max(kb_req, 0);
     const int k0 = kb * NB, nb = min(NB, n - k0);
+    // ONE running address (32 precomputed ones per panel spilled).  Columns >= k0 are not part of the panel: their threads load one fixed
+    // word instead (the same number of loads in every wave keeps the vmcnt arithmetic of `step` valid; all 512 threads loading real columns
+    // made the substitution bound by the one CU's path to the L2: 131 KB per block)
+    const bool live = tid < k0;
+    const double* pp = live ? L + (long)k0 * ldw + tid : L;
 #pragma unroll
-    for (int t = 0; t < NB; ++t) lp[t] = L[(long)(k0 + min(t, nb - 1)) * ldw + min(i, n - 1)];
+    for (int t = 0; t < NB; ++t) {
+      lp[t] = asm_load(pp);
+      pp += (live && t + 1 < nb) ? ldw : 0;
+    }
   };
-  load_diag(nblk - 1);
-  load_panel(nblk - 1);
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int k0 = kb * NB;
-    const int nb = min(NB, n - k0);
+  double lpA[NB], lpB[NB], xrA[EPT], xrB[EPT];
+  const int last = nblk - 1;
+  load_x(last, xrA);
+  load_x(last - 1, xrB);
+  load_panel(last, lpA);
+  load_panel(last - 1, lpB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int h = 0; h < EPT; ++h) D[dr + h * (BACK_THREADS / NB)][dc] = dreg[h];
-    double lcur[NB];
+  for (int h = 0; h < EPT; ++h) asm volatile("" : "+v"(xrA[h]));
+  store_x(last, xrA);
+  if (stamp) trace[1] = wall_clock64();
+  // from here on the loads in flight are, oldest first: [inverse last - 2 | panel .. ] ... see the count in `step`
+  load_x(last - 2, xrA);
+  // block kb with its panel in `lp`; `xr` holds the inverse of block kb - 1 (parked in LDS here, then reloaded with block kb - 3's)
+  auto step = [&](int kb, double (&lp)[NB], double (&xr)[EPT]) {
+    const int k0 = kb * NB, nb = min(NB, n - k0);
+    // `lp` and `xr` were loaded two steps ago; what was issued since (the other inverse and the other panel: EPT + NB loads) may stay in
+    // flight.  The compiler cannot see this wait, and for registers loaded behind the loop's back edge it would put a vmcnt(0) in front of
+    // their first use — i.e. wait for the loads of the NEXT block as well: the values pass through an empty asm (as in schur_reg3_body).
+    static_assert(NB + EPT == 34, "vmcnt below");
+    asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < NB; ++t) lcur[t] = lp[t];
-    __syncthreads();
-    // in flight during this block's solve and update: the next block's diagonal block and update panel
-    load_diag(kb - 1);
-    load_panel(kb - 1);
-    if (threadIdx.x < WAVE) {
-      // D is identity-padded to NB x NB: the triangle is solved at full size from registers (column `lane` of D)
-      const int c = lane & (NB - 1);
-      double col[NB];
+    for (int t = 0; t < NB; ++t) asm volatile("" : "+v"(lp[t]));
 #pragma unroll
-      for (int t = 0; t < NB; ++t) col[t] = D[t][c];
-      double xj = (lane < nb) ? y[k0 + lane] : 0.0;
-      const double dinv = 1.0 / D[c][c];
+    for (int h = 0; h < EPT; ++h) asm volatile("" : "+v"(xr[h]));
+    __syncthreads();  // y_kb is final (the folds of block kb + 1), the inverse of block kb is in its LDS copy
+    if (tid < NB) {
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = NB - 1; t >= 0; --t) {
-        const double xt = readlane_f64(xj * dinv, t);
-        if (lane == t) xj = xt;
-        else if (lane < t) xj -= col[t] * xt;
+      for (int r = 0; r < NB; ++r) a[r & 3] = fma(sh_X[kb & 1][r][tid], y[k0 + r], a[r & 3]);  // (rows >= nb: zeros behind y, times the identity padding)
+      const double xt = (a[0] + a[1]) + (a[2] + a[3]);
+      sh_x[tid] = (tid < nb) ? xt : 0.0;
+    }
+    store_x(kb + 1, xr);  // the copy block kb + 1 used: now block kb - 1's (kb = 0: nobody reads it)
+    load_x(kb - 3, xr);
+    __syncthreads();  // x_kb
+    if (tid < nb) y[k0 + tid] = sh_x[tid];
+    {
+      double acc[2] = {0.0, 0.0};
+#pragma unroll
+      for (int t0 = 0; t0 < NB; t0 += 8) {  // eight at a time: with all 32 LDS reads hoisted in front of the FMAs the two panel sets spilled
+#pragma unroll
+        for (int t = t0; t < t0 + 8; ++t) acc[t & 1] = fma(lp[t], sh_x[t], acc[t & 1]);  // (t >= nb: x_t = 0)
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (lane < nb) y[k0 + lane] = xj;
+      if (tid < k0) y[tid] -= acc[0] + acc[1];
     }
-    __syncthreads();
-    if (i < k0) {
-      double acc = 0.0;
-#pragma unroll
-      for (int t = 0; t < NB; ++t)
-        if (t < nb) acc += lcur[t] * y[k0 + t];
-      y[i] -= acc;
-    }
-    for (int i2 = threadIdx.x + BACK_THREADS; i2 < k0; i2 += BACK_THREADS) {  // wider systems: the rest of the panel
+    for (int i2 = tid + BACK_THREADS; i2 < k0; i2 += BACK_THREADS) {  // wider systems: the rest of the panel
       double acc = 0.0;
 #pragma unroll 8
-      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * ldw + i2] * y[k0 + t];
+      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * ldw + i2] * sh_x[t];
       y[i2] -= acc;
     }
+    __builtin_amdgcn_sched_barrier(0);  // (hoisted in front of the fold, the reload needs a third set of panel registers)
+    load_panel(kb - 2, lp);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kb = last; kb >= 0; kb -= 2) {
+    step(kb, lpA, xrB);
+    if (stamp && kb == last) trace[2] = wall_clock64();
+    if (kb >= 1) step(kb - 1, lpB, xrA);
+    if (stamp && kb == last) trace[3] = wall_clock64();
   }
+  if (stamp) trace[4] = wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches (clamped, unused)
+  if (stamp) trace[5] = wall_clock64();
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += BACK_THREADS) out[i] = y[i];
+  for (int i = tid; i < n; i += BACK_THREADS) out[i] = y[i];
+  if (stamp) trace[6] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -876,7 +876,7 @@ static int configure_kernels(cba_problem* p) {
   }
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
-  if ((rc = allow_lds(k_chol_backward, (size_t)p->ncp * 8))) return rc;
+  if ((rc = allow_lds(k_chol_backward, (size_t)(p->ncp + NB) * 8))) return rc;
   return CBA_OK;
 }
 
@@ -1091,7 +1091,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
   }
   TRY(dev_alloc(p, &p->S, (size_t)ncp * ncp)); p->ldw = (ncp + 3) & ~3;
-  if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 1) * 8));
+  if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 2) * 8));
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->Xinv, (size_t)((ncp + NB - 1) / NB + 1) * NB * NB));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
@@ -1364,7 +1364,8 @@ static int enqueue_cholesky(cba_problem* p) {
     const int x = nbk - k - 1, n_trailing = k < 1 ? 0 : x * (x + 1) / 2;
     hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace, p->Xinv);
   }
-  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)n * 8, p->stream, p->Lbuf, n, p->ldw, p->s);
+  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)(n + NB) * 8, p->stream, p->Lbuf, n, p->ldw, p->Xinv, p->s,
+                     p->chol_trace ? p->chol_trace + (size_t)((n + NB - 1) / NB + 1) * 8 : (long long*)nullptr);
   return CBA_OK;
 }
 
@@ -1386,12 +1387,17 @@ static int ensure_cholesky_graph(cba_problem* p) {
 static int run_cholesky(cba_problem* p) {
   if (p->chol_trace) {  // traced run: plain launches, then dump the stamps of the critical workgroups
     const int nbk = (p->ncp + NB - 1) / NB;
-    HIPCHK(hipMemsetAsync(p->chol_trace, 0, (size_t)(nbk + 1) * 8 * sizeof(long long), p->stream));
+    HIPCHK(hipMemsetAsync(p->chol_trace, 0, (size_t)(nbk + 2) * 8 * sizeof(long long), p->stream));
     int rc = enqueue_cholesky(p);
     if (rc) return rc;
-    std::vector<long long> h((size_t)(nbk + 1) * 8);
+    std::vector<long long> h((size_t)(nbk + 2) * 8);
     HIPCHK(hipMemcpyAsync(h.data(), p->chol_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
+    {  // k_chol_backward: start, prologue done, first block, second block, all blocks, last loads landed, solution stored
+      const long long* b = &h[(size_t)(nbk + 1) * 8];
+      fprintf(stderr, "chol backward: prologue %.2f us, first block %.2f, second block %.2f, remaining %d blocks %.2f, tail wait %.2f, store %.2f | total %.2f us\n",
+              (b[1] - b[0]) * 0.01, (b[2] - b[1]) * 0.01, (b[3] - b[2]) * 0.01, std::max(nbk - 2, 0), (b[4] - b[3]) * 0.01, (b[5] - b[4]) * 0.01, (b[6] - b[5]) * 0.01, (b[6] - b[0]) * 0.01);
+    }
     for (int s = 0; s <= nbk; ++s) {
       fprintf(stderr, "chol step %2d:", s - 1);
       for (int ph = 1; ph < 7; ++ph)
