@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
 k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ dbg_times = nullptr) {
   using Cfg = Reg2Cfg<NC>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int REG_BLOCK = Cfg::REG_BLOCK, REC = Cfg::REC, NPH = Cfg::NPH, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, NPH = Cfg::NPH, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
   constexpr int NCD = 4;                        // codes of a chunk that travel in registers
   extern __shared__ __attribute__((aligned(16))) double sh[];
