@@ -15,7 +15,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libcaliscope_ba.so"
 SOURCES = [CSRC / "cba_lib.hip", CSRC / "cba_solve.cpp"]
-DEPENDS = [CSRC / "cba_kernels.h", CSRC / "schur_plan.h", CSRC / "host_plan.h", CSRC / "ba_math.h", CSRC / "trf_math.h", HERE.parent / "include" / "caliscope_ba.h"]
+DEPENDS = [CSRC / "cba_kernels.h", CSRC / "schur_plan.h", CSRC / "host_plan.h", CSRC / "wg_binding.h", CSRC / "ba_math.h", CSRC / "trf_math.h", HERE.parent / "include" / "caliscope_ba.h"]
 ARCH = "gfx950"
 
 

@@ -29,6 +29,7 @@
 #include "cba_kernels.h"
 #include "schur_plan.h"
 #include "host_plan.h"
+#include "wg_binding.h"
 
 using namespace cba;
 
@@ -542,73 +543,10 @@ constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads (the wide ke
 static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
-// Workgroup -> tile binding shared by the tile plans: workgroups proportional to the chunk count of each tile (at least
-// one per tile), XCD-aware for the register kernels.  TCB = first chunk of every tile.
-struct WgBinding { std::vector<int> wgb, wt, wfirst, wend, wstride; };
-// `tile_cost` (optional): estimated time of every tile's chunks; workgroups are then handed out in proportion to it instead of the chunk counts (a
-// diagonal tile's chunks hold 3 pair iterations per wave where an off-diagonal tile's hold 2: with equal chunk counts per workgroup the
-// diagonal tiles' workgroups ran 30 % longer than the rest, and the kernel lasts as long as its slowest workgroup).
+// Workgroup -> tile binding shared by the tile plans (csrc/wg_binding.h): sets the grid of the tiled Schur kernel
 static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, bool reg, const std::vector<double>* tile_cost = nullptr) {
-  WgBinding out;
-  // workgroups: proportional to the chunk count (or the cost) of each tile, at least one per tile
-  std::vector<long> nch(nT);
-  for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
-  std::vector<double> wt_cost(nT);
-  double cost_total = 0.0;
-  for (int t = 0; t < nT; ++t) { wt_cost[t] = tile_cost ? (*tile_cost)[t] : (double)nch[t]; cost_total += wt_cost[t]; }
-  auto allocate = [&](int budget) {
-    std::vector<int> nwg(nT);
-    long used = 0;
-    for (int t = 0; t < nT; ++t) {
-      const long w = cost_total > 0.0 ? (long)(wt_cost[t] * budget / cost_total) : 1;
-      nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
-      used += nwg[t];
-    }
-    // hand out what is left (or take back the excess) where the chunks-per-workgroup load is most uneven
-    while (used != budget) {
-      int best = -1;
-      double score = 0.0;
-      for (int t = 0; t < nT; ++t) {
-        if (used < budget) {
-          if (nwg[t] >= nch[t]) continue;
-          const double sc = wt_cost[t] / nwg[t];
-          if (best < 0 || sc > score) { best = t; score = sc; }
-        } else {
-          if (nwg[t] <= 1) continue;
-          const double sc = -wt_cost[t] / (nwg[t] - 1);
-          if (best < 0 || sc > score) { best = t; score = sc; }
-        }
-      }
-      if (best < 0) break;
-      if (used < budget) { nwg[best]++; used++; } else { nwg[best]--; used--; }
-    }
-    return nwg;
-  };
-  const int budget = std::max(nT, std::min(max_blocks, std::max(1, p->n_tile_chunks)));
-  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD gets the same share of every
-  // tile and walks one eighth of the point range, so the G tiles that gather a given T record do so through the
-  // same L2 at about the same time; HBM then serves each record once instead of G times.
-  constexpr int XCDS = 8;
-  const bool xcd_mode = reg && budget % XCDS == 0 && nT <= budget / XCDS && p->n_tile_chunks >= 4 * budget;
-  std::vector<int> nwg = allocate(xcd_mode ? budget / XCDS : budget), wgb(nT + 1, 0);
-  if (xcd_mode) for (int& w : nwg) w *= XCDS;
-  for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
-  p->tile_grid = wgb[nT];
-  std::vector<int> wt(p->tile_grid), wfirst(p->tile_grid), wend(p->tile_grid), wstride(p->tile_grid);
-  for (int t = 0; t < nT; ++t)
-    for (int r = 0; r < nwg[t]; ++r) {
-      const int b = wgb[t] + r;
-      wt[b] = t;
-      if (xcd_mode) {
-        const int x = r % XCDS, s = r / XCDS;
-        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
-        wfirst[b] = TCB[t] + (int)lo + s; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
-      } else {
-        wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t];
-      }
-    }
-
-  out.wgb = std::move(wgb); out.wt = std::move(wt); out.wfirst = std::move(wfirst); out.wend = std::move(wend); out.wstride = std::move(wstride);
+  WgBinding out = cba::bind_workgroups(TCB, nT, max_blocks, reg, tile_cost);
+  p->tile_grid = out.grid;
   return out;
 }
 
@@ -764,21 +702,7 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   // slowest wave
   double cost_a = 2.0;
   if (const char* e = std::getenv("CBA_PLAN_COST_A")) cost_a = std::atof(e);
-  std::vector<double> tile_cost(nT, 0.0);
-  {
-    const int nword = KCfg::CODE_WAVES / 4, vb = KCfg::CODE_WAVES / (KCfg::REG_BLOCK / KCfg::SPLIT / WAVE);  // blocks per thread: their iterations add up
-    const int pwaves = KCfg::CODE_WAVES / vb;
-    for (int t = 0; t < nT; ++t)
-      for (int ch = plan.tile_chunk_begin[t]; ch < plan.tile_chunk_begin[t + 1]; ++ch) {
-        int mx = 0;
-        for (int w = 0; w < pwaves; ++w) {
-          int its = 0;
-          for (int v = 0; v < vb; ++v) { const int vw = v * pwaves + w; its += (int)((plan.nit[(size_t)ch * nword + vw / 4] >> (8 * (vw % 4))) & 0xffu); }
-          mx = std::max(mx, its);
-        }
-        tile_cost[t] += cost_a + mx;
-      }
-  }
+  const std::vector<double> tile_cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, KCfg::CODE_WAVES, KCfg::REG_BLOCK / KCfg::SPLIT / WAVE, cost_a);
   const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, true, cost_a >= 0.0 ? &tile_cost : nullptr);
   lap("workgroup binding");
   std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);

@@ -1,0 +1,107 @@
+// Workgroup -> tile binding of the tiled Schur kernels, host side only: plain C++, so that the CPU suite can build it with g++ and check
+// that every chunk is bound exactly once (tests/native/plan_harness.cpp, tests/test_schur_plan.py).
+//
+// A kernel's workgroups are persistent: workgroup b belongs to tile wt[b] and walks the chunks wfirst[b], wfirst[b] + wstride[b], ... <
+// wend[b].  Workgroups are handed out to the tiles in proportion to the tiles' estimated cost (at least one each): a diagonal tile's
+// chunks hold 3 pair iterations per wave where an off-diagonal tile's hold 2 — with equal chunk COUNTS per workgroup the diagonal
+// tiles' workgroups ran 30 % longer than the rest, and the kernel lasts as long as its slowest workgroup.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+namespace cba {
+
+struct WgBinding {
+  std::vector<int> wgb;                         // [nT + 1] first workgroup of every tile
+  std::vector<int> wt, wfirst, wend, wstride;   // [grid] tile, first chunk, end of the chunk range, stride
+  int grid = 0;
+  bool xcd_mode = false;
+};
+
+// TCB: first chunk of every tile ([nT + 1]); tile_cost: optional, default the chunk counts; reg: the register kernels (XCD-aware binding).
+inline WgBinding bind_workgroups(const std::vector<int>& TCB, int nT, int max_blocks, bool reg, const std::vector<double>* tile_cost = nullptr) {
+  WgBinding out;
+  const int n_tile_chunks = TCB[nT] - TCB[0];
+  std::vector<long> nch(nT);
+  for (int t = 0; t < nT; ++t) nch[t] = TCB[t + 1] - TCB[t];
+  std::vector<double> wt_cost(nT);
+  double cost_total = 0.0;
+  for (int t = 0; t < nT; ++t) { wt_cost[t] = tile_cost ? (*tile_cost)[t] : (double)nch[t]; cost_total += wt_cost[t]; }
+  auto allocate = [&](int budget) {
+    std::vector<int> nwg(nT);
+    long used = 0;
+    for (int t = 0; t < nT; ++t) {
+      const long w = cost_total > 0.0 ? (long)(wt_cost[t] * budget / cost_total) : 1;
+      nwg[t] = (int)std::max<long>(1, std::min<long>(w, std::max<long>(nch[t], 1)));
+      used += nwg[t];
+    }
+    // hand out what is left (or take back the excess) where the cost per workgroup is most uneven
+    while (used != budget) {
+      int best = -1;
+      double score = 0.0;
+      for (int t = 0; t < nT; ++t) {
+        if (used < budget) {
+          if (nwg[t] >= nch[t]) continue;
+          const double sc = wt_cost[t] / nwg[t];
+          if (best < 0 || sc > score) { best = t; score = sc; }
+        } else {
+          if (nwg[t] <= 1) continue;
+          const double sc = -wt_cost[t] / (nwg[t] - 1);
+          if (best < 0 || sc > score) { best = t; score = sc; }
+        }
+      }
+      if (best < 0) break;
+      if (used < budget) { nwg[best]++; used++; } else { nwg[best]--; used--; }
+    }
+    return nwg;
+  };
+  const int budget = std::max(nT, std::min(max_blocks, std::max(1, n_tile_chunks)));
+  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD gets the same share of every
+  // tile and walks one eighth of the point range, so the G tiles that gather a given T record do so through the
+  // same L2 at about the same time; HBM then serves each record once instead of G times.
+  constexpr int XCDS = 8;
+  const bool xcd_mode = reg && budget % XCDS == 0 && nT <= budget / XCDS && n_tile_chunks >= 4 * budget;
+  std::vector<int> nwg = allocate(xcd_mode ? budget / XCDS : budget), wgb(nT + 1, 0);
+  if (xcd_mode) for (int& w : nwg) w *= XCDS;
+  for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
+  const int grid = wgb[nT];
+  std::vector<int> wt(grid), wfirst(grid), wend(grid), wstride(grid);
+  for (int t = 0; t < nT; ++t)
+    for (int r = 0; r < nwg[t]; ++r) {
+      const int b = wgb[t] + r;
+      wt[b] = t;
+      if (xcd_mode) {
+        const int x = r % XCDS, s = r / XCDS;
+        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
+        wfirst[b] = TCB[t] + (int)lo + s; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
+      } else {
+        wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t];
+      }
+    }
+  out.wgb = std::move(wgb); out.wt = std::move(wt); out.wfirst = std::move(wfirst); out.wend = std::move(wend); out.wstride = std::move(wstride);
+  out.grid = grid; out.xcd_mode = xcd_mode;
+  return out;
+}
+
+// Estimated cost of every tile for the binding above, from the plan's iteration counts.  Per chunk: `cost_a` for gather + barrier (in units of
+// one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its slowest PHYSICAL wave (a physical wave
+// runs `code_waves / phys_waves` of the plan's waves one after the other: their iterations add up).
+inline std::vector<double> tile_costs(const std::vector<unsigned>& nit, const std::vector<int>& tile_chunk_begin, int nT, int code_waves, int phys_waves,
+                                      double cost_a) {
+  std::vector<double> cost(nT, 0.0);
+  const int nword = code_waves / 4, vb = std::max(1, code_waves / std::max(phys_waves, 1));
+  const int pw = code_waves / vb;
+  for (int t = 0; t < nT; ++t)
+    for (int ch = tile_chunk_begin[t]; ch < tile_chunk_begin[t + 1]; ++ch) {
+      int mx = 0;
+      for (int w = 0; w < pw; ++w) {
+        int its = 0;
+        for (int v = 0; v < vb; ++v) { const int vw = v * pw + w; its += (int)((nit[(size_t)ch * nword + vw / 4] >> (8 * (vw % 4))) & 0xffu); }
+        mx = std::max(mx, its);
+      }
+      cost[t] += cost_a + mx;
+    }
+  return cost;
+}
+
+}  // namespace cba

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../caliscope_amd/csrc/schur_plan.h"
+#include "../../caliscope_amd/csrc/wg_binding.h"
 
 extern "C" {
 
@@ -79,5 +80,30 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
   }
   stats_out[5] = plan.lds_groups; stats_out[6] = plan.lds_cycles; stats_out[7] = plan.lds_cycles_arrival;
   return 0;
+}
+
+// Workgroup binding (csrc/wg_binding.h) of a plan built like plan_replay's: per workgroup (tile, first, end, stride), per tile its cost.
+// Returns the grid (or a negative plan error); out arrays sized by the caller for `max_blocks + n_tiles` workgroups.
+int bind_replay(int C, int P, int G, int g, int rep, int chunk_cap, int slots_per_wave, int lds_stride, int wave_pieces, int region_chunks, int n_waves,
+                int pair_cap, int phys_waves, double cost_a, int max_blocks, int reg, const int* hcam, const int* hps, int* wt, int* wfirst, int* wend,
+                int* wstride, int* tcb_out, double* cost_out, int* xcd_out) {
+  cba::Reg2Params prm;
+  prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap;
+  prm.rec_pieces = lds_stride; prm.slots_per_wave = slots_per_wave; prm.wave_pieces = wave_pieces;
+  prm.zero_piece = (chunk_cap + slots_per_wave - 1) / slots_per_wave * wave_pieces;
+  prm.region_chunks = region_chunks; prm.threads = 4; prm.n_waves = n_waves; prm.pair_cap = pair_cap;
+  const long N = hps[P];
+  std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
+  cba::Reg2Plan plan;
+  const int rc = cba::build_reg2_plan(prm, vcam, vps, plan);
+  if (rc) return rc;
+  const int nT = G * (G + 1) / 2;
+  const std::vector<double> cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, n_waves, phys_waves, cost_a);
+  const cba::WgBinding b = cba::bind_workgroups(plan.tile_chunk_begin, nT, max_blocks, reg != 0, cost_a >= 0.0 ? &cost : nullptr);
+  for (int i = 0; i < b.grid; ++i) { wt[i] = b.wt[i]; wfirst[i] = b.wfirst[i]; wend[i] = b.wend[i]; wstride[i] = b.wstride[i]; }
+  for (int t = 0; t <= nT; ++t) tcb_out[t] = plan.tile_chunk_begin[t];
+  for (int t = 0; t < nT; ++t) cost_out[t] = cost[t];
+  *xcd_out = b.xcd_mode ? 1 : 0;
+  return b.grid;
 }
 }

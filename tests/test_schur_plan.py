@@ -21,6 +21,8 @@ def harness(tmp_path_factory):
     lib = C.CDLL(str(out))
     lib.plan_replay.restype = C.c_int
     lib.plan_replay.argtypes = [C.c_int] * 16 + [I32P, I32P, F64P, F64P, I64P]
+    lib.bind_replay.restype = C.c_int
+    lib.bind_replay.argtypes = [C.c_int] * 13 + [C.c_double, C.c_int, C.c_int, I32P, I32P, I32P, I32P, I32P, I32P, I32P, F64P, I32P]
     return lib
 
 
@@ -191,3 +193,47 @@ def test_lane_utilisation_at_the_bench_shape(harness):
     # in 16 different bank groups): the coloured slots stay below 1.6 cycles per group, the arrival order needs ~2.5
     groups, cycles, arrival = stats[5], stats[6], stats[7]
     assert cycles / groups < 1.7 and arrival / groups > 2.2, (cycles / groups, arrival / groups)
+
+
+@pytest.mark.parametrize("shape", [dict(n_cams=64, n_points=20000, k=10, max_blocks=512), dict(n_cams=64, n_points=20000, k=10, max_blocks=512, cost_a=-1.0),
+                                   dict(n_cams=40, n_points=3000, k=8, max_blocks=512), dict(n_cams=128, n_points=6000, k=10, max_blocks=256, nc=9),
+                                   dict(n_cams=8, n_points=400, k=6, max_blocks=512), dict(n_cams=64, n_points=20000, k=10, max_blocks=512, layout="wide")])
+def test_workgroup_binding_covers_every_chunk_once(harness, shape):
+    """csrc/wg_binding.h: the persistent workgroups of the pair kernel walk (first, first + stride, ... < end); every chunk of every tile must be
+    walked by exactly one workgroup of that tile, and the workgroups are handed out in proportion to the tiles' estimated cost."""
+    cfg = dict(shape)
+    nc, layout, cost_a, max_blocks = cfg.pop("nc", 6), cfg.pop("layout", "reg3"), cfg.pop("cost_a", 2.0), cfg.pop("max_blocks")
+    rng = np.random.default_rng(12)
+    hcam, hps = _visibility(rng, cfg["n_cams"], cfg["n_points"], cfg["k"], cfg["k"])
+    gmax = 32 if layout == "wide" else 16
+    G = -(-cfg["n_cams"] // gmax)
+    g = -(-cfg["n_cams"] // G)
+    threads = 1024 if layout == "wide" else 256
+    rep = threads // (g * g) if (nc == 6 and g * g <= threads // 2) else 1
+    epw, lst, wp, cap = (64, 7, 448, 512) if layout == "wide" else ((80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384))
+    n_waves, phys = (16, 8) if layout == "wide" else (4, 4)
+    nT = G * (G + 1) // 2
+    cap_wg = max_blocks + nT
+    wt, wf, we, ws = (np.zeros(cap_wg, dtype=np.int32) for _ in range(4))
+    tcb, cost, xcd = np.zeros(nT + 1, dtype=np.int32), np.zeros(nT), np.zeros(1, dtype=np.int32)
+    grid = harness.bind_replay(cfg["n_cams"], len(hps) - 1, G, g, rep, cap, epw, lst, wp, 32, n_waves, 2 if layout == "wide" else 0, phys, cost_a, max_blocks, 1,
+                               hcam.ctypes.data_as(I32P), hps.ctypes.data_as(I32P), *(a.ctypes.data_as(I32P) for a in (wt, wf, we, ws, tcb)),
+                               cost.ctypes.data_as(F64P), xcd.ctypes.data_as(I32P))
+    assert 0 < grid <= cap_wg
+    n_chunks = int(tcb[nT])
+    seen = np.zeros(n_chunks, dtype=np.int32)
+    per_tile = np.zeros(nT, dtype=np.int64)
+    for b in range(grid):
+        t = wt[b]
+        per_tile[t] += 1
+        walk = np.arange(wf[b], we[b], ws[b])
+        assert ws[b] >= 1 and tcb[t] <= wf[b] and we[b] <= tcb[t + 1]
+        seen[walk] += 1
+    assert np.all(seen == 1), (int((seen == 0).sum()), int((seen > 1).sum()))
+    assert np.all(per_tile >= 1) and np.all(np.diff(wt[:grid]) >= 0)  # tiles own contiguous runs of workgroups (k_reg_reduce relies on it)
+    if xcd[0]:
+        assert grid % 8 == 0 and np.all(per_tile % 8 == 0)
+    if grid >= 4 * nT:  # enough workgroups to balance: cost per workgroup within a quarter of the mean
+        weight = cost if cost_a >= 0 else np.diff(tcb).astype(float)
+        load = weight / per_tile
+        assert load.max() <= 1.3 * load.mean(), (load, per_tile)
