@@ -14,6 +14,7 @@
 
 #include "ba_math.h"
 #include "trf_math.h"
+#include "wg_binding.h"
 
 namespace cba {
 
@@ -1332,14 +1333,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
   const int tid = (int)threadIdx.x;
-  // workgroup id: groups of eight consecutive ids (one per XCD) alternate between the two halves of the grid.  With two workgroups per CU the ones
-  // dispatched later run slower (phase clocks: the time per trip grows by a third from the first to the last quarter of the grid); spread like this
-  // every tile gets the same mix, and the cost model of the binding (cba_lib.hip, bind_workgroups) holds for all of them
-  int wg = (int)blockIdx.x;
-  if ((gridDim.x & 15u) == 0) {
-    const int gh = wg >> 3, halfg = (int)(gridDim.x >> 4);
-    wg = ((gh < halfg ? 2 * gh : 2 * (gh - halfg) + 1) << 3) | (wg & 7);
-  }
+  const int wg = logical_workgroup((int)blockIdx.x, (int)gridDim.x);  // csrc/wg_binding.h: interleaved over the dispatch order
   const int ct = tid % PT;                      // code thread: the SPLIT parts of a block multiply the same pairs
   const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
   const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave

@@ -9,7 +9,24 @@
 #include <algorithm>
 #include <vector>
 
+#if defined(__HIPCC__)
+#define CBA_WG_HD __host__ __device__ __forceinline__
+#else
+#define CBA_WG_HD inline
+#endif
+
 namespace cba {
+
+// The id a workgroup of k_schur_reg3 works under (the index into wt / wfirst / ... above and of its partial row): groups of eight consecutive
+// hardware ids (one per XCD) alternate between the two halves of the grid.  With two workgroups per CU the ones dispatched later run slower
+// (phase clocks: the time per trip grows by a third from the first to the last quarter of the grid); spread like this every tile gets the
+// same mix, and the cost model of the binding holds for all of them.  A permutation of [0, grid) that keeps id mod 8 (the XCD); the
+// identity when the grid is not a multiple of 16.
+CBA_WG_HD int logical_workgroup(int block, int grid) {
+  if ((grid & 15) != 0) return block;
+  const int gh = block >> 3, halfg = grid >> 4;
+  return ((gh < halfg ? 2 * gh : 2 * (gh - halfg) + 1) << 3) | (block & 7);
+}
 
 struct WgBinding {
   std::vector<int> wgb;                         // [nT + 1] first workgroup of every tile

@@ -106,4 +106,6 @@ int bind_replay(int C, int P, int G, int g, int rep, int chunk_cap, int slots_pe
   *xcd_out = b.xcd_mode ? 1 : 0;
   return b.grid;
 }
+
+int logical_workgroup_of(int block, int grid) { return cba::logical_workgroup(block, grid); }
 }

@@ -237,3 +237,16 @@ def test_workgroup_binding_covers_every_chunk_once(harness, shape):
         weight = cost if cost_a >= 0 else np.diff(tcb).astype(float)
         load = weight / per_tile
         assert load.max() <= 1.3 * load.mean(), (load, per_tile)
+
+
+def test_workgroup_renumbering_is_a_permutation_that_keeps_the_xcd(harness):
+    """csrc/wg_binding.h logical_workgroup: what k_schur_reg3 uses as its workgroup id."""
+    for grid in (16, 256, 512, 288, 40, 7):
+        ids = np.array([harness.logical_workgroup_of(b, grid) for b in range(grid)])
+        assert sorted(ids) == list(range(grid))
+        if grid % 16 == 0:
+            assert np.all(ids % 8 == np.arange(grid) % 8)
+            first_half = ids[: grid // 2] // 8
+            assert np.all(first_half % 2 == 0) and np.all((ids[grid // 2:] // 8) % 2 == 1)  # groups of eight alternate between the halves
+        else:
+            assert np.all(ids == np.arange(grid))
