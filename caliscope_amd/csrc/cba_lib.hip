@@ -146,6 +146,8 @@ struct cba_problem {
   double t_ms[T_COUNT] = {0};
   long t_calls[T_COUNT] = {0};
   std::vector<void*> allocs;   // arena chunks (dev_alloc)
+  std::vector<size_t> alloc_bytes;
+  size_t mail_doubles = 0;     // capacity of the mapped host mailbox (h_scal)
   char* arena_cur = nullptr; size_t arena_left = 0, arena_next = (size_t)4 << 20;
   // sharded solve (points partitioned over ranks, cameras replicated): RCCL over xGMI
   ncclComm_t comm = nullptr;
@@ -182,6 +184,19 @@ static hipError_t guarded_memcpy(void* dst, const void* src, size_t bytes, hipMe
   return hipMemcpy(dst, src, bytes, kind);
 }
 
+// What a small handle is made of is recycled: per device the library keeps up to four first arena chunks (4 MB), streams and mapped host
+// mailboxes of destroyed handles and hands them to the next cba_create.  hipMalloc / hipFree / hipStreamCreate / hipHostMalloc are
+// 0.3 - 1 ms each; on the reference's own 4-camera session creating and destroying a handle took 3.5 + 2.4 ms next to a 0.7 ms solve.
+constexpr size_t kPoolChunk = (size_t)4 << 20;
+constexpr size_t kPoolKeep = 4;
+struct DevicePool {
+  std::vector<void*> chunks;
+  std::vector<hipStream_t> streams;
+  std::vector<std::pair<double*, size_t>> mail;  // (mapped host pointer, doubles)
+};
+static std::mutex g_pool_mu;
+static std::map<int, DevicePool> g_pool;
+
 // Device memory of a handle comes from an arena: a handle has ~60 buffers, and on the reference's own 4-camera session
 // creating and freeing them one hipMalloc / hipFree at a time was more than half of an optimize() call (the solve itself takes
 // 1 ms).  Buffers are carved out of chunks (the first 4 MB, then doubling; a large buffer gets a chunk of its own), 256-byte
@@ -192,8 +207,14 @@ static int dev_alloc(cba_problem* p, T** out, size_t count) {
   if (bytes > p->arena_left) {
     const size_t chunk = std::max(bytes, p->arena_next);
     void* ptr = nullptr;
-    HIPCHK(guarded_malloc(&ptr, chunk));
+    if (chunk == kPoolChunk) {
+      std::lock_guard<std::mutex> lock(g_pool_mu);
+      DevicePool& pool = g_pool[p->device];
+      if (!pool.chunks.empty()) { ptr = pool.chunks.back(); pool.chunks.pop_back(); }
+    }
+    if (!ptr) HIPCHK(guarded_malloc(&ptr, chunk));
     p->allocs.push_back(ptr);
+    p->alloc_bytes.push_back(chunk);
     if (bytes >= p->arena_next) {  // a buffer of its own: the open chunk stays open
       p->device_bytes += (long)bytes;
       *out = static_cast<T*>(ptr);
@@ -475,12 +496,21 @@ void cba_destroy(cba_problem* p) {
   if (p->chol_graph) (void)hipGraphDestroy(p->chol_graph);
   {
     CaptureSafe g(g_capture_mu);
-    for (void* a : p->allocs) (void)hipFree(a);
-    if (p->h_scal) (void)hipHostFree(p->h_scal);
-    if (p->h_flags) (void)hipHostFree(p->h_flags);
-    if (p->h_cam) (void)hipHostFree(p->h_cam);
+    std::lock_guard<std::mutex> lock(g_pool_mu);  // (the stream is drained: nothing of this handle is in flight)
+    DevicePool& pool = g_pool[p->device];
+    for (size_t i = 0; i < p->allocs.size(); ++i) {
+      if (p->alloc_bytes[i] == kPoolChunk && pool.chunks.size() < kPoolKeep) pool.chunks.push_back(p->allocs[i]);
+      else (void)hipFree(p->allocs[i]);
+    }
+    if (p->h_scal) {  // (h_cam and h_flags live in the same allocation)
+      if (pool.mail.size() < kPoolKeep) pool.mail.emplace_back(p->h_scal, p->mail_doubles);
+      else (void)hipHostFree(p->h_scal);
+    }
+    if (p->stream) {
+      if (pool.streams.size() < kPoolKeep) pool.streams.push_back(p->stream);
+      else (void)hipStreamDestroy(p->stream);
+    }
   }
-  if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
 
@@ -822,8 +852,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (!(opt && opt->device_id >= 0)) (void)hipGetDevice(&dev);
   if (dev >= ndev) return fail(CBA_ERR_INVALID, "device %d requested, %d available", dev, ndev);
   HIPCHK(hipSetDevice(dev));
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, dev));
+  int n_cus = 0;  // (hipGetDeviceProperties is a millisecond per call: a visible share of creating a handle for a small session)
+  if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cus = 0;
 
   cba_problem* p = new cba_problem();
   p->device = dev;
@@ -894,19 +924,32 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 
   {
     CaptureSafe not_while_recording(g_capture_mu);
-    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIPCHK(hipHostMalloc((void**)&p->h_scal, 64 * sizeof(double), hipHostMallocMapped));
-    HIPCHK(hipHostMalloc((void**)&p->h_flags, 4 * sizeof(int), hipHostMallocMapped));
+    // one mapped host allocation for the three mailboxes: scalars (64 doubles), camera blocks (3 ncp + 8 doubles), flags (4 ints)
+    const size_t n_mail = 64 + ((size_t)3 * ncp + 8) + 2;
+    {
+      std::lock_guard<std::mutex> lock(g_pool_mu);
+      DevicePool& pool = g_pool[dev];
+      if (!pool.streams.empty()) { p->stream = pool.streams.back(); pool.streams.pop_back(); }
+      for (size_t i = 0; i < pool.mail.size(); ++i)
+        if (pool.mail[i].second >= n_mail) {
+          p->h_scal = pool.mail[i].first; p->mail_doubles = pool.mail[i].second;
+          pool.mail.erase(pool.mail.begin() + (long)i);
+          break;
+        }
+    }
+    if (!p->stream) HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    if (!p->h_scal) {
+      p->mail_doubles = std::max<size_t>(n_mail, 64 + 3 * 96 + 10);  // (room for 96 camera parameters: small rigs share mailboxes)
+      HIPCHK(hipHostMalloc((void**)&p->h_scal, p->mail_doubles * sizeof(double), hipHostMallocMapped));
+    }
     HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
-    HIPCHK(hipHostGetDevicePointer((void**)&p->d_hflags, p->h_flags, 0));
-    HIPCHK(hipHostMalloc((void**)&p->h_cam, ((size_t)3 * ncp + 8) * sizeof(double), hipHostMallocMapped));
-    HIPCHK(hipHostGetDevicePointer((void**)&p->d_hcam, p->h_cam, 0));
+    p->h_cam = p->h_scal + 64; p->d_hcam = p->d_hscal + 64;
+    p->h_flags = reinterpret_cast<int*>(p->h_cam + ((size_t)3 * ncp + 8)); p->d_hflags = reinterpret_cast<int*>(p->d_hcam + ((size_t)3 * ncp + 8));
   }
-  std::memset(p->h_scal, 0, 64 * sizeof(double));
-  std::memset(p->h_cam, 0, ((size_t)3 * ncp + 8) * sizeof(double));
+  std::memset(p->h_scal, 0, (64 + ((size_t)3 * ncp + 8) + 2) * sizeof(double));
   if (const char* sp = std::getenv("CBA_SPIN")) p->spin_wait = sp[0] != '0';
 
-  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const int cus = n_cus > 0 ? n_cus : 256;
   int grid_mult = 2;  // persistent workgroups per CU of the per-observation kernels
   if (const char* e = std::getenv("CBA_GRID_MULT")) grid_mult = std::max(1, std::atoi(e));
   int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : grid_mult * cus;
