@@ -5,12 +5,16 @@
 //
 // Arithmetic: the per-observation code the kernels inline (csrc/ba_math.h: projection, Jacobian blocks, robust-loss
 // scaling) on DENSE matrices; the trust-region primitives are those of dense_engine.cpp (included below), the damped step
-// is one dense Cholesky of J^T J + lam D^2.  Sizes: test scenes (n <~ 3000 parameters).  No device, no RCCL: world 1 only;
-// cba_triangulate is not available.
+// eliminates the points of an envelope Cholesky of J^T J + lam D^2 and solves the reduced camera system.  Sizes: test scenes
+// (n <~ 3000 parameters).  No device and no RCCL; cba_group_* joins handles of one process (one host thread each) into a
+// point-sharded solve with a host all-reduce, the protocol of the device build.  cba_triangulate is not available.
 #define CBA_CPU_LIBRARY 1
 #include "dense_engine.cpp"
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
+#include <mutex>
 
 #include "../../caliscope_amd/csrc/ba_math.h"
 #include "../../caliscope_amd/csrc/host_plan.h"
@@ -286,19 +290,68 @@ int cba_get_timers(cba_problem*, double* ms, int64_t* calls) { for (int i = 0; i
 int cba_reset_timers(cba_problem*) { return CBA_OK; }
 int cba_enable_timers(cba_problem*, int32_t) { return CBA_OK; }
 
-// one rank only
+// RCCL has no CPU counterpart ...
 int cba_comm_unique_id(char* out128) { std::memset(out128, 0, 128); return CBA_OK; }
 int cba_comm_init(cba_problem*, const char*, int32_t rank, int32_t world) {
-  return (world == 1 && rank == 0) ? CBA_OK : failf(CBA_ERR_UNSUPPORTED, "the CPU test build of the C ABI runs one rank");
+  return (world == 1 && rank == 0) ? CBA_OK : failf(CBA_ERR_UNSUPPORTED, "the CPU test build of the C ABI has no RCCL: one rank per communicator (use a cba_group)");
 }
-struct cba_group { int world; };
+
+// ... but the in-process group does: one host thread per member handle, a mutex/condvar barrier and one staging slot per rank.
+// Every rank folds the slots in rank order, so the replicas stay bit-identical.
+struct cba_group {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long generation = 0;
+  bool aborted = false;
+  std::vector<std::vector<double>> slot;
+
+  bool barrier() {  // false: the group was aborted
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
+    const unsigned long gen = generation;
+    if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+    else if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || aborted; })) aborted = true;  // a rank never arrived
+    if (aborted) { cv.notify_all(); return false; }
+    return true;
+  }
+  int all_reduce(int rank, double* buf, int n_sum, int n_max) {
+    slot[rank].assign(buf, buf + n_sum + n_max);
+    if (!barrier()) return 1;
+    for (int r = 0; r < world; ++r)
+      if ((int)slot[r].size() != n_sum + n_max) { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); return 1; }  // the ranks disagree about the collective
+    for (int j = 0; j < n_sum + n_max; ++j) {
+      double acc = slot[0][j];
+      for (int r = 1; r < world; ++r) acc = j < n_sum ? acc + slot[r][j] : std::fmax(acc, slot[r][j]);
+      buf[j] = acc;
+    }
+    return barrier() ? 0 : 1;  // the slots are free again
+  }
+};
+
 int cba_group_create(int32_t world, cba_group** out) {
-  if (world != 1) return failf(CBA_ERR_UNSUPPORTED, "the CPU test build of the C ABI runs one rank");
-  *out = new cba_group{1};
+  if (!out || world < 1 || world > 16) return failf(CBA_ERR_INVALID, "cba_group_create: world %d outside 1..16", world);
+  cba_group* g = new cba_group;
+  g->world = world; g->slot.resize(world);
+  *out = g;
   return CBA_OK;
 }
-int cba_group_join(cba_problem*, cba_group*, int32_t) { return CBA_OK; }
-void cba_group_abort(cba_group*) {}
+int cba_group_join(cba_problem* p, cba_group* g, int32_t rank) {
+  if (!p || !g || rank < 0 || rank >= g->world) return failf(CBA_ERR_INVALID, "cba_group_join: bad arguments");
+  if (!g->barrier()) return failf(CBA_ERR_INVALID, "cba_group_join: the group was aborted (another rank failed before joining)");
+  if (g->world > 1) {
+    p->reduce = [g, rank](double* buf, int n_sum, int n_max) { return g->all_reduce(rank, buf, n_sum, n_max); };
+    p->lead = rank == 0;
+  }
+  return CBA_OK;
+}
+void cba_group_abort(cba_group* g) {
+  if (!g) return;
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->aborted = true;
+  g->cv.notify_all();
+}
 void cba_group_destroy(cba_group* g) { delete g; }
 
 int cba_triangulate(const cba_triangulate_desc*, int32_t, double*, double*) {

@@ -3,6 +3,11 @@
 // callbacks of the test (de_create: linear loss, cost = 0.5 |f|^2) or the bundle-adjustment model of cpu_library.cpp, which
 // includes this file and adds the rest of the C ABI.  It lets the CPU suite run csrc/cba_solve.cpp (compiled by g++ together
 // with this file) without a GPU.
+//
+// Sharded by point: a handle that joined a group (cpu_library.cpp) holds the replicated camera block and ITS points
+// and rows; `reduce` is the group's all-reduce.  Sums over parameters count the camera block on the lead rank only, sums over rows
+// are local; the damped step eliminates the local points, all-reduces the reduced camera system and solves it on every rank —
+// the exchange pattern of the device engine (csrc/cba_lib.hip, exchange_at), run by host threads.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -25,6 +30,12 @@ struct cba_problem {
   double cost = 0.0, cost_new = 0.0, last_lam = 0.0;
   bool first_scale = true, cam_scaled = false;
   BaModel* model = nullptr;
+  // all-reduce over the group: the first n_sum entries are summed, the next n_max maximised; non-zero = the group was aborted
+  std::function<int(double* buf, int n_sum, int n_max)> reduce;
+  bool lead = true;  // this rank counts the replicated camera block in sums over the parameters
+  int exchange(double* buf, int n_sum, int n_max = 0) {
+    return (reduce && reduce(buf, n_sum, n_max)) ? cba_set_error(CBA_ERR_INVALID, "group aborted: another rank failed or never arrived") : 0;
+  }
 };
 
 static thread_local std::string g_err;
@@ -66,6 +77,7 @@ int cba_get_info(cba_problem* p, cba_info* out) {
 static int begin_common(cba_problem* p, double* cost_out) {
   p->x = p->x0;
   p->cost = p->fun(p->x.data(), p->f.data());
+  if (p->exchange(&p->cost, 1)) return CBA_ERR_INVALID;
   p->first_scale = true; p->cam_scaled = false;
   p->cam_diag.assign(p->n, 0.0);
   *cost_out = p->cost;
@@ -82,10 +94,10 @@ int cba_begin_deferred(cba_problem* p, const double* x0) {  // the double evalua
   return begin_common(p, &unused);
 }
 
-static void lin_scalars(cba_problem* p, int max_from, cba_linearization* out) {
+static int lin_scalars(cba_problem* p, int max_from, cba_linearization* out) {
   const int m = p->m, n = p->n;
   double ginf = 0.0, gh_sq = 0.0, xs = 0.0, xn = 0.0;
-  for (int j = 0; j < n; ++j) {
+  for (int j = p->lead ? 0 : p->ncp; j < n; ++j) {
     const double g = p->g[j], sc = p->sinv[j];
     if (j >= max_from) ginf = std::fmax(ginf, std::fabs(g));
     gh_sq += (g / sc) * (g / sc);
@@ -98,25 +110,36 @@ static void lin_scalars(cba_problem* p, int max_from, cba_linearization* out) {
     for (int j = 0; j < n; ++j) r += p->J[(size_t)i * n + j] * p->g[j] / (p->sinv[j] * p->sinv[j]);
     jg_sq += r * r;
   }
-  out->g_norm_inf = ginf; out->gh_sq = gh_sq; out->jg_sq = jg_sq; out->x_scaled_norm = std::sqrt(xs); out->x_norm = std::sqrt(xn);
+  double v[5] = {gh_sq, xs, xn, jg_sq, ginf};
+  if (p->exchange(v, 4, 1)) return CBA_ERR_INVALID;
+  out->g_norm_inf = v[4]; out->gh_sq = v[0]; out->jg_sq = v[3]; out->x_scaled_norm = std::sqrt(v[1]); out->x_norm = std::sqrt(v[2]);
   out->cost = p->cost;
+  return CBA_OK;
 }
 
 int cba_linearize(cba_problem* p, cba_linearization* out) {
   const int m = p->m, n = p->n;
   p->jac(p->x.data(), p->J.data());
+  std::vector<double> col2(n);
   for (int j = 0; j < n; ++j) {
     double g = 0.0, c2 = 0.0;
     for (int i = 0; i < m; ++i) { g += p->J[(size_t)i * n + j] * p->f[i]; c2 += p->J[(size_t)i * n + j] * p->J[(size_t)i * n + j]; }
-    p->g[j] = g;
-    double sc = std::sqrt(c2);
+    p->g[j] = g; col2[j] = c2;
+  }
+  if (p->reduce) {  // the camera columns have rows on every rank
+    std::vector<double> v(2 * p->ncp);
+    for (int j = 0; j < p->ncp; ++j) { v[j] = p->g[j]; v[p->ncp + j] = col2[j]; }
+    if (p->exchange(v.data(), 2 * p->ncp)) return CBA_ERR_INVALID;
+    for (int j = 0; j < p->ncp; ++j) { p->g[j] = v[j]; col2[j] = v[p->ncp + j]; }
+  }
+  for (int j = 0; j < n; ++j) {
+    double sc = std::sqrt(col2[j]);
     if (p->first_scale) { if (sc == 0.0) sc = 1.0; } else sc = std::fmax(sc, p->sinv_state[j]);  // monotone max (common.py:598-610)
     p->sinv_state[j] = sc;
     p->sinv[j] = sc;
   }
   p->first_scale = false;
-  lin_scalars(p, 0, out);
-  return CBA_OK;
+  return lin_scalars(p, 0, out);
 }
 
 int cba_linearize_build(cba_problem* p) { cba_linearization unused; return cba_linearize(p, &unused); }
@@ -127,18 +150,32 @@ int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* dia
     p->cam_diag[j] = diag_h[j] * p->sinv[j] * p->sinv[j];
   }
   p->cam_scaled = true;
-  lin_scalars(p, p->ncp, out);
+  return lin_scalars(p, p->ncp, out);
+}
+
+// ||p_h||^2, g_h.p_h and ||w||^2 (w = p_h - (g_h.p_h / ||g_h||^2) g_h) of the step in p->s, over the whole parameter vector
+static int step_scalars(cba_problem* p, cba_newton_info* out) {
+  const int n = p->n, j0 = p->lead ? 0 : p->ncp;
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int j = j0; j < n; ++j) { const double pj = p->s[j] * p->sinv[j], gh = p->g[j] / p->sinv[j]; v[0] += pj * pj; v[1] += gh * pj; v[2] += gh * gh; }
+  if (p->exchange(v, 3)) return CBA_ERR_INVALID;
+  double w_sq = 0.0;
+  for (int j = j0; j < n; ++j) { const double w = p->s[j] * p->sinv[j] - (v[1] / v[2]) * p->g[j] / p->sinv[j]; w_sq += w * w; }
+  if (p->exchange(&w_sq, 1)) return CBA_ERR_INVALID;
+  out->p_sq = v[0]; out->gh_dot_p = v[1]; out->w_sq = w_sq;
   return CBA_OK;
 }
 
 // Damped normal equations (J^T J + lam D^2 + cam_diag) s = -g by an envelope ("skyline") Cholesky in REVERSED parameter order:
 // bundle-adjustment rows touch one camera and a few points, so with the points first the factor of the arrow matrix has no
 // fill outside the camera rows and a few-thousand-parameter session factors in milliseconds; a dense test problem simply has a
-// full envelope.  The rows of J are scanned for their nonzeros once.
+// full envelope.  The rows of J are scanned for their nonzeros once.  The point rows are eliminated first; what is left of the
+// camera rows is the reduced camera system of THIS rank's rows, which is summed over the group before the cameras are solved
+// (identically on every rank) and the points substituted back.
 int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
-  const int m = p->m, n = p->n;
+  const int m = p->m, n = p->n, ncp = p->ncp, np3 = n - ncp;  // positions [0, np3): points, [np3, n): cameras
   p->last_lam = lam;
-  std::vector<double> A((size_t)n * n, 0.0), b(n);
+  std::vector<double> A((size_t)n * n, 0.0), b(n, 0.0);
   std::vector<int> first(n), nz;
   for (int a = 0; a < n; ++a) first[a] = a;
   auto q = [n](int j) { return n - 1 - j; };  // position of parameter j in the factorisation order
@@ -152,34 +189,69 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
       for (size_t v = 0; v <= u; ++v) A[(size_t)r * n + q(nz[v])] += row[nz[u]] * row[nz[v]];
     }
   }
-  for (int a = 0; a < n; ++a) {
+  for (int a = ncp; a < n; ++a) {  // the camera block's damping and gradient enter once, after the sum over the ranks
     A[(size_t)q(a) * n + q(a)] += lam * p->sinv[a] * p->sinv[a] + p->cam_diag[a];
     b[q(a)] = -p->g[a];
   }
-  out->ok = 1; out->reserved = 0;
-  for (int i = 0; i < n; ++i) {  // row-oriented Cholesky inside the envelope
+  double failed = 0.0;
+  for (int i = 0; i < n && failed == 0.0; ++i) {  // row-oriented Cholesky inside the envelope; camera rows stop at the point columns
     double* Li = &A[(size_t)i * n];
-    for (int j = first[i]; j <= i; ++j) {
+    const int j_end = std::min(i, np3 - 1);
+    for (int j = first[i]; j <= j_end; ++j) {
       const double* Lj = &A[(size_t)j * n];
       double v = Li[j];
       for (int k = std::max(first[i], first[j]); k < j; ++k) v -= Li[k] * Lj[k];
       if (j < i) Li[j] = v / Lj[j];
-      else {
-        if (!(v > 0.0)) { out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
-        Li[i] = std::sqrt(v);
-      }
+      else if (!(v > 0.0)) { failed = 1.0; break; }
+      else Li[i] = std::sqrt(v);
     }
   }
-  for (int i = 0; i < n; ++i) { double v = b[i]; for (int k = first[i]; k < i; ++k) v -= A[(size_t)i * n + k] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
-  for (int i = n - 1; i >= 0; --i) { b[i] /= A[(size_t)i * n + i]; for (int k = first[i]; k < i; ++k) b[k] -= A[(size_t)i * n + k] * b[i]; }
+  // reduced system of this rank: [S (ncp x ncp, camera positions, lower) | y_c | failed]
+  std::vector<double> R((size_t)ncp * ncp + ncp + 1, 0.0);
+  if (failed == 0.0) {
+    for (int i = 0; i < np3; ++i) { double v = b[i]; for (int k = first[i]; k < i; ++k) v -= A[(size_t)i * n + k] * b[k]; b[i] = v / A[(size_t)i * n + i]; }
+    for (int i = np3; i < n; ++i) {
+      const double* Li = &A[(size_t)i * n];
+      for (int j = np3; j <= i; ++j) {
+        const double* Lj = &A[(size_t)j * n];
+        double v = Li[j];
+        for (int k = std::max(first[i], first[j]); k < np3; ++k) v -= Li[k] * Lj[k];
+        R[(size_t)(i - np3) * ncp + (j - np3)] = v;
+      }
+      double y = 0.0;
+      for (int k = first[i]; k < np3; ++k) y -= Li[k] * b[k];
+      R[(size_t)ncp * ncp + (i - np3)] = y;
+    }
+  }
+  R.back() = failed;
+  if (p->exchange(R.data(), (int)R.size())) return CBA_ERR_INVALID;
+  out->ok = 1; out->reserved = 0;
+  bool ok = R.back() == 0.0;
+  std::vector<double> xc(ncp);
+  if (ok) {
+    for (int a = 0; a < ncp; ++a) {
+      const int i = q(a) - np3;
+      R[(size_t)i * ncp + i] += lam * p->sinv[a] * p->sinv[a] + p->cam_diag[a];
+      xc[i] = R[(size_t)ncp * ncp + i] - p->g[a];
+    }
+    for (int i = 0; i < ncp && ok; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double v = R[(size_t)i * ncp + j];
+        for (int k = 0; k < j; ++k) v -= R[(size_t)i * ncp + k] * R[(size_t)j * ncp + k];
+        if (j < i) R[(size_t)i * ncp + j] = v / R[(size_t)j * ncp + j];
+        else if (!(v > 0.0)) { ok = false; break; }
+        else R[(size_t)i * ncp + i] = std::sqrt(v);
+      }
+  }
+  if (!ok) { out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
+  for (int i = 0; i < ncp; ++i) { double v = xc[i]; for (int k = 0; k < i; ++k) v -= R[(size_t)i * ncp + k] * xc[k]; xc[i] = v / R[(size_t)i * ncp + i]; }
+  for (int i = ncp - 1; i >= 0; --i) { xc[i] /= R[(size_t)i * ncp + i]; for (int k = 0; k < i; ++k) xc[k] -= R[(size_t)i * ncp + k] * xc[i]; }
+  // back-substitution of the points: the camera unknowns first leave the point rows' right-hand sides
+  for (int i = n - 1; i >= np3; --i) { b[i] = xc[i - np3]; for (int k = first[i]; k < np3; ++k) b[k] -= A[(size_t)i * n + k] * b[i]; }
+  for (int i = np3 - 1; i >= 0; --i) { b[i] /= A[(size_t)i * n + i]; for (int k = first[i]; k < i; ++k) b[k] -= A[(size_t)i * n + k] * b[i]; }
   for (int a = 0; a < n / 2; ++a) std::swap(b[a], b[q(a)]);  // back to parameter order
   p->s = b;
-  double p_sq = 0.0, ghp = 0.0, gh_sq = 0.0;
-  for (int j = 0; j < n; ++j) { const double pj = b[j] * p->sinv[j], gh = p->g[j] / p->sinv[j]; p_sq += pj * pj; ghp += gh * pj; gh_sq += gh * gh; }
-  double w_sq = 0.0;
-  for (int j = 0; j < n; ++j) { const double w = b[j] * p->sinv[j] - (ghp / gh_sq) * p->g[j] / p->sinv[j]; w_sq += w * w; }
-  out->p_sq = p_sq; out->gh_dot_p = ghp; out->w_sq = w_sq;
-  return CBA_OK;
+  return step_scalars(p, out);
 }
 
 int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam1, double a2, double b2, const double* cam2, double* gram) {
@@ -195,7 +267,7 @@ int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam
     s11 += r1 * r1; s12 += r1 * r2; s22 += r2 * r2;
   }
   gram[0] = s11; gram[1] = s12; gram[2] = s22;
-  return CBA_OK;
+  return p->exchange(gram, 3) ? CBA_ERR_INVALID : CBA_OK;
 }
 
 int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2, double* gram) {
@@ -208,9 +280,12 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
     double step = alpha * p->g[j] / (p->sinv[j] * p->sinv[j]) + beta * p->s[j];
     p->x_new[j] = p->x[j] + step;
     if (cam_x_new && j < p->ncp) { p->x_new[j] = cam_x_new[j]; step = p->x_new[j] - p->x[j]; }
-    sn += step * step;
+    if (p->lead || j >= p->ncp) sn += step * step;
   }
   p->cost_new = p->fun(p->x_new.data(), p->f_new.data());
+  double v[2] = {sn, p->cost_new};
+  if (p->exchange(v, 2)) return CBA_ERR_INVALID;
+  sn = v[0]; p->cost_new = v[1];
   out->cost = p->cost_new; out->step_norm = std::sqrt(sn); out->finite = std::isfinite(out->cost) ? 1 : 0; out->reserved = 0;
   if (!out->finite) out->cost = NAN;
   return CBA_OK;
@@ -222,12 +297,13 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { 
 int cba_step_supported(cba_problem* p) { return p->cam_scaled ? 0 : 1; }
 int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
   std::memset(out, 0, sizeof(*out));
-  cba_linearize(p, &out->lin);
+  int rc = cba_linearize(p, &out->lin);
+  if (rc) return rc;
   const double gh_sq = out->lin.gh_sq, gh_norm = std::sqrt(gh_sq);
   const double radius = radius_in > 0.0 ? radius_in : (out->lin.x_scaled_norm > 0.0 ? out->lin.x_scaled_norm : 1.0);
   const double lam = -trf::min_quadratic_on_segment(0.5 * out->lin.jg_sq, -gh_sq, radius / gh_norm) / (radius * radius);
   out->lam = lam; out->radius = radius;
-  cba_newton_step(p, lam, &out->newton);
+  if ((rc = cba_newton_step(p, lam, &out->newton))) return rc;
   const double p_sq = out->newton.p_sq, ghp = out->newton.gh_dot_p;
   const double w_sq = p_sq - ghp * ghp / gh_sq;  // derived, as on the device
   out->newton.w_sq = w_sq;
@@ -247,12 +323,8 @@ int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
 }
 
 int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
-  const int n = p->n;
-  double p_sq = 0.0, ghp = 0.0, gh_sq = 0.0, w_sq = 0.0;
-  for (int j = 0; j < n; ++j) { const double pj = p->s[j] * p->sinv[j], gh = p->g[j] / p->sinv[j]; p_sq += pj * pj; ghp += gh * pj; gh_sq += gh * gh; }
-  for (int j = 0; j < n; ++j) { const double w = p->s[j] * p->sinv[j] - (ghp / gh_sq) * p->g[j] / p->sinv[j]; w_sq += w * w; }
-  out->ok = 1; out->reserved = 0; out->p_sq = p_sq; out->gh_dot_p = ghp; out->w_sq = w_sq;
-  return CBA_OK;
+  out->ok = 1; out->reserved = 0;
+  return step_scalars(p, out);
 }
 
 int cba_accept(cba_problem* p) { p->x = p->x_new; p->f = p->f_new; p->cost = p->cost_new; return CBA_OK; }

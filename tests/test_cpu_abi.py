@@ -219,6 +219,111 @@ def test_engine_cache_and_set_loss_on_the_cpu_build(cpu_lib):
     assert out["ok"] and out["stats"] == {"hits": 1, "misses": 2} and out["rel"] < 1e-6, out
 
 
+# ---- more than one rank: the in-process group of the CPU build (host threads, host all-reduce) -------------------------------
+# The same Python that drives a multi-GPU node — caliscope_amd.distributed.solve_multi_device: shard by point, one thread per
+# rank, HipEngine.group_join, csrc/cba_solve.cpp on every rank, gather — against cba_group_* of the CPU build.  SURVEY.md 8e.
+
+_SHARD_PRELUDE = """
+    import json
+    import numpy as np
+    from caliscope_amd.engine import BAProblem
+    from caliscope_amd.least_squares import least_squares
+    from caliscope_amd.distributed import solve_multi_device
+    from tests.helpers import aligned_difference, small_problem
+
+    def problem(**kw):
+        loss = kw.get("loss", "linear")
+        sc, par, x0 = small_problem(**kw)
+        fs = sc.f_scale_1px() * 2.0 if loss != "linear" else 1.0
+        return par, BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs), x0, fs, sc
+
+    def single(par, prob, x0, fs, **kw):
+        return least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", loss=prob.loss, f_scale=fs, method="trf",
+                             args=(par, prob.camera_indices, prob.image_coords, prob.obj_indices), **kw)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [dict(n_cams=4, n_points=90, k=4), dict(n_cams=5, n_points=80, k=4, loss="huber", outliers=0.05)],
+                         ids=["linear", "huber"])
+def test_ranks_of_a_host_group_match_the_single_rank_solve(cpu_lib, world, case):
+    out = _run(cpu_lib, _SHARD_PRELUDE + f"""
+    par, prob, x0, fs, _ = problem(**{case!r})
+    tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)
+    one = single(par, prob, x0, fs, **tol)
+    many = solve_multi_device(prob, x0, [0] * {world}, backend="direct", **tol)
+    pos, ang, scale = aligned_difference(par, many.x, one.x)
+    print(json.dumps(dict(status=[int(one.status), int(many.status)], rel=float(abs(many.cost - one.cost) / one.cost),
+                          nfev=[int(one.nfev), int(many.nfev)], pos=float(pos), ang=float(ang), scale=float(scale))))
+    """)
+    assert out["status"][0] == out["status"][1] and out["rel"] <= 1e-9, out
+    assert abs(out["nfev"][0] - out["nfev"][1]) <= 5, out  # the sums are formed in another order
+    assert out["pos"] < 1e-7 and out["ang"] < 1e-7 and abs(out["scale"] - 1) < 1e-4, out
+
+
+def test_the_seam_shards_over_a_host_group(cpu_lib):
+    """``devices=`` and CALISCOPE_HIP_DEVICES at the least_squares seam (what CaptureVolume.optimize() calls)."""
+    out = _run(cpu_lib, _SHARD_PRELUDE + """
+    import os
+    par, prob, x0, fs, _ = problem(n_cams=4, n_points=70, k=4)
+    one = single(par, prob, x0, fs)
+    os.environ["CBA_XCHG"] = "direct"
+    two = single(par, prob, x0, fs, devices=[0, 0])
+    os.environ["CALISCOPE_HIP_DEVICES"] = "0,0,0"
+    three = single(par, prob, x0, fs)
+    rows = []
+    for res in (two, three):
+        pos, ang, _ = aligned_difference(par, res.x, one.x)
+        rows.append(dict(same=bool(res.status == one.status), rel=float(abs(res.cost - one.cost) / one.cost), pos=float(pos), ang=float(ang)))
+    print(json.dumps(rows))
+    """)
+    for row in out:
+        assert row["same"] and row["rel"] <= 1e-8 and row["pos"] < 1e-6 and row["ang"] < 1e-6, out
+
+
+def test_bounded_and_constrained_solves_on_a_host_group(cpu_lib):
+    """Free intrinsics (the Coleman-Li route of cba_solve: camera state, scaling, step and trial exchanged per primitive) and
+    rigid-distance rows (components stay on one rank) on two ranks."""
+    out = _run(cpu_lib, _SHARD_PRELUDE + """
+    from tests.constrained_scene import board_scene
+    tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)
+    par, prob, x0, fs, _ = problem(n_cams=4, n_points=90, k=4, refine=True)
+    lb, ub = par.bounds()
+    one = single(par, prob, x0, fs, **tol)
+    two = solve_multi_device(prob, x0, [0, 0], backend="direct", **tol)
+    ncp = par.n_camera_params
+    intr = float(np.abs(two.x[:ncp].reshape(-1, 9)[:, 6:] - one.x[:ncp].reshape(-1, 9)[:, 6:]).max())
+    free = dict(rel=float(abs(two.cost - one.cost) / one.cost), inside=bool(np.all(two.x[:ncp] > lb[:ncp]) and np.all(two.x[:ncp] < ub[:ncp])), intr=intr)
+
+    sc = board_scene(n_cams=4, n_frames=4)
+    ga, gb, d, w = sc["constraints"]
+    par = sc["par"]
+    prob = BAProblem(par, sc["cam"], sc["uv"], sc["obj"], constraint_groups_a=ga, constraint_groups_b=gb, constraint_distances=d, constraint_weights=w)
+    one = least_squares(None, sc["x0"], jac=None, bounds=par.bounds(), x_scale="jac", method="trf", args=(par, sc["cam"], sc["uv"], sc["obj"], ga, gb, d, w), **tol)
+    two = solve_multi_device(prob, sc["x0"], [0, 0], backend="direct", **tol)
+    pos, ang, scale = aligned_difference(par, two.x, one.x)
+    print(json.dumps(dict(free=free, con=dict(rel=float(abs(two.cost - one.cost) / one.cost), pos=float(pos), ang=float(ang), scale=float(scale)))))
+    """)
+    assert out["free"]["rel"] <= 1e-8 and out["free"]["inside"] and out["free"]["intr"] < 1e-6, out
+    assert out["con"]["rel"] <= 1e-8 and out["con"]["pos"] < 1e-6 and out["con"]["ang"] < 1e-6 and abs(out["con"]["scale"] - 1) < 1e-4, out
+
+
+def test_a_failing_rank_releases_the_host_group(cpu_lib):
+    """One rank fails before joining (its shard has no observations): the others must come back with an error, not wait."""
+    out = _run(cpu_lib, _SHARD_PRELUDE + """
+    par, prob, x0, fs, sc = problem(n_cams=4, n_points=40, k=4)
+    keep = sc.obj_indices < 3
+    tiny = BAProblem(par, sc.camera_indices[keep], sc.image_coords[keep], sc.obj_indices[keep])
+    try:
+        solve_multi_device(tiny, x0, [0, 0, 0, 0], backend="direct", max_nfev=5)
+        msg = "no error"
+    except ValueError as e:
+        msg = str(e)
+    print(json.dumps(dict(msg=msg)))
+    """, timeout=60)
+    assert "owns no observations" in out["msg"]
+
+
 def test_unsupported_entries_fail_loudly(cpu_lib):
     out = _run(cpu_lib, """
         import json
@@ -230,7 +335,8 @@ def test_unsupported_entries_fail_loudly(cpu_lib):
         msg = _lib.last_error(lib)
         import ctypes as C
         g = C.c_void_p()
-        rc2 = lib.cba_group_create(2, C.byref(g))
-        print(json.dumps(dict(rc=rc, msg=msg, rc2=rc2)))
+        rc2 = lib.cba_group_create(17, C.byref(g))
+        rc3 = lib.cba_triangulate(None, 0, None, None)
+        print(json.dumps(dict(rc=rc, msg=msg, rc2=rc2, rc3=rc3)))
     """)
-    assert out["rc"] == -4 and "one rank" in out["msg"] and out["rc2"] == -4
+    assert out["rc"] == -4 and "one rank" in out["msg"] and out["rc2"] == -1 and out["rc3"] == -4
