@@ -1806,80 +1806,81 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// 1/sqrt(d) to double precision: v_rsq_f64 seed + two Newton steps (an IEEE sqrt followed by an IEEE divide is
-// ~35 dependent FP64 instructions and sits on the serial pivot chain of the factorisation)
-__device__ __forceinline__ double fast_rsqrt(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - 0.5 * d * y * y);
-  y = y * (1.5 - 0.5 * d * y * y);
-  return y;
-}
-
-// Factor the NB x NB block parked in `D` (LDS, row stride NB + 1, `nb` live rows, identity-padded) with wave 0.
-// Left-looking by columns, lane r keeps row r in registers:  v_r = D_rj - sum_{t<j} L_rt L_jt, L_jj = sqrt(v_j),
-// L_rj = v_r / L_jj.  Row j of L is read back from LDS as broadcasts (every lane stores its new entry D[r][j] = L_rj
-// at pivot j; a wave executes its DS instructions in order, wave-scope fences only pin the compiler), prefetched one
-// pivot ahead; only the newest entry L_j,j-1 is on the critical path and travels by v_readlane instead.
-// History: a right-looking version (row[c] -= L_rj L_cj for all c > j at each pivot) needed ~20 us per block: its
-// 496 in-place updates of 32 live row registers made the register allocator spill 1.3 KB per lane.  This form has
-// one short-lived dot product per pivot: 88 VGPRs, no scratch, 2x faster (tools/chol_factor_bench).
-// The factor goes to the lower triangle of the global block at `out` (row stride ldw).
-__device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, double* __restrict__ out, int ldw,
-                                                  int* __restrict__ flags, double* __restrict__ xinv) {
-  // D has 2 NB rows (rows NB.. are scratch).  Lanes 0..31 factor: lane r keeps row r of L.  Lanes 32..63 run the SAME instruction stream on a column of X = L^-1
-  // (lane 32 + c keeps column c):  X_jc = (delta_jc - sum_{t<j} L_jt X_tc) / L_jj  is the row recurrence
-  // v_r = D_rj - sum_{t<j} L_rt L_jt with the lane's own values X_tc in the place of L_rt and delta_jc in the place of D_rj;
-  // the broadcast row L_j,: and the pivot are shared.  The inverse costs nothing (the lanes were idle) and turns the panel
-  // solves of the next step and the backward substitution into matrix products (k_chol_step, k_chol_backward).
-  const int lane = threadIdx.x;
+// Factor the NB x NB block parked in `D` (LDS, 2 NB rows of stride NB + 1, `nb` live rows, identity-padded) with wave 0; the factor stays
+// in LDS: rows 0..NB-1 of D hold L (zeros above the diagonal), row NB + c holds column c of X = L^-1 (chol_factor_store copies both out).
+// Left-looking by columns, lane r < NB keeps row r of L in registers:  v_r = D_rj - sum_{t<j} L_rt L_jt, L_jj = sqrt(v_j), L_rj = v_r / L_jj.
+// Lanes NB.. run the SAME instruction stream on a column of X (lane NB + c keeps column c):  X_jc = (delta_jc - sum_{t<j} L_jt X_tc) / L_jj
+// is the row recurrence with the lane's own values X_tc in the place of L_rt and delta_jc in the place of D_rj; the broadcast row L_j,: and
+// the pivot are shared.  The inverse costs nothing (the lanes were idle) and turns the panel solves of the next step and the backward
+// substitution into matrix products (k_chol_step, k_chol_backward).
+// Row j + 1 of L is read back from LDS as broadcasts (every lane stores its new entry D[lane][j] at pivot j; a wave executes its DS
+// instructions in order, wave-scope fences only pin the compiler) at the top of pivot j, and the sum over its final columns t < j is formed
+// between the instructions of pivot j's chain; the newest entry L_j+1,j travels by v_readlane.
+// A pivot is a chain of DEPENDENT FP64 instructions, ~300 cycles, and 32 of them are the critical path of a panel step, so the chain is short:
+//   * the pivot d_j = a_j - L_j,j-1^2 is formed by lane j from its own registers (no broadcast of L_j,j-1 in front of it);
+//   * 1/sqrt(d) is v_rsq_f64 and ONE third-order correction folded into the product with the lane's value:
+//       u = v y0, e = 1 - (d y0) y0, L_rj = u + (u e)(1/2 + 3/8 e)            (rsq, d y0, e, u e, fma: five levels);
+//   * the checks of the pivot (positive, finite) and the zeros above the diagonal are applied beside the chain.  A failed pivot raises
+//     flags[2] (the caller discards the step) and the block is replaced by the identity, so nothing non-finite leaves it.
+// History (tools/chol_factor_bench, us per block): right-looking updates of 32 live row registers 20 (1.3 KB of scratch per lane);
+// left-looking, IEEE sqrt and divide 9; v_rsq + two Newton steps, pivot replaced by 1.0 on the chain, each lane storing its row and its
+// column of X to global memory 7.3; 2 x 2 pivots (two independent rsqrt chains) 6.8; two 16-wide stages joined by FP64 MFMA products 5.9
+// (a 16-wide pivot takes 300 cycles, a 32-wide one 360: the chain, not the instruction count); this form 5.5, of which the copy-out 0.35.
+__device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, int* __restrict__ flags) {
+  int lane = threadIdx.x;
+  asm volatile("" : "+v"(lane));  // (a caller's loop must not hoist the lane masks of all 32 pivots out of it: they do not fit the SGPRs)
   const int r = lane & (NB - 1);
   const bool isX = lane >= NB;
   double row[NB];
 #pragma unroll
   for (int c = 0; c < NB; ++c) row[c] = isX ? (c == r ? 1.0 : 0.0) : D[r][c];
-  bool bad = false;
-  double s_prev = 0.0;
-  double pre[NB];
-#pragma unroll
-  for (int t = 0; t < NB; ++t) pre[t] = 0.0;
+  int bad = 0;
+  double s_prev = 0.0, raw_prev = 0.0;  // L_j,j-1 (broadcast) and this lane's own unmasked entry of column j - 1
+  double asum = row[0];                 // D_rj - sum_{t<j-1} L_rt L_jt of the pivot at hand, formed during the previous pivot's chain
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     double nxt[NB];  // row j + 1 of L, entries t < j (final since pivot j - 1)
 #pragma unroll
     for (int t = 0; t < NB; ++t) nxt[t] = (j + 1 < NB && t < j) ? D[(j + 1) & (NB - 1)][t] : 0.0;
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this pivot's arithmetic (the scheduler sinks it otherwise)
-    double a[4] = {row[j], 0.0, 0.0, 0.0};  // four chains: a dependent FP64 FMA costs ~20 cycles
+    __builtin_amdgcn_sched_barrier(0);  // the reads go first
+    const double d = readlane_f64(fma(-raw_prev, raw_prev, asum), j);        // lane j: its own L_j,j-1 twice
+    const double acc = (j >= 1) ? fma(-row[j - 1], s_prev, asum) : asum;     // every lane (lane j: bit-identical to d)
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double u = acc * y0;
+    const double e = fma(-(d * y0), y0, 1.0);
+    const double raw = fma(u * e, fma(0.375, e, 0.5), u);
+    // independent of the chain above and issued between its instructions: the next pivot's sum over the columns that are final
+    double a[4] = {j + 1 < NB ? row[(j + 1) & (NB - 1)] : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t + 1 < j; ++t) a[t & 3] -= row[t] * pre[t];
-    double acc = (a[0] + a[1]) + (a[2] + a[3]);
-    if (j >= 1) acc -= row[j - 1] * s_prev;
-    double d = readlane_f64(acc, j);
-    if (j < nb && (!(d > 0.0) || !isfinite(d))) { bad = true; d = 1.0; }
-    const double inv = fast_rsqrt(d);
-    // selects on values, one multiply: written as nested products the compiler put divergent branches on the pivot chain
-    double v = acc;
-    v = (!isX && r == j) ? d : v;
-    v = (!isX && r < j) ? 0.0 : v;
-    const double l = v * inv;
+    for (int t = 0; t < j; ++t) a[t & 3] -= row[t] * nxt[t];
+    asum = (a[0] + a[1]) + (a[2] + a[3]);
+    if (j + 1 < NB) s_prev = readlane_f64(raw, j + 1);
+    raw_prev = raw;
+    const double l = (!isX && r < j) ? 0.0 : raw;
     row[j] = l;
-    D[lane][j] = l;  // rows NB.. of D take the X lanes' values (never read): no divergent store inside the pivot chain
-    if (j + 1 < NB) s_prev = readlane_f64(l, j + 1);
+    D[lane][j] = l;
+    if (j < nb && (!(d > 0.0) || !isfinite(d))) bad = 1;
+    asm volatile("" : "+v"(bad));  // settled per pivot (left alone, the compiler keeps every pivot's comparison masks to the end and spills them)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int t = 0; t < NB; ++t) pre[t] = nxt[t];
   }
-  if (bad && lane == 0) flags[2] = 1;
-  if (!isX) {
-    if (lane < nb) {
+  if (bad) {  // wave-uniform (d is)
+    if (lane == 0) flags[2] = 1;
 #pragma unroll
-      for (int c = 0; c < NB; ++c)
-        if (c <= lane) out[(long)lane * ldw + c] = row[c];
-    }
-  } else {  // X (NB x NB, row-major, identity-padded beyond nb): lane 32 + c holds column c
-#pragma unroll
-    for (int t = 0; t < NB; ++t) xinv[t * NB + r] = row[t];
+    for (int c = 0; c < NB; ++c) D[lane][c] = (c == r) ? 1.0 : 0.0;
+  }
+}
+
+// every thread of the workgroup, behind a barrier: L (lower triangle, live rows) to the global block at `out` (row stride ldw) and
+// X = L^-1 (NB x NB, row-major, identity-padded beyond nb) to `xinv`.  Three stores per thread instead of 32 per lane of the factoring wave.
+__device__ __forceinline__ void chol_factor_store(double (*D)[NB + 1], int nb, double* __restrict__ out, int ldw, double* __restrict__ xinv,
+                                                  int tid, int nthreads) {
+  for (int e = tid; e < NB * NB; e += nthreads) {
+    const int i = e / NB, c = e % NB;
+    const double l = D[i][c], x = D[NB + c][i];
+    if (i < nb && c <= i) out[(long)i * ldw + c] = l;
+    xinv[e] = x;
   }
 }
 
@@ -1990,7 +1991,9 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
 #pragma unroll
     for (int h = 0; h < EPT; ++h) sh_D[i0 + h * ISTEP][j] = d_ij[h];
     __syncthreads();
-    if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags, Xinv);  // X_0
+    if (tid < WAVE) chol_factor_block(sh_D, rc, flags);
+    __syncthreads();
+    chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv, tid, CHOL_THREADS);  // L_00, X_0
     return;
   }
   const int k0 = k * NB, nbp = min(NB, n - k0);
@@ -2067,7 +2070,9 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   // 4. look-ahead: the next panel's diagonal block
   __syncthreads();
   CHOL_STAMP(5);
-  if (tid < WAVE) chol_factor_block(sh_D, rc, Wb + rb, ldw, flags, Xinv + (long)(k + 1) * NB * NB);
+  if (tid < WAVE) chol_factor_block(sh_D, rc, flags);
+  __syncthreads();
+  chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv + (long)(k + 1) * NB * NB, tid, CHOL_THREADS);
   CHOL_STAMP(6);
 #undef CHOL_STAMP
 }
