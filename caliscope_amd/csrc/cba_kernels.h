@@ -2386,7 +2386,7 @@ __global__ void k_fused_subspace(double* __restrict__ scal, const int* __restric
 __device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) {
   const double gh_sq = scal[0], jg_sq = scal[12], xs = sqrt(scal[1]);
   const double radius = radius_in > 0.0 ? radius_in : (xs > 0.0 ? xs : 1.0);  // first iteration: Delta = ||x0 * scale_inv||
-  const double lam = -trf::min_quadratic_on_segment(0.5 * jg_sq, -gh_sq, radius / sqrt(gh_sq)) / (radius * radius);
+  const double lam = trf::damping(jg_sq, gh_sq, radius);
   fz[0] = lam; fz[1] = radius;
   scal[40] = lam; scal[41] = radius;
 }

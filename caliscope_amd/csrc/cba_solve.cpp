@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/caliscope_ba.h"
@@ -23,7 +24,6 @@ namespace {
 // ||w||^2 / ||p||^2 below which the subspace model is built from explicit J.v products (trf.py, same constant)
 constexpr double SUBSPACE_EXPLICIT_BELOW = 1e-6;
 
-using trf::min_quadratic_on_segment;
 using trf::solve_subspace_2d;
 
 int termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
@@ -74,6 +74,32 @@ void minimize_quadratic_1d(double a, double b, double lo, double hi, double c, d
   }
 }
 
+// CBA_SOLVE_TRACE=1: host wall-clock per primitive (enqueue + whatever the call waits for), printed to stderr at the end of the solve
+struct CallTrace {
+  struct Row { const char* name; double s; long n; };
+  bool on = std::getenv("CBA_SOLVE_TRACE") != nullptr;
+  Row rows[24];
+  int used = 0;
+  template <class F> int run(const char* name, F&& f) {
+    if (!on) return f();
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = f();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int i = 0;
+    while (i < used && std::strcmp(rows[i].name, name) != 0) ++i;
+    if (i == used) { if (used == 24) return rc; rows[used++] = Row{name, 0.0, 0}; }
+    rows[i].s += dt; ++rows[i].n;
+    return rc;
+  }
+  void print(double total_s, long iterations) const {
+    if (!on) return;
+    double sum = 0.0;
+    for (int i = 0; i < used; ++i) sum += rows[i].s;
+    std::fprintf(stderr, "cba_solve trace: %ld iterations, %.3f ms, of which %.3f ms inside the primitives\n", iterations, total_s * 1e3, sum * 1e3);
+    for (int i = 0; i < used; ++i) std::fprintf(stderr, "  %-22s %5ld calls %9.3f ms  %8.1f us each\n", rows[i].name, rows[i].n, rows[i].s * 1e3, rows[i].s * 1e6 / rows[i].n);
+  }
+};
+
 }  // namespace
 
 extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_options* opt_in, double* x_out, cba_result* out) {
@@ -100,6 +126,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   CamBlock cb;
   if (bounded) { cb.resize(ncp); cb.lb = opt.lb; cb.ub = opt.ub; }
   const auto t_begin = std::chrono::steady_clock::now();
+  CallTrace calls;
 
   auto not_finite_at_x0 = [&](double c) {  // scipy raises "Residuals are not finite in the initial point": status -1, nothing solved
     out->status = -1; out->reserved = 0; out->nfev = 1; out->njev = 0; out->n_iterations = 0; out->cost = c; out->optimality = NAN;
@@ -111,12 +138,12 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   // pass over the observations and one wait less per solve.
   const char* defer_env = std::getenv("CBA_DEFER");
   const bool deferred = !bounded && !(defer_env && defer_env[0] == '0');
-  if (deferred) rc = cba_begin_deferred(p, x0);
-  else rc = x0 ? cba_begin(p, x0, &cost) : cba_restart(p, &cost);
+  if (deferred) rc = calls.run("begin_deferred", [&] { return cba_begin_deferred(p, x0); });
+  else rc = x0 ? calls.run("begin", [&] { return cba_begin(p, x0, &cost); }) : calls.run("restart", [&] { return cba_restart(p, &cost); });
   if (rc) return rc;
   if (!deferred && !std::isfinite(cost)) return not_finite_at_x0(cost);
   if (bounded) {  // scipy: "`x0` is infeasible." (callers nudge on-bound entries inside first, least_squares.py:820-821)
-    if ((rc = cba_get_camera_params(p, CBA_VEC_X, cb.x.data()))) return rc;
+    if ((rc = calls.run("get_camera_params", [&] { return cba_get_camera_params(p, CBA_VEC_X, cb.x.data()); }))) return rc;
     for (int i = 0; i < ncp; ++i)
       if (!(cb.x[i] > cb.lb[i] && cb.x[i] < cb.ub[i])) return cba_set_error(CBA_ERR_INVALID, "cba_solve: x0 is not strictly inside the bounds");
   }
@@ -141,11 +168,11 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     bool have_step = false;  // `si` holds this iteration's damped step and first trial
     if (!lin_valid) {
       if (status == -100 && fuse_next && nfev < max_nfev) {
-        if ((rc = cba_step(p, std::isnan(radius) ? -1.0 : radius, &si))) return rc;
+        if ((rc = calls.run("step", [&] { return cba_step(p, std::isnan(radius) ? -1.0 : radius, &si); }))) return rc;
         lin = si.lin; have_step = true;
       } else if (bounded) {
-        if ((rc = cba_linearize_build(p))) return rc;  // the scalars follow from cba_set_camera_scaling below
-      } else if ((rc = cba_linearize(p, &lin))) return rc;
+        if ((rc = calls.run("linearize_build", [&] { return cba_linearize_build(p); }))) return rc;  // the scalars follow from cba_set_camera_scaling below
+      } else if ((rc = calls.run("linearize", [&] { return cba_linearize(p, &lin); }))) return rc;
       lin_valid = true;
       if (std::isnan(cost)) {  // deferred begin: this was the evaluation of x0
         cost = lin.cost;
@@ -154,7 +181,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     }
     if (bounded) {
       // Coleman-Li scaling vector of the camera block (common.py CL_scaling_vector) and what follows from it
-      if ((rc = cba_get_camera_state(p, cb.x.data(), cb.g.data(), cb.sinv.data()))) return rc;  // sinv: the Jacobi scale (restored by the linearisation)
+      if ((rc = calls.run("get_camera_state", [&] { return cba_get_camera_state(p, cb.x.data(), cb.g.data(), cb.sinv.data()); }))) return rc;  // sinv: the Jacobi scale (restored by the linearisation)
       double gv_max = 0.0;
       for (int i = 0; i < ncp; ++i) {
         double v = 1.0, dv = 0.0;
@@ -168,7 +195,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         cb.gh[i] = cb.g[i] * cb.d[i];
         C_gg += cb.diag_h[i] * cb.gh[i] * cb.gh[i];
       }
-      if ((rc = cba_set_camera_scaling(p, cb.mult.data(), cb.diag_h.data(), &lin))) return rc;
+      if ((rc = calls.run("set_camera_scaling", [&] { return cba_set_camera_scaling(p, cb.mult.data(), cb.diag_h.data(), &lin); }))) return rc;
       g_norm = std::max(gv_max, lin.g_norm_inf);               // ||g * v||_inf: lin.g_norm_inf covers the point block (v = 1)
     } else {
       g_norm = lin.g_norm_inf;
@@ -186,21 +213,23 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     const double gh_sq = lin.gh_sq, gh_norm = std::sqrt(gh_sq);
     const double H_gg = lin.jg_sq + C_gg;
     // regularisation = model decrease along -g_h inside the region, per unit radius^2 (trf.py:303-309 / :477-483)
-    double lam = -min_quadratic_on_segment(0.5 * H_gg, -gh_sq, radius / gh_norm) / (radius * radius);
+    double lam = trf::damping(H_gg, gh_sq, radius);
     cba_newton_info st;
     if (have_step) {
       lam = si.lam; st = si.newton;
       // collinear step: the explicit-model branch below needs ||w||^2 measured, not derived (cba_step's shortcut)
-      if (si.need_host && st.ok && (rc = cba_refresh_step_scalars(p, &st))) return rc;
-    } else if ((rc = cba_newton_step(p, lam, &st))) return rc;
+      if (si.need_host && st.ok && (rc = calls.run("refresh_step_scalars", [&] { return cba_refresh_step_scalars(p, &st); }))) return rc;
+    } else if ((rc = calls.run("newton_step", [&] { return cba_newton_step(p, lam, &st); }))) return rc;
     bool first_trial_ready = have_step && st.ok && !si.need_host;
+    if (calls.on) std::fprintf(stderr, "  iteration %ld: lam %.3e radius %.3e ok %d%s\n", iteration, lam, radius, st.ok, have_step ? " (fused)" : "");
     for (int retries = 0; !st.ok;) {
       // positive definite in exact arithmetic; rounding on a gauge-singular problem can still break the factorisation
       if (++retries > max_retries) return cba_set_error(CBA_ERR_NUMERIC, "cba_solve: normal equations could not be factorised even with heavy damping");
       lam = std::max(lam * 10.0, 1e-14 * std::pow(10.0, retries));
-      if ((rc = cba_newton_step(p, lam, &st))) return rc;
+      if ((rc = calls.run("newton_step", [&] { return cba_newton_step(p, lam, &st); }))) return rc;
+      if (calls.on) std::fprintf(stderr, "    retry %d: lam %.3e ok %d\n", retries, lam, st.ok);
     }
-    if (bounded && (rc = cba_get_camera_params(p, CBA_VEC_STEP, cb.s.data()))) return rc;
+    if (bounded && (rc = calls.run("get_camera_params", [&] { return cba_get_camera_params(p, CBA_VEC_STEP, cb.s.data()); }))) return rc;
     // orthonormal basis of span{g_h, p}: q1 = g_h / ||g_h||, q2 = w / ||w||, w = p - c g_h
     const double c = st.gh_dot_p / gh_sq, w_sq = st.w_sq;
     const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * st.p_sq;
@@ -214,7 +243,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     } else {
       // p nearly collinear with g_h (heavy damping): the identities cancel, form J_h q1, J_h q2 explicitly
       double gram[3];
-      if ((rc = cba_subspace_gram(p, 1.0 / gh_norm, 0.0, -c / w_norm, 1.0 / w_norm, gram))) return rc;
+      if ((rc = calls.run("subspace_gram", [&] { return cba_subspace_gram(p, 1.0 / gh_norm, 0.0, -c / w_norm, 1.0 / w_norm, gram); }))) return rc;
       b00 = gram[0]; b01 = gram[1]; b11 = gram[2];
       for (int i = 0; i < cb.n; ++i) {  // + S^T C S
         const double q1 = cb.gh[i] / gh_norm, q2 = (cb.s[i] / cb.d[i] - c * cb.gh[i]) / w_norm;
@@ -241,7 +270,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if (first_pass && first_trial_ready) {
         tr = si.trial; predicted = si.predicted;  // the trial cba_step already evaluated
       } else if (!bounded) {
-        if ((rc = cba_trial(p, alpha, beta, &tr))) return rc;
+        if ((rc = calls.run("trial", [&] { return cba_trial(p, alpha, beta, &tr); }))) return rc;
       } else {
         // select_step (trf.py:129-202): the trust-region step if it stays inside the bounds, else the best of the step
         // truncated at the bound, its reflection from the bound, and the scaled-gradient step
@@ -280,7 +309,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
           if (r_lo <= r_hi) {
             // quadratic along r_h from s0 = p_stride p_h (build_quadratic_1d with s0): needs J_h p_h, J_h r_h
             double gram[3];
-            if ((rc = cba_subspace_gram_ex(p, alpha, beta, nullptr, alpha, beta, cb.r.data(), gram))) return rc;
+            if ((rc = calls.run("subspace_gram_ex", [&] { return cba_subspace_gram_ex(p, alpha, beta, nullptr, alpha, beta, cb.r.data(), gram); }))) return rc;
             const double qa = 0.5 * (gram[2] + C_rr);
             const double qb = (lin_p - 2.0 * hit_gh_ph) + p_stride * (gram[1] + C_pr);
             const double qc = 0.5 * p_stride * p_stride * (gram[0] + C_pp) + p_stride * lin_p;
@@ -317,7 +346,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
           else if (xn >= cb.ub[i]) xn = std::nextafter(cb.ub[i], cb.lb[i]);
           cb.x_new[i] = xn;
         }
-        if ((rc = cba_trial_ex(p, pt_alpha, pt_beta, cb.x_new.data(), &tr))) return rc;
+        if ((rc = calls.run("trial_ex", [&] { return cba_trial_ex(p, pt_alpha, pt_beta, cb.x_new.data(), &tr); }))) return rc;
       }
       ++nfev;
       const bool was_first = first_pass;
@@ -341,7 +370,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       radius = radius_new;
     }
     if (actual > 0) {
-      if ((rc = cba_accept(p))) return rc;
+      if ((rc = calls.run("accept", [&] { return cba_accept(p); }))) return rc;
       cost = cost_new;
       lin_valid = false;  // linearised at the top of the next pass (by cba_step when fused)
       ++njev;
@@ -351,11 +380,12 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
     ++iteration;
   }
   if (status == -100) status = 0;
-  if (x_out && (rc = cba_get_vector(p, CBA_VEC_X, x_out))) return rc;
+  if (x_out && (rc = calls.run("get_vector", [&] { return cba_get_vector(p, CBA_VEC_X, x_out); }))) return rc;
   out->status = std::isfinite(cost) ? status : -1;
   out->reserved = std::min(n_truncated, 1023) | (std::min(n_reflected, 1023) << 10) | (std::min(n_gradient, 1023) << 20);
   out->nfev = nfev; out->njev = njev; out->n_iterations = iteration;
   out->cost = cost; out->optimality = g_norm;
   out->t_total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  calls.print(out->t_total_s, iteration);
   return CBA_OK;
 }

@@ -22,6 +22,19 @@ TRF_HD inline double min_quadratic_on_segment(double a, double b, double hi) {
   return best;
 }
 
+// Marquardt damping of an iteration = the model decrease along -g_h inside the trust region, per unit radius^2 (scipy trf.py:303-309 /
+// :477-483; H_gg = |J_h g_h|^2 (+ g_h^T C g_h with bounds)).  Near a minimum it falls like the squared gradient norm — 1e-17 .. 1e-20 in
+// the last iterations of a solve — while the reduced camera system of a gauge-free problem is singular without it: below ~n eps the
+// damped matrix is not positive definite in double precision, the factorisation fails and the step has to be formed again (a whole
+// Schur pass; measured on the 128-camera workload: every iteration after the fifth paid twice).  The floor is the value such a retry
+// used anyway; against a step equation solved exactly it moves the step by O(floor / sigma_min^2) outside the gauge directions, orders
+// of magnitude below the 1e-6 tolerance scipy's LSMR solves the same equation to.
+constexpr double DAMPING_FLOOR = 1e-13;
+TRF_HD inline double damping(double H_gg, double gh_sq, double radius) {
+  const double lam = -min_quadratic_on_segment(0.5 * H_gg, -gh_sq, radius / sqrt(gh_sq)) / (radius * radius);
+  return lam > DAMPING_FLOOR ? lam : DAMPING_FLOOR;
+}
+
 TRF_HD inline double poly_eval(const double* c, int deg, double t) {
   double p = c[0];
   for (int i = 1; i <= deg; ++i) p = p * t + c[i];

@@ -70,6 +70,9 @@ class TrfResult:
         return self.status > 0
 
 
+DAMPING_FLOOR = 1e-13  # csrc/trf_math.h
+
+
 def _min_quadratic_on_segment(a: float, b: float, hi: float) -> float:
     """min over t in [0, hi] of a t^2 + b t."""
     best = min(0.0, hi * (a * hi + b))
@@ -195,7 +198,8 @@ def trf_solve(
         gh_sq = lin.gh_sq
         gh_norm = math.sqrt(gh_sq)
         # Regularisation = the model decrease along -g_h inside the region, per unit radius^2.
-        lam = -_min_quadratic_on_segment(0.5 * lin.jg_sq, -gh_sq, radius / gh_norm) / (radius * radius)
+        # (floored where the damped system can still be factorised in double precision: csrc/trf_math.h, trf::damping)
+        lam = max(-_min_quadratic_on_segment(0.5 * lin.jg_sq, -gh_sq, radius / gh_norm) / (radius * radius), DAMPING_FLOOR)
 
         st = engine.newton_step(lam)
         retries = 0

@@ -301,7 +301,7 @@ int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
   if (rc) return rc;
   const double gh_sq = out->lin.gh_sq, gh_norm = std::sqrt(gh_sq);
   const double radius = radius_in > 0.0 ? radius_in : (out->lin.x_scaled_norm > 0.0 ? out->lin.x_scaled_norm : 1.0);
-  const double lam = -trf::min_quadratic_on_segment(0.5 * out->lin.jg_sq, -gh_sq, radius / gh_norm) / (radius * radius);
+  const double lam = trf::damping(out->lin.jg_sq, gh_sq, radius);
   out->lam = lam; out->radius = radius;
   if ((rc = cba_newton_step(p, lam, &out->newton))) return rc;
   const double p_sq = out->newton.p_sq, ghp = out->newton.gh_dot_p;

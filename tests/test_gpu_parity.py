@@ -204,7 +204,8 @@ def test_step_parity(name):
             D2 = sp.diags(ora.scale_inv ** 2)
             H = (ora.J.T @ ora.J + lam * D2).tocsc()
             s_full = splu(H).solve(-ora.g)
-            assert np.abs(s_h - s_full).max() < 1e-8 * np.abs(s_full).max(), lam
+            # (at lam = 1e-7 the gauge directions are held by the damping alone: cond(H) eps ~ 1e-8 is the accuracy of EITHER solve)
+            assert np.abs(s_h - s_full).max() < (1e-8 if lam >= 1e-3 else 1e-7) * np.abs(s_full).max(), lam
             Hcc, Hcp, Hpp = H[:ncp, :ncp].toarray(), H[:ncp, ncp:], H[ncp:, ncp:].tocsc()
             S_ref = Hcc - Hcp @ splu(Hpp).solve(Hcp.T.toarray())
             assert np.abs(S - S_ref).max() < 1e-9 * np.abs(S_ref).max(), lam
