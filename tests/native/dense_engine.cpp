@@ -33,6 +33,7 @@ struct cba_problem {
   // all-reduce over the group: the first n_sum entries are summed, the next n_max maximised; non-zero = the group was aborted
   std::function<int(double* buf, int n_sum, int n_max)> reduce;
   bool lead = true;  // this rank counts the replicated camera block in sums over the parameters
+  long n_damped_steps = 0, n_failed_factorisations = 0;  // since creation (de_counters)
   int exchange(double* buf, int n_sum, int n_max = 0) {
     return (reduce && reduce(buf, n_sum, n_max)) ? cba_set_error(CBA_ERR_INVALID, "group aborted: another rank failed or never arrived") : 0;
   }
@@ -62,6 +63,8 @@ void de_subspace(double b00, double b01, double b11, double g0, double g1, doubl
   trf::solve_subspace_2d(b00, b01, b11, g0, g1, radius, p);
 }
 int de_real_roots(const double* c, int n_coef, double* out) { return trf::real_roots(c, n_coef, out); }
+double de_damping(double H_gg, double gh_sq, double radius) { return trf::damping(H_gg, gh_sq, radius); }
+void de_counters(cba_problem* p, long* out) { out[0] = p->n_damped_steps; out[1] = p->n_failed_factorisations; }
 
 int cba_set_error(int32_t code, const char* message) { g_err = message ? message : ""; return code; }
 const char* cba_last_error(void) { return g_err.c_str(); }
@@ -175,6 +178,7 @@ static int step_scalars(cba_problem* p, cba_newton_info* out) {
 int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
   const int m = p->m, n = p->n, ncp = p->ncp, np3 = n - ncp;  // positions [0, np3): points, [np3, n): cameras
   p->last_lam = lam;
+  ++p->n_damped_steps;
   std::vector<double> A((size_t)n * n, 0.0), b(n, 0.0);
   std::vector<int> first(n), nz;
   for (int a = 0; a < n; ++a) first[a] = a;
@@ -243,7 +247,7 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
         else R[(size_t)i * ncp + i] = std::sqrt(v);
       }
   }
-  if (!ok) { out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
+  if (!ok) { ++p->n_failed_factorisations; out->ok = 0; out->p_sq = out->gh_dot_p = out->w_sq = 0.0; return CBA_OK; }
   for (int i = 0; i < ncp; ++i) { double v = xc[i]; for (int k = 0; k < i; ++k) v -= R[(size_t)i * ncp + k] * xc[k]; xc[i] = v / R[(size_t)i * ncp + i]; }
   for (int i = ncp - 1; i >= 0; --i) { xc[i] /= R[(size_t)i * ncp + i]; for (int k = 0; k < i; ++k) xc[k] -= R[(size_t)i * ncp + k] * xc[i]; }
   // back-substitution of the points: the camera unknowns first leave the point rows' right-hand sides

@@ -53,6 +53,9 @@ def _solve(lib, fun, jac, x0, m, ncp=0, lb=None, ub=None, **kw):
                             verbose=0, max_damping_retries=0)
     res, x = _lib.Result(), np.empty(n)
     rc = lib.cba_solve(h, x0.ctypes.data_as(_lib.c_double_p), C.byref(opt), x.ctypes.data_as(_lib.c_double_p), C.byref(res))
+    counters = (C.c_long * 2)()
+    lib.de_counters(C.c_void_p(h), counters)
+    res.damped_steps, res.failed_factorisations = int(counters[0]), int(counters[1])
     lib.de_destroy(h)
     assert rc == 0, lib.cba_last_error()
     return res, x, evals
@@ -213,3 +216,28 @@ def test_bounded_driver_uses_all_three_candidates_of_select_step(native):
         assert np.allclose(x, sci.x, rtol=1e-4, atol=1e-5), (k, x, sci.x)
         used += np.array([res.reserved & 1023, (res.reserved >> 10) & 1023, (res.reserved >> 20) & 1023])
     assert np.all(used > 0), used
+
+
+def test_damping_rule_and_its_floor(native):
+    """trf::damping (csrc/trf_math.h): scipy's regularisation rule (trf.py:477-483) above the floor, the floor below — and a gauge-free
+    bundle solved to a vanishing gradient forms every damped step once (without the floor the factorisation of the late iterations fails:
+    their damping, ~|g|^2, is lost in the rounding of the singular reduced system)."""
+    from caliscope_amd.trf import DAMPING_FLOOR, _min_quadratic_on_segment
+
+    native.de_damping.restype = C.c_double
+    native.de_damping.argtypes = [C.c_double] * 3
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        gh_sq, radius = 10.0 ** rng.uniform(-30, 2), 10.0 ** rng.uniform(-3, 4)
+        H_gg = gh_sq * 10.0 ** rng.uniform(-2, 2)
+        rule = -_min_quadratic_on_segment(0.5 * H_gg, -gh_sq, radius / np.sqrt(gh_sq)) / radius ** 2
+        got = native.de_damping(H_gg, gh_sq, radius)
+        assert got == max(rule, DAMPING_FLOOR) or abs(got - rule) <= 1e-15 * rule
+    assert native.de_damping(1.0, 1e-40, 1e3) == DAMPING_FLOOR == 1e-13
+
+    sc, par, x0 = small_problem(n_cams=4, n_points=40, k=4)
+    args = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    res, _, _ = _solve(native, lambda x: joint_residuals(x, *args), lambda x: joint_jacobian(x, *args).toarray(), x0, 2 * len(sc.camera_indices),
+                       ncp=par.n_camera_params, ftol=1e-15, xtol=1e-15, gtol=1e-13, max_nfev=60)
+    assert res.status > 0 and res.optimality < 1e-10
+    assert res.failed_factorisations == 0 and res.damped_steps - res.n_iterations in (0, 1)  # (+1: the fused step speculated before the gtol exit)
