@@ -1,0 +1,20 @@
+#!/bin/bash
+# experiment: the six-parameter pair kernel with 192-slot chunks (49 KB of LDS) and three workgroups per CU (launch bounds for 170 registers) against the default
+# (320 slots, two per CU).  The variant libraries are built by hand (see the macros in csrc/cba_kernels.h / cba_lib.hip) into tools/exp/.
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+O=$GRAFT_REPO_ROOT/gpurun_out/exp; mkdir -p $O
+run() {  # name, library ("" = the product's), CBA_GRID_MULT
+  local lib="X_UNUSED=1"; [ -n "$2" ] && lib="CALISCOPE_BA_LIB=$GRAFT_REPO_ROOT/tools/exp/$2"
+  env $lib CBA_GRID_MULT=$3 timeout 100 python bench.py --no-cpu --also "" --steps 30 --warmup 6 > $O/$1.json 2> $O/$1.err
+  python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/exp/{sys.argv[1]}.json").read().strip().splitlines()[-1]); k = d["roofline"]["kernels"]
+print(sys.argv[1], d["ms_per_step"], "pairs", k["schur_pairs"]["avg_us"], "schur", k["schur"]["avg_us"], "build", k["build"]["avg_us"], "rms", d["final_rms_px"])
+PY
+}
+[ -n "$ONLY_DEPTH3" ] || run default "" 2
+export CBA_PLAN_REGION=256
+[ -n "$ONLY_DEPTH3" ] || run chunks192_2perCU libcba_exp2.so 2
+[ -n "$ONLY_DEPTH3" ] || run chunks192_3perCU libcba_exp3.so 3
+run chunks192_3buffers libcba_depth3.so 2
