@@ -1289,7 +1289,8 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 // into two sets of accumulators.  One workgroup per CU (8 waves, as two narrow workgroups), every wave loads 64 slots of a
 // 512-slot chunk: seven full load instructions.
 // (experiments: -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_MINW6=3 -DCBA_PER_CU6=3 builds the six-parameter kernel for three workgroups per CU;
-// -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_NBUF6=3 for three chunk buffers, the gather issued two trips ahead)
+// -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_NBUF6=3 for three chunk buffers, the gather issued two trips ahead; with -DCBA_NPROD6=1 -DCBA_MINW6=3 on top a
+// fifth wave of the workgroup issues all gathers and the four others only multiply — NOT RUN YET, written at the end of round 2 for round 3)
 #ifndef CBA_SCHUNK6
 #define CBA_SCHUNK6 320
 #endif
@@ -1298,6 +1299,9 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #endif
 #ifndef CBA_NBUF6
 #define CBA_NBUF6 2
+#endif
+#ifndef CBA_NPROD6
+#define CBA_NPROD6 0
 #endif
 template <int NC, bool WIDE = false> struct Reg3Cfg {
   static_assert(!WIDE || NC == 6, "the wide tile is the one-thread-per-block kernel");
@@ -1320,6 +1324,8 @@ template <int NC, bool WIDE = false> struct Reg3Cfg {
   static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                          // (+1: keeps the second buffer 32-byte aligned)
   static constexpr int NBUF = (!WIDE && NC == 6) ? CBA_NBUF6 : 2;                   // chunk buffers in LDS: a gather is issued NBUF - 1 trips before it is read
   static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_PIECES * 16;
+  static constexpr int NPROD = (!WIDE && NC == 6) ? CBA_NPROD6 : 0;                  // waves that only issue gathers (experiment)
+  static constexpr int LAUNCH_THREADS = REG_BLOCK + NPROD * WAVE;
   static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
   static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
   static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
@@ -1509,6 +1515,106 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     }
   };
 
+  if constexpr (Cfg::NPROD == 1) {
+    // EXPERIMENT (CBA_NPROD6=1, with CBA_NBUF6=3): a fifth wave issues every gather of the workgroup, two trips ahead, and the four block-owning
+    // waves only load their codes and multiply.  profiles/r02_pair_kernel_experiments.txt: the nine gathers of a trip cost a wave 59k of its 76k
+    // issue clocks queueing for the CU's vector-memory path, in order — here only the producer queues.  NOT RUN YET.
+    static_assert(Cfg::NBUF == 3 && VB == 1 && SPLIT == 1 && EPW <= WAVE && NLD == 6, "producer experiment: the narrow kernel with 192-slot chunks (vmcnt below)");
+    auto chunk_at = [&](int k) { return min(first + k * stride, last); };
+    if (tid >= PT) {  // ---- producer wave
+      const int pl = tid - PT;
+      auto issue_for = [&](int buf, int swv, int idxv) {  // the loads wave `swv` of the plain kernel issues for its run of the chunk
+        constexpr int Q = WAVE / LST, RM = WAVE % LST;
+        double2* wbase = sh_p + buf * Cfg::BUF_PIECES + swv * Cfg::WAVE_PIECES;
+        const double2* g[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+          int piece = k * RM + pl % LST;
+          int el = k * Q + pl / LST + piece / LST;
+          piece %= LST;
+          el = min(el, EPW - 1);
+          const int id = __shfl(idxv, el, WAVE);
+          g[k] = reinterpret_cast<const double2*>(Trec + (long)id * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
+      };
+      auto ald = [](const void* ptr) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+      };
+      int idxv[4];
+      {  // records of the first two chunks, the indices of the third, the stream offset of the fourth
+        const int cs0 = p_chunk_start[chunk_at(0)], cs1 = p_chunk_start[chunk_at(1)], cs2 = p_chunk_start[chunk_at(2)];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) issue_for(0, w, p_obs[cs0 + w * EPW + pl]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) issue_for(1, w, p_obs[cs1 + w * EPW + pl]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) idxv[w] = p_obs[cs2 + w * EPW + pl];
+      }
+      int cs_next = p_chunk_start[chunk_at(3)];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(idxv[w]));
+      asm volatile("" : "+v"(cs_next));
+      int buf = 0, k = 0;
+      for (int cur = first; cur < ch_end; cur += stride, ++k) {
+        // state: idxv = indices(t + 2), cs_next = stream offset of chunk t + 3; in flight: records(t + 1), the 4 * NLD = 24 newest loads
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#pragma unroll
+        for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(idxv[w]));
+        asm volatile("" : "+v"(cs_next));
+        __syncthreads();  // records(t) have landed; nobody reads the buffer of trip t - 1 any more
+        int idn[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) idn[w] = (int)ald(p_obs + cs_next + w * EPW + pl);  // indices(t + 3)
+        const int cs_n = (int)ald(p_chunk_start + chunk_at(k + 4));
+        const int target = buf == 0 ? 2 : buf - 1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) issue_for(target, w, idxv[w]);                       // records(t + 2)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) idxv[w] = idn[w];
+        cs_next = cs_n;
+        buf = buf == 2 ? 0 : buf + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+    // ---- the four waves that own blocks: ordinary loads, nothing of theirs has to stay in flight across a trip
+    load_codes(load_raw(chunk_at(0), chunk_at(1)));   // codes(0)
+    Raw rA = load_raw(chunk_at(1), chunk_at(2));      // counts / code offset of chunk 1
+    int buf = 0, k = 0;
+    for (int cur = first; cur < ch_end; cur += stride, ++k) {
+      unsigned cc[NCD];
+#pragma unroll
+      for (int q = 0; q < NCD; ++q) cc[q] = cd[0][q];
+      const int n_cur = n_nx[0];
+      const long code_cur = code_nx[0];
+      __syncthreads();
+      load_codes(rA);                                 // codes(t + 1)
+      rA = load_raw(chunk_at(k + 2), chunk_at(k + 3));
+      const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
+#pragma unroll
+      for (int it = 0; it < NCD; ++it)
+        if (it < n_cur) pair(acc[0], bufp, cc[it]);
+      for (int it = NCD; it < n_cur; ++it) pair(acc[0], bufp, p_codes[code_cur + (long)it * WAVE]);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    bool owner;
+    double* dst = out_of(0, &owner);
+    if (owner) {
+#pragma unroll
+      for (int r = 0; r < RH; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (r0 + r < NC) dst[r * NC + c] = acc[0][r][c];
+    }
+    return;
+  }
   if constexpr (Cfg::NBUF == 3) {
     // EXPERIMENT (CBA_NBUF6=3): three chunk buffers.  The probes of tools/gpu_exp_pair_phases.sh say a trip is bound by the latency of the gather
     // issued one trip earlier (without the pair arithmetic, without the pairs' LDS reads or without the gather the kernel takes 117 / 121 / 109
@@ -1704,14 +1810,14 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
 }
 
 template <int NC, int SPLIT, int MINW, bool WIDE = false>
-__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::REG_BLOCK), MINW)
+__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::LAUNCH_THREADS), MINW)
 k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   schur_reg3_body<NC, SPLIT, WIDE, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh);
 }
 
 template <int NC, int SPLIT, int MINW, bool WIDE = false>
-__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::REG_BLOCK), MINW)
+__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::LAUNCH_THREADS), MINW)
 k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   schur_reg3_body<NC, SPLIT, WIDE, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk);

@@ -1492,7 +1492,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
         }
       } else if (p->schur_v3) {
         constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
-        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, false>), dim3(p->tile_grid), dim3(BLOCK * SP), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
+        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, false>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
       } else {
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);

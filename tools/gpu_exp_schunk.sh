@@ -1,6 +1,10 @@
 #!/bin/bash
 # experiment: the six-parameter pair kernel with 192-slot chunks (49 KB of LDS) and three workgroups per CU (launch bounds for 170 registers) against the default
-# (320 slots, two per CU).  The variant libraries are built by hand (see the macros in csrc/cba_kernels.h / cba_lib.hip) into tools/exp/.
+# (320 slots, two per CU), three chunk buffers, and the producer-wave build.  Build the variants first (on the machine that has hipcc; tools/exp/ travels):
+#   tools/build_exp_lib.sh exp2     -DCBA_SCHUNK6=192 -DCBA_NCD6=4
+#   tools/build_exp_lib.sh exp3     -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_MINW6=3 -DCBA_PER_CU6=3
+#   tools/build_exp_lib.sh depth3   -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_NBUF6=3
+#   tools/build_exp_lib.sh producer -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_NBUF6=3 -DCBA_NPROD6=1 -DCBA_MINW6=3      (written at the end of round 2, not run yet)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=$GRAFT_REPO_ROOT/gpurun_out/exp; mkdir -p $O
@@ -18,3 +22,4 @@ export CBA_PLAN_REGION=256
 [ -n "$ONLY_DEPTH3" ] || run chunks192_2perCU libcba_exp2.so 2
 [ -n "$ONLY_DEPTH3" ] || run chunks192_3perCU libcba_exp3.so 3
 run chunks192_3buffers libcba_depth3.so 2
+[ -f tools/exp/libcba_producer.so ] && run chunks192_producer_wave libcba_producer.so 2
