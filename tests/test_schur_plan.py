@@ -52,6 +52,9 @@ def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_ch
     # apart in runs of 384 (nc = 9).  `layout` = "reg2": k_schur_reg2's 512 = 4 x 128 slots, unpadded runs.
     if layout == "reg2":
         epw, lst, wp, cap = (128, 7, 896, 512) if nc == 6 else (32, 11, 352, 384)
+    elif layout == "reg3_192":  # the experiment builds of k_schur_reg3<6> (CBA_SCHUNK6=192: three chunk buffers / producer wave): 4 waves x 48 slots, runs of 384 pieces
+        assert nc == 6
+        epw, lst, wp, cap = 48, 7, 384, 192
     elif layout == "wide":  # Reg3Cfg<6, true>: 1024 blocks (16 code waves), 512 slots = 8 loading waves x 64, runs of 448 pieces
         assert nc == 6
         epw, lst, wp, cap = 64, 7, 448, 512
@@ -151,6 +154,15 @@ def test_wide_tiles_of_the_1024_thread_kernel(harness):
     stats = _check(harness, rng, 64, 10000, 10, 10, 6, gmax=32, layout="wide")
     print("wide: lane utilisation", stats[1] / stats[2], "LDS cycles per group", stats[6] / stats[5], "chunks", stats[0], "stream", stats[4])
     assert stats[1] == 10000 * 55 and stats[1] / stats[2] > 0.42   # ~1 pair per block and chunk: the cap of 2 leaves half of the lane-iterations idle
+
+
+def test_192_slot_chunks_of_the_experiment_builds(harness):
+    """CBA_SCHUNK6=192 (csrc/cba_kernels.h): a wave stages 48 slots in a run padded to six load instructions."""
+    rng = np.random.default_rng(12)
+    _check(harness, rng, 64, 900, 2, 10, 6, layout="reg3_192")
+    _check(harness, rng, 20, 400, 1, 6, 6, layout="reg3_192", duplicates=0.1, unobserved=0.05)
+    stats = _check(harness, rng, 64, 6000, 10, 10, 6, layout="reg3_192", region_chunks=256)
+    assert stats[1] == 6000 * 55 and stats[1] / stats[2] > 0.6   # lane utilisation (0.75 with 320-slot chunks)
 
 
 def test_duplicate_rows_and_unobserved_points(harness):
