@@ -2,6 +2,14 @@
 """Headline benchmark: observations/sec per LM iteration (+ final RMS reprojection error, px).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--scaling strong|weak] [--no-cpu] [--also cfg2,cfg3,cfg5]
+                    [--devices 0,1,..] [--xchg auto|rccl|direct]
+
+``--gpus N`` works two ways.  Under a launcher that sets RANK / WORLD_SIZE (``python -m torch.distributed.run --nproc-per-node N ...``)
+this process is one rank of N.  Started plainly, the N ranks run INSIDE this process — one host thread per device, the engines joined
+by an RCCL communicator (threads share the unique id), exactly the route ``CaptureVolume.optimize()`` takes with
+``CALISCOPE_HIP_DEVICES`` (caliscope_amd.distributed.solve_multi_device; the reference's solve is one in-process call,
+core/capture_volume.py:387-411).  ``--xchg direct`` uses the library's peer-to-peer device group instead of RCCL (also the only
+way to place several ranks on ONE device: ``--devices 0,0``).
 
 A *step* is one trust-region (LM) iteration of the hot path over the whole observation set: trial-point
 evaluation plus — for accepted steps — linearisation (residuals, Jacobian blocks, J^T J / J^T r
@@ -19,8 +27,10 @@ words it ("2M obs sharded across 8 x MI355X"): the same 2M observations, their p
 cfg3, and cfg5 = 128 cameras / 1M points / 10M observations with joint intrinsics, on one GPU) are run
 untimed-by-the-driver after the headline and reported under ``also`` (cfg5 with its full roofline block).
 
-``cpu_baseline`` is the reference's scipy call on a bounded sample of the workload, and the SAME sample is then solved
-on the GPU: ``parity`` holds the differences (RMS px, cost, gauge-aligned poses / points) of the two solutions.
+``cpu_baseline`` is the reference's scipy call on the headline's OWN arrays (full cfg4: 4 evaluations, ~25 s on one host core);
+``parity`` compares its solution with the headline's solve on the device (RMS px, cost, gauge-aligned poses / points) and times the
+same arrays through the product seam end to end (``setup_ms``, ``value_end_to_end``).  ``also.cfg5.parity`` does the same on a
+cfg5-recipe sample (128 cameras / 100k points / 1M observations, free intrinsics with the reference's bounds).
 """
 
 from __future__ import annotations
@@ -102,7 +112,8 @@ class _Solo:
         return float(v)
 
 
-def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, control=None, scaling="strong", **overrides):
+def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, control=None, scaling="strong", group=None, prebuilt=None,
+            **overrides):
     """Strong scaling: every rank generates the same scene and keeps the shard of points ``shard_problem`` gives it.
     Weak scaling: rank r draws its own points/observations of the same cameras.  Either way the engine all-reduces the
     camera blocks, the reduced camera system and the scalar sums over RCCL."""
@@ -114,7 +125,8 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     t_gen = time.time()
     n_total, n_params_global = None, None
     if scaling == "strong" and control.world > 1:
-        sc, par, x0, prob, cfg = build_problem(name, seed=seed, shard=0, **overrides)
+        # (in-process ranks share one generated scene: `prebuilt`; launcher ranks each generate the same one)
+        sc, par, x0, prob, cfg = prebuilt if prebuilt is not None else build_problem(name, seed=seed, shard=0, **overrides)
         n_total = prob.n_obs
         shard = shard_problem(prob, control.rank, control.world)
         x0 = shard.local_x(x0)
@@ -126,10 +138,15 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     if par.has_finite_bounds:  # free intrinsics: the bounds of BundleParameterization.bounds(), as CaptureVolume.optimize passes them
         lb, ub = par.bounds()
         solve_kw.update(lb=np.ascontiguousarray(lb[: par.n_camera_params]), ub=np.ascontiguousarray(ub[: par.n_camera_params]))
-    eng = HipEngine(prob, device_id=device_id)
+    t_setup = time.perf_counter()
+    eng = HipEngine(prob, device_id=device_id)  # sort, Schur plan, upload, graph capture: paid once per problem structure, NOT part of `value`
+    t_setup = time.perf_counter() - t_setup
     if control.world > 1:
-        uid = control.broadcast_bytes(eng.comm_unique_id() if control.rank == 0 else None, 128)
-        eng.comm_init(uid, control.rank, control.world)
+        if group is not None:  # the library's peer-to-peer device group (one process, --xchg direct)
+            eng.group_join(group, control.rank)
+        else:                  # RCCL: rank 0's unique id travels over the host-side control plane
+            uid = control.broadcast_bytes(eng.comm_unique_id() if control.rank == 0 else None, 128)
+            eng.comm_init(uid, control.rank, control.world)
     info = eng.info()
     eng.begin(x0)
     run_iterations(eng, max(warmup, 1), solve_kw)
@@ -168,7 +185,7 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         "nct": 9 if any(b.n_params == 9 for b in par.blocks) else 6, "loss": prob.loss, "elapsed": elapsed, "steps": steps,
         "solves": solves, "timers": tm, "final_rms_px": rms, "initial_rms_px": rms0, "full_nfev": full.nfev,
         "full_status": full.status, "full_cost": full.cost, "info": info, "t_generate_s": t_gen,
-        "scene": sc, "par": par, "x0": x0,
+        "scene": sc, "par": par, "x0": x0, "x_full": full.x, "setup_s": t_setup, "rank": control.rank,
     }
 
 
@@ -264,60 +281,160 @@ def solution_parity(par, x_a, x_b):
     return float(pos), float(ang)
 
 
-def cpu_baseline(device_id=0):
-    """The reference's scipy call on the oracle callables, one host core, on a bounded sample of the workload: cfg4's
-    cameras and visibility recipe at half the points (64 cams / 100k points / 1M obs), full solve with the reference's
-    default tolerances.  The same arrays and the same x0 then go through the product's solver on the GPU; `parity` is the
-    difference of the two solutions (north star: RMS within 1e-4 px, poses / points within 1e-6 relative after gauge
-    alignment — at default tolerances both solvers stop at ftol, so the alignment figure shows their stopping distance)."""
-    from caliscope_amd.bundle_parameterization import BundleParameterization
+def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear", f_scale=1.0):
+    """The reference's scipy call (oracle callables, one host core) and the product on the SAME arrays and x0:
+    returns (cpu_baseline block, parity block).  `x_gpu_solve`: a solution the device already produced from these arrays (the
+    headline's full solve), or None — the solution of the seam call below is compared then.  Either way the arrays also go
+    through the product seam (`caliscope_amd.least_squares.least_squares`, what CaptureVolume.optimize calls) once, timed end to
+    end: handle set-up (sort, Schur plan, upload) + solve + download."""
+    from caliscope_amd import engine_cache
     from caliscope_amd.least_squares import least_squares
-    from caliscope_amd.synthetic import make_scene
     from oracle.residuals import joint_residuals
     from oracle.solver import optimize_scipy
 
-    sc = make_scene("cfg4-sample", n_cams=64, n_points=100_000, n_obs=1_000_000)
-    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=100_000, refine_intrinsics=False)
-    x0 = par.pack(sc.cameras_init, sc.points_init)
     t0 = time.perf_counter()
-    res = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0)
+    res = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, loss=loss, f_scale=f_scale)
     dt = time.perf_counter() - t0
     iters = max(res.nfev - 1, 1)
+    engine_cache.clear()  # a cold call: the handle is built inside the timed call
     t1 = time.perf_counter()
-    gpu = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", method="trf",
+    gpu = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", method="trf", loss=loss, f_scale=f_scale,
                         args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), devices=[device_id])
     dt_gpu = time.perf_counter() - t1
+    t2 = time.perf_counter()  # second call on the same observations: the kept handle is found by its fingerprint (engine_cache)
+    warm = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", method="trf", loss=loss, f_scale=f_scale,
+                         args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), devices=[device_id])
+    dt_warm = time.perf_counter() - t2
+    engine_cache.clear()
     fx = np.array([b.fx_initial for b in par.blocks])[sc.camera_indices]
 
     def rms(x):  # the oracle's residuals for both solutions: independent of the device code
         e = joint_residuals(x, par, sc.camera_indices, sc.image_coords, sc.obj_indices).reshape(-1, 2) * fx[:, None]
         return float(np.sqrt(np.mean(np.sum(e * e, axis=1))))
 
-    rms_cpu, rms_gpu = rms(res.x), rms(gpu.x)
-    pos, ang = solution_parity(par, gpu.x, res.x)
+    x_cmp = gpu.x if x_gpu_solve is None else x_gpu_solve
+    rms_cpu, rms_gpu = rms(res.x), rms(x_cmp)
+    pos, ang = solution_parity(par, x_cmp, res.x)
+    cost_gpu = 0.5 * float(np.sum(joint_residuals(x_cmp, par, sc.camera_indices, sc.image_coords, sc.obj_indices) ** 2)) if loss == "linear" else float(gpu.cost)
     base = {
         "value": round(sc.n_obs * iters / dt, 1), "unit": "obs/s", "cores": 1, "kind": "port",
-        "sample": f"64 cams / 100k points / 1M obs (half of cfg4), scipy least_squares trf+lsmr, default tolerances: "
+        "sample": f"{label}, scipy least_squares trf+lsmr, default tolerances: "
                   f"{res.nfev} evaluations in {dt:.1f} s; host has {os.cpu_count()} cores, the scipy path is single-threaded",
         "seconds": round(dt, 2), "nfev": int(res.nfev), "status": int(res.status), "cost": float(res.cost), "final_rms_px": round(rms_cpu, 6),
     }
+    gpu_iters = max(gpu.nfev - 1, 1)
     parity = {
-        "sample": "the cpu_baseline sample: same arrays, same x0, default tolerances on both sides",
-        "gpu": {"nfev": int(gpu.nfev), "status": int(gpu.status), "cost": float(gpu.cost), "final_rms_px": round(rms_gpu, 6),
-                "seconds_end_to_end": round(dt_gpu, 3)},
-        "d_rms_px": rms_gpu - rms_cpu, "rel_cost": (float(gpu.cost) - float(res.cost)) / float(res.cost),
+        "sample": f"{label}: same arrays, same x0, default tolerances on both sides"
+                  + ("; the device solution compared is the headline's own full solve" if x_gpu_solve is not None else ""),
+        "gpu": {"nfev": int(gpu.nfev), "status": int(gpu.status), "cost": cost_gpu, "final_rms_px": round(rms_gpu, 6),
+                "seconds_end_to_end": round(dt_gpu, 4), "seconds_end_to_end_cached_handle": round(dt_warm, 4),
+                "setup_ms": round(float(getattr(gpu, "setup_seconds", float("nan"))) * 1e3, 2),
+                "solve_ms": round(float(getattr(gpu, "solve_seconds", float("nan"))) * 1e3, 2),
+                "value_end_to_end": round(sc.n_obs * gpu_iters / dt_gpu, 1), "host_cores": os.cpu_count()},
+        "d_rms_px": rms_gpu - rms_cpu, "rel_cost": (cost_gpu - float(res.cost)) / float(res.cost),
         "aligned_pos": pos, "aligned_ang_rad": ang,
-        "value_ratio_gpu_end_to_end_over_cpu": round(sc.n_obs * max(gpu.nfev - 1, 1) / dt_gpu / (sc.n_obs * iters / dt), 1),
+        "within_north_star": bool(abs(rms_gpu - rms_cpu) <= 1e-4 and pos <= 1e-6 and ang <= 1e-6),
+        "value_ratio_gpu_end_to_end_over_cpu": round(sc.n_obs * gpu_iters / dt_gpu / (sc.n_obs * iters / dt), 1),
     }
     return base, parity
 
 
-def main():
+def cpu_baseline(m, device_id=0):
+    """scipy on the headline's own arrays (one host core; `m` = the headline's measure() record), compared with the headline's own
+    solve.  north star: RMS within 1e-4 px, poses / points within 1e-6 relative after gauge alignment."""
+    sc = m["scene"]
+    label = f"the headline's arrays: {m['name']}, {m['n_cams']} cams / {m['n_points']} points / {m['n_obs']} obs (full size)"
+    fs = sc.f_scale_1px() if sc.loss != "linear" else 1.0
+    return _scipy_vs_product(sc, m["par"], m["x0"], m["x_full"], device_id, label, loss=sc.loss, f_scale=fs)
+
+
+def cfg5_sample_parity(device_id=0):
+    """cfg5's recipe at a size scipy finishes in about a minute (SURVEY.md 8d allows a 1M-observation sample for cfg5): 128 cameras,
+    100k points, 1M observations, free intrinsics with the perturbed start (f x 1.03, k1 + 0.02, k2 + 0.05) and the bounds of
+    core/bundle_parameterization.py:151-164 — scipy runs trf_bounds, the product its Coleman-Li variant (cba_solve)."""
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+    from caliscope_amd.synthetic import make_scene
+
+    sc = make_scene("cfg5-sample", n_cams=128, n_points=100_000, n_obs=1_000_000, refine=True)
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=100_000, refine_intrinsics=True)
+    x0 = par.pack(sc.cameras_init, sc.points_init)
+    base, parity = _scipy_vs_product(sc, par, x0, None, device_id, "cfg5 recipe sample: 128 cams / 100k points / 1M obs, refine_intrinsics=True, bounds")
+    parity["scipy"] = {k: base[k] for k in ("seconds", "nfev", "status", "cost", "final_rms_px")}
+    return parity
+
+
+def _also_block(a, name):
+    rf = roofline_from(a)
+    return {
+        "value": round(a["n_obs"] * a["steps"] / a["elapsed"], 1), "unit": "obs/s",
+        "ms_per_step": round(a["elapsed"] / a["steps"] * 1e3, 4), "final_rms_px": round(a["final_rms_px"], 6),
+        "workload": f"{a['n_cams']} cams / {a['n_points']} points / {a['n_obs']} obs, {a['loss']} loss",
+        "nfev": a["full_nfev"], "status": a["full_status"], "accepted_steps": a["full_njev"] - 1,
+        "rejected_trials": a["full_nfev"] - a["full_njev"], "initial_rms_px": round(a["initial_rms_px"], 4),
+        "setup_ms": round(a["setup_s"] * 1e3, 1),
+        # cfg5 is the largest single-GPU configuration of BASELINE.json: its full roofline block, not a digest
+        "roofline": rf if (rf is None or name == "cfg5") else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic")},
+    }
+
+
+def run_ranks_in_process(args, devices, xchg):
+    """``--gpus N`` without a launcher: the N ranks as host threads of this process, one engine per entry of `devices`, joined by
+    RCCL (threads share the unique id through the ThreadControlPlane) or by the library's device group (`xchg` = "direct").
+    Returns the per-rank measure() records, rank order."""
+    import threading
+
+    from caliscope_amd.distributed import ThreadControlPlane, _ThreadGroupState
+    from caliscope_amd.hip_engine import DeviceGroup
+
+    world = len(devices)
+    prebuilt = build_problem(args.workload) if args.scaling == "strong" else None  # one scene, shared by the ranks (read-only)
+    group = DeviceGroup(world) if xchg == "direct" else None
+    state = _ThreadGroupState(world)
+    records, errors = [None] * world, [None] * world
+
+    def member(rank):
+        ctl = ThreadControlPlane(state, rank)
+        try:
+            records[rank] = measure(args.workload, args.steps, args.warmup, device_id=devices[rank], control=ctl, scaling=args.scaling,
+                                    group=group, prebuilt=prebuilt)
+        except BaseException as exc:  # noqa: BLE001 - reported by the main thread
+            errors[rank] = exc
+            ctl.abort()
+            if group is not None:
+                group.abort()
+
+    threads = [threading.Thread(target=member, args=(r,), name=f"bench-rank{r}", daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if group is not None:
+        group.close()
+    failed = [(r, e) for r, e in enumerate(errors) if e is not None]
+    if failed:
+        real = [(r, e) for r, e in failed if "BrokenBarrier" not in type(e).__name__] or failed
+        raise RuntimeError(f"rank {real[0][0]} of {world} failed: {real[0][1]!r}") from real[0][1]
+    return records
+
+
+def main(argv=None):
     # The contract is ONE JSON line on stdout.  Libraries underneath (RCCL prints a version banner when a
     # communicator is created, HIP/amdgpu warnings) write to fd 1 directly, so everything except the final
     # line is sent to stderr at the file-descriptor level.
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    try:
+        line = _run(argv)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+    if line is not None:
+        os.write(1, (line + "\n").encode())
+    os.close(real_stdout)
+    return line
+
+
+def _run(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -326,29 +443,62 @@ def main():
     ap.add_argument("--also", default="cfg2,cfg3,cfg5")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
-    args = ap.parse_args()
+    ap.add_argument("--devices", default="", help="in-process ranks: device ordinal of every rank (default 0..N-1)")
+    ap.add_argument("--xchg", choices=("auto", "rccl", "direct"), default="auto",
+                    help="in-process ranks: RCCL communicator (default for distinct devices) or the library's peer-to-peer device group")
+    args = ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch multi-GPU runs with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
-    control = None
-    if world > 1:
-        from caliscope_amd.distributed import SocketControlPlane
-
-        control = SocketControlPlane.from_env()  # host-side control plane only (TCP on the loopback); the data plane is RCCL inside the engine
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else args.gpus
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if launched and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     import __graft_entry__ as entry
 
+    control = None
+    if launched and world > 1:
+        from caliscope_amd.distributed import SocketControlPlane
+
+        control = SocketControlPlane.from_env()  # host-side control plane only (TCP on the loopback); the data plane is RCCL inside the engine
     if rank == 0:
         entry.build()
     if control is not None:
         control.barrier()
-    m = measure(args.workload, args.steps, args.warmup, device_id=local_rank, control=control, scaling=args.scaling)
+
+    per_rank = None
+    route = "single GPU"
+    if not launched and world > 1:
+        # the N ranks inside this process: what `python bench.py --gpus N` means on a node without a launcher
+        from caliscope_amd.hip_engine import device_count
+
+        devices = [int(t) for t in args.devices.split(",") if t.strip() != ""] or list(range(world))
+        if len(devices) != world:
+            raise SystemExit(f"--devices names {len(devices)} devices for --gpus {world}")
+        xchg = args.xchg if args.xchg != "auto" else os.environ.get("CBA_XCHG", "rccl" if len(set(devices)) == world else "direct")
+        n_dev = device_count()
+        if max(devices) >= n_dev or min(devices) < 0:
+            raise SystemExit(f"--gpus {world}: device ordinals {devices} requested but this node shows {n_dev} HIP device(s); "
+                             f"run with --gpus <= {max(n_dev, 1)}, or name ranks per device with --devices (e.g. --devices 0,0 --xchg direct "
+                             f"places two ranks of the protocol on one GPU)")
+        if xchg == "rccl" and len(set(devices)) != world:
+            raise SystemExit("RCCL needs one distinct device per rank; use --xchg direct to place several ranks on one device")
+        per_rank = run_ranks_in_process(args, devices, xchg)
+        m = per_rank[0]
+        route = f"{world} ranks in one process (one host thread per device {devices}), exchange: {'RCCL communicator' if xchg == 'rccl' else 'peer-to-peer device group'}"
+        exchange_backend = xchg
+    else:
+        m = measure(args.workload, args.steps, args.warmup, device_id=local_rank, control=control, scaling=args.scaling)
+        exchange_backend = "rccl" if world > 1 else None
+        if world > 1:
+            route = f"{world} processes (launcher), one per GPU, exchange: RCCL communicator"
     total_obs = m["n_obs_total"]
     value = total_obs * m["steps"] / m["elapsed"]
+    obs_per_rank = [r["n_obs"] for r in per_rank] if per_rank else [m["n_obs"]]
+    comm = m["timers"].get("exchange") if m["timers"] else None
     out = {
         "metric": "observations/sec per LM iteration",
         "value": round(value, 1),
@@ -366,9 +516,14 @@ def main():
             "workload": f"{args.workload}: {m['n_cams']} cams / {total_obs} obs in total ({m['n_points']} points / {m['n_obs']} obs on rank 0), "
                         f"{'extrinsics+intrinsics' if m['nct'] == 9 else 'extrinsics-only'} BA, {m['loss']} loss",
             "n_obs_total": total_obs, "params_per_camera": m["nct"],
-            "parallelism": f"points sharded x{world} ({args.scaling if world > 1 else 'single GPU'}); RCCL all-reduce of camera blocks + reduced camera system per iteration",
+            "parallelism": f"points sharded x{world} ({args.scaling if world > 1 else 'single GPU'}); all-reduce of camera blocks + reduced camera system per iteration; {route}"
+                           + (f"; obs per rank {obs_per_rank}" if world > 1 else ""),
             "tolerances": "ftol=xtol=gtol=1e-8 (reference defaults)", "solves_in_timed_region": m["solves"],
         },
+        "rccl_ranks": world if exchange_backend == "rccl" else 0,
+        # device time of the all-reduces per step (HIP events around every exchange on rank 0's stream, instrumented repeat); None on one GPU
+        "comm_ms_per_step": round(comm[0] / max(m["steps"], 1), 4) if comm and comm[1] else None,
+        "setup_ms": round(m["setup_s"] * 1e3, 1),  # cba_create for this workload (sort, Schur plan, upload): once per problem structure, not in `value`
         "final_rms_px": round(m["final_rms_px"], 6),
         "initial_rms_px": round(m["initial_rms_px"], 4),
         # accepted iterations re-linearise (njev - 1 of them after x0); the other trial points were rejected
@@ -379,36 +534,28 @@ def main():
     }
     if not args.no_cpu and rank == 0 and world == 1:
         try:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(device_id=local_rank)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(m, device_id=local_rank)
         except Exception as exc:  # the baseline must never break the bench line
-            out["cpu_baseline"] = {"value": None, "unit": "obs/s", "cores": 1, "kind": "port", "sample": f"failed: {exc}"}
+            out["cpu_baseline"] = {"value": None, "unit": "obs/s", "cores": 1, "kind": "port", "sample": f"failed: {exc!r}"}
     also = {}
     if rank == 0 and world == 1 and args.also:
         for name in [s for s in args.also.split(",") if s and s != args.workload]:
             try:
-                kw = {}
-                a = measure(name, args.steps, args.warmup, device_id=local_rank, solve_kw=kw)
-                rf = roofline_from(a)
-                also[name] = {
-                    "value": round(a["n_obs"] * a["steps"] / a["elapsed"], 1), "unit": "obs/s",
-                    "ms_per_step": round(a["elapsed"] / a["steps"] * 1e3, 4), "final_rms_px": round(a["final_rms_px"], 6),
-                    "workload": f"{a['n_cams']} cams / {a['n_points']} points / {a['n_obs']} obs, {a['loss']} loss",
-                    "nfev": a["full_nfev"], "status": a["full_status"], "accepted_steps": a["full_njev"] - 1,
-                    "rejected_trials": a["full_nfev"] - a["full_njev"], "initial_rms_px": round(a["initial_rms_px"], 4),
-                    # cfg5 is the largest single-GPU configuration of BASELINE.json: its full roofline block, not a digest
-                    "roofline": rf if (rf is None or name == "cfg5") else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic")},
-                }
+                a = measure(name, args.steps, args.warmup, device_id=local_rank, solve_kw={})
+                also[name] = _also_block(a, name)
+                if name == "cfg5" and not args.no_cpu:
+                    also[name]["parity"] = cfg5_sample_parity(device_id=local_rank)
             except Exception as exc:
-                also[name] = {"error": str(exc)}
+                also.setdefault(name, {})["error"] = repr(exc)
     if also:
         out["also"] = also
+    line = None
     if rank == 0:
         line = json.dumps(out, default=lambda o: int(o) if isinstance(o, np.integer) else float(o))
-        sys.stdout.flush()
-        os.write(real_stdout, (line + "\n").encode())
     if control is not None:
         control.barrier()
         control.close()
+    return line
 
 
 if __name__ == "__main__":

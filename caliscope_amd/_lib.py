@@ -67,7 +67,7 @@ class Info(C.Structure):
         ("n_obs", C.c_int64), ("n_chunks", C.c_int32), ("grid_blocks", C.c_int32), ("schur_in_lds", C.c_int32),
         ("max_obs_per_point", C.c_int32), ("device_bytes", C.c_int64),
         ("schur_groups", C.c_int32), ("schur_tiles", C.c_int32), ("schur_grid", C.c_int32), ("n_heavy_points", C.c_int32),
-        ("schur_stream_len", C.c_int64), ("schur_pairs", C.c_int64), ("schur_wide", C.c_int32), ("reserved", C.c_int32),
+        ("schur_stream_len", C.c_int64), ("schur_pairs", C.c_int64), ("schur_wide", C.c_int32), ("build_camg", C.c_int32),
     ]
 
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "cba_destroy": (None, [C.c_void_p]),
     "cba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cba_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "cba_comm_abort": (C.c_int, [C.c_void_p]),
     "cba_group_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     "cba_group_join": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "cba_group_abort": (None, [C.c_void_p]),

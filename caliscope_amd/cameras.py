@@ -18,6 +18,8 @@ from typing import Dict
 
 import numpy as np
 
+from caliscope_amd.persistence import PersistenceError, safe_write_toml
+
 _TINY = np.finfo(np.float64).eps
 
 
@@ -204,7 +206,6 @@ class CameraArray:
     def to_toml(self, path: Path | str) -> None:
         """Save to ``camera_array.toml`` (reference camera_array.py:443-487): rotations as Rodrigues vectors, ``None``
         fields omitted, atomic write."""
-        from caliscope_amd.persistence import PersistenceError, safe_write_toml
 
         path = Path(path)
         try:
@@ -226,7 +227,6 @@ class CameraArray:
 
     def to_aniposelib_toml(self, path: Path | str) -> None:
         """aniposelib-compatible export of the posed cameras (reference camera_array.py:489-534)."""
-        from caliscope_amd.persistence import PersistenceError, safe_write_toml
 
         path = Path(path)
         try:

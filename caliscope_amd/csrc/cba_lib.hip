@@ -55,11 +55,11 @@ static int fail(int code, const char* fmt, ...) {
 
 enum TimerId {
   T_CAM_PREP = 0, T_COST, T_BUILD, T_BUILD_REDUCE, T_SCALE_SCALARS, T_JV, T_SCHUR, T_SCHUR_REDUCE, T_CHOLESKY,
-  T_BACKSUB, T_VECTOR, T_SCHUR_PAIRS, T_COUNT
+  T_BACKSUB, T_VECTOR, T_SCHUR_PAIRS, T_EXCHANGE, T_COUNT
 };
 static const char* kTimerNames[T_COUNT] = {
     "cam_prep", "cost", "build", "build_reduce", "scale_scalars", "jv", "schur", "schur_reduce_finalize",
-    "cholesky_solve", "backsub", "vector_ops", "schur_pairs"};
+    "cholesky_solve", "backsub", "vector_ops", "schur_pairs", "exchange"};
 
 struct EventPair { hipEvent_t a, b; };
 struct cba_group;
@@ -395,8 +395,9 @@ static int group_allreduce(cba_problem* p, double* buf, size_t count) {
 
 // in-place sum over the ranks of a sharded solve, enqueued on the engine's stream (no-op for world 1)
 static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
+  if (!p->group && !p->comm) return CBA_OK;
+  ScopedTimer t(p, T_EXCHANGE);  // nested inside the family that needs the sum: comm time per step, reported next to the families
   if (p->group) return group_allreduce(p, buf, count);
-  if (!p->comm) return CBA_OK;
   NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, p->comm, p->stream));
   return CBA_OK;
 }
@@ -870,6 +871,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->want_chol_trace = std::getenv("CBA_CHOL_TRACE") != nullptr;
   int rc = CBA_OK;
   auto bail = [&](int code) { cba_destroy(p); return code; };
+  // a HIP failure after the handle owns resources goes through bail(): the handle, its arena chunks and the pooled stream are released
+#define HIPBAIL(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(CBA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__)); } while (0)
 
   // camera tables
   std::vector<int> np(p->C), model(p->C), off(p->C);
@@ -943,12 +946,12 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
           break;
         }
     }
-    if (!p->stream) HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    if (!p->stream) HIPBAIL(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     if (!p->h_scal) {
       p->mail_doubles = std::max<size_t>(n_mail, 64 + 3 * 96 + 10);  // (room for 96 camera parameters: small rigs share mailboxes)
-      HIPCHK(hipHostMalloc((void**)&p->h_scal, p->mail_doubles * sizeof(double), hipHostMallocMapped));
+      HIPBAIL(hipHostMalloc((void**)&p->h_scal, p->mail_doubles * sizeof(double), hipHostMallocMapped));
     }
-    HIPCHK(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
+    HIPBAIL(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
     p->h_cam = p->h_scal + 64; p->d_hcam = p->d_hscal + 64;
     p->h_flags = reinterpret_cast<int*>(p->h_cam + ((size_t)3 * ncp + 8)); p->d_hflags = reinterpret_cast<int*>(p->d_hcam + ((size_t)3 * ncp + 8));
   }
@@ -1019,7 +1022,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     if (hipMemset(*v, 0, (size_t)p->lay.ncp_pad * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
   TRY(dev_alloc(p, &p->V, (size_t)6 * p->lay.Ppad));
-  HIPCHK(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
+  HIPBAIL(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride + 128));  // + room for the scalars that ride with the blocks (exchange_at)
   lap("allocate vectors");
@@ -1071,17 +1074,17 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
   TRY(dev_alloc(p, &p->U2, (size_t)p->C * ustride + 128));
-  HIPCHK(hipMemset(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double))); HIPCHK(hipMemset(p->g2, 0, (size_t)tot * sizeof(double)));
-  HIPCHK(hipMemset(p->scal, 0, 64 * sizeof(double)));
-  HIPCHK(hipMemset(p->flags, 0, 4 * sizeof(int)));
-  HIPCHK(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
+  HIPBAIL(hipMemset(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double))); HIPBAIL(hipMemset(p->g2, 0, (size_t)tot * sizeof(double)));
+  HIPBAIL(hipMemset(p->scal, 0, 64 * sizeof(double)));
+  HIPBAIL(hipMemset(p->flags, 0, 4 * sizeof(int)));
+  HIPBAIL(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
 #undef TRY
   p->h_vec.resize((size_t)tot);
   if (!p->eval_only && !p->want_chol_trace) {
     rc = ensure_cholesky_graph(p);
     if (rc) return bail(rc);
   }
-  HIPCHK(hipDeviceSynchronize());
+  HIPBAIL(hipDeviceSynchronize());
   *out = p;
   return CBA_OK;
 }
@@ -1102,7 +1105,8 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_reg ? 0 : 1;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
-  o->schur_wide = (p->schur_reg && p->schur_wide) ? 1 : 0; o->reserved = 0;
+  o->schur_wide = (p->schur_reg && p->schur_wide) ? 1 : 0;
+  o->build_camg = (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p)) ? 1 : 0;
   return CBA_OK;
 }
 
@@ -2051,6 +2055,17 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
     HIPCHK(hipMemcpyAsync(&total, p->xbuf, sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     p->peer_needs_primitives = total > 0.0;
+  }
+  return CBA_OK;
+}
+
+int cba_comm_abort(cba_problem* p) {
+  // no api guard: this is called from another thread while the owner may be blocked inside a collective
+  if (!p) return fail(CBA_ERR_INVALID, "cba_comm_abort: null problem");
+  ncclComm_t c = p->comm;
+  if (c) {
+    p->comm = nullptr;  // cba_destroy must not destroy an aborted communicator
+    (void)ncclCommAbort(c);
   }
   return CBA_OK;
 }

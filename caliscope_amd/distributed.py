@@ -229,13 +229,15 @@ class ThreadControlPlane:
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def make_sharded_hip_engine(problem: BAProblem, control, device_id: int = -1, group=None):
+def make_sharded_hip_engine(problem: BAProblem, control, device_id: int = -1, group=None, on_engine=None):
     """Shard ``problem`` for this rank, create its HIP engine and join the communicator: the device group ``group``
     (``caliscope_amd.hip_engine.DeviceGroup``, in-process) or RCCL (unique id passed over ``control``)."""
     from caliscope_amd.hip_engine import HipEngine
 
     shard = shard_problem(problem, control.rank, control.world)
     engine = HipEngine(shard.problem, device_id=device_id)
+    if on_engine is not None:
+        on_engine(engine)  # before the communicator is created: a peer that fails during the rendezvous can already abort this rank
     try:
         if control.world > 1:
             if group is not None:
@@ -260,16 +262,19 @@ def gather_solution(shard: Shard, x_local: np.ndarray, control) -> np.ndarray:
 
 
 def solve_sharded(problem: BAProblem, x0: np.ndarray, control, *, device_id: int = -1, engine_factory=None, group=None, cam_bounds=None,
-                  **tol) -> TrfResult:
+                  on_engine=None, **tol) -> TrfResult:
     """Solve ``problem`` with its points sharded over ``control.world`` ranks; every rank returns the full x.
 
     ``engine_factory(shard, control)`` is a test hook (the CPU tests plug the numpy oracle engine in); ``cam_bounds`` =
-    (lb, ub) of the camera block when the caller's bounds are not ``parameterization.bounds()``."""
+    (lb, ub) of the camera block when the caller's bounds are not ``parameterization.bounds()``; ``on_engine(engine)`` is told
+    the rank's engine as soon as it exists (``solve_multi_device`` keeps it to abort this rank's communicator when a peer fails)."""
     if engine_factory is None:
-        engine, shard = make_sharded_hip_engine(problem, control, device_id, group)
+        engine, shard = make_sharded_hip_engine(problem, control, device_id, group, on_engine=on_engine)
     else:
         shard = shard_problem(problem, control.rank, control.world)
         engine = engine_factory(shard, control)
+        if on_engine is not None:
+            on_engine(engine)
     try:
         par = shard.problem.parameterization
         ncp = par.n_camera_params
@@ -331,16 +336,38 @@ def solve_multi_device(problem: BAProblem, x0: np.ndarray, devices, *, backend: 
     state = _ThreadGroupState(world)
     results: list = [None] * world
     errors: list = [None] * world
+    engines: list = [None] * world
+    engines_lock = threading.Lock()
 
     def member(rank):
         ctl = ThreadControlPlane(state, rank)
+
+        def keep(engine):
+            with engines_lock:
+                engines[rank] = engine
+
         try:
-            results[rank] = solve_sharded(problem, x0, ctl, device_id=devices[rank], group=group, **dict(tol))
+            results[rank] = solve_sharded(problem, x0, ctl, device_id=devices[rank], group=group, on_engine=keep, **dict(tol))
         except BaseException as exc:  # noqa: BLE001 - re-raised in the caller's thread
             errors[rank] = (time.monotonic(), exc)
             ctl.abort()  # peers waiting in a host-side exchange fail instead of hanging
             if group is not None:
                 group.abort()  # ... and so do peers spinning in the library's group barrier
+            else:
+                # RCCL: a peer may already sit in an all-reduce (or in the stream wait behind it) that this rank will never join;
+                # ncclCommAbort on its communicator makes that call return an error instead of hanging least_squares for ever
+                with engines_lock:
+                    peers = [e for r, e in enumerate(engines) if r != rank and e is not None]
+                for e in peers:
+                    abort = getattr(e, "comm_abort", None)
+                    if abort is not None:
+                        try:
+                            abort()
+                        except Exception:  # noqa: BLE001 - best effort on the failure path
+                            pass
+        finally:
+            with engines_lock:
+                engines[rank] = None  # closed by solve_sharded: never abort a destroyed handle
 
     threads = [threading.Thread(target=member, args=(r,), name=f"cba-rank{r}", daemon=True) for r in range(world)]
     for t in threads:

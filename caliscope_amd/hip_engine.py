@@ -212,6 +212,12 @@ class HipEngine:
             raise ValueError("unique_id must be the 128 bytes produced by comm_unique_id()")
         self._check(self.lib.cba_comm_init(self._h, unique_id, int(rank), int(world)), "cba_comm_init")
 
+    def comm_abort(self) -> None:
+        """``ncclCommAbort`` on this handle's communicator — from ANOTHER thread, when a peer rank failed: a collective this rank is
+        blocked in returns an error instead of waiting for ever.  The handle is only good for ``close()`` afterwards."""
+        if self._h:
+            self.lib.cba_comm_abort(self._h)
+
     def group_join(self, group: "DeviceGroup", rank: int) -> None:
         """Join an in-process device group (one host thread per member; returns when all have joined)."""
         self._check(self.lib.cba_group_join(self._h, group.handle, int(rank)), "cba_group_join")

@@ -36,6 +36,8 @@ CONFIGS = {
     "cfg3": dict(n_cams=32, n_points=50_000, n_obs=400_000, loss="huber", outliers=0.05, refine=False),
     "cfg4": dict(n_cams=64, n_points=200_000, n_obs=2_000_000, loss="linear", outliers=0.0, refine=False),
     "cfg5": dict(n_cams=128, n_points=1_000_000, n_obs=10_000_000, loss="linear", outliers=0.0, refine=True),
+    # not a BASELINE config: the size the CPU test build of the ABI can solve, so that bench.py's own code paths run in the CPU suite
+    "tiny": dict(n_cams=5, n_points=90, n_obs=450, loss="linear", outliers=0.0, refine=False),
 }
 
 

@@ -87,9 +87,13 @@ void cba_destroy(cba_problem* p);
  * After cba_comm_init the primitives below all-reduce — over RCCL/xGMI, on the engine's stream — exactly
  * the camera blocks U_c, g_c, the reduced camera system (S, b) and the scalar sums; the dense solve is
  * repeated identically on every rank.  Rank 0 calls cba_comm_unique_id and distributes the 128 bytes by any
- * host-side channel (bench.py uses torch.distributed). */
+ * host-side channel (caliscope_amd/distributed.py: a shared variable between the threads of one process, TCP on the
+ * loopback between processes).  cba_comm_abort (ncclCommAbort) is for the failure path: when one rank fails, the others
+ * may already sit in a collective that will never complete; aborting their communicators from another thread makes the
+ * pending call return an error (CBA_ERR_COMM / CBA_ERR_HIP) instead of hanging.  The handle is only good for cba_destroy afterwards. */
 int cba_comm_unique_id(char* out128);
 int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world);
+int cba_comm_abort(cba_problem* p);
 
 /* ---- sharded solves inside ONE process (one host thread per GPU) ----------------------------------
  * `CaptureVolume.optimize()` is a single in-process call in the reference (core/capture_volume.py:322-334), so a
@@ -295,7 +299,8 @@ typedef struct {
   int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
   int64_t schur_pairs;      /* observation pairs (blocks of W V^-1 W^T) formed per Schur pass */
   int32_t schur_wide;       /* 1: 32 x 32 camera tiles, two blocks per thread (opt-in: CBA_SCHUR_WIDE=1) */
-  int32_t reserved;
+  int32_t build_camg;       /* 1: the linearisation kernel reads the camera table through the vector cache instead of LDS (chosen when the
+                               table is what keeps a second workgroup off the CU, ~100+ nine-parameter cameras; CBA_BUILD_CAMG=0/1 forces) */
 } cba_info;
 int cba_get_info(cba_problem* p, cba_info* out);
 

@@ -283,10 +283,10 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
 
 // timers: names of the device build, no time (there is no device)
 static const char* kTimers[] = {"cam_prep", "cost", "build", "build_reduce", "scale_scalars", "jv", "schur", "schur_reduce_finalize",
-                                "cholesky_solve", "backsub", "vector_ops", "schur_pairs"};
-int cba_timer_count(void) { return 12; }
-const char* cba_timer_name(int32_t i) { return (i >= 0 && i < 12) ? kTimers[i] : ""; }
-int cba_get_timers(cba_problem*, double* ms, int64_t* calls) { for (int i = 0; i < 12; ++i) { ms[i] = 0.0; calls[i] = 0; } return CBA_OK; }
+                                "cholesky_solve", "backsub", "vector_ops", "schur_pairs", "exchange"};
+int cba_timer_count(void) { return 13; }
+const char* cba_timer_name(int32_t i) { return (i >= 0 && i < 13) ? kTimers[i] : ""; }
+int cba_get_timers(cba_problem*, double* ms, int64_t* calls) { for (int i = 0; i < 13; ++i) { ms[i] = 0.0; calls[i] = 0; } return CBA_OK; }
 int cba_reset_timers(cba_problem*) { return CBA_OK; }
 int cba_enable_timers(cba_problem*, int32_t) { return CBA_OK; }
 
@@ -295,6 +295,8 @@ int cba_comm_unique_id(char* out128) { std::memset(out128, 0, 128); return CBA_O
 int cba_comm_init(cba_problem*, const char*, int32_t rank, int32_t world) {
   return (world == 1 && rank == 0) ? CBA_OK : failf(CBA_ERR_UNSUPPORTED, "the CPU test build of the C ABI has no RCCL: one rank per communicator (use a cba_group)");
 }
+
+int cba_comm_abort(cba_problem*) { return CBA_OK; }
 
 // ... but the in-process group does: one host thread per member handle, a mutex/condvar barrier and one staging slot per rank.
 // Every rank folds the slots in rank order, so the replicas stay bit-identical.

@@ -48,7 +48,7 @@ def test_cpu_build_exports_the_whole_header(cpu_lib):
                               timers=[lib.cba_timer_name(i).decode() for i in range(lib.cba_timer_count())])))
     """)
     assert out["missing"] == [] and out["version"] == 100 and out["devices"] == 1
-    assert len(out["timers"]) == 12 and out["timers"][2] == "build"
+    assert len(out["timers"]) == 13 and out["timers"][2] == "build" and out["timers"][12] == "exchange"
 
 
 @pytest.mark.parametrize("case", ["locked", "refine", "huber", "fisheye_mixed"])
@@ -340,3 +340,36 @@ def test_unsupported_entries_fail_loudly(cpu_lib):
         print(json.dumps(dict(rc=rc, msg=msg, rc2=rc2, rc3=rc3)))
     """)
     assert out["rc"] == -4 and "one rank" in out["msg"] and out["rc2"] == -1 and out["rc3"] == -4
+
+
+# ---- bench.py --gpus N started plainly: the ranks run inside the process (SURVEY.md 8e; the reference's solve is one in-process call) --------
+def test_bench_starts_its_own_ranks_without_a_launcher(cpu_lib):
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment: bench.main() starts two rank threads, joins their
+    engines (here: the device group of the CPU build, both ranks on "device" 0) and prints one contract line; the sharded run ends at
+    the single-rank run's solution."""
+    out = _run(cpu_lib, """
+        import io, json, os, sys
+        from contextlib import redirect_stdout
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        import bench
+        lines = {}
+        for name, argv in (("two", ["--gpus", "2", "--devices", "0,0", "--xchg", "direct"]), ("one", ["--gpus", "1"])):
+            lines[name] = json.loads(bench.main(argv + ["--workload", "tiny", "--steps", "4", "--warmup", "1", "--no-cpu", "--also", ""]))
+        try:
+            bench.main(["--gpus", "3", "--workload", "tiny", "--no-cpu", "--also", ""])
+            refused = ""
+        except SystemExit as exc:
+            refused = str(exc)
+        print(json.dumps(dict(two=lines["two"], one=lines["one"], refused=refused)))
+    """)
+    two, one = out["two"], out["one"]
+    for d in (two, one):
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "rccl_ranks", "comm_ms_per_step", "setup_ms"):
+            assert key in d, key
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["rccl_ranks"] == 0 and "2 ranks in one process" in two["config"]["parallelism"]
+    assert two["config"]["n_obs_total"] == one["config"]["n_obs_total"] == 450 and "obs per rank" in two["config"]["parallelism"]
+    assert one["n_gpus"] == 1 and abs(two["final_rms_px"] - one["final_rms_px"]) < 1e-6 and two["solve"]["status"] > 0
+    assert abs(two["value"] - 450 / (two["ms_per_step"] * 1e-3)) < 1e-2 * two["value"]
+    assert "1 HIP device" in out["refused"] and "--gpus 3" in out["refused"]  # fewer devices than ranks: a clear message, no hang

@@ -54,7 +54,13 @@ CASES = {
     "arctan_outliers_C6": dict(n_cams=6, n_points=300, k=6, loss="arctan", outliers=0.05),
     "global_atomics_C24": dict(n_cams=24, n_points=600, k=10),
     "refine_global_C20": dict(n_cams=20, n_points=400, k=8, refine=True),
+    # cfg5's shape (BASELINE.json configs[4]: 128 nine-parameter cameras): the camera table no longer fits next to the accumulators, so the
+    # linearisation runs k_build<9, 0, true> (table through the vector cache), k_tprep<9> stages its records in two turns and the pair kernel
+    # k_schur_reg3<9, 3, 3> works on 8 camera groups = 36 tiles
+    "refine_global_C128": dict(n_cams=128, n_points=2000, k=8, refine=True),
 }
+# the kernel variants a handle is expected to pick for a case (cba_info.build_camg, schur_groups)
+EXPECT_CAMG = {"refine_global_C128": 1}
 
 
 def _case(name):
@@ -67,12 +73,28 @@ def _case(name):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_evaluation_parity(name):
+    _check_evaluation(name)
+
+
+# k_build<NC, 0, CAMG>: the camera table in LDS (CAMG = 0) or read through the vector cache (CAMG = 1).  Left alone the library picks CAMG = 1 only
+# beyond ~100 nine-parameter cameras (cfg5); forced here for one six- and one nine-parameter case each way, so that both variants of both
+# instantiations are compared with the oracle (evaluation: U, V, g blocks; step: the fused damped step built on them).
+@pytest.mark.parametrize("camg", ["0", "1"])
+@pytest.mark.parametrize("name", ["global_atomics_C24", "refine_global_C20", "huber_outliers_C8"])
+def test_build_kernel_variants(name, camg, monkeypatch):
+    monkeypatch.setenv("CBA_BUILD_CAMG", camg)
+    _check_evaluation(name, expect_camg=int(camg))
+    _check_step(name, expect_camg=int(camg))
+
+
+def _check_evaluation(name, expect_camg=None):
     from oracle.residuals import joint_jacobian, joint_residuals
     from scipy.optimize._lsq.common import scale_for_robust_loss_function
     from scipy.optimize._lsq.least_squares import construct_loss_function
 
     sc, par, x0, loss, fs = _case(name)
     hip, _ = _engines(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss, fs)
+    assert hip.info()["build_camg"] == (EXPECT_CAMG.get(name, 0) if expect_camg is None else expect_camg)
     r_ref = joint_residuals(x0, par, sc.camera_indices, sc.image_coords, sc.obj_indices)
     r, cost = hip.residuals(x0)
     assert _rel(r, r_ref) < 1e-12
@@ -159,8 +181,13 @@ def test_wide_tiles_match_the_narrow_kernel(shape, monkeypatch):
 # is compared in test_evaluation_parity, their converged solves in tests/test_trf_driver.py
 @pytest.mark.parametrize("name", [n for n in CASES if not n.startswith(("cauchy", "arctan"))])
 def test_step_parity(name):
+    _check_step(name)
+
+
+def _check_step(name, expect_camg=None):
     sc, par, x0, loss, fs = _case(name)
     hip, ora = _engines(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss, fs)
+    assert hip.info()["build_camg"] == (EXPECT_CAMG.get(name, 0) if expect_camg is None else expect_camg)
     c_h, c_o = hip.begin(x0), ora.begin(x0)
     assert abs(c_h - c_o) <= 1e-13 * c_o
     lh, lo = hip.linearize(), ora.linearize()

@@ -111,3 +111,24 @@ def test_camera_helpers_without_opencv():
     for c in arr.cameras.values():
         c.synthesize_default_intrinsics(); c.rotation = np.eye(3); c.translation = np.zeros(3)
     assert arr.all_intrinsics_calibrated() and arr.all_extrinsics_calibrated()
+
+
+def test_from_toml_failures_raise_persistence_error(tmp_path):
+    """The reference's repository layer catches PersistenceError (cameras/camera_array.py:377-470): a missing file, invalid TOML and a
+    malformed camera entry must all surface as that type, never as an unrelated exception."""
+    from caliscope_amd.persistence import PersistenceError
+
+    with pytest.raises(PersistenceError, match="not found"):
+        CameraArray.from_toml(tmp_path / "missing.toml")
+    bad = tmp_path / "bad.toml"
+    bad.write_text("[cameras\nthis is = not toml")
+    with pytest.raises(PersistenceError, match="Failed to load"):
+        CameraArray.from_toml(bad)
+    shape = tmp_path / "shape.toml"
+    shape.write_text('[cameras.0]\nsize = [640, 480]\nrotation = [1.0, 2.0]\n')
+    with pytest.raises(PersistenceError, match="Failed to parse camera 0"):
+        CameraArray.from_toml(shape)
+    nosize = tmp_path / "nosize.toml"
+    nosize.write_text('[cameras.3]\nrotation_count = 0\n')
+    with pytest.raises(PersistenceError, match="Failed to parse camera 3"):
+        CameraArray.from_toml(nosize)
