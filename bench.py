@@ -254,7 +254,7 @@ def _similarity(src, dst):
     return sc, R, mu_d - sc * R @ mu_s
 
 
-def solution_parity(par, x_a, x_b):
+def solution_parity(par, x_a, x_b, detail=False):
     """Gauge-aligned difference of two solutions: (max relative position difference of camera centres and points, max
     rotation angle between corresponding cameras [rad])."""
     from caliscope_amd.cameras import rvec_to_matrix
@@ -272,12 +272,18 @@ def solution_parity(par, x_a, x_b):
     pa, pb = x_a[par.n_camera_params:].reshape(-1, 3), x_b[par.n_camera_params:].reshape(-1, 3)
     sc, R, t = _similarity(np.vstack([ca, pa]), np.vstack([cb, pb]))
     extent = np.abs(np.vstack([cb, pb])).max()
-    pos = max(np.abs(sc * ca @ R.T + t - cb).max(), np.abs(sc * pa @ R.T + t - pb).max()) / extent
+    d_cam = np.abs(sc * ca @ R.T + t - cb).max(axis=1) / extent
+    d_pts = np.abs(sc * pa @ R.T + t - pb).max(axis=1) / extent
+    pos = max(d_cam.max(), d_pts.max())
     ang = 0.0
     for A, B in zip(Ra, Rb):
         rel = (A @ R.T) @ B.T
         w = np.array([rel[2, 1] - rel[1, 2], rel[0, 2] - rel[2, 0], rel[1, 0] - rel[0, 1]])
         ang = max(ang, float(np.arctan2(0.5 * np.linalg.norm(w), 0.5 * (np.trace(rel) - 1.0))))
+    if detail:  # where the maximum sits: camera centres alone, and the distribution over the points
+        return {"aligned_pos": float(pos), "aligned_ang_rad": float(ang), "cameras_pos": float(d_cam.max()),
+                "points_pos_median": float(np.median(d_pts)), "points_pos_p999": float(np.quantile(d_pts, 0.999)), "points_pos_max": float(d_pts.max()),
+                "points_above_1e-6": int(np.sum(d_pts > 1e-6)), "n_points": int(len(d_pts))}
     return float(pos), float(ang)
 
 
@@ -332,7 +338,7 @@ def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear",
                 "solve_ms": round(float(getattr(gpu, "solve_seconds", float("nan"))) * 1e3, 2),
                 "value_end_to_end": round(sc.n_obs * gpu_iters / dt_gpu, 1), "host_cores": os.cpu_count()},
         "d_rms_px": rms_gpu - rms_cpu, "rel_cost": (cost_gpu - float(res.cost)) / float(res.cost),
-        "aligned_pos": pos, "aligned_ang_rad": ang,
+        "aligned_pos": pos, "aligned_ang_rad": ang, "detail": solution_parity(par, x_cmp, res.x, detail=True),
         "within_north_star": bool(abs(rms_gpu - rms_cpu) <= 1e-4 and pos <= 1e-6 and ang <= 1e-6),
         "value_ratio_gpu_end_to_end_over_cpu": round(sc.n_obs * gpu_iters / dt_gpu / (sc.n_obs * iters / dt), 1),
     }

@@ -1153,7 +1153,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     int el, piece;
     slot_piece(k, el, piece);
     const bool useB = EPW > WAVE && k * WAVE >= WAVE * NPH;  // slots >= 64: the second index register
-    const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
+    const const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
     if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC)[piece];  // (piece < NPH here)
   };
   auto pair = [&](unsigned code) {
@@ -1288,21 +1288,6 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 // made for 16 "virtual" waves of 64 blocks, physical wave w runs the pair codes of virtual waves w and w + 8 one after the other
 // into two sets of accumulators.  One workgroup per CU (8 waves, as two narrow workgroups), every wave loads 64 slots of a
 // 512-slot chunk: seven full load instructions.
-// (experiments: -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_MINW6=3 -DCBA_PER_CU6=3 builds the six-parameter kernel for three workgroups per CU;
-// -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_NBUF6=3 for three chunk buffers, the gather issued two trips ahead; with -DCBA_NPROD6=1 -DCBA_MINW6=3 on top a
-// fifth wave of the workgroup issues all gathers and the four others only multiply — NOT RUN YET, written at the end of round 2 for round 3)
-#ifndef CBA_SCHUNK6
-#define CBA_SCHUNK6 320
-#endif
-#ifndef CBA_NCD6
-#define CBA_NCD6 8
-#endif
-#ifndef CBA_NBUF6
-#define CBA_NBUF6 2
-#endif
-#ifndef CBA_NPROD6
-#define CBA_NPROD6 0
-#endif
 template <int NC, bool WIDE = false> struct Reg3Cfg {
   static_assert(!WIDE || NC == 6, "the wide tile is the one-thread-per-block kernel");
   static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
@@ -1314,18 +1299,17 @@ template <int NC, bool WIDE = false> struct Reg3Cfg {
   static constexpr int GROUP = WIDE ? 32 : 16;                                     // cameras per group: GROUP^2 blocks <= CODE_THREADS
   // pair codes per block and chunk that travel in registers (a code beyond them is loaded inside the pair loop: a vmcnt(0) behind the record loads
   // in flight).  The wide kernel's register file is full at two; its plan caps the pairs of a block per chunk there and opens more chunks instead.
-  static constexpr int NCD = WIDE ? 2 : (NC == 6) ? CBA_NCD6 : 4;
+  static constexpr int NCD = WIDE ? 2 : (NC == 6) ? 8 : 4;
   static constexpr int PAIR_CAP = WIDE ? NCD : 0;
-  static constexpr int SCHUNK = WIDE ? 512 : (NC == 9) ? 384 : CBA_SCHUNK6;        // slots per chunk (per LDS buffer)
+  static constexpr int SCHUNK = WIDE ? 512 : (NC == 9) ? 384 : 320;                // slots per chunk (per LDS buffer)
   static constexpr int EPW = SCHUNK / NWAVES;                                      // slots loaded by one wave (80 / 32; wide: 64)
   static constexpr int NLD = (EPW * LST + WAVE - 1) / WAVE;                        // load instructions per wave and chunk (9 / 6; wide: 7)
   static constexpr int WAVE_PIECES = NLD * WAVE;                                   // LDS pieces of one wave's run, padded to whole loads
   static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // all-zero record behind the chunk, in each buffer
   static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                          // (+1: keeps the second buffer 32-byte aligned)
-  static constexpr int NBUF = (!WIDE && NC == 6) ? CBA_NBUF6 : 2;                   // chunk buffers in LDS: a gather is issued NBUF - 1 trips before it is read
+  static constexpr int NBUF = 2;                                                    // chunk buffers in LDS: a gather is issued one trip before it is read
   static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_PIECES * 16;
-  static constexpr int NPROD = (!WIDE && NC == 6) ? CBA_NPROD6 : 0;                  // waves that only issue gathers (experiment)
-  static constexpr int LAUNCH_THREADS = REG_BLOCK + NPROD * WAVE;
+  static constexpr int LAUNCH_THREADS = REG_BLOCK;
   static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
   static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
   static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
@@ -1455,10 +1439,6 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
       g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-#if defined(CBA_EXP_NOGATHER)  // timing experiment (wrong sums): no record travels, the pair loops read whatever the LDS holds
-    (void)wbase;
-    return;
-#endif
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
@@ -1467,19 +1447,8 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     const double2* Ri = bufp + (code & 0xffffu);
     const double2* Rj = bufp + (code >> 16);
     if constexpr (NC == 6) {
-#if defined(CBA_EXP_PAIR_NOREAD)  // timing experiment (wrong sums): the arithmetic of a pair without its twelve LDS reads
-      const double cz = (double)code * 1e-300;
-      const double2 i0 = make_double2(cz, cz), i1 = i0, i2 = i0, i3 = i0, i4 = i0, i5 = i0, j0 = make_double2(cz, 1.0), j1 = j0, j2 = j0, j3 = j0, j4 = j0, j5 = j0;
-      (void)Ri; (void)Rj;
-#else
       const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
       const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
-#endif
-#if defined(CBA_EXP_PAIR_NOMATH)  // timing experiment (wrong sums): the twelve LDS reads of a pair without its arithmetic
-      A[0][0] += ((i0.x + i1.x) + (i2.x + i3.x)) + ((i4.x + i5.x) + (j0.x + j1.x)) + ((j2.x + j3.x) + (j4.x + j5.x));
-      A[0][1] += ((i0.y + i1.y) + (i2.y + i3.y)) + ((i4.y + i5.y) + (j0.y + j1.y)) + ((j2.y + j3.y) + (j4.y + j5.y));
-      return;
-#endif
       const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
       const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
       const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
@@ -1515,206 +1484,6 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     }
   };
 
-  if constexpr (Cfg::NPROD == 1) {
-    // EXPERIMENT (CBA_NPROD6=1, with CBA_NBUF6=3): a fifth wave issues every gather of the workgroup, two trips ahead, and the four block-owning
-    // waves only load their codes and multiply.  profiles/r02_pair_kernel_experiments.txt: the nine gathers of a trip cost a wave 59k of its 76k
-    // issue clocks queueing for the CU's vector-memory path, in order — here only the producer queues.  NOT RUN YET.
-    static_assert(Cfg::NBUF == 3 && VB == 1 && SPLIT == 1 && EPW <= WAVE && NLD == 6, "producer experiment: the narrow kernel with 192-slot chunks (vmcnt below)");
-    auto chunk_at = [&](int k) { return min(first + k * stride, last); };
-    if (tid >= PT) {  // ---- producer wave
-      const int pl = tid - PT;
-      auto issue_for = [&](int buf, int swv, int idxv) {  // the loads wave `swv` of the plain kernel issues for its run of the chunk
-        constexpr int Q = WAVE / LST, RM = WAVE % LST;
-        double2* wbase = sh_p + buf * Cfg::BUF_PIECES + swv * Cfg::WAVE_PIECES;
-        const double2* g[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-          int piece = k * RM + pl % LST;
-          int el = k * Q + pl / LST + piece / LST;
-          piece %= LST;
-          el = min(el, EPW - 1);
-          const int id = __shfl(idxv, el, WAVE);
-          g[k] = reinterpret_cast<const double2*>(Trec + (long)id * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NLD; ++k)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
-      };
-      auto ald = [](const void* ptr) {
-        unsigned v;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-        return v;
-      };
-      int idxv[4];
-      {  // records of the first two chunks, the indices of the third, the stream offset of the fourth
-        const int cs0 = p_chunk_start[chunk_at(0)], cs1 = p_chunk_start[chunk_at(1)], cs2 = p_chunk_start[chunk_at(2)];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) issue_for(0, w, p_obs[cs0 + w * EPW + pl]);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) issue_for(1, w, p_obs[cs1 + w * EPW + pl]);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) idxv[w] = p_obs[cs2 + w * EPW + pl];
-      }
-      int cs_next = p_chunk_start[chunk_at(3)];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(idxv[w]));
-      asm volatile("" : "+v"(cs_next));
-      int buf = 0, k = 0;
-      for (int cur = first; cur < ch_end; cur += stride, ++k) {
-        // state: idxv = indices(t + 2), cs_next = stream offset of chunk t + 3; in flight: records(t + 1), the 4 * NLD = 24 newest loads
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-#pragma unroll
-        for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(idxv[w]));
-        asm volatile("" : "+v"(cs_next));
-        __syncthreads();  // records(t) have landed; nobody reads the buffer of trip t - 1 any more
-        int idn[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) idn[w] = (int)ald(p_obs + cs_next + w * EPW + pl);  // indices(t + 3)
-        const int cs_n = (int)ald(p_chunk_start + chunk_at(k + 4));
-        const int target = buf == 0 ? 2 : buf - 1;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) issue_for(target, w, idxv[w]);                       // records(t + 2)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) idxv[w] = idn[w];
-        cs_next = cs_n;
-        buf = buf == 2 ? 0 : buf + 1;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      return;
-    }
-    // ---- the four waves that own blocks: ordinary loads, nothing of theirs has to stay in flight across a trip
-    load_codes(load_raw(chunk_at(0), chunk_at(1)));   // codes(0)
-    Raw rA = load_raw(chunk_at(1), chunk_at(2));      // counts / code offset of chunk 1
-    int buf = 0, k = 0;
-    for (int cur = first; cur < ch_end; cur += stride, ++k) {
-      unsigned cc[NCD];
-#pragma unroll
-      for (int q = 0; q < NCD; ++q) cc[q] = cd[0][q];
-      const int n_cur = n_nx[0];
-      const long code_cur = code_nx[0];
-      __syncthreads();
-      load_codes(rA);                                 // codes(t + 1)
-      rA = load_raw(chunk_at(k + 2), chunk_at(k + 3));
-      const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
-#pragma unroll
-      for (int it = 0; it < NCD; ++it)
-        if (it < n_cur) pair(acc[0], bufp, cc[it]);
-      for (int it = NCD; it < n_cur; ++it) pair(acc[0], bufp, p_codes[code_cur + (long)it * WAVE]);
-      buf = buf == 2 ? 0 : buf + 1;
-    }
-    bool owner;
-    double* dst = out_of(0, &owner);
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < RH; ++r)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-          if (r0 + r < NC) dst[r * NC + c] = acc[0][r][c];
-    }
-    return;
-  }
-  if constexpr (Cfg::NBUF == 3) {
-    // EXPERIMENT (CBA_NBUF6=3): three chunk buffers.  The probes of tools/gpu_exp_pair_phases.sh say a trip is bound by the latency of the gather
-    // issued one trip earlier (without the pair arithmetic, without the pairs' LDS reads or without the gather the kernel takes 117 / 121 / 109
-    // instead of 136 us): here the records of chunk t + 2 are issued in trip t, and the wait at the top of a trip leaves the newest NLD loads —
-    // the previous trip's gather — in flight.  The small loads keep their distance of one trip and are issued BEFORE the gather of their trip.
-    static_assert(VB == 1 && EPW <= WAVE && NLD == 6, "depth-3 experiment: the narrow kernel with 192-slot chunks (vmcnt below)");
-    const int c1 = min(first + stride, last), c2 = min(c1 + stride, last), c3 = min(c2 + stride, last);
-    int idx0 = 0, idx1 = 0, idx = 0, unused = 0;
-    const Raw raw0 = load_raw(first, c1);
-    load_indices(p_chunk_start[first], &idx0, &unused);
-    issue(0, idx0, 0);                                  // records(0)
-    load_codes(raw0);                                   // codes(0)
-    load_indices(raw0.obs_start, &idx1, &unused);       // indices(1)
-    Raw rA = load_raw(c1, c2);                          // counts / offsets of chunk 1, stream offset of chunk 2
-    issue(1, idx1, 0);                                  // records(1)
-    load_indices(rA.obs_start, &idx, &unused);          // indices(2)
-    Raw rB = load_raw(c2, c3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Inside the loop the small loads are inline asm: the compiler does not track them, so it cannot put its own wait — across the loop's back
-    // edge a vmcnt(0) — in front of the first use of their registers; the wait they need is the explicit one at the top of a trip.
-    auto ald = [](const void* ptr) {
-      unsigned v;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-      return v;
-    };
-    auto codes_asm = [&](const Raw& r) {
-      int pre = 0, mine = 0;
-#pragma unroll
-      for (int q = 0; q < NWORD; ++q)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const int n = (int)((r.nit[q] >> (8 * w)) & 0xffu);
-          pre += (4 * q + w < pw) ? n : 0;
-          mine = (4 * q + w == pw) ? n : mine;
-        }
-      n_nx[0] = __builtin_amdgcn_readfirstlane(mine);
-      code_nx[0] = (long)r.code_start + (long)pre * WAVE + lane;
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) cd[0][k] = ald(p_codes + code_nx[0] + k * WAVE);
-    };
-    auto raw_asm = [&](int chunk, int successor) {
-      Raw r;
-#pragma unroll
-      for (int q = 0; q < NWORD; ++q) r.nit[q] = ald(p_nit + (long)chunk * NWORD + q);
-      r.code_start = (int)ald(p_code_start + chunk);
-      r.obs_start = (int)ald(p_chunk_start + successor);
-      return r;
-    };
-    // (what the prologue loaded with ordinary loads passes through an empty asm here: the compiler's wait for it lands in front of the loop, not in it)
-#pragma unroll
-    for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[0][k]));
-#pragma unroll
-    for (int q = 0; q < NWORD; ++q) { asm volatile("" : "+v"(rA.nit[q])); asm volatile("" : "+v"(rB.nit[q])); }
-    asm volatile("" : "+v"(rA.code_start)); asm volatile("" : "+v"(rA.obs_start));
-    asm volatile("" : "+v"(rB.code_start)); asm volatile("" : "+v"(rB.obs_start));
-    asm volatile("" : "+v"(idx));
-    asm volatile("" : "+v"(code_nx[0]));
-    int buf = 0, ahead3 = c3;
-    for (int cur = first; cur < ch_end; cur += stride) {
-      // state: cd / n_nx / code_nx = codes(t), idx = indices(t + 2), rA = raw(t + 1), rB = raw(t + 2); records(t) in `buf`, records(t + 1) in flight
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[0][k]));
-#pragma unroll
-      for (int q = 0; q < NWORD; ++q) { asm volatile("" : "+v"(rA.nit[q])); asm volatile("" : "+v"(rB.nit[q])); }
-      asm volatile("" : "+v"(rA.code_start)); asm volatile("" : "+v"(rA.obs_start));
-      asm volatile("" : "+v"(rB.code_start)); asm volatile("" : "+v"(rB.obs_start));
-      asm volatile("" : "+v"(idx));
-      __syncthreads();
-      unsigned cc[NCD];
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) cc[k] = cd[0][k];
-      const int n_cur = n_nx[0];
-      const long code_cur = code_nx[0];
-      codes_asm(rA);                                    // codes(t + 1)
-      const int idx_n = (int)ald(p_obs + rB.obs_start + sw * EPW + lane);  // indices(t + 3)
-      const int ahead4 = min(ahead3 + stride, last);
-      const Raw r_n = raw_asm(ahead3, ahead4);          // raw(t + 3)
-      issue(buf == 0 ? 2 : buf - 1, idx, 0);            // records(t + 2) into the buffer read a trip ago
-      __builtin_amdgcn_sched_barrier(0);
-      const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
-#pragma unroll
-      for (int it = 0; it < NCD; ++it)
-        if (it < n_cur) pair(acc[0], bufp, cc[it]);
-      for (int it = NCD; it < n_cur; ++it) pair(acc[0], bufp, p_codes[code_cur + (long)it * WAVE]);
-      rA = rB; rB = r_n; idx = idx_n; ahead3 = ahead4;
-      buf = buf == 2 ? 0 : buf + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bool owner;
-    double* dst = out_of(0, &owner);
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < RH; ++r)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-          if (r0 + r < NC) dst[r * NC + c] = acc[0][r][c];
-    }
-    return;
-  }
   long long clk_sum[6] = {0, 0, 0, 0, 0, 0};
   const long long t_start = CLK ? clock64() : 0;
   int idxA = 0, idxB = 0;

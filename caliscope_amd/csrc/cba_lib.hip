@@ -563,13 +563,7 @@ template <int NC> static size_t lds_schur_tile(int g) {
 // Register-accumulating Schur kernel per camera width: rows of a camera-pair block per thread = NC / SPLIT, minimum waves
 // per SIMD the kernel is compiled for, resident workgroups per CU the plan sizes its grid for (see k_schur_reg).
 template <int NC> struct RegCfg;
-#ifndef CBA_MINW6
-#define CBA_MINW6 2
-#endif
-#ifndef CBA_PER_CU6
-#define CBA_PER_CU6 2
-#endif
-template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = CBA_MINW6, PER_CU = CBA_PER_CU6; };
+template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
   if (p->det_m) return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;

@@ -1,8 +1,7 @@
 #!/bin/bash
 # Build a VARIANT of the library for a timing experiment (never the product: caliscope_amd/build.py builds that):
 #   tools/build_exp_lib.sh NAME -DCBA_SCHUNK6=192 -DCBA_NCD6=4 -DCBA_NBUF6=3      -> tools/exp/libcba_NAME.so
-# and point CALISCOPE_BA_LIB at it (tools/gpu_exp_schunk.sh, tools/gpu_exp_pair_phases.sh).  Macros: csrc/cba_kernels.h (CBA_SCHUNK6, CBA_NCD6,
-# CBA_NBUF6, CBA_EXP_PAIR_NOMATH, CBA_EXP_PAIR_NOREAD, CBA_EXP_NOGATHER) and csrc/cba_lib.hip (CBA_MINW6, CBA_PER_CU6).
+# and point CALISCOPE_BA_LIB at it.  The macros live in tools/pair_kernel_experiments/cba_kernels_experiments.patch (apply it to a scratch copy first).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift

@@ -1,14 +1,18 @@
 #!/usr/bin/env python
 """Parity at BASELINE.json's sizes: the product's solver on the GPU against the reference's scipy call (oracle callables) on
-identical arrays and x0, written to profiles/parity_r02.json.
+identical arrays and x0, written to profiles/parity_r03.json by the last GPU run of the round.
 
-    python tools/parity_at_size.py [out.json]
+    python tools/parity_at_size.py [out.json] [--skip-converged]
 
-cfg2  8 cams / 5k points / 40k obs, linear loss, tight tolerances (both solvers reach the minimum)
-cfg3  32 cams / 50k points / 400k obs, 5 % outliers, Huber at 1 px, ftol 1e-4 and max_nfev 60 — the settings
-      ``calibrate_extrinsics`` passes for its robust stage (reference core/calibrate_extrinsics.py:231-238): neither solver
-      converges in 60 evaluations, the comparison is cost and RMS at the stopping point
-(the half-cfg4 sample is compared in every bench.py run: ``parity`` in its JSON line)
+cfg2            8 cams / 5k points / 40k obs, linear loss, tight tolerances (both solvers reach the minimum)
+cfg3_product    32 cams / 50k points / 400k obs, 5 % outliers, Huber at 1 px, ftol 1e-4 and max_nfev 60 — the settings
+                ``calibrate_extrinsics`` passes for its robust stage (reference core/calibrate_extrinsics.py:231-238): neither solver
+                converges in 60 evaluations, the comparison is cost and RMS at the stopping point
+cfg3_converged  the same arrays run to scipy's OWN convergence at the reference's default tolerances (ftol = xtol = gtol = 1e-8, no
+                evaluation cap: ~530 evaluations, minutes of one host core — BASELINE.md 1b), the product with the same settings
+cfg3_tight      the product alone at 1e-13: how far the default-tolerance stopping points are from the minimum (both solvers stop at
+                ftol while still crawling; their distance to each other is bounded by their distances to this point)
+(full cfg4 and a cfg5-recipe sample are compared in every bench.py run: ``parity`` / ``also.cfg5.parity`` in its JSON line)
 """
 import json
 import os
@@ -24,12 +28,21 @@ from oracle.residuals import joint_residuals
 from oracle.solver import optimize_scipy
 
 
-def run(name, tol):
+_REF_CACHE = {}
+
+
+def run(name, tol, ref_from=None, tight_gpu=False, polish=False):
     sc, par, x0, prob, cfg = bench.build_problem(name)
     fs = prob.f_scale
     t0 = time.perf_counter()
-    ref = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, loss=prob.loss, f_scale=fs, **tol)
-    t_ref = time.perf_counter() - t0
+    if ref_from is not None:  # compare the product with a scipy solution computed earlier in this run (other product settings, same arrays)
+        ref, t_ref = _REF_CACHE[ref_from]
+    else:
+        ref = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, loss=prob.loss, f_scale=fs, **tol)
+        t_ref = time.perf_counter() - t0
+        _REF_CACHE[(name, json.dumps(tol, sort_keys=True))] = (ref, t_ref)
+    if tight_gpu:
+        tol = dict(ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=20000)
     t0 = time.perf_counter()
     got = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", loss=prob.loss, f_scale=fs, method="trf",
                         args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), **tol)
@@ -41,7 +54,22 @@ def run(name, tol):
         return float(np.sqrt(np.mean(np.sum(e * e, axis=1))))
 
     pos, ang = bench.solution_parity(par, got.x, ref.x)
-    return {
+    extra = {}
+    if polish:
+        # Is the distance between the two stopping points the solvers' or the problem's?  The product started again from scipy's stopping
+        # point, tight tolerances: where it ends is the minimum nearest to scipy's answer.  `scipy_to_its_minimum` is how far scipy stopped
+        # from it, `minimum_from_x0_vs_minimum_from_scipy` whether the product's own solve (from x0) found the same minimum.
+        tight = dict(ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=20000)
+        near = least_squares(None, ref.x, jac=None, bounds=par.bounds(), x_scale="jac", loss=prob.loss, f_scale=fs, method="trf",
+                             args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), **tight)
+        extra["polish"] = {
+            "gpu_from_scipy_x": {"nfev": int(near.nfev), "status": int(near.status), "cost": float(near.cost), "rms_px": rms(near.x)},
+            "scipy_to_its_minimum": bench.solution_parity(par, ref.x, near.x, detail=True),
+            "minimum_from_x0_vs_minimum_from_scipy": bench.solution_parity(par, got.x, near.x, detail=True),
+            "rel_cost_scipy_above_minimum": (float(ref.cost) - float(near.cost)) / float(near.cost),
+            "rel_cost_gpu_above_minimum": (float(got.cost) - float(near.cost)) / float(near.cost),
+        }
+    return {**extra, "detail": bench.solution_parity(par, got.x, ref.x, detail=True),
         "workload": f"{name}: {len(par.blocks)} cams / {par.n_points} points / {prob.n_obs} obs, {prob.loss} loss", "settings": tol,
         "scipy": {"nfev": int(ref.nfev), "njev": int(ref.njev), "status": int(ref.status), "cost": float(ref.cost), "rms_px": rms(ref.x), "seconds": round(t_ref, 2)},
         "gpu": {"nfev": int(got.nfev), "njev": int(got.njev), "accepted_steps": int(got.njev) - 1, "rejected_trials": int(got.nfev) - int(got.njev),
@@ -52,12 +80,18 @@ def run(name, tol):
 
 
 if __name__ == "__main__":
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     out = {
         "cfg2": run("cfg2", dict(ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=400)),
-        "cfg3": run("cfg3", dict(ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=60)),
+        "cfg3_product": run("cfg3", dict(ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=60)),
         "host_cores": os.cpu_count(),
     }
-    path = sys.argv[1] if len(sys.argv) > 1 else "profiles/parity_r02.json"
+    if "--skip-converged" not in sys.argv:
+        default = dict(ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None)
+        out["cfg3_converged"] = run("cfg3", default)
+        out["cfg3_tight"] = run("cfg3", default, ref_from=("cfg3", json.dumps(default, sort_keys=True)), tight_gpu=True, polish=True)
+        out["cfg3_tight"]["note"] = "gpu at 1e-13 against scipy at its default-tolerance stopping point"
+    path = argv[0] if argv else "profiles/parity_r03.json"
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
