@@ -89,6 +89,14 @@ __device__ __forceinline__ void stage_camtab(double* sh_tab, const double* tab, 
 __device__ __forceinline__ const CamTab& cam_at(const double* sh_tab, int cam) {
   return *reinterpret_cast<const CamTab*>(sh_tab + cam * CAMTAB_LDS);
 }
+// CAMG variants of the per-observation kernels read the camera table from global memory (through the vector cache) instead of staging it in
+// LDS: chosen by cba_create when the LDS copy (296 B per camera) would not fit next to the kernel's other LDS data, so that the camera count is
+// bounded by the per-camera accumulators of the linearisation alone (reference: no limit, core/reprojection.py:75-119 loops over cameras).
+template <bool CAMG>
+__device__ __forceinline__ const CamTab& cam_of(const double* sh_tab, const double* __restrict__ tab, int cam) {
+  if constexpr (CAMG) return *reinterpret_cast<const CamTab*>(tab + (long)cam * CAMTAB_DOUBLES);
+  else return cam_at(sh_tab, cam);
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-camera constants of an evaluation point
@@ -108,7 +116,7 @@ __global__ void k_cam_prep(const double* __restrict__ xvec, const double* __rest
 
 // ------------------------------------------------------------------------------------------------
 // cost (and optionally the residual vector) at xvec:   0.5 * sum rho  is formed by the caller
-template <bool WRITE_R>
+template <bool WRITE_R, bool CAMG = false>
 __global__ void __launch_bounds__(BLOCK)
 k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
        const int* __restrict__ obs_pt, long n_obs, const double* __restrict__ xvec, VecLayout lay,
@@ -116,8 +124,8 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
        int* __restrict__ flags, double* __restrict__ r_out, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_red = sh + n_cams * CAMTAB_LDS;
-  stage_camtab(sh_tab, tab, n_cams);
+  double* sh_red = sh + (CAMG ? 0 : n_cams * CAMTAB_LDS);
+  if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
   __syncthreads();
   const double* px = xvec + lay.ncp_pad;
   double acc = 0.0;
@@ -125,7 +133,7 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
     const int cam = obs_cam[i], pt = obs_pt[i];
     double e[2];
-    project_residual(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], e);
+    project_residual(cam_of<CAMG>(sh_tab, tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], e);
     if (!(isfinite(e[0]) && isfinite(e[1]))) bad = true;
     acc += robust_cost_one(loss, f_scale, e[0]) + robust_cost_one(loss, f_scale, e[1]);
     if (WRITE_R) {
@@ -547,7 +555,7 @@ __global__ void k_combine(const double* __restrict__ g, const double* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // J.v for one or two vectors: partial[b][0..2] = sum |Jv1|^2, <Jv1,Jv2>, |Jv2|^2
-template <int NC, int NV>
+template <int NC, int NV, bool CAMG = false>
 __global__ void __launch_bounds__(BLOCK)
 k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
      const int* __restrict__ obs_pt, long n_obs, const double* __restrict__ xvec, VecLayout lay,
@@ -555,9 +563,9 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
      const double* __restrict__ v1, const double* __restrict__ v2, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
-  double* sh_v = sh_tab + n_cams * CAMTAB_LDS;  // NV * ncp_pad
+  double* sh_v = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);  // NV * ncp_pad
   double* sh_red = sh_v + NV * lay.ncp_pad;
-  stage_camtab(sh_tab, tab, n_cams);
+  if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) {
     sh_v[i] = v1[i];
     if (NV == 2) sh_v[lay.ncp_pad + i] = v2[i];
@@ -570,9 +578,9 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
     const int cam = obs_cam[i], pt = obs_pt[i];
     double e[2], A[2][MAX_NC], B[2][3];
-    obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e,
-                      A, B);
-    const int np = (int)cam_at(sh_tab, cam).nparams;
+    const CamTab& ctj = cam_of<CAMG>(sh_tab, tab, cam);
+    obs_linearize<NC>(ctj, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e, A, B);
+    const int np = (int)ctj.nparams;
     const double* vc = sh_v + cam_off[cam];
     double a0 = B[0][0] * p1[pt] + B[0][1] * p1[lay.Ppad + pt] + B[0][2] * p1[2 * lay.Ppad + pt];
     double a1 = B[1][0] * p1[pt] + B[1][1] * p1[lay.Ppad + pt] + B[1][2] * p1[2 * lay.Ppad + pt];
@@ -860,7 +868,7 @@ __device__ __forceinline__ void expand_record(const double* __restrict__ rec, co
   }
 }
 
-template <int NC, int DETM = 0>
+template <int NC, int DETM = 0, bool CAMG = false>
 __global__ void __launch_bounds__(BLOCK)
 k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ chunk_start, int n_chunks,
@@ -871,11 +879,12 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   constexpr int REC = SchurRec<NC>::HREC, NP = REC / 2, SP = SchurRec<NC>::STAGE, SW = SchurRec<NC>::STAGE_WAVES;  // the records as they lie in HBM
   static_assert((BLOCK / WAVE) % SW == 0, "stage turns");
   constexpr bool DET = DETM > 0;
+  static_assert(!(DET && CAMG), "the fixed-order sums keep the camera table in LDS");
   if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double2* sh_stage = reinterpret_cast<double2*>(sh);        // [SW][WAVE * SP]  record transpose, per wave (of a turn)
   double* sh_tab = sh + (size_t)SW * WAVE * SP * 2;
-  double* sh_b = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad (DET: the parking area of det_round, then the chunk's camera order)
+  double* sh_b = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);  // ncp_pad (DET: the parking area of det_round, then the chunk's camera order)
   int* sh_perm = reinterpret_cast<int*>(sh_b + DET_ROUND * DET_LD);
   int* sh_cs = sh_perm + CHUNK;
   constexpr int DM = DET ? DETM : 1;
@@ -917,7 +926,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     }
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
-      const CamTab& ct = cam_at(sh_tab, cam);
+      const CamTab& ct = cam_of<CAMG>(sh_tab, tab, cam);
       const double X = px[pt], Yw = px[lay.Ppad + pt], Zw = px[2 * lay.Ppad + pt];
       double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
       obs_linearize<NC>(ct, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);
@@ -1153,7 +1162,7 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     int el, piece;
     slot_piece(k, el, piece);
     const bool useB = EPW > WAVE && k * WAVE >= WAVE * NPH;  // slots >= 64: the second index register
-    const const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
+    const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
     if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC)[piece];  // (piece < NPH here)
   };
   auto pair = [&](unsigned code) {
@@ -2210,7 +2219,7 @@ k_chol_backward(const double* __restrict__ L, int n, int ldw, const double* __re
 
 // ------------------------------------------------------------------------------------------------
 // back-substitution:  dp = -V'^-1 (g_p + sum_i W_i^T dc_{c_i}),  W_i^T dc = B_i^T (A_i dc)
-template <int NC>
+template <int NC, bool CAMG = false>
 __global__ void __launch_bounds__(BLOCK)
 k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
           const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
@@ -2221,9 +2230,9 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
   extern __shared__ __attribute__((aligned(16))) double sh[];
   if (lam_dev) lam = *lam_dev;
   double* sh_tab = sh;
-  double* sh_dc = sh_tab + n_cams * CAMTAB_LDS;  // ncp_pad
+  double* sh_dc = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);  // ncp_pad
   double* sh_pt = sh_dc + lay.ncp_pad;               // [3][CHUNK]
-  stage_camtab(sh_tab, tab, n_cams);
+  if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_dc[i] = svec[i];
   __syncthreads();
   const double* px = xvec + lay.ncp_pad;
@@ -2278,9 +2287,9 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
       double e[2], A[2][MAX_NC], B[2][3];
-      obs_linearize<NC>(cam_at(sh_tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss, f_scale,
-                        e, A, B);
-      const int np = (int)cam_at(sh_tab, cam).nparams;
+      const CamTab& ctb = cam_of<CAMG>(sh_tab, tab, cam);
+      obs_linearize<NC>(ctb, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss, f_scale, e, A, B);
+      const int np = (int)ctb.nparams;
       const double* dc = sh_dc + cam_off[cam];
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll

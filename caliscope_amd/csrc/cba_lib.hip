@@ -100,6 +100,7 @@ struct cba_problem {
   long long* chol_trace = nullptr;  // CBA_CHOL_TRACE=1: phase stamps of k_chol_step (tools/chol_trace.py)
   int ldw = 0;             // row stride of the Cholesky work matrix Lbuf (multiple of 4 doubles)
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
+  bool tab_global = false;  // the per-observation kernels read the camera table from global memory (CAMG variants): its LDS copy would not fit
   int det_m = 0;  // cba_options.deterministic: tasks per thread of the fixed-order camera sums (3, 5 or 8; 0: atomics)
   DetPlan det{nullptr, nullptr};
   double* tri = nullptr;   // packed upper triangle of Sacc + b for the exchange of a sharded solve
@@ -539,13 +540,16 @@ static int allow_lds(K kernel, size_t bytes) {
   return raise_lds_ceiling(reinterpret_cast<const void*>(kernel), bytes);
 }
 
-static size_t lds_cost(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + 8) * 8; }
+static size_t lds_tab(const cba_problem* p) { return p->tab_global ? 0 : (size_t)p->C * CAMTAB_LDS; }  // doubles of the LDS copy of the camera table
+static size_t lds_cost(const cba_problem* p) { return (lds_tab(p) + 8) * 8; }
 // k_build<NC, 0, true> reads the camera table from global memory: chosen when the table is what keeps a second workgroup off the CU
 template <int NC> static size_t lds_build_camg(const cba_problem* p) { return ((size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8; }
 template <int NC> static bool build_camg(const cba_problem* p) {
+  if (p->tab_global) return true;
   const size_t with_tab = ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
   if (const char* e = std::getenv("CBA_BUILD_CAMG")) return std::atoi(e) != 0 && !p->det_m;
-  return !p->det_m && with_tab > 80 * 1024 && lds_build_camg<NC>(p) <= 80 * 1024;
+  // (a second workgroup per CU when the table is what keeps it off; no choice at all when table + accumulators exceed the LDS)
+  return !p->det_m && ((with_tab > 80 * 1024 && lds_build_camg<NC>(p) <= 80 * 1024) || with_tab > 160 * 1024);
 }
 template <int NC> static size_t lds_build(const cba_problem* p) {
   if (build_camg<NC>(p)) return lds_build_camg<NC>(p);
@@ -553,7 +557,7 @@ template <int NC> static size_t lds_build(const cba_problem* p) {
     return ((size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD + 9 * CHUNK + 8) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
   return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
 }
-static size_t lds_jv(const cba_problem* p, int nv) { return ((size_t)p->C * CAMTAB_LDS + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
+static size_t lds_jv(const cba_problem* p, int nv) { return (lds_tab(p) + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
 static inline int tile_cs(int nc) { return nc | 1; }
 static inline int tile_ld(int g, int nc) { const int w = g * tile_cs(nc); return (w & 1) ? w : w + 1; }
 template <int NC> static size_t lds_schur_tile(int g) {
@@ -567,11 +571,11 @@ template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU 
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
 template <int NC> static size_t lds_tprep(const cba_problem* p) {
   if (p->det_m) return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
-  return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad) * 8;
+  return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + lds_tab(p) + p->lay.ncp_pad) * 8;
 }
 constexpr size_t kSchurLdsBudget = 144 * 1024;
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads (the wide kernel: Reg3Cfg<6, true>::GROUP)
-static size_t lds_backsub(const cba_problem* p) { return ((size_t)p->C * CAMTAB_LDS + p->lay.ncp_pad + 3 * CHUNK) * 8; }
+static size_t lds_backsub(const cba_problem* p) { return (lds_tab(p) + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
 // Workgroup -> tile binding shared by the tile plans (csrc/wg_binding.h): sets the grid of the tiled Schur kernel
@@ -782,8 +786,19 @@ static int regroup_for_lds_tile(cba_problem* p) {
 template <int NC>
 static int configure_kernels(cba_problem* p) {
   int rc;
+  // The camera table in LDS (296 B per camera) next to the largest other LDS user: beyond the budget every per-observation kernel switches to
+  // its CAMG variant (table through the vector cache).  What then bounds the camera count is the per-camera accumulators of the linearisation
+  // (nc (nc + 3) / 2 doubles per camera in LDS: ~650 six-parameter or ~320 nine-parameter cameras).  CBA_CAMTAB_GLOBAL=0/1 forces the choice (tests).
+  {
+    p->tab_global = false;
+    const size_t worst = std::max(std::max(lds_jv(p, 2), lds_backsub(p)), lds_tprep<NC>(p));  // (the linearisation has its own switch: build_camg)
+    p->tab_global = !p->det_m && worst > 150 * 1024;
+    if (const char* e = std::getenv("CBA_CAMTAB_GLOBAL")) p->tab_global = std::atoi(e) != 0 && !p->det_m;
+  }
   if ((rc = allow_lds(k_cost<false>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<true>, lds_cost(p)))) return rc;
+  if ((rc = allow_lds(k_cost<false, true>, lds_cost(p)))) return rc;
+  if ((rc = allow_lds(k_cost<true, true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
   if ((rc = allow_lds(k_build<NC, 0, true>, lds_build<NC>(p)))) return rc;
   if (p->det_m) {
@@ -796,6 +811,8 @@ static int configure_kernels(cba_problem* p) {
   }
   if ((rc = allow_lds(k_jv<NC, 1>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
+  if ((rc = allow_lds(k_jv<NC, 1, true>, lds_jv(p, 1)))) return rc;
+  if ((rc = allow_lds(k_jv<NC, 2, true>, lds_jv(p, 2)))) return rc;
   int gmax = 1;
   const char* force_tile = std::getenv("CBA_SCHUR");
   p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
@@ -828,8 +845,10 @@ static int configure_kernels(cba_problem* p) {
         if ((rc = raise_lds_ceiling(fn, Reg2Cfg<NC>::LDS_BYTES))) return rc;
     }
     if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
   }
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
+  if ((rc = allow_lds(k_backsub<NC, true>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_backward, (size_t)(p->ncp + NB) * 8))) return rc;
   return CBA_OK;
@@ -1100,7 +1119,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
   o->schur_wide = (p->schur_reg && p->schur_wide) ? 1 : 0;
-  o->build_camg = (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p)) ? 1 : 0;
+  o->build_camg = ((p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p)) ? 1 : 0) | (p->tab_global ? 2 : 0);
   return CBA_OK;
 }
 
@@ -1158,13 +1177,12 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
   const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
   {
     ScopedTimer t(p, T_COST);
-    if (r_out)
-      hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(BLOCK), lds_cost(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                         p->obs_pt, p->N, xvec, p->lay, tab, p->C, p->loss, p->f_scale, p->partial1, p->flags, r_out, p->order);
-    else
-      hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(BLOCK), lds_cost(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                         p->obs_pt, p->N, xvec, p->lay, tab, p->C, p->loss, p->f_scale, p->partial1, p->flags,
-                         (double*)nullptr, (const int*)nullptr);
+    auto launch = [&](auto kernel, double* r, const int* ord) {
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_cost(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                         p->obs_pt, p->N, xvec, p->lay, tab, p->C, p->loss, p->f_scale, p->partial1, p->flags, r, ord);
+    };
+    if (r_out) { if (p->tab_global) launch(k_cost<true, true>, r_out, (const int*)p->order); else launch(k_cost<true>, r_out, (const int*)p->order); }
+    else { if (p->tab_global) launch(k_cost<false, true>, (double*)nullptr, (const int*)nullptr); else launch(k_cost<false>, (double*)nullptr, (const int*)nullptr); }
   }
   ScopedTimer t(p, T_VECTOR);
   int rows = grid;
@@ -1237,12 +1255,12 @@ template <int NC>
 static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr) {
   ScopedTimer t(p, T_JV);
   const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
-  if (nv == 1)
-    hipLaunchKernelGGL((k_jv<NC, 1>), dim3(grid), dim3(BLOCK), lds_jv(p, 1), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
+  auto launch_jv = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_jv(p, nv), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                        p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
-  else
-    hipLaunchKernelGGL((k_jv<NC, 2>), dim3(grid), dim3(BLOCK), lds_jv(p, 2), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
-                       p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
+  };
+  if (nv == 1) { if (p->tab_global) launch_jv(k_jv<NC, 1, true>); else launch_jv(k_jv<NC, 1>); }
+  else { if (p->tab_global) launch_jv(k_jv<NC, 2, true>); else launch_jv(k_jv<NC, 2>); }
   int rows = grid;
   if (p->con.n_con) {
     if (nv == 1) hipLaunchKernelGGL(k_con_jv<1>, dim3(p->con_grid), dim3(BLOCK), 0, p->stream, p->con, p->lay, p->v1, p->v2, p->partial4 + 4 * grid);
@@ -1426,7 +1444,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
         case 3: launch_tprep(k_tprep<NC, 3>); break;
         case 5: launch_tprep(k_tprep<NC, 5>); break;
         case 8: launch_tprep(k_tprep<NC, 8>); break;
-        default: launch_tprep(k_tprep<NC, 0>); break;
+        default: if (p->tab_global) launch_tprep(k_tprep<NC, 0, true>); else launch_tprep(k_tprep<NC, 0>); break;
       }
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
@@ -1575,9 +1593,12 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     if (p->n_heavy)  // fragments add sum_i W_i^T dc of a heavy point into s by atomics; k_heavy_finish solves for dp
       hipLaunchKernelGGL(k_zero_heavy, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->n_heavy, p->lay,
                          p->s + p->lay.ncp_pad, 3, p->s + p->lay.ncp_pad, 0);
-    hipLaunchKernelGGL((k_backsub<NC>), dim3(p->grid_backsub), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
-                       p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
-                       p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s);
+    auto launch_backsub = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(p->grid_backsub), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
+                         p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
+                         p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s);
+    };
+    if (p->tab_global) launch_backsub(k_backsub<NC, true>); else launch_backsub(k_backsub<NC>);
     if (p->n_heavy)
       hipLaunchKernelGGL(k_heavy_finish, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->heavy_frag, p->n_heavy, p->lay, lam,
                          p->V, p->g, p->sinv, p->s);

@@ -299,8 +299,11 @@ typedef struct {
   int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
   int64_t schur_pairs;      /* observation pairs (blocks of W V^-1 W^T) formed per Schur pass */
   int32_t schur_wide;       /* 1: 32 x 32 camera tiles, two blocks per thread (opt-in: CBA_SCHUR_WIDE=1) */
-  int32_t build_camg;       /* 1: the linearisation kernel reads the camera table through the vector cache instead of LDS (chosen when the
-                               table is what keeps a second workgroup off the CU, ~100+ nine-parameter cameras; CBA_BUILD_CAMG=0/1 forces) */
+  int32_t build_camg;       /* bit 0: the linearisation kernel reads the camera table through the vector cache instead of LDS (chosen when the
+                               table is what keeps a second workgroup off the CU, ~100+ nine-parameter cameras; CBA_BUILD_CAMG=0/1 forces);
+                               bit 1: EVERY per-observation kernel does (the LDS copy of the table would not fit: beyond ~230 six- / ~170
+                               nine-parameter cameras; CBA_CAMTAB_GLOBAL=0/1 forces).  The camera count is then bounded by the per-camera
+                               accumulators of the linearisation: ~650 six- / ~320 nine-parameter cameras. */
 } cba_info;
 int cba_get_info(cba_problem* p, cba_info* out);
 
