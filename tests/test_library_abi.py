@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.cba_version() == 100
-    assert lib.cba_timer_count() == 12 and lib.cba_timer_name(2) == b"build"
+    assert lib.cba_timer_count() == 13 and lib.cba_timer_name(2) == b"build" and lib.cba_timer_name(12) == b"exchange"
 
 
 def test_create_fails_loudly_without_device(lib):
