@@ -2439,13 +2439,15 @@ __global__ void __launch_bounds__(BLOCK)
 k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk, const int* __restrict__ param_cam,
             const int* __restrict__ param_loc, VecLayout lay, int first, double* __restrict__ sinv, const double* __restrict__ cdiag,
             const double* __restrict__ x, const double* __restrict__ g, double* __restrict__ v1, double* __restrict__ partial,
-            double* __restrict__ partial_max) {
+            double* __restrict__ partial_max, const double* __restrict__ sinv_in = nullptr) {
+  // sinv_in != nullptr: the scale is read there and written to `sinv` (the speculative linearisation of a trial point leaves the current one alone)
   using UP = UPack<NC>;
   __shared__ double sh_red[BLOCK / WAVE];
   const long total = lay.total();
+  const double* sin = sinv_in ? sinv_in : sinv;
   double s0 = 0, s1 = 0, s2 = 0, m = 0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
-    double si = sinv[i];
+    double si = sin[i];
     bool live = true;
     double v = 0.0;
     if (i < lay.ncp_pad) {
@@ -2465,6 +2467,8 @@ k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
       if (first) { if (v == 0.0) v = 1.0; } else v = fmax(v, si);
       si = v;
       sinv[i] = si;
+    } else if (sinv_in) {
+      sinv[i] = si;  // padding entries: carried over
     }
     const double gi = g[i], xi = x[i];
     const double gh = gi / si;

@@ -132,6 +132,13 @@ struct cba_problem {
   bool spin_wait = true;  // CBA_SPIN=0: sleep in hipStreamSynchronize instead
   int* d_hflags = nullptr;
   bool first_scale = true;
+  // Speculative linearisation (single-rank fused iterations): right behind the k_publish of a cba_step — while the host reads the packet, decides
+  // and enqueues the next iteration — the Jacobi scale, the vector sums and ||J_h g_h||^2 of the TRIAL point are formed as if it were accepted (it
+  // usually is), into shadow outputs: sinv2 instead of sinv, the reduction partials.  cba_accept makes them current; the next cba_step then starts
+  // with k_lin_finish.  A rejected trial just leaves ~50 us of device work unused.
+  double* sinv2 = nullptr;
+  bool spec_enqueued = false, spec_valid = false;
+  int spec_rows_jv = 0;
   bool have_x0 = false;
   std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
   bool schur_clock = false;  // profiling only (CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
@@ -279,13 +286,17 @@ static void drain_timers(cba_problem* p) {
 }
 
 // part_a / part_b: per-workgroup partial columns whose sums belong to scal[slot_a] / scal[slot_b] (compact fused step)
-static int sync_scalars(cba_problem* p, int n_scal, const double* part_a = nullptr, int rows_a = 0, int slot_a = 0,
-                        const double* part_b = nullptr, int rows_b = 0, int slot_b = 0) {
-  // every primitive ends here: scalars and flags to the host, flags cleared for the next primitive
+static unsigned long long publish_enqueue(cba_problem* p, int n_scal, const double* part_a = nullptr, int rows_a = 0, int slot_a = 0,
+                                          const double* part_b = nullptr, int rows_b = 0, int slot_b = 0) {
   const unsigned long long seq = ++p->publish_seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, seq, part_a, rows_a,
                      slot_a, part_b, rows_b, slot_b);
-  if (p->spin_wait) {
+  return seq;
+}
+// wait until the k_publish with sequence number `seq` has written its packet.  `drain`: nothing was enqueued behind it, a stream synchronize
+// is equivalent (the CBA_SPIN=0 route); with speculative work behind the publish only the sequence word says when the packet is there.
+static int publish_wait(cba_problem* p, unsigned long long seq, bool drain = true) {
+  if (p->spin_wait || !drain) {
     // the solver owns this host thread anyway: poll the sequence number k_publish writes last (a few hundred ns per poll of
     // pinned memory) rather than sleep in hipStreamSynchronize and pay its wake-up latency once per iteration
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->h_scal) + 63;
@@ -302,6 +313,11 @@ static int sync_scalars(cba_problem* p, int n_scal, const double* part_a = nullp
   }
   HIPCHK(hipStreamSynchronize(p->stream));
   return CBA_OK;
+}
+static int sync_scalars(cba_problem* p, int n_scal, const double* part_a = nullptr, int rows_a = 0, int slot_a = 0,
+                        const double* part_b = nullptr, int rows_b = 0, int slot_b = 0) {
+  // every primitive ends here: scalars and flags to the host, flags cleared for the next primitive
+  return publish_wait(p, publish_enqueue(p, n_scal, part_a, rows_a, slot_a, part_b, rows_b, slot_b));
 }
 
 #define NCCLCHK(expr)                                                                                  \
@@ -1026,7 +1042,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("upload observations");
   TRY(dev_alloc(p, &p->tab, (size_t)p->C * CAMTAB_DOUBLES)); TRY(dev_alloc(p, &p->tab_new, (size_t)p->C * CAMTAB_DOUBLES));
   const long tot = p->lay.total();
-  for (double** v : {&p->x0, &p->x, &p->x_new, &p->g, &p->s, &p->sinv, &p->v1, &p->v2}) {
+  for (double** v : {&p->x0, &p->x, &p->x_new, &p->g, &p->s, &p->sinv, &p->v1, &p->v2, &p->sinv2}) {
     TRY(dev_alloc(p, v, (size_t)tot));
     if (hipMemset(*v, 0, tot * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
@@ -1252,12 +1268,13 @@ template <int NC>
 static int run_build(cba_problem* p) { return run_build_into<NC>(p, p->x, p->tab, p->V, p->g, p->Upacked, 8, nullptr, false, false, 3); }
 
 template <int NC>
-static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr) {
+static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr, const double* xvec = nullptr, const double* tab = nullptr) {
   ScopedTimer t(p, T_JV);
+  if (!xvec) { xvec = p->x; tab = p->tab; }  // (the speculative linearisation evaluates the trial point: x_new, tab_new)
   const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
   auto launch_jv = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_jv(p, nv), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
-                       p->N, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
+                       p->N, xvec, p->lay, tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
   };
   if (nv == 1) { if (p->tab_global) launch_jv(k_jv<NC, 1, true>); else launch_jv(k_jv<NC, 1>); }
   else { if (p->tab_global) launch_jv(k_jv<NC, 2, true>); else launch_jv(k_jv<NC, 2>); }
@@ -1282,7 +1299,18 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
     if (rcb) return rcb;
     p->cost_pending = true;
     p->have_build = true;  // V, g, Upacked belong to the current x until it changes
+    p->spec_valid = false;
   }
+  if (compact && p->spec_valid) {
+    // the accepted trial was linearised speculatively behind the previous iteration's k_publish (run_step): scale, vector sums and
+    // ||J_h g_h||^2 are there, only the damping depends on the radius the host has just decided
+    p->spec_valid = false;
+    ScopedTimer t(p, T_SCALE_SCALARS);
+    hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vec_grid(p->lay.total()), p->partial4, p->spec_rows_jv, radius,
+                       p->scal, p->fz);
+    return CBA_OK;
+  }
+  p->spec_valid = false;
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   if (p->cam_scaled)  // the monotone-max rule of the Jacobi scale runs on the unmodified state of the camera block
@@ -1654,7 +1682,24 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
   rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact);  // skipped when need_host
   if (rc) return rc;
   if (compact) {
-    rc = sync_scalars(p, 48, p->partial1, p->grid, 24, p->partial4, vg, 28);
+    const unsigned long long seq = publish_enqueue(p, 48, p->partial1, p->grid, 24, p->partial4, vg, 28);
+    // speculative linearisation of the trial point, enqueued BEHIND the publish: the device works on it while the host reads the packet,
+    // decides and enqueues the next iteration (k_publish -> host -> first kernel of the next cba_step used to be an idle gap per iteration)
+    p->spec_enqueued = false;
+    static const bool spec_on = [] { const char* e = std::getenv("CBA_SPECULATE"); return !(e && e[0] == '0'); }();
+    if (spec_on) {
+      {
+        ScopedTimer t(p, T_SCALE_SCALARS);
+        hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
+                           (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv);
+        int rows_jv = 0;
+        rc = run_jv<NC>(p, 1, &rows_jv, p->x_new, p->tab_new);
+        p->spec_rows_jv = rows_jv;
+      }
+      if (rc) return rc;
+      p->spec_enqueued = true;
+    }
+    rc = publish_wait(p, seq, !p->spec_enqueued);
   } else {
     // one collective for the trial's camera blocks, its cost, the step norm and the flags
     rc = exchange_at(p, SLOT(24) | SLOT(28), false, p->U2, (size_t)p->C * UPack<NC>::STRIDE);
@@ -2024,10 +2069,13 @@ int cba_accept(cba_problem* p) {
   if (!p->have_trial) return fail(CBA_ERR_INVALID, "cba_accept: no trial point");
   std::swap(p->x, p->x_new);
   std::swap(p->tab, p->tab_new);
+  p->spec_valid = false;
   if (p->trial_built) {  // the trial point came with its own build (cba_step): it becomes the linearisation point as it is
     std::swap(p->V, p->V2); std::swap(p->g, p->g2); std::swap(p->Upacked, p->U2);
     p->cost_x = p->trial_cost;
+    if (p->spec_enqueued) { std::swap(p->sinv, p->sinv2); p->spec_valid = true; }  // ... and so does its speculative linearisation
   }
+  p->spec_enqueued = false;
   p->have_build = p->trial_built;
   p->trial_built = false;
   p->have_trial = false; p->linearized = false; p->stepped = false;

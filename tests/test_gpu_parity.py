@@ -623,7 +623,8 @@ def test_non_finite_start_raises_like_scipy(refine):
 
 
 def test_limits_are_reported_not_crashed():
-    """Empty input, more cameras than the LDS camera table holds, calls out of order: clean errors with a message."""
+    """Empty input, more cameras than the per-camera accumulators of the linearisation fit in LDS (800 six-parameter cameras; 320 — beyond
+    round 2's camera-table limit — now solve), calls out of order: clean errors with a message."""
     from caliscope_amd.exceptions import BackendError
     from caliscope_amd.hip_engine import HipEngine
 
@@ -631,10 +632,14 @@ def test_limits_are_reported_not_crashed():
     empty = BAProblem(par, sc.camera_indices[:0], sc.image_coords[:0], sc.obj_indices[:0])
     with pytest.raises(BackendError, match="empty problem"):
         HipEngine(empty)
-    big = make_scene(n_cams=320, n_points=400, n_obs=1600)
+    big = make_scene(n_cams=800, n_points=400, n_obs=1600)
     par_big = BundleParameterization.from_camera_array(big.cameras_init, n_points=400, refine_intrinsics=False)
     with pytest.raises(BackendError, match="LDS|cameras|160 KiB"):
         HipEngine(BAProblem(par_big, big.camera_indices, big.image_coords, big.obj_indices))
+    mid = make_scene(n_cams=320, n_points=400, n_obs=1600)
+    par_mid = BundleParameterization.from_camera_array(mid.cameras_init, n_points=400, refine_intrinsics=False)
+    with HipEngine(BAProblem(par_mid, mid.camera_indices, mid.image_coords, mid.obj_indices)) as eng_mid:
+        assert eng_mid.info()["build_camg"] & 1
     with HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)) as eng:
         with pytest.raises(BackendError, match="cba_begin first"):
             eng.linearize()
