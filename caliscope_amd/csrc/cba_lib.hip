@@ -737,6 +737,8 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   prm.zero_piece = KCfg::ZERO_PIECE;
   if (KCfg::CODE_WAVES > 4) prm.region_chunks = 128;  // wide tiles: ~1 pair per block and chunk, the dealing needs room (lane utilisation 0.44 at 32, 0.50 at 128); only two tiles gather a record
   if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("CBA_PLAN_SWEEPS")) prm.colour_sweeps = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("CBA_PLAN_THREADS")) prm.threads = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
   Reg2Plan plan;
   if (build_reg2_plan(prm, hcam, hps, plan)) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
@@ -937,10 +939,19 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("sort by point, chunk table");
   std::vector<double> hu(p->N), hv(p->N);
   std::vector<int> hcam(p->N), hpt(p->N), hord(p->N), hps((size_t)p->P + 1), hcs((size_t)nch + 1);
-  for (int64_t i = 0; i < p->N; ++i) {
-    const int64_t o = order[i];
-    hu[i] = d->obs_uv[2 * o]; hv[i] = d->obs_uv[2 * o + 1];
-    hcam[i] = d->obs_cam[o]; hpt[i] = d->obs_pt[o]; hord[i] = (int)o;
+  {  // gather into the sorted order, by a few host threads (1M observations: 6 ms on one)
+    auto gather = [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; ++i) {
+        const int64_t o = order[i];
+        hu[i] = d->obs_uv[2 * o]; hv[i] = d->obs_uv[2 * o + 1];
+        hcam[i] = d->obs_cam[o]; hpt[i] = d->obs_pt[o]; hord[i] = (int)o;
+      }
+    };
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), p->N / 65536));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(gather, p->N * t / nth, p->N * (t + 1) / nth);
+    gather(0, p->N / nth);
+    for (auto& th : pool) th.join();
   }
   int maxk = 0;
   for (int q = 0; q <= p->P; ++q) { hps[q] = (int)pstart[q]; if (q) maxk = std::max<int>(maxk, (int)(pstart[q] - pstart[q - 1])); }

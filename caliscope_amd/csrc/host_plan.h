@@ -9,9 +9,18 @@ template <typename Fail>
 static int64_t host_plan_impl(Fail fail, int32_t n_points, int64_t n_obs, const int32_t* obs_pt, const int32_t* obs_cam, int32_t n_cams,
                       int32_t chunk_cap, int64_t* order_out, int64_t* pt_start_out, int64_t* chunk_start_out) {
   if (n_points < 0 || n_obs < 0 || chunk_cap <= 0 || (n_obs > 0 && !obs_pt)) return fail(CBA_ERR_INVALID, "cba_host_plan: bad arguments");
+  // Already in (point, camera) order?  One sequential pass decides (the arrays CaptureVolume hands over after a first optimize() are, and so is
+  // anything produced point by point); the two scattering passes below cost ~9 ns per observation.
+  bool sorted = true;
+  for (int64_t i = 0; i < n_obs; ++i) {
+    const int32_t p = obs_pt[i];
+    if (p < 0 || p >= n_points) return fail(CBA_ERR_INVALID, "observation %lld: world-point index %d out of range", (long long)i, p);
+    if (obs_cam && n_cams > 0 && (obs_cam[i] < 0 || obs_cam[i] >= n_cams)) return fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, obs_cam[i]);
+    if (i > 0 && (p < obs_pt[i - 1] || (p == obs_pt[i - 1] && obs_cam && n_cams > 0 && obs_cam[i] < obs_cam[i - 1]))) sorted = false;
+  }
   // optional first key: camera (stable counting sort), so that the final order is (point, camera, input order)
   std::vector<int64_t> by_cam;
-  if (obs_cam && n_cams > 0) {
+  if (!sorted && obs_cam && n_cams > 0) {
     std::vector<int64_t> cc((size_t)n_cams + 1, 0);
     for (int64_t i = 0; i < n_obs; ++i) {
       if (obs_cam[i] < 0 || obs_cam[i] >= n_cams) return fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, obs_cam[i]);
@@ -29,10 +38,14 @@ static int64_t host_plan_impl(Fail fail, int32_t n_points, int64_t n_obs, const 
   }
   for (int32_t p = 0; p < n_points; ++p) count[p + 1] += count[p];
   for (int32_t p = 0; p <= n_points; ++p) pt_start_out[p] = count[p];
-  std::vector<int64_t> cursor(count.begin(), count.end() - 1);
-  for (int64_t q = 0; q < n_obs; ++q) {  // stable counting sort by point
-    const int64_t i = by_cam.empty() ? q : by_cam[q];
-    order_out[cursor[obs_pt[i]]++] = i;
+  if (sorted) {
+    for (int64_t q = 0; q < n_obs; ++q) order_out[q] = q;
+  } else {
+    std::vector<int64_t> cursor(count.begin(), count.end() - 1);
+    for (int64_t q = 0; q < n_obs; ++q) {  // stable counting sort by point
+      const int64_t i = by_cam.empty() ? q : by_cam[q];
+      order_out[cursor[obs_pt[i]]++] = i;
+    }
   }
   int64_t n_chunks = 0;
   int64_t start = 0;

@@ -57,6 +57,8 @@ struct Reg2Params {
   int pair_cap = 0;       // > 0: pairs of one block per chunk the kernel takes without an extra load; the dealing opens new chunks rather than going beyond
                           // (a single point with more pairs of one block than this still gets its chunk)
   int n_waves = 4;        // waves of a workgroup that multiply pairs (4: 256 threads, 16: the 1024-thread kernel of 32 x 32 tiles)
+  int colour_sweeps = 0;  // refinement sweeps of the slot colouring behind the greedy pass.  Two sweeps (round 2) buy 1.35 instead of 1.36 LDS cycles
+                          // per 16-lane read group on cfg4 and cost a quarter of the plan's time: off by default (CBA_PLAN_SWEEPS)
 };
 
 struct Reg2Plan {
@@ -187,6 +189,9 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
     job.chunk_start.push_back(0);
     job.code_start.push_back(0);
     if (cand.empty()) return;
+    // one allocation each for what the job emits (growing them by doubling re-maps tens of megabytes under all the worker threads at once)
+    job.obs.reserve((size_t)(tot_rec + tot_rec / 8) + 64);
+    job.codes.reserve((size_t)((double)tot_pairs * 1.7) + 256 * (size_t)NW);
     // capacity of a key per unit of the cap t: rep thread slots per block, all helper slots of a camera
     std::vector<int> unit((size_t)nblk + g, rep);
     int active_slots = 0;
@@ -211,36 +216,69 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       long cost = 0;
     };
     const double mean = (double)tot_pairs / active_slots / std::max(1.0, (double)tot_rec / R);  // pairs per thread slot per full chunk
+    // per candidate the set of its keys as a bit mask, per chunk the set of keys that have reached the cap: a chunk where the two intersect cannot take
+    // the candidate — one AND per 64 keys instead of a walk over the candidate's keys with increments to take back (most first-fit probes fail)
+    const int W = nblk + g, MW = (W + 63) / 64;
+    std::vector<unsigned long long> cand_mask(cand.size() * (size_t)MW, 0ull);
+    for (size_t ci = 0; ci < cand.size(); ++ci)
+      for (int k = cand[ci].key_begin; k < cand[ci].key_end; ++k) cand_mask[ci * MW + keys[k] / 64] |= 1ull << (keys[k] % 64);
     auto deal = [&](int t0, int r_eff, Deal& d) {
       const int want = (int)((tot_rec + r_eff - 1) / r_eff);
       const int max_chunks = want + std::max(2, want / 12);
       std::vector<unsigned short> cnt;  // [chunk][nblk + g]
+      std::vector<unsigned long long> atcap;  // [chunk][MW]
       std::vector<int> fill;
-      const int W = nblk + g;
-      auto open_chunk = [&]() { cnt.resize(cnt.size() + W, 0); fill.push_back(0); d.members.emplace_back(); };
+      auto open_chunk = [&]() { cnt.resize(cnt.size() + W, 0); atcap.resize(atcap.size() + MW, 0ull); fill.push_back(0); d.members.emplace_back(); };
       std::vector<int> todo(order), left;
       for (int t = t0; !todo.empty(); ++t) {
+        if (t > t0)  // a higher cap: what was full may have room again
+          for (size_t ch = 0; ch < fill.size(); ++ch) {
+            unsigned long long* am = &atcap[ch * MW];
+            const unsigned short* cc = &cnt[ch * W];
+            for (int w = 0; w < MW; ++w) am[w] = 0ull;
+            for (int k = 0; k < W; ++k)
+              if (cc[k] >= t * unit[k]) am[k / 64] |= 1ull << (k % 64);
+          }
         left.clear();
         int first = 0;
         for (int ci : todo) {
           const Cand& c = cand[ci];
+          const unsigned long long* cm = &cand_mask[(size_t)ci * MW];
           while (first < (int)fill.size() && fill[first] + min_rec > r_eff) ++first;
           bool placed = false;
           for (int ch = first; ch <= (int)fill.size() && !placed; ++ch) {
             if (ch == (int)fill.size()) {
               if (ch >= max_chunks && t < t0 + 6 && (prm.pair_cap <= 0 || t < prm.pair_cap)) break;  // the region is full at this cap: try again with t + 1
               open_chunk();
+              if (t > 0) {  // (keys without capacity — unit 0 — are at the cap from the start)
+                unsigned long long* am = &atcap[(size_t)ch * MW];
+                for (int k = 0; k < W; ++k)
+                  if (t * unit[k] <= 0) am[k / 64] |= 1ull << (k % 64);
+              }
             }
             if (fill[ch] + c.n_rec > r_eff) continue;
+            const bool fresh = fill[ch] == 0 && ch + 1 == (int)fill.size();
+            {
+              const unsigned long long* am = &atcap[(size_t)ch * MW];
+              unsigned long long hit = 0ull;
+              for (int w = 0; w < MW; ++w) hit |= am[w] & cm[w];
+              if (hit) {
+                if (fresh) break;  // does not even fit an empty chunk at this cap
+                continue;
+              }
+            }
             unsigned short* cc = &cnt[(size_t)ch * W];
             int k = c.key_begin;
             for (; k < c.key_end; ++k)
               if (++cc[keys[k]] > t * unit[keys[k]]) break;
-            if (k < c.key_end) {  // over the cap: take the increments back
+            if (k < c.key_end) {  // over the cap (a key the candidate holds more than once): take the increments back
               for (int k2 = c.key_begin; k2 <= k; ++k2) --cc[keys[k2]];
-              if (fill[ch] == 0 && ch + 1 == (int)fill.size()) break;  // does not even fit an empty chunk at this cap
+              if (fresh) break;  // does not even fit an empty chunk at this cap
               continue;
             }
+            unsigned long long* am = &atcap[(size_t)ch * MW];
+            for (k = c.key_begin; k < c.key_end; ++k)
+              if (cc[keys[k]] >= t * unit[keys[k]]) am[keys[k] / 64] |= 1ull << (keys[k] % 64);
             fill[ch] += c.n_rec;
             d.members[ch].push_back(ci);
             placed = true;
@@ -278,10 +316,16 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
     std::vector<unsigned> rr((size_t)nblk, 0), rrc((size_t)g, 0);
     std::vector<int> rec_obs;                 // chunk record id (arrival order) -> observation
     std::vector<int> slot_of, residue;        // record id -> slot / residue
-    std::vector<std::vector<int>> cliques;    // distinct record ids a lane group reads in one instruction
-    std::vector<std::vector<int>> rec_cl;     // record id -> cliques it belongs to
+    // cliques: the distinct record ids a lane group reads in one instruction (at most 16: one per lane of the group), flat arrays;
+    // rec_cl: record id -> the cliques it belongs to, as CSR.  (Round 2 kept both as vectors of vectors: half of the plan's time went into
+    // their allocation and into the strided walk of best_residue.)
+    std::vector<int> clq_item;                // [clique][16]
+    std::vector<unsigned char> clq_n;         // [clique]
+    std::vector<int> rcl_start, rcl_item, rcl_fill;
     std::vector<int> clq_cnt;                 // [clique][16] members per residue
-    std::vector<int> mark;
+    std::vector<int> mark, class_size, order_r, deg_start;
+    std::vector<size_t> nit_w((size_t)NW);
+    std::vector<unsigned> packed((size_t)NWORD, 0u);
     for (const std::vector<int>& mem : best.members) {
       if (mem.empty()) continue;
       for (auto& l : lists) l.clear();
@@ -316,38 +360,40 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
         }
       }
       const int n_rec = (int)rec_obs.size();
-      std::vector<size_t> nit_w((size_t)NW);
       for (int w = 0; w < NW; ++w) {
         size_t mx = 0;
         for (int l = 0; l < 64; ++l) mx = std::max(mx, lists[(size_t)w * 64 + l].size());
         nit_w[w] = std::min<size_t>(mx, 255);  // a byte per wave; 255 pairs of one block in one chunk cannot happen (chunk_cap records)
       }
       // cliques of the LDS reads: per wave, iteration, lane group and operand the distinct records read together
-      cliques.clear();
+      size_t n_clq = 0;
+      for (int w = 0; w < NW; ++w) n_clq += nit_w[w] * 8;
+      clq_item.resize(n_clq * 16);
+      clq_n.assign(n_clq, 0);
       mark.assign((size_t)n_rec, -1);
-      for (int w = 0; w < NW; ++w)
-        for (size_t it = 0; it < nit_w[w]; ++it)
-          for (int side = 0; side < 2; ++side) {
-            const size_t c0 = cliques.size();
-            cliques.resize(c0 + 4);
-            for (int l = 0; l < 64; ++l) {
-              const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
-              if (it >= li.size()) continue;
-              const int r = side ? (int)(li[it] >> 16) : (int)(li[it] & 0xffffu);
-              const int cq = (int)c0 + b128_group(l);
-              if (mark[r] == cq) continue;  // the same record twice in a group: one address, a broadcast
-              mark[r] = cq;
-              cliques[cq].push_back(r);
-            }
-          }
+      {
+        size_t c0 = 0;
+        for (int w = 0; w < NW; ++w)
+          for (size_t it = 0; it < nit_w[w]; ++it)
+            for (int side = 0; side < 2; ++side, c0 += 4)
+              for (int l = 0; l < 64; ++l) {
+                const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
+                if (it >= li.size()) continue;
+                const int r = side ? (int)(li[it] >> 16) : (int)(li[it] & 0xffffu);
+                const int cq = (int)c0 + b128_group(l);
+                if (mark[r] == cq) continue;  // the same record twice in a group: one address, a broadcast
+                mark[r] = cq;
+                clq_item[(size_t)cq * 16 + clq_n[cq]++] = r;
+              }
+      }
       auto clique_cost = [&](const std::vector<int>& res) {
         long cyc = 0;
         int cnt[16];
-        for (const std::vector<int>& cq : cliques) {
-          if (cq.empty()) continue;
+        for (size_t cq = 0; cq < n_clq; ++cq) {
+          if (!clq_n[cq]) continue;
           std::fill(cnt, cnt + 16, 0);
           int mx = 0;
-          for (int r : cq) mx = std::max(mx, ++cnt[res[r] & 15]);
+          for (int k = 0; k < clq_n[cq]; ++k) mx = std::max(mx, ++cnt[res[clq_item[cq * 16 + k]] & 15]);
           cyc += mx;
         }
         return cyc;
@@ -355,38 +401,52 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       residue.resize((size_t)n_rec);
       for (int r = 0; r < n_rec; ++r) residue[r] = r & 15;
       long groups = 0;
-      for (const std::vector<int>& cq : cliques) groups += cq.empty() ? 0 : 1;
+      for (size_t cq = 0; cq < n_clq; ++cq) groups += clq_n[cq] ? 1 : 0;
       job.lds_groups += groups;
       job.lds_cycles_arrival += clique_cost(residue);
       // colouring
-      const int cap_class = (R + 15) / 16;
-      rec_cl.assign((size_t)n_rec, {});
-      for (size_t cq = 0; cq < cliques.size(); ++cq)
-        for (int r : cliques[cq]) rec_cl[r].push_back((int)cq);
-      clq_cnt.assign(cliques.size() * 16, 0);
-      std::vector<int> class_size(16, 0), order_r((size_t)n_rec);
-      for (int r = 0; r < n_rec; ++r) order_r[r] = r;
-      std::stable_sort(order_r.begin(), order_r.end(), [&](int x, int y) { return rec_cl[x].size() > rec_cl[y].size(); });
+      rcl_start.assign((size_t)n_rec + 1, 0);
+      for (size_t cq = 0; cq < n_clq; ++cq)
+        for (int k = 0; k < clq_n[cq]; ++k) rcl_start[(size_t)clq_item[cq * 16 + k] + 1]++;
+      for (int r = 0; r < n_rec; ++r) rcl_start[(size_t)r + 1] += rcl_start[r];
+      rcl_item.resize((size_t)rcl_start[n_rec]);
+      rcl_fill.assign(rcl_start.begin(), rcl_start.end() - 1);
+      for (size_t cq = 0; cq < n_clq; ++cq)  // ascending clique order per record, as the vectors of round 2 had it
+        for (int k = 0; k < clq_n[cq]; ++k) rcl_item[(size_t)rcl_fill[clq_item[cq * 16 + k]]++] = (int)cq;
+      clq_cnt.assign(n_clq * 16, 0);
+      class_size.assign(16, 0);
+      order_r.resize((size_t)n_rec);
+      {  // records by the number of cliques they are in, most first, stable (counting sort)
+        int maxd = 0;
+        for (int r = 0; r < n_rec; ++r) maxd = std::max(maxd, rcl_start[r + 1] - rcl_start[r]);
+        deg_start.assign((size_t)maxd + 2, 0);
+        for (int r = 0; r < n_rec; ++r) deg_start[(size_t)maxd - (rcl_start[r + 1] - rcl_start[r]) + 1]++;
+        for (int d = 0; d <= maxd; ++d) deg_start[(size_t)d + 1] += deg_start[d];
+        for (int r = 0; r < n_rec; ++r) order_r[(size_t)deg_start[(size_t)maxd - (rcl_start[r + 1] - rcl_start[r])]++] = r;
+      }
       std::fill(residue.begin(), residue.end(), -1);
       auto best_residue = [&](int r) {
+        long cost[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = rcl_start[r]; e < rcl_start[r + 1]; ++e) {
+          const int* row = &clq_cnt[(size_t)rcl_item[e] * 16];  // one contiguous row per clique: the 16 sums vectorise
+          for (int rho = 0; rho < 16; ++rho) cost[rho] += row[rho];
+        }
         int best_rho = -1;
         long best_cost = 0;
         for (int rho = 0; rho < 16; ++rho) {
-          if (class_size[rho] >= cap_class) continue;
-          long cost = 0;
-          for (int cq : rec_cl[r]) cost += clq_cnt[(size_t)cq * 16 + rho];
-          cost = cost * 64 + class_size[rho];
-          if (best_rho < 0 || cost < best_cost) { best_rho = rho; best_cost = cost; }
+          if (class_size[rho] >= (R - rho + 15) / 16) continue;  // slots rho, rho + 16, ... below the chunk's R slots
+          const long c = cost[rho] * 64 + class_size[rho];
+          if (best_rho < 0 || c < best_cost) { best_rho = rho; best_cost = c; }
         }
         return best_rho;
       };
       auto put = [&](int r, int rho, int d) {
         residue[r] = d > 0 ? rho : -1;
         class_size[rho] += d;
-        for (int cq : rec_cl[r]) clq_cnt[(size_t)cq * 16 + rho] += d;
+        for (int e = rcl_start[r]; e < rcl_start[r + 1]; ++e) clq_cnt[(size_t)rcl_item[e] * 16 + rho] += d;
       };
       for (int r : order_r) put(r, best_residue(r), +1);
-      for (int sweep = 0; sweep < 2; ++sweep)
+      for (int sweep = 0; sweep < prm.colour_sweeps; ++sweep)
         for (int r : order_r) {
           const int old = residue[r];
           put(r, old, -1);
@@ -404,7 +464,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
       const size_t open = job.obs.size();
       job.obs.resize(open + n_slots, 0);  // holes point at observation 0: loaded, never referenced
       for (int r = 0; r < n_rec; ++r) job.obs[open + slot_of[r]] = rec_obs[r];
-      std::vector<unsigned> packed((size_t)NWORD, 0u);
+      std::fill(packed.begin(), packed.end(), 0u);
       for (int w = 0; w < NW; ++w) {
         const size_t mx = nit_w[w];
         packed[w / 4] |= (unsigned)mx << (8 * (w % 4));
@@ -424,8 +484,10 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
     }
   };
 
+  // (more than ~64 workers do not pay: a job is a few milliseconds, and starting a thread costs the main thread ~20 us)
+  const unsigned n_threads = prm.threads > 0 ? (unsigned)prm.threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
   {
-    unsigned hw = prm.threads > 0 ? (unsigned)prm.threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned hw = n_threads;
     hw = std::min<unsigned>(hw, (unsigned)jobs.size());
     std::atomic<size_t> next{0};
     auto worker = [&]() {
@@ -439,34 +501,50 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
   for (const Job& j : jobs)
     if (j.rc) return j.rc;
 
-  // concatenate in (tile, region) order
+  // concatenate in (tile, region) order: offsets first, then the copies by the worker threads
   size_t n_obs = 0, n_codes = 0, n_chunks = 0;
-  for (const Job& j : jobs) { n_obs += j.obs.size(); n_codes += j.codes.size(); n_chunks += j.nit.size() / NWORD; }
-  out.obs.assign(n_obs + 2 * (size_t)R, 0);
-  out.codes.assign(n_codes + (size_t)4 * 64 * NW, ZERO);
+  std::vector<size_t> job_o(jobs.size()), job_c(jobs.size()), job_ch(jobs.size());
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    job_o[j] = n_obs; job_c[j] = n_codes; job_ch[j] = n_chunks;
+    n_obs += jobs[j].obs.size(); n_codes += jobs[j].codes.size(); n_chunks += jobs[j].nit.size() / NWORD;
+  }
+  out.obs.resize(n_obs + 2 * (size_t)R);
+  out.codes.resize(n_codes + (size_t)4 * 64 * NW);
+  std::fill(out.obs.begin() + (long)n_obs, out.obs.end(), 0);
+  std::fill(out.codes.begin() + (long)n_codes, out.codes.end(), ZERO);
   out.chunk_start.assign(n_chunks + 1, 0);
   out.code_start.assign(n_chunks + 1, 0);
   out.nit.assign(n_chunks * NWORD, 0);
   out.tile_chunk_begin.assign(nT + 1, 0);
   out.n_pairs = 0; out.lane_iters = 0; out.lds_groups = 0; out.lds_cycles = 0; out.lds_cycles_arrival = 0;
-  size_t o = 0, cpos = 0, ch = 0;
-  for (int t = 0; t < nT; ++t) {
-    out.tile_chunk_begin[t] = (int)ch;
-    for (int r = 0; r < n_regions; ++r) {
-      const Job& j = jobs[(size_t)t * n_regions + r];
-      std::copy(j.obs.begin(), j.obs.end(), out.obs.begin() + o);
-      std::copy(j.codes.begin(), j.codes.end(), out.codes.begin() + cpos);
-      const size_t jch = j.nit.size() / NWORD;
-      std::copy(j.nit.begin(), j.nit.end(), out.nit.begin() + ch * NWORD);
-      for (size_t c = 0; c < jch; ++c) {
-        out.chunk_start[ch + c + 1] = (int)(o + j.chunk_start[c + 1]);
-        out.code_start[ch + c + 1] = (int)(cpos + j.code_start[c + 1]);
+  for (int t = 0; t < nT; ++t) out.tile_chunk_begin[t] = (int)job_ch[(size_t)t * n_regions];
+  {
+    std::atomic<size_t> next{0};
+    auto copier = [&]() {
+      for (size_t ji = next++; ji < jobs.size(); ji = next++) {
+        const Job& j = jobs[ji];
+        const size_t o = job_o[ji], cpos = job_c[ji], ch = job_ch[ji];
+        std::copy(j.obs.begin(), j.obs.end(), out.obs.begin() + (long)o);
+        std::copy(j.codes.begin(), j.codes.end(), out.codes.begin() + (long)cpos);
+        const size_t jch = j.nit.size() / NWORD;
+        std::copy(j.nit.begin(), j.nit.end(), out.nit.begin() + (long)(ch * NWORD));
+        for (size_t c = 0; c < jch; ++c) {
+          out.chunk_start[ch + c + 1] = (int)(o + j.chunk_start[c + 1]);
+          out.code_start[ch + c + 1] = (int)(cpos + j.code_start[c + 1]);
+        }
       }
-      o += j.obs.size(); cpos += j.codes.size(); ch += jch;
-      out.n_pairs += j.n_pairs; out.lane_iters += j.lane_iters;
-      out.lds_groups += j.lds_groups; out.lds_cycles += j.lds_cycles; out.lds_cycles_arrival += j.lds_cycles_arrival;
-    }
+    };
+    const unsigned nth = std::min<unsigned>(n_threads, (unsigned)jobs.size());
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < nth; ++i) pool.emplace_back(copier);
+    copier();
+    for (auto& th : pool) th.join();
   }
+  for (const Job& j : jobs) {
+    out.n_pairs += j.n_pairs; out.lane_iters += j.lane_iters;
+    out.lds_groups += j.lds_groups; out.lds_cycles += j.lds_cycles; out.lds_cycles_arrival += j.lds_cycles_arrival;
+  }
+  const size_t ch = n_chunks;
   out.tile_chunk_begin[nT] = (int)ch;
   return 0;
 }
