@@ -1885,13 +1885,15 @@ __device__ __forceinline__ void chol_factor_block(double (*D)[NB + 1], int nb, i
 
 // every thread of the workgroup, behind a barrier: L (lower triangle, live rows) to the global block at `out` (row stride ldw) and
 // X = L^-1 (NB x NB, row-major, identity-padded beyond nb) to `xinv`.  Three stores per thread instead of 32 per lane of the factoring wave.
+// tdiag != nullptr: the diagonal block of T = L^-T (k_chol_apply) receives X^T as well.
 __device__ __forceinline__ void chol_factor_store(double (*D)[NB + 1], int nb, double* __restrict__ out, int ldw, double* __restrict__ xinv,
-                                                  int tid, int nthreads) {
+                                                  int tid, int nthreads, double* __restrict__ tdiag = nullptr) {
   for (int e = tid; e < NB * NB; e += nthreads) {
     const int i = e / NB, c = e % NB;
     const double l = D[i][c], x = D[NB + c][i];
     if (i < nb && c <= i) out[(long)i * ldw + c] = l;
     xinv[e] = x;
+    if (tdiag && i < nb && c < nb) tdiag[(long)c * ldw + i] = x;  // T_kk[c][i] = X[i][c]
   }
 }
 
@@ -1946,7 +1948,8 @@ __device__ __forceinline__ void chol_rank_nb(const double* __restrict__ A, int r
 }
 
 __global__ void __launch_bounds__(CHOL_THREADS)
-k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace, double* __restrict__ Xinv) {
+k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace, double* __restrict__ Xinv,
+            double* __restrict__ Tinv = nullptr) {
   __shared__ double sh_red[4][16][17];
   __shared__ double sh_U[NB][NB + 1], sh_X[NB][NB + 1], sh_D[2 * NB][NB + 1];
   __shared__ __attribute__((aligned(16))) double sh_L[NB][NB + 2];  // even row stride: pairs of coefficients are 16-byte aligned
@@ -1955,6 +1958,58 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   constexpr int EPT = NB * NB / CHOL_THREADS, ISTEP = CHOL_THREADS / NB;  // elements of a 32 x 32 block per thread
   const int j = tid & 31, i0 = tid >> 5;                  // (i0 + h * ISTEP, j), h < EPT
   const int n_panel = (k < 0) ? 1 : nbk - k;
+  const int n_trailing = (k < 1) ? 0 : (nbk - k - 1) * (nbk - k) / 2;
+
+  if ((int)blockIdx.x >= n_panel + n_trailing) {
+    // inverse role (Tinv != nullptr, k >= 1): T = L^-T is built next to the factorisation, off its critical path, so that the backward substitution
+    // — a serial chain of one workgroup, 2.3 us per block — becomes one matrix-vector product (k_chol_apply).  With M = L^-1:
+    //     M_ij = -X_i sum_{m=j}^{i-1} L_im M_mj   (i > j),   M_jj = X_j;    T_ji = M_ij^T is what is stored (upper block triangle).
+    // The sum is accumulated right-looking: launch k adds the term m = k - 1 to every block (i >= k, j < k) — L_i,k-1 comes from the panel solves
+    // of launch k - 1, T_j,k-1 was finalised there — and finalises row i = k with X_k (factored by launch k - 1's look-ahead):
+    //     acc^T_ji += T_j,k-1 L_i,k-1^T ;      i == k:  T_jk = -acc^T_jk X_k^T.
+    const int t2 = blockIdx.x - n_panel - n_trailing;
+    const int bi = k + t2 / k, bj = t2 % k, m = k - 1;
+    const int ri = bi * NB, rci = min(NB, n - ri), rj = bj * NB, rcj = min(NB, n - rj);
+    double* Tb = Tinv + (long)rj * ldw + ri;  // block (bj, bi)
+    double old[EPT];
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      old[h] = (m != bj && i < rcj && j < rci) ? Tb[(long)i * ldw + j] : 0.0;  // m == bj: the first term
+    }
+    chol_rank_nb(Tinv + (long)rj * ldw + m * NB, rcj, W + (long)ri * ldw + m * NB, rci, ldw, sh_red, wv, lane);
+    __syncthreads();
+    if (bi != k) {
+#pragma unroll
+      for (int h = 0; h < EPT; ++h) {
+        const int i = i0 + h * ISTEP;
+        if (i < rcj && j < rci) Tb[(long)i * ldw + j] = old[h] + sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
+      }
+      return;
+    }
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      sh_U[i][j] = (i < rcj && j < rci) ? old[h] + sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15] : 0.0;
+      sh_L[i][j] = Xinv[(long)k * NB * NB + i * NB + j];  // X_k, identity-padded
+    }
+    __syncthreads();
+    if (wv < 4) {
+      const int ti = wv >> 1, tj = wv & 1;
+      v4f64 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < NB / 4; ++t) {
+        const int q = 4 * t + (lane >> 4);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_U[ti * 16 + (lane & 15)][q], sh_L[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + (lane >> 4) + 4 * r, jj = tj * 16 + (lane & 15);
+        if (i < rcj && jj < rci) Tb[(long)i * ldw + jj] = -c[r];
+      }
+    }
+    return;
+  }
 
   if ((int)blockIdx.x >= n_panel) {
     // trailing role: block (bi, bj), k + 1 <= bj < bi <= nbk, takes the update of panel k - 1
@@ -2004,7 +2059,7 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
     __syncthreads();
     if (tid < WAVE) chol_factor_block(sh_D, rc, flags);
     __syncthreads();
-    chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv, tid, CHOL_THREADS);  // L_00, X_0
+    chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv, tid, CHOL_THREADS, Tinv ? Tinv + (long)rb * ldw + rb : nullptr);  // L_00, X_0
     return;
   }
   const int k0 = k * NB, nbp = min(NB, n - k0);
@@ -2083,9 +2138,32 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
   CHOL_STAMP(5);
   if (tid < WAVE) chol_factor_block(sh_D, rc, flags);
   __syncthreads();
-  chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv + (long)(k + 1) * NB * NB, tid, CHOL_THREADS);
+  chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv + (long)(k + 1) * NB * NB, tid, CHOL_THREADS, Tinv ? Tinv + (long)rb * ldw + rb : nullptr);
   CHOL_STAMP(6);
 #undef CHOL_STAMP
+}
+
+// x = L^-T y = T y with the explicit T of the inverse role above: one workgroup per block row, 16 threads per row (coalesced 128-byte reads),
+// fixed summation order.  Replaces k_chol_backward's serial chain (33 us at n = 384, 139 us at n = 1152) by a launch of a few microseconds.
+constexpr int APPLY_THREADS = 512;
+__global__ void __launch_bounds__(APPLY_THREADS)
+k_chol_apply(const double* __restrict__ Tinv, const double* __restrict__ W, int n, int ldw, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double y[];  // n
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += APPLY_THREADS) y[i] = W[(long)n * ldw + i];
+  __syncthreads();
+  const int r = tid >> 4, cl = tid & 15, row = blockIdx.x * NB + r;
+  double a0 = 0.0, a1 = 0.0;
+  if (row < n) {
+    const double* Tr = Tinv + (long)row * ldw;
+    int c = blockIdx.x * NB + cl;
+    for (; c + 16 < n; c += 32) { a0 = fma(Tr[c], y[c], a0); a1 = fma(Tr[c + 16], y[c + 16], a1); }
+    if (c < n) a0 = fma(Tr[c], y[c], a0);
+  }
+  double s = a0 + a1;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (cl == 0 && row < n) out[row] = s;
 }
 
 // backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block kb (last to first):

@@ -105,6 +105,7 @@ struct cba_problem {
   DetPlan det{nullptr, nullptr};
   double* tri = nullptr;   // packed upper triangle of Sacc + b for the exchange of a sharded solve
   double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
+  double* Tinv = nullptr;  // T = L^-T, built block by block next to the factorisation (inverse role of k_chol_step); nullptr: CBA_CHOL_BACKWARD=subst
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
@@ -869,6 +870,7 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_backsub<NC, true>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_backward, (size_t)(p->ncp + NB) * 8))) return rc;
+  if ((rc = allow_lds(k_chol_apply, (size_t)p->ncp * 8))) return rc;
   return CBA_OK;
 }
 
@@ -1110,6 +1112,13 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 2) * 8));
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->Xinv, (size_t)((ncp + NB - 1) / NB + 1) * NB * NB));
+  {
+    const char* e = std::getenv("CBA_CHOL_BACKWARD");
+    if (!(e && std::strcmp(e, "subst") == 0)) {  // default: x = T y with the explicit inverse transpose; "subst": the backward substitution of round 2
+      TRY(dev_alloc(p, &p->Tinv, (size_t)ncp * p->ldw));
+      HIPBAIL(hipMemset(p->Tinv, 0, (size_t)ncp * p->ldw * sizeof(double)));
+    }
+  }
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
@@ -1390,10 +1399,14 @@ static int enqueue_cholesky(cba_problem* p) {
     // rank-NB update of panel k - 1 to the blocks right of the current panel
     const int n_panel = k < 0 ? 1 : nbk - k;
     const int x = nbk - k - 1, n_trailing = k < 1 ? 0 : x * (x + 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace, p->Xinv);
+    const int n_inverse = (p->Tinv && k >= 1) ? (nbk - k) * k : 0;  // blocks (i >= k, j < k) of T = L^-T take the term of panel k - 1
+    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing + n_inverse), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace, p->Xinv, p->Tinv);
   }
-  hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)(n + NB) * 8, p->stream, p->Lbuf, n, p->ldw, p->Xinv, p->s,
-                     p->chol_trace ? p->chol_trace + (size_t)((n + NB - 1) / NB + 1) * 8 : (long long*)nullptr);
+  if (p->Tinv)
+    hipLaunchKernelGGL(k_chol_apply, dim3(nbk), dim3(APPLY_THREADS), (size_t)n * 8, p->stream, (const double*)p->Tinv, (const double*)p->Lbuf, n, p->ldw, p->s);
+  else
+    hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)(n + NB) * 8, p->stream, p->Lbuf, n, p->ldw, p->Xinv, p->s,
+                       p->chol_trace ? p->chol_trace + (size_t)((n + NB - 1) / NB + 1) * 8 : (long long*)nullptr);
   return CBA_OK;
 }
 
