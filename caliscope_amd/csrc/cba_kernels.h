@@ -2573,7 +2573,8 @@ __device__ __forceinline__ double column_sum(const double* __restrict__ partial,
 // the three reductions of the linearisation (sums, max |g|, ||J v||^2) and the damping in one launch
 __global__ void __launch_bounds__(BLOCK)
 k_lin_finish(const double* __restrict__ partial_lin, const double* __restrict__ partial_max, int rows_lin,
-             const double* __restrict__ partial_jv, int rows_jv, double radius, double* __restrict__ scal, double* __restrict__ fz) {
+             const double* __restrict__ partial_jv, int rows_jv, double radius, double* __restrict__ scal, double* __restrict__ fz,
+             const double* __restrict__ radius_dev = nullptr) {  // radius_dev: the radius is read from (mapped host) memory — replayed step graphs
   // nine sums and a maximum in ONE pass and one barrier (column by column — ten block reductions in a row — the kernel took 10.6 us);
   // per value the order of the additions is the one of column_sum / block_sum
   __shared__ double sh_red[10][BLOCK / WAVE];
@@ -2603,7 +2604,7 @@ k_lin_finish(const double* __restrict__ partial_lin, const double* __restrict__ 
       for (int i = 0; i < BLOCK / WAVE; ++i) r = (q == 4) ? fmax(r, sh_red[q][i]) : r + sh_red[q][i];
       scal[q < 5 ? q : 12 + (q - 5)] = r;
     }
-    fused_lam(scal, radius, fz);
+    fused_lam(scal, radius_dev ? *radius_dev : radius, fz);
   }
 }
 
@@ -2639,9 +2640,10 @@ k_step_finish(const double* __restrict__ partial, int rows, double* __restrict__
 __global__ void __launch_bounds__(BLOCK)
 k_publish(double* __restrict__ scal, int n_scal, int* __restrict__ flags, double* __restrict__ host_scal,
           int* __restrict__ host_flags, unsigned long long seq, const double* __restrict__ part_a, int rows_a, int slot_a,
-          const double* __restrict__ part_b, int rows_b, int slot_b) {
+          const double* __restrict__ part_b, int rows_b, int slot_b, const unsigned long long* __restrict__ seq_dev = nullptr) {
   __shared__ double sh_red[BLOCK / WAVE];
   const int t = threadIdx.x;
+  if (seq_dev) seq = *reinterpret_cast<const volatile unsigned long long*>(seq_dev);  // replayed step graphs: the host leaves the number in the mailbox
   // single-rank fused step: the last two per-workgroup partial columns (trial cost, step norm) are summed here
   if (part_a) { const double r = column_sum(part_a, rows_a, 1, 0, sh_red); if (t == 0) scal[slot_a] = r; }
   if (part_b) { const double r = column_sum(part_b, rows_b, 1, 0, sh_red); if (t == 0) scal[slot_b] = r; }

@@ -140,6 +140,13 @@ struct cba_problem {
   double* sinv2 = nullptr;
   bool spec_enqueued = false, spec_valid = false;
   int spec_rows_jv = 0;
+  // Steady-state fused iterations are replayed from a hipGraph (one per pointer parity: x / V / sinv swap on acceptance): ~30 launches become one
+  // hipGraphLaunch.  What changes from iteration to iteration travels through the mapped mailbox: h_scal[60] the radius, h_scal[61] the
+  // sequence number k_publish answers with.  `capturing`: the launches are being recorded, not executed (run_cholesky records its launches inline).
+  struct StepGraph { const void *x, *V, *sinv; hipGraph_t graph; hipGraphExec_t exec; };
+  std::vector<StepGraph> step_graphs;
+  bool capturing = false;
+  long step_graph_launches = 0;
   bool have_x0 = false;
   std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
   bool schur_clock = false;  // profiling only (CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
@@ -289,9 +296,14 @@ static void drain_timers(cba_problem* p) {
 // part_a / part_b: per-workgroup partial columns whose sums belong to scal[slot_a] / scal[slot_b] (compact fused step)
 static unsigned long long publish_enqueue(cba_problem* p, int n_scal, const double* part_a = nullptr, int rows_a = 0, int slot_a = 0,
                                           const double* part_b = nullptr, int rows_b = 0, int slot_b = 0) {
+  if (p->capturing) {  // the recorded k_publish reads its sequence number from the mailbox (h_scal[61], written by the host before every replay)
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, 0ull, part_a, rows_a,
+                       slot_a, part_b, rows_b, slot_b, reinterpret_cast<const unsigned long long*>(p->d_hscal + 61));
+    return p->publish_seq;
+  }
   const unsigned long long seq = ++p->publish_seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, seq, part_a, rows_a,
-                     slot_a, part_b, rows_b, slot_b);
+                     slot_a, part_b, rows_b, slot_b, (const unsigned long long*)nullptr);
   return seq;
 }
 // wait until the k_publish with sequence number `seq` has written its packet.  `drain`: nothing was enqueued behind it, a stream synchronize
@@ -511,6 +523,8 @@ void cba_destroy(cba_problem* p) {
   drain_timers(p);
   for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (p->comm) (void)ncclCommDestroy(p->comm);
+  for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  p->step_graphs.clear();
   if (p->chol_exec) (void)hipGraphExecDestroy(p->chol_exec);
   if (p->chol_graph) (void)hipGraphDestroy(p->chol_graph);
   {
@@ -1145,6 +1159,10 @@ int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
   if (loss != CBA_LOSS_LINEAR && !(f_scale > 0.0)) return fail(CBA_ERR_INVALID, "cba_set_loss: f_scale must be positive");
   p->loss = loss; p->f_scale = f_scale;
   p->have_build = false;  // blocks and gradient of the current point belong to the old loss
+  p->spec_valid = false; p->spec_enqueued = false;
+  // the recorded step graphs carry loss and f_scale as kernel arguments: record again
+  for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  p->step_graphs.clear();
   return CBA_OK;
 }
 
@@ -1327,7 +1345,7 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
     p->spec_valid = false;
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vec_grid(p->lay.total()), p->partial4, p->spec_rows_jv, radius,
-                       p->scal, p->fz);
+                       p->scal, p->fz, p->capturing ? (const double*)(p->d_hscal + 60) : (const double*)nullptr);
     return CBA_OK;
   }
   p->spec_valid = false;
@@ -1348,7 +1366,7 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
       int rcj = run_jv<NC>(p, 1, &rows_jv);
       if (rcj) return rcj;
       hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vg, p->partial4, rows_jv, radius,
-                         p->scal, p->fz);
+                         p->scal, p->fz, (const double*)nullptr);
       return CBA_OK;
     }
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
@@ -1448,6 +1466,7 @@ static int run_cholesky(cba_problem* p) {
     }
     return CBA_OK;
   }
+  if (p->capturing) return enqueue_cholesky(p);  // inside the recording of a step graph: its launches become nodes of that graph
   int rcg = ensure_cholesky_graph(p);
   if (rcg) return rcg;
   ScopedTimer t(p, T_CHOLESKY);
@@ -1682,12 +1701,10 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
 // skipped when the accepted trial brought its own), damping and 2-D subspace step decided on the device
 // (k_fused_lam / k_fused_subspace, the same code the host driver runs: csrc/trf_math.h), damped step, and the trial
 // point evaluated by a full build pass into the second set of buffers, so that accepting it costs nothing more.
+// everything an iteration enqueues, up to and including the speculative linearisation behind k_publish; *seq_out: what k_publish will answer with
+// (compact), *waited: the non-compact route has already synchronised
 template <int NC>
-static int run_step(cba_problem* p, double radius, cba_step_info* out) {
-  RoctxRange range("cba:step");  // one fused trust-region iteration
-  // single rank: no exchange steps in between, so neighbouring small kernels are folded together (k_scale_lin, k_lin_finish,
-  // k_step_finish, gradient written by k_reduce_rows, last sums taken by k_publish): 8 launches fewer per iteration
-  const bool compact = !p->sharded();
+static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned long long* seq_out) {
   int rc = run_lin_chain<NC>(p, true, compact, radius);
   if (rc) return rc;
   if (!compact) hipLaunchKernelGGL(k_fused_lam, dim3(1), dim3(1), 0, p->stream, p->scal, radius, p->fz);
@@ -1705,26 +1722,84 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
   launch_cam_prep(p, p->x_new, p->tab_new);
   rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact);  // skipped when need_host
   if (rc) return rc;
-  if (compact) {
-    const unsigned long long seq = publish_enqueue(p, 48, p->partial1, p->grid, 24, p->partial4, vg, 28);
-    // speculative linearisation of the trial point, enqueued BEHIND the publish: the device works on it while the host reads the packet,
-    // decides and enqueues the next iteration (k_publish -> host -> first kernel of the next cba_step used to be an idle gap per iteration)
-    p->spec_enqueued = false;
-    static const bool spec_on = [] { const char* e = std::getenv("CBA_SPECULATE"); return !(e && e[0] == '0'); }();
-    if (spec_on) {
-      {
-        ScopedTimer t(p, T_SCALE_SCALARS);
-        hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
-                           (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv);
-        int rows_jv = 0;
-        rc = run_jv<NC>(p, 1, &rows_jv, p->x_new, p->tab_new);
-        p->spec_rows_jv = rows_jv;
+  if (!compact) return CBA_OK;
+  *seq_out = publish_enqueue(p, 48, p->partial1, p->grid, 24, p->partial4, vg, 28);
+  // speculative linearisation of the trial point, enqueued BEHIND the publish: the device works on it while the host reads the packet,
+  // decides and enqueues the next iteration (k_publish -> host -> first kernel of the next cba_step used to be an idle gap per iteration)
+  p->spec_enqueued = false;
+  static const bool spec_on = [] { const char* e = std::getenv("CBA_SPECULATE"); return !(e && e[0] == '0'); }();
+  if (spec_on) {
+    {
+      ScopedTimer t(p, T_SCALE_SCALARS);
+      hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
+                         (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv);
+      int rows_jv = 0;
+      rc = run_jv<NC>(p, 1, &rows_jv, p->x_new, p->tab_new);
+      p->spec_rows_jv = rows_jv;
+    }
+    if (rc) return rc;
+    p->spec_enqueued = true;
+  }
+  return CBA_OK;
+}
+
+template <int NC>
+static int run_step(cba_problem* p, double radius, cba_step_info* out) {
+  RoctxRange range("cba:step");  // one fused trust-region iteration
+  // single rank: no exchange steps in between, so neighbouring small kernels are folded together (k_scale_lin, k_lin_finish,
+  // k_step_finish, gradient written by k_reduce_rows, last sums taken by k_publish): 8 launches fewer per iteration
+  const bool compact = !p->sharded();
+  int rc;
+  // Opt-in (CBA_STEP_GRAPH=1).  Measured on MI355X / ROCm 7.2: replaying the ~30 launches of an iteration from a graph is no faster than enqueueing
+  // them (cfg4 0.693 against 0.690 ms per iteration, cfg2 0.150 against 0.157, cfg3 0.185 against 0.192), and recording the two graphs costs a
+  // one-shot 5-evaluation solve 0.7 ms (the reference's 4-camera session: optimize() 2.0 instead of 1.3 ms).
+  static const bool graph_on = [] { const char* e = std::getenv("CBA_STEP_GRAPH"); return e && e[0] == '1'; }();
+  // steady state (the accepted trial brought its build AND its speculative linearisation): the iteration is a fixed sequence of launches on fixed
+  // buffers — replayed from a graph recorded once per pointer parity
+  if (compact && graph_on && p->have_build && p->spec_valid && !p->timers_on && !p->chol_trace && !p->schur_clock && !p->debug_skip && radius > 0.0) {
+    cba_problem::StepGraph* sg = nullptr;
+    for (auto& g : p->step_graphs)
+      if (g.x == p->x && g.V == p->V && g.sinv == p->sinv) sg = &g;
+    const unsigned long long seq = ++p->publish_seq;
+    p->h_scal[60] = radius;
+    reinterpret_cast<volatile unsigned long long*>(p->h_scal)[61] = seq;
+    std::atomic_thread_fence(std::memory_order_release);
+    if (!sg) {
+      if (p->step_graphs.size() >= 8) {  // pointer combinations beyond the two of the steady state: start over rather than grow
+        for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        p->step_graphs.clear();
       }
-      if (rc) return rc;
+      cba_problem::StepGraph ng{p->x, p->V, p->sinv, nullptr, nullptr};
+      {
+        CaptureRecording recording;
+        HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+        p->capturing = true;
+        unsigned long long unused = 0;
+        rc = step_enqueue<NC>(p, radius, true, &unused);
+        p->capturing = false;
+        const hipError_t e = hipStreamEndCapture(p->stream, &ng.graph);
+        if (rc) { if (ng.graph) (void)hipGraphDestroy(ng.graph); return rc; }
+        if (e != hipSuccess) return fail(CBA_ERR_HIP, "hipStreamEndCapture (step graph): %s", hipGetErrorString(e));
+        HIPCHK(hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+      }
+      p->step_graphs.push_back(ng);
+      sg = &p->step_graphs.back();
+    } else {  // what recording the launches did to the host-side state
+      p->spec_valid = false;
       p->spec_enqueued = true;
     }
+    HIPCHK(hipGraphLaunch(sg->exec, p->stream));
+    ++p->step_graph_launches;
+    rc = publish_wait(p, seq, false);
+  } else if (compact) {
+    unsigned long long seq = 0;
+    rc = step_enqueue<NC>(p, radius, true, &seq);
+    if (rc) return rc;
     rc = publish_wait(p, seq, !p->spec_enqueued);
   } else {
+    unsigned long long seq = 0;
+    rc = step_enqueue<NC>(p, radius, false, &seq);
+    if (rc) return rc;
     // one collective for the trial's camera blocks, its cost, the step norm and the flags
     rc = exchange_at(p, SLOT(24) | SLOT(28), false, p->U2, (size_t)p->C * UPack<NC>::STRIDE);
     if (rc) return rc;

@@ -711,3 +711,25 @@ def test_live_handles_of_different_size_and_worker_threads():
     assert not errors, errors
     for got, ref in zip(results, serial):
         assert got.status == ref.status and abs(got.nfev - ref.nfev) <= 1 and abs(got.cost - ref.cost) <= 1e-9 * ref.cost
+
+
+def test_step_graph_replay_matches_the_enqueued_iteration(monkeypatch):
+    """CBA_STEP_GRAPH=1 (opt-in): steady-state fused iterations replayed from a hipGraph per pointer parity — radius and sequence number travel through
+    the mapped mailbox — end at the same iterate, after the same evaluations, as the enqueued launches; a change of loss records the graphs again."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0 = small_problem(n_cams=8, n_points=600, k=6, loss="huber", outliers=0.03)
+    fs = sc.f_scale_1px() * 2.0
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CBA_STEP_GRAPH", mode)
+        with HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)) as eng:
+            lin = eng.solve(x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)
+            again = eng.solve(x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)   # recorded graphs are reused by the second solve
+            eng.set_loss("huber", fs)
+            rob = eng.solve(x0, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=400)
+        assert lin.status > 0 and rob.status > 0 and again.nfev == lin.nfev and abs(again.cost - lin.cost) <= 1e-12 * lin.cost
+        results[mode] = (lin, rob)
+    for a, b in zip(results["0"], results["1"]):
+        assert abs(a.nfev - b.nfev) <= 1 and abs(a.cost - b.cost) <= 1e-10 * a.cost
+        assert np.abs(a.x - b.x).max() <= 1e-7 * np.abs(a.x).max()
