@@ -732,4 +732,5 @@ def test_step_graph_replay_matches_the_enqueued_iteration(monkeypatch):
         results[mode] = (lin, rob)
     for a, b in zip(results["0"], results["1"]):
         assert abs(a.nfev - b.nfev) <= 1 and abs(a.cost - b.cost) <= 1e-10 * a.cost
-        assert np.abs(a.x - b.x).max() <= 1e-7 * np.abs(a.x).max()
+        pos, ang, _ = aligned_difference(par, a.x, b.x)  # raw x wanders along the gauge directions between any two runs
+        assert pos < 1e-7 and ang < 1e-7
