@@ -1332,7 +1332,8 @@ template <int NC, bool WIDE = false> struct Reg3Cfg {
 template <int NC, int SPLIT, bool WIDE, bool CLK = false>
 __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
                                                 const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
-                                                const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr) {
+                                                const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr,
+                                                const double* __restrict__ tab = nullptr) {
   using Cfg = Reg3Cfg<NC, WIDE>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
   constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
@@ -1574,6 +1575,46 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     o[7] = ((long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 40) | (wall_clock64() & 0xffffffffffLL);  // HW_ID, start stamp (100 MHz)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last trip's loads target LDS: let them land before the workgroup retires
+  // The accumulators hold PRIMED blocks T'_i T'_j^T (T' = [[Y]x Q ; Q ; T_intr]); the true block is P_i^T (.) P_j with P = blockdiag(J_l, I).  That
+  // map is linear, so every thread applies it to its own partial block here — ~100 FMAs once per kernel — and no separate pass over the reduced
+  // matrix is needed (k_unprime, one launch per damped step, remains for k_schur_reg2).  tab == nullptr: the caller unprimes.
+  if (tab) {
+    const int tile = tp.wg_tile[wg];
+    const int ga = tp.tile_a[tile], gb = tp.tile_b[tile];
+    const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+    const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      const int vt = (SPLIT == 1) ? v * PT + tid : ct;
+      const int blk = (rep > 1) ? vt % nblk : vt;
+      if (blk >= nblk) continue;
+      const int li = blk / tp.g, lj = blk % tp.g;
+      int ci, cj;
+      if (ga == gb && lj <= li) {  // helper thread of a diagonal tile: the (i, i) items of one camera (schur_plan.h)
+        const int hk = li * (li + 1) / 2 + lj;
+        ci = cj = ca0 + hk % max(na, 1);
+      } else {
+        if (li >= na || lj >= nb) continue;  // ragged group: no such camera, nothing was accumulated
+        ci = ca0 + li; cj = cb0 + lj;
+      }
+      const double* Ji = tab + (long)ci * CAMTAB_DOUBLES + 12;  // CamTab::Jl, row-major
+      const double* Jj = tab + (long)cj * CAMTAB_DOUBLES + 12;
+      if (r0 == 0) {  // rows 0..2 <- J_i^T rows 0..2 (all columns)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const double b0 = acc[v][0][c], b1 = acc[v][1][c], b2 = acc[v][2][c];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) acc[v][r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {  // columns 0..2 <- (.) J_j, every row the thread owns
+        const double a0 = acc[v][r][0], a1 = acc[v][r][1], a2 = acc[v][r][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[v][r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
+      }
+    }
+  }
 #pragma unroll
   for (int v = 0; v < VB; ++v) {
     bool owner;
@@ -1589,16 +1630,16 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
 
 template <int NC, int SPLIT, int MINW, bool WIDE = false>
 __global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::LAUNCH_THREADS), MINW)
-k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial) {
+k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, WIDE, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh);
+  schur_reg3_body<NC, SPLIT, WIDE, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
 }
 
 template <int NC, int SPLIT, int MINW, bool WIDE = false>
 __global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::LAUNCH_THREADS), MINW)
-k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk) {
+k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, WIDE, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk);
+  schur_reg3_body<NC, SPLIT, WIDE, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
 }
 
 // The pair kernel accumulates PRIMED blocks T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr]; the true rows 0..2 are J_l^T times the primed
@@ -2442,24 +2483,48 @@ k_w_scalar(const double* __restrict__ g, const double* __restrict__ sinv, const 
 }
 
 // x_new = x + alpha g / sinv^2 + beta s (entries below n_over: x_new = cam_x_new) ; partial[b] = sum step^2
+// tab_out != nullptr: workgroup 0 takes the whole camera block and then prepares the camera table of the new point (k_cam_prep's work: one
+// launch fewer per trial point; the other workgroups share the point block).
 __global__ void __launch_bounds__(BLOCK)
 k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
                const double* __restrict__ s, double alpha, double beta, long total, int cam_end, int count_cams,
                const double* __restrict__ cam_x_new, int n_over, const double* __restrict__ ab_dev, double* __restrict__ x_new,
-               double* __restrict__ partial) {
+               double* __restrict__ partial, double* __restrict__ tab_out = nullptr, const double* __restrict__ cam_const = nullptr,
+               const int* __restrict__ cam_model = nullptr, const int* __restrict__ cam_np = nullptr, const int* __restrict__ cam_off = nullptr,
+               int n_cams = 0) {
   __shared__ double sh_red[BLOCK / WAVE];
   if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }  // fused step: coefficients from k_fused_subspace
   double s0 = 0;
-  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+  auto entry = [&](long i) {
     const double si = sinv[i];
     double st = alpha * g[i] / (si * si) + beta * s[i];
     double xn = x[i] + st;
     if (i < n_over) { xn = cam_x_new[i]; st = xn - x[i]; }  // camera block placed by the caller (bounded solves)
     x_new[i] = xn;
     if (i >= cam_end || count_cams) s0 += st * st;
+  };
+  if (tab_out) {
+    if (blockIdx.x == 0)
+      for (long i = threadIdx.x; i < cam_end; i += BLOCK) entry(i);
+    for (long i = cam_end + (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) entry(i);
+  } else {
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) entry(i);
   }
   const double r = block_sum(s0, sh_red);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
+  if (tab_out && blockIdx.x == 0) {
+    __threadfence();   // the camera block of x_new, written by this workgroup above, is read back below
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
+      double xc[MAX_NC];
+      const int np = cam_np[c];
+      for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? __builtin_nontemporal_load(&x_new[cam_off[c] + i]) : 0.0;
+      CamTab t;
+      cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t);
+      const double* src = reinterpret_cast<const double*>(&t);
+      for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab_out[c * CAMTAB_DOUBLES + i] = src[i];
+    }
+  }
 }
 
 // ---- fused iteration (cba_step): the two scalar decisions of an iteration made on the device, so that one iteration

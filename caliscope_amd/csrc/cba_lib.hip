@@ -1529,7 +1529,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
           (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
           auto launch_clk = [&](auto kernel, int threads, size_t lds) {
             if (raise_lds_ceiling((const void*)kernel, lds)) return CBA_ERR_HIP;
-            hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(threads), lds, p->stream, p->tp, p->Trec, p->partial, d);
+            hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(threads), lds, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
             return CBA_OK;
           };
           using Wide = Reg3Cfg<6, true>;
@@ -1575,11 +1575,11 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       } else if (p->schur_wide) {
         if constexpr (NC == 6) {
           using Wide = Reg3Cfg<6, true>;
-          hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
+          hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
         }
       } else if (p->schur_v3) {
         constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
-        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, false>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial);
+        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, false>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
       } else {
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);
@@ -1629,7 +1629,8 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
       hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                          p->cam_off, p->cam_np, NC, ncp, p->Sacc);
-      hipLaunchKernelGGL((k_unprime<NC>), dim3((p->C * p->C + 255) / 256), dim3(256), 0, p->stream, p->Sacc, p->tab, p->cam_off, p->cam_np, p->C, ncp);
+      if (!p->schur_v3)  // k_schur_reg3 unprimes its partial blocks itself (epilogue of schur_reg3_body)
+        hipLaunchKernelGGL((k_unprime<NC>), dim3((p->C * p->C + 255) / 256), dim3(256), 0, p->stream, p->Sacc, p->tab, p->cam_off, p->cam_np, p->C, ncp);
       if (p->n_heavy)  // per-camera sums of the heavy points, one workgroup each (the pair plan skips them)
         hipLaunchKernelGGL((k_heavy_schur<NC>), dim3(p->n_heavy), dim3(BLOCK), (size_t)ncp * 3 * sizeof(double) + (size_t)ncp * sizeof(int), p->stream,
                            p->heavy_pts, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Trec, p->tab, p->heavy_W, p->Sacc);
@@ -1715,11 +1716,12 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
   const int vg = vec_grid(tot);
   {
     ScopedTimer t(p, T_VECTOR);
+    // (the camera table of the trial point is prepared by workgroup 0 of the same launch)
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, 0.0, 0.0, tot, p->lay.ncp_pad,
-                       p->rank == 0 ? 1 : 0, (const double*)nullptr, 0, (const double*)(p->fz + 2), p->x_new, p->partial4);
+                       p->rank == 0 ? 1 : 0, (const double*)nullptr, 0, (const double*)(p->fz + 2), p->x_new, p->partial4, p->tab_new,
+                       (const double*)p->cam_const, (const int*)p->cam_model, (const int*)p->cam_np, (const int*)p->cam_off, p->C);
     if (!compact) hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
   }
-  launch_cam_prep(p, p->x_new, p->tab_new);
   rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact);  // skipped when need_host
   if (rc) return rc;
   if (!compact) return CBA_OK;
