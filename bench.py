@@ -354,17 +354,20 @@ def cpu_baseline(m, device_id=0):
     return _scipy_vs_product(sc, m["par"], m["x0"], m["x_full"], device_id, label, loss=sc.loss, f_scale=fs)
 
 
-def cfg5_sample_parity(device_id=0):
-    """cfg5's recipe at a size scipy finishes in about a minute (SURVEY.md 8d allows a 1M-observation sample for cfg5): 128 cameras,
-    100k points, 1M observations, free intrinsics with the perturbed start (f x 1.03, k1 + 0.02, k2 + 0.05) and the bounds of
-    core/bundle_parameterization.py:151-164 — scipy runs trf_bounds, the product its Coleman-Li variant (cba_solve)."""
+def cfg5_sample_parity(device_id=0, n_points=10_000):
+    """cfg5's recipe at a size scipy finishes: 128 cameras, `n_points` points seen by 10 cameras each, free intrinsics with the perturbed start
+    (f x 1.03, k1 + 0.02, k2 + 0.05) and the bounds of core/bundle_parameterization.py:151-164 — scipy runs trf_bounds (96 evaluations on this
+    recipe: LSMR steps crawl along the intrinsics), the product its Coleman-Li variant (cba_solve).  Default 10k points / 100k observations
+    (about a minute of one host core, so that the default bench run stays within minutes); SURVEY.md 8d's 1M-observation sample
+    (--cfg5-sample-points 100000: ~7 minutes of scipy) is run once per round by tools/parity_at_size.py -> profiles/parity_r03.json."""
     from caliscope_amd.bundle_parameterization import BundleParameterization
     from caliscope_amd.synthetic import make_scene
 
-    sc = make_scene("cfg5-sample", n_cams=128, n_points=100_000, n_obs=1_000_000, refine=True)
-    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=100_000, refine_intrinsics=True)
+    sc = make_scene("cfg5-sample", n_cams=128, n_points=n_points, n_obs=10 * n_points, refine=True)
+    par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=n_points, refine_intrinsics=True)
     x0 = par.pack(sc.cameras_init, sc.points_init)
-    base, parity = _scipy_vs_product(sc, par, x0, None, device_id, "cfg5 recipe sample: 128 cams / 100k points / 1M obs, refine_intrinsics=True, bounds")
+    base, parity = _scipy_vs_product(sc, par, x0, None, device_id,
+                                     f"cfg5 recipe sample: 128 cams / {n_points} points / {10 * n_points} obs, refine_intrinsics=True, bounds")
     parity["scipy"] = {k: base[k] for k in ("seconds", "nfev", "status", "cost", "final_rms_px")}
     return parity
 
@@ -450,6 +453,7 @@ def _run(argv):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--devices", default="", help="in-process ranks: device ordinal of every rank (default 0..N-1)")
+    ap.add_argument("--cfg5-sample-points", type=int, default=10_000, help="points of the cfg5-recipe parity sample (10 observations each)")
     ap.add_argument("--xchg", choices=("auto", "rccl", "direct"), default="auto",
                     help="in-process ranks: RCCL communicator (default for distinct devices) or the library's peer-to-peer device group")
     args = ap.parse_args(argv)
@@ -550,7 +554,7 @@ def _run(argv):
                 a = measure(name, args.steps, args.warmup, device_id=local_rank, solve_kw={})
                 also[name] = _also_block(a, name)
                 if name == "cfg5" and not args.no_cpu:
-                    also[name]["parity"] = cfg5_sample_parity(device_id=local_rank)
+                    also[name]["parity"] = cfg5_sample_parity(device_id=local_rank, n_points=args.cfg5_sample_points)
             except Exception as exc:
                 also.setdefault(name, {})["error"] = repr(exc)
     if also:

@@ -466,6 +466,117 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   if (bad) flags[0] = 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_build_cs: the build pass over CAMERA-SORTED super-chunks.  k_build adds an observation's share of U_c, g_c with nc (nc + 3) / 2 FP64 LDS
+// atomics (27 / 54 per observation: ~28 clocks per wave instruction, 40 of the 90 us of the pass on cfg4, over half of it for nine-parameter
+// cameras).  Here a workgroup takes a SUPER-CHUNK — a run of consecutive chunks, i.e. of whole points: up to CS_MAX_OBS observations and
+// CS_MAX_PTS points — whose observations cba_create has laid out a second time sorted by camera.  A thread walks R = ceil(n / 256) CONSECUTIVE
+// observations of that order: they belong to one camera (at most a few), so U_c, g_c accumulate in REGISTERS and go to the workgroup's LDS copy
+// once per camera change: ~2 atomics per observation instead of 27.  What the point order gave for free now costs atomics: V_p, g_p (9 values per
+// observation) are added to per-point LDS slots of the super-chunk and written out once — 11 atomics per observation instead of 27 (19 instead of 54).
+// Same outputs as k_build (V, g point part, per-workgroup partials of the packed camera blocks, cost partials, flags), same arithmetic per
+// observation; the order of the sums differs, as it does between two runs of k_build.
+constexpr int CS_MAX_OBS = 3072;   // observations per super-chunk: R <= 12 per thread
+constexpr int CS_MAX_PTS = 320;    // points per super-chunk (9 + 3 doubles of LDS each)
+struct CsPlan {
+  const double* u;        // [N] observations in super-chunk / camera order
+  const double* v;
+  const int* cam;
+  const int* ptl;         // point index local to the super-chunk
+  const int* obs_start;   // [n_sc + 1]
+  const int* pt_first;    // [n_sc]
+  const int* pt_count;    // [n_sc]
+  int n_sc;
+};
+template <int NC, bool CAMG = false>
+__global__ void __launch_bounds__(BLOCK)
+k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams, int loss, double f_scale,
+           double* __restrict__ Vblk, double* __restrict__ gvec, double* __restrict__ partialU, double* __restrict__ partial_cost,
+           int* __restrict__ flags, const double* __restrict__ skip) {
+  using UP = UPack<NC>;
+  if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_tab = sh;
+  double* sh_U = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);
+  double* sh_vg = sh_U + n_cams * UP::STRIDE;        // [9][CS_MAX_PTS]
+  double* sh_x = sh_vg + 9 * CS_MAX_PTS;             // [3][CS_MAX_PTS]
+  double* sh_red = sh_x + 3 * CS_MAX_PTS;
+  if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
+  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
+  const double* px = xvec + lay.ncp_pad;
+  double* gp = gvec + lay.ncp_pad;
+  double cost = 0.0;
+  bool bad = false;
+  for (int s = blockIdx.x; s < cs.n_sc; s += gridDim.x) {
+    const int o0 = cs.obs_start[s], o1 = cs.obs_start[s + 1], p0 = cs.pt_first[s], npts = cs.pt_count[s];
+    __syncthreads();  // the previous super-chunk's sums have been written out (and, first pass, the table / U zeroing is done)
+    for (int i = threadIdx.x; i < 9 * CS_MAX_PTS; i += BLOCK) sh_vg[i] = 0.0;
+    for (int i = threadIdx.x; i < npts; i += BLOCK) {
+      sh_x[i] = px[p0 + i]; sh_x[CS_MAX_PTS + i] = px[lay.Ppad + p0 + i]; sh_x[2 * CS_MAX_PTS + i] = px[2 * lay.Ppad + p0 + i];
+    }
+    __syncthreads();
+    const int R = (o1 - o0 + BLOCK - 1) / BLOCK;
+    const int j0 = o0 + (int)threadIdx.x * R, j1 = min(j0 + R, o1);
+    double acc[UP::STRIDE];
+#pragma unroll
+    for (int q = 0; q < UP::STRIDE; ++q) acc[q] = 0.0;
+    int cur_cam = -1, cur_np = 0;
+    auto flush = [&]() {
+      if (cur_cam < 0) return;
+      double* Uc = sh_U + cur_cam * UP::STRIDE;
+#pragma unroll
+      for (int r = 0; r < NC; ++r) {
+        if (r < cur_np) {
+#pragma unroll
+          for (int c = r; c < NC; ++c)
+            if (c < cur_np) lds_add(&Uc[UP::idx(r, c)], acc[UP::idx(r, c)]);
+          lds_add(&Uc[UP::TRI + r], acc[UP::TRI + r]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < UP::STRIDE; ++q) acc[q] = 0.0;
+    };
+    for (int j = j0; j < j1; ++j) {
+      const int cam = cs.cam[j], pl = cs.ptl[j];
+      const double u = cs.u[j], v = cs.v[j];
+      if (cam != cur_cam) { flush(); cur_cam = cam; cur_np = (int)cam_of<CAMG>(sh_tab, tab, cam).nparams; }
+      double e[2], A[2][MAX_NC], B[2][3];
+      cost += obs_linearize<NC>(cam_of<CAMG>(sh_tab, tab, cam), sh_x[pl], sh_x[CS_MAX_PTS + pl], sh_x[2 * CS_MAX_PTS + pl], u, v, loss, f_scale, e, A, B);
+      if (!isfinite(e[0] + e[1])) bad = true;
+#pragma unroll
+      for (int r = 0; r < NC; ++r) {
+#pragma unroll
+        for (int c = r; c < NC; ++c) acc[UP::idx(r, c)] = fma(A[1][r], A[1][c], fma(A[0][r], A[0][c], acc[UP::idx(r, c)]));
+        acc[UP::TRI + r] = fma(A[1][r], e[1], fma(A[0][r], e[0], acc[UP::TRI + r]));
+      }
+      lds_add(&sh_vg[0 * CS_MAX_PTS + pl], B[0][0] * B[0][0] + B[1][0] * B[1][0]);
+      lds_add(&sh_vg[1 * CS_MAX_PTS + pl], B[0][0] * B[0][1] + B[1][0] * B[1][1]);
+      lds_add(&sh_vg[2 * CS_MAX_PTS + pl], B[0][0] * B[0][2] + B[1][0] * B[1][2]);
+      lds_add(&sh_vg[3 * CS_MAX_PTS + pl], B[0][1] * B[0][1] + B[1][1] * B[1][1]);
+      lds_add(&sh_vg[4 * CS_MAX_PTS + pl], B[0][1] * B[0][2] + B[1][1] * B[1][2]);
+      lds_add(&sh_vg[5 * CS_MAX_PTS + pl], B[0][2] * B[0][2] + B[1][2] * B[1][2]);
+      lds_add(&sh_vg[6 * CS_MAX_PTS + pl], B[0][0] * e[0] + B[1][0] * e[1]);
+      lds_add(&sh_vg[7 * CS_MAX_PTS + pl], B[0][1] * e[0] + B[1][1] * e[1]);
+      lds_add(&sh_vg[8 * CS_MAX_PTS + pl], B[0][2] * e[0] + B[1][2] * e[1]);
+    }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < npts; i += BLOCK) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Vblk[(long)q * lay.Ppad + p0 + i] = sh_vg[q * CS_MAX_PTS + i];
+      gp[p0 + i] = sh_vg[6 * CS_MAX_PTS + i];
+      gp[lay.Ppad + p0 + i] = sh_vg[7 * CS_MAX_PTS + i];
+      gp[2 * lay.Ppad + p0 + i] = sh_vg[8 * CS_MAX_PTS + i];
+    }
+  }
+  __syncthreads();
+  double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
+  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
+  const double tot = block_sum(cost, sh_red);
+  if (threadIdx.x == 0) partial_cost[blockIdx.x] = tot;
+  if (bad) flags[0] = 1;
+}
+
 // unpack the reduced camera blocks: gradient -> gvec camera part
 template <int NC>
 __global__ void k_unpack_camera_grad(const double* __restrict__ Upacked, const int* __restrict__ cam_off,

@@ -100,6 +100,7 @@ struct cba_problem {
   long long* chol_trace = nullptr;  // CBA_CHOL_TRACE=1: phase stamps of k_chol_step (tools/chol_trace.py)
   int ldw = 0;             // row stride of the Cholesky work matrix Lbuf (multiple of 4 doubles)
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
+  CsPlan cs{};              // camera-sorted super-chunks of the build pass (k_build_cs); cs.n_sc == 0: k_build (CBA_BUILD_CS=0, deterministic sums, fragments)
   bool tab_global = false;  // the per-observation kernels read the camera table from global memory (CAMG variants): its LDS copy would not fit
   int det_m = 0;  // cba_options.deterministic: tasks per thread of the fixed-order camera sums (3, 5 or 8; 0: atomics)
   DetPlan det{nullptr, nullptr};
@@ -582,6 +583,11 @@ template <int NC> static bool build_camg(const cba_problem* p) {
   // (a second workgroup per CU when the table is what keeps it off; no choice at all when table + accumulators exceed the LDS)
   return !p->det_m && ((with_tab > 80 * 1024 && lds_build_camg<NC>(p) <= 80 * 1024) || with_tab > 160 * 1024);
 }
+template <int NC> static size_t lds_build_cs(const cba_problem* p, bool camg) {
+  return ((camg ? 0 : (size_t)p->C * CAMTAB_LDS) + (size_t)p->C * UPack<NC>::STRIDE + 12 * CS_MAX_PTS + 8) * 8;
+}
+// k_build_cs keeps the camera table in LDS while that leaves room for two workgroups per CU
+template <int NC> static bool build_cs_camg(const cba_problem* p) { return p->tab_global || lds_build_cs<NC>(p, false) > 80 * 1024; }
 template <int NC> static size_t lds_build(const cba_problem* p) {
   if (build_camg<NC>(p)) return lds_build_camg<NC>(p);
   if (p->det_m)  // parking area of the fixed-order sums instead of the packed blocks, + the chunk's camera order (ints)
@@ -832,6 +838,10 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_cost<true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<false, true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<true, true>, lds_cost(p)))) return rc;
+  if (p->cs.n_sc) {
+    if (lds_build_cs<NC>(p, build_cs_camg<NC>(p)) > 160 * 1024) p->cs.n_sc = 0;  // too many cameras for its LDS copy of the blocks: k_build
+    else if ((rc = build_cs_camg<NC>(p) ? allow_lds(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)) : allow_lds(k_build_cs<NC, false>, lds_build_cs<NC>(p, false)))) return rc;
+  }
   if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
   if ((rc = allow_lds(k_build<NC, 0, true>, lds_build<NC>(p)))) return rc;
   if (p->det_m) {
@@ -1057,6 +1067,51 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
       if (hps[hpt[hcs[q]] + 1] - hps[hpt[hcs[q]]] > CHUNK) hcp[2 * q + 1] = -1;  // fragment of a point larger than a chunk
     }
     TRY(dev_upload(p, &p->chunk_pts, hcp));
+    // camera-sorted super-chunks for k_build_cs: consecutive chunks while observations <= CS_MAX_OBS and points <= CS_MAX_PTS, their observations
+    // a second time in (super-chunk, camera, point) order.  Not for the fixed-order sums (their own per-chunk order) nor with fragments of
+    // points larger than a chunk (those add to V / g by global atomics in k_build).
+    const char* cs_env = std::getenv("CBA_BUILD_CS");
+    bool cs_ok = !(opt && opt->deterministic) && !(cs_env && cs_env[0] == '0') && nch > 0;
+    for (int64_t q = 0; q < nch && cs_ok; ++q)
+      if (hcp[2 * q + 1] < 0 || hcp[2 * q + 1] > CS_MAX_PTS) cs_ok = false;
+    if (cs_ok) {
+      std::vector<int> sc_chunk{0}, sc_obs{0}, sc_p0, sc_np;
+      for (int64_t q = 0; q < nch;) {
+        int64_t e = q + 1;
+        while (e < nch && hcs[e + 1] - hcs[q] <= CS_MAX_OBS && hcp[2 * e] + hcp[2 * e + 1] - hcp[2 * q] <= CS_MAX_PTS) ++e;
+        sc_chunk.push_back((int)e); sc_obs.push_back(hcs[e]);
+        sc_p0.push_back(hcp[2 * q]); sc_np.push_back(hcp[2 * (e - 1)] + hcp[2 * (e - 1) + 1] - hcp[2 * q]);
+        q = e;
+      }
+      const int n_sc = (int)sc_p0.size();
+      std::vector<double> cu(p->N), cv(p->N);
+      std::vector<int> ccam(p->N), cptl(p->N);
+      auto fill = [&](int s0, int s1) {
+        std::vector<int> start((size_t)p->C + 1);
+        for (int sidx = s0; sidx < s1; ++sidx) {
+          const int o0 = sc_obs[sidx], o1 = sc_obs[sidx + 1];
+          std::fill(start.begin(), start.end(), 0);
+          for (int i = o0; i < o1; ++i) start[(size_t)hcam[i] + 1]++;
+          for (int c = 0; c < p->C; ++c) start[(size_t)c + 1] += start[c];
+          for (int i = o0; i < o1; ++i) {  // stable: point order inside a camera
+            const int dst = o0 + start[hcam[i]]++;
+            cu[dst] = hu[i]; cv[dst] = hv[i]; ccam[dst] = hcam[i]; cptl[dst] = hpt[i] - sc_p0[sidx];
+          }
+        }
+      };
+      {
+        const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n_sc / 64));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(fill, (int)((int64_t)n_sc * t / nth), (int)((int64_t)n_sc * (t + 1) / nth));
+        fill(0, (int)((int64_t)n_sc / nth));
+        for (auto& th : pool) th.join();
+      }
+      double *dcu = nullptr, *dcv = nullptr;
+      int *dcc = nullptr, *dcp = nullptr, *dso = nullptr, *dp0 = nullptr, *dnp = nullptr;
+      TRY(dev_upload(p, &dcu, cu)); TRY(dev_upload(p, &dcv, cv)); TRY(dev_upload(p, &dcc, ccam)); TRY(dev_upload(p, &dcp, cptl));
+      TRY(dev_upload(p, &dso, sc_obs)); TRY(dev_upload(p, &dp0, sc_p0)); TRY(dev_upload(p, &dnp, sc_np));
+      p->cs = CsPlan{dcu, dcv, dcc, dcp, dso, dp0, dnp, n_sc};
+    }
   }
   if (p->n_heavy) {
     TRY(dev_upload(p, &p->heavy_pts, heavy)); TRY(dev_upload(p, &p->heavy_frag, heavy_frag));
@@ -1173,7 +1228,11 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
   o->schur_wide = (p->schur_reg && p->schur_wide) ? 1 : 0;
-  o->build_camg = ((p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p)) ? 1 : 0) | (p->tab_global ? 2 : 0);
+  {
+    const bool cs = p->cs.n_sc && !p->det_m && !p->n_heavy;
+    const bool camg = cs ? (p->nct == 6 ? build_cs_camg<6>(p) : build_cs_camg<9>(p)) : (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p));
+    o->build_camg = (camg ? 1 : 0) | (p->tab_global ? 2 : 0) | (cs ? 4 : 0);
+  }
   return CBA_OK;
 }
 
@@ -1265,6 +1324,13 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
                          p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
                          V, g, p->partial, p->partial1, p->flags + flag_slot, skip, p->det);
     };
+    if (p->cs.n_sc && !p->det_m && !p->n_heavy) {  // camera-sorted super-chunks: the camera blocks accumulate in registers
+      auto launch_cs = [&](auto kernel, size_t lds) {
+        hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds, p->stream, p->cs, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
+                           V, g, p->partial, p->partial1, p->flags + flag_slot, skip);
+      };
+      if (build_cs_camg<NC>(p)) launch_cs(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)); else launch_cs(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
+    } else
     switch (p->det_m) {  // deterministic: fixed-order camera sums (k_build<NC, tasks per thread>)
       case 3: launch_build(k_build<NC, 3>); break;
       case 5: launch_build(k_build<NC, 5>); break;

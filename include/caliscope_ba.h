@@ -303,7 +303,9 @@ typedef struct {
                                table is what keeps a second workgroup off the CU, ~100+ nine-parameter cameras; CBA_BUILD_CAMG=0/1 forces);
                                bit 1: EVERY per-observation kernel does (the LDS copy of the table would not fit: beyond ~230 six- / ~170
                                nine-parameter cameras; CBA_CAMTAB_GLOBAL=0/1 forces).  The camera count is then bounded by the per-camera
-                               accumulators of the linearisation: ~650 six- / ~320 nine-parameter cameras. */
+                               accumulators of the linearisation: ~650 six- / ~320 nine-parameter cameras;
+                               bit 2: the linearisation runs over camera-sorted super-chunks (k_build_cs: camera blocks accumulated in registers,
+                               the default; CBA_BUILD_CS=0, deterministic sums or fragments of very large points fall back to k_build). */
 } cba_info;
 int cba_get_info(cba_problem* p, cba_info* out);
 

@@ -88,6 +88,7 @@ def test_evaluation_parity(name):
 @pytest.mark.parametrize("camg", ["0", "1"])
 @pytest.mark.parametrize("name", ["global_atomics_C24", "refine_global_C20", "huber_outliers_C8"])
 def test_build_kernel_variants(name, camg, monkeypatch):
+    monkeypatch.setenv("CBA_BUILD_CS", "0")  # (k_build's own switch; the camera-sorted kernel has its own rule, exercised by CBA_CAMTAB_GLOBAL below)
     monkeypatch.setenv("CBA_BUILD_CAMG", camg)
     _check_evaluation(name, expect_camg=int(camg))
     _check_step(name, expect_camg=int(camg))
@@ -102,6 +103,31 @@ def test_camera_table_through_the_vector_cache(name, monkeypatch):
     _check_step(name, expect_camg=3)
 
 
+def _expect_build_variant(hip, name, expect_camg):
+    """cba_info.build_camg: bits 0 / 1 = camera table through the vector cache (linearisation / every kernel), bit 2 = camera-sorted build
+    (k_build_cs, the default; CBA_BUILD_CS=0 selects k_build).  With k_build_cs bit 0 follows ITS rule (table in LDS while two workgroups fit)."""
+    info = hip.info()["build_camg"]
+    cs_on = os.environ.get("CBA_BUILD_CS", "1") != "0"
+    assert bool(info & 4) == cs_on, info
+    if expect_camg is not None:
+        if not cs_on or (expect_camg & 2):
+            assert (info & 3) == expect_camg, info
+    elif not cs_on:
+        assert (info & 3) == EXPECT_CAMG.get(name, 0), info
+    else:
+        assert (info & 2) == (EXPECT_CAMG.get(name, 0) & 2), info
+
+
+# the camera-sorted build (k_build_cs, default) against k_build (CBA_BUILD_CS=0): every other test of this file runs the default; these run the
+# point-ordered kernel and its CAMG variant so that both stay compared with the oracle
+@pytest.mark.parametrize("name", ["pinhole_locked_C8", "refine_global_C20", "huber_outliers_C8", "global_atomics_C24", "refine_global_C128"])
+def test_point_ordered_build_kernel(name, monkeypatch):
+    monkeypatch.setenv("CBA_BUILD_CS", "0")
+    _check_evaluation(name)
+    if name != "refine_global_C128":
+        _check_step(name)
+
+
 def _check_evaluation(name, expect_camg=None):
     from oracle.residuals import joint_jacobian, joint_residuals
     from scipy.optimize._lsq.common import scale_for_robust_loss_function
@@ -109,7 +135,7 @@ def _check_evaluation(name, expect_camg=None):
 
     sc, par, x0, loss, fs = _case(name)
     hip, _ = _engines(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss, fs)
-    assert hip.info()["build_camg"] == (EXPECT_CAMG.get(name, 0) if expect_camg is None else expect_camg)
+    _expect_build_variant(hip, name, expect_camg)
     r_ref = joint_residuals(x0, par, sc.camera_indices, sc.image_coords, sc.obj_indices)
     r, cost = hip.residuals(x0)
     assert _rel(r, r_ref) < 1e-12
@@ -202,7 +228,7 @@ def test_step_parity(name):
 def _check_step(name, expect_camg=None):
     sc, par, x0, loss, fs = _case(name)
     hip, ora = _engines(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss, fs)
-    assert hip.info()["build_camg"] == (EXPECT_CAMG.get(name, 0) if expect_camg is None else expect_camg)
+    _expect_build_variant(hip, name, expect_camg)
     c_h, c_o = hip.begin(x0), ora.begin(x0)
     assert abs(c_h - c_o) <= 1e-13 * c_o
     lh, lo = hip.linearize(), ora.linearize()

@@ -91,6 +91,10 @@ if __name__ == "__main__":
         out["cfg3_converged"] = run("cfg3", default)
         out["cfg3_tight"] = run("cfg3", default, ref_from=("cfg3", json.dumps(default, sort_keys=True)), tight_gpu=True, polish=True)
         out["cfg3_tight"]["note"] = "gpu at 1e-13 against scipy at its default-tolerance stopping point"
+    if "--skip-cfg5" not in sys.argv:  # SURVEY.md 8d's cfg5 sample: 128 cams / 100k points / 1M obs, free intrinsics + bounds (~96 scipy evaluations)
+        t0 = time.perf_counter()
+        out["cfg5_sample_1M"] = bench.cfg5_sample_parity(n_points=100_000)
+        out["cfg5_sample_1M"]["wall_seconds"] = round(time.perf_counter() - t0, 1)
     path = argv[0] if argv else "profiles/parity_r03.json"
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
