@@ -469,15 +469,15 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
 // ------------------------------------------------------------------------------------------------
 // k_build_cs: the build pass over CAMERA-SORTED super-chunks.  k_build adds an observation's share of U_c, g_c with nc (nc + 3) / 2 FP64 LDS
 // atomics (27 / 54 per observation: ~28 clocks per wave instruction, 40 of the 90 us of the pass on cfg4, over half of it for nine-parameter
-// cameras).  Here a workgroup takes a SUPER-CHUNK — a run of consecutive chunks, i.e. of whole points: up to CS_MAX_OBS observations and
-// CS_MAX_PTS points — whose observations cba_create has laid out a second time sorted by camera.  A thread walks R = ceil(n / 256) CONSECUTIVE
+// cameras).  Here a workgroup takes a SUPER-CHUNK — a run of consecutive chunks, i.e. of whole points; cba_create sizes them so that every
+// workgroup gets the same number of them (~2000 observations for six-, ~4000 for nine-parameter cameras, at most CS_MAX_PTS points) — whose
+// observations it has laid out a second time sorted by camera.  A thread walks R = ceil(n / 256) CONSECUTIVE
 // observations of that order: they belong to one camera (at most a few), so U_c, g_c accumulate in REGISTERS and go to the workgroup's LDS copy
 // once per camera change: ~2 atomics per observation instead of 27.  What the point order gave for free now costs atomics: V_p, g_p (9 values per
 // observation) are added to per-point LDS slots of the super-chunk and written out once — 11 atomics per observation instead of 27 (19 instead of 54).
 // Same outputs as k_build (V, g point part, per-workgroup partials of the packed camera blocks, cost partials, flags), same arithmetic per
 // observation; the order of the sums differs, as it does between two runs of k_build.
-constexpr int CS_MAX_OBS = 3072;   // observations per super-chunk: R <= 12 per thread
-constexpr int CS_MAX_PTS = 320;    // points per super-chunk (9 + 3 doubles of LDS each)
+constexpr int CS_MAX_PTS = 512;    // points per super-chunk at most (9 + 3 doubles of LDS each; the launch sizes its LDS for the largest super-chunk: CsPlan::pmax)
 struct CsPlan {
   const double* u;        // [N] observations in super-chunk / camera order
   const double* v;
@@ -487,6 +487,7 @@ struct CsPlan {
   const int* pt_first;    // [n_sc]
   const int* pt_count;    // [n_sc]
   int n_sc;
+  int pmax;               // points of the largest super-chunk, rounded up to a multiple of 32: row stride of the per-point LDS arrays
 };
 template <int NC, bool CAMG = false>
 __global__ void __launch_bounds__(BLOCK)
@@ -498,9 +499,10 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
   double* sh_U = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);
-  double* sh_vg = sh_U + n_cams * UP::STRIDE;        // [9][CS_MAX_PTS]
-  double* sh_x = sh_vg + 9 * CS_MAX_PTS;             // [3][CS_MAX_PTS]
-  double* sh_red = sh_x + 3 * CS_MAX_PTS;
+  const int PM = cs.pmax;
+  double* sh_vg = sh_U + n_cams * UP::STRIDE;        // [9][PM]
+  double* sh_x = sh_vg + 9 * PM;                     // [3][PM]
+  double* sh_red = sh_x + 3 * PM;
   if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
   const double* px = xvec + lay.ncp_pad;
@@ -510,9 +512,9 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
   for (int s = blockIdx.x; s < cs.n_sc; s += gridDim.x) {
     const int o0 = cs.obs_start[s], o1 = cs.obs_start[s + 1], p0 = cs.pt_first[s], npts = cs.pt_count[s];
     __syncthreads();  // the previous super-chunk's sums have been written out (and, first pass, the table / U zeroing is done)
-    for (int i = threadIdx.x; i < 9 * CS_MAX_PTS; i += BLOCK) sh_vg[i] = 0.0;
+    for (int i = threadIdx.x; i < 9 * PM; i += BLOCK) sh_vg[i] = 0.0;
     for (int i = threadIdx.x; i < npts; i += BLOCK) {
-      sh_x[i] = px[p0 + i]; sh_x[CS_MAX_PTS + i] = px[lay.Ppad + p0 + i]; sh_x[2 * CS_MAX_PTS + i] = px[2 * lay.Ppad + p0 + i];
+      sh_x[i] = px[p0 + i]; sh_x[PM + i] = px[lay.Ppad + p0 + i]; sh_x[2 * PM + i] = px[2 * lay.Ppad + p0 + i];
     }
     __syncthreads();
     const int R = (o1 - o0 + BLOCK - 1) / BLOCK;
@@ -541,7 +543,7 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
       const double u = cs.u[j], v = cs.v[j];
       if (cam != cur_cam) { flush(); cur_cam = cam; cur_np = (int)cam_of<CAMG>(sh_tab, tab, cam).nparams; }
       double e[2], A[2][MAX_NC], B[2][3];
-      cost += obs_linearize<NC>(cam_of<CAMG>(sh_tab, tab, cam), sh_x[pl], sh_x[CS_MAX_PTS + pl], sh_x[2 * CS_MAX_PTS + pl], u, v, loss, f_scale, e, A, B);
+      cost += obs_linearize<NC>(cam_of<CAMG>(sh_tab, tab, cam), sh_x[pl], sh_x[PM + pl], sh_x[2 * PM + pl], u, v, loss, f_scale, e, A, B);
       if (!isfinite(e[0] + e[1])) bad = true;
 #pragma unroll
       for (int r = 0; r < NC; ++r) {
@@ -549,24 +551,24 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
         for (int c = r; c < NC; ++c) acc[UP::idx(r, c)] = fma(A[1][r], A[1][c], fma(A[0][r], A[0][c], acc[UP::idx(r, c)]));
         acc[UP::TRI + r] = fma(A[1][r], e[1], fma(A[0][r], e[0], acc[UP::TRI + r]));
       }
-      lds_add(&sh_vg[0 * CS_MAX_PTS + pl], B[0][0] * B[0][0] + B[1][0] * B[1][0]);
-      lds_add(&sh_vg[1 * CS_MAX_PTS + pl], B[0][0] * B[0][1] + B[1][0] * B[1][1]);
-      lds_add(&sh_vg[2 * CS_MAX_PTS + pl], B[0][0] * B[0][2] + B[1][0] * B[1][2]);
-      lds_add(&sh_vg[3 * CS_MAX_PTS + pl], B[0][1] * B[0][1] + B[1][1] * B[1][1]);
-      lds_add(&sh_vg[4 * CS_MAX_PTS + pl], B[0][1] * B[0][2] + B[1][1] * B[1][2]);
-      lds_add(&sh_vg[5 * CS_MAX_PTS + pl], B[0][2] * B[0][2] + B[1][2] * B[1][2]);
-      lds_add(&sh_vg[6 * CS_MAX_PTS + pl], B[0][0] * e[0] + B[1][0] * e[1]);
-      lds_add(&sh_vg[7 * CS_MAX_PTS + pl], B[0][1] * e[0] + B[1][1] * e[1]);
-      lds_add(&sh_vg[8 * CS_MAX_PTS + pl], B[0][2] * e[0] + B[1][2] * e[1]);
+      lds_add(&sh_vg[0 * PM + pl], B[0][0] * B[0][0] + B[1][0] * B[1][0]);
+      lds_add(&sh_vg[1 * PM + pl], B[0][0] * B[0][1] + B[1][0] * B[1][1]);
+      lds_add(&sh_vg[2 * PM + pl], B[0][0] * B[0][2] + B[1][0] * B[1][2]);
+      lds_add(&sh_vg[3 * PM + pl], B[0][1] * B[0][1] + B[1][1] * B[1][1]);
+      lds_add(&sh_vg[4 * PM + pl], B[0][1] * B[0][2] + B[1][1] * B[1][2]);
+      lds_add(&sh_vg[5 * PM + pl], B[0][2] * B[0][2] + B[1][2] * B[1][2]);
+      lds_add(&sh_vg[6 * PM + pl], B[0][0] * e[0] + B[1][0] * e[1]);
+      lds_add(&sh_vg[7 * PM + pl], B[0][1] * e[0] + B[1][1] * e[1]);
+      lds_add(&sh_vg[8 * PM + pl], B[0][2] * e[0] + B[1][2] * e[1]);
     }
     flush();
     __syncthreads();
     for (int i = threadIdx.x; i < npts; i += BLOCK) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) Vblk[(long)q * lay.Ppad + p0 + i] = sh_vg[q * CS_MAX_PTS + i];
-      gp[p0 + i] = sh_vg[6 * CS_MAX_PTS + i];
-      gp[lay.Ppad + p0 + i] = sh_vg[7 * CS_MAX_PTS + i];
-      gp[2 * lay.Ppad + p0 + i] = sh_vg[8 * CS_MAX_PTS + i];
+      for (int q = 0; q < 6; ++q) Vblk[(long)q * lay.Ppad + p0 + i] = sh_vg[q * PM + i];
+      gp[p0 + i] = sh_vg[6 * PM + i];
+      gp[lay.Ppad + p0 + i] = sh_vg[7 * PM + i];
+      gp[2 * lay.Ppad + p0 + i] = sh_vg[8 * PM + i];
     }
   }
   __syncthreads();

@@ -584,7 +584,7 @@ template <int NC> static bool build_camg(const cba_problem* p) {
   return !p->det_m && ((with_tab > 80 * 1024 && lds_build_camg<NC>(p) <= 80 * 1024) || with_tab > 160 * 1024);
 }
 template <int NC> static size_t lds_build_cs(const cba_problem* p, bool camg) {
-  return ((camg ? 0 : (size_t)p->C * CAMTAB_LDS) + (size_t)p->C * UPack<NC>::STRIDE + 12 * CS_MAX_PTS + 8) * 8;
+  return ((camg ? 0 : (size_t)p->C * CAMTAB_LDS) + (size_t)p->C * UPack<NC>::STRIDE + 12 * (size_t)p->cs.pmax + 8) * 8;
 }
 // k_build_cs keeps the camera table in LDS while that leaves room for two workgroups per CU
 template <int NC> static bool build_cs_camg(const cba_problem* p) { return p->tab_global || lds_build_cs<NC>(p, false) > 80 * 1024; }
@@ -1075,12 +1075,21 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     for (int64_t q = 0; q < nch && cs_ok; ++q)
       if (hcp[2 * q + 1] < 0 || hcp[2 * q + 1] > CS_MAX_PTS) cs_ok = false;
     if (cs_ok) {
+      // Size: every workgroup of the launch (p->grid persistent ones) should get the same number of super-chunks — with 1.3 per workgroup a
+      // quarter of the pass is a tail.  Cap ~2000 observations for six-parameter cameras (two workgroups per CU), ~4000 for nine-parameter
+      // ones (54 values per camera change: longer runs pay; measured on cfg4 / cfg5: 59 / 72 / 120 us at 2048 / 3072 / 4096, 545 / 530 / 508 us).
+      const int64_t s_cap = (nct == 9) ? 4096 : 2048;
+      const int64_t wgs = std::max(1, p->grid);  // the persistent workgroups of the launch
+      const int64_t rounds = std::max<int64_t>(1, (p->N + wgs * s_cap - 1) / (wgs * s_cap));
+      const int64_t s_target = std::max<int64_t>(CHUNK, (p->N + wgs * rounds - 1) / (wgs * rounds));
       std::vector<int> sc_chunk{0}, sc_obs{0}, sc_p0, sc_np;
+      int pmax = 0;
       for (int64_t q = 0; q < nch;) {
         int64_t e = q + 1;
-        while (e < nch && hcs[e + 1] - hcs[q] <= CS_MAX_OBS && hcp[2 * e] + hcp[2 * e + 1] - hcp[2 * q] <= CS_MAX_PTS) ++e;
+        while (e < nch && hcs[e + 1] - hcs[q] <= s_target && hcp[2 * e] + hcp[2 * e + 1] - hcp[2 * q] <= CS_MAX_PTS) ++e;
         sc_chunk.push_back((int)e); sc_obs.push_back(hcs[e]);
         sc_p0.push_back(hcp[2 * q]); sc_np.push_back(hcp[2 * (e - 1)] + hcp[2 * (e - 1) + 1] - hcp[2 * q]);
+        pmax = std::max(pmax, sc_np.back());
         q = e;
       }
       const int n_sc = (int)sc_p0.size();
@@ -1110,7 +1119,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
       int *dcc = nullptr, *dcp = nullptr, *dso = nullptr, *dp0 = nullptr, *dnp = nullptr;
       TRY(dev_upload(p, &dcu, cu)); TRY(dev_upload(p, &dcv, cv)); TRY(dev_upload(p, &dcc, ccam)); TRY(dev_upload(p, &dcp, cptl));
       TRY(dev_upload(p, &dso, sc_obs)); TRY(dev_upload(p, &dp0, sc_p0)); TRY(dev_upload(p, &dnp, sc_np));
-      p->cs = CsPlan{dcu, dcv, dcc, dcp, dso, dp0, dnp, n_sc};
+      p->cs = CsPlan{dcu, dcv, dcc, dcp, dso, dp0, dnp, n_sc, (pmax + 31) / 32 * 32};
     }
   }
   if (p->n_heavy) {
