@@ -1527,7 +1527,8 @@ static int run_cholesky(cba_problem* p) {
     std::vector<long long> h((size_t)(nbk + 2) * 8);
     HIPCHK(hipMemcpyAsync(h.data(), p->chol_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
-    {  // k_chol_backward: start, prologue done, first block, second block, all blocks, last loads landed, solution stored
+    if (p->Tinv) fprintf(stderr, "chol apply: x = T y in one launch (k_chol_apply; CBA_CHOL_BACKWARD=subst traces the substitution)\n");
+    else {  // k_chol_backward: start, prologue done, first block, second block, all blocks, last loads landed, solution stored
       const long long* b = &h[(size_t)(nbk + 1) * 8];
       fprintf(stderr, "chol backward: prologue %.2f us, first block %.2f, second block %.2f, remaining %d blocks %.2f, tail wait %.2f, store %.2f | total %.2f us\n",
               (b[1] - b[0]) * 0.01, (b[2] - b[1]) * 0.01, (b[3] - b[2]) * 0.01, std::max(nbk - 2, 0), (b[4] - b[3]) * 0.01, (b[5] - b[4]) * 0.01, (b[6] - b[5]) * 0.01, (b[6] - b[0]) * 0.01);

@@ -32,8 +32,12 @@ class HipEngine:
     def __init__(self, problem: BAProblem, device_id: int = -1, max_blocks: int = 0, evaluation_only: bool = False,
                  deterministic: bool | None = None):
         """``evaluation_only``: residuals / costs only (``residuals``, ``begin``) — skips the Schur plan and the solver buffers.
-        ``deterministic`` (default: the environment variable ``CBA_DETERMINISTIC=1``): fixed-order sums everywhere, two solves
-        of the same problem return the same bits (as the reference's single-threaded scipy does); a few percent slower."""
+        ``deterministic`` (default: the environment variable ``CBA_DETERMINISTIC=1``): the per-camera sums of the linearisation and of the
+        Schur right-hand side are formed in a fixed order (the point-ordered k_build / k_tprep variants instead of the camera-sorted build), so
+        two solves of the same problem return the same bits, as the reference's single-threaded scipy does; ~15 % slower.  Limits, stated
+        rather than hidden: up to 227 cameras (``cba_create`` reports CBA_ERR_UNSUPPORTED beyond — it does not fall back silently), and
+        problems with constraint rows or heavy points (> 40 observations of one point) still add those few sums with FP64 atomics: they are
+        reproducible to rounding, not bit for bit."""
         import os
 
         if deterministic is None:
