@@ -321,6 +321,23 @@ def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear",
     x_cmp = gpu.x if x_gpu_solve is None else x_gpu_solve
     rms_cpu, rms_gpu = rms(res.x), rms(x_cmp)
     pos, ang = solution_parity(par, x_cmp, res.x)
+    # Whose distance is it?  Both solvers stop on ftol; scipy's LSMR steps are inexact, so it can stop well short of the minimum (the bounded
+    # cfg5 recipe: 120 evaluations, cost 4e-6 above).  The product started again from scipy's stopping point with tight tolerances ends at the
+    # minimum nearest to scipy's answer; the product started from x0 with the same tolerances must end at the SAME minimum.
+    tight = dict(ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=2000)
+    kw = dict(jac=None, bounds=par.bounds(), x_scale="jac", method="trf", loss=loss, f_scale=f_scale,
+              args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices), devices=[device_id])
+    near = least_squares(None, res.x, **kw, **tight)
+    mine = least_squares(None, x0, **kw, **tight)
+    engine_cache.clear()
+    polish = {
+        "what": "product at 1e-13 from scipy's stopping point (= the minimum nearest to scipy's answer) against the product at 1e-13 from x0",
+        "same_minimum": solution_parity(par, mine.x, near.x, detail=True),
+        "d_rms_px": rms(mine.x) - rms(near.x), "rel_cost": (float(mine.cost) - float(near.cost)) / float(near.cost),
+        "scipy_to_its_minimum": solution_parity(par, res.x, near.x, detail=True),
+        "rel_cost_scipy_above_minimum": (float(res.cost) - float(near.cost)) / float(near.cost),
+        "nfev": {"from_x0": int(mine.nfev), "from_scipy_x": int(near.nfev)},
+    }
     cost_gpu = 0.5 * float(np.sum(joint_residuals(x_cmp, par, sc.camera_indices, sc.image_coords, sc.obj_indices) ** 2)) if loss == "linear" else float(gpu.cost)
     base = {
         "value": round(sc.n_obs * iters / dt, 1), "unit": "obs/s", "cores": 1, "kind": "port",
@@ -340,6 +357,9 @@ def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear",
         "d_rms_px": rms_gpu - rms_cpu, "rel_cost": (cost_gpu - float(res.cost)) / float(res.cost),
         "aligned_pos": pos, "aligned_ang_rad": ang, "detail": solution_parity(par, x_cmp, res.x, detail=True),
         "within_north_star": bool(abs(rms_gpu - rms_cpu) <= 1e-4 and pos <= 1e-6 and ang <= 1e-6),
+        "polish": polish,
+        "same_minimum_within_north_star": bool(abs(polish["d_rms_px"]) <= 1e-4 and polish["same_minimum"]["aligned_pos"] <= 1e-6
+                                               and polish["same_minimum"]["aligned_ang_rad"] <= 1e-6),
         "value_ratio_gpu_end_to_end_over_cpu": round(sc.n_obs * gpu_iters / dt_gpu / (sc.n_obs * iters / dt), 1),
     }
     return base, parity

@@ -36,16 +36,43 @@ def test_roofline_block_from_timers():
     assert bench.roofline_from({**m, "timers": {}}) is None
 
 
+def _latest_bench_line():
+    files = sorted((ROOT / "profiles").glob("r[0-9][0-9]_end_bench.json"))
+    assert files, "no committed bench line under profiles/"
+    return files[-1].name, json.loads(files[-1].read_text().strip().splitlines()[-1])
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    line = (ROOT / "profiles" / "r01_end_bench.json").read_text().strip().splitlines()[-1]
-    d = json.loads(line)
+    """The newest end-of-round bench line under profiles/ (written by the round's last GPU run, tools/gpu_profile_run.sh) against the JSON contract
+    of the task: the driver's keys, the roofline and cpu_baseline objects, and — from round 3 on — the parity legs on BASELINE-sized inputs."""
+    name, d = _latest_bench_line()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["metric"] == "observations/sec per LM iteration" and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["config"]["workload"].startswith("cfg4")
+    assert d["metric"] == "observations/sec per LM iteration" and d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["scaling"] in ("strong", "weak") and d["n_gpus"] == 1 and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["workload"].startswith("cfg4") and "model" not in d["config"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"], key
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] == 1
     assert abs(d["value"] - d["config"]["n_obs_total"] * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    if name < "r03":
+        return
+    # round 3: the scipy leg runs on the headline's own arrays; cfg5 carries its roofline block and a parity sample of its recipe
+    for key in ("rccl_ranks", "comm_ms_per_step", "setup_ms", "parity"):
+        assert key in d, key
+    par = d["parity"]
+    assert "full size" in d["cpu_baseline"]["sample"] and "headline" in par["sample"]
+    for key in ("d_rms_px", "rel_cost", "aligned_pos", "aligned_ang_rad", "within_north_star", "detail", "gpu"):
+        assert key in par, key
+    assert abs(par["d_rms_px"]) <= 1e-4 and par["aligned_pos"] <= 1e-6 and par["aligned_ang_rad"] <= 1e-6 and par["within_north_star"] is True
+    for key in ("seconds_end_to_end", "setup_ms", "value_end_to_end"):
+        assert key in par["gpu"], key
+    c5 = d["also"]["cfg5"]
+    for key in ("bound", "achieved", "peak", "frac", "traffic", "kernels"):
+        assert key in c5["roofline"], key
+    assert "parity" in c5 and abs(c5["parity"]["d_rms_px"]) <= 1e-4 and c5["parity"]["aligned_pos"] <= 1e-6 and c5["parity"]["aligned_ang_rad"] <= 1e-6
+    assert "refine_intrinsics=True" in c5["parity"]["sample"]
