@@ -3082,6 +3082,7 @@ struct ConPlan {
   const int* heavy_pts;   // sorted heavy points (k_heavy_schur) and their per-camera sums W [n_heavy][ncp][3]
   const double* heavy_W;
   int n_heavy;
+  double* big;            // 9 doubles per component point (offset 9 comp_pt[k]): per-point scratch of the components that do not fit the LDS copy; else nullptr
 };
 
 __device__ __forceinline__ void con_geometry(const ConPlan& cp, int c, const double* __restrict__ px, VecLayout lay, double* unit,
@@ -3181,7 +3182,10 @@ k_con_jv(ConPlan cp, VecLayout lay, const double* __restrict__ v1, const double*
   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = 0.0;
 }
 
-constexpr int CON_MAX_POINTS = 256;  // points of one constraint component (one board in one frame)
+// Points of one constraint component whose per-point factors fit the workgroup's LDS copy (one board in one frame: tens).  A larger component — all
+// static markers of a room are ONE component, core/capture_volume.py:446-531 — keeps them in global scratch (ConPlan::big) instead: same code, the
+// pointers differ.
+constexpr int CON_LDS_POINTS = 256;
 
 // L^T x for the 3 x 3 factor in chol3's convention (reciprocal diagonal entries)
 __device__ __forceinline__ void chol3_lt_mul(const double* L, const double* x, double* y) {
@@ -3213,12 +3217,13 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
             const int* __restrict__ obs_cam, const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
             double* __restrict__ Sacc, double* __restrict__ bacc, int* __restrict__ flags) {
   constexpr int REC = SchurRec<NC>::HREC;
-  __shared__ double sh_L[CON_MAX_POINTS][6];
-  __shared__ double sh_y[CON_MAX_POINTS][3];
+  __shared__ double sh_Ly[CON_LDS_POINTS * 9];
   __shared__ double sh_piv;
   const int k = blockIdx.x;
   const int c0 = cp.comp_con[k], m = cp.comp_con[k + 1] - c0;
   const int p0 = cp.comp_pt[k], np = cp.comp_pt[k + 1] - p0;
+  double* pL = (np <= CON_LDS_POINTS) ? sh_Ly : cp.big + (long)p0 * 9;  // [np][6] factors, then [np][3] y
+  double* py = pL + (long)np * 6;
   double* M = cp.M + cp.comp_m[k];
   const int gw = ncp + 1;
   double* G = cp.G + (long)c0 * gw;
@@ -3233,8 +3238,8 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
     double y[3];
     chol3_fwd(L, g3, y);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) sh_L[lp][q] = L[q];
-    sh_y[lp][0] = y[0]; sh_y[lp][1] = y[1]; sh_y[lp][2] = y[2];
+    for (int q = 0; q < 6; ++q) pL[lp * 6 + q] = L[q];
+    py[lp * 3] = y[0]; py[lp * 3 + 1] = y[1]; py[lp * 3 + 2] = y[2];
   }
   __syncthreads();
   // 2. z for every (constraint, slot); rows of G zeroed
@@ -3243,7 +3248,7 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
     const double q = (s < 4) ? 0.25 : -0.25;
     const double j3[3] = {q * cp.u[c * 3], q * cp.u[c * 3 + 1], q * cp.u[c * 3 + 2]};
     double z[3];
-    chol3_fwd(sh_L[cp.lp[c * 8 + s]], j3, z);
+    chol3_fwd(pL + (long)cp.lp[c * 8 + s] * 6, j3, z);
     cp.z[(long)(c * 8 + s) * 3] = z[0]; cp.z[(long)(c * 8 + s) * 3 + 1] = z[1]; cp.z[(long)(c * 8 + s) * 3 + 2] = z[2];
   }
   for (long e = threadIdx.x; e < (long)m * gw; e += BLOCK) G[e] = 0.0;
@@ -3268,7 +3273,7 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
     double h = 0.0;
     for (int s = 0; s < 8; ++s) {
       const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
-      const double* y = sh_y[cp.lp[(c0 + c) * 8 + s]];
+      const double* y = py + (long)cp.lp[(c0 + c) * 8 + s] * 3;
       h += z[0] * y[0] + z[1] * y[1] + z[2] * y[2];
     }
     G[(long)c * gw + ncp] = h;
@@ -3339,12 +3344,13 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
 __global__ void __launch_bounds__(BLOCK)
 k_con_backsub(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vblk, const double* __restrict__ sinv,
               double* __restrict__ svec) {
-  __shared__ double sh_L[CON_MAX_POINTS][6];
-  __shared__ double sh_q[CON_MAX_POINTS][3];
+  __shared__ double sh_Lq[CON_LDS_POINTS * 9];
   __shared__ double sh_w;
   const int k = blockIdx.x;
   const int c0 = cp.comp_con[k], m = cp.comp_con[k + 1] - c0;
   const int p0 = cp.comp_pt[k], np = cp.comp_pt[k + 1] - p0;
+  double* pL = (np <= CON_LDS_POINTS) ? sh_Lq : cp.big + (long)p0 * 9;  // [np][6] factors, then [np][3] q (k_con_schur's layout)
+  double* pq = pL + (long)np * 6;
   const double* M = cp.M + cp.comp_m[k];
   double* u = cp.w + c0;
   const double* dp = sinv + lay.ncp_pad;
@@ -3357,15 +3363,15 @@ k_con_backsub(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ 
     double yq[3];
     chol3_lt_mul(L, d0, yq);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) sh_L[lp][q] = L[q];
-    sh_q[lp][0] = yq[0]; sh_q[lp][1] = yq[1]; sh_q[lp][2] = yq[2];
+    for (int q = 0; q < 6; ++q) pL[lp * 6 + q] = L[q];
+    pq[lp * 3] = yq[0]; pq[lp * 3 + 1] = yq[1]; pq[lp * 3 + 2] = yq[2];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < m; c += BLOCK) {
     double acc = 0.0;
     for (int s = 0; s < 8; ++s) {
       const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
-      const double* y = sh_q[cp.lp[(c0 + c) * 8 + s]];
+      const double* y = pq + (long)cp.lp[(c0 + c) * 8 + s] * 3;
       acc += z[0] * y[0] + z[1] * y[1] + z[2] * y[2];
     }
     u[c] = acc;
@@ -3387,20 +3393,20 @@ k_con_backsub(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ 
     __syncthreads();
   }
   // scatter: acc_p = sum_{(c, s) -> p} z w_c, then dp_p += L_p^-T acc_p
-  for (int lp = threadIdx.x; lp < np; lp += BLOCK) { sh_q[lp][0] = 0.0; sh_q[lp][1] = 0.0; sh_q[lp][2] = 0.0; }
+  for (int lp = threadIdx.x; lp < np; lp += BLOCK) { pq[lp * 3] = 0.0; pq[lp * 3 + 1] = 0.0; pq[lp * 3 + 2] = 0.0; }
   __syncthreads();
   for (int e = threadIdx.x; e < m * 8; e += BLOCK) {
     const int c = e / 8, s = e % 8;
     const double* z = cp.z + (long)((c0 + c) * 8 + s) * 3;
     const double w = u[c];
-    double* a = sh_q[cp.lp[(c0 + c) * 8 + s]];
+    double* a = pq + (long)cp.lp[(c0 + c) * 8 + s] * 3;  // (LDS or global: a flat atomic either way)
     lds_add(&a[0], z[0] * w); lds_add(&a[1], z[1] * w); lds_add(&a[2], z[2] * w);
   }
   __syncthreads();
   for (int lp = threadIdx.x; lp < np; lp += BLOCK) {
     const int p = cp.comp_pts[p0 + lp];
     double t[3];
-    chol3_bwd(sh_L[lp], sh_q[lp], t);
+    chol3_bwd(pL + lp * 6, pq + lp * 3, t);
     sp[p] += t[0]; sp[lay.Ppad + p] += t[1]; sp[2 * lay.Ppad + p] += t[2];
   }
 }

@@ -735,18 +735,14 @@ static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const 
   return CBA_OK;
 }
 
-// Plan of k_schur_reg2 (schur_plan.h builds it on the host; here: workgroup binding and upload).
+// Plan of the register kernels (schur_plan.h builds it on the host).  The dealing is ~1 us of host work per observation and needs nothing but the
+// sorted camera indices, so cba_create starts it on a thread of its own as soon as those exist (PlanTask) and does its uploads, the camera-sorted
+// copy and the allocations meanwhile; finish_reg2_tile_plan then binds the workgroups and uploads the plan.
 template <int NC, typename KCfg>
-static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, const std::vector<int>& hps,
-                                const std::vector<int>& cam_off, int max_blocks) {
-  const int G = p->G, g = p->gsz, C = p->C;
-  const int nT = p->n_tiles;
-  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
-  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_mark = t_now();
-  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
+static Reg2Params reg2_params(const cba_problem* p) {
   Reg2Params prm;
-  prm.C = C; prm.P = p->P; prm.G = G; prm.g = g;
+  const int g = p->gsz;
+  prm.C = p->C; prm.P = p->P; prm.G = p->G; prm.g = g;
   constexpr int CT = KCfg::CODE_THREADS;
   prm.rep = (NC == 6 && g * g <= CT / 2) ? CT / (g * g) : 1;  // small groups: several threads per block
   if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), CT / std::max(g * g, 1))) : 1;
@@ -761,9 +757,45 @@ static int build_reg2_tile_plan(cba_problem* p, const std::vector<int>& hcam, co
   if (const char* e = std::getenv("CBA_PLAN_SWEEPS")) prm.colour_sweeps = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("CBA_PLAN_THREADS")) prm.threads = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
+  return prm;
+}
+
+// the dealing on its own thread; the destructor joins, so every exit of cba_create waits for it before the vectors it reads go away
+struct PlanTask {
+  Reg2Params prm;
   Reg2Plan plan;
-  if (build_reg2_plan(prm, hcam, hps, plan)) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
-  lap("dealt streams and codes (host threads)");
+  int rc = 0;
+  double seconds = 0.0;
+  std::thread th;
+  bool started = false;
+  void start(const Reg2Params& params, const std::vector<int>& hcam, const std::vector<int>& hps) {
+    prm = params;
+    started = true;
+    th = std::thread([this, &hcam, &hps] {
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = build_reg2_plan(prm, hcam, hps, plan);
+      seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    });
+  }
+  void wait() { if (th.joinable()) th.join(); }
+  ~PlanTask() { wait(); }
+};
+
+template <int NC, typename KCfg>
+static int finish_reg2_tile_plan(cba_problem* p, PlanTask& task, const std::vector<int>& cam_off, int max_blocks) {
+  const int G = p->G, g = p->gsz, C = p->C;
+  const int nT = p->n_tiles;
+  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = t_now();
+  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
+  task.wait();
+  if (plan_timing) fprintf(stderr, "  plan: dealt streams and codes took %.3f s on its own threads, started before the uploads\n", task.seconds);
+  lap("waited for the dealing");
+  if (task.rc) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
+  const Reg2Params& prm = task.prm;
+  Reg2Plan& plan = task.plan;
+  constexpr int CT = KCfg::CODE_THREADS;
   p->n_tile_chunks = plan.tile_chunk_begin[nT];
   p->tile_stream_len = (long)plan.obs.size() - 2 * KCfg::SCHUNK;
   p->n_pairs = plan.n_pairs;
@@ -822,6 +854,28 @@ static int regroup_for_lds_tile(cba_problem* p) {
   return allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz));
 }
 
+// Which Schur kernel and which camera groups: host-only (environment, camera count), decided before anything touches the device so that the plan
+// of the register kernels can be dealt while cba_create uploads.  The LDS-tile kernel's groups follow from its LDS budget (regroup_for_lds_tile).
+template <int NC>
+static void choose_schur_path(cba_problem* p) {
+  const char* force_tile = std::getenv("CBA_SCHUR");
+  p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
+  p->schur_v2 = p->schur_reg;
+  p->schur_v3 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg2") == 0) && !p->debug_skip;  // the profiling variants are k_schur_reg2's
+  {
+    const char* wide_env = std::getenv("CBA_SCHUR_WIDE");
+    // opt-in (CBA_SCHUR_WIDE=1, more than 16 cameras): measured on cfg4 the wide kernel gathers half the bytes and takes the same time
+    // as the narrow one (DESIGN.md 5.3: the pair kernel is bound by issue, barrier and pair arithmetic in equal parts, not by the bytes)
+    p->schur_wide = NC == 6 && p->schur_v3 && wide_env && std::atoi(wide_env) == 1 && p->C > kSchurRegMaxGroup;
+  }
+  if (p->schur_reg) {
+    const int gmax = std::min(p->C, p->schur_wide ? Reg3Cfg<6, true>::GROUP : kSchurRegMaxGroup);
+    p->G = (p->C + gmax - 1) / gmax;
+    p->gsz = (p->C + p->G - 1) / p->G;
+    p->n_tiles = p->G * (p->G + 1) / 2;
+  }
+}
+
 template <int NC>
 static int configure_kernels(cba_problem* p) {
   int rc;
@@ -856,23 +910,7 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 1, true>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2, true>, lds_jv(p, 2)))) return rc;
-  int gmax = 1;
-  const char* force_tile = std::getenv("CBA_SCHUR");
-  p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
-  p->schur_v2 = p->schur_reg;
-  p->schur_v3 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg2") == 0) && !p->debug_skip;  // the profiling variants are k_schur_reg2's
-  {
-    const char* wide_env = std::getenv("CBA_SCHUR_WIDE");
-    // opt-in (CBA_SCHUR_WIDE=1, more than 16 cameras): measured on cfg4 the wide kernel gathers half the bytes and takes the same time
-    // as the narrow one (DESIGN.md 5.3: the pair kernel is bound by issue, barrier and pair arithmetic in equal parts, not by the bytes)
-    p->schur_wide = NC == 6 && p->schur_v3 && wide_env && std::atoi(wide_env) == 1 && p->C > kSchurRegMaxGroup;
-  }
-  if (p->schur_reg) {
-    gmax = std::min(p->C, p->schur_wide ? Reg3Cfg<6, true>::GROUP : kSchurRegMaxGroup);
-    p->G = (p->C + gmax - 1) / gmax;
-    p->gsz = (p->C + p->G - 1) / p->G;
-    p->n_tiles = p->G * (p->G + 1) / 2;
-  } else if ((rc = regroup_for_lds_tile<NC>(p))) return rc;
+  if (!p->schur_reg && (rc = regroup_for_lds_tile<NC>(p))) return rc;  // (the register kernels' groups: choose_schur_path, before the plan thread starts)
   if (p->schur_reg) {
     if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
     if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, false>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
@@ -996,6 +1034,17 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   }
   p->n_heavy = (int)heavy.size();
   p->h_heavy_pts = heavy;
+  // the Schur plan of the register kernels is dealt on its own thread from here on (declared after the vectors it reads: joined before they go)
+  p->eval_only = opt && opt->evaluation_only != 0;
+  if (nct == 9) choose_schur_path<9>(p); else choose_schur_path<6>(p);
+  PlanTask plan_task;
+  if (p->schur_reg && !p->eval_only) {
+    Reg2Params prm;
+    if (p->schur_wide) prm = reg2_params<6, Reg3Cfg<6, true>>(p);
+    else if (p->schur_v3) prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
+    else prm = (nct == 9) ? reg2_params<9, Reg2Cfg<9>>(p) : reg2_params<6, Reg2Cfg<6>>(p);
+    plan_task.start(prm, hcam, hps);
+  }
 
   {
     CaptureSafe not_while_recording(g_capture_mu);
@@ -1148,7 +1197,6 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("allocate vectors");
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   lap("reorder, upload, allocate");
-  p->eval_only = opt && opt->evaluation_only != 0;
   for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
     const size_t tile_lds = p->schur_reg ? (p->schur_wide ? Reg3Cfg<6, true>::LDS_BYTES
                                             : p->schur_v3 ? ((nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES) : ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES))
@@ -1158,9 +1206,9 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     const int resident = cus * per_cu;  // no partial last round
     if (p->schur_reg && p->schur_v2) {
       const int mb = std::min(resident, std::max(max_blocks, cus));
-      if (p->schur_wide) rc = build_reg2_tile_plan<6, Reg3Cfg<6, true>>(p, hcam, hps, off, mb);
-      else if (p->schur_v3) rc = (nct == 9) ? build_reg2_tile_plan<9, Reg3Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg3Cfg<6>>(p, hcam, hps, off, mb);
-      else rc = (nct == 9) ? build_reg2_tile_plan<9, Reg2Cfg<9>>(p, hcam, hps, off, mb) : build_reg2_tile_plan<6, Reg2Cfg<6>>(p, hcam, hps, off, mb);
+      if (p->schur_wide) rc = finish_reg2_tile_plan<6, Reg3Cfg<6, true>>(p, plan_task, off, mb);
+      else if (p->schur_v3) rc = (nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan_task, off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan_task, off, mb);
+      else rc = (nct == 9) ? finish_reg2_tile_plan<9, Reg2Cfg<9>>(p, plan_task, off, mb) : finish_reg2_tile_plan<6, Reg2Cfg<6>>(p, plan_task, off, mb);
     }
     else
       rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
@@ -1952,6 +2000,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   std::vector<long> comp_m(K + 1, 0);
   std::vector<int> local(P, -1);
   long max_m = 0;
+  int max_pts = 0;  // beyond CON_LDS_POINTS the per-point factors of a component live in global scratch (ConPlan::big)
   for (int k = 0; k < K; ++k) {
     const int first = (int)comp_pts.size();
     for (int i = comp_con[k]; i < comp_con[k + 1]; ++i) {
@@ -1968,8 +2017,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
     const long m = comp_con[k + 1] - comp_con[k];
     comp_m[k + 1] = comp_m[k] + m * m;
     max_m = std::max(max_m, m);
-    if ((int)comp_pts.size() - first > CON_MAX_POINTS)
-      return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: a constraint component couples %d points (limit %d)", (int)comp_pts.size() - first, CON_MAX_POINTS);
+    max_pts = std::max(max_pts, (int)comp_pts.size() - first);
   }
   // memory of the Woodbury correction: M (sum of m^2 over the components) and G (n_con x (ncp + 1)), doubles
   if (comp_m[K] > (1L << 28) || (long)n_con * (p->ncp + 1) > (1L << 29))
@@ -1991,6 +2039,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   TRYC(dev_alloc(p, &cp.f, (size_t)n_con)); TRYC(dev_alloc(p, &cp.u, (size_t)n_con * 3)); TRYC(dev_alloc(p, &cp.z, (size_t)n_con * 24));
   TRYC(dev_alloc(p, &cp.M, (size_t)std::max<long>(comp_m[K], 1))); TRYC(dev_alloc(p, &cp.G, (size_t)n_con * (p->ncp + 1)));
   TRYC(dev_alloc(p, &cp.cdiag, (size_t)3 * p->lay.Ppad)); TRYC(dev_alloc(p, &cp.w, (size_t)n_con));
+  if (max_pts > CON_LDS_POINTS) TRYC(dev_alloc(p, &cp.big, comp_pts.size() * 9));
 #undef TRYC
   HIPCHK(hipMemset(cp.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double)));
   p->con = cp;

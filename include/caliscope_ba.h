@@ -330,8 +330,9 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
  * residual, :207-226 Jacobian; group arrays as built by capture_volume.py:446-531):
  *   r_c = weights[c] * (|| mean(X[groups_a[c][0..3]]) - mean(X[groups_b[c][0..3]]) || - distances[c]).
  * A corner endpoint repeats one point index four times.  The robust loss applies to these rows as to the others.
- * Call once, after cba_create and before cba_begin.  One connected component of the constraint graph (one board in
- * one frame) may couple at most 256 points; in a sharded solve every rank passes the rows of its own points (the host
+ * Call once, after cba_create and before cba_begin.  A connected component of the constraint graph (one board in one
+ * frame; all static markers together) may couple any number of points; its m rows cost m^2 doubles (2 GB over all
+ * components is the limit, CBA_ERR_UNSUPPORTED beyond).  In a sharded solve every rank passes the rows of its own points (the host
  * sharder keeps a component on one rank, caliscope_amd/sharding.py). */
 int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, const int32_t* groups_b, const double* distances,
                         const double* weights);

@@ -110,6 +110,37 @@ def test_device_step_with_constraints():
 
 
 @pytest.mark.gpu
+def test_component_larger_than_the_lds_copy():
+    """An 18 x 16 board: 288 points and ~1100 rows in ONE connected component per frame.  Up to 256 points a component's
+    per-point factors sit in the workgroup's LDS, beyond that in global scratch (ConPlan::big) — the reference has no
+    limit (core/capture_volume.py:446-531: all static markers of a room are one component)."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc = board_scene(n_cams=4, n_frames=2, rows=18, cols=16, spacing=0.02)
+    assert sc["n_per"] == 288
+    ga, gb, dist, w = sc["constraints"]
+    prob = BAProblem(sc["par"], sc["cam"], sc["uv"], sc["obj"], constraint_groups_a=ga, constraint_groups_b=gb,
+                     constraint_distances=dist, constraint_weights=w)
+    hip, ora = HipEngine(prob), _oracle(sc)
+    c_h, c_o = hip.begin(sc["x0"]), ora.begin(sc["x0"])
+    assert abs(c_h - c_o) <= 1e-13 * c_o
+    hip.linearize(); ora.linearize()
+    assert np.abs(hip.get_vector(2) - ora.g).max() < 1e-11 * np.abs(ora.g).max()
+    for lam in (1e-3, 1e-7):
+        sh, so = hip.newton_step(lam), ora.newton_step(lam)
+        assert sh.ok and so.ok
+        assert np.abs(hip.get_vector(3) - ora.s).max() < 1e-8 * np.abs(ora.s).max(), lam
+        for fld in ("p_sq", "gh_dot_p", "w_sq"):
+            assert abs(getattr(sh, fld) - getattr(so, fld)) <= 1e-7 * abs(getattr(so, fld)), (fld, lam)
+    res = hip.solve(sc["x0"])
+    hip.close()
+    assert res.status > 0
+    pts = res.x[sc["par"].n_camera_params:].reshape(-1, 3)
+    got = np.linalg.norm(pts[ga].mean(axis=1) - pts[gb].mean(axis=1), axis=1)
+    assert np.abs(got - dist).max() < 0.01
+
+
+@pytest.mark.gpu
 def test_converged_parity_with_constraints():
     """Full solve through the reference seam against scipy on the oracle callables (constraints fix the scale, so the
     gauge left is a rigid motion)."""
