@@ -17,7 +17,9 @@
 #include <map>
 #include <mutex>
 #include <shared_mutex>
+#include <memory>
 #include <string>
+#include <type_traits>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -247,13 +249,27 @@ static int dev_alloc(cba_problem* p, T** out, size_t count) {
   p->device_bytes += (long)bytes;
   return CBA_OK;
 }
-template <typename T>
-static int dev_upload(cba_problem* p, T** out, const std::vector<T>& h) {
+template <typename T, typename V>
+static int dev_upload(cba_problem* p, T** out, const V& h) {  // V: any contiguous host array of T (std::vector, HostVec, RawVec)
+  static_assert(std::is_same<typename std::remove_cv<typename std::remove_pointer<decltype(h.data())>::type>::type, T>::value, "element type");
   int rc = dev_alloc(p, out, h.size());
   if (rc) return rc;
   if (!h.empty()) HIPCHK(guarded_memcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return CBA_OK;
 }
+
+// std::vector without value-initialisation of its elements: the threads that fill the observation-sized host arrays of cba_create are the first to
+// touch their pages (zero-filling ~70 bytes per observation on the calling thread was a third of "reorder on host")
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <typename U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <typename U, typename... A> void construct(U* ptr, A&&... args) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)ptr) U; else ::new ((void*)ptr) U(std::forward<A>(args)...);
+  }
+};
+template <typename T> using HostVec = std::vector<T, NoInitAlloc<T>>;
 
 // roctx range around the host-side enqueue of a phase: `rocprofv3 --marker-trace --kernel-trace` shows the kernels of an
 // iteration under build / linearize / schur / cholesky / backsub / trial (free when no profiler is attached)
@@ -768,10 +784,10 @@ struct PlanTask {
   double seconds = 0.0;
   std::thread th;
   bool started = false;
-  void start(const Reg2Params& params, const std::vector<int>& hcam, const std::vector<int>& hps) {
+  void start(const Reg2Params& params, const int* hcam, const int* hps) {
     prm = params;
     started = true;
-    th = std::thread([this, &hcam, &hps] {
+    th = std::thread([this, hcam, hps] {
       const auto t0 = std::chrono::steady_clock::now();
       rc = build_reg2_plan(prm, hcam, hps, plan);
       seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -947,6 +963,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (!d->cam_n_params || !d->cam_model || !d->cam_const || !d->obs_cam || !d->obs_pt || !d->obs_uv) return fail(CBA_ERR_INVALID, "cba_create: null array");
   if (d->loss < CBA_LOSS_LINEAR || d->loss > CBA_LOSS_ARCTAN) return fail(CBA_ERR_INVALID, "cba_create: unknown loss %d", d->loss);
   if (d->loss != CBA_LOSS_LINEAR && !(d->f_scale > 0.0)) return fail(CBA_ERR_INVALID, "cba_create: f_scale must be positive");
+  const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(CBA_ERR_NO_DEVICE, "no HIP device available: the MI355X engine has no CPU fallback");
@@ -994,15 +1011,15 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   double t_mark = t_now();
   auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "cba_create: %-28s %.3f s\n", what, t - t_mark); t_mark = t; } };
   // plan: sort by point, chunk table
-  std::vector<int64_t> order(p->N), pstart((size_t)p->P + 1), cstart((size_t)p->N + 2);
-  for (int64_t i = 0; i < p->N; ++i)
-    if (d->obs_cam[i] < 0 || d->obs_cam[i] >= p->C) return bail(fail(CBA_ERR_INVALID, "observation %lld: camera index %d out of range", (long long)i, d->obs_cam[i]));
+  HostVec<int64_t> order(p->N), pstart((size_t)p->P + 1), cstart((size_t)p->N + 2);  // (written by cba_host_plan: order and pstart in full, cstart up to the chunk count)
+  // (cba_host_plan checks the point and camera indices of every observation)
   int64_t nch = cba_host_plan(p->P, p->N, d->obs_pt, d->obs_cam, p->C, CHUNK, order.data(), pstart.data(), cstart.data());
   if (nch < 0) return bail((int)nch);
   p->n_chunks = (int)nch;
   lap("sort by point, chunk table");
-  std::vector<double> hu(p->N), hv(p->N);
-  std::vector<int> hcam(p->N), hpt(p->N), hord(p->N), hps((size_t)p->P + 1), hcs((size_t)nch + 1);
+  HostVec<double> hu(p->N), hv(p->N);
+  HostVec<int> hcam(p->N), hpt(p->N), hord(p->N);
+  std::vector<int> hps((size_t)p->P + 1), hcs((size_t)nch + 1);
   {  // gather into the sorted order, by a few host threads (1M observations: 6 ms on one)
     auto gather = [&](int64_t lo, int64_t hi) {
       for (int64_t i = lo; i < hi; ++i) {
@@ -1043,7 +1060,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     if (p->schur_wide) prm = reg2_params<6, Reg3Cfg<6, true>>(p);
     else if (p->schur_v3) prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
     else prm = (nct == 9) ? reg2_params<9, Reg2Cfg<9>>(p) : reg2_params<6, Reg2Cfg<6>>(p);
-    plan_task.start(prm, hcam, hps);
+    plan_task.start(prm, hcam.data(), hps.data());
   }
 
   {
@@ -1142,8 +1159,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
         q = e;
       }
       const int n_sc = (int)sc_p0.size();
-      std::vector<double> cu(p->N), cv(p->N);
-      std::vector<int> ccam(p->N), cptl(p->N);
+      HostVec<double> cu(p->N), cv(p->N);
+      HostVec<int> ccam(p->N), cptl(p->N);
       auto fill = [&](int s0, int s1) {
         std::vector<int> start((size_t)p->C + 1);
         for (int sidx = s0; sidx < s1; ++sidx) {
@@ -1211,7 +1228,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
       else rc = (nct == 9) ? finish_reg2_tile_plan<9, Reg2Cfg<9>>(p, plan_task, off, mb) : finish_reg2_tile_plan<6, Reg2Cfg<6>>(p, plan_task, off, mb);
     }
     else
-      rc = build_tile_plan(p, hu, hv, hcam, hpt, hps, off, std::min(resident, std::max(max_blocks, cus)));
+      rc = build_tile_plan(p, std::vector<double>(hu.begin(), hu.end()), std::vector<double>(hv.begin(), hv.end()), std::vector<int>(hcam.begin(), hcam.end()),
+                           std::vector<int>(hpt.begin(), hpt.end()), hps, off, std::min(resident, std::max(max_blocks, cus)));  // (the fallback kernel's plan: rare)
     if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) {  // a point too large for the pair plan: the LDS-tile kernel, with the groups that fit its tile
       p->schur_reg = false; p->schur_v2 = false; p->schur_v3 = false; p->schur_wide = false;
       if ((rc = (nct == 9) ? regroup_for_lds_tile<9>(p) : regroup_for_lds_tile<6>(p))) return bail(rc);
@@ -1255,11 +1273,15 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPBAIL(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
 #undef TRY
   p->h_vec.resize((size_t)tot);
+  lap("solver buffers");
   if (!p->eval_only && !p->want_chol_trace) {
     rc = ensure_cholesky_graph(p);
     if (rc) return bail(rc);
   }
+  lap("Cholesky graph");
   HIPBAIL(hipDeviceSynchronize());
+  lap("device synchronize");
+  if (plan_timing) fprintf(stderr, "cba_create: %.3f s in total\n", t_now() - t_enter);
   *out = p;
   return CBA_OK;
 }

@@ -34,10 +34,28 @@
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
 namespace cba {
+
+// An array without value-initialisation: the worker threads that fill it are the first to touch its pages (a std::vector of the plan's 40+ MB would
+// be zero-filled, page by page, by the one thread that resizes it).
+template <typename T>
+struct RawVec {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void resize_uninit(size_t m) { p.reset(new T[m]); n = m; }
+  T* data() { return p.get(); }
+  const T* data() const { return p.get(); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* begin() { return p.get(); }
+  T* end() { return p.get() + n; }
+};
 
 struct Reg2Params {
   int C = 0, P = 0;       // cameras, world points
@@ -62,11 +80,11 @@ struct Reg2Params {
 };
 
 struct Reg2Plan {
-  std::vector<int> obs;               // stream entry -> observation (index into the T records); padded with 2 * chunk_cap zeros
+  RawVec<int> obs;                    // stream entry -> observation (index into the T records); padded with 2 * chunk_cap zeros
   std::vector<int> chunk_start;       // [n_chunks + 1] offsets into obs
   std::vector<int> code_start;        // [n_chunks + 1] offsets into codes
   std::vector<unsigned> nit;          // [n_chunks][n_waves / 4] iterations of the waves, one byte each
-  std::vector<unsigned> codes;        // transposed pair codes; padded with 4 * 64 n_waves ZERO codes
+  RawVec<unsigned> codes;             // transposed pair codes; padded with 4 * 64 n_waves ZERO codes
   std::vector<int> tile_chunk_begin;  // [n_tiles + 1]
   long n_pairs = 0;                   // pair codes that do work
   long lane_iters = 0;                // 64 x wave-iterations (n_pairs / lane_iters = lane utilisation)
@@ -99,7 +117,7 @@ inline int b128_group(int lane) {
 
 // hcam / hps: cameras of the observations sorted by (point, camera) and the first observation of every point.
 // Returns 0, or -1 when a single point does not fit a chunk.
-inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, const std::vector<int>& hps, Reg2Plan& out) {
+inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hps, Reg2Plan& out) {
   using namespace reg2_detail;
   const int G = prm.G, g = prm.g, C = prm.C, P = prm.P, rep = std::max(1, prm.rep);
   const int nT = G * (G + 1) / 2, nblk = g * g, R = prm.chunk_cap;
@@ -114,18 +132,34 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
     for (int a = 0; a < G; ++a)
       for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
   }
+  // (more than ~64 workers do not pay: a job is a few milliseconds, and starting a thread costs the main thread ~20 us)
+  const unsigned n_threads = prm.threads > 0 ? (unsigned)prm.threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
   // observations of a point are sorted by camera => by group; pgb[q*(G+1) + a] .. [a+1] is group a's run
-  std::vector<int> pgb((size_t)P * (G + 1));
+  RawVec<int> pgb;
+  pgb.resize_uninit((size_t)P * (G + 1));
   long stream_total = 0;
-  for (int q = 0; q < P; ++q) {
-    int cur = hps[q];
-    const int s1 = hps[q + 1];
-    for (int a = 0; a < G; ++a) {
-      pgb[(size_t)q * (G + 1) + a] = cur;
-      while (cur < s1 && hcam[cur] < gcam[a + 1]) ++cur;
-    }
-    pgb[(size_t)q * (G + 1) + G] = s1;
-    stream_total += (long)(s1 - hps[q]) * G;  // an observation takes part in the G tiles of its group (upper bound)
+  {
+    auto runs = [&](int q0, int q1, long* total) {
+      long tot = 0;
+      for (int q = q0; q < q1; ++q) {
+        int cur = hps[q];
+        const int s1 = hps[q + 1];
+        for (int a = 0; a < G; ++a) {
+          pgb[(size_t)q * (G + 1) + a] = cur;
+          while (cur < s1 && hcam[cur] < gcam[a + 1]) ++cur;
+        }
+        pgb[(size_t)q * (G + 1) + G] = s1;
+        tot += (long)(s1 - hps[q]) * G;  // an observation takes part in the G tiles of its group (upper bound)
+      }
+      *total = tot;
+    };
+    const int nth = (int)std::max(1u, std::min(n_threads, (unsigned)(P / 8192)));  // (a thread per 8k points at least: below that starting it costs more)
+    std::vector<long> part((size_t)nth, 0);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(runs, (int)((long)P * t / nth), (int)((long)P * (t + 1) / nth), &part[t]);
+    runs(0, (int)((long)P / nth), &part[0]);
+    for (auto& th : pool) th.join();
+    for (long v : part) stream_total += v;
   }
   // regions: the same point ranges for every tile, about region_chunks chunks of an average tile each
   const long per_tile = std::max<long>(1, stream_total / std::max(nT, 1));
@@ -484,8 +518,6 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
     }
   };
 
-  // (more than ~64 workers do not pay: a job is a few milliseconds, and starting a thread costs the main thread ~20 us)
-  const unsigned n_threads = prm.threads > 0 ? (unsigned)prm.threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
   {
     unsigned hw = n_threads;
     hw = std::min<unsigned>(hw, (unsigned)jobs.size());
@@ -508,8 +540,8 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
     job_o[j] = n_obs; job_c[j] = n_codes; job_ch[j] = n_chunks;
     n_obs += jobs[j].obs.size(); n_codes += jobs[j].codes.size(); n_chunks += jobs[j].nit.size() / NWORD;
   }
-  out.obs.resize(n_obs + 2 * (size_t)R);
-  out.codes.resize(n_codes + (size_t)4 * 64 * NW);
+  out.obs.resize_uninit(n_obs + 2 * (size_t)R);
+  out.codes.resize_uninit(n_codes + (size_t)4 * 64 * NW);
   std::fill(out.obs.begin() + (long)n_obs, out.obs.end(), 0);
   std::fill(out.codes.begin() + (long)n_codes, out.codes.end(), ZERO);
   out.chunk_start.assign(n_chunks + 1, 0);
@@ -547,6 +579,10 @@ inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, 
   const size_t ch = n_chunks;
   out.tile_chunk_begin[nT] = (int)ch;
   return 0;
+}
+
+inline int build_reg2_plan(const Reg2Params& prm, const std::vector<int>& hcam, const std::vector<int>& hps, Reg2Plan& out) {
+  return build_reg2_plan(prm, hcam.data(), hps.data(), out);
 }
 
 }  // namespace cba

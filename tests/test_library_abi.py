@@ -85,6 +85,36 @@ def test_host_plan_sorts_by_point_and_chunks_whole_points(lib):
         assert sizes[c] + counts[nxt] > 256
 
 
+def test_host_plan_threaded_passes_on_sorted_input(lib):
+    """Above 2 x 131072 observations the range / sortedness pass and, for input already in (point, camera) order, the point table and the
+    identity order run on several threads (slices of the observation range): same answers as the sort."""
+    rng = np.random.default_rng(1)
+    n_points = 90_000
+    counts = rng.integers(0, 14, n_points)  # ragged, unobserved points at both ends of slices
+    counts[:3] = 0
+    counts[-2:] = 0
+    obs_pt = np.repeat(np.arange(n_points), counts)
+    assert len(obs_pt) > 4 * 131072
+    obs_cam = np.concatenate([np.sort(rng.choice(40, c, replace=False)) for c in counts]).astype(np.int32)
+    nch, order, pstart, cstart = _plan(lib, n_points, obs_pt, 256, obs_cam, 40)
+    assert nch > 0 and np.array_equal(order, np.arange(len(obs_pt)))
+    assert np.array_equal(pstart, np.concatenate([[0], np.cumsum(counts)]))
+    assert cstart[0] == 0 and cstart[-1] == len(obs_pt) and np.diff(cstart).max() <= 256 and np.all(np.isin(cstart, pstart))
+    # one pair of neighbours out of camera order, deep inside a later slice: the sort path, same tables
+    k = int(np.flatnonzero(np.diff(obs_pt) == 0)[-5])
+    cam2 = obs_cam.copy()
+    cam2[k], cam2[k + 1] = cam2[k + 1], cam2[k]
+    nch2, order2, pstart2, cstart2 = _plan(lib, n_points, obs_pt, 256, cam2, 40)
+    assert nch2 == nch and np.array_equal(pstart2, pstart) and np.array_equal(cstart2, cstart)
+    expect = np.arange(len(obs_pt)); expect[k], expect[k + 1] = k + 1, k
+    assert np.array_equal(order2, expect)
+    # a bad index in the last slice is reported with its position
+    bad = obs_cam.copy()
+    bad[-7] = 40
+    nch3, *_ = _plan(lib, n_points, obs_pt, 256, bad, 40)
+    assert nch3 == -1 and f"observation {len(obs_pt) - 7}: camera index 40".encode() in lib.cba_last_error()
+
+
 def test_host_plan_rejects_bad_input(lib):
     nch, *_ = _plan(lib, 4, np.array([0, 1, 7]), 256)
     assert nch == -1 and b"out of range" in lib.cba_last_error()
