@@ -75,6 +75,10 @@ struct Reg2Params {
   int pair_cap = 0;       // > 0: pairs of one block per chunk the kernel takes without an extra load; the dealing opens new chunks rather than going beyond
                           // (a single point with more pairs of one block than this still gets its chunk)
   int n_waves = 4;        // waves of a workgroup that multiply pairs (4: 256 threads, 16: the 1024-thread kernel of 32 x 32 tiles)
+  bool cheap = false;     // the plan a handle starts with while the dealt one is being made: one open chunk filled in point order (no dealing), the
+                          // records in arrival order (no colouring) — a quarter of the host time; the pair kernel then runs at ~0.5 lane utilisation
+                          // and ~2.4 LDS cycles per read group instead of 0.7 / 1.4
+  const std::atomic<bool>* cancel = nullptr;  // set by the owner to make the workers stop between jobs (build_reg2_plan then returns -2)
   int colour_sweeps = 0;  // refinement sweeps of the slot colouring behind the greedy pass.  Two sweeps (round 2) buy 1.35 instead of 1.36 LDS cycles
                           // per 16-lane read group on cfg4 and cost a quarter of the plan's time: off by default (CBA_PLAN_SWEEPS)
 };
@@ -253,8 +257,8 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
     // per candidate the set of its keys as a bit mask, per chunk the set of keys that have reached the cap: a chunk where the two intersect cannot take
     // the candidate — one AND per 64 keys instead of a walk over the candidate's keys with increments to take back (most first-fit probes fail)
     const int W = nblk + g, MW = (W + 63) / 64;
-    std::vector<unsigned long long> cand_mask(cand.size() * (size_t)MW, 0ull);
-    for (size_t ci = 0; ci < cand.size(); ++ci)
+    std::vector<unsigned long long> cand_mask(prm.cheap ? 0 : cand.size() * (size_t)MW, 0ull);
+    for (size_t ci = 0; ci < cand.size() && !prm.cheap; ++ci)
       for (int k = cand[ci].key_begin; k < cand[ci].key_end; ++k) cand_mask[ci * MW + keys[k] / 64] |= 1ull << (keys[k] % 64);
     auto deal = [&](int t0, int r_eff, Deal& d) {
       const int want = (int)((tot_rec + r_eff - 1) / r_eff);
@@ -333,7 +337,15 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
       }
     };
     Deal best;
-    {
+    if (prm.cheap) {
+      int fill = 0;
+      best.members.emplace_back();
+      for (int ci = 0; ci < (int)cand.size(); ++ci) {
+        if (fill + cand[ci].n_rec > R) { best.members.emplace_back(); fill = 0; }
+        best.members.back().push_back(ci);
+        fill += cand[ci].n_rec;
+      }
+    } else {
       int t_hi = std::max(1, (int)std::ceil(mean - 1e-9));
       if (prm.pair_cap > 0) t_hi = std::min(t_hi, prm.pair_cap);
       int r_hi = R;
@@ -399,97 +411,99 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
         for (int l = 0; l < 64; ++l) mx = std::max(mx, lists[(size_t)w * 64 + l].size());
         nit_w[w] = std::min<size_t>(mx, 255);  // a byte per wave; 255 pairs of one block in one chunk cannot happen (chunk_cap records)
       }
-      // cliques of the LDS reads: per wave, iteration, lane group and operand the distinct records read together
-      size_t n_clq = 0;
-      for (int w = 0; w < NW; ++w) n_clq += nit_w[w] * 8;
-      clq_item.resize(n_clq * 16);
-      clq_n.assign(n_clq, 0);
-      mark.assign((size_t)n_rec, -1);
-      {
-        size_t c0 = 0;
-        for (int w = 0; w < NW; ++w)
-          for (size_t it = 0; it < nit_w[w]; ++it)
-            for (int side = 0; side < 2; ++side, c0 += 4)
-              for (int l = 0; l < 64; ++l) {
-                const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
-                if (it >= li.size()) continue;
-                const int r = side ? (int)(li[it] >> 16) : (int)(li[it] & 0xffffu);
-                const int cq = (int)c0 + b128_group(l);
-                if (mark[r] == cq) continue;  // the same record twice in a group: one address, a broadcast
-                mark[r] = cq;
-                clq_item[(size_t)cq * 16 + clq_n[cq]++] = r;
-              }
-      }
-      auto clique_cost = [&](const std::vector<int>& res) {
-        long cyc = 0;
-        int cnt[16];
-        for (size_t cq = 0; cq < n_clq; ++cq) {
-          if (!clq_n[cq]) continue;
-          std::fill(cnt, cnt + 16, 0);
-          int mx = 0;
-          for (int k = 0; k < clq_n[cq]; ++k) mx = std::max(mx, ++cnt[res[clq_item[cq * 16 + k]] & 15]);
-          cyc += mx;
-        }
-        return cyc;
-      };
-      residue.resize((size_t)n_rec);
-      for (int r = 0; r < n_rec; ++r) residue[r] = r & 15;
-      long groups = 0;
-      for (size_t cq = 0; cq < n_clq; ++cq) groups += clq_n[cq] ? 1 : 0;
-      job.lds_groups += groups;
-      job.lds_cycles_arrival += clique_cost(residue);
-      // colouring
-      rcl_start.assign((size_t)n_rec + 1, 0);
-      for (size_t cq = 0; cq < n_clq; ++cq)
-        for (int k = 0; k < clq_n[cq]; ++k) rcl_start[(size_t)clq_item[cq * 16 + k] + 1]++;
-      for (int r = 0; r < n_rec; ++r) rcl_start[(size_t)r + 1] += rcl_start[r];
-      rcl_item.resize((size_t)rcl_start[n_rec]);
-      rcl_fill.assign(rcl_start.begin(), rcl_start.end() - 1);
-      for (size_t cq = 0; cq < n_clq; ++cq)  // ascending clique order per record, as the vectors of round 2 had it
-        for (int k = 0; k < clq_n[cq]; ++k) rcl_item[(size_t)rcl_fill[clq_item[cq * 16 + k]]++] = (int)cq;
-      clq_cnt.assign(n_clq * 16, 0);
-      class_size.assign(16, 0);
-      order_r.resize((size_t)n_rec);
-      {  // records by the number of cliques they are in, most first, stable (counting sort)
-        int maxd = 0;
-        for (int r = 0; r < n_rec; ++r) maxd = std::max(maxd, rcl_start[r + 1] - rcl_start[r]);
-        deg_start.assign((size_t)maxd + 2, 0);
-        for (int r = 0; r < n_rec; ++r) deg_start[(size_t)maxd - (rcl_start[r + 1] - rcl_start[r]) + 1]++;
-        for (int d = 0; d <= maxd; ++d) deg_start[(size_t)d + 1] += deg_start[d];
-        for (int r = 0; r < n_rec; ++r) order_r[(size_t)deg_start[(size_t)maxd - (rcl_start[r + 1] - rcl_start[r])]++] = r;
-      }
-      std::fill(residue.begin(), residue.end(), -1);
-      auto best_residue = [&](int r) {
-        long cost[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int e = rcl_start[r]; e < rcl_start[r + 1]; ++e) {
-          const int* row = &clq_cnt[(size_t)rcl_item[e] * 16];  // one contiguous row per clique: the 16 sums vectorise
-          for (int rho = 0; rho < 16; ++rho) cost[rho] += row[rho];
-        }
-        int best_rho = -1;
-        long best_cost = 0;
-        for (int rho = 0; rho < 16; ++rho) {
-          if (class_size[rho] >= (R - rho + 15) / 16) continue;  // slots rho, rho + 16, ... below the chunk's R slots
-          const long c = cost[rho] * 64 + class_size[rho];
-          if (best_rho < 0 || c < best_cost) { best_rho = rho; best_cost = c; }
-        }
-        return best_rho;
-      };
-      auto put = [&](int r, int rho, int d) {
-        residue[r] = d > 0 ? rho : -1;
-        class_size[rho] += d;
-        for (int e = rcl_start[r]; e < rcl_start[r + 1]; ++e) clq_cnt[(size_t)rcl_item[e] * 16 + rho] += d;
-      };
-      for (int r : order_r) put(r, best_residue(r), +1);
-      for (int sweep = 0; sweep < prm.colour_sweeps; ++sweep)
-        for (int r : order_r) {
-          const int old = residue[r];
-          put(r, old, -1);
-          put(r, best_residue(r), +1);
-        }
-      job.lds_cycles += clique_cost(residue);
-      // slots: residue rho takes rho, rho + 16, rho + 32, ...
       slot_of.assign((size_t)n_rec, 0);
-      {
+      if (prm.cheap) {
+        for (int r = 0; r < n_rec; ++r) slot_of[r] = r;  // arrival order
+      } else {
+        // cliques of the LDS reads: per wave, iteration, lane group and operand the distinct records read together
+        size_t n_clq = 0;
+        for (int w = 0; w < NW; ++w) n_clq += nit_w[w] * 8;
+        clq_item.resize(n_clq * 16);
+        clq_n.assign(n_clq, 0);
+        mark.assign((size_t)n_rec, -1);
+        {
+          size_t c0 = 0;
+          for (int w = 0; w < NW; ++w)
+            for (size_t it = 0; it < nit_w[w]; ++it)
+              for (int side = 0; side < 2; ++side, c0 += 4)
+                for (int l = 0; l < 64; ++l) {
+                  const std::vector<unsigned>& li = lists[(size_t)w * 64 + l];
+                  if (it >= li.size()) continue;
+                  const int r = side ? (int)(li[it] >> 16) : (int)(li[it] & 0xffffu);
+                  const int cq = (int)c0 + b128_group(l);
+                  if (mark[r] == cq) continue;  // the same record twice in a group: one address, a broadcast
+                  mark[r] = cq;
+                  clq_item[(size_t)cq * 16 + clq_n[cq]++] = r;
+                }
+        }
+        auto clique_cost = [&](const std::vector<int>& res) {
+          long cyc = 0;
+          int cnt[16];
+          for (size_t cq = 0; cq < n_clq; ++cq) {
+            if (!clq_n[cq]) continue;
+            std::fill(cnt, cnt + 16, 0);
+            int mx = 0;
+            for (int k = 0; k < clq_n[cq]; ++k) mx = std::max(mx, ++cnt[res[clq_item[cq * 16 + k]] & 15]);
+            cyc += mx;
+          }
+          return cyc;
+        };
+        residue.resize((size_t)n_rec);
+        for (int r = 0; r < n_rec; ++r) residue[r] = r & 15;
+        long groups = 0;
+        for (size_t cq = 0; cq < n_clq; ++cq) groups += clq_n[cq] ? 1 : 0;
+        job.lds_groups += groups;
+        job.lds_cycles_arrival += clique_cost(residue);
+        // colouring
+        rcl_start.assign((size_t)n_rec + 1, 0);
+        for (size_t cq = 0; cq < n_clq; ++cq)
+          for (int k = 0; k < clq_n[cq]; ++k) rcl_start[(size_t)clq_item[cq * 16 + k] + 1]++;
+        for (int r = 0; r < n_rec; ++r) rcl_start[(size_t)r + 1] += rcl_start[r];
+        rcl_item.resize((size_t)rcl_start[n_rec]);
+        rcl_fill.assign(rcl_start.begin(), rcl_start.end() - 1);
+        for (size_t cq = 0; cq < n_clq; ++cq)  // ascending clique order per record, as the vectors of round 2 had it
+          for (int k = 0; k < clq_n[cq]; ++k) rcl_item[(size_t)rcl_fill[clq_item[cq * 16 + k]]++] = (int)cq;
+        clq_cnt.assign(n_clq * 16, 0);
+        class_size.assign(16, 0);
+        order_r.resize((size_t)n_rec);
+        {  // records by the number of cliques they are in, most first, stable (counting sort)
+          int maxd = 0;
+          for (int r = 0; r < n_rec; ++r) maxd = std::max(maxd, rcl_start[r + 1] - rcl_start[r]);
+          deg_start.assign((size_t)maxd + 2, 0);
+          for (int r = 0; r < n_rec; ++r) deg_start[(size_t)maxd - (rcl_start[r + 1] - rcl_start[r]) + 1]++;
+          for (int d = 0; d <= maxd; ++d) deg_start[(size_t)d + 1] += deg_start[d];
+          for (int r = 0; r < n_rec; ++r) order_r[(size_t)deg_start[(size_t)maxd - (rcl_start[r + 1] - rcl_start[r])]++] = r;
+        }
+        std::fill(residue.begin(), residue.end(), -1);
+        auto best_residue = [&](int r) {
+          long cost[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int e = rcl_start[r]; e < rcl_start[r + 1]; ++e) {
+            const int* row = &clq_cnt[(size_t)rcl_item[e] * 16];  // one contiguous row per clique: the 16 sums vectorise
+            for (int rho = 0; rho < 16; ++rho) cost[rho] += row[rho];
+          }
+          int best_rho = -1;
+          long best_cost = 0;
+          for (int rho = 0; rho < 16; ++rho) {
+            if (class_size[rho] >= (R - rho + 15) / 16) continue;  // slots rho, rho + 16, ... below the chunk's R slots
+            const long c = cost[rho] * 64 + class_size[rho];
+            if (best_rho < 0 || c < best_cost) { best_rho = rho; best_cost = c; }
+          }
+          return best_rho;
+        };
+        auto put = [&](int r, int rho, int d) {
+          residue[r] = d > 0 ? rho : -1;
+          class_size[rho] += d;
+          for (int e = rcl_start[r]; e < rcl_start[r + 1]; ++e) clq_cnt[(size_t)rcl_item[e] * 16 + rho] += d;
+        };
+        for (int r : order_r) put(r, best_residue(r), +1);
+        for (int sweep = 0; sweep < prm.colour_sweeps; ++sweep)
+          for (int r : order_r) {
+            const int old = residue[r];
+            put(r, old, -1);
+            put(r, best_residue(r), +1);
+          }
+        job.lds_cycles += clique_cost(residue);
+        // slots: residue rho takes rho, rho + 16, rho + 32, ...
         int next_k[16] = {0};
         for (int r = 0; r < n_rec; ++r) slot_of[r] = residue[r] + 16 * next_k[residue[r]]++;
       }
@@ -523,13 +537,17 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
     hw = std::min<unsigned>(hw, (unsigned)jobs.size());
     std::atomic<size_t> next{0};
     auto worker = [&]() {
-      for (size_t j = next++; j < jobs.size(); j = next++) run_job(jobs[j]);
+      for (size_t j = next++; j < jobs.size(); j = next++) {
+        if (prm.cancel && prm.cancel->load(std::memory_order_relaxed)) return;
+        run_job(jobs[j]);
+      }
     };
     std::vector<std::thread> pool;
     for (unsigned i = 1; i < hw; ++i) pool.emplace_back(worker);
     worker();
     for (auto& th : pool) th.join();
   }
+  if (prm.cancel && prm.cancel->load(std::memory_order_relaxed)) return -2;
   for (const Job& j : jobs)
     if (j.rc) return j.rc;
 
