@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -152,6 +153,10 @@ struct cba_problem {
   long step_graph_launches = 0;
   bool have_x0 = false;
   std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
+  struct PlanTask* plan_task = nullptr;  // CBA_PLAN=swap: the thread still dealing the Schur plan while the handle works with the cheap one
+  int plan_max_blocks = 0;               // workgroup budget of the pair kernel (the dealt plan is bound with the same one when it is swapped in)
+  size_t partial_capacity = 0;           // doubles behind `partial`
+  bool plan_is_cheap = false;
   bool schur_clock = false;  // profiling only (CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
   int debug_skip = 0;  // profiling only (CBA_DEBUG_SCHUR_SKIP): 1 = skip the pair phase, 2 = skip the block recomputation
   bool begun = false, linearized = false, stepped = false, have_trial = false;
@@ -532,9 +537,12 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
                         order_out, pt_start_out, chunk_start_out);
 }
 
+static void drop_plan_task(cba_problem* p);  // (PlanTask is defined with the plans further down)
+
 void cba_destroy(cba_problem* p) {
   CaptureSafe api_guard(g_capture_mu);
   if (!p) return;
+  drop_plan_task(p);  // a plan thread still dealing: cancelled and joined before anything it could look at goes away
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drain_timers(p);
@@ -776,41 +784,61 @@ static Reg2Params reg2_params(const cba_problem* p) {
   return prm;
 }
 
-// the dealing on its own thread; the destructor joins, so every exit of cba_create waits for it before the vectors it reads go away
+// The dealing on its own thread.  One stage (default): cba_create waits for the dealt plan before it returns.  Two stages (CBA_PLAN=swap): the thread
+// first makes the CHEAP plan (Reg2Params::cheap: a quarter of the host time), cba_create goes on with that one and returns; the dealt plan follows on
+// the same thread and the first damped step that finds it ready swaps it in (maybe_swap_plan).  The task then owns the two host arrays the thread
+// reads (cba_create moves them in: the buffers stay where they are).  The destructor cancels and joins.
 struct PlanTask {
   Reg2Params prm;
-  Reg2Plan plan;
-  int rc = 0;
-  double seconds = 0.0;
+  Reg2Plan cheap, plan;
+  int rc_cheap = 0, rc = 0;
+  double seconds_cheap = 0.0, seconds = 0.0;
+  bool two_stage = false;
+  std::atomic<int> stage{0};  // 1: the cheap plan is ready, 2: the dealt plan is ready (or has failed: rc)
+  std::atomic<bool> cancel{false};
+  std::mutex mu;
+  std::condition_variable cv;
   std::thread th;
-  bool started = false;
-  void start(const Reg2Params& params, const int* hcam, const int* hps) {
+  HostVec<int> hcam_keep;
+  std::vector<int> hps_keep;
+  void start(const Reg2Params& params, const int* hcam, const int* hps, bool two) {
     prm = params;
-    started = true;
+    prm.cancel = &cancel;
+    two_stage = two;
     th = std::thread([this, hcam, hps] {
+      auto publish = [this](int s) { { std::lock_guard<std::mutex> lock(mu); stage.store(s, std::memory_order_release); } cv.notify_all(); };
+      if (two_stage) {
+        const auto t0 = std::chrono::steady_clock::now();
+        Reg2Params c = prm;
+        c.cheap = true;
+        rc_cheap = build_reg2_plan(c, hcam, hps, cheap);
+        seconds_cheap = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        publish(1);
+      }
       const auto t0 = std::chrono::steady_clock::now();
-      rc = build_reg2_plan(prm, hcam, hps, plan);
+      rc = (two_stage && rc_cheap) ? rc_cheap : build_reg2_plan(prm, hcam, hps, plan);
       seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      publish(2);
     });
   }
-  void wait() { if (th.joinable()) th.join(); }
-  ~PlanTask() { wait(); }
+  void wait_stage(int s) {
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [&] { return stage.load(std::memory_order_acquire) >= s; });
+  }
+  ~PlanTask() {
+    cancel.store(true);
+    if (th.joinable()) th.join();
+  }
 };
 
 template <int NC, typename KCfg>
-static int finish_reg2_tile_plan(cba_problem* p, PlanTask& task, const std::vector<int>& cam_off, int max_blocks) {
+static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm, const std::vector<int>& cam_off, int max_blocks) {
   const int G = p->G, g = p->gsz, C = p->C;
   const int nT = p->n_tiles;
   const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
   auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = t_now();
   auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
-  task.wait();
-  if (plan_timing) fprintf(stderr, "  plan: dealt streams and codes took %.3f s on its own threads, started before the uploads\n", task.seconds);
-  lap("waited for the dealing");
-  if (task.rc) return CBA_ERR_UNSUPPORTED;  // a point larger than a chunk: LDS-tile fallback
-  const Reg2Params& prm = task.prm;
-  Reg2Plan& plan = task.plan;
   constexpr int CT = KCfg::CODE_THREADS;
   p->n_tile_chunks = plan.tile_chunk_begin[nT];
   p->tile_stream_len = (long)plan.obs.size() - 2 * KCfg::SCHUNK;
@@ -857,6 +885,19 @@ static int finish_reg2_tile_plan(cba_problem* p, PlanTask& task, const std::vect
   tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
   p->tp = tp;
   return CBA_OK;
+}
+
+static void drop_plan_task(cba_problem* p) {
+  delete p->plan_task;
+  p->plan_task = nullptr;
+}
+
+// binds and uploads `plan` for the register kernel the handle runs
+static int install_reg2_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm) {
+  const int mb = p->plan_max_blocks;
+  if (p->schur_wide) return finish_reg2_tile_plan<6, Reg3Cfg<6, true>>(p, plan, prm, p->h_cam_off, mb);
+  if (p->schur_v3) return (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
+  return (p->nct == 9) ? finish_reg2_tile_plan<9, Reg2Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg2Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
 }
 
 // camera groups of the LDS-tile kernel (k_schur_tile): the widest group whose tile fits the LDS budget
@@ -1054,13 +1095,18 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   // the Schur plan of the register kernels is dealt on its own thread from here on (declared after the vectors it reads: joined before they go)
   p->eval_only = opt && opt->evaluation_only != 0;
   if (nct == 9) choose_schur_path<9>(p); else choose_schur_path<6>(p);
-  PlanTask plan_task;
+  // CBA_PLAN=swap (opt-in): start with the cheap plan, swap the dealt one in when its thread is done.  Not with fixed-order sums (the iteration the
+  // swap lands on would vary from run to run) nor with the profiling builds (they want the plan they profile).
+  bool plan_two_stage = false;
+  if (const char* e = std::getenv("CBA_PLAN")) plan_two_stage = std::strcmp(e, "swap") == 0 && !(opt && opt->deterministic) && !p->schur_clock && !p->debug_skip;
   if (p->schur_reg && !p->eval_only) {
     Reg2Params prm;
     if (p->schur_wide) prm = reg2_params<6, Reg3Cfg<6, true>>(p);
     else if (p->schur_v3) prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
     else prm = (nct == 9) ? reg2_params<9, Reg2Cfg<9>>(p) : reg2_params<6, Reg2Cfg<6>>(p);
-    plan_task.start(prm, hcam.data(), hps.data());
+    if (const char* e = std::getenv("CBA_PLAN")) prm.cheap = std::strcmp(e, "cheap") == 0;  // (measurements: the cheap plan for good)
+    p->plan_task = new PlanTask();  // owned by the handle: cba_destroy (also through bail) cancels and joins it while the arrays it reads are alive
+    p->plan_task->start(prm, hcam.data(), hps.data(), plan_two_stage);
   }
 
   {
@@ -1223,9 +1269,16 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     const int resident = cus * per_cu;  // no partial last round
     if (p->schur_reg && p->schur_v2) {
       const int mb = std::min(resident, std::max(max_blocks, cus));
-      if (p->schur_wide) rc = finish_reg2_tile_plan<6, Reg3Cfg<6, true>>(p, plan_task, off, mb);
-      else if (p->schur_v3) rc = (nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan_task, off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan_task, off, mb);
-      else rc = (nct == 9) ? finish_reg2_tile_plan<9, Reg2Cfg<9>>(p, plan_task, off, mb) : finish_reg2_tile_plan<6, Reg2Cfg<6>>(p, plan_task, off, mb);
+      PlanTask& task = *p->plan_task;
+      const double t_wait = t_now();
+      task.wait_stage(task.two_stage ? 1 : 2);
+      if (plan_timing)
+        fprintf(stderr, "  plan: %s took %.3f s on its own threads, started before the uploads; waited %.3f s for it\n", task.two_stage ? "the cheap plan" : "dealt streams and codes",
+                task.two_stage ? task.seconds_cheap : task.seconds, t_now() - t_wait);
+      p->plan_max_blocks = mb;
+      rc = (task.two_stage ? task.rc_cheap : task.rc) ? CBA_ERR_UNSUPPORTED  // a point larger than a chunk: LDS-tile fallback
+                                                     : install_reg2_plan(p, task.two_stage ? task.cheap : task.plan, task.prm);
+      p->plan_is_cheap = task.two_stage || task.prm.cheap;
     }
     else
       rc = build_tile_plan(p, std::vector<double>(hu.begin(), hu.end()), std::vector<double>(hv.begin(), hv.end()), std::vector<int>(hcam.begin(), hcam.end()),
@@ -1243,7 +1296,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
-  TRY(dev_alloc(p, &p->partial, (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems)));
+  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems);
+  TRY(dev_alloc(p, &p->partial, p->partial_capacity));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->tri, (size_t)ncp * (ncp + 1) / 2 + p->lay.ncp_pad));
@@ -1281,6 +1335,14 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("Cholesky graph");
   HIPBAIL(hipDeviceSynchronize());
   lap("device synchronize");
+  if (p->plan_task) {
+    if (p->plan_task->two_stage && p->schur_reg) {  // the thread goes on dealing: it reads these two arrays
+      p->plan_task->hcam_keep = std::move(hcam);
+      p->plan_task->hps_keep = std::move(hps);
+    } else {
+      drop_plan_task(p);
+    }
+  }
   if (plan_timing) fprintf(stderr, "cba_create: %.3f s in total\n", t_now() - t_enter);
   *out = p;
   return CBA_OK;
@@ -1643,10 +1705,44 @@ static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false
   return exchange(p, SLOT(20), false);  // ||w||^2 and the flags
 }
 
+// CBA_PLAN=swap: the handle started with the cheap Schur plan; once the plan thread has the dealt one, the next damped step uploads it and goes on
+// with it (the cheap plan's buffers stay in the arena until the handle goes).  Called between iterations by the thread that drives the handle.
+static int maybe_swap_plan(cba_problem* p) {
+  PlanTask* task = p->plan_task;
+  if (!task || p->capturing || task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
+  int rc = CBA_OK;
+  if (task->rc == 0) {
+    const bool timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = install_reg2_plan(p, task->plan, task->prm);
+    if (!rc) {
+      const size_t need = (size_t)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems;
+      if (need > p->partial_capacity) {  // (the dealt plan has a few chunks more or fewer than the cheap one; small problems get a workgroup per chunk)
+        rc = dev_alloc(p, &p->partial, need);
+        if (!rc) p->partial_capacity = need;
+      }
+    }
+    if (!rc) {
+      p->plan_is_cheap = false;
+      for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }  // recorded with the cheap plan's pointers
+      p->step_graphs.clear();
+    }
+    if (timing)
+      fprintf(stderr, "  plan: the dealt plan (%.3f s on its own threads) swapped in, %.3f s to bind and upload it\n", task->seconds,
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+  drop_plan_task(p);
+  return rc;
+}
+
 // device part of the damped step; lam_dev != nullptr: the damping is read from device memory (fused step)
 template <int NC>
 static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, bool compact = false) {
   const int ncp = p->ncp;
+  if (p->plan_task) {
+    const int rcs = maybe_swap_plan(p);
+    if (rcs) return rcs;
+  }
   RoctxRange range("cba:damped_step");
   {
     RoctxRange r2("cba:schur");

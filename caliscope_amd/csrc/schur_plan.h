@@ -229,7 +229,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
     if (cand.empty()) return;
     // one allocation each for what the job emits (growing them by doubling re-maps tens of megabytes under all the worker threads at once)
     job.obs.reserve((size_t)(tot_rec + tot_rec / 8) + 64);
-    job.codes.reserve((size_t)((double)tot_pairs * 1.7) + 256 * (size_t)NW);
+    job.codes.reserve((size_t)((double)tot_pairs * (prm.cheap ? 3.6 : 1.7)) + 256 * (size_t)NW);  // (1 / lane utilisation: ~0.7 dealt, ~0.35 in point order)
     // capacity of a key per unit of the cap t: rep thread slots per block, all helper slots of a camera
     std::vector<int> unit((size_t)nblk + g, rep);
     int active_slots = 0;

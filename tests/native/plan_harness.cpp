@@ -12,7 +12,7 @@ extern "C" {
 
 // acc_out: [n_tiles][64 n_waves][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
 int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int slots_per_wave, int lds_stride, int wave_pieces, int region_chunks,
-                int heavy_obs, int threads, int n_waves, int pair_cap, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
+                int heavy_obs, int threads, int n_waves, int pair_cap, int cheap, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
   cba::Reg2Params prm;
   prm.C = C; prm.P = P; prm.G = G; prm.g = g; prm.rep = rep; prm.chunk_cap = chunk_cap;
   // the kernel's staging layout (cba_kernels.h, Reg2Cfg): a wave stages slots_per_wave slots, lds_stride pieces apart, in a run of wave_pieces pieces (k_schur_reg3 pads it to whole loads)
@@ -20,6 +20,7 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
   const int zero_piece = (chunk_cap + slots_per_wave - 1) / slots_per_wave * prm.wave_pieces;
   prm.zero_piece = zero_piece;
   prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads; prm.n_waves = n_waves; prm.pair_cap = pair_cap;
+  prm.cheap = cheap != 0;  // the plan a handle starts with: one open chunk in point order, records in arrival order
   const long N = hps[P];
   std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
   cba::Reg2Plan plan;

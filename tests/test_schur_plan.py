@@ -20,7 +20,7 @@ def harness(tmp_path_factory):
                    check=True)
     lib = C.CDLL(str(out))
     lib.plan_replay.restype = C.c_int
-    lib.plan_replay.argtypes = [C.c_int] * 16 + [I32P, I32P, F64P, F64P, I64P]
+    lib.plan_replay.argtypes = [C.c_int] * 17 + [I32P, I32P, F64P, F64P, I64P]
     lib.bind_replay.restype = C.c_int
     lib.bind_replay.argtypes = [C.c_int] * 13 + [C.c_double, C.c_int, C.c_int, I32P, I32P, I32P, I32P, I32P, I32P, I32P, F64P, I32P]
     return lib
@@ -41,7 +41,7 @@ def _visibility(rng, n_cams, n_points, k_lo, k_hi, duplicates=0.0, unobserved=0.
     return np.concatenate(cams).astype(np.int32), np.asarray(starts, dtype=np.int32)
 
 
-def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_chunks=64, heavy_obs=0, layout="reg3", pair_cap=None):
+def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_chunks=64, heavy_obs=0, layout="reg3", pair_cap=None, cheap=False):
     P = len(hps) - 1
     G = -(-n_cams // gmax)
     g = -(-n_cams // G)
@@ -67,7 +67,7 @@ def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_ch
     stats = np.zeros(9, dtype=np.int64)
     if pair_cap is None:  # Reg3Cfg::PAIR_CAP
         pair_cap = 2 if layout == "wide" else 0
-    rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, threads // 64, pair_cap, hcam.ctypes.data_as(I32P),
+    rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, threads // 64, pair_cap, int(cheap), hcam.ctypes.data_as(I32P),
                          hps.ctypes.data_as(I32P), T.ctypes.data_as(F64P), acc.ctypes.data_as(F64P), stats.ctypes.data_as(I64P))
     assert rc == 0, rc
     return acc, stats, (G, g, rep)
@@ -175,6 +175,20 @@ def test_small_chunks_and_regions(harness):
     rng = np.random.default_rng(7)
     _check(harness, rng, 48, 700, 2, 12, 6, chunk_cap=64, region_chunks=4)   # many regions, caps rise in the leftover passes
     _check(harness, rng, 16, 50, 16, 16, 6, chunk_cap=40)                    # every point fills two fifths of a chunk
+
+
+def test_cheap_plan_sums_the_same_pairs(harness):
+    """Reg2Params::cheap — the plan a handle may start with while the dealt one is being made (CBA_PLAN=swap): one open chunk filled in point
+    order, records in arrival order.  Same sums, every pair once; fewer busy lanes and more LDS conflicts are its price."""
+    rng = np.random.default_rng(21)
+    _check(harness, rng, 64, 900, 2, 10, 6, cheap=True)
+    _check(harness, rng, 8, 300, 2, 8, 6, cheap=True)
+    _check(harness, rng, 20, 400, 1, 6, 6, cheap=True, duplicates=0.2, unobserved=0.1)
+    _check(harness, rng, 40, 500, 3, 9, 9, cheap=True)
+    _check(harness, rng, 48, 700, 2, 12, 6, chunk_cap=64, region_chunks=4, cheap=True)
+    _check(harness, rng, 64, 900, 2, 10, 6, gmax=32, layout="wide", cheap=True)  # (more than two pairs of a block per chunk: the kernel's in-loop code loads)
+    stats = _check(harness, rng, 64, 10000, 10, 10, 6, cheap=True)
+    assert stats[1] == 10000 * 55 and 0.3 < stats[1] / stats[2] < 0.68, stats[1] / stats[2]
 
 
 def test_heavy_points_are_left_to_their_own_kernel(harness):
