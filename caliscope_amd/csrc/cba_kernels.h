@@ -1805,15 +1805,18 @@ __global__ void k_unprime(double* __restrict__ Sacc, const double* __restrict__ 
   }
 }
 
-// Reduce the partials of k_schur_reg over the workgroups of each tile (fixed order).  blockDim = (64, 4) as
-// k_tile_reduce: x walks the per-thread partial entries, y splits the workgroups four ways.  Off-diagonal
-// blocks go straight into Sacc; the helper-thread entries of diagonal tiles are parked in `red` and folded per
-// camera by k_reg_fold.
-__global__ void __launch_bounds__(256)
+// Reduce the partials of k_schur_reg over the workgroups of each tile (fixed order).  blockDim = (64, Y): x walks the per-thread partial entries,
+// y splits the partial rows of the tile Y ways, Y = 4 or REG_REDUCE_Y_MAX = 16 (the caller's choice: a small rig has ONE tile and up to 500 partial
+// rows — with four ways that is 60 dependent load-add steps per thread, 13 us of cfg2's iteration, 7 with sixteen; cfg4 has 51 rows per tile and
+// is 3 us faster with four).  Off-diagonal blocks go straight into Sacc; the helper-thread entries of diagonal tiles are parked in `red` and
+// folded per camera by k_reg_fold.
+constexpr int REG_REDUCE_Y_MAX = 16;
+__global__ void __launch_bounds__(64 * REG_REDUCE_Y_MAX)
 k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
              double* __restrict__ Sacc, double* __restrict__ red) {
-  __shared__ double sh[4][64];
+  const int Y = (int)blockDim.y;  // 4 or 16
+  __shared__ double sh[REG_REDUCE_Y_MAX][64];
   const int t = blockIdx.y;
   const int ga = tp.tile_a[t], gb = tp.tile_b[t];
   const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
@@ -1833,16 +1836,17 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
   double s0 = 0.0, s1 = 0.0;
   if (dst != -1) {
     int w = w0 + threadIdx.y;
-    for (; w + 4 < w1; w += 8) {
+    for (; w + Y < w1; w += 2 * Y) {
       s0 += partial[(long)w * tp.tile_elems + e];
-      s1 += partial[(long)(w + 4) * tp.tile_elems + e];
+      s1 += partial[(long)(w + Y) * tp.tile_elems + e];
     }
     if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
   }
   sh[threadIdx.y][threadIdx.x] = s0 + s1;
   __syncthreads();
   if (threadIdx.y != 0 || dst == -1) return;
-  const double tot = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  double tot = 0.0;
+  for (int y = 0; y < Y; y += 4) tot += (sh[y][threadIdx.x] + sh[y + 1][threadIdx.x]) + (sh[y + 2][threadIdx.x] + sh[y + 3][threadIdx.x]);
   if (dst >= 0) Sacc[dst] = tot;
   else red[(long)ga * tp.tile_elems + e] = tot;
 }

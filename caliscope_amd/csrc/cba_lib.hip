@@ -154,6 +154,7 @@ struct cba_problem {
   bool have_x0 = false;
   std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
   struct PlanTask* plan_task = nullptr;  // CBA_PLAN=swap: the thread still dealing the Schur plan while the handle works with the cheap one
+  int reg_reduce_y = 4;                  // y extent of k_reg_reduce's workgroups (4 or 16: by the partial rows per tile)
   int plan_max_blocks = 0;               // workgroup budget of the pair kernel (the dealt plan is bound with the same one when it is swapped in)
   size_t partial_capacity = 0;           // doubles behind `partial`
   bool plan_is_cheap = false;
@@ -877,6 +878,11 @@ static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Param
   TRYP(dev_upload(p, &p->tile_wg_begin, bind.wgb));
 #undef TRYP
   p->h_tile_wg_begin = bind.wgb;
+  {  // k_reg_reduce splits a tile's partial rows 4 or 16 ways
+    int rows = 0;
+    for (int t = 0; t < nT; ++t) rows = std::max(rows, (bind.wgb[t + 1] - bind.wgb[t]) * std::max(prm.rep, 1));
+    p->reg_reduce_y = rows > 96 ? REG_REDUCE_Y_MAX : 4;
+  }
   lap("upload");
   TilePlan tp{};
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
@@ -1867,7 +1873,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     // (fold + unprime + finalize as ONE kernel, a thread per camera pair, measured slower than the three launches: 42 instead of 31 us — 2080 threads
     // with 36 entries each against 147k threads with one)
     if (p->schur_reg) {
-      hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
+      hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, p->reg_reduce_y), 0, p->stream, p->tp,
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
       hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                          p->cam_off, p->cam_np, NC, ncp, p->Sacc);
