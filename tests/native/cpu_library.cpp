@@ -7,14 +7,24 @@
 // scaling) on DENSE matrices; the trust-region primitives are those of dense_engine.cpp (included below), the damped step
 // eliminates the points of an envelope Cholesky of J^T J + lam D^2 and solves the reduced camera system.  Sizes: test scenes
 // (n <~ 3000 parameters).  No device and no RCCL; cba_group_* joins handles of one process (one host thread each) into a
-// point-sharded solve with a host all-reduce, the protocol of the device build.  cba_triangulate is not available.
+// point-sharded solve with a host all-reduce, the protocol of the device build, and cba_comm_* does the same between processes over a
+// unix-domain socket (the launcher route of bench.py).  cba_triangulate is not available.
 #define CBA_CPU_LIBRARY 1
 #include "dense_engine.cpp"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
+#include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
+
+#include <sys/socket.h>
+#include <sys/time.h>
+#include <sys/un.h>
+#include <unistd.h>
 
 #include "../../caliscope_amd/csrc/ba_math.h"
 #include "../../caliscope_amd/csrc/host_plan.h"
@@ -290,10 +300,94 @@ int cba_get_timers(cba_problem*, double* ms, int64_t* calls) { for (int i = 0; i
 int cba_reset_timers(cba_problem*) { return CBA_OK; }
 int cba_enable_timers(cba_problem*, int32_t) { return CBA_OK; }
 
-// RCCL has no CPU counterpart ...
-int cba_comm_unique_id(char* out128) { std::memset(out128, 0, 128); return CBA_OK; }
-int cba_comm_init(cba_problem*, const char*, int32_t rank, int32_t world) {
-  return (world == 1 && rank == 0) ? CBA_OK : failf(CBA_ERR_UNSUPPORTED, "the CPU test build of the C ABI has no RCCL: one rank per communicator (use a cba_group)");
+// RCCL has no CPU counterpart.  Between PROCESSES (what `python -m torch.distributed.run` starts) the test build offers the same call shape instead
+// — rank 0 makes a 128-byte id, every rank calls cba_comm_init with it — over a unix-domain socket the id names: rank 0 listens, folds the ranks'
+// buffers in rank order and answers.  It exists so that bench.py's launcher branch (control plane, id broadcast, sharding per rank, max over ranks)
+// runs end to end on a GPU-less machine; it is test plumbing, not a transport.
+struct ProcComm {
+  int rank = 0, world = 1, listener = -1;
+  std::vector<int> fd;  // rank 0: fd[r] of rank r; other ranks: fd[0] to rank 0
+  std::string path;
+  std::vector<double> tmp;
+  ~ProcComm() {
+    for (int f : fd) if (f >= 0) ::close(f);
+    if (listener >= 0) { ::close(listener); ::unlink(path.c_str()); }
+  }
+  static bool send_all(int f, const void* buf, size_t n) {
+    const char* c = static_cast<const char*>(buf);
+    while (n) { const ssize_t k = ::send(f, c, n, MSG_NOSIGNAL); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+  }
+  static bool recv_all(int f, void* buf, size_t n) {
+    char* c = static_cast<char*>(buf);
+    while (n) { const ssize_t k = ::recv(f, c, n, 0); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+  }
+  int all_reduce(double* buf, int n_sum, int n_max) {
+    const int n = n_sum + n_max;
+    if (rank != 0) {
+      const int32_t hdr[2] = {n_sum, n_max};
+      if (!send_all(fd[0], hdr, sizeof hdr) || !send_all(fd[0], buf, sizeof(double) * n) || !recv_all(fd[0], buf, sizeof(double) * n)) return 1;
+      return 0;
+    }
+    tmp.resize((size_t)n);
+    for (int r = 1; r < world; ++r) {  // rank order: every replica gets the same bits
+      int32_t hdr[2];
+      if (!recv_all(fd[r], hdr, sizeof hdr) || hdr[0] != n_sum || hdr[1] != n_max || !recv_all(fd[r], tmp.data(), sizeof(double) * n)) return 1;
+      for (int j = 0; j < n; ++j) buf[j] = j < n_sum ? buf[j] + tmp[j] : std::fmax(buf[j], tmp[j]);
+    }
+    for (int r = 1; r < world; ++r)
+      if (!send_all(fd[r], buf, sizeof(double) * n)) return 1;
+    return 0;
+  }
+};
+
+int cba_comm_unique_id(char* out128) {
+  static std::atomic<int> counter{0};
+  std::memset(out128, 0, 128);
+  std::snprintf(out128, 100, "/tmp/cba_cpu_comm_%d_%d_%lld", (int)::getpid(), counter++,
+                (long long)std::chrono::steady_clock::now().time_since_epoch().count());
+  return CBA_OK;
+}
+int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world) {
+  if (!p || !id128 || world < 1 || rank < 0 || rank >= world) return failf(CBA_ERR_INVALID, "cba_comm_init: bad arguments");
+  if (world == 1) return CBA_OK;
+  auto comm = std::make_shared<ProcComm>();
+  comm->rank = rank; comm->world = world; comm->path.assign(id128, strnlen(id128, 100));
+  sockaddr_un addr{};
+  addr.sun_family = AF_UNIX;
+  std::snprintf(addr.sun_path, sizeof addr.sun_path, "%s", comm->path.c_str());
+  const timeval tv{120, 0};
+  if (rank == 0) {
+    comm->listener = ::socket(AF_UNIX, SOCK_STREAM, 0);
+    if (comm->listener < 0 || ::bind(comm->listener, reinterpret_cast<sockaddr*>(&addr), sizeof addr) || ::listen(comm->listener, world))
+      return failf(CBA_ERR_INVALID, "cba_comm_init (CPU test build): cannot listen on %s", comm->path.c_str());
+    ::setsockopt(comm->listener, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);  // (accept gives up after two minutes: a rank that never came)
+    comm->fd.assign((size_t)world, -1);
+    for (int k = 1; k < world; ++k) {
+      const int f = ::accept(comm->listener, nullptr, nullptr);
+      int32_t r = -1;
+      if (f < 0) return failf(CBA_ERR_INVALID, "cba_comm_init (CPU test build): a rank did not connect");
+      ::setsockopt(f, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+      if (!ProcComm::recv_all(f, &r, sizeof r) || r < 1 || r >= world || comm->fd[(size_t)r] >= 0) { ::close(f); return failf(CBA_ERR_INVALID, "cba_comm_init (CPU test build): bad rank on the wire"); }
+      comm->fd[(size_t)r] = f;
+    }
+  } else {
+    const int f = ::socket(AF_UNIX, SOCK_STREAM, 0);
+    if (f < 0) return failf(CBA_ERR_INVALID, "cba_comm_init (CPU test build): socket");
+    comm->fd.assign(1, f);
+    bool ok = false;
+    for (int attempt = 0; attempt < 6000 && !ok; ++attempt) {  // rank 0 may not be listening yet
+      ok = ::connect(f, reinterpret_cast<sockaddr*>(&addr), sizeof addr) == 0;
+      if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    ::setsockopt(f, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    const int32_t r = rank;
+    if (!ok || !ProcComm::send_all(f, &r, sizeof r)) return failf(CBA_ERR_INVALID, "cba_comm_init (CPU test build): rank %d could not reach rank 0 at %s", rank, comm->path.c_str());
+  }
+  p->reduce = [comm](double* buf, int n_sum, int n_max) { return comm->all_reduce(buf, n_sum, n_max); };
+  p->lead = rank == 0;
+  return CBA_OK;
 }
 
 int cba_comm_abort(cba_problem*) { return CBA_OK; }

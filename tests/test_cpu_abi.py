@@ -20,7 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 @pytest.fixture(scope="module")
 def cpu_lib(tmp_path_factory):
     out = tmp_path_factory.mktemp("cpuabi") / "libcaliscope_ba_cpu.so"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", str(ROOT / "include"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I", str(ROOT / "include"),
                     str(ROOT / "tests" / "native" / "cpu_library.cpp"), str(ROOT / "caliscope_amd" / "csrc" / "cba_solve.cpp"),
                     "-o", str(out)], check=True)
     return out
@@ -373,3 +373,34 @@ def test_bench_starts_its_own_ranks_without_a_launcher(cpu_lib):
     assert one["n_gpus"] == 1 and abs(two["final_rms_px"] - one["final_rms_px"]) < 1e-6 and two["solve"]["status"] > 0
     assert abs(two["value"] - 450 / (two["ms_per_step"] * 1e-3)) < 1e-2 * two["value"]
     assert "1 HIP device" in out["refused"] and "--gpus 3" in out["refused"]  # fewer devices than ranks: a clear message, no hang
+
+
+def test_bench_under_the_launcher_one_process_per_rank(cpu_lib):
+    """The driver's multi-GPU command — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...` — with two ranks: RANK / WORLD_SIZE / LOCAL_RANK from the launcher, the host-side control plane finds its own port
+    (MASTER_PORT belongs to the launcher's store), rank 0's communicator id travels over it, every rank solves its shard, rank 0 prints the one
+    line.  The CPU build's cba_comm_* stands in for RCCL (a unix-domain socket between the processes); everything above the C ABI is the code
+    that runs on the GPUs."""
+    pytest.importorskip("torch")
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, CALISCOPE_BA_LIB=str(cpu_lib), PYTHONPATH=str(ROOT))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CBA_HOST_LOOP", "CBA_CONTROL_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "4", "--warmup", "1", "--no-cpu", "--also", ""]
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rccl_ranks"] == 2 and d["steps"] == 4
+    assert "2 processes (launcher)" in d["config"]["parallelism"] and d["config"]["n_obs_total"] == 450
+    assert abs(d["value"] - 450 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["solve"]["status"] > 0 and abs(d["final_rms_px"] - 0.5) < 0.5  # converged on the sharded problem (the single-rank figure: the test above)
+    single = json.loads(subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--workload", "tiny", "--steps", "4", "--warmup", "1", "--no-cpu",
+                                        "--also", ""], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300, check=True).stdout.strip().splitlines()[-1])
+    assert abs(d["final_rms_px"] - single["final_rms_px"]) < 1e-6 and d["solve"]["nfev"] == single["solve"]["nfev"]
