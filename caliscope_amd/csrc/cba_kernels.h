@@ -1939,15 +1939,34 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
                                  const double* __restrict__ sinv, const int* __restrict__ param_cam,
                                  const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ lam_dev,
                                  const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
-                                 double* __restrict__ W, int ldw) {
+                                 double* __restrict__ W, int ldw, const double* __restrict__ red = nullptr, int g = 0, long tile_elems = 0,
+                                 const int* __restrict__ group_cam_begin = nullptr) {
   using UP = UPack<NC>;
   if (lam_dev) lam = *lam_dev;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)ncp * ncp) return;
   const int row = (int)(t / ncp), col = (int)(t % ncp);
   if (col < row) return;
-  double v = -Sacc[(long)row * ncp + col];
-  if (param_cam[row] == param_cam[col]) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
+  const bool same_cam = param_cam[row] == param_cam[col];
+  double v;
+  if (red && same_cam) {
+    // red != nullptr (single rank, no heavy points, no constraint rows): the diagonal camera blocks are folded HERE from the helper-thread sums
+    // k_reg_reduce parked in `red` (what k_reg_fold does — one launch less; Sacc's diagonal blocks are then never written nor read)
+    const int cam = param_cam[row], ga = cam / g, ca0 = group_cam_begin[ga], na = group_cam_begin[ga + 1] - ca0;
+    const double* src = red + (long)ga * tile_elems + param_loc[row] * NC + param_loc[col];
+    double sum = 0.0;
+    for (int k = cam - ca0; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj
+      int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
+      while (li * (li + 1) / 2 > k) --li;
+      while ((li + 1) * (li + 2) / 2 <= k) ++li;
+      const int lj = k - li * (li + 1) / 2;
+      sum += src[(long)(li * g + lj) * (NC * NC)];
+    }
+    v = -sum;
+  } else {
+    v = -Sacc[(long)row * ncp + col];
+  }
+  if (same_cam) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
   if (row == col) {
     v += lam * sinv[row] * sinv[row] + cam_diag[row];  // cam_diag: zero unless the caller set a bound scaling
     const double rv = -gvec[row] + bacc[row];
@@ -2813,6 +2832,32 @@ k_step_finish(const double* __restrict__ partial, int rows, double* __restrict__
       for (int i = 0; i < BLOCK / WAVE; ++i) r += sh_red[j][i];
       scal[16 + j] = r;
     }
+    fused_subspace(scal, flags, fz);
+  }
+}
+
+// Small problems (a few thousand parameters: the reference's own sessions, cfg2): k_step_scalars and k_step_finish as ONE workgroup — the sums
+// over the whole vector by 1024 threads, then the subspace step — one launch (~4 us) less per iteration.
+constexpr int STEP_SMALL_THREADS = 1024;
+constexpr long STEP_SMALL_MAX = 32768;  // parameters (32 per thread)
+__global__ void __launch_bounds__(STEP_SMALL_THREADS)
+k_step_small(const double* __restrict__ g, const double* __restrict__ sinv, const double* __restrict__ s, long total, double* __restrict__ scal,
+             const int* __restrict__ flags, double* __restrict__ fz) {
+  __shared__ double sh_red[2][STEP_SMALL_THREADS / WAVE];
+  double s0 = 0.0, s1 = 0.0;
+  for (long i = threadIdx.x; i < total; i += STEP_SMALL_THREADS) {
+    const double p = s[i] * sinv[i];
+    s0 += p * p;
+    s1 += g[i] * s[i];
+  }
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const double r0 = wave_sum(s0), r1 = wave_sum(s1);
+  if (lane == 0) { sh_red[0][w] = r0; sh_red[1][w] = r1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < STEP_SMALL_THREADS / WAVE; ++i) { a += sh_red[0][i]; b += sh_red[1][i]; }
+    scal[16] = a; scal[17] = b; scal[18] = 0.0; scal[19] = 0.0;
     fused_subspace(scal, flags, fz);
   }
 }

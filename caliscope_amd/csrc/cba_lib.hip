@@ -189,6 +189,7 @@ struct cba_problem {
 // mode notwithstanding.  The recording takes this lock exclusively; every entry point that talks to the device holds it
 // shared, so handles run concurrently across threads and only wait while another thread records its graph (once per handle).
 static int ensure_cholesky_graph(cba_problem* p);
+static bool cholesky_as_graph();
 static std::shared_mutex g_capture_mu;
 static thread_local int tl_capture_safe_depth = 0;
 struct CaptureSafe {  // shared side; nests within a thread (entry point -> helper)
@@ -1334,7 +1335,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 #undef TRY
   p->h_vec.resize((size_t)tot);
   lap("solver buffers");
-  if (!p->eval_only && !p->want_chol_trace) {
+  if (cholesky_as_graph() && !p->eval_only && !p->want_chol_trace) {
     rc = ensure_cholesky_graph(p);
     if (rc) return bail(rc);
   }
@@ -1620,9 +1621,15 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
   return CBA_OK;
 }
 
-// The dense solve is ~26 small dependent launches; enqueued one by one the GPU waits on the host between
-// them (the stream was just drained by the previous primitive).  Nothing in the sequence changes from call
-// to call (same buffers, same n), so it is captured once into a hipGraph and replayed.
+// The dense solve is ncp / 32 + 2 small dependent launches.  Rounds 1-2 replayed them from a hipGraph recorded at create time: every primitive
+// then began on a drained stream and the GPU waited on the host between the launches.  Since the fused iteration keeps the host a whole
+// iteration ahead of the device, plain launches are the faster form — round 3, MI355X / ROCm 7.2, per iteration: cfg2 139 against 149 us,
+// cfg3 177 against 188, cfg4 645 against 654, cfg5 the same (the kernel behind a graph launch starts ~10 us late) — and a handle no longer
+// pays for the recording.  CBA_CHOL_GRAPH=1 brings the graph back.
+static bool cholesky_as_graph() {
+  static const bool on = [] { const char* e = std::getenv("CBA_CHOL_GRAPH"); return e && e[0] == '1'; }();
+  return on;
+}
 static int enqueue_cholesky(cba_problem* p) {
   const int n = p->ncp, nbk = (n + NB - 1) / NB;
   for (int k = -1; k < nbk; ++k) {
@@ -1681,6 +1688,10 @@ static int run_cholesky(cba_problem* p) {
     return CBA_OK;
   }
   if (p->capturing) return enqueue_cholesky(p);  // inside the recording of a step graph: its launches become nodes of that graph
+  if (!cholesky_as_graph()) {
+    ScopedTimer t(p, T_CHOLESKY);
+    return enqueue_cholesky(p);
+  }
   int rcg = ensure_cholesky_graph(p);
   if (rcg) return rcg;
   ScopedTimer t(p, T_CHOLESKY);
@@ -1696,6 +1707,11 @@ static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   const long first = (p->rank == 0) ? 0 : p->lay.ncp_pad;  // replicated camera entries are counted on rank 0 only
+  static const bool small_env = [] { const char* e = std::getenv("CBA_STEP_SMALL"); return !(e && e[0] == '0'); }();
+  if (compact && small_env && first == 0 && tot <= STEP_SMALL_MAX) {  // small problems: sums and subspace step by one workgroup, one launch
+    hipLaunchKernelGGL(k_step_small, dim3(1), dim3(STEP_SMALL_THREADS), 0, p->stream, p->g, p->sinv, p->s, tot, p->scal, (const int*)p->flags, p->fz);
+    return CBA_OK;
+  }
   hipLaunchKernelGGL(k_step_scalars, dim3(vg), dim3(BLOCK), 0, p->stream, p->g, p->sinv, p->s, tot, first, p->partial4);
   if (compact) {  // single-rank fused step: the reduction and the subspace step in one launch
     hipLaunchKernelGGL(k_step_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, p->scal, (const int*)p->flags, p->fz);
@@ -1868,6 +1884,10 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
                          p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
   }
+  // single rank, nothing else adds to the diagonal camera blocks (heavy points, constraint rows) and the pair kernel has unprimed its sums: k_schur_finalize
+  // folds the helper-thread sums of the diagonal blocks itself, k_reg_fold is not launched (CBA_FOLD=kernel: the separate launch)
+  static const bool fold_env = [] { const char* e = std::getenv("CBA_FOLD"); return !(e && std::strcmp(e, "kernel") == 0); }();
+  const bool fold_in_finalize = fold_env && p->schur_reg && p->schur_v3 && !p->n_heavy && !p->con.n_con && !p->sharded();
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
     // (fold + unprime + finalize as ONE kernel, a thread per camera pair, measured slower than the three launches: 42 instead of 31 us — 2080 threads
@@ -1875,8 +1895,9 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     if (p->schur_reg) {
       hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, p->reg_reduce_y), 0, p->stream, p->tp,
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
-      hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
-                         p->cam_off, p->cam_np, NC, ncp, p->Sacc);
+      if (!fold_in_finalize)
+        hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
+                           p->cam_off, p->cam_np, NC, ncp, p->Sacc);
       if (!p->schur_v3)  // k_schur_reg3 unprimes its partial blocks itself (epilogue of schur_reg3_body)
         hipLaunchKernelGGL((k_unprime<NC>), dim3((p->C * p->C + 255) / 256), dim3(256), 0, p->stream, p->Sacc, p->tab, p->cam_off, p->cam_np, p->C, ncp);
       if (p->n_heavy)  // per-camera sums of the heavy points, one workgroup each (the pair plan skips them)
@@ -1899,7 +1920,8 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     }
     const long nn = (long)ncp * ncp;
     hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
-                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw);
+                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw,
+                       fold_in_finalize ? (const double*)p->red : (const double*)nullptr, p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin);
   }
   int rc;
   {
