@@ -83,12 +83,18 @@ def run_iterations(engine, k_steps, solve_kw):
     """Execute exactly k_steps trial iterations through cba_solve (the product's driver: the trust-region loop runs in
     the library, restarting from the x0 kept on the device); returns (n_solves, last_result)."""
     done, solves, last = 0, 0, None
+    mix = {"accepted": 0, "rejected": 0, "rejected_timed": 0, "rejected_s": 0.0}
     while done < k_steps:
         last = engine.solve(None, max_nfev=(k_steps - done) + 1, fetch_x=False, **solve_kw)
         done += last.nfev - 1
         solves += 1
+        mix["accepted"] += last.njev - 1
+        mix["rejected"] += last.nfev - last.njev
+        mix["rejected_timed"] += last.rejected_timed
+        mix["rejected_s"] += last.rejected_seconds
         if last.nfev <= 1:  # already converged at x0: nothing to iterate on
             break
+    last.mix = mix
     return solves, last
 
 
@@ -185,7 +191,7 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         "nct": 9 if any(b.n_params == 9 for b in par.blocks) else 6, "loss": prob.loss, "elapsed": elapsed, "steps": steps,
         "solves": solves, "timers": tm, "final_rms_px": rms, "initial_rms_px": rms0, "full_nfev": full.nfev,
         "full_status": full.status, "full_cost": full.cost, "info": info, "t_generate_s": t_gen,
-        "scene": sc, "par": par, "x0": x0, "x_full": full.x, "setup_s": t_setup, "rank": control.rank,
+        "scene": sc, "par": par, "x0": x0, "x_full": full.x, "setup_s": t_setup, "rank": control.rank, "mix": last.mix,
     }
 
 
@@ -287,7 +293,57 @@ def solution_parity(par, x_a, x_b, detail=False):
     return float(pos), float(ang)
 
 
-def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear", f_scale=1.0):
+def oracle_cost(sc, par, x, loss="linear", f_scale=1.0):
+    """0.5 * sum rho(f) at x from the ORACLE's residuals and scipy's own loss functions (nothing of the product involved)."""
+    from oracle.residuals import joint_residuals
+
+    f = joint_residuals(x, par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    if loss == "linear":
+        return 0.5 * float(f @ f)
+    from scipy.optimize._lsq.least_squares import construct_loss_function
+
+    return float(construct_loss_function(f.size, loss, f_scale)(f, cost_only=True))
+
+
+def oracle_polish(sc, par, x_product, loss="linear", f_scale=1.0, max_nfev=60, tight_inner=True):
+    """The independent direction of the converged-parity check: the REFERENCE's solver (oracle/solver.py = scipy on the
+    oracle callables) started AT the product's converged point with ftol = xtol = gtol = 1e-15.  If that point is the minimum, scipy has
+    nothing to gain: it must stop within a few evaluations, having moved (gauge-aligned) by far less than 1e-6 and lowered the cost by less
+    than 1e-12 relative.  Run twice: with scipy's default inner LSMR tolerance (1e-6, the reference's call) and, `tight_inner`, with
+    tr_options atol = btol = 1e-14 so that its steps are exact to rounding and it really tries to improve on the point."""
+    from oracle.solver import optimize_scipy
+
+    cost0 = oracle_cost(sc, par, x_product, loss, f_scale)
+    out = {"what": "scipy (oracle callables) started at the product's converged x, ftol = xtol = gtol = 1e-15", "cost_at_product_x": cost0}
+    ok = True
+    for name, tr in (("lsmr_default", None), ("lsmr_tight", dict(atol=1e-14, btol=1e-14)))[: 2 if tight_inner else 1]:
+        t0 = time.perf_counter()
+        sp = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x_product, loss=loss, f_scale=f_scale,
+                            ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=max_nfev, tr_options=tr)
+        moved = solution_parity(par, sp.x, x_product, detail=True)
+        gain = (cost0 - float(sp.cost)) / cost0
+        out[name] = {"nfev": int(sp.nfev), "njev": int(sp.njev), "status": int(sp.status), "seconds": round(time.perf_counter() - t0, 2),
+                     "moved": moved, "rel_cost_gain": gain}
+        ok = ok and moved["aligned_pos"] <= 1e-6 and moved["aligned_ang_rad"] <= 1e-6 and gain <= 1e-12
+    out["scipy_moves_within_1e-6_and_gains_within_1e-12"] = bool(ok)
+    return out
+
+
+def stored_scipy_reference(case, x0):
+    """tests/golden/scipy_refs/<case>.npz (tests/golden/make_scipy_refs.py: the reference's scipy call run on the CPU, minutes at these sizes)
+    when it was made from this very x0, else None."""
+    try:
+        sys.path.insert(0, str(ROOT / "tests" / "golden"))
+        import make_scipy_refs
+
+        return make_scipy_refs.load(case, x0)
+    except Exception:  # noqa: BLE001 - an optional fixture
+        return None
+    finally:
+        sys.path.pop(0)
+
+
+def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear", f_scale=1.0, stored=None):
     """The reference's scipy call (oracle callables, one host core) and the product on the SAME arrays and x0:
     returns (cpu_baseline block, parity block).  `x_gpu_solve`: a solution the device already produced from these arrays (the
     headline's full solve), or None — the solution of the seam call below is compared then.  Either way the arrays also go
@@ -298,9 +354,18 @@ def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear",
     from oracle.residuals import joint_residuals
     from oracle.solver import optimize_scipy
 
-    t0 = time.perf_counter()
-    res = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, loss=loss, f_scale=f_scale)
-    dt = time.perf_counter() - t0
+    # `stored` = (default-tolerance case, tight case) of tests/golden/scipy_refs: scipy solutions of these very arrays computed beforehand
+    ref_default = stored_scipy_reference(stored[0], x0) if stored else None
+    ref_tight = stored_scipy_reference(stored[1], x0) if stored else None
+    if ref_default is not None:
+        from types import SimpleNamespace
+
+        res = SimpleNamespace(x=ref_default["x"], nfev=ref_default["nfev"], status=ref_default["status"], cost=ref_default["cost"])
+        dt = float(ref_default["seconds"])
+    else:
+        t0 = time.perf_counter()
+        res = optimize_scipy(par, sc.camera_indices, sc.image_coords, sc.obj_indices, x0, loss=loss, f_scale=f_scale)
+        dt = time.perf_counter() - t0
     iters = max(res.nfev - 1, 1)
     engine_cache.clear()  # a cold call: the handle is built inside the timed call
     t1 = time.perf_counter()
@@ -338,11 +403,23 @@ def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear",
         "rel_cost_scipy_above_minimum": (float(res.cost) - float(near.cost)) / float(near.cost),
         "nfev": {"from_x0": int(mine.nfev), "from_scipy_x": int(near.nfev)},
     }
-    cost_gpu = 0.5 * float(np.sum(joint_residuals(x_cmp, par, sc.camera_indices, sc.image_coords, sc.obj_indices) ** 2)) if loss == "linear" else float(gpu.cost)
+    cost_gpu = oracle_cost(sc, par, x_cmp, loss, f_scale)
+    # the independent direction: scipy restarted at the product's tight solution (tight inner solves where a matrix-vector product is cheap)
+    opolish = oracle_polish(sc, par, mine.x, loss, f_scale, tight_inner=sc.n_obs <= 1_200_000)
+    tight_ref = None
+    if ref_tight is not None:  # SURVEY.md 7 protocol (iii): scipy at ftol = xtol = gtol = 1e-15 from the same x0, against the product at 1e-13
+        d = solution_parity(par, mine.x, ref_tight["x"], detail=True)
+        c_mine = oracle_cost(sc, par, mine.x, loss, f_scale)
+        tight_ref = {"what": "product at 1e-13 from x0 against scipy at 1e-15 (inner LSMR 1e-14) from x0, tests/golden/scipy_refs/" + stored[1],
+                     "scipy": {k: ref_tight[k] for k in ("nfev", "njev", "status", "cost", "seconds", "settings")},
+                     "detail": d, "d_rms_px": rms(mine.x) - rms(ref_tight["x"]), "rel_cost": (c_mine - float(ref_tight["cost"])) / float(ref_tight["cost"]),
+                     "within_north_star": bool(d["aligned_pos"] <= 1e-6 and d["aligned_ang_rad"] <= 1e-6
+                                               and abs(rms(mine.x) - rms(ref_tight["x"])) <= 1e-4)}
     base = {
         "value": round(sc.n_obs * iters / dt, 1), "unit": "obs/s", "cores": 1, "kind": "port",
         "sample": f"{label}, scipy least_squares trf+lsmr, default tolerances: "
-                  f"{res.nfev} evaluations in {dt:.1f} s; host has {os.cpu_count()} cores, the scipy path is single-threaded",
+                  f"{res.nfev} evaluations in {dt:.1f} s; host has {os.cpu_count()} cores, the scipy path is single-threaded"
+                  + (f" (solution and time stored beforehand: tests/golden/scipy_refs/{stored[0]}.npz)" if ref_default is not None else ""),
         "seconds": round(dt, 2), "nfev": int(res.nfev), "status": int(res.status), "cost": float(res.cost), "final_rms_px": round(rms_cpu, 6),
     }
     gpu_iters = max(gpu.nfev - 1, 1)
@@ -358,6 +435,8 @@ def _scipy_vs_product(sc, par, x0, x_gpu_solve, device_id, label, loss="linear",
         "aligned_pos": pos, "aligned_ang_rad": ang, "detail": solution_parity(par, x_cmp, res.x, detail=True),
         "within_north_star": bool(abs(rms_gpu - rms_cpu) <= 1e-4 and pos <= 1e-6 and ang <= 1e-6),
         "polish": polish,
+        "oracle_polish": opolish,
+        "tight_reference": tight_ref,
         "same_minimum_within_north_star": bool(abs(polish["d_rms_px"]) <= 1e-4 and polish["same_minimum"]["aligned_pos"] <= 1e-6
                                                and polish["same_minimum"]["aligned_ang_rad"] <= 1e-6),
         "value_ratio_gpu_end_to_end_over_cpu": round(sc.n_obs * gpu_iters / dt_gpu / (sc.n_obs * iters / dt), 1),
@@ -386,17 +465,39 @@ def cfg5_sample_parity(device_id=0, n_points=10_000):
     sc = make_scene("cfg5-sample", n_cams=128, n_points=n_points, n_obs=10 * n_points, refine=True)
     par = BundleParameterization.from_camera_array(sc.cameras_init, n_points=n_points, refine_intrinsics=True)
     x0 = par.pack(sc.cameras_init, sc.points_init)
+    stored = {10_000: ("cfg5s100k_default", "cfg5s100k_tight"), 100_000: ("cfg5s1M_default", "cfg5s1M_tight")}.get(n_points)
     base, parity = _scipy_vs_product(sc, par, x0, None, device_id,
-                                     f"cfg5 recipe sample: 128 cams / {n_points} points / {10 * n_points} obs, refine_intrinsics=True, bounds")
+                                     f"cfg5 recipe sample: 128 cams / {n_points} points / {10 * n_points} obs, refine_intrinsics=True, bounds",
+                                     stored=stored)
     parity["scipy"] = {k: base[k] for k in ("seconds", "nfev", "status", "cost", "final_rms_px")}
     return parity
 
 
+def step_mix(m):
+    """The timed region's steps by kind.  A step of the metric is one trial point; an ACCEPTED step costs a whole iteration (linearisation,
+    Schur pass, dense solve, back-substitution, trial build), a rejected trial evaluated by a call of its own (cba_trial) one cost pass.  The
+    driver times those calls (cba_result.t_rejected_s); a rejected FIRST trial of a fused iteration was built inside cba_step and costs what
+    an accepted one costs, so it counts with the accepted ones here."""
+    mix = m["mix"]
+    full_iters = mix["accepted"] + mix["rejected"] - mix["rejected_timed"]
+    t_full = max(m["elapsed"] - mix["rejected_s"], 0.0)
+    return {
+        "accepted_steps": mix["accepted"], "rejected_trials": mix["rejected"], "rejected_trials_timed": mix["rejected_timed"],
+        "ms_per_accepted_step": round(t_full / full_iters * 1e3, 4) if full_iters else None,
+        "ms_per_rejected_trial": round(mix["rejected_s"] / mix["rejected_timed"] * 1e3, 4) if mix["rejected_timed"] else None,
+    }
+
+
 def _also_block(a, name):
     rf = roofline_from(a)
+    sm = step_mix(a)
+    per_acc = sm["ms_per_accepted_step"]
     return {
-        "value": round(a["n_obs"] * a["steps"] / a["elapsed"], 1), "unit": "obs/s",
-        "ms_per_step": round(a["elapsed"] / a["steps"] * 1e3, 4), "final_rms_px": round(a["final_rms_px"], 6),
+        # accepted iterations only: with K small the first Huber evaluations from x0 are mostly rejected trials (a 25 us cost pass each), and a
+        # "step" averaged over that mix says nothing about the iteration (cfg3: 0.077 ms at K = 20 against 0.177 ms at K = 40 in round 3)
+        "value": round(a["n_obs"] / (per_acc * 1e-3), 1) if per_acc else None, "unit": "obs/s",
+        "ms_per_step": per_acc, "timed_region": {**sm, "steps": a["steps"], "ms_per_step_mixed": round(a["elapsed"] / a["steps"] * 1e3, 4)},
+        "final_rms_px": round(a["final_rms_px"], 6),
         "workload": f"{a['n_cams']} cams / {a['n_points']} points / {a['n_obs']} obs, {a['loss']} loss",
         "nfev": a["full_nfev"], "status": a["full_status"], "accepted_steps": a["full_njev"] - 1,
         "rejected_trials": a["full_nfev"] - a["full_njev"], "initial_rms_px": round(a["initial_rms_px"], 4),
@@ -444,6 +545,12 @@ def run_ranks_in_process(args, devices, xchg):
         real = [(r, e) for r, e in failed if "BrokenBarrier" not in type(e).__name__] or failed
         raise RuntimeError(f"rank {real[0][0]} of {world} failed: {real[0][1]!r}") from real[0][1]
     return records
+
+
+def _source_digest():
+    from caliscope_amd.build import source_digest
+
+    return source_digest()
 
 
 def main(argv=None):
@@ -557,10 +664,12 @@ def _run(argv):
         "final_rms_px": round(m["final_rms_px"], 6),
         "initial_rms_px": round(m["initial_rms_px"], 4),
         # accepted iterations re-linearise (njev - 1 of them after x0); the other trial points were rejected
+        "timed_region": step_mix(m),
         "solve": {"nfev": m["full_nfev"], "njev": m["full_njev"], "accepted_steps": m["full_njev"] - 1,
                   "rejected_trials": m["full_nfev"] - m["full_njev"], "status": m["full_status"], "cost": m["full_cost"]},
         "roofline": roofline_from(m),
         "engine": m["info"],
+        "library_source_sha256": _source_digest(),  # the code this line was measured on (profiles/parity_r*.json carries the same field)
     }
     if not args.no_cpu and rank == 0 and world == 1:
         try:

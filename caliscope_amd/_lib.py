@@ -82,6 +82,7 @@ class Result(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("reserved", C.c_int32), ("nfev", C.c_int64), ("njev", C.c_int64), ("n_iterations", C.c_int64),
         ("cost", C.c_double), ("optimality", C.c_double), ("t_total_s", C.c_double),
+        ("t_rejected_s", C.c_double), ("n_rejected_timed", C.c_int64),
     ]
 
 

@@ -33,6 +33,18 @@ def needs_build() -> bool:
     return any(p.stat().st_mtime > t for p in SOURCES + DEPENDS)
 
 
+def source_digest() -> str:
+    """sha256 over the sources the library is built from (names and bytes, fixed order): what identifies "the final library" in the committed
+    measurements (profiles/parity_r*.json and r*_end_bench.json must carry the same one, tests/test_bench_contract.py)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(SOURCES + DEPENDS, key=lambda q: q.name):
+        h.update(path.name.encode())
+        h.update(path.read_bytes())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return OUT

@@ -130,6 +130,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
 
   auto not_finite_at_x0 = [&](double c) {  // scipy raises "Residuals are not finite in the initial point": status -1, nothing solved
     out->status = -1; out->reserved = 0; out->nfev = 1; out->njev = 0; out->n_iterations = 0; out->cost = c; out->optimality = NAN;
+    out->t_rejected_s = 0.0; out->n_rejected_timed = 0;
     out->t_total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return CBA_OK;
   };
@@ -148,6 +149,8 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if (!(cb.x[i] > cb.lb[i] && cb.x[i] < cb.ub[i])) return cba_set_error(CBA_ERR_INVALID, "cba_solve: x0 is not strictly inside the bounds");
   }
   long nfev = 1, njev = 1, iteration = 0;
+  double t_rejected = 0.0;   // wall time of the separate trial evaluations that were rejected (bench.py: ms per rejected trial)
+  long n_rejected_timed = 0;
   int n_truncated = 0, n_reflected = 0, n_gradient = 0;  // which candidate select_step took when the step left the bounds
   // Fused iterations (cba_step): linearisation, damping, damped step, subspace step and first trial behind ONE host
   // synchronisation; the trial is evaluated by a build pass, so an accepted step needs no further pass.  A rejected
@@ -267,7 +270,10 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       const double alpha = pS[0] / gh_norm - beta * c;
       double predicted = -(quad_p + lin_p), step_h_norm = std::hypot(pS[0], pS[1]);
       cba_trial_info tr;
+      const auto t_trial = std::chrono::steady_clock::now();
+      bool own_call = true;  // this trial is evaluated by a call of its own (cba_step brought the first one)
       if (first_pass && first_trial_ready) {
+        own_call = false;
         tr = si.trial; predicted = si.predicted;  // the trial cba_step already evaluated
       } else if (!bounded) {
         if ((rc = calls.run("trial", [&] { return cba_trial(p, alpha, beta, &tr); }))) return rc;
@@ -351,9 +357,11 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       ++nfev;
       const bool was_first = first_pass;
       first_pass = false;
-      if (!tr.finite) { radius = 0.25 * step_h_norm; if (was_first) fuse_next = false; continue; }
+      const double dt_trial = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_trial).count();
+      if (!tr.finite) { radius = 0.25 * step_h_norm; if (was_first) fuse_next = false; if (own_call) { t_rejected += dt_trial; ++n_rejected_timed; } continue; }
       cost_new = tr.cost;
       actual = cost - cost_new;
+      if (own_call && !(actual > 0)) { t_rejected += dt_trial; ++n_rejected_timed; }
       // speculate again only after an accepted first trial of a well-conditioned subspace (a collinear step needs the
       // explicit J.v model, which cba_step leaves to the host)
       if (was_first) fuse_next = fused && actual > 0 && w_sq > 1e-2 * st.p_sq;  // (cba_step needs w_sq > 1e-3 p_sq: hysteresis)
@@ -386,6 +394,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   out->nfev = nfev; out->njev = njev; out->n_iterations = iteration;
   out->cost = cost; out->optimality = g_norm;
   out->t_total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  out->t_rejected_s = t_rejected; out->n_rejected_timed = n_rejected_timed;
   calls.print(out->t_total_s, iteration);
   return CBA_OK;
 }

@@ -168,7 +168,8 @@ class HipEngine:
         self._check(self.lib.cba_solve(self._h, None if x_in is None else _dp(x_in), C.byref(opt), None if x_out is None else _dp(x_out),
                                        C.byref(res)), "cba_solve")
         return TrfResult(x=x_out, cost=res.cost, optimality=res.optimality, nfev=int(res.nfev), njev=int(res.njev), status=int(res.status),
-                         n_iterations=int(res.n_iterations))
+                         n_iterations=int(res.n_iterations), seconds=float(res.t_total_s), rejected_seconds=float(res.t_rejected_s),
+                         rejected_timed=int(res.n_rejected_timed))
 
     # -- parity hooks --------------------------------------------------------------------------------
     def get_vector(self, which: int) -> np.ndarray:

@@ -59,6 +59,9 @@ class TrfResult:
     njev: int
     status: int
     n_iterations: int = 0
+    seconds: float = 0.0            # wall time of the solve (cba_result.t_total_s)
+    rejected_seconds: float = 0.0   # of it: the separately evaluated trial points that were rejected (cba_result.t_rejected_s) ...
+    rejected_timed: int = 0         # ... and their number
     trace: list = field(default_factory=list)  # per outer iteration: dict(cost, g_norm, Delta, lam, nfev)
 
     @property

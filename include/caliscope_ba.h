@@ -244,6 +244,9 @@ typedef struct {
   double cost;                 /* 0.5 * sum rho(f) at the returned x                                           */
   double optimality;           /* ||J^T f||_inf at the returned x                                              */
   double t_total_s;            /* wall time of the call                                                        */
+  double t_rejected_s;         /* of it: wall time of the cba_trial / cba_trial_ex calls whose trial point was rejected (a cost pass  */
+  int64_t n_rejected_timed;    /*   each) and their number; a rejected FIRST trial of a fused iteration is not in here (it was built  */
+                               /*   inside cba_step): nfev - njev - n_rejected_timed of those                                          */
 } cba_result;
 
 /* x0 [n] (NULL: restart from the x0 of the previous cba_begin / cba_solve, kept on the device), opt (NULL: defaults),

@@ -362,7 +362,7 @@ def _solve_both(par, cam, uv, obj, x0, loss="linear", f_scale=1.0, **tol):
 
 @pytest.mark.parametrize("name", ["pinhole_locked_C8", "huber_outliers_C8", "global_atomics_C24", "pinhole_refine_C6"])
 def test_converged_parity_with_scipy(name):
-    from oracle.solver import rms_reprojection_px
+    from oracle.solver import optimize_scipy, rms_reprojection_px
 
     sc, par, x0, loss, fs = _case(name)
     tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=400)
@@ -371,9 +371,30 @@ def test_converged_parity_with_scipy(name):
     assert got.cost <= ref.cost * (1 + 1e-8)
     args = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
     assert abs(rms_reprojection_px(*args, got.x) - rms_reprojection_px(*args, ref.x)) < 1e-4
+    if "refine" in name:
+        # Free f / k1 / k2 has a weakly determined scale-focal direction along which scipy's LSMR steps (atol = btol = 1e-6) crawl: measured on this
+        # case, 2000 evaluations at 1e-15 leave scipy-lsmr's intrinsics 5e-3 from the point scipy's OWN exact solver (tr_solver="exact", dense SVD
+        # steps) reaches in 35.  The referee for north_star's 1e-6 is therefore scipy-exact at 1e-15 (minutes of one core: computed beforehand,
+        # tests/golden/make_scipy_refs.py "refine_C6_exact"; recomputed here if the stored x0 does not match).
+        from tests.golden.make_scipy_refs import load
+
+        stored = load("refine_C6_exact", x0)
+        tight = dict(ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400)
+        x_exact = stored["x"] if stored is not None else optimize_scipy(*args, x0, tr_solver="exact", **tight).x
+        got_t = least_squares(None, x0, args=(*args, None, None, None, None), x_scale="jac", bounds=par.bounds(), method="trf",
+                              ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=400)
+        pos, ang, _ = aligned_difference(par, got_t.x, x_exact)
+        assert pos < 1e-6 and ang < 1e-6, (pos, ang)  # north_star's number on the nine-parameter path (measured 6e-12 on the CPU build of the driver)
+        assert abs(rms_reprojection_px(*args, got_t.x) - rms_reprojection_px(*args, x_exact)) < 1e-4
+        ncp = par.n_camera_params
+        assert np.abs(got_t.x[:ncp].reshape(-1, 9)[:, 6:] - x_exact[:ncp].reshape(-1, 9)[:, 6:]).max() < 1e-6  # s, k1, k2 themselves
+        # against the reference's own (lsmr) call at the same tolerances the distance is scipy's: bounded by ITS distance to the exact solution
+        pos_l, ang_l, _ = aligned_difference(par, got.x, ref.x)
+        pos_s, ang_s, _ = aligned_difference(par, ref.x, x_exact)
+        assert pos_l < 1e-5 and ang_l < 1e-5 and pos_l <= pos_s * 1.5 + 1e-7, (pos_l, pos_s)
+        return
     pos, ang, _ = aligned_difference(par, got.x, ref.x)
-    lim = 1e-6 if "refine" not in name else 1e-5  # free f/k1/k2 has a weakly determined scale-focal direction
-    assert pos < lim and ang < lim, (pos, ang)
+    assert pos < 1e-6 and ang < 1e-6, (pos, ang)
 
 
 def test_default_tolerances_match_scipy_iteration_count():
@@ -628,7 +649,9 @@ def test_solution_on_an_intrinsic_bound_matches_scipy():
     got_t = least_squares(joint_residuals, x0, args=(*args, None, None, None, None), jac=joint_jacobian, x_scale="jac", method="trf", bounds=(lb, ub), **tight)
     ref_t = optimize_scipy(*args, x0, tr_solver="exact", **tight)
     assert abs(got_t.cost - ref_t.cost) <= 1e-10 * ref_t.cost
-    assert np.abs(got_t.x[:ncp].reshape(-1, 9)[:, 6:] - ref_t.x[:ncp].reshape(-1, 9)[:, 6:]).max() < 1e-5
+    assert np.abs(got_t.x[:ncp].reshape(-1, 9)[:, 6:] - ref_t.x[:ncp].reshape(-1, 9)[:, 6:]).max() < 1e-6  # (7e-9 on the CPU build of the driver)
+    pos, ang, _ = aligned_difference(par, got_t.x, ref_t.x)
+    assert pos < 1e-6 and ang < 1e-6, (pos, ang)
 
 
 @pytest.mark.parametrize("refine", [False, True])
