@@ -119,7 +119,7 @@ class _Solo:
 
 
 def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=None, control=None, scaling="strong", group=None, prebuilt=None,
-            **overrides):
+            on_engine=None, **overrides):
     """Strong scaling: every rank generates the same scene and keeps the shard of points ``shard_problem`` gives it.
     Weak scaling: rank r draws its own points/observations of the same cameras.  Either way the engine all-reduces the
     camera blocks, the reduced camera system and the scalar sums over RCCL."""
@@ -147,6 +147,8 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     t_setup = time.perf_counter()
     eng = HipEngine(prob, device_id=device_id)  # sort, Schur plan, upload, graph capture: paid once per problem structure, NOT part of `value`
     t_setup = time.perf_counter() - t_setup
+    if on_engine is not None:
+        on_engine(eng)  # (in-process ranks: a failing peer aborts this rank's communicator instead of leaving it in a collective)
     if control.world > 1:
         if group is not None:  # the library's peer-to-peer device group (one process, --xchg direct)
             eng.group_join(group, control.rank)
@@ -521,17 +523,34 @@ def run_ranks_in_process(args, devices, xchg):
     group = DeviceGroup(world) if xchg == "direct" else None
     state = _ThreadGroupState(world)
     records, errors = [None] * world, [None] * world
+    engines, engines_lock = [None] * world, threading.Lock()
 
     def member(rank):
         ctl = ThreadControlPlane(state, rank)
+
+        def keep(engine):
+            with engines_lock:
+                engines[rank] = engine
+
         try:
             records[rank] = measure(args.workload, args.steps, args.warmup, device_id=devices[rank], control=ctl, scaling=args.scaling,
-                                    group=group, prebuilt=prebuilt)
+                                    group=group, prebuilt=prebuilt, on_engine=keep)
         except BaseException as exc:  # noqa: BLE001 - reported by the main thread
             errors[rank] = exc
             ctl.abort()
             if group is not None:
                 group.abort()
+            else:  # RCCL: peers sitting in an all-reduce this rank will never join (as caliscope_amd.distributed.solve_multi_device does)
+                with engines_lock:
+                    peers = [e for r, e in enumerate(engines) if r != rank and e is not None]
+                for e in peers:
+                    try:
+                        e.comm_abort()  # (excluded against the peer's own close() by the engine's lock)
+                    except Exception:  # noqa: BLE001 - best effort on the failure path
+                        pass
+        finally:
+            with engines_lock:
+                engines[rank] = None
 
     threads = [threading.Thread(target=member, args=(r,), name=f"bench-rank{r}", daemon=True) for r in range(world)]
     for t in threads:

@@ -726,26 +726,12 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
 //     Sacc[c_i, c_j] += A_i^T (Z_i Z_j^T) A_j          ( = W_i V'^-1 W_j^T )
 // The reduced system is S = U + lam D_c^2 - Sacc, rhs = -g_c + b   (SURVEY.md Appendix A.4).
 //
-// Scatter-reducing Sacc is the expensive part (k(k+1)/2 blocks of nc^2 per point).  FP64 global atomics
-// manage ~2e10 updates/s on this chip, LDS atomics (ds_add_f64) ~1e13, so Sacc must live in LDS.  It does
-// not fit for more than ~18 cameras, hence the cameras are cut into G groups of g and the block-upper-
-// triangle of Sacc into G(G+1)/2 tiles (a <= b) of (g nc)^2 doubles.  Because the sparsity pattern is
-// static, cba_create lays out one observation STREAM per tile: the observations (sorted by point, then
-// camera) whose camera is in group a or b and whose point is seen from both groups, chunked like the main
-// array, plus the list of (i, j) observation pairs of every chunk, so that in the pair phase every lane has
-// exactly one 6x6 (9x9) block to form — no partner loops of uneven length.  A workgroup is bound to
-// one tile, keeps that tile in LDS across all of the tile's chunks, and flushes it once (per-workgroup
-// partials, reduced in fixed order).  The Jacobian blocks are recomputed per stream (G times per
-// observation) rather than stored: 24 B + ~600 flop beats 144 B of HBM traffic per use.
-typedef unsigned int pair_t;  // two 16-bit chunk-local observation indices
+// Scatter-reducing Sacc is the expensive part (k(k+1)/2 blocks of nc^2 per point).  FP64 global atomics manage ~2e10 updates/s on this chip
+// and an LDS-atomic tile kernel 1.0 ms per pass on cfg4 (rounds 1-3 kept it as a fallback; deleted in round 4), so the sums are formed in
+// REGISTERS: the cameras are cut into G groups of g <= 16, the block upper triangle of Sacc into G(G+1)/2 tiles (a <= b), a workgroup is
+// bound to one tile and every thread owns one camera-pair block of it (k_schur_reg3 below; plan: schur_plan.h).
 struct TilePlan {
-  const double* u;
-  const double* v;
-  const int* pt;
-  const unsigned char* camloc;   // camera index inside the tile: [0,g) group a, [g,2g) group b
-  const pair_t* pairs;           // (i | j << 16): chunk-local indices of every observation pair to multiply
-  const int* pair_start;         // [n_tile_chunks + 1] offsets into `pairs`
-  const int* chunk_start;        // [n_tile_chunks + 1] offsets into the stream arrays
+  const int* chunk_start;        // [n_tile_chunks + 1] offsets into `obs`
   const int* wg_first;           // [grid] first chunk of the workgroup
   const int* wg_end;             // [grid] end of the chunk range the workgroup strides through
   const int* wg_tile;            // [grid] tile of each workgroup
@@ -755,187 +741,22 @@ struct TilePlan {
   const int* group_cam_begin;    // [G + 1]
   const int* group_par_begin;    // [G + 1]
   int g;                         // cameras per group (max)
-  int cs;                        // column stride of one camera block inside the LDS tile (odd: nc | 1)
-  int ld;                        // leading dimension of the LDS tile (odd)
-  int tile_elems;                // width of one workgroup's partial (LDS-tile kernel: g nc ld + g nc)
-  // register kernels (k_schur_reg2 / k_schur_reg3, plan: schur_plan.h)
+  int tile_elems;                // width of one workgroup's partial row: 256 blocks of nc^2
   const int* obs;                // chunk slot -> observation (index into the T records)
   int rep;                       // threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
   const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_addr | j_addr << 16), LDS addresses in 16-byte pieces
   const int* code_start;         // [n_tile_chunks + 1] offsets into `codes`
   const unsigned* nit;           // [n_tile_chunks] iterations of waves 0..3, one byte each
 };
-// LDS tile addressing.  Rows are packed (camera offsets as in the parameter vector); columns are padded to
-// an odd per-camera stride `cs` and the leading dimension is odd.  With the natural layout (6-wide blocks,
-// ld = 96 == 0 mod 32) the 64 lanes of one ds_add_f64 — same (r, c), different camera pairs — could reach
-// only 16 of the 32 bank pairs (measured: ~8-way conflicts, pair phase 830 us of a 1290 us pass on cfg4).
-
-// The pair phase is LDS-bound (36 ds_add_f64 + ~40 ds_read per pair) and the tile allows one workgroup per
-// CU, so the workgroup is 512 threads: the first 256 recompute the blocks of the chunk (one observation each),
-// then all eight waves share the chunk's pairs — twice the LDS requests in flight for the same LDS footprint.
-constexpr int SCHUR_BLOCK = 512;
-
-template <int NC>
-__global__ void __launch_bounds__(SCHUR_BLOCK)
-k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab,
-             const int* __restrict__ cam_off, int loss, double f_scale, double lam, const double* __restrict__ Vblk,
-             const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ partial,
-             int* __restrict__ flags, int debug_skip) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int g = tp.g;
-  const int gn = g * NC;
-  const int ld = tp.ld;
-  double* sh_tab = sh;                          // [2g][CAMTAB_LDS]
-  double* sh_A = sh_tab + 2 * g * CAMTAB_LDS;   // [2*NC][CHUNK]
-  double* sh_Z = sh_A + 2 * NC * CHUNK;         // [6][CHUNK]
-  double* sh_b = sh_Z + 6 * CHUNK;              // [gn]
-  double* sh_S = sh_b + gn;                     // [gn][ld]
-  int* sh_loff = reinterpret_cast<int*>(sh_S + gn * ld);  // [2g] row offset (packed) of each tile camera
-  int* sh_coff = sh_loff + 2 * g;                         // [2g] column offset (padded stride cs)
-  int* sh_cam = sh_coff + 2 * g;                          // [CHUNK]
-
-  const int t = tp.wg_tile[blockIdx.x];
-  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
-  const bool diag = (ga == gb);
-  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
-  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
-  const int pa0 = tp.group_par_begin[ga], pb0 = tp.group_par_begin[gb];
-
-  for (int i = threadIdx.x; i < na * CAMTAB_LIVE; i += SCHUR_BLOCK)
-    sh_tab[(i / CAMTAB_LIVE) * CAMTAB_LDS + (i % CAMTAB_LIVE)] = tab[(long)(ca0 + i / CAMTAB_LIVE) * CAMTAB_DOUBLES + (i % CAMTAB_LIVE)];
-  if (!diag)
-    for (int i = threadIdx.x; i < nb * CAMTAB_LIVE; i += SCHUR_BLOCK)
-      sh_tab[(g + i / CAMTAB_LIVE) * CAMTAB_LDS + (i % CAMTAB_LIVE)] = tab[(long)(cb0 + i / CAMTAB_LIVE) * CAMTAB_DOUBLES + (i % CAMTAB_LIVE)];
-  for (int i = threadIdx.x; i < 2 * g; i += SCHUR_BLOCK) {
-    int off = 0;
-    if (i < g) { if (i < na) off = cam_off[ca0 + i] - pa0; }
-    else if (i - g < nb) off = cam_off[cb0 + i - g] - pb0;
-    sh_loff[i] = off;
-    // column block of a tile camera: group-local camera index times the padded stride.  In a diagonal tile
-    // both roles use indices [0, g); in an off-diagonal tile the column cameras are the [g, 2g) entries.
-    sh_coff[i] = (i < g ? i : i - g) * tp.cs;
-  }
-  for (int i = threadIdx.x; i < gn + gn * ld; i += SCHUR_BLOCK) sh_b[i] = 0.0;  // sh_b and sh_S are contiguous
-  __syncthreads();
-
-  const double* px = xvec + lay.ncp_pad;
-  const double* gp = gvec + lay.ncp_pad;
-  const double* dp = sinv + lay.ncp_pad;
-  bool fail = false;
-  const int ch_end = tp.wg_end[blockIdx.x], ch_stride = tp.wg_stride[blockIdx.x];
-  for (int ch = tp.wg_first[blockIdx.x]; ch < ch_end; ch += ch_stride) {
-    const int o0 = tp.chunk_start[ch], o1 = tp.chunk_start[ch + 1];
-    const int i = o0 + threadIdx.x;
-    const bool active = threadIdx.x < CHUNK && i < o1;  // block recomputation: one thread per observation
-    if (active && !(debug_skip & 2)) {
-      double Ai[2][MAX_NC], Zi[2][3];
-      const int pt = tp.pt[i];
-      const int cl_i = tp.camloc[i];
-      const CamTab& ct = cam_at(sh_tab, cl_i);
-      double e[2], B[2][3];
-      obs_linearize<NC>(ct, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], tp.u[i], tp.v[i], loss, f_scale, e, Ai, B);
-      const int np_i = (int)ct.nparams;
-      double Vd[6], L[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
-      const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
-      Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
-      if (!chol3(Vd, L)) {
-        fail = true;
-        L[0] = L[2] = L[5] = 1.0; L[1] = L[3] = L[4] = 0.0;
-      }
-      chol3_fwd(L, B[0], Zi[0]);
-      chol3_fwd(L, B[1], Zi[1]);
-      if (diag) {  // every observation lives in exactly one diagonal tile: accumulate the rhs term there
-        const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
-        double y[3];
-        chol3_fwd(L, gpt, y);
-        const double zy0 = Zi[0][0] * y[0] + Zi[0][1] * y[1] + Zi[0][2] * y[2];
-        const double zy1 = Zi[1][0] * y[0] + Zi[1][1] * y[1] + Zi[1][2] * y[2];
-        double* bc = sh_b + sh_loff[cl_i];
-#pragma unroll
-        for (int k = 0; k < NC; ++k)
-          if (k < np_i) lds_add(&bc[k], Ai[0][k] * zy0 + Ai[1][k] * zy1);
-      }
-#pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        if (k >= np_i) { Ai[0][k] = 0.0; Ai[1][k] = 0.0; }
-        sh_A[k * CHUNK + threadIdx.x] = Ai[0][k];
-        sh_A[(NC + k) * CHUNK + threadIdx.x] = Ai[1][k];
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        sh_Z[k * CHUNK + threadIdx.x] = Zi[0][k];
-        sh_Z[(3 + k) * CHUNK + threadIdx.x] = Zi[1][k];
-      }
-      sh_cam[threadIdx.x] = cl_i;
-    }
-    __syncthreads();
-    const int q1 = (debug_skip & 1) ? 0 : tp.pair_start[ch + 1];
-    for (int q = tp.pair_start[ch] + threadIdx.x; q < q1; q += SCHUR_BLOCK) {
-      const unsigned pr = tp.pairs[q];
-      const int i_loc = pr & 0xffffu, j_loc = pr >> 16;
-      const int cl_i = sh_cam[i_loc], cl_j = sh_cam[j_loc];
-      const int row0 = sh_loff[cl_i], col0 = sh_coff[cl_j];
-      const int np_i = (int)cam_at(sh_tab, cl_i).nparams, np_j = (int)cam_at(sh_tab, cl_j).nparams;
-      double Zi[2][3], Zj[2][3], Ai[2][NC], Aj[2][NC];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Zi[0][k] = sh_Z[k * CHUNK + i_loc]; Zi[1][k] = sh_Z[(3 + k) * CHUNK + i_loc];
-        Zj[0][k] = sh_Z[k * CHUNK + j_loc]; Zj[1][k] = sh_Z[(3 + k) * CHUNK + j_loc];
-      }
-#pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        Ai[0][k] = sh_A[k * CHUNK + i_loc]; Ai[1][k] = sh_A[(NC + k) * CHUNK + i_loc];
-        Aj[0][k] = sh_A[k * CHUNK + j_loc]; Aj[1][k] = sh_A[(NC + k) * CHUNK + j_loc];
-      }
-      double M[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) M[a][b] = Zi[a][0] * Zj[b][0] + Zi[a][1] * Zj[b][1] + Zi[a][2] * Zj[b][2];
-      const bool same_obs = (i_loc == j_loc);
-      const bool same_cam = (cl_j == cl_i);
-      double* Sblk = sh_S + row0 * ld + col0;
-#pragma unroll
-      for (int r = 0; r < NC; ++r) {
-        if (r >= np_i) continue;
-        const double t0 = Ai[0][r] * M[0][0] + Ai[1][r] * M[1][0];
-        const double t1 = Ai[0][r] * M[0][1] + Ai[1][r] * M[1][1];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          if (c >= np_j) continue;
-          const double val = t0 * Aj[0][c] + t1 * Aj[1][c];  // block(r, c) of W_i V'^-1 W_j^T
-          if (same_obs) {
-            if (c >= r) lds_add(&Sblk[r * ld + c], val);
-          } else if (same_cam) {
-            // two observations of one camera (duplicates): block + block^T on the diagonal block
-            const int lo = r < c ? r : c, hi = r < c ? c : r;
-            lds_add(&Sblk[lo * ld + hi], (r == c) ? 2.0 * val : val);
-          } else {
-            // pairs are listed with (row camera) < (column camera): upper block triangle
-            lds_add(&Sblk[r * ld + c], val);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (fail) flags[1] = 1;
-  double* dst = partial + (long)blockIdx.x * tp.tile_elems;
-  for (int i = threadIdx.x; i < gn * ld; i += SCHUR_BLOCK) dst[i] = sh_S[i];
-  for (int i = threadIdx.x; i < gn; i += SCHUR_BLOCK) dst[gn * ld + i] = sh_b[i];
-}
 
 // ------------------------------------------------------------------------------------------------
-// Schur pass, register-accumulating variant: k_tprep + k_schur_reg2 (+ k_reg_reduce, k_reg_fold, k_unprime).
+// Schur pass: k_tprep + k_schur_reg3 (+ k_reg_reduce, k_reg_fold).
 //
 // With Z_i = B_i L^-T (L L^T = V + lam D^2 of the point) the pair term A_i^T (Z_i Z_j^T) A_j is T_i T_j^T for the
 // per-observation NC x 3 matrix T_i = A_i^T Z_i, and the rhs term is T_i y with y = L^-1 g_point.
 //
-// k_tprep evaluates every observation ONCE (the LDS-tile kernel re-linearises an observation in each of the G tiles it
-// takes part in), stores a record per observation in HBM and reduces the rhs per camera (LDS atomics, per-workgroup
-// partials, k_reduce_rows).
+// k_tprep evaluates every observation ONCE, stores a record per observation in HBM and reduces the rhs per camera (LDS atomics,
+// per-workgroup partials, k_reduce_rows).
 //
 // The record is COMPACT.  The camera block factors (ba_math.h, project_full): A = G [C | I | A_intr] with G = d(pixel)/dX_c
 // (2 x 3), C = -[Y]x J_l the derivative of the rotated point Y = R X by the rotation vector, so
@@ -944,7 +765,7 @@ k_schur_tile(TilePlan tp, const double* __restrict__ xvec, VecLayout lay, const 
 // (in LDS: 112 / 176 B apart, an odd stride in 16-byte pieces); the pair kernel gathers, stages and reads a third less, and it never forms the top rows: with D = Q_i Q_j^T
 //     [Y_i]x D [Y_j]x^T | [Y_i]x D | D [Y_j]x^T | D
 // are the four 3 x 3 quarters of the PRIMED block T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr] (99 FP64 operations per pair
-// instead of 108 on 18 + 18 doubles).  The per-camera factor J_l^T is applied once per block at the end (k_unprime).
+// instead of 108 on 18 + 18 doubles).  The per-camera factor J_l^T is applied once per block in the pair kernel's epilogue.
 // The rhs needs the true rows 0..2, which k_tprep has in registers anyway.
 template <int NC> struct SchurRec {
   static constexpr int NVAL = (NC == 9) ? 21 : 12;        // doubles that carry data
@@ -1122,39 +943,6 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   }
 }
 
-// k_schur_reg2.  A 256-thread workgroup is bound to one tile (camera group a x camera group b) of the reduced camera
-// system; every THREAD owns one camera-pair block of the tile for the whole kernel and keeps its NC x NC accumulators in
-// registers (NC = 9: three threads per block, three rows each) — no atomics, no S tile in LDS, a fixed summation order.
-// A tile's work is a stream of chunks (schur_plan.h): the workgroup gathers the chunk's compact records into LDS, then
-// every thread multiplies the record pairs that belong to its block.
-//   * the plan equalises the pairs per block of every chunk (cap t, first-fit dealing over a region of chunks), so a wave
-//     spends ~80 % of its lane-iterations on real pairs (round 1's greedy window: ~45 %);
-//   * the pair list is transposed: iteration `it` of wave w reads 64 consecutive codes, one per lane; a code holds the
-//     LDS addresses of the two records, idle lanes get the address of an all-zero record.  No per-thread slice table, no
-//     pair list in LDS, no divergence: the trip count is wave-uniform and the body is straight-line code;
-//   * the plan also picks the slot of every record inside the chunk so that the 16 lanes the LDS serves together read
-//     from 16 different bank groups (schur_plan.h, "LDS bank conflicts");
-//   * records are gathered piece-wise (lane e of a wave loads 16-byte piece e % NPH of slot e / NPH of the wave's run of
-//     slots: ~10 whole records per load instruction; a thread fetching its own record would touch 64 cache lines per
-//     instruction), through registers, one chunk ahead; the first four codes of the next chunk travel the same way.
-template <int NC> struct Reg2Cfg {
-  static constexpr int REC = SchurRec<NC>::REC, NPH = SchurRec<NC>::NPH, LST = SchurRec<NC>::LST;
-  static constexpr int SPLIT = (NC == 9) ? 3 : 1;
-  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;
-  static constexpr int CODE_THREADS = BLOCK, CODE_WAVES = BLOCK / WAVE, GROUP = 16, PAIR_CAP = 0;
-  // slots (records) per chunk: 512 x 7 pieces = 56 KB (two workgroups per CU) / 384 x 11 pieces = 66 KB (one 12-wave workgroup;
-  // its 168-register budget leaves room for six staging registers per thread, not eleven)
-  static constexpr int SCHUNK = (NC == 9) ? 384 : 512;
-  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots staged by one wave (128 / 32)
-  static constexpr int NLD = (EPW * NPH + WAVE - 1) / WAVE;                        // gather loads per thread (12 / 6; the tail lanes of
-                                                                                   // a last, partial load repeat the wave's last slot)
-  static constexpr int WAVE_PIECES = EPW * LST;                                    // LDS pieces of one wave's run
-  static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // the all-zero record sits behind the staged chunk
-  static constexpr size_t LDS_BYTES = (size_t)(ZERO_PIECE + LST) * 16;
-  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
-  static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
-};
-
 // Primed pair product of a thread that owns three rows (NC = 9): with Rm = Q_i (or T_intr,i) the three rows are
 //   Rm T'_j^T = [ (Rm Q_j^T) [Y_j]x^T | Rm Q_j^T | Rm T_intr,j^T ],   and [Y_i]x times that for the rows of [Y_i]x Q_i.
 // Column group by column group, so that few values are live at a time (the kernel has 168 registers per thread).
@@ -1197,28 +985,88 @@ __device__ __forceinline__ void pair_rows(double (*acc)[NC], const double* Rm, c
   }
 }
 
-// DBG (profiling builds of the NC = 6 kernel only, tools/schur_split.py; the results are garbage): 1 no pair loop, 2 no record
-// gather, 4 no LDS stores, 8 no index / code loads, 16 phase clock.  Compile-time: a run-time switch in front of the loads made
-// the compiler drain vmcnt behind every one of them and doubled the kernel's time.
-template <int NC, int SPLIT, int MINW, int DBG = 0>
-__global__ void __launch_bounds__(BLOCK * SPLIT, MINW)
-k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ dbg_times = nullptr) {
-  using Cfg = Reg2Cfg<NC>;
+// k_schur_reg3.  A workgroup is bound to one tile (camera group a x camera group b) of the reduced camera system; every THREAD owns one
+// camera-pair block of the tile for the whole kernel and keeps its NC x NC accumulators in registers (NC = 9: three threads per block, three
+// rows each) — no atomics, no S tile in LDS, a fixed summation order.  A tile's work is a stream of chunks (schur_plan.h):
+//   * the plan equalises the pairs per block of every chunk (cap t, first-fit dealing over a region of chunks), so a wave spends ~75 % of its
+//     lane-iterations on real pairs;
+//   * the pair list is transposed: iteration `it` of wave w reads 64 consecutive codes, one per lane; a code holds the LDS addresses of the two
+//     records, idle lanes get the address of an all-zero record.  No per-thread slice table, no pair list in LDS, no divergence: the trip
+//     count is wave-uniform and the body is straight-line code;
+//   * the plan also picks the slot of every record inside the chunk so that the 16 lanes the LDS serves together read from 16 different bank
+//     groups (schur_plan.h, "LDS bank conflicts");
+//   * the records go straight from HBM into LDS (global_load_lds_dwordx4: 64 lanes, 64 consecutive 16-byte pieces of LDS, any global
+//     addresses) into the buffer that is NOT being read (two buffers), so a trip is: wait for the loads issued a trip ago, one barrier, issue
+//     the next chunk's loads, multiply.  No staging registers.
+//
+// SETS = 2 (round 4, six-parameter cameras): the ping-pong form.  Measured per trip and workgroup on cfg4 (phase clocks, two 4-wave workgroups
+// per CU): issuing 1600 clocks, pair arithmetic 2000, barrier 750 — while the pure costs are ~900 (the CU's vector-memory path takes a 64-lane
+// gather every ~26 clocks: 35 per chunk) and ~800 (99 FP64 instructions of 4 clocks per pair, two pair iterations per chunk): both phases take
+// TWICE their floor because the CU's two workgroups drift into the same phase and then contend — for the address path while both issue, for
+// the FP64 pipe while both multiply.  Here ONE 8-wave workgroup holds two SETS of four waves, each with its own chunk sequence, accumulators
+// and pair of LDS buffers, i.e. exactly the two workgroups of before — but a barrier of the WHOLE workgroup separates the issue phase from the
+// pair phase, and set 1 runs half a period behind set 0: whenever one set issues its gathers the other one multiplies.
+template <int NC, int SETS = 1> struct Reg3Cfg {
+  static_assert(SETS == 1 || SETS == 2, "one set, or two in anti-phase");
+  static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
+  static constexpr int SPLIT = (NC == 9) ? 3 : 1;
+  static constexpr int CODE_THREADS = BLOCK, CODE_WAVES = BLOCK / WAVE;             // blocks of a tile = pair-code streams
+  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;        // threads / waves of one set
+  static constexpr int GROUP = 16;                                                  // cameras per group: GROUP^2 blocks <= CODE_THREADS
+  // pair codes per block and chunk that travel in registers (a code beyond them is loaded inside the pair loop: a vmcnt(0) behind the record loads
+  // in flight)
+  static constexpr int NCD = (NC == 6) ? 8 : 4;
+  static constexpr int PAIR_CAP = 0;
+  static constexpr int SCHUNK = (NC == 9) ? 384 : 320;                              // slots per chunk (per LDS buffer)
+  static constexpr int EPW = SCHUNK / NWAVES;                                       // slots loaded by one wave (80 / 32)
+  static constexpr int NLD = (EPW * LST + WAVE - 1) / WAVE;                         // load instructions per wave and chunk (9 / 6)
+  static constexpr int WAVE_PIECES = NLD * WAVE;                                    // LDS pieces of one wave's run, padded to whole loads
+  static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                           // all-zero record behind the chunk, in each buffer
+  static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                           // (+1: keeps the second buffer 32-byte aligned)
+  static constexpr int NBUF = 2;                                                    // chunk buffers of a set: a gather is issued one trip before it is read
+  static constexpr int SET_PIECES = NBUF * BUF_PIECES;
+  static constexpr size_t LDS_BYTES = (size_t)SETS * SET_PIECES * 16;
+  static constexpr int LAUNCH_THREADS = SETS * REG_BLOCK;
+  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
+  static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
+  static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
+  static_assert(LDS_BYTES <= 160 * 1024 && LAUNCH_THREADS <= 1024, "one workgroup");
+};
+
+// The body is a function of its own with `Trec` as a __restrict__ PARAMETER: inlined into the kernel, every access in it carries
+// alias-scope metadata, and only with that does the compiler's wait-count insertion let a ds_read pass a pending LDS-DMA load (with
+// the body written directly in the kernel it put a vmcnt(0) in front of the first record read of every trip: the wave sat out the
+// gather it had just issued).
+// CLK (profiling build, -DCBA_PROFILING + CBA_SCHUR_CLOCK=1): per wave the shader clocks spent waiting for loads, in barriers, issuing, multiplying.
+template <int NC, int SPLIT, int SETS, bool CLK = false>
+__device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
+                                                const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
+                                                const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr,
+                                                const double* __restrict__ tab = nullptr) {
+  using Cfg = Reg3Cfg<NC, SETS>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int REG_BLOCK = Cfg::REG_BLOCK, NPH = Cfg::NPH, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
+  constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW, NWORD = Cfg::CODE_WAVES / 4;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
-  constexpr int NCD = 4;                        // codes of a chunk that travel in registers
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  double2* sh_p = reinterpret_cast<double2*>(sh);  // the staged chunk, in 16-byte pieces
+  constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
 
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
-  const int tid = (int)threadIdx.x;
+  const int set = (SETS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / REG_BLOCK);
+  const int tid = (int)threadIdx.x % REG_BLOCK;  // thread of the set
+  // the id this set works under (index into wg_first / ... and of its partial row).  One set: csrc/wg_binding.h, interleaved over the dispatch
+  // order.  Two sets: physical workgroup B (XCD B mod 8) runs the logical workgroups 16 (B / 8) + B mod 8 and that + 8 — both ids keep
+  // B mod 8, which is what the XCD-aware binding (bind_workgroups) goes by
+  const int n_logical = (int)gridDim.x * SETS;
+  auto logical_of = [&](int s) {
+    if (SETS == 1) return logical_workgroup((int)blockIdx.x, (int)gridDim.x);
+    return ((n_logical & 15) == 0) ? (((int)blockIdx.x >> 3) << 4) + ((int)blockIdx.x & 7) + 8 * s : (int)blockIdx.x * SETS + s;
+  };
+  const int wg = logical_of(set);
+  double2* sh_p = reinterpret_cast<double2*>(sh) + set * Cfg::SET_PIECES;  // this set's two chunk buffers, in 16-byte pieces
   const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
-  const int cw = ct / WAVE, lane = ct % WAVE;
-  const int sw = tid / WAVE;                    // staging wave
-  const int blk = (rep > 1) ? tid % nblk : ct;
-  const int slot = (rep > 1) ? tid / nblk : 0, half = (rep > 1) ? 0 : tid / BLOCK;
+  const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
+  const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave of the set
+  const int half = (rep > 1) ? 0 : tid / BLOCK;
   const int r0 = half * RH;
   double acc[RH][NC];
 #pragma unroll
@@ -1226,63 +1074,88 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
 
-  const int first = tp.wg_first[blockIdx.x], ch_end = tp.wg_end[blockIdx.x], stride = tp.wg_stride[blockIdx.x];
-  double* dst = partial + ((long)blockIdx.x * rep + min(slot, rep - 1)) * tp.tile_elems + (long)blk * NC * NC + r0 * NC;
-  if (first >= ch_end) {  // more workgroups than chunks in this range
-    if (slot < rep) {
-#pragma unroll
-      for (int k = 0; k < RH * NC; ++k)
-        if (r0 * NC + k < NC * NC) dst[k] = 0.0;
-    }
-    return;
-  }
-  for (int k = tid; k < LST; k += REG_BLOCK) sh_p[Cfg::ZERO_PIECE + k] = make_double2(0.0, 0.0);
-  const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
-  const unsigned zero_code = (unsigned)Cfg::ZERO_PIECE | ((unsigned)Cfg::ZERO_PIECE << 16);
-  constexpr bool dbg_pairs = !(DBG & 1), dbg_gather = !(DBG & 2), dbg_store = !(DBG & 4), dbg_index = !(DBG & 8);
+  // this thread's block: virtual thread vt of the plan; rep > 1: vt = slot * nblk + block
+  const int vt = (SPLIT == 1) ? tid : ct;
+  const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
+  const bool owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
+  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
 
-  // Software pipeline: while the pairs of chunk `cur` are multiplied, the registers receive the records and the first
-  // codes of the next chunk and the record indices of the one after.  Every load is unconditional (the streams are padded,
-  // the last chunk is simply fetched again): a load under a divergent branch makes the compiler drain vmcnt at the join.
-  // The record index of a slot comes from two coalesced loads per wave (slots 0..63 and 64..EPW-1 of the wave's run) and a
-  // ds_bpermute per gather: load k covers slots [64 k / NPH, (64 k + 63) / NPH], which lie entirely in one of the two
-  // registers (64 slots are a whole number of loads).
-  double2 rec[NLD];
-  int idxA = 0, idxB = 0;
+  // chunk range of this set; a workgroup's sets run the same number of trips (the barriers are the workgroup's), a set that is out of
+  // chunks idles through the rest: it gathers its last chunk again and multiplies nothing
+  auto trips_of = [&](int w) { const int f = tp.wg_first[w], e = tp.wg_end[w], s = tp.wg_stride[w]; return f < e ? (e - 1 - f) / s + 1 : 0; };
+  const int stride = tp.wg_stride[wg], ch_end = tp.wg_end[wg];
+  const int own_trips = trips_of(wg);
+  const int first = own_trips ? tp.wg_first[wg] : max(ch_end - 1, 0);  // (no chunk of its own: somebody's valid chunk, never multiplied)
+  int trips = own_trips;
+  if (SETS == 2) trips = max(trips, trips_of(logical_of(set ^ 1)));
+  for (int k = tid; k < Cfg::NBUF * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
+  const int last = first + (own_trips ? (own_trips - 1) * stride : 0);  // last chunk of this set
+  // Per trip every wave issues, in this order and WITHOUT waiting in between: the codes of the next chunk and the record indices
+  // of the chunk after next (their addresses come from the iteration counts / offsets loaded a trip earlier), the counts and
+  // offsets of the chunks behind those, the records of the next chunk; then it multiplies the current chunk while all of that
+  // is in flight.  (Until round 2's last revision addresses were computed from values loaded in the same trip: the wait for them
+  // was a vmcnt(0) behind the record loads, i.e. every wave sat out its own gather before it multiplied.)
+  struct Raw { unsigned nit[NWORD]; int code_start; int obs_start; };  // counts / code offset of one chunk, stream offset of its successor
+  auto load_raw = [&](int chunk, int successor) {
+    Raw r;
+#pragma unroll
+    for (int q = 0; q < NWORD; ++q) r.nit[q] = p_nit[(long)chunk * NWORD + q];
+    r.code_start = p_code_start[chunk];
+    r.obs_start = p_chunk_start[successor];
+    return r;
+  };
+  auto load_indices = [&](int obs_start, int* iA, int* iB) {
+    const int* src = p_obs + obs_start + sw * EPW;
+    *iA = src[lane];
+    if (EPW > WAVE) *iB = src[WAVE + (lane & (EPW - WAVE - 1))];
+  };
+  static_assert(EPW <= WAVE || ((EPW - WAVE) & (EPW - WAVE - 1)) == 0, "second index register");
   unsigned cd[NCD];
+  int n_nx = 0;
+  long code_nx = 0;
+  auto load_codes = [&](const Raw& r) {
+    int pre = 0, mine = 0;
 #pragma unroll
-  for (int k = 0; k < NLD; ++k) rec[k] = make_double2(0.0, 0.0);
+    for (int q = 0; q < NWORD; ++q) {
 #pragma unroll
-  for (int k = 0; k < NCD; ++k) cd[k] = zero_code;
-  int n_nx = 0;          // iterations of this wave in the fetched chunk
-  long code_nx = 0;      // offset of this lane's first code of the fetched chunk
-  auto load_indices = [&](int chunk) {
-    if (!dbg_index) return;
-    const int* src = tp.obs + tp.chunk_start[chunk] + sw * EPW;
-    idxA = src[lane];
-    if (EPW > WAVE) idxB = src[WAVE + lane];
+      for (int w = 0; w < 4; ++w) {
+        const int n = (int)((r.nit[q] >> (8 * w)) & 0xffu);
+        pre += (4 * q + w < pw) ? n : 0;
+        mine = (4 * q + w == pw) ? n : mine;
+      }
+    }
+    n_nx = __builtin_amdgcn_readfirstlane(mine);
+    code_nx = (long)r.code_start + (long)pre * WAVE + lane;
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
   };
-  load_indices(first);
-  // slot (inside the wave's run) and piece of load k of this lane: k * 64 + lane = el * NPH + piece
-  auto slot_piece = [&](int k, int& el, int& piece) {
-    constexpr int Q = WAVE / NPH, RM = WAVE % NPH;
-    piece = k * RM + lane % NPH;
-    el = k * Q + lane / NPH + piece / NPH;
-    piece %= NPH;
-    el = min(el, EPW - 1);
+  // load k of this wave fills LDS pieces [k * 64, k * 64 + 64) of the wave's run: piece (k * 64 + lane) % LST of slot
+  // (k * 64 + lane) / LST; the record index of the slot comes from the wave's index registers (ds_bpermute)
+  auto issue = [&](int buf, int idxA, int idxB) {
+    constexpr int Q = WAVE / LST, RM = WAVE % LST;
+    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
+    // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
+    // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
+    const double2* g[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      int piece = k * RM + lane % LST;
+      int el = k * Q + lane / LST + piece / LST;
+      piece %= LST;
+      el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
+      const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
+      const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
+      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
   };
-  auto gather = [&](int k) {
-    int el, piece;
-    slot_piece(k, el, piece);
-    const bool useB = EPW > WAVE && k * WAVE >= WAVE * NPH;  // slots >= 64: the second index register
-    const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-    if (dbg_gather) rec[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC)[piece];  // (piece < NPH here)
-  };
-  auto pair = [&](unsigned code) {
-    const double2* Ri = sh_p + (code & 0xffffu);
-    const double2* Rj = sh_p + (code >> 16);
-    // record: [Y0 Y1][Y2 Q00][Q01 Q02][Q10 Q11][Q12 Q20][Q21 Q22] ([I00 I01] .. [I22 -])
-    if constexpr (NC == 6) {  // the thread owns all six rows: rows 3..5 are Q_i T'_j^T, rows 0..2 [Y_i]x times the same products
+  auto pair = [&](const double2* bufp, unsigned code) {
+    const double2* Ri = bufp + (code & 0xffffu);
+    const double2* Rj = bufp + (code >> 16);
+    if constexpr (NC == 6) {
       const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
       const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
       const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
@@ -1294,7 +1167,6 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
 #pragma unroll
         for (int b2 = 0; b2 < 3; ++b2)
           M[a][3 + b2] = fma(Qi[3 * a + 2], Qj[3 * b2 + 2], fma(Qi[3 * a + 1], Qj[3 * b2 + 1], Qi[3 * a] * Qj[3 * b2]));
-        // (D [Y_j]x^T)[a][c] = (Y_j x D[a, :])_c
         M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
         M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
         M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
@@ -1321,292 +1193,6 @@ k_schur_reg2(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ 
     }
   };
 
-  // DBG & 16: shader-clock time of every phase of a trip, summed per wave (tools/schur_split.py prints them)
-  constexpr bool dbg_time = (DBG & 16) != 0;
-  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  auto stamp = [&](int ph) {
-    if (dbg_time) { const long long t = clock64(); tacc[ph] += t - tlast; tlast = t; }
-  };
-  if (dbg_time) tlast = clock64();
-  int nxt = first;
-  for (int cur = first - stride; cur < ch_end; cur += stride) {  // first trip: fetch only
-    int n_cur = 0;
-    long code_cur = 0;
-    unsigned cc[NCD];
-#pragma unroll
-    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
-    if (cur >= first) {
-      if (dbg_time) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }  // 0: waiting for the gathered records
-      double2* dstrec = sh_p + sw * Cfg::WAVE_PIECES;
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        int el, piece;
-        slot_piece(k, el, piece);
-        if (dbg_store) dstrec[el * LST + piece] = rec[k];
-      }
-      n_cur = n_nx; code_cur = code_nx;
-      if (dbg_time) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }  // 1: LDS stores
-      __syncthreads();
-      stamp(2);                                                                           // 2: barrier A
-      nxt = min(cur + stride, last);
-    }
-    // first half of the next chunk's gather
-#pragma unroll
-    for (int k = 0; k < NLD / 2; ++k) gather(k);
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(3);                                                                             // 3: first half of the gather issued
-    if (cur >= first && dbg_pairs && n_cur > 0) pair(cc[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(4);                                                                             // 4: first pair
-#pragma unroll
-    for (int k = NLD / 2; k < NLD; ++k) gather(k);
-    {
-      const unsigned packed = tp.nit[nxt];
-      int pre = 0;
-#pragma unroll
-      for (int w = 0; w < 3; ++w) pre += (w < cw) ? (int)((packed >> (8 * w)) & 0xffu) : 0;
-      n_nx = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * cw)) & 0xffu));
-      code_nx = (long)tp.code_start[nxt] + (long)pre * WAVE + lane;
-#pragma unroll
-      for (int k = 0; k < NCD; ++k)
-        if (dbg_index) cd[k] = tp.codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
-      load_indices(min(nxt + stride, last));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(5);                                                                             // 5: second half, codes, indices issued
-    if (cur < first) continue;
-    if (dbg_pairs) {
-#pragma unroll
-      for (int it = 1; it < NCD; ++it)
-        if (it < n_cur) pair(cc[it]);
-      for (int it = NCD; it < n_cur; ++it) pair(tp.codes[code_cur + (long)it * WAVE]);  // rare: more than four pairs of one block in a chunk
-    }
-    stamp(6);                                                                             // 6: remaining pairs
-    __syncthreads();
-    stamp(7);                                                                             // 7: barrier B
-  }
-  if (dbg_time && dbg_times && lane == 0 && half == 0) {
-#pragma unroll
-    for (int ph = 0; ph < 8; ++ph) dbg_times[((long)blockIdx.x * 4 + cw) * 8 + ph] = tacc[ph];
-  }
-  if (slot >= rep) return;
-#pragma unroll
-  for (int r = 0; r < RH; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
-}
-
-// k_schur_reg3: the same ownership, plan format and pair arithmetic as k_schur_reg2 with another data path.  k_schur_reg2 moves
-// a chunk HBM -> registers -> LDS: per trip every wave waits for its loads, issues NLD ds_write_b128 (13 cycles each and
-// serialised with the other waves' reads), and two barriers fence the single LDS copy; tools/schur_split.py puts 80 % of the
-// kernel's time into that skeleton, and with one 12-wave workgroup per CU (NC = 9) nothing overlaps it.  Here the records go
-// straight from HBM into LDS (global_load_lds_dwordx4: 64 lanes, 64 consecutive 16-byte pieces of LDS, any global addresses)
-// into the buffer that is NOT being read (two buffers of half the size), so a trip is: wait for the loads issued a trip ago,
-// one barrier, issue the next chunk's loads, multiply.  No staging registers (the 168-register NC = 9 kernel no longer spills).
-// WIDE (NC = 6, more than 16 cameras): a workgroup owns a 32 x 32 camera tile, so a record is gathered by half as many tiles
-// (cfg4: 2 instead of 4 — the kernel's time follows the bytes it gathers, 5.3).  1024 threads with a block each would have 128
-// registers (the 36 accumulators and one pair in flight need ~176: it spilled); so 512 threads own TWO blocks each: the plan is
-// made for 16 "virtual" waves of 64 blocks, physical wave w runs the pair codes of virtual waves w and w + 8 one after the other
-// into two sets of accumulators.  One workgroup per CU (8 waves, as two narrow workgroups), every wave loads 64 slots of a
-// 512-slot chunk: seven full load instructions.
-template <int NC, bool WIDE = false> struct Reg3Cfg {
-  static_assert(!WIDE || NC == 6, "the wide tile is the one-thread-per-block kernel");
-  static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
-  static constexpr int SPLIT = (NC == 9) ? 3 : 1;
-  static constexpr int VB = WIDE ? 2 : 1;                                          // blocks per thread
-  static constexpr int PHYS_THREADS = WIDE ? 2 * BLOCK : BLOCK;                    // threads that own blocks (x SPLIT row parts)
-  static constexpr int CODE_THREADS = PHYS_THREADS * VB;                           // blocks of a tile = pair-code streams
-  static constexpr int REG_BLOCK = PHYS_THREADS * SPLIT, NWAVES = REG_BLOCK / WAVE, CODE_WAVES = CODE_THREADS / WAVE;
-  static constexpr int GROUP = WIDE ? 32 : 16;                                     // cameras per group: GROUP^2 blocks <= CODE_THREADS
-  // pair codes per block and chunk that travel in registers (a code beyond them is loaded inside the pair loop: a vmcnt(0) behind the record loads
-  // in flight).  The wide kernel's register file is full at two; its plan caps the pairs of a block per chunk there and opens more chunks instead.
-  static constexpr int NCD = WIDE ? 2 : (NC == 6) ? 8 : 4;
-  static constexpr int PAIR_CAP = WIDE ? NCD : 0;
-  static constexpr int SCHUNK = WIDE ? 512 : (NC == 9) ? 384 : 320;                // slots per chunk (per LDS buffer)
-  static constexpr int EPW = SCHUNK / NWAVES;                                      // slots loaded by one wave (80 / 32; wide: 64)
-  static constexpr int NLD = (EPW * LST + WAVE - 1) / WAVE;                        // load instructions per wave and chunk (9 / 6; wide: 7)
-  static constexpr int WAVE_PIECES = NLD * WAVE;                                   // LDS pieces of one wave's run, padded to whole loads
-  static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                          // all-zero record behind the chunk, in each buffer
-  static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                          // (+1: keeps the second buffer 32-byte aligned)
-  static constexpr int NBUF = 2;                                                    // chunk buffers in LDS: a gather is issued one trip before it is read
-  static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_PIECES * 16;
-  static constexpr int LAUNCH_THREADS = REG_BLOCK;
-  static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
-  static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
-  static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
-};
-
-// The body is a function of its own with `Trec` as a __restrict__ PARAMETER: inlined into the kernel, every access in it carries
-// alias-scope metadata, and only with that does the compiler's wait-count insertion let a ds_read pass a pending LDS-DMA load (with
-// the body written directly in the kernel it put a vmcnt(0) in front of the first record read of every trip: the wave sat out the
-// gather it had just issued).
-// CLK (profiling build, CBA_SCHUR_CLOCK=1): per wave the shader clocks spent waiting for loads, in the barrier, issuing and multiplying.
-template <int NC, int SPLIT, bool WIDE, bool CLK = false>
-__device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
-                                                const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
-                                                const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr,
-                                                const double* __restrict__ tab = nullptr) {
-  using Cfg = Reg3Cfg<NC, WIDE>;
-  static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW;
-  constexpr int VB = Cfg::VB, PT = Cfg::PHYS_THREADS, PW = PT / WAVE, NWORD = Cfg::CODE_WAVES / 4;
-  constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
-  constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
-  double2* sh_p = reinterpret_cast<double2*>(sh);  // two chunk buffers, in 16-byte pieces
-
-  const int nblk = tp.g * tp.g;
-  const int rep = (SPLIT == 1) ? tp.rep : 1;
-  const int tid = (int)threadIdx.x;
-  const int wg = logical_workgroup((int)blockIdx.x, (int)gridDim.x);  // csrc/wg_binding.h: interleaved over the dispatch order
-  const int ct = tid % PT;                      // code thread: the SPLIT parts of a block multiply the same pairs
-  const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
-  const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave
-  const int half = (rep > 1) ? 0 : tid / PT;
-  const int r0 = half * RH;
-  double acc[VB][RH][NC];
-#pragma unroll
-  for (int v = 0; v < VB; ++v)
-#pragma unroll
-    for (int r = 0; r < RH; ++r)
-#pragma unroll
-      for (int c = 0; c < NC; ++c) acc[v][r][c] = 0.0;
-
-  // block v of this thread: virtual thread vt = v * PT + ct of the plan; rep > 1: vt = slot * nblk + block
-  auto out_of = [&](int v, bool* owner) -> double* {
-    const int vt = (SPLIT == 1) ? v * PT + tid : ct;
-    const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
-    *owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
-    return partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
-  };
-  const int first = tp.wg_first[wg], ch_end = tp.wg_end[wg], stride = tp.wg_stride[wg];
-  if (first >= ch_end) {  // more workgroups than chunks in this range
-#pragma unroll
-    for (int v = 0; v < VB; ++v) {
-      bool owner;
-      double* dst = out_of(v, &owner);
-      if (owner) {
-#pragma unroll
-        for (int k = 0; k < RH * NC; ++k)
-          if (r0 * NC + k < NC * NC) dst[k] = 0.0;
-      }
-    }
-    return;
-  }
-  for (int k = tid; k < Cfg::NBUF * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
-  const int last = first + ((ch_end - 1 - first) / stride) * stride;  // last chunk of this workgroup
-  // Per trip every wave issues, in this order and WITHOUT waiting in between: the codes of the next chunk and the record indices
-  // of the chunk after next (their addresses come from the iteration counts / offsets loaded a trip earlier), the counts and
-  // offsets of the chunks behind those, the records of the next chunk; then it multiplies the current chunk while all of that
-  // is in flight.  (Until round 2's last revision addresses were computed from values loaded in the same trip: the wait for them
-  // was a vmcnt(0) behind the record loads, i.e. every wave sat out its own gather before it multiplied; only the second
-  // workgroup of the CU overlapped.)
-  struct Raw { unsigned nit[NWORD]; int code_start; int obs_start; };  // counts / code offset of one chunk, stream offset of its successor
-  auto load_raw = [&](int chunk, int successor) {
-    Raw r;
-#pragma unroll
-    for (int q = 0; q < NWORD; ++q) r.nit[q] = p_nit[(long)chunk * NWORD + q];
-    r.code_start = p_code_start[chunk];
-    r.obs_start = p_chunk_start[successor];
-    return r;
-  };
-  auto load_indices = [&](int obs_start, int* iA, int* iB) {
-    const int* src = p_obs + obs_start + sw * EPW;
-    *iA = src[lane];
-    if (EPW > WAVE) *iB = src[WAVE + (lane & (EPW - WAVE - 1))];
-  };
-  static_assert(EPW <= WAVE || ((EPW - WAVE) & (EPW - WAVE - 1)) == 0, "second index register");
-  unsigned cd[VB][NCD];
-  int n_nx[VB];
-  long code_nx[VB];
-  auto load_codes = [&](const Raw& r) {
-    int pre[VB], mine[VB];
-#pragma unroll
-    for (int v = 0; v < VB; ++v) { pre[v] = 0; mine[v] = 0; }
-#pragma unroll
-    for (int q = 0; q < NWORD; ++q) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int n = (int)((r.nit[q] >> (8 * w)) & 0xffu);
-#pragma unroll
-        for (int v = 0; v < VB; ++v) {  // virtual wave of block v: v * PW + pw
-          pre[v] += (4 * q + w < v * PW + pw) ? n : 0;
-          mine[v] = (4 * q + w == v * PW + pw) ? n : mine[v];
-        }
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < VB; ++v) {
-      n_nx[v] = __builtin_amdgcn_readfirstlane(mine[v]);
-      code_nx[v] = (long)r.code_start + (long)pre[v] * WAVE + lane;
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) cd[v][k] = p_codes[code_nx[v] + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
-    }
-  };
-  // load k of this wave fills LDS pieces [k * 64, k * 64 + 64) of the wave's run: piece (k * 64 + lane) % LST of slot
-  // (k * 64 + lane) / LST; the record index of the slot comes from the wave's index registers (ds_bpermute)
-  auto issue = [&](int buf, int idxA, int idxB) {
-    constexpr int Q = WAVE / LST, RM = WAVE % LST;
-    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
-    // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
-    // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
-    const double2* g[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      int piece = k * RM + lane % LST;
-      int el = k * Q + lane / LST + piece / LST;
-      piece %= LST;
-      el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
-      const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
-      const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < NLD; ++k)
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
-  };
-  auto pair = [&](double (&A)[RH][NC], const double2* bufp, unsigned code) {
-    const double2* Ri = bufp + (code & 0xffffu);
-    const double2* Rj = bufp + (code >> 16);
-    if constexpr (NC == 6) {
-      const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
-      const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
-      const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
-      const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
-      const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
-      double M[3][NC];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2)
-          M[a][3 + b2] = fma(Qi[3 * a + 2], Qj[3 * b2 + 2], fma(Qi[3 * a + 1], Qj[3 * b2 + 1], Qi[3 * a] * Qj[3 * b2]));
-        M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
-        M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
-        M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
-      }
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        A[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], A[0][c]));
-        A[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], A[1][c]));
-        A[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], A[2][c]));
-        A[3][c] += M[0][c]; A[4][c] += M[1][c]; A[5][c] += M[2][c];
-      }
-    } else {
-      double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
-      if (half == 2) {  // rows of T_intr,i
-        const double2 i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
-        Rm[0] = i6.x; Rm[1] = i6.y; Rm[2] = i7.x; Rm[3] = i7.y; Rm[4] = i8.x; Rm[5] = i8.y; Rm[6] = i9.x; Rm[7] = i9.y; Rm[8] = i10.x;
-      } else {
-        const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
-        Yi[0] = i0.x; Yi[1] = i0.y; Yi[2] = i1.x;
-        Rm[0] = i1.y; Rm[1] = i2.x; Rm[2] = i2.y; Rm[3] = i3.x; Rm[4] = i3.y; Rm[5] = i4.x; Rm[6] = i4.y; Rm[7] = i5.x; Rm[8] = i5.y;
-      }
-      if (half == 0) pair_rows<NC, true>(A, Rm, Yi, Rj);
-      else pair_rows<NC, false>(A, Rm, Yi, Rj);
-    }
-  };
-
   long long clk_sum[6] = {0, 0, 0, 0, 0, 0};
   const long long t_start = CLK ? clock64() : 0;
   int idxA = 0, idxB = 0;
@@ -1618,10 +1204,12 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
   raw = load_raw(second, min(second + stride, last));
   int buf = 0;
-  for (int cur = first; cur < ch_end; cur += stride) {
+  if (SETS == 2 && set == 1) __syncthreads();  // half a period behind set 0: its issue phase falls into set 0's pair phase and vice versa
+  for (int trip = 0; trip < trips; ++trip) {
+    const int cur = min(first + trip * stride, last);
     // everything issued a trip ago has landed (the records of `cur` in `buf`, its codes, the counts and indices of the next
     // chunk), and every wave is done reading the other buffer
-    long long tA = 0, tB = 0, tC = 0, tD = 0;
+    long long tA = 0, tB = 0, tC = 0, tD = 0, tP = 0;
     if (CLK) tA = clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (CLK) tB = clock64();
@@ -1629,9 +1217,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     // still pending (it cannot see the wait above, and for registers whose load sits behind the loop's back edge it inserted
     // its own vmcnt(0) at their first use — in the middle of the pair loop, behind the record loads just issued).
 #pragma unroll
-    for (int v = 0; v < VB; ++v)
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[v][k]));
+    for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[k]));
     // (raw is wave-uniform: left alone the compiler moves it to SGPRs right behind its load — v_readfirstlane, i.e. a wait in the
     // middle of the issue sequence; scalar loads are not used inside the loop, the LDS-DMA intrinsic counts as a clobber)
 #pragma unroll
@@ -1642,16 +1228,11 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     if (EPW > WAVE) asm volatile("" : "+v"(idxB));
     __syncthreads();
     if (CLK) tC = clock64();
-    unsigned cc[VB][NCD];
-    int n_cur[VB];
-    long code_cur[VB];
+    unsigned cc[NCD];
 #pragma unroll
-    for (int v = 0; v < VB; ++v) {
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) cc[v][k] = cd[v][k];
-      n_cur[v] = n_nx[v];
-      code_cur[v] = code_nx[v];
-    }
+    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
+    const int n_cur = (trip < own_trips) ? n_nx : 0;
+    const long code_cur = code_nx;
     const int nxt2 = min(min(cur + stride, last) + stride, last);
     load_codes(raw);                        // codes of the next chunk: addresses from registers, no wait
     int idxA_n = 0, idxB_n = 0;
@@ -1660,26 +1241,24 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     issue(buf ^ 1, idxA, idxB);             // records of the next chunk
     __builtin_amdgcn_sched_barrier(0);
     if (CLK) { tD = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    if (SETS == 2) __syncthreads();         // phase boundary of the whole workgroup: the other set starts issuing, this one multiplies
+    if (CLK) { tP = clock64(); __builtin_amdgcn_sched_barrier(0); }
     const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
-    // (reading the records of pair it + 1 while pair it is multiplied — there would be registers for it in the narrow NC = 6 kernel — measured
+    // (reading the records of pair it + 1 while pair it is multiplied — there would be registers for it in the NC = 6 kernel — measured
     // slower: 112k instead of 98k clocks per wave in the pair phase)
 #pragma unroll
-    for (int v = 0; v < VB; ++v) {
-#pragma unroll
-      for (int it = 0; it < NCD; ++it)
-        if (it < n_cur[v]) pair(acc[v], bufp, cc[v][it]);
-      for (int it = NCD; it < n_cur[v]; ++it) pair(acc[v], bufp, p_codes[code_cur[v] + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
-    }
+    for (int it = 0; it < NCD; ++it)
+      if (it < n_cur) pair(bufp, cc[it]);
+    for (int it = NCD; it < n_cur; ++it) pair(bufp, p_codes[code_cur + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
     if (CLK) {
       __builtin_amdgcn_sched_barrier(0);
       const long long tE = clock64();
-      clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[3] += tE - tD; clk_sum[4] += 1;
-#pragma unroll
-      for (int v = 0; v < VB; ++v) clk_sum[5] += n_cur[v];
+      clk_sum[0] += tB - tA; clk_sum[1] += (tC - tB) + (tP - tD); clk_sum[2] += tD - tC; clk_sum[3] += tE - tP; clk_sum[4] += 1; clk_sum[5] += n_cur;
     }
     raw = raw_n; idxA = idxA_n; idxB = idxB_n;
     buf ^= 1;
   }
+  if (SETS == 2 && set == 0) __syncthreads();  // (set 1's extra barrier at the top)
   if (CLK && lane == 0 && clk) {
     long long* o = clk + ((long)wg * Cfg::NWAVES + sw) * 8;
 #pragma unroll
@@ -1690,120 +1269,62 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last trip's loads target LDS: let them land before the workgroup retires
   // The accumulators hold PRIMED blocks T'_i T'_j^T (T' = [[Y]x Q ; Q ; T_intr]); the true block is P_i^T (.) P_j with P = blockdiag(J_l, I).  That
   // map is linear, so every thread applies it to its own partial block here — ~100 FMAs once per kernel — and no separate pass over the reduced
-  // matrix is needed (k_unprime, one launch per damped step, remains for k_schur_reg2).  tab == nullptr: the caller unprimes.
-  if (tab) {
+  // matrix is needed.
+  if (blk < nblk) {
     const int tile = tp.wg_tile[wg];
     const int ga = tp.tile_a[tile], gb = tp.tile_b[tile];
     const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
     const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
-#pragma unroll
-    for (int v = 0; v < VB; ++v) {
-      const int vt = (SPLIT == 1) ? v * PT + tid : ct;
-      const int blk = (rep > 1) ? vt % nblk : vt;
-      if (blk >= nblk) continue;
-      const int li = blk / tp.g, lj = blk % tp.g;
-      int ci, cj;
-      if (ga == gb && lj <= li) {  // helper thread of a diagonal tile: the (i, i) items of one camera (schur_plan.h)
-        const int hk = li * (li + 1) / 2 + lj;
-        ci = cj = ca0 + hk % max(na, 1);
-      } else {
-        if (li >= na || lj >= nb) continue;  // ragged group: no such camera, nothing was accumulated
-        ci = ca0 + li; cj = cb0 + lj;
-      }
+    const int li = blk / tp.g, lj = blk % tp.g;
+    int ci = -1, cj = -1;
+    if (ga == gb && lj <= li) {  // helper thread of a diagonal tile: the (i, i) items of one camera (schur_plan.h)
+      const int hk = li * (li + 1) / 2 + lj;
+      ci = cj = ca0 + hk % max(na, 1);
+    } else if (li < na && lj < nb) {  // (else a ragged group: no such camera, nothing was accumulated)
+      ci = ca0 + li; cj = cb0 + lj;
+    }
+    if (ci >= 0) {
       const double* Ji = tab + (long)ci * CAMTAB_DOUBLES + 12;  // CamTab::Jl, row-major
       const double* Jj = tab + (long)cj * CAMTAB_DOUBLES + 12;
       if (r0 == 0) {  // rows 0..2 <- J_i^T rows 0..2 (all columns)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const double b0 = acc[v][0][c], b1 = acc[v][1][c], b2 = acc[v][2][c];
+          const double b0 = acc[0][c], b1 = acc[1][c], b2 = acc[2][c];
 #pragma unroll
-          for (int r = 0; r < 3; ++r) acc[v][r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
+          for (int r = 0; r < 3; ++r) acc[r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
         }
       }
 #pragma unroll
       for (int r = 0; r < RH; ++r) {  // columns 0..2 <- (.) J_j, every row the thread owns
-        const double a0 = acc[v][r][0], a1 = acc[v][r][1], a2 = acc[v][r][2];
+        const double a0 = acc[r][0], a1 = acc[r][1], a2 = acc[r][2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[v][r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
+        for (int c = 0; c < 3; ++c) acc[r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
       }
     }
   }
+  if (!owner) return;
 #pragma unroll
-  for (int v = 0; v < VB; ++v) {
-    bool owner;
-    double* dst = out_of(v, &owner);
-    if (!owner) continue;
+  for (int r = 0; r < RH; ++r)
 #pragma unroll
-    for (int r = 0; r < RH; ++r)
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-        if (r0 + r < NC) dst[r * NC + c] = acc[v][r][c];
-  }
+    for (int c = 0; c < NC; ++c)
+      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
 }
 
-template <int NC, int SPLIT, int MINW, bool WIDE = false>
-__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::LAUNCH_THREADS), MINW)
+template <int NC, int SPLIT, int MINW, int SETS = 1>
+__global__ void __launch_bounds__((Reg3Cfg<NC, SETS>::LAUNCH_THREADS), MINW)
 k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, WIDE, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
+  schur_reg3_body<NC, SPLIT, SETS, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
 }
 
-template <int NC, int SPLIT, int MINW, bool WIDE = false>
-__global__ void __launch_bounds__((Reg3Cfg<NC, WIDE>::LAUNCH_THREADS), MINW)
+#ifdef CBA_PROFILING  // tools/build_profiling_lib.sh: the phase-clock build of the pair kernel is not part of the product library
+template <int NC, int SPLIT, int MINW, int SETS = 1>
+__global__ void __launch_bounds__((Reg3Cfg<NC, SETS>::LAUNCH_THREADS), MINW)
 k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, WIDE, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
+  schur_reg3_body<NC, SPLIT, SETS, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
 }
-
-// The pair kernel accumulates PRIMED blocks T'_i T'_j^T, T' = [[Y]x Q ; Q ; T_intr]; the true rows 0..2 are J_l^T times the primed
-// ones, so block (ci, cj) of Sacc becomes P_i^T block P_j with P = blockdiag(J_l, I).  One thread per camera pair ci <= cj,
-// after k_reg_reduce / k_reg_fold and before anything else adds to Sacc (heavy points, constraint rows, the all-reduce).
-template <int NC>
-__global__ void k_unprime(double* __restrict__ Sacc, const double* __restrict__ tab, const int* __restrict__ cam_off,
-                          const int* __restrict__ cam_np, int n_cams, int ncp) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ci = t / n_cams, cj = t % n_cams;
-  if (ci >= n_cams || cj < ci) return;
-  const int npi = cam_np[ci], npj = cam_np[cj];
-  double* base = Sacc + (long)cam_off[ci] * ncp + cam_off[cj];
-  const double* Ji = tab + (long)ci * CAMTAB_DOUBLES + 12;  // CamTab::Jl, row-major
-  const double* Jj = tab + (long)cj * CAMTAB_DOUBLES + 12;
-  // rows 0..2:  J_i^T B (all columns);  for the diagonal block only the upper triangle is stored: mirror what is missing
-  auto at = [&](int r, int c) -> double { return (ci == cj && c < r) ? base[(long)c * ncp + r] : base[(long)r * ncp + c]; };
-  double B[3][NC], Cc[NC][3], TL[3][3];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const double b0 = c < npj ? at(0, c) : 0.0, b1 = c < npj ? at(1, c) : 0.0, b2 = c < npj ? at(2, c) : 0.0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) B[r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
-  }
-  // columns 0..2 of rows 3..: B J_j
-#pragma unroll
-  for (int r = 3; r < NC; ++r) {
-    const double a0 = r < npi ? at(r, 0) : 0.0, a1 = r < npi ? at(r, 1) : 0.0, a2 = r < npi ? at(r, 2) : 0.0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Cc[r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
-  }
-  // top-left 3 x 3: J_i^T B J_j
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) TL[r][c] = B[r][0] * Jj[c] + B[r][1] * Jj[3 + c] + B[r][2] * Jj[6 + c];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (c >= npj || (ci == cj && c < r)) continue;
-      base[(long)r * ncp + c] = (c < 3) ? TL[r][c] : B[r][c];
-    }
-  if (ci != cj) {  // (below the diagonal of a diagonal block: the mirror image of rows 0..2, not stored)
-#pragma unroll
-    for (int r = 3; r < NC; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (r < npi) base[(long)r * ncp + c] = Cc[r][c];
-  }
-}
+#endif
 
 // Reduce the partials of k_schur_reg over the workgroups of each tile (fixed order).  blockDim = (64, Y): x walks the per-thread partial entries,
 // y splits the partial rows of the tile Y ways, Y = 4 or REG_REDUCE_Y_MAX = 16 (the caller's choice: a small rig has ONE tile and up to 500 partial
@@ -1876,44 +1397,6 @@ k_reg_fold(TilePlan tp, const double* __restrict__ red, const int* __restrict__ 
   Sacc[(long)(cam_off[ca0 + cam] + r) * ncp + cam_off[ca0 + cam] + c] = s;
 }
 
-// Sum the per-workgroup tile partials (fixed order) and scatter them into the dense Sacc / bacc, undoing the
-// padded column layout of the LDS tile.  blockDim = (64, 4): x walks the tile entries (coalesced), y splits
-// the workgroups of the tile four ways so that the dependent-load chain per thread stays short.
-__global__ void __launch_bounds__(256)
-k_tile_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
-              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
-              double* __restrict__ Sacc, double* __restrict__ bacc) {
-  __shared__ double sh[4][64];
-  const int t = blockIdx.y;
-  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
-  const int pa0 = tp.group_par_begin[ga], npa = tp.group_par_begin[ga + 1] - pa0;
-  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
-  const int gn = tp.g * NCt, ld = tp.ld;
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  const int w0 = tile_wg_begin[t], w1 = tile_wg_begin[t + 1];
-  double s0 = 0.0, s1 = 0.0;
-  if (e < tp.tile_elems) {
-    int w = w0 + threadIdx.y;
-    for (; w + 4 < w1; w += 8) {
-      s0 += partial[(long)w * tp.tile_elems + e];
-      s1 += partial[(long)(w + 4) * tp.tile_elems + e];
-    }
-    if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
-  }
-  sh[threadIdx.y][threadIdx.x] = s0 + s1;
-  __syncthreads();
-  if (threadIdx.y != 0 || e >= tp.tile_elems) return;
-  const double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-  if (e < gn * ld) {
-    const int r = e / ld, cpad = e % ld;
-    const int cj = cpad / tp.cs, within = cpad % tp.cs;
-    if (r >= npa || cj >= nb || within >= cam_np[cb0 + cj]) return;
-    Sacc[(long)(pa0 + r) * ncp + cam_off[cb0 + cj] + within] = s;
-  } else if (ga == gb && e < gn * ld + npa) {
-    bacc[pa0 + (e - gn * ld)] = s;
-  }
-}
-
 // Sharded solves exchange the reduced camera system: only the upper triangle of Sacc carries data, so the all-reduce moves
 // ncp (ncp + 1) / 2 + ncp doubles (0.59 MB for cfg4) instead of ncp^2 + ncp.  dir = 0 packs [triangle | b], dir = 1 unpacks.
 __global__ void __launch_bounds__(256)
@@ -1983,7 +1466,7 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
 // Dense solve of the reduced camera system  S dc = rhs  (n <= 1152) by blocked Cholesky, NB = 32.
 // The work matrix is (n+1) x ldw, row-major: rows 0..n-1 hold S, row n holds rhs^T.  Row n is "below" every
 // diagonal block, so the panel solves of the factorisation turn it into y^T = (L^-1 rhs)^T for free — the forward
-// substitution needs no kernel of its own; only L^T x = y remains (k_chol_backward).
+// substitution needs no kernel of its own; L^T x = y becomes x = T y with T = L^-T built beside the factorisation (k_chol_apply).
 constexpr int NB = 32;
 
 // broadcast lane `src` (wave-uniform) of a double through SGPRs: two v_readlane_b32, no LDS round trip
@@ -2000,7 +1483,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // Lanes NB.. run the SAME instruction stream on a column of X (lane NB + c keeps column c):  X_jc = (delta_jc - sum_{t<j} L_jt X_tc) / L_jj
 // is the row recurrence with the lane's own values X_tc in the place of L_rt and delta_jc in the place of D_rj; the broadcast row L_j,: and
 // the pivot are shared.  The inverse costs nothing (the lanes were idle) and turns the panel solves of the next step and the backward
-// substitution into matrix products (k_chol_step, k_chol_backward).
+// substitution into matrix products (k_chol_step, k_chol_apply).
 // Row j + 1 of L is read back from LDS as broadcasts (every lane stores its new entry D[lane][j] at pivot j; a wave executes its DS
 // instructions in order, wave-scope fences only pin the compiler) at the top of pivot j, and the sum over its final columns t < j is formed
 // between the instructions of pivot j's chain; the newest entry L_j+1,j travels by v_readlane.
@@ -2321,7 +1804,7 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
 }
 
 // x = L^-T y = T y with the explicit T of the inverse role above: one workgroup per block row, 16 threads per row (coalesced 128-byte reads),
-// fixed summation order.  Replaces k_chol_backward's serial chain (33 us at n = 384, 139 us at n = 1152) by a launch of a few microseconds.
+// fixed summation order.  Replaces the serial chain of a backward substitution (33 us at n = 384, 139 us at n = 1152 in round 2) by a launch of a few microseconds.
 constexpr int APPLY_THREADS = 512;
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_chol_apply(const double* __restrict__ Tinv, const double* __restrict__ W, int n, int ldw, double* __restrict__ out) {
@@ -2341,135 +1824,6 @@ k_chol_apply(const double* __restrict__ Tinv, const double* __restrict__ W, int 
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
   if (cl == 0 && row < n) out[row] = s;
-}
-
-// backward substitution L^T x = y with one workgroup; y^T is row n of the work matrix.  Per diagonal block kb (last to first):
-//   x_kb = X_kb^T y_kb     with the stored inverse X_kb = L_kb,kb^-1 (a 32-term dot product per lane of half a wave; the triangle solve it
-//                          replaces was 32 dependent readlane steps, 0.9 us per block),
-//   y_i -= sum_t L[k0 + t][i] x_t  for every i < k0 (one thread per column, the block's update panel in registers).
-// Everything a block needs from global memory is loaded TWO blocks ahead: its update panel into one of two register sets, its inverse
-// into registers and from there, a block ahead, into one of two LDS copies.  History: loads issued one block ahead landed behind the
-// 0.9 us triangle solve they were meant to overlap with: 3.9 us per block, 47 us for ncp = 384, of which ~2 us per block were exposed
-// load latency; a first inverse-based variant without the deeper prefetch was slower still.
-constexpr int BACK_THREADS = 512;
-__global__ void __launch_bounds__(BACK_THREADS)
-k_chol_backward(const double* __restrict__ L, int n, int ldw, const double* __restrict__ Xinv, double* __restrict__ out,
-                long long* __restrict__ trace = nullptr) {  // trace (CBA_CHOL_TRACE=1): eight 100 MHz stamps
-  extern __shared__ __attribute__((aligned(16))) double y[];  // n + NB
-  __shared__ double sh_X[2][NB][NB + 1];
-  __shared__ double sh_x[NB];
-  constexpr int EPT = NB * NB / BACK_THREADS;  // elements of an inverse per thread
-  const int tid = threadIdx.x;
-  const int nblk = (n + NB - 1) / NB;
-  const bool stamp = trace != nullptr && tid == 0;
-  if (stamp) trace[0] = wall_clock64();
-  for (int i = tid; i < n + NB; i += BACK_THREADS) y[i] = (i < n) ? L[(long)n * ldw + i] : 0.0;  // NB zeros behind y: the last block may be partial
-  // loads are unconditional (clamped block index, results of a block < 0 are never used): a load under a branch makes the compiler
-  // drain vmcnt at the join
-  // The prefetching loads are inline asm: the compiler does not track them, so it inserts no waits of its own for them (for a register
-  // loaded behind the loop's back edge that is a vmcnt(0) at the first use, i.e. a wait for the NEXT block's loads too); the one wait they
-  // need is the explicit s_waitcnt at the top of a step.  (Its own loads stay correct: vmcnt counts in order, extra loads in flight only make
-  // a compiler-inserted wait stricter.)
-  auto asm_load = [](const double* ptr) {
-    double v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-  };
-  auto load_x = [&](int kb_req, double (&xr)[EPT]) {
-    const int kb = max(kb_req, 0);
-#pragma unroll
-    for (int h = 0; h < EPT; ++h) xr[h] = asm_load(Xinv + (long)kb * NB * NB + tid + h * BACK_THREADS);
-  };
-  auto store_x = [&](int kb, const double (&xr)[EPT]) {
-#pragma unroll
-    for (int h = 0; h < EPT; ++h) {
-      const int e = tid + h * BACK_THREADS;
-      sh_X[kb & 1][e / NB][e % NB] = xr[h];
-    }
-  };
-  auto load_panel = [&](int kb_req, double (&lp)[NB]) {  // column min(tid, n - 1) of rows k0 .. k0 + NB (clamped into the block)
-    const int kb = max(kb_req, 0);
-    const int k0 = kb * NB, nb = min(NB, n - k0);
-    // ONE running address (32 precomputed ones per panel spilled).  Columns >= k0 are not part of the panel: their threads load one fixed
-    // word instead (the same number of loads in every wave keeps the vmcnt arithmetic of `step` valid; all 512 threads loading real columns
-    // made the substitution bound by the one CU's path to the L2: 131 KB per block)
-    const bool live = tid < k0;
-    const double* pp = live ? L + (long)k0 * ldw + tid : L;
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      lp[t] = asm_load(pp);
-      pp += (live && t + 1 < nb) ? ldw : 0;
-    }
-  };
-  double lpA[NB], lpB[NB], xrA[EPT], xrB[EPT];
-  const int last = nblk - 1;
-  load_x(last, xrA);
-  load_x(last - 1, xrB);
-  load_panel(last, lpA);
-  load_panel(last - 1, lpB);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int h = 0; h < EPT; ++h) asm volatile("" : "+v"(xrA[h]));
-  store_x(last, xrA);
-  if (stamp) trace[1] = wall_clock64();
-  // from here on the loads in flight are, oldest first: [inverse last - 2 | panel .. ] ... see the count in `step`
-  load_x(last - 2, xrA);
-  // block kb with its panel in `lp`; `xr` holds the inverse of block kb - 1 (parked in LDS here, then reloaded with block kb - 3's)
-  auto step = [&](int kb, double (&lp)[NB], double (&xr)[EPT]) {
-    const int k0 = kb * NB, nb = min(NB, n - k0);
-    // `lp` and `xr` were loaded two steps ago; what was issued since (the other inverse and the other panel: EPT + NB loads) may stay in
-    // flight.  The compiler cannot see this wait, and for registers loaded behind the loop's back edge it would put a vmcnt(0) in front of
-    // their first use — i.e. wait for the loads of the NEXT block as well: the values pass through an empty asm (as in schur_reg3_body).
-    static_assert(NB + EPT == 34, "vmcnt below");
-    asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < NB; ++t) asm volatile("" : "+v"(lp[t]));
-#pragma unroll
-    for (int h = 0; h < EPT; ++h) asm volatile("" : "+v"(xr[h]));
-    __syncthreads();  // y_kb is final (the folds of block kb + 1), the inverse of block kb is in its LDS copy
-    if (tid < NB) {
-      double a[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < NB; ++r) a[r & 3] = fma(sh_X[kb & 1][r][tid], y[k0 + r], a[r & 3]);  // (rows >= nb: zeros behind y, times the identity padding)
-      const double xt = (a[0] + a[1]) + (a[2] + a[3]);
-      sh_x[tid] = (tid < nb) ? xt : 0.0;
-    }
-    store_x(kb + 1, xr);  // the copy block kb + 1 used: now block kb - 1's (kb = 0: nobody reads it)
-    load_x(kb - 3, xr);
-    __syncthreads();  // x_kb
-    if (tid < nb) y[k0 + tid] = sh_x[tid];
-    {
-      double acc[2] = {0.0, 0.0};
-#pragma unroll
-      for (int t0 = 0; t0 < NB; t0 += 8) {  // eight at a time: with all 32 LDS reads hoisted in front of the FMAs the two panel sets spilled
-#pragma unroll
-        for (int t = t0; t < t0 + 8; ++t) acc[t & 1] = fma(lp[t], sh_x[t], acc[t & 1]);  // (t >= nb: x_t = 0)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (tid < k0) y[tid] -= acc[0] + acc[1];
-    }
-    for (int i2 = tid + BACK_THREADS; i2 < k0; i2 += BACK_THREADS) {  // wider systems: the rest of the panel
-      double acc = 0.0;
-#pragma unroll 8
-      for (int t = 0; t < nb; ++t) acc += L[(long)(k0 + t) * ldw + i2] * sh_x[t];
-      y[i2] -= acc;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (hoisted in front of the fold, the reload needs a third set of panel registers)
-    load_panel(kb - 2, lp);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int kb = last; kb >= 0; kb -= 2) {
-    step(kb, lpA, xrB);
-    if (stamp && kb == last) trace[2] = wall_clock64();
-    if (kb >= 1) step(kb - 1, lpB, xrA);
-    if (stamp && kb == last) trace[3] = wall_clock64();
-  }
-  if (stamp) trace[4] = wall_clock64();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches (clamped, unused)
-  if (stamp) trace[5] = wall_clock64();
-  __syncthreads();
-  for (int i = tid; i < n; i += BACK_THREADS) out[i] = y[i];
-  if (stamp) trace[6] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2774,8 +2128,7 @@ __device__ __forceinline__ double column_sum(const double* __restrict__ partial,
 // the three reductions of the linearisation (sums, max |g|, ||J v||^2) and the damping in one launch
 __global__ void __launch_bounds__(BLOCK)
 k_lin_finish(const double* __restrict__ partial_lin, const double* __restrict__ partial_max, int rows_lin,
-             const double* __restrict__ partial_jv, int rows_jv, double radius, double* __restrict__ scal, double* __restrict__ fz,
-             const double* __restrict__ radius_dev = nullptr) {  // radius_dev: the radius is read from (mapped host) memory — replayed step graphs
+             const double* __restrict__ partial_jv, int rows_jv, double radius, double* __restrict__ scal, double* __restrict__ fz) {
   // nine sums and a maximum in ONE pass and one barrier (column by column — ten block reductions in a row — the kernel took 10.6 us);
   // per value the order of the additions is the one of column_sum / block_sum
   __shared__ double sh_red[10][BLOCK / WAVE];
@@ -2805,7 +2158,7 @@ k_lin_finish(const double* __restrict__ partial_lin, const double* __restrict__ 
       for (int i = 0; i < BLOCK / WAVE; ++i) r = (q == 4) ? fmax(r, sh_red[q][i]) : r + sh_red[q][i];
       scal[q < 5 ? q : 12 + (q - 5)] = r;
     }
-    fused_lam(scal, radius_dev ? *radius_dev : radius, fz);
+    fused_lam(scal, radius, fz);
   }
 }
 
@@ -2867,10 +2220,9 @@ k_step_small(const double* __restrict__ g, const double* __restrict__ sinv, cons
 __global__ void __launch_bounds__(BLOCK)
 k_publish(double* __restrict__ scal, int n_scal, int* __restrict__ flags, double* __restrict__ host_scal,
           int* __restrict__ host_flags, unsigned long long seq, const double* __restrict__ part_a, int rows_a, int slot_a,
-          const double* __restrict__ part_b, int rows_b, int slot_b, const unsigned long long* __restrict__ seq_dev = nullptr) {
+          const double* __restrict__ part_b, int rows_b, int slot_b) {
   __shared__ double sh_red[BLOCK / WAVE];
   const int t = threadIdx.x;
-  if (seq_dev) seq = *reinterpret_cast<const volatile unsigned long long*>(seq_dev);  // replayed step graphs: the host leaves the number in the mailbox
   // single-rank fused step: the last two per-workgroup partial columns (trial cost, step norm) are summed here
   if (part_a) { const double r = column_sum(part_a, rows_a, 1, 0, sh_red); if (t == 0) scal[slot_a] = r; }
   if (part_b) { const double r = column_sum(part_b, rows_b, 1, 0, sh_red); if (t == 0) scal[slot_b] = r; }

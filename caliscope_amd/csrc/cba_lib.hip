@@ -75,11 +75,9 @@ struct cba_problem {
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  bool schur_reg = false;  // register-accumulating Schur kernel (k_tprep + k_schur_reg / k_schur_reg2); false: LDS-atomic tile kernel
-  bool schur_v2 = false;   // dealt plan + register kernel (always with schur_reg)
-  bool schur_wide = false; // k_schur_reg3<6, ..., WIDE>: 32 x 32 camera tiles, 512 threads with two blocks each (CBA_SCHUR_WIDE=1; six-parameter cameras, more than 16)
-  bool schur_v3 = true;    // k_schur_reg3 (records loaded straight into a double-buffered LDS chunk); CBA_SCHUR=reg2: k_schur_reg2 (register-staged)
-  double plan_lane_util = 0.0;  // schur_v2: share of the lane-iterations of the pair loops that multiply a real pair
+  bool schur_pp = false;   // k_schur_reg3<6, .., SETS = 2>: two sets of four waves per workgroup in anti-phase (one workgroup per CU) instead of two workgroups per CU
+  int cus = 256;           // compute units of the device
+  double plan_lane_util = 0.0;  // share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
   TilePlan tp{};
   int* tile_wg_begin = nullptr;
@@ -109,7 +107,7 @@ struct cba_problem {
   DetPlan det{nullptr, nullptr};
   double* tri = nullptr;   // packed upper triangle of Sacc + b for the exchange of a sharded solve
   double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
-  double* Tinv = nullptr;  // T = L^-T, built block by block next to the factorisation (inverse role of k_chol_step); nullptr: CBA_CHOL_BACKWARD=subst
+  double* Tinv = nullptr;  // T = L^-T, built block by block next to the factorisation (inverse role of k_chol_step)
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
@@ -144,22 +142,14 @@ struct cba_problem {
   double* sinv2 = nullptr;
   bool spec_enqueued = false, spec_valid = false;
   int spec_rows_jv = 0;
-  // Steady-state fused iterations are replayed from a hipGraph (one per pointer parity: x / V / sinv swap on acceptance): ~30 launches become one
-  // hipGraphLaunch.  What changes from iteration to iteration travels through the mapped mailbox: h_scal[60] the radius, h_scal[61] the
-  // sequence number k_publish answers with.  `capturing`: the launches are being recorded, not executed (run_cholesky records its launches inline).
-  struct StepGraph { const void *x, *V, *sinv; hipGraph_t graph; hipGraphExec_t exec; };
-  std::vector<StepGraph> step_graphs;
-  bool capturing = false;
-  long step_graph_launches = 0;
   bool have_x0 = false;
   std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
-  struct PlanTask* plan_task = nullptr;  // CBA_PLAN=swap: the thread still dealing the Schur plan while the handle works with the cheap one
+  struct PlanTask* plan_task = nullptr;  // two-stage plan: the thread still dealing the Schur plan while the handle works with the cheap one
   int reg_reduce_y = 4;                  // y extent of k_reg_reduce's workgroups (4 or 16: by the partial rows per tile)
   int plan_max_blocks = 0;               // workgroup budget of the pair kernel (the dealt plan is bound with the same one when it is swapped in)
   size_t partial_capacity = 0;           // doubles behind `partial`
   bool plan_is_cheap = false;
-  bool schur_clock = false;  // profiling only (CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
-  int debug_skip = 0;  // profiling only (CBA_DEBUG_SCHUR_SKIP): 1 = skip the pair phase, 2 = skip the block recomputation
+  bool schur_clock = false;  // profiling build only (-DCBA_PROFILING, CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
   bool begun = false, linearized = false, stepped = false, have_trial = false;
   double gh_sq = 0.0;
   std::vector<int> h_cam_off, h_cam_np;
@@ -175,40 +165,13 @@ struct cba_problem {
   size_t mail_doubles = 0;     // capacity of the mapped host mailbox (h_scal)
   char* arena_cur = nullptr; size_t arena_left = 0, arena_next = (size_t)4 << 20;
   // sharded solve (points partitioned over ranks, cameras replicated): RCCL over xGMI
-  ncclComm_t comm = nullptr;
+  std::atomic<ncclComm_t> comm{nullptr};
+  std::atomic<bool> comm_aborted{false};  // cba_comm_abort was called (from another thread): every collective of this handle fails from now on
   cba_group* group = nullptr;  // in-process device group (cba_group_join): direct peer-to-peer exchange instead of RCCL
   int rank = 0, world = 1;
   unsigned long long group_generation = 0;
-  bool sharded() const { return comm != nullptr || group != nullptr; }
-  hipGraph_t chol_graph = nullptr;
-  hipGraphExec_t chol_exec = nullptr;
+  bool sharded() const { return comm.load() != nullptr || group != nullptr || comm_aborted.load(); }
 };
-
-// Stream capture and other threads: while one thread records the Cholesky graph, this runtime rejects allocation,
-// memset and synchronous-copy calls of every other thread (they fail, and the capture is invalidated), thread-local capture
-// mode notwithstanding.  The recording takes this lock exclusively; every entry point that talks to the device holds it
-// shared, so handles run concurrently across threads and only wait while another thread records its graph (once per handle).
-static int ensure_cholesky_graph(cba_problem* p);
-static bool cholesky_as_graph();
-static std::shared_mutex g_capture_mu;
-static thread_local int tl_capture_safe_depth = 0;
-struct CaptureSafe {  // shared side; nests within a thread (entry point -> helper)
-  explicit CaptureSafe(std::shared_mutex&) { if (tl_capture_safe_depth++ == 0) g_capture_mu.lock_shared(); }
-  ~CaptureSafe() { if (--tl_capture_safe_depth == 0) g_capture_mu.unlock_shared(); }
-  CaptureSafe(const CaptureSafe&) = delete;
-  CaptureSafe& operator=(const CaptureSafe&) = delete;
-};
-struct CaptureRecording {  // exclusive side; gives the thread's shared hold back for the duration (no upgrade deadlock)
-  bool held = tl_capture_safe_depth > 0;
-  CaptureRecording() { if (held) g_capture_mu.unlock_shared(); g_capture_mu.lock(); }
-  ~CaptureRecording() { g_capture_mu.unlock(); if (held) g_capture_mu.lock_shared(); }
-};
-static hipError_t guarded_malloc(void** ptr, size_t bytes) { CaptureSafe g(g_capture_mu); return hipMalloc(ptr, bytes); }
-static hipError_t guarded_free(void* ptr) { CaptureSafe g(g_capture_mu); return hipFree(ptr); }
-static hipError_t guarded_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
-  CaptureSafe g(g_capture_mu);
-  return hipMemcpy(dst, src, bytes, kind);
-}
 
 // What a small handle is made of is recycled: per device the library keeps up to four first arena chunks (4 MB), streams and mapped host
 // mailboxes of destroyed handles and hands them to the next cba_create.  hipMalloc / hipFree / hipStreamCreate / hipHostMalloc are
@@ -238,7 +201,7 @@ static int dev_alloc(cba_problem* p, T** out, size_t count) {
       DevicePool& pool = g_pool[p->device];
       if (!pool.chunks.empty()) { ptr = pool.chunks.back(); pool.chunks.pop_back(); }
     }
-    if (!ptr) HIPCHK(guarded_malloc(&ptr, chunk));
+    if (!ptr) HIPCHK(hipMalloc(&ptr, chunk));
     p->allocs.push_back(ptr);
     p->alloc_bytes.push_back(chunk);
     if (bytes >= p->arena_next) {  // a buffer of its own: the open chunk stays open
@@ -261,7 +224,7 @@ static int dev_upload(cba_problem* p, T** out, const V& h) {  // V: any contiguo
   static_assert(std::is_same<typename std::remove_cv<typename std::remove_pointer<decltype(h.data())>::type>::type, T>::value, "element type");
   int rc = dev_alloc(p, out, h.size());
   if (rc) return rc;
-  if (!h.empty()) HIPCHK(guarded_memcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!h.empty()) HIPCHK(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return CBA_OK;
 }
 
@@ -320,14 +283,9 @@ static void drain_timers(cba_problem* p) {
 // part_a / part_b: per-workgroup partial columns whose sums belong to scal[slot_a] / scal[slot_b] (compact fused step)
 static unsigned long long publish_enqueue(cba_problem* p, int n_scal, const double* part_a = nullptr, int rows_a = 0, int slot_a = 0,
                                           const double* part_b = nullptr, int rows_b = 0, int slot_b = 0) {
-  if (p->capturing) {  // the recorded k_publish reads its sequence number from the mailbox (h_scal[61], written by the host before every replay)
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, 0ull, part_a, rows_a,
-                       slot_a, part_b, rows_b, slot_b, reinterpret_cast<const unsigned long long*>(p->d_hscal + 61));
-    return p->publish_seq;
-  }
   const unsigned long long seq = ++p->publish_seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, p->stream, p->scal, n_scal, p->flags, p->d_hscal, p->d_hflags, seq, part_a, rows_a,
-                     slot_a, part_b, rows_b, slot_b, (const unsigned long long*)nullptr);
+                     slot_a, part_b, rows_b, slot_b);
   return seq;
 }
 // wait until the k_publish with sequence number `seq` has written its packet.  `drain`: nothing was enqueued behind it, a stream synchronize
@@ -449,10 +407,12 @@ static int group_allreduce(cba_problem* p, double* buf, size_t count) {
 
 // in-place sum over the ranks of a sharded solve, enqueued on the engine's stream (no-op for world 1)
 static int allreduce_sum(cba_problem* p, double* buf, size_t count) {
-  if (!p->group && !p->comm) return CBA_OK;
+  if (p->comm_aborted.load(std::memory_order_acquire)) return fail(CBA_ERR_COMM, "the communicator of rank %d was aborted (another rank failed)", p->rank);
+  ncclComm_t comm = p->comm.load();
+  if (!p->group && !comm) return CBA_OK;
   ScopedTimer t(p, T_EXCHANGE);  // nested inside the family that needs the sum: comm time per step, reported next to the families
   if (p->group) return group_allreduce(p, buf, count);
-  NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, p->comm, p->stream));
+  NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, p->stream));
   return CBA_OK;
 }
 // one all-reduce for the host-visible scalars of a primitive: scal slots in `mask`, the flags, optionally max |g|
@@ -476,7 +436,6 @@ static inline int vec_grid(long total) { return (int)std::min<long>((total + BLO
 extern "C" {
 
 int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_out, double* undistorted_out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!d || !xyz_out) return fail(CBA_ERR_INVALID, "cba_triangulate: null argument");
   if (d->n_cams <= 0 || d->n_points < 0 || !d->cam_P || (d->n_points > 0 && (!d->pt_start || !d->obs_cam || !d->obs_xy)))
     return fail(CBA_ERR_INVALID, "cba_triangulate: bad descriptor");
@@ -490,12 +449,12 @@ int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_o
   for (int64_t i = 0; i < n_obs; ++i)
     if (d->obs_cam[i] < 0 || d->obs_cam[i] >= d->n_cams) return fail(CBA_ERR_INVALID, "cba_triangulate: obs_cam[%lld] out of range", (long long)i);
   std::vector<void*> bufs;
-  auto cleanup = [&]() { for (void* b : bufs) (void)guarded_free(b); };
+  auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); };
   auto up = [&](const void* src, size_t bytes, void** dst) -> int {
     void* ptr = nullptr;
-    if (guarded_malloc(&ptr, std::max<size_t>(bytes, 8)) != hipSuccess) return CBA_ERR_HIP;
+    if (hipMalloc(&ptr, std::max<size_t>(bytes, 8)) != hipSuccess) return CBA_ERR_HIP;
     bufs.push_back(ptr);
-    if (src && bytes && guarded_memcpy(ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CBA_ERR_HIP;
+    if (src && bytes && hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CBA_ERR_HIP;
     *dst = ptr;
     return CBA_OK;
   };
@@ -514,8 +473,8 @@ int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_o
   hipLaunchKernelGGL(k_triangulate, dim3(grid), dim3(BLOCK), 0, 0, (long)d->n_points, (const long*)dps, (const int*)dcam, (const double*)dxy,
                      (const int*)dmodel, (const double*)dintr, (const double*)dP, d->float32_io ? 1 : 0, (double*)dxyz, (double*)dund);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = guarded_memcpy(xyz_out, dxyz, (size_t)d->n_points * 3 * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && undistorted_out) e = guarded_memcpy(undistorted_out, dund, (size_t)n_obs * 2 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(xyz_out, dxyz, (size_t)d->n_points * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && undistorted_out) e = hipMemcpy(undistorted_out, dund, (size_t)n_obs * 2 * sizeof(double), hipMemcpyDeviceToHost);
   cleanup();
   if (e != hipSuccess) return fail(CBA_ERR_HIP, "cba_triangulate: %s", hipGetErrorString(e));
   return CBA_OK;
@@ -542,20 +501,14 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
 static void drop_plan_task(cba_problem* p);  // (PlanTask is defined with the plans further down)
 
 void cba_destroy(cba_problem* p) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return;
   drop_plan_task(p);  // a plan thread still dealing: cancelled and joined before anything it could look at goes away
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drain_timers(p);
   for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  if (p->comm) (void)ncclCommDestroy(p->comm);
-  for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-  p->step_graphs.clear();
-  if (p->chol_exec) (void)hipGraphExecDestroy(p->chol_exec);
-  if (p->chol_graph) (void)hipGraphDestroy(p->chol_graph);
+  if (ncclComm_t c = p->comm.exchange(nullptr)) (void)ncclCommDestroy(c);  // (an aborted communicator was taken out by cba_comm_abort)
   {
-    CaptureSafe g(g_capture_mu);
     std::lock_guard<std::mutex> lock(g_pool_mu);  // (the stream is drained: nothing of this handle is in flight)
     DevicePool& pool = g_pool[p->device];
     for (size_t i = 0; i < p->allocs.size(); ++i) {
@@ -621,14 +574,8 @@ template <int NC> static size_t lds_build(const cba_problem* p) {
   return ((size_t)p->C * CAMTAB_LDS + (size_t)p->C * UPack<NC>::STRIDE + 9 * CHUNK + 8) * 8;
 }
 static size_t lds_jv(const cba_problem* p, int nv) { return (lds_tab(p) + (size_t)nv * p->lay.ncp_pad + 8) * 8; }
-static inline int tile_cs(int nc) { return nc | 1; }
-static inline int tile_ld(int g, int nc) { const int w = g * tile_cs(nc); return (w & 1) ? w : w + 1; }
-template <int NC> static size_t lds_schur_tile(int g) {
-  const size_t gn = (size_t)g * NC;
-  return ((size_t)2 * g * CAMTAB_LDS + 2 * NC * CHUNK + 6 * CHUNK + gn + gn * tile_ld(g, NC)) * 8 + ((size_t)4 * g + CHUNK) * sizeof(int);
-}
 // Register-accumulating Schur kernel per camera width: rows of a camera-pair block per thread = NC / SPLIT, minimum waves
-// per SIMD the kernel is compiled for, resident workgroups per CU the plan sizes its grid for (see k_schur_reg).
+// per SIMD the kernel is compiled for, resident workgroups per CU the plan sizes its grid for (see k_schur_reg3).
 template <int NC> struct RegCfg;
 template <> struct RegCfg<6> { static constexpr int SPLIT = 1, MINW = 2, PER_CU = 2; };
 template <> struct RegCfg<9> { static constexpr int SPLIT = 3, MINW = 3, PER_CU = 1; };
@@ -636,134 +583,25 @@ template <int NC> static size_t lds_tprep(const cba_problem* p) {
   if (p->det_m) return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + (size_t)p->C * CAMTAB_LDS + (size_t)DET_ROUND * DET_LD) * 8 + ((size_t)CHUNK + p->C + 1) * 4;
   return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + lds_tab(p) + p->lay.ncp_pad) * 8;
 }
-constexpr size_t kSchurLdsBudget = 144 * 1024;
-constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads (the wide kernel: Reg3Cfg<6, true>::GROUP)
+constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 static size_t lds_backsub(const cba_problem* p) { return (lds_tab(p) + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
 // Workgroup -> tile binding shared by the tile plans (csrc/wg_binding.h): sets the grid of the tiled Schur kernel
-static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, bool reg, const std::vector<double>* tile_cost = nullptr) {
-  WgBinding out = cba::bind_workgroups(TCB, nT, max_blocks, reg, tile_cost);
+static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, const std::vector<double>* tile_cost = nullptr) {
+  WgBinding out = cba::bind_workgroups(TCB, nT, max_blocks, true, tile_cost);
   p->tile_grid = out.grid;
   return out;
 }
 
-// Static plan of the LDS-tile Schur kernel (k_schur_tile, the fallback behind CBA_SCHUR=lds and for points too large
-// for the pair plan): camera groups, one observation stream per tile (a <= b) in point order, chunk tables, the
-// observation pairs of every chunk and the workgroup -> tile binding.  The register kernels have their own plan
-// (schur_plan.h, build_reg2_tile_plan).
-static int build_tile_plan(cba_problem* p, const std::vector<double>& hu, const std::vector<double>& hv,
-                           const std::vector<int>& hcam, const std::vector<int>& hpt, const std::vector<int>& hps,
-                           const std::vector<int>& cam_off, int max_blocks) {
-  const int G = p->G, g = p->gsz, C = p->C, P = p->P;
-  const int nT = p->n_tiles;
-  std::vector<int> gcam(G + 1), gpar(G + 1);
-  for (int a = 0; a <= G; ++a) {
-    gcam[a] = std::min(a * g, C);
-    gpar[a] = (gcam[a] < C) ? cam_off[gcam[a]] : p->ncp;
-  }
-  std::vector<int> ta(nT), tb(nT);
-  {
-    int t = 0;
-    for (int a = 0; a < G; ++a)
-      for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
-  }
-  struct Stream {
-    std::vector<double> u, v;
-    std::vector<int> pt;
-    std::vector<unsigned char> cl;
-    std::vector<pair_t> pairs;
-    std::vector<int> chunk_start{0}, pair_start{0};
-    int rc = CBA_OK;
-  };
-  std::vector<Stream> st(nT);
-  auto build_stream = [&](int t) {
-    Stream& s = st[t];
-    const int a = ta[t], b = tb[t];
-    int open = 0;
-    for (int q = 0; q < P; ++q) {
-      int ia = hps[q], s1 = hps[q + 1];
-      while (ia < s1 && hcam[ia] < gcam[a]) ++ia;
-      int ea = ia;
-      while (ea < s1 && hcam[ea] < gcam[a + 1]) ++ea;
-      int ib = ea, eb = ea;
-      if (b != a) {
-        while (ib < s1 && hcam[ib] < gcam[b]) ++ib;
-        eb = ib;
-        while (eb < s1 && hcam[eb] < gcam[b + 1]) ++eb;
-      }
-      const int na = ea - ia, nb = (b == a) ? 0 : eb - ib;
-      if (na <= 0 || (b != a && nb <= 0)) continue;
-      if (na + nb > CHUNK) { s.rc = CBA_ERR_UNSUPPORTED; return; }
-      if ((int)s.pt.size() - open + na + nb > CHUNK) {
-        s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size()); open = (int)s.pt.size();
-      }
-      const int base = (int)s.pt.size() - open;  // chunk-local index of this point's first entry
-      for (int i = ia; i < ea; ++i) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.cl.push_back((unsigned char)(hcam[i] - gcam[a])); }
-      for (int i = ib; i < ib + nb; ++i) { s.u.push_back(hu[i]); s.v.push_back(hv[i]); s.pt.push_back(hpt[i]); s.cl.push_back((unsigned char)(g + hcam[i] - gcam[b])); }
-      // pairs (row observation i, column observation j), chunk-local, camera(i) <= camera(j)
-      for (int i = 0; i < na; ++i)
-        for (int j = (b == a) ? i : na; j < ((b == a) ? na : na + nb); ++j) s.pairs.push_back((pair_t)((base + i) | ((base + j) << 16)));
-    }
-    if ((int)s.pt.size() > open || s.chunk_start.size() == 1) { s.chunk_start.push_back((int)s.pt.size()); s.pair_start.push_back((int)s.pairs.size()); }
-  };
-  {
-    std::vector<std::thread> workers;
-    for (int t = 1; t < nT; ++t) workers.emplace_back(build_stream, t);
-    build_stream(0);
-    for (auto& w : workers) w.join();
-  }
-  for (const Stream& sj : st)
-    if (sj.rc) return sj.rc;
-  std::vector<double> U, V;
-  std::vector<int> PT, CS{0}, PS{0}, TCB(nT + 1, 0);
-  std::vector<unsigned char> CL;
-  std::vector<pair_t> PR;
-  for (int t = 0; t < nT; ++t) {
-    Stream& sj = st[t];
-    TCB[t] = (int)CS.size() - 1;
-    const int base = (int)PT.size(), pbase = (int)PR.size();
-    U.insert(U.end(), sj.u.begin(), sj.u.end()); V.insert(V.end(), sj.v.begin(), sj.v.end());
-    PT.insert(PT.end(), sj.pt.begin(), sj.pt.end()); CL.insert(CL.end(), sj.cl.begin(), sj.cl.end());
-    PR.insert(PR.end(), sj.pairs.begin(), sj.pairs.end());
-    for (size_t c = 1; c < sj.chunk_start.size(); ++c) {
-      if (sj.chunk_start[c] == sj.chunk_start[c - 1]) continue;  // an empty stream: no chunk
-      CS.push_back(base + sj.chunk_start[c]); PS.push_back(pbase + sj.pair_start[c]);
-    }
-    sj = Stream();
-  }
-  TCB[nT] = (int)CS.size() - 1;
-  p->n_tile_chunks = TCB[nT];
-  p->tile_stream_len = (long)PT.size();
-  p->n_pairs = (long)PR.size();
-  const WgBinding bind = bind_workgroups(p, TCB, nT, max_blocks, false);
-
-  int rc;
-  double *du = nullptr, *dv = nullptr;
-  int *dpt = nullptr, *dcs = nullptr, *dps = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
-      *dgc = nullptr, *dgp = nullptr;
-  unsigned char* dcl = nullptr;
-  pair_t* dpr = nullptr;
-#define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
-  TRYP(dev_upload(p, &du, U)); TRYP(dev_upload(p, &dv, V)); TRYP(dev_upload(p, &dpt, PT)); TRYP(dev_upload(p, &dcl, CL));
-  TRYP(dev_upload(p, &dpr, PR)); TRYP(dev_upload(p, &dps, PS)); TRYP(dev_upload(p, &dcs, CS));
-  TRYP(dev_upload(p, &dwf, bind.wfirst)); TRYP(dev_upload(p, &dwt, bind.wt)); TRYP(dev_upload(p, &dwe, bind.wend)); TRYP(dev_upload(p, &dws, bind.wstride));
-  TRYP(dev_upload(p, &dta, ta)); TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
-  TRYP(dev_upload(p, &p->tile_wg_begin, bind.wgb));
-#undef TRYP
-  const int gn = g * p->nct;
-  TilePlan tp{};
-  tp.u = du; tp.v = dv; tp.pt = dpt; tp.camloc = dcl; tp.pairs = dpr; tp.pair_start = dps; tp.chunk_start = dcs;
-  tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
-  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
-  tp.tile_elems = gn * tp.ld + gn; tp.rep = 1;
-  p->tp = tp;
-  return CBA_OK;
-}
-
-// Plan of the register kernels (schur_plan.h builds it on the host).  The dealing is ~1 us of host work per observation and needs nothing but the
+// Plan of the pair kernel (schur_plan.h builds it on the host).  The dealing is ~1 us of host work per observation and needs nothing but the
 // sorted camera indices, so cba_create starts it on a thread of its own as soon as those exist (PlanTask) and does its uploads, the camera-sorted
 // copy and the allocations meanwhile; finish_reg2_tile_plan then binds the workgroups and uploads the plan.
+static bool plan_timing_on() {  // CBA_PLAN_TIMING=1: the phases of cba_create and of the plan builder on stderr (tools/create_timing.py)
+  static const bool on = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  return on;
+}
+
 template <int NC, typename KCfg>
 static Reg2Params reg2_params(const cba_problem* p) {
   Reg2Params prm;
@@ -771,17 +609,11 @@ static Reg2Params reg2_params(const cba_problem* p) {
   prm.C = p->C; prm.P = p->P; prm.G = p->G; prm.g = g;
   constexpr int CT = KCfg::CODE_THREADS;
   prm.rep = (NC == 6 && g * g <= CT / 2) ? CT / (g * g) : 1;  // small groups: several threads per block
-  if (const char* e = std::getenv("CBA_SCHUR_REP")) prm.rep = (NC == 6) ? std::max(1, std::min(std::atoi(e), CT / std::max(g * g, 1))) : 1;
   prm.n_waves = KCfg::CODE_WAVES;
   prm.pair_cap = KCfg::PAIR_CAP;
-  if (const char* e = std::getenv("CBA_PLAN_PAIR_CAP")) prm.pair_cap = std::atoi(e);
   prm.chunk_cap = KCfg::SCHUNK;
   prm.slots_per_wave = KCfg::EPW; prm.wave_pieces = KCfg::WAVE_PIECES; prm.rec_pieces = KCfg::LST;
   prm.zero_piece = KCfg::ZERO_PIECE;
-  if (KCfg::CODE_WAVES > 4) prm.region_chunks = 128;  // wide tiles: ~1 pair per block and chunk, the dealing needs room (lane utilisation 0.44 at 32, 0.50 at 128); only two tiles gather a record
-  if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("CBA_PLAN_SWEEPS")) prm.colour_sweeps = std::max(0, std::atoi(e));
-  if (const char* e = std::getenv("CBA_PLAN_THREADS")) prm.threads = std::max(1, std::atoi(e));
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
   return prm;
 }
@@ -837,7 +669,7 @@ template <int NC, typename KCfg>
 static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm, const std::vector<int>& cam_off, int max_blocks) {
   const int G = p->G, g = p->gsz, C = p->C;
   const int nT = p->n_tiles;
-  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  const bool plan_timing = plan_timing_on();
   auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = t_now();
   auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
@@ -852,10 +684,9 @@ static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Param
             plan.lds_groups ? (double)plan.lds_cycles / plan.lds_groups : 0.0, plan.lds_groups ? (double)plan.lds_cycles_arrival / plan.lds_groups : 0.0);
   // cost of a chunk: gather + barrier (in units of one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its
   // slowest wave
-  double cost_a = 2.0;
-  if (const char* e = std::getenv("CBA_PLAN_COST_A")) cost_a = std::atof(e);
+  const double cost_a = 2.0;
   const std::vector<double> tile_cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, KCfg::CODE_WAVES, KCfg::REG_BLOCK / KCfg::SPLIT / WAVE, cost_a);
-  const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, true, cost_a >= 0.0 ? &tile_cost : nullptr);
+  const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, &tile_cost);
   lap("workgroup binding");
   std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
   for (int a = 0; a <= G; ++a) {
@@ -887,7 +718,7 @@ static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Param
   lap("upload");
   TilePlan tp{};
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
-  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g; tp.cs = tile_cs(p->nct); tp.ld = tile_ld(g, p->nct);
+  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g;
   tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
   tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
   p->tp = tp;
@@ -899,45 +730,25 @@ static void drop_plan_task(cba_problem* p) {
   p->plan_task = nullptr;
 }
 
-// binds and uploads `plan` for the register kernel the handle runs
+// binds and uploads `plan`; decides the form of the pair kernel from the grid the binding chose
 static int install_reg2_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm) {
   const int mb = p->plan_max_blocks;
-  if (p->schur_wide) return finish_reg2_tile_plan<6, Reg3Cfg<6, true>>(p, plan, prm, p->h_cam_off, mb);
-  if (p->schur_v3) return (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
-  return (p->nct == 9) ? finish_reg2_tile_plan<9, Reg2Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg2Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
+  int rc = (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
+  if (rc) return rc;
+  // Six-parameter cameras with more than one workgroup per CU: the two workgroups of a CU become the two anti-phased sets of ONE 8-wave workgroup
+  // (k_schur_reg3<6, .., SETS = 2>, cba_kernels.h).  A launch that does not fill the chip keeps the 4-wave workgroups: one per CU, nothing to de-phase.
+  p->schur_pp = p->nct == 6 && (p->tile_grid % 2) == 0 && p->tile_grid > p->cus;
+  if (const char* e = std::getenv("CBA_SCHUR_PP")) p->schur_pp = p->nct == 6 && (p->tile_grid % 2) == 0 && std::atoi(e) != 0;  // (A/B measurements)
+  return CBA_OK;
 }
 
-// camera groups of the LDS-tile kernel (k_schur_tile): the widest group whose tile fits the LDS budget
-template <int NC>
-static int regroup_for_lds_tile(cba_problem* p) {
-  int gmax = 1;
-  while (gmax < p->C && gmax < 127 && lds_schur_tile<NC>(gmax + 1) <= kSchurLdsBudget) ++gmax;
+// Camera groups of the pair kernel: host-only (camera count), decided before anything touches the device so that the plan can be dealt while
+// cba_create uploads.
+static void choose_schur_groups(cba_problem* p) {
+  const int gmax = std::min(p->C, kSchurRegMaxGroup);
   p->G = (p->C + gmax - 1) / gmax;
   p->gsz = (p->C + p->G - 1) / p->G;
   p->n_tiles = p->G * (p->G + 1) / 2;
-  return allow_lds(k_schur_tile<NC>, lds_schur_tile<NC>(p->gsz));
-}
-
-// Which Schur kernel and which camera groups: host-only (environment, camera count), decided before anything touches the device so that the plan
-// of the register kernels can be dealt while cba_create uploads.  The LDS-tile kernel's groups follow from its LDS budget (regroup_for_lds_tile).
-template <int NC>
-static void choose_schur_path(cba_problem* p) {
-  const char* force_tile = std::getenv("CBA_SCHUR");
-  p->schur_reg = !(force_tile && std::strcmp(force_tile, "lds") == 0);
-  p->schur_v2 = p->schur_reg;
-  p->schur_v3 = p->schur_reg && !(force_tile && std::strcmp(force_tile, "reg2") == 0) && !p->debug_skip;  // the profiling variants are k_schur_reg2's
-  {
-    const char* wide_env = std::getenv("CBA_SCHUR_WIDE");
-    // opt-in (CBA_SCHUR_WIDE=1, more than 16 cameras): measured on cfg4 the wide kernel gathers half the bytes and takes the same time
-    // as the narrow one (the pair kernel is bound by issue, barrier and pair arithmetic in equal parts, not by the bytes)
-    p->schur_wide = NC == 6 && p->schur_v3 && wide_env && std::atoi(wide_env) == 1 && p->C > kSchurRegMaxGroup;
-  }
-  if (p->schur_reg) {
-    const int gmax = std::min(p->C, p->schur_wide ? Reg3Cfg<6, true>::GROUP : kSchurRegMaxGroup);
-    p->G = (p->C + gmax - 1) / gmax;
-    p->gsz = (p->C + p->G - 1) / p->G;
-    p->n_tiles = p->G * (p->G + 1) / 2;
-  }
 }
 
 template <int NC>
@@ -974,28 +785,16 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 1, true>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2, true>, lds_jv(p, 2)))) return rc;
-  if (!p->schur_reg && (rc = regroup_for_lds_tile<NC>(p))) return rc;  // (the register kernels' groups: choose_schur_path, before the plan thread starts)
-  if (p->schur_reg) {
-    if ((rc = allow_lds(k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 0>, Reg2Cfg<NC>::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, false>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
-    if constexpr (NC == 6) {
-      if (p->schur_wide && (rc = allow_lds(k_schur_reg3<6, 1, 2, true>, Reg3Cfg<6, true>::LDS_BYTES))) return rc;
-    }
-    if (NC == 6 && p->debug_skip) {
-      constexpr int D6 = (NC == 6);
-      for (const void* fn : {(const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 2 * D6>,
-                             (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 4 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 8 * D6>,
-                             (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 10 * D6>, (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 15 * D6>,
-                             (const void*)k_schur_reg2<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 16 * D6>})
-        if ((rc = raise_lds_ceiling(fn, Reg2Cfg<NC>::LDS_BYTES))) return rc;
-    }
-    if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
-    if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
+  if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
+  if constexpr (NC == 6) {
+    using PP = Reg3Cfg<6, 2>;
+    if ((rc = allow_lds(k_schur_reg3<6, 1, 2, 2>, PP::LDS_BYTES))) return rc;
   }
+  if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
+  if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC, true>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
-  if ((rc = allow_lds(k_chol_backward, (size_t)(p->ncp + NB) * 8))) return rc;
   if ((rc = allow_lds(k_chol_apply, (size_t)p->ncp * 8))) return rc;
   return CBA_OK;
 }
@@ -1003,7 +802,6 @@ static int configure_kernels(cba_problem* p) {
 extern "C" {
 
 int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!d || !out) return fail(CBA_ERR_INVALID, "cba_create: null argument");
   *out = nullptr;
   if (d->n_cams <= 0 || d->n_points <= 0 || d->n_obs <= 0) return fail(CBA_ERR_INVALID, "cba_create: empty problem (cams=%d points=%d obs=%lld)", d->n_cams, d->n_points, (long long)d->n_obs);
@@ -1026,9 +824,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->device = dev;
   p->C = d->n_cams; p->P = d->n_points; p->N = d->n_obs;
   p->loss = d->loss; p->f_scale = d->f_scale;
-  if (const char* dbg = std::getenv("CBA_DEBUG_SCHUR_SKIP")) p->debug_skip = std::atoi(dbg);
+#ifdef CBA_PROFILING
   p->schur_clock = std::getenv("CBA_SCHUR_CLOCK") != nullptr;
   p->want_chol_trace = std::getenv("CBA_CHOL_TRACE") != nullptr;
+#endif
   int rc = CBA_OK;
   auto bail = [&](int code) { cba_destroy(p); return code; };
   // a HIP failure after the handle owns resources goes through bail(): the handle, its arena chunks and the pooled stream are released
@@ -1054,7 +853,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   for (int c = 0; c < p->C; ++c)
     for (int r = 0; r < np[c]; ++r) { pcam[off[c] + r] = c; ploc[off[c] + r] = r; }
 
-  const bool plan_timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+  const bool plan_timing = plan_timing_on();
   auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = t_now();
   auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "cba_create: %-28s %.3f s\n", what, t - t_mark); t_mark = t; } };
@@ -1101,23 +900,20 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->h_heavy_pts = heavy;
   // the Schur plan of the register kernels is dealt on its own thread from here on (declared after the vectors it reads: joined before they go)
   p->eval_only = opt && opt->evaluation_only != 0;
-  if (nct == 9) choose_schur_path<9>(p); else choose_schur_path<6>(p);
+  choose_schur_groups(p);
   // CBA_PLAN=swap (opt-in): start with the cheap plan, swap the dealt one in when its thread is done.  Not with fixed-order sums (the iteration the
-  // swap lands on would vary from run to run) nor with the profiling builds (they want the plan they profile).
+  // swap lands on would vary from run to run) nor with the profiling build (it wants the plan it profiles).
   bool plan_two_stage = false;
-  if (const char* e = std::getenv("CBA_PLAN")) plan_two_stage = std::strcmp(e, "swap") == 0 && !(opt && opt->deterministic) && !p->schur_clock && !p->debug_skip;
-  if (p->schur_reg && !p->eval_only) {
-    Reg2Params prm;
-    if (p->schur_wide) prm = reg2_params<6, Reg3Cfg<6, true>>(p);
-    else if (p->schur_v3) prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
-    else prm = (nct == 9) ? reg2_params<9, Reg2Cfg<9>>(p) : reg2_params<6, Reg2Cfg<6>>(p);
-    if (const char* e = std::getenv("CBA_PLAN")) prm.cheap = std::strcmp(e, "cheap") == 0;  // (measurements: the cheap plan for good)
+  const char* plan_env = std::getenv("CBA_PLAN");
+  if (plan_env) plan_two_stage = std::strcmp(plan_env, "swap") == 0 && !(opt && opt->deterministic) && !p->schur_clock;
+  if (!p->eval_only) {
+    Reg2Params prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
+    if (plan_env) prm.cheap = std::strcmp(plan_env, "cheap") == 0;  // (measurements: the cheap plan for good)
     p->plan_task = new PlanTask();  // owned by the handle: cba_destroy (also through bail) cancels and joins it while the arrays it reads are alive
     p->plan_task->start(prm, hcam.data(), hps.data(), plan_two_stage);
   }
 
   {
-    CaptureSafe not_while_recording(g_capture_mu);
     // one mapped host allocation for the three mailboxes: scalars (64 doubles), camera blocks (3 ncp + 8 doubles), flags (4 ints)
     const size_t n_mail = 64 + ((size_t)3 * ncp + 8) + 2;
     {
@@ -1141,18 +937,12 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     p->h_flags = reinterpret_cast<int*>(p->h_cam + ((size_t)3 * ncp + 8)); p->d_hflags = reinterpret_cast<int*>(p->d_hcam + ((size_t)3 * ncp + 8));
   }
   std::memset(p->h_scal, 0, (64 + ((size_t)3 * ncp + 8) + 2) * sizeof(double));
-  if (const char* sp = std::getenv("CBA_SPIN")) p->spin_wait = sp[0] != '0';
 
   const int cus = n_cus > 0 ? n_cus : 256;
-  int grid_mult = 2;  // persistent workgroups per CU of the per-observation kernels
-  if (const char* e = std::getenv("CBA_GRID_MULT")) grid_mult = std::max(1, std::atoi(e));
-  int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : grid_mult * cus;
+  p->cus = cus;
+  const int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;  // two persistent workgroups per CU for the per-observation kernels
   p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
-  {
-    int mult = 2;
-    if (const char* e = std::getenv("CBA_BACKSUB_WGS")) mult = std::max(1, std::atoi(e));
-    p->grid_backsub = std::max(1, std::min(p->n_chunks, mult * cus));
-  }
+  p->grid_backsub = std::max(1, std::min(p->n_chunks, 2 * cus));
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
   lap("reorder on host");
@@ -1267,39 +1057,24 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("allocate vectors");
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   lap("reorder, upload, allocate");
-  for (int attempt = 0; attempt < 2 && !p->eval_only; ++attempt) {
-    const size_t tile_lds = p->schur_reg ? (p->schur_wide ? Reg3Cfg<6, true>::LDS_BYTES
-                                            : p->schur_v3 ? ((nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES) : ((nct == 9) ? Reg2Cfg<9>::LDS_BYTES : Reg2Cfg<6>::LDS_BYTES))
-                                         : ((nct == 9) ? lds_schur_tile<9>(p->gsz) : lds_schur_tile<6>(p->gsz));
-    int per_cu = std::max<int>(1, (int)((160 * 1024) / tile_lds));
-    if (p->schur_reg) per_cu = std::min(per_cu, (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // register budget
+  if (!p->eval_only) {
+    const size_t tile_lds = (nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES;
+    const int per_cu = std::min(std::max<int>(1, (int)((160 * 1024) / tile_lds)), (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // LDS, register budget
     const int resident = cus * per_cu;  // no partial last round
-    if (p->schur_reg && p->schur_v2) {
-      const int mb = std::min(resident, std::max(max_blocks, cus));
-      PlanTask& task = *p->plan_task;
-      const double t_wait = t_now();
-      task.wait_stage(task.two_stage ? 1 : 2);
-      if (plan_timing)
-        fprintf(stderr, "  plan: %s took %.3f s on its own threads, started before the uploads; waited %.3f s for it\n", task.two_stage ? "the cheap plan" : "dealt streams and codes",
-                task.two_stage ? task.seconds_cheap : task.seconds, t_now() - t_wait);
-      p->plan_max_blocks = mb;
-      rc = (task.two_stage ? task.rc_cheap : task.rc) ? CBA_ERR_UNSUPPORTED  // a point larger than a chunk: LDS-tile fallback
-                                                     : install_reg2_plan(p, task.two_stage ? task.cheap : task.plan, task.prm);
-      p->plan_is_cheap = task.two_stage || task.prm.cheap;
-    }
-    else
-      rc = build_tile_plan(p, std::vector<double>(hu.begin(), hu.end()), std::vector<double>(hv.begin(), hv.end()), std::vector<int>(hcam.begin(), hcam.end()),
-                           std::vector<int>(hpt.begin(), hpt.end()), hps, off, std::min(resident, std::max(max_blocks, cus)));  // (the fallback kernel's plan: rare)
-    if (rc == CBA_ERR_UNSUPPORTED && p->schur_reg) {  // a point too large for the pair plan: the LDS-tile kernel, with the groups that fit its tile
-      p->schur_reg = false; p->schur_v2 = false; p->schur_v3 = false; p->schur_wide = false;
-      if ((rc = (nct == 9) ? regroup_for_lds_tile<9>(p) : regroup_for_lds_tile<6>(p))) return bail(rc);
-      continue;
-    }
+    PlanTask& task = *p->plan_task;
+    const double t_wait = t_now();
+    task.wait_stage(task.two_stage ? 1 : 2);
+    if (plan_timing)
+      fprintf(stderr, "  plan: %s took %.3f s on its own threads, started before the uploads; waited %.3f s for it\n", task.two_stage ? "the cheap plan" : "dealt streams and codes",
+              task.two_stage ? task.seconds_cheap : task.seconds, t_now() - t_wait);
+    p->plan_max_blocks = std::min(resident, std::max(max_blocks, cus));
+    if (task.two_stage ? task.rc_cheap : task.rc)
+      return bail(fail(CBA_ERR_UNSUPPORTED, "a world point has more observations inside one camera-group tile than a chunk of the pair plan holds (%d records)",
+                       (nct == 9) ? Reg3Cfg<9>::SCHUNK : Reg3Cfg<6>::SCHUNK));
+    rc = install_reg2_plan(p, task.two_stage ? task.cheap : task.plan, task.prm);
+    p->plan_is_cheap = task.two_stage || task.prm.cheap;
     if (rc) return bail(rc);
-    break;
   }
-  if (p->n_heavy && !p->schur_reg)
-    return bail(fail(CBA_ERR_UNSUPPORTED, "%d world points have more than %d observations: they need the T-record Schur path (CBA_SCHUR=lds is set)", p->n_heavy, HEAVY_OBS));
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
@@ -1308,7 +1083,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->tri, (size_t)ncp * (ncp + 1) / 2 + p->lay.ncp_pad));
-  if (p->schur_reg && !p->eval_only) {
+  if (!p->eval_only) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
     TRY(dev_alloc(p, &p->Trec, (size_t)std::max<long>(p->N, 1) * ((nct == 9) ? SchurRec<9>::HREC : SchurRec<6>::HREC)));
     TRY(dev_alloc(p, &p->partial_b, (size_t)p->grid * p->lay.ncp_pad));
@@ -1317,13 +1092,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (p->want_chol_trace) TRY(dev_alloc(p, &p->chol_trace, (size_t)((ncp + NB - 1) / NB + 2) * 8));
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->Xinv, (size_t)((ncp + NB - 1) / NB + 1) * NB * NB));
-  {
-    const char* e = std::getenv("CBA_CHOL_BACKWARD");
-    if (!(e && std::strcmp(e, "subst") == 0)) {  // default: x = T y with the explicit inverse transpose; "subst": the backward substitution of round 2
-      TRY(dev_alloc(p, &p->Tinv, (size_t)ncp * p->ldw));
-      HIPBAIL(hipMemset(p->Tinv, 0, (size_t)ncp * p->ldw * sizeof(double)));
-    }
-  }
+  TRY(dev_alloc(p, &p->Tinv, (size_t)ncp * p->ldw));
+  HIPBAIL(hipMemset(p->Tinv, 0, (size_t)ncp * p->ldw * sizeof(double)));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
@@ -1335,15 +1105,10 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 #undef TRY
   p->h_vec.resize((size_t)tot);
   lap("solver buffers");
-  if (cholesky_as_graph() && !p->eval_only && !p->want_chol_trace) {
-    rc = ensure_cholesky_graph(p);
-    if (rc) return bail(rc);
-  }
-  lap("Cholesky graph");
   HIPBAIL(hipDeviceSynchronize());
   lap("device synchronize");
   if (p->plan_task) {
-    if (p->plan_task->two_stage && p->schur_reg) {  // the thread goes on dealing: it reads these two arrays
+    if (p->plan_task->two_stage) {  // the thread goes on dealing: it reads these two arrays
       p->plan_task->hcam_keep = std::move(hcam);
       p->plan_task->hps_keep = std::move(hps);
     } else {
@@ -1356,26 +1121,22 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 }
 
 int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_set_loss: null problem");
   if (loss < CBA_LOSS_LINEAR || loss > CBA_LOSS_ARCTAN) return fail(CBA_ERR_INVALID, "cba_set_loss: unknown loss %d", loss);
   if (loss != CBA_LOSS_LINEAR && !(f_scale > 0.0)) return fail(CBA_ERR_INVALID, "cba_set_loss: f_scale must be positive");
   p->loss = loss; p->f_scale = f_scale;
   p->have_build = false;  // blocks and gradient of the current point belong to the old loss
   p->spec_valid = false; p->spec_enqueued = false;
-  // the recorded step graphs carry loss and f_scale as kernel arguments: record again
-  for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-  p->step_graphs.clear();
   return CBA_OK;
 }
 
 int cba_get_info(cba_problem* p, cba_info* o) {
   if (!p || !o) return fail(CBA_ERR_INVALID, "null argument");
   o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
-  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = p->schur_reg ? 0 : 1;
+  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 0;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
-  o->schur_wide = (p->schur_reg && p->schur_wide) ? 1 : 0;
+  o->schur_wide = p->schur_pp ? 2 : 0;  // 2: the two-set (ping-pong) form of the pair kernel
   {
     const bool cs = p->cs.n_sc && !p->det_m && !p->n_heavy;
     const bool camg = cs ? (p->nct == 6 ? build_cs_camg<6>(p) : build_cs_camg<9>(p)) : (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p));
@@ -1386,7 +1147,6 @@ int cba_get_info(cba_problem* p, cba_info* o) {
 
 int cba_enable_timers(cba_problem* p, int32_t on) { if (!p) return fail(CBA_ERR_INVALID, "null"); p->timers_on = on != 0; return CBA_OK; }
 int cba_reset_timers(cba_problem* p) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "null");
   (void)hipSetDevice(p->device);
   drain_timers(p);
@@ -1394,7 +1154,6 @@ int cba_reset_timers(cba_problem* p) {
   return CBA_OK;
 }
 int cba_get_timers(cba_problem* p, double* ms, int64_t* calls) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "null");
   (void)hipSetDevice(p->device);
   drain_timers(p);
@@ -1559,7 +1318,7 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
     p->spec_valid = false;
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vec_grid(p->lay.total()), p->partial4, p->spec_rows_jv, radius,
-                       p->scal, p->fz, p->capturing ? (const double*)(p->d_hscal + 60) : (const double*)nullptr);
+                       p->scal, p->fz);
     return CBA_OK;
   }
   p->spec_valid = false;
@@ -1580,7 +1339,7 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
       int rcj = run_jv<NC>(p, 1, &rows_jv);
       if (rcj) return rcj;
       hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vg, p->partial4, rows_jv, radius,
-                         p->scal, p->fz, (const double*)nullptr);
+                         p->scal, p->fz);
       return CBA_OK;
     }
     hipLaunchKernelGGL((k_scale_update<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc,
@@ -1621,15 +1380,9 @@ static int run_linearize(cba_problem* p, cba_linearization* out) {
   return CBA_OK;
 }
 
-// The dense solve is ncp / 32 + 2 small dependent launches.  Rounds 1-2 replayed them from a hipGraph recorded at create time: every primitive
-// then began on a drained stream and the GPU waited on the host between the launches.  Since the fused iteration keeps the host a whole
-// iteration ahead of the device, plain launches are the faster form — round 3, MI355X / ROCm 7.2, per iteration: cfg2 139 against 149 us,
-// cfg3 177 against 188, cfg4 645 against 654, cfg5 the same (the kernel behind a graph launch starts ~10 us late) — and a handle no longer
-// pays for the recording.  CBA_CHOL_GRAPH=1 brings the graph back.
-static bool cholesky_as_graph() {
-  static const bool on = [] { const char* e = std::getenv("CBA_CHOL_GRAPH"); return e && e[0] == '1'; }();
-  return on;
-}
+// The dense solve is ncp / 32 + 2 small dependent launches.  Rounds 1-2 replayed them from a hipGraph recorded at create time; since the fused
+// iteration keeps the host a whole iteration ahead of the device, plain launches are the faster form (round 3, per iteration: cfg2 139 against
+// 149 us, cfg4 645 against 654 — the kernel behind a graph launch starts ~10 us late), and the graph is gone (round 4).
 static int enqueue_cholesky(cba_problem* p) {
   const int n = p->ncp, nbk = (n + NB - 1) / NB;
   for (int k = -1; k < nbk; ++k) {
@@ -1637,34 +1390,16 @@ static int enqueue_cholesky(cba_problem* p) {
     // rank-NB update of panel k - 1 to the blocks right of the current panel
     const int n_panel = k < 0 ? 1 : nbk - k;
     const int x = nbk - k - 1, n_trailing = k < 1 ? 0 : x * (x + 1) / 2;
-    const int n_inverse = (p->Tinv && k >= 1) ? (nbk - k) * k : 0;  // blocks (i >= k, j < k) of T = L^-T take the term of panel k - 1
+    const int n_inverse = (k >= 1) ? (nbk - k) * k : 0;  // blocks (i >= k, j < k) of T = L^-T take the term of panel k - 1
     hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_trailing + n_inverse), dim3(CHOL_THREADS), 0, p->stream, p->Lbuf, n, p->ldw, k, p->flags, p->chol_trace, p->Xinv, p->Tinv);
   }
-  if (p->Tinv)
-    hipLaunchKernelGGL(k_chol_apply, dim3(nbk), dim3(APPLY_THREADS), (size_t)n * 8, p->stream, (const double*)p->Tinv, (const double*)p->Lbuf, n, p->ldw, p->s);
-  else
-    hipLaunchKernelGGL(k_chol_backward, dim3(1), dim3(BACK_THREADS), (size_t)(n + NB) * 8, p->stream, p->Lbuf, n, p->ldw, p->Xinv, p->s,
-                       p->chol_trace ? p->chol_trace + (size_t)((n + NB - 1) / NB + 1) * 8 : (long long*)nullptr);
-  return CBA_OK;
-}
-
-// Recording takes the capture lock exclusively, i.e. waits until no other thread is inside an entry point.  cba_create
-// records the graph up front: inside a sharded solve a rank waiting for that lock while its peers wait for it in a
-// collective (holding the lock shared) would never get it.
-static int ensure_cholesky_graph(cba_problem* p) {
-  if (p->chol_exec) return CBA_OK;
-  CaptureRecording recording;
-  HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_cholesky(p);
-  hipError_t e = hipStreamEndCapture(p->stream, &p->chol_graph);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(CBA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-  HIPCHK(hipGraphInstantiate(&p->chol_exec, p->chol_graph, nullptr, nullptr, 0));
+  hipLaunchKernelGGL(k_chol_apply, dim3(nbk), dim3(APPLY_THREADS), (size_t)n * 8, p->stream, (const double*)p->Tinv, (const double*)p->Lbuf, n, p->ldw, p->s);
   return CBA_OK;
 }
 
 static int run_cholesky(cba_problem* p) {
-  if (p->chol_trace) {  // traced run: plain launches, then dump the stamps of the critical workgroups
+#ifdef CBA_PROFILING
+  if (p->chol_trace) {  // traced run: dump the stamps of the critical workgroups
     const int nbk = (p->ncp + NB - 1) / NB;
     HIPCHK(hipMemsetAsync(p->chol_trace, 0, (size_t)(nbk + 2) * 8 * sizeof(long long), p->stream));
     int rc = enqueue_cholesky(p);
@@ -1672,12 +1407,6 @@ static int run_cholesky(cba_problem* p) {
     std::vector<long long> h((size_t)(nbk + 2) * 8);
     HIPCHK(hipMemcpyAsync(h.data(), p->chol_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
-    if (p->Tinv) fprintf(stderr, "chol apply: x = T y in one launch (k_chol_apply; CBA_CHOL_BACKWARD=subst traces the substitution)\n");
-    else {  // k_chol_backward: start, prologue done, first block, second block, all blocks, last loads landed, solution stored
-      const long long* b = &h[(size_t)(nbk + 1) * 8];
-      fprintf(stderr, "chol backward: prologue %.2f us, first block %.2f, second block %.2f, remaining %d blocks %.2f, tail wait %.2f, store %.2f | total %.2f us\n",
-              (b[1] - b[0]) * 0.01, (b[2] - b[1]) * 0.01, (b[3] - b[2]) * 0.01, std::max(nbk - 2, 0), (b[4] - b[3]) * 0.01, (b[5] - b[4]) * 0.01, (b[6] - b[5]) * 0.01, (b[6] - b[0]) * 0.01);
-    }
     for (int s = 0; s <= nbk; ++s) {
       fprintf(stderr, "chol step %2d:", s - 1);
       for (int ph = 1; ph < 7; ++ph)
@@ -1687,16 +1416,9 @@ static int run_cholesky(cba_problem* p) {
     }
     return CBA_OK;
   }
-  if (p->capturing) return enqueue_cholesky(p);  // inside the recording of a step graph: its launches become nodes of that graph
-  if (!cholesky_as_graph()) {
-    ScopedTimer t(p, T_CHOLESKY);
-    return enqueue_cholesky(p);
-  }
-  int rcg = ensure_cholesky_graph(p);
-  if (rcg) return rcg;
+#endif
   ScopedTimer t(p, T_CHOLESKY);
-  HIPCHK(hipGraphLaunch(p->chol_exec, p->stream));
-  return CBA_OK;
+  return enqueue_cholesky(p);
 }
 
 // scalars of the damped step s: ||p||^2 and <g_h, p> (scal[16], [17]) and ||w||^2, w = p - (<g_h,p> / ||g_h||^2) g_h (scal[20]).
@@ -1707,8 +1429,7 @@ static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
   const long first = (p->rank == 0) ? 0 : p->lay.ncp_pad;  // replicated camera entries are counted on rank 0 only
-  static const bool small_env = [] { const char* e = std::getenv("CBA_STEP_SMALL"); return !(e && e[0] == '0'); }();
-  if (compact && small_env && first == 0 && tot <= STEP_SMALL_MAX) {  // small problems: sums and subspace step by one workgroup, one launch
+  if (compact && first == 0 && tot <= STEP_SMALL_MAX) {  // small problems: sums and subspace step by one workgroup, one launch
     hipLaunchKernelGGL(k_step_small, dim3(1), dim3(STEP_SMALL_THREADS), 0, p->stream, p->g, p->sinv, p->s, tot, p->scal, (const int*)p->flags, p->fz);
     return CBA_OK;
   }
@@ -1731,10 +1452,10 @@ static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false
 // with it (the cheap plan's buffers stay in the arena until the handle goes).  Called between iterations by the thread that drives the handle.
 static int maybe_swap_plan(cba_problem* p) {
   PlanTask* task = p->plan_task;
-  if (!task || p->capturing || task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
+  if (!task || task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
   int rc = CBA_OK;
   if (task->rc == 0) {
-    const bool timing = std::getenv("CBA_PLAN_TIMING") != nullptr;
+    const bool timing = plan_timing_on();
     const auto t0 = std::chrono::steady_clock::now();
     rc = install_reg2_plan(p, task->plan, task->prm);
     if (!rc) {
@@ -1744,11 +1465,7 @@ static int maybe_swap_plan(cba_problem* p) {
         if (!rc) p->partial_capacity = need;
       }
     }
-    if (!rc) {
-      p->plan_is_cheap = false;
-      for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }  // recorded with the cheap plan's pointers
-      p->step_graphs.clear();
-    }
+    if (!rc) p->plan_is_cheap = false;
     if (timing)
       fprintf(stderr, "  plan: the dealt plan (%.3f s on its own threads) swapped in, %.3f s to bind and upload it\n", task->seconds,
               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1756,6 +1473,59 @@ static int maybe_swap_plan(cba_problem* p) {
   drop_plan_task(p);
   return rc;
 }
+
+#ifdef CBA_PROFILING
+// profiling build of the pair kernel (six-parameter cameras): phase clocks per wave, printed per launch
+template <int NC>
+static int run_pairs_clocked(cba_problem* p) {
+  if constexpr (NC != 6) return fail(CBA_ERR_UNSUPPORTED, "CBA_SCHUR_CLOCK: six-parameter cameras only");
+  else {
+    const int nw = Reg3Cfg<6>::NWAVES;
+    const size_t n = (size_t)p->tile_grid * nw * 8;
+    long long* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
+    (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
+    if (p->schur_pp) {
+      using PP = Reg3Cfg<6, 2>;
+      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 2>, PP::LDS_BYTES)) return CBA_ERR_HIP;
+      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+    } else {
+      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 1>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
+      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+    }
+    std::vector<long long> h(n);
+    (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(d);
+    static const char* names[4] = {"wait for loads", "barriers", "issue", "pairs"};
+    double sum[8] = {0};
+    double tmax = 0.0;
+    size_t waves = 0;
+    for (size_t w = 0; w < n / 8; ++w) {
+      if (!h[w * 8 + 4]) continue;
+      ++waves;
+      for (int k = 0; k < 7; ++k) sum[k] += (double)h[w * 8 + k];
+      tmax = std::max(tmax, (double)h[w * 8 + 6]);
+    }
+    const double wv = (double)std::max<size_t>(waves, 1);
+    fprintf(stderr, "k_schur_reg3%s phases, mean clocks per wave (%zu waves, %.1f trips, %.1f pair iterations each):", p->schur_pp ? " (two sets)" : "", waves, sum[4] / wv, sum[5] / wv);
+    for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
+    fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
+    for (int t = 0; t + 1 < (int)p->h_tile_wg_begin.size(); ++t) {  // the kernel lasts as long as its slowest workgroup
+      double mean = 0.0, mx = 0.0, trips = 0.0, its = 0.0;
+      const int b0 = p->h_tile_wg_begin[t], b1 = p->h_tile_wg_begin[t + 1];
+      for (int b = b0; b < b1; ++b) {
+        double life = 0.0;
+        for (int w = 0; w < nw; ++w) life = std::max(life, (double)h[((size_t)b * nw + w) * 8 + 6]);
+        mean += life; mx = std::max(mx, life); trips += (double)h[(size_t)b * nw * 8 + 4]; its += (double)h[(size_t)b * nw * 8 + 5];
+      }
+      const double nb = std::max(1, b1 - b0);
+      fprintf(stderr, "    tile %2d: %3d workgroups, %.1f trips and %.1f pair iterations (wave 0) each, lifetime mean %.0f max %.0f clocks\n", t, b1 - b0, trips / nb, its / nb, mean / nb, mx);
+    }
+    return CBA_OK;
+  }
+}
+#endif
 
 // device part of the damped step; lam_dev != nullptr: the damping is read from device memory (fused step)
 template <int NC>
@@ -1769,7 +1539,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
   {
     RoctxRange r2("cba:schur");
     ScopedTimer t(p, T_SCHUR);
-    if (p->schur_reg) {
+    {
       auto launch_tprep = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds_tprep<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                            p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, lam_dev, p->V, p->g,
@@ -1784,122 +1554,36 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
                          p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
-      if (p->schur_v3 && NC == 6 && p->schur_clock) {  // profiling build of the pair kernel: phase clocks per wave, printed per launch (tools/schur_split.py)
+      constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
+#ifdef CBA_PROFILING
+      if (p->schur_clock) {  // phase clocks per wave, printed per launch (tools/build_profiling_lib.sh)
+        int rcc = run_pairs_clocked<NC>(p);
+        if (rcc) return rcc;
+      } else
+#endif
+      if (p->schur_pp) {
         if constexpr (NC == 6) {
-          const int nw = p->schur_wide ? Reg3Cfg<6, true>::NWAVES : Reg3Cfg<6>::NWAVES;
-          const size_t n = (size_t)p->tile_grid * nw * 8;
-          long long* d = nullptr;
-          if (guarded_malloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
-          (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
-          auto launch_clk = [&](auto kernel, int threads, size_t lds) {
-            if (raise_lds_ceiling((const void*)kernel, lds)) return CBA_ERR_HIP;
-            hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(threads), lds, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
-            return CBA_OK;
-          };
-          using Wide = Reg3Cfg<6, true>;
-          using Narrow = Reg3Cfg<6>;
-          int rcl;
-          if (p->schur_wide) rcl = launch_clk(k_schur_reg3_clk<6, 1, 2, true>, Wide::REG_BLOCK, Wide::LDS_BYTES);
-          else rcl = launch_clk(k_schur_reg3_clk<6, 1, 2, false>, Narrow::REG_BLOCK, Narrow::LDS_BYTES);
-          if (rcl) return rcl;
-          std::vector<long long> h(n);
-          (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
-          (void)hipStreamSynchronize(p->stream);
-          (void)guarded_free(d);
-          static const char* names[4] = {"wait for loads", "barrier", "issue", "pairs"};
-          double sum[8] = {0};
-          double tmax = 0.0;
-          size_t waves = 0;
-          for (size_t w = 0; w < n / 8; ++w) {
-            if (!h[w * 8 + 4]) continue;
-            ++waves;
-            for (int k = 0; k < 7; ++k) sum[k] += (double)h[w * 8 + k];
-            tmax = std::max(tmax, (double)h[w * 8 + 6]);
-          }
-          const double wv = (double)std::max<size_t>(waves, 1);
-          fprintf(stderr, "k_schur_reg3%s phases, mean clocks per wave (%zu waves, %.1f trips, %.1f pair iterations each):", p->schur_wide ? " (wide)" : "", waves, sum[4] / wv, sum[5] / wv);
-          for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
-          fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
-          if (const char* e = std::getenv("CBA_SCHUR_CLOCK"); e && std::atoi(e) == 2)  // per workgroup: lifetime of wave 0, its HW_ID register, its end stamp
-            for (int b = 0; b < p->tile_grid; ++b)
-              fprintf(stderr, "wg %d life %lld hwid %llx end100MHz %lld trips %lld\n", b, h[(size_t)b * nw * 8 + 6], (unsigned long long)h[(size_t)b * nw * 8 + 7] >> 40,
-                      h[(size_t)b * nw * 8 + 7] & 0xffffffffffLL, h[(size_t)b * nw * 8 + 4]);
-          for (int t = 0; t + 1 < (int)p->h_tile_wg_begin.size(); ++t) {  // the kernel lasts as long as its slowest workgroup
-            double mean = 0.0, mx = 0.0, trips = 0.0, its = 0.0;
-            const int b0 = p->h_tile_wg_begin[t], b1 = p->h_tile_wg_begin[t + 1];
-            for (int b = b0; b < b1; ++b) {
-              double life = 0.0;
-              for (int w = 0; w < nw; ++w) life = std::max(life, (double)h[((size_t)b * nw + w) * 8 + 6]);
-              mean += life; mx = std::max(mx, life); trips += (double)h[(size_t)b * nw * 8 + 4]; its += (double)h[(size_t)b * nw * 8 + 5];
-            }
-            const double nb = std::max(1, b1 - b0);
-            fprintf(stderr, "    tile %2d: %3d workgroups, %.1f trips and %.1f pair iterations (wave 0) each, lifetime mean %.0f max %.0f clocks\n", t, b1 - b0, trips / nb, its / nb, mean / nb, mx);
-          }
+          using PP = Reg3Cfg<6, 2>;
+          hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
         }
-      } else if (p->schur_wide) {
-        if constexpr (NC == 6) {
-          using Wide = Reg3Cfg<6, true>;
-          hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, true>), dim3(p->tile_grid), dim3(Wide::REG_BLOCK), Wide::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
-        }
-      } else if (p->schur_v3) {
-        constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
-        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, false>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
       } else {
-        auto launch = [&](auto kernel) {
-          hipLaunchKernelGGL(kernel, dim3(p->tile_grid), dim3(BLOCK * RegCfg<NC>::SPLIT), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (long long*)nullptr);
-        };
-        constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
-        switch (NC == 6 ? p->debug_skip : 0) {  // profiling variants (CBA_DEBUG_SCHUR_SKIP, tools/schur_split.py)
-          case 1: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 1 : 0)>); break;
-          case 2: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 2 : 0)>); break;
-          case 4: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 4 : 0)>); break;
-          case 8: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 8 : 0)>); break;
-          case 10: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 10 : 0)>); break;
-          case 15: launch(k_schur_reg2<NC, SP, MW, (NC == 6 ? 15 : 0)>); break;
-          case 16: {  // phase clock of every wave (profiling): printed per launch
-            long long* d = nullptr;
-            const size_t n = (size_t)p->tile_grid * 4 * 8;
-            if (guarded_malloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
-            (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
-            hipLaunchKernelGGL((k_schur_reg2<NC, SP, MW, (NC == 6 ? 16 : 0)>), dim3(p->tile_grid), dim3(BLOCK * SP), Reg2Cfg<NC>::LDS_BYTES, p->stream, p->tp,
-                               p->Trec, p->partial, d);
-            std::vector<long long> h(n);
-            (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
-            (void)hipStreamSynchronize(p->stream);
-            (void)guarded_free(d);
-            static const char* names[8] = {"wait records", "LDS stores", "barrier A", "gather 1 issue", "pair 0", "gather 2 + idx issue", "pairs 1..", "barrier B"};
-            double tot = 0.0, sum[8] = {0};
-            for (size_t w = 0; w < n / 8; ++w)
-              for (int ph = 0; ph < 8; ++ph) { sum[ph] += (double)h[w * 8 + ph]; tot += (double)h[w * 8 + ph]; }
-            fprintf(stderr, "k_schur_reg2 phases, mean shader clocks per wave (%zu waves):", n / 8);
-            for (int ph = 0; ph < 8; ++ph) fprintf(stderr, "  %s %.0f (%.1f%%)", names[ph], sum[ph] / (n / 8), 100.0 * sum[ph] / std::max(tot, 1.0));
-            fprintf(stderr, "  | total %.0f\n", tot / (n / 8));
-          } break;
-          default: launch(k_schur_reg2<NC, SP, MW, 0>); break;
-        }
+        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
       }
-
     }
-    if (!p->schur_reg)
-      hipLaunchKernelGGL((k_schur_tile<NC>), dim3(p->tile_grid), dim3(SCHUR_BLOCK), lds_schur_tile<NC>(p->gsz), p->stream, p->tp, p->x, p->lay,
-                         p->tab, p->cam_off, p->loss, p->f_scale, lam, p->V, p->g, p->sinv, p->partial, p->flags, p->debug_skip);
   }
   // single rank, nothing else adds to the diagonal camera blocks (heavy points, constraint rows) and the pair kernel has unprimed its sums: k_schur_finalize
-  // folds the helper-thread sums of the diagonal blocks itself, k_reg_fold is not launched (CBA_FOLD=kernel: the separate launch)
-  static const bool fold_env = [] { const char* e = std::getenv("CBA_FOLD"); return !(e && std::strcmp(e, "kernel") == 0); }();
-  const bool fold_in_finalize = fold_env && p->schur_reg && p->schur_v3 && !p->n_heavy && !p->con.n_con && !p->sharded();
+  // folds the helper-thread sums of the diagonal blocks itself, k_reg_fold is not launched
+  const bool fold_in_finalize = !p->n_heavy && !p->con.n_con && !p->sharded();
   {
     ScopedTimer t(p, T_SCHUR_REDUCE);
     // (fold + unprime + finalize as ONE kernel, a thread per camera pair, measured slower than the three launches: 42 instead of 31 us — 2080 threads
     // with 36 entries each against 147k threads with one)
-    if (p->schur_reg) {
+    {
       hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, p->reg_reduce_y), 0, p->stream, p->tp,
                          p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
       if (!fold_in_finalize)
         hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                            p->cam_off, p->cam_np, NC, ncp, p->Sacc);
-      if (!p->schur_v3)  // k_schur_reg3 unprimes its partial blocks itself (epilogue of schur_reg3_body)
-        hipLaunchKernelGGL((k_unprime<NC>), dim3((p->C * p->C + 255) / 256), dim3(256), 0, p->stream, p->Sacc, p->tab, p->cam_off, p->cam_np, p->C, ncp);
       if (p->n_heavy)  // per-camera sums of the heavy points, one workgroup each (the pair plan skips them)
         hipLaunchKernelGGL((k_heavy_schur<NC>), dim3(p->n_heavy), dim3(BLOCK), (size_t)ncp * 3 * sizeof(double) + (size_t)ncp * sizeof(int), p->stream,
                            p->heavy_pts, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Trec, p->tab, p->heavy_W, p->Sacc);
@@ -1907,9 +1591,6 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
         hipLaunchKernelGGL((k_con_schur<NC>), dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->g, p->sinv,
                            p->Trec, p->tab, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
     }
-    else
-      hipLaunchKernelGGL(k_tile_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, 4), 0, p->stream, p->tp,
-                         p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp);
     if (p->sharded()) {  // reduced camera system: the one real exchange step — upper triangle and b, packed
       const size_t ntri = (size_t)ncp * (ncp + 1) / 2 + ncp;
       const int tg = (int)std::min<size_t>(((size_t)ncp * ncp + ncp + 255) / 256, 1024);
@@ -1999,8 +1680,7 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
   // speculative linearisation of the trial point, enqueued BEHIND the publish: the device works on it while the host reads the packet,
   // decides and enqueues the next iteration (k_publish -> host -> first kernel of the next cba_step used to be an idle gap per iteration)
   p->spec_enqueued = false;
-  static const bool spec_on = [] { const char* e = std::getenv("CBA_SPECULATE"); return !(e && e[0] == '0'); }();
-  if (spec_on) {
+  {
     {
       ScopedTimer t(p, T_SCALE_SCALARS);
       hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
@@ -2022,48 +1702,9 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
   // k_step_finish, gradient written by k_reduce_rows, last sums taken by k_publish): 8 launches fewer per iteration
   const bool compact = !p->sharded();
   int rc;
-  // Opt-in (CBA_STEP_GRAPH=1).  Measured on MI355X / ROCm 7.2: replaying the ~30 launches of an iteration from a graph is no faster than enqueueing
-  // them (cfg4 0.693 against 0.690 ms per iteration, cfg2 0.150 against 0.157, cfg3 0.185 against 0.192), and recording the two graphs costs a
-  // one-shot 5-evaluation solve 0.7 ms (the reference's 4-camera session: optimize() 2.0 instead of 1.3 ms).
-  static const bool graph_on = [] { const char* e = std::getenv("CBA_STEP_GRAPH"); return e && e[0] == '1'; }();
-  // steady state (the accepted trial brought its build AND its speculative linearisation): the iteration is a fixed sequence of launches on fixed
-  // buffers — replayed from a graph recorded once per pointer parity
-  if (compact && graph_on && p->have_build && p->spec_valid && !p->timers_on && !p->chol_trace && !p->schur_clock && !p->debug_skip && radius > 0.0) {
-    cba_problem::StepGraph* sg = nullptr;
-    for (auto& g : p->step_graphs)
-      if (g.x == p->x && g.V == p->V && g.sinv == p->sinv) sg = &g;
-    const unsigned long long seq = ++p->publish_seq;
-    p->h_scal[60] = radius;
-    reinterpret_cast<volatile unsigned long long*>(p->h_scal)[61] = seq;
-    std::atomic_thread_fence(std::memory_order_release);
-    if (!sg) {
-      if (p->step_graphs.size() >= 8) {  // pointer combinations beyond the two of the steady state: start over rather than grow
-        for (auto& g : p->step_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-        p->step_graphs.clear();
-      }
-      cba_problem::StepGraph ng{p->x, p->V, p->sinv, nullptr, nullptr};
-      {
-        CaptureRecording recording;
-        HIPCHK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-        p->capturing = true;
-        unsigned long long unused = 0;
-        rc = step_enqueue<NC>(p, radius, true, &unused);
-        p->capturing = false;
-        const hipError_t e = hipStreamEndCapture(p->stream, &ng.graph);
-        if (rc) { if (ng.graph) (void)hipGraphDestroy(ng.graph); return rc; }
-        if (e != hipSuccess) return fail(CBA_ERR_HIP, "hipStreamEndCapture (step graph): %s", hipGetErrorString(e));
-        HIPCHK(hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
-      }
-      p->step_graphs.push_back(ng);
-      sg = &p->step_graphs.back();
-    } else {  // what recording the launches did to the host-side state
-      p->spec_valid = false;
-      p->spec_enqueued = true;
-    }
-    HIPCHK(hipGraphLaunch(sg->exec, p->stream));
-    ++p->step_graph_launches;
-    rc = publish_wait(p, seq, false);
-  } else if (compact) {
+  // (replaying the ~30 launches of a steady-state iteration from a hipGraph was measured no faster than enqueueing them — round 3: cfg4 0.693
+  // against 0.690 ms, cfg2 0.150 against 0.157 — and cost 0.7 ms to record: removed in round 4)
+  if (compact) {
     unsigned long long seq = 0;
     rc = step_enqueue<NC>(p, radius, true, &seq);
     if (rc) return rc;
@@ -2103,13 +1744,11 @@ static int begin_common(cba_problem* p, double* cost_out, bool evaluate = true);
 
 int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, const int32_t* groups_b, const double* distances,
                         const double* weights) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_set_constraints: null problem");
   if (p->begun) return fail(CBA_ERR_INVALID, "cba_set_constraints: call it before cba_begin");
   if (p->con.n_con) return fail(CBA_ERR_INVALID, "cba_set_constraints: constraints are already set");
   if (n_con <= 0) return CBA_OK;
   if (!groups_a || !groups_b || !distances || !weights) return fail(CBA_ERR_INVALID, "cba_set_constraints: null array");
-  if (!p->schur_reg && !p->eval_only) return fail(CBA_ERR_UNSUPPORTED, "cba_set_constraints: constraint rows need the T-record Schur path (CBA_SCHUR=lds is set, or a point exceeds the pair capacity)");
   HIPCHK(hipSetDevice(p->device));
   const int P = p->P;
   for (long e = 0; e < (long)n_con * 4; ++e)
@@ -2194,7 +1833,6 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
 }
 
 int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x0 || !cost_out) return fail(CBA_ERR_INVALID, "cba_begin: null argument");
   HIPCHK(hipSetDevice(p->device));
   pack_host(p, x0, p->h_vec.data(), 0.0);
@@ -2204,7 +1842,6 @@ int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
 }
 
 int cba_restart(cba_problem* p, double* cost_out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !cost_out) return fail(CBA_ERR_INVALID, "cba_restart: null argument");
   if (!p->have_x0) return fail(CBA_ERR_INVALID, "cba_restart: call cba_begin first");
   HIPCHK(hipSetDevice(p->device));
@@ -2212,7 +1849,6 @@ int cba_restart(cba_problem* p, double* cost_out) {
 }
 
 int cba_begin_deferred(cba_problem* p, const double* x0) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_begin_deferred: null argument");
   if (!x0 && !p->have_x0) return fail(CBA_ERR_INVALID, "cba_begin_deferred: no x0 on the device yet");
   HIPCHK(hipSetDevice(p->device));
@@ -2251,7 +1887,6 @@ static int begin_common(cba_problem* p, double* cost_out, bool evaluate) {
 }
 
 int cba_linearize(cba_problem* p, cba_linearization* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_linearize: null argument");
   if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_linearize: the problem was created with evaluation_only");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize: call cba_begin first");
@@ -2264,7 +1899,6 @@ int cba_linearize(cba_problem* p, cba_linearization* out) {
 }
 
 int cba_linearize_build(cba_problem* p) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_linearize_build: null argument");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_linearize_build: call cba_begin first");
   if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_linearize_build: the problem was created with evaluation_only");
@@ -2277,7 +1911,6 @@ int cba_linearize_build(cba_problem* p) {
 }
 
 int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_newton_step: null argument");
   if (!p->linearized) return fail(CBA_ERR_INVALID, "cba_newton_step: call cba_linearize first");
   if (!(lam >= 0.0) || !std::isfinite(lam)) return fail(CBA_ERR_INVALID, "cba_newton_step: lam must be finite and >= 0");
@@ -2290,7 +1923,6 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
 }
 
 int cba_step(cba_problem* p, double radius, cba_step_info* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_step: null argument");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_step: call cba_begin first");
   if (!cba_step_supported(p)) return fail(CBA_ERR_UNSUPPORTED, "cba_step: not available for this problem (constraint rows, heavy points, bound scaling or the LDS Schur path): use the primitives");
@@ -2305,7 +1937,6 @@ int cba_step(cba_problem* p, double radius, cba_step_info* out) {
 }
 
 int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: no damped step to measure");
   HIPCHK(hipSetDevice(p->device));
@@ -2319,7 +1950,7 @@ int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
 }
 
 int cba_step_supported(cba_problem* p) {
-  return (p && !p->eval_only && p->schur_reg && !p->con.n_con && !p->n_heavy && !p->cam_scaled && !p->peer_needs_primitives) ? 1 : 0;
+  return (p && !p->eval_only && !p->con.n_con && !p->n_heavy && !p->cam_scaled && !p->peer_needs_primitives) ? 1 : 0;
 }
 
 // camera-block override of a device vector: `host` [ncp] -> dev [ncp_pad] (padding stays zero)
@@ -2330,7 +1961,6 @@ static int upload_cam(cba_problem* p, const double* host, double* dev) {
 
 int cba_subspace_gram_ex(cba_problem* p, double a1, double b1, const double* cam1, double a2, double b2, const double* cam2,
                          double* gram_out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !gram_out) return fail(CBA_ERR_INVALID, "cba_subspace_gram: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_subspace_gram: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
@@ -2358,7 +1988,6 @@ int cba_subspace_gram(cba_problem* p, double a1, double b1, double a2, double b2
 }
 
 int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !mult || !diag_h || !out) return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: null argument");
   if (!p->linearized) return fail(CBA_ERR_INVALID, "cba_set_camera_scaling: call cba_linearize first");
   for (int i = 0; i < p->ncp; ++i)
@@ -2398,7 +2027,6 @@ int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* dia
 int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { return cba_trial_ex(p, alpha, beta, nullptr, out); }
 
 int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_new, cba_trial_info* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_trial: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_trial: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
@@ -2436,7 +2064,6 @@ int cba_trial_ex(cba_problem* p, double alpha, double beta, const double* cam_x_
 }
 
 int cba_accept(cba_problem* p) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_accept: null argument");
   if (!p->have_trial) return fail(CBA_ERR_INVALID, "cba_accept: no trial point");
   std::swap(p->x, p->x_new);
@@ -2465,10 +2092,10 @@ int cba_comm_unique_id(char* out128) {
 }
 
 int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !id128) return fail(CBA_ERR_INVALID, "cba_comm_init: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(CBA_ERR_INVALID, "cba_comm_init: rank %d of %d", rank, world);
-  if (p->comm) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
+  if (p->comm.load()) return fail(CBA_ERR_INVALID, "cba_comm_init: communicator already initialised");
+  if (p->comm_aborted.load()) return fail(CBA_ERR_COMM, "cba_comm_init: a peer rank failed before the communicator was created");
   HIPCHK(hipSetDevice(p->device));
   p->rank = rank; p->world = world;
   // A one-rank communicator is pointless in production but exercises every RCCL call site on a single GPU
@@ -2478,14 +2105,18 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
   if (world == 1 && !forced) return CBA_OK;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
-  NCCLCHK(ncclCommInitRank(&p->comm, world, id, rank));
+  {
+    ncclComm_t c = nullptr;
+    NCCLCHK(ncclCommInitRank(&c, world, id, rank));
+    p->comm.store(c);
+  }
   // cba_step issues one collective more than the primitives (the camera blocks of the trial build): every rank must
   // take the same route.  A rank whose shard needs the primitives (constraint rows, heavy points, LDS Schur path)
   // switches the fused route off for all of them.
   {
     const double mine = cba_step_supported(p) ? 0.0 : 1.0;
     HIPCHK(hipMemcpyAsync(p->xbuf, &mine, sizeof(double), hipMemcpyHostToDevice, p->stream));
-    NCCLCHK(ncclAllReduce(p->xbuf, p->xbuf, 1, ncclDouble, ncclSum, p->comm, p->stream));
+    NCCLCHK(ncclAllReduce(p->xbuf, p->xbuf, 1, ncclDouble, ncclSum, p->comm.load(), p->stream));
     double total = 0.0;
     HIPCHK(hipMemcpyAsync(&total, p->xbuf, sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -2497,11 +2128,10 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
 int cba_comm_abort(cba_problem* p) {
   // no api guard: this is called from another thread while the owner may be blocked inside a collective
   if (!p) return fail(CBA_ERR_INVALID, "cba_comm_abort: null problem");
-  ncclComm_t c = p->comm;
-  if (c) {
-    p->comm = nullptr;  // cba_destroy must not destroy an aborted communicator
-    (void)ncclCommAbort(c);
-  }
+  // Sticky: from here on every collective of the handle fails with CBA_ERR_COMM (the owner, if it was not blocked inside one, must not carry on
+  // as a single-rank solve of its shard), and the communicator is taken out atomically so that cba_destroy does not destroy what was aborted.
+  p->comm_aborted.store(true, std::memory_order_release);
+  if (ncclComm_t c = p->comm.exchange(nullptr)) (void)ncclCommAbort(c);
   return CBA_OK;
 }
 
@@ -2526,17 +2156,16 @@ int cba_group_create(int32_t world, cba_group** out) {
 int cba_group_join(cba_problem* p, cba_group* g, int32_t rank) {
   if (!p || !g) return fail(CBA_ERR_INVALID, "cba_group_join: null argument");
   if (rank < 0 || rank >= g->world) return fail(CBA_ERR_INVALID, "cba_group_join: rank %d of %d", rank, g->world);
-  if (p->comm || p->group) return fail(CBA_ERR_INVALID, "cba_group_join: the handle already belongs to a communicator");
+  if (p->comm.load() || p->group) return fail(CBA_ERR_INVALID, "cba_group_join: the handle already belongs to a communicator");
   int rc = CBA_OK;
   {
-    CaptureSafe api_guard(g_capture_mu);
     if (hipSetDevice(p->device) != hipSuccess) rc = fail(CBA_ERR_HIP, "hipSetDevice(%d) failed", p->device);
     // staging: the largest payload is the reduced camera system with its right-hand side, or the camera blocks with the
     // packed scalars behind them
     const size_t ustride = (p->nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
     const size_t cap = std::max<size_t>((size_t)p->ncp * p->ncp + p->lay.ncp_pad, (size_t)p->C * ustride + 128) + 128;
     for (int par = 0; par < 2 && !rc; ++par) {
-      if (guarded_malloc((void**)&g->stage[par][rank], cap * sizeof(double)) != hipSuccess) { rc = fail(CBA_ERR_HIP, "staging allocation failed"); break; }
+      if (hipMalloc((void**)&g->stage[par][rank], cap * sizeof(double)) != hipSuccess) { rc = fail(CBA_ERR_HIP, "staging allocation failed"); break; }
       if (hipEventCreateWithFlags(&g->ready[par][rank], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&g->done[par][rank], hipEventDisableTiming) != hipSuccess) { rc = fail(CBA_ERR_HIP, "hipEventCreate failed"); break; }
       // a first record, so that the waits of the first two collectives find completed events
@@ -2550,7 +2179,6 @@ int cba_group_join(cba_problem* p, cba_group* g, int32_t rank) {
   if (!g->barrier()) return fail(CBA_ERR_INVALID, "cba_group_join: the group was aborted (another rank failed before joining)");  // every rank has allocated and published its staging buffers
   if (g->failed.load()) return rc ? rc : fail(CBA_ERR_HIP, "cba_group_join: another rank failed to join");
   {
-    CaptureSafe api_guard(g_capture_mu);
     for (int q = 0; q < g->world && !rc; ++q) {
       const int dq = g->member[q]->device;
       if (dq == p->device) continue;
@@ -2586,7 +2214,6 @@ void cba_group_abort(cba_group* g) { if (g) g->aborted.store(1, std::memory_orde
 // After the member handles are destroyed (or at least idle).
 void cba_group_destroy(cba_group* g) {
   if (!g) return;
-  CaptureSafe api_guard(g_capture_mu);
   for (int par = 0; par < 2; ++par)
     for (int q = 0; q < g->world; ++q) {
       if (g->stage[par][q]) (void)hipFree(g->stage[par][q]);
@@ -2622,7 +2249,6 @@ static int fetch_camera_blocks(cba_problem* p, const double* const* srcs, double
 }
 
 int cba_get_vector(cba_problem* p, int32_t which, double* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_vector: null argument");
   HIPCHK(hipSetDevice(p->device));
   const double* src = nullptr;
@@ -2635,13 +2261,12 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out) {
     default: return fail(CBA_ERR_INVALID, "cba_get_vector: unknown vector %d", which);
   }
   HIPCHK(hipStreamSynchronize(p->stream));
-  HIPCHK(guarded_memcpy(p->h_vec.data(), src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(p->h_vec.data(), src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
   unpack_host(p, p->h_vec.data(), out);
   return CBA_OK;
 }
 
 int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_get_camera_params: null argument");
   HIPCHK(hipSetDevice(p->device));
   const double* src = nullptr;
@@ -2659,7 +2284,6 @@ int cba_get_camera_params(cba_problem* p, int32_t which, double* out) {
 }
 
 int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale_inv_c) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x_c || !g_c || !scale_inv_c) return fail(CBA_ERR_INVALID, "cba_get_camera_state: null argument");
   HIPCHK(hipSetDevice(p->device));
   const double* srcs[3] = {p->x, p->g, p->sinv};
@@ -2668,13 +2292,12 @@ int cba_get_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale
 }
 
 int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_out) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x || !r_out) return fail(CBA_ERR_INVALID, "cba_residuals: null argument");
   HIPCHK(hipSetDevice(p->device));
   // scratch: v2 holds the vector, tab_new the camera table (both are dead between solver calls)
   double* d_r = nullptr;
   const size_t n_rows = (size_t)2 * p->N + (size_t)p->con.n_con;  // reprojection rows, then the constraint rows
-  HIPCHK(guarded_malloc((void**)&d_r, n_rows * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
   pack_host(p, x, p->h_vec.data(), 0.0);
   p->have_trial = false; p->trial_built = false;  // the evaluation borrows the trial point's camera table: a pending trial is gone
   hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
@@ -2685,7 +2308,7 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   }
   int rc = (e == hipSuccess) ? exchange(p, SLOT(24), false) : fail(CBA_ERR_HIP, "cba_residuals: %s", hipGetErrorString(e));
   if (!rc) rc = sync_scalars(p, 32);
-  (void)guarded_free(d_r);
+  (void)hipFree(d_r);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   p->have_trial = false;  // tab_new was overwritten
@@ -2694,7 +2317,6 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
 }
 
 int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, double* gc, double* gp) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p || !x) return fail(CBA_ERR_INVALID, "cba_normal_blocks: null argument");
   HIPCHK(hipSetDevice(p->device));
   if (p->eval_only) return fail(CBA_ERR_INVALID, "cba_normal_blocks: the problem was created with evaluation_only");
@@ -2703,11 +2325,11 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   double cost;
   std::vector<double> saved((size_t)p->lay.total());
   HIPCHK(hipStreamSynchronize(p->stream));
-  HIPCHK(guarded_memcpy(saved.data(), p->x, saved.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(saved.data(), p->x, saved.size() * sizeof(double), hipMemcpyDeviceToHost));
   const bool was_begun = p->begun;
   const bool first = p->first_scale;
   pack_host(p, x, p->h_vec.data(), 0.0);
-  HIPCHK(guarded_memcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
   launch_cam_prep(p, p->x, p->tab);
   DISPATCH_NC(p, run_build<6>(p), run_build<9>(p));
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));  // parity hook: no publish here, leave no flag behind
@@ -2717,7 +2339,7 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   const int ustride = (p->nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   const int tri = (p->nct == 9) ? UPack<9>::TRI : UPack<6>::TRI;
   std::vector<double> hU((size_t)p->C * ustride);
-  HIPCHK(guarded_memcpy(hU.data(), p->Upacked, hU.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hU.data(), p->Upacked, hU.size() * sizeof(double), hipMemcpyDeviceToHost));
   if (U) {
     std::fill(U, U + (size_t)p->C * 81, 0.0);
     for (int c = 0; c < p->C; ++c) {
@@ -2736,19 +2358,19 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
       for (int r = 0; r < p->h_cam_np[c]; ++r) gc[p->h_cam_off[c] + r] = hU[(size_t)c * ustride + tri + r];
   if (V) {
     std::vector<double> hV((size_t)6 * p->lay.Ppad);
-    HIPCHK(guarded_memcpy(hV.data(), p->V, hV.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hV.data(), p->V, hV.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int q = 0; q < p->P; ++q)
       for (int k = 0; k < 6; ++k) V[(size_t)q * 6 + k] = hV[(size_t)k * p->lay.Ppad + q];
   }
   if (gp) {
-    HIPCHK(guarded_memcpy(p->h_vec.data(), p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(p->h_vec.data(), p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
     const double* vx = p->h_vec.data() + p->lay.ncp_pad;
     for (int q = 0; q < p->P; ++q) {
       gp[3 * q] = vx[q]; gp[3 * q + 1] = vx[p->lay.Ppad + q]; gp[3 * q + 2] = vx[2 * p->lay.Ppad + q];
     }
   }
   // restore the solver's current point (its blocks must be rebuilt by the next cba_linearize)
-  HIPCHK(guarded_memcpy(p->x, saved.data(), saved.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->x, saved.data(), saved.size() * sizeof(double), hipMemcpyHostToDevice));
   launch_cam_prep(p, p->x, p->tab);
   HIPCHK(hipStreamSynchronize(p->stream));
   p->begun = was_begun; p->first_scale = first; p->linearized = false; p->stepped = false;
@@ -2756,13 +2378,12 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
 }
 
 int cba_reduced_system(cba_problem* p, double* S, double* rhs) {
-  CaptureSafe api_guard(g_capture_mu);
   if (!p) return fail(CBA_ERR_INVALID, "cba_reduced_system: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_reduced_system: call cba_newton_step first");
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipStreamSynchronize(p->stream));
-  if (S) HIPCHK(guarded_memcpy(S, p->S, (size_t)p->ncp * p->ncp * sizeof(double), hipMemcpyDeviceToHost));
-  if (rhs) HIPCHK(guarded_memcpy(rhs, p->rhs, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost));
+  if (S) HIPCHK(hipMemcpy(S, p->S, (size_t)p->ncp * p->ncp * sizeof(double), hipMemcpyDeviceToHost));
+  if (rhs) HIPCHK(hipMemcpy(rhs, p->rhs, (size_t)p->ncp * sizeof(double), hipMemcpyDeviceToHost));
   return CBA_OK;
 }
 

@@ -137,8 +137,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   double cost = NAN;
   // Without bounds the evaluation of x0 is left to the first linearisation (its build pass computes the cost anyway): one
   // pass over the observations and one wait less per solve.
-  const char* defer_env = std::getenv("CBA_DEFER");
-  const bool deferred = !bounded && !(defer_env && defer_env[0] == '0');
+  const bool deferred = !bounded;
   if (deferred) rc = calls.run("begin_deferred", [&] { return cba_begin_deferred(p, x0); });
   else rc = x0 ? calls.run("begin", [&] { return cba_begin(p, x0, &cost); }) : calls.run("restart", [&] { return cba_restart(p, &cost); });
   if (rc) return rc;
@@ -155,8 +154,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   // Fused iterations (cba_step): linearisation, damping, damped step, subspace step and first trial behind ONE host
   // synchronisation; the trial is evaluated by a build pass, so an accepted step needs no further pass.  A rejected
   // first trial costs a build instead of a cost pass: after one, the next iteration goes through the primitives.
-  const char* fused_env = std::getenv("CBA_FUSED");
-  const bool fused = !bounded && cba_step_supported(p) && !(fused_env && fused_env[0] == '0');
+  const bool fused = !bounded && cba_step_supported(p);
   bool fuse_next = fused;
   cba_linearization lin;
   cba_step_info si;

@@ -237,7 +237,10 @@ def make_sharded_hip_engine(problem: BAProblem, control, device_id: int = -1, gr
     shard = shard_problem(problem, control.rank, control.world)
     engine = HipEngine(shard.problem, device_id=device_id)
     if on_engine is not None:
-        on_engine(engine)  # before the communicator is created: a peer that fails during the rendezvous can already abort this rank
+        # before the communicator is created: a peer that fails from here on marks this handle aborted, so that comm_init (if it has not begun) and
+        # every later collective fail instead of waiting for it.  (A rank already INSIDE ncclCommInitRank when a peer dies before calling it is not
+        # released by this — RCCL's blocking rendezvous has no abort; the peers' host-side barrier abort covers the ranks that have not entered it.)
+        on_engine(engine)
     try:
         if control.world > 1:
             if group is not None:

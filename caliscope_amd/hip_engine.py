@@ -9,6 +9,7 @@ of ``caliscope_amd/csrc``; if the library or a device is missing the constructor
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -63,6 +64,7 @@ class HipEngine:
         opt = _lib.Options(device_id=device_id, max_blocks=max_blocks, deterministic=1 if deterministic else 0, evaluation_only=1 if evaluation_only else 0)
         handle = C.c_void_p()
         self._h = None
+        self._life = threading.Lock()  # close() against comm_abort() from a peer's thread
         _lib.check(self.lib, self.lib.cba_create(C.byref(desc), C.byref(opt), C.byref(handle)), "cba_create")
         self._h = handle
         self.n_params = problem.n_params
@@ -80,9 +82,16 @@ class HipEngine:
 
     # -- lifetime ------------------------------------------------------------------------------------
     def close(self) -> None:
-        if getattr(self, "_h", None) is not None:
-            self.lib.cba_destroy(self._h)
-            self._h = None
+        # close() and comm_abort() exclude each other: a peer thread's abort (solve_multi_device, a failing rank) must never reach a handle that is
+        # being destroyed.  The handle is taken out of the object BEFORE cba_destroy runs (ctypes releases the GIL inside it), so an abort that
+        # waited for the lock finds nothing to abort.
+        lock = getattr(self, "_life", None)
+        if lock is None:
+            return
+        with lock:
+            h, self._h = getattr(self, "_h", None), None
+            if h is not None:
+                self.lib.cba_destroy(h)
 
     def __del__(self):
         try:
@@ -220,8 +229,9 @@ class HipEngine:
     def comm_abort(self) -> None:
         """``ncclCommAbort`` on this handle's communicator — from ANOTHER thread, when a peer rank failed: a collective this rank is
         blocked in returns an error instead of waiting for ever.  The handle is only good for ``close()`` afterwards."""
-        if self._h:
-            self.lib.cba_comm_abort(self._h)
+        with self._life:  # not while close() destroys the handle, and not after it
+            if self._h:
+                self.lib.cba_comm_abort(self._h)
 
     def group_join(self, group: "DeviceGroup", rank: int) -> None:
         """Join an in-process device group (one host thread per member; returns when all have joined)."""
