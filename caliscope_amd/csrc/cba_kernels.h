@@ -489,22 +489,27 @@ struct CsPlan {
   int n_sc;
   int pmax;               // points of the largest super-chunk, rounded up to a multiple of 32: row stride of the per-point LDS arrays
 };
-template <int NC, bool CAMG = false>
+// UGLOB (more cameras than the LDS holds packed blocks for: > ~650 six- / ~320 nine-parameter cameras; the reference has no limit,
+// core/reprojection.py:75-119): a thread's register sums go to ONE global copy of the blocks by FP64 global atomics (the caller zeroes it; a thread
+// flushes once per camera change, ~13 atomics per observation at 1000 cameras) instead of to the workgroup's LDS copy; partialU is that copy.
+template <int NC, bool CAMG = false, bool UGLOB = false>
 __global__ void __launch_bounds__(BLOCK)
 k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams, int loss, double f_scale,
            double* __restrict__ Vblk, double* __restrict__ gvec, double* __restrict__ partialU, double* __restrict__ partial_cost,
            int* __restrict__ flags, const double* __restrict__ skip) {
   using UP = UPack<NC>;
+  static_assert(!UGLOB || CAMG, "a camera count beyond the LDS copy of the blocks is beyond the LDS copy of the table as well");
   if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
   double* sh_U = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);
   const int PM = cs.pmax;
-  double* sh_vg = sh_U + n_cams * UP::STRIDE;        // [9][PM]
+  double* sh_vg = sh_U + (UGLOB ? 0 : n_cams * UP::STRIDE);        // [9][PM]
   double* sh_x = sh_vg + 9 * PM;                     // [3][PM]
   double* sh_red = sh_x + 3 * PM;
   if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
-  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
+  if (!UGLOB)
+    for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
   const double* px = xvec + lay.ncp_pad;
   double* gp = gvec + lay.ncp_pad;
   double cost = 0.0;
@@ -525,14 +530,14 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
     int cur_cam = -1, cur_np = 0;
     auto flush = [&]() {
       if (cur_cam < 0) return;
-      double* Uc = sh_U + cur_cam * UP::STRIDE;
+      double* Uc = (UGLOB ? partialU : sh_U) + (long)cur_cam * UP::STRIDE;
 #pragma unroll
       for (int r = 0; r < NC; ++r) {
         if (r < cur_np) {
 #pragma unroll
           for (int c = r; c < NC; ++c)
-            if (c < cur_np) lds_add(&Uc[UP::idx(r, c)], acc[UP::idx(r, c)]);
-          lds_add(&Uc[UP::TRI + r], acc[UP::TRI + r]);
+            if (c < cur_np) { if (UGLOB) atomicAdd(&Uc[UP::idx(r, c)], acc[UP::idx(r, c)]); else lds_add(&Uc[UP::idx(r, c)], acc[UP::idx(r, c)]); }
+          if (UGLOB) atomicAdd(&Uc[UP::TRI + r], acc[UP::TRI + r]); else lds_add(&Uc[UP::TRI + r], acc[UP::TRI + r]);
         }
       }
 #pragma unroll
@@ -572,8 +577,10 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
     }
   }
   __syncthreads();
-  double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
-  for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
+  if (!UGLOB) {
+    double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
+    for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
+  }
   const double tot = block_sum(cost, sh_red);
   if (threadIdx.x == 0) partial_cost[blockIdx.x] = tot;
   if (bad) flags[0] = 1;
@@ -744,6 +751,7 @@ struct TilePlan {
   int tile_elems;                // width of one workgroup's partial row: 256 blocks of nc^2
   const int* obs;                // chunk slot -> observation (index into the T records)
   int rep;                       // threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
+  int rows_per_wg;               // partial rows a (logical) workgroup writes: rep, times two in the two-set form (two waves share a wave's pair codes)
   const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_addr | j_addr << 16), LDS addresses in 16-byte pieces
   const int* code_start;         // [n_tile_chunks + 1] offsets into `codes`
   const unsigned* nit;           // [n_tile_chunks] iterations of waves 0..3, one byte each
@@ -999,23 +1007,27 @@ __device__ __forceinline__ void pair_rows(double (*acc)[NC], const double* Rm, c
 //     addresses) into the buffer that is NOT being read (two buffers), so a trip is: wait for the loads issued a trip ago, one barrier, issue
 //     the next chunk's loads, multiply.  No staging registers.
 //
-// SETS = 2 (round 4, six-parameter cameras): the ping-pong form.  Measured per trip and workgroup on cfg4 (phase clocks, two 4-wave workgroups
-// per CU): issuing 1600 clocks, pair arithmetic 2000, barrier 750 — while the pure costs are ~900 (the CU's vector-memory path takes a 64-lane
-// gather every ~26 clocks: 35 per chunk) and ~800 (99 FP64 instructions of 4 clocks per pair, two pair iterations per chunk): both phases take
-// TWICE their floor because the CU's two workgroups drift into the same phase and then contend — for the address path while both issue, for
-// the FP64 pipe while both multiply.  Here ONE 8-wave workgroup holds two SETS of four waves, each with its own chunk sequence, accumulators
-// and pair of LDS buffers, i.e. exactly the two workgroups of before — but a barrier of the WHOLE workgroup separates the issue phase from the
-// pair phase, and set 1 runs half a period behind set 0: whenever one set issues its gathers the other one multiplies.
-template <int NC, int SETS = 1> struct Reg3Cfg {
-  static_assert(SETS == 1 || SETS == 2, "one set, or two in anti-phase");
+// SETS = 2, PW = 2 (round 4, six-parameter cameras): the anti-phase form.  Phase clocks of the one-set kernel on cfg4 (two 4-wave workgroups per
+// CU), per trip and workgroup: issuing 1450 clocks, pair arithmetic 1900, barrier 680.  The pair phase is FP64 issue: 99 instructions of 4
+// clocks per pair iteration, ~830 clocks per iteration with TWO waves per SIMD multiplying — the pipe is full — while ONE wave alone on its
+// SIMD needs ~900 for the same iteration (measured with two 4-wave sets forced into anti-phase: no faster).  The issue phase is the CU's address
+// path: a 64-lane gather every ~26 clocks, 35 per chunk, whoever issues them.  The two phases use different units and never overlapped: the
+// CU's two workgroups drift into the same phase.  Here ONE 16-wave workgroup holds two SETS (own chunk sequence, own pair of LDS buffers — the
+// two workgroups of before), each made of PW = 2 waves per pair-code wave: the first four waves of a set gather, all eight multiply, wave
+// parity q taking the pair iterations it = q, q + 2, ... of its code wave into its own accumulators (one more partial row).  A bare s_barrier
+// of the WHOLE workgroup separates a set's issue phase from its pair phase and set 1 runs half a period behind set 0: while one set's eight
+// waves fill the FP64 pipes, the other set's four loaders keep the address path busy.
+template <int NC, int SETS = 1, int PW = 1> struct Reg3Cfg {
+  static_assert((SETS == 1 && PW == 1) || (SETS == 2 && (PW == 1 || PW == 2)), "one set, or two in anti-phase");
   static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
   static constexpr int SPLIT = (NC == 9) ? 3 : 1;
   static constexpr int CODE_THREADS = BLOCK, CODE_WAVES = BLOCK / WAVE;             // blocks of a tile = pair-code streams
-  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;        // threads / waves of one set
+  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;        // loading threads / waves of one set
+  static constexpr int SET_THREADS = REG_BLOCK * PW;                                // threads of one set
   static constexpr int GROUP = 16;                                                  // cameras per group: GROUP^2 blocks <= CODE_THREADS
   // pair codes per block and chunk that travel in registers (a code beyond them is loaded inside the pair loop: a vmcnt(0) behind the record loads
   // in flight)
-  static constexpr int NCD = (NC == 6) ? 8 : 4;
+  static constexpr int NCD = ((NC == 6 && SETS == 1) ? 8 : 4) / (SETS == 2 && PW == 2 ? 2 : 1);  // (two sets: the register file is full at four)
   static constexpr int PAIR_CAP = 0;
   static constexpr int SCHUNK = (NC == 9) ? 384 : 320;                              // slots per chunk (per LDS buffer)
   static constexpr int EPW = SCHUNK / NWAVES;                                       // slots loaded by one wave (80 / 32)
@@ -1026,7 +1038,7 @@ template <int NC, int SETS = 1> struct Reg3Cfg {
   static constexpr int NBUF = 2;                                                    // chunk buffers of a set: a gather is issued one trip before it is read
   static constexpr int SET_PIECES = NBUF * BUF_PIECES;
   static constexpr size_t LDS_BYTES = (size_t)SETS * SET_PIECES * 16;
-  static constexpr int LAUNCH_THREADS = SETS * REG_BLOCK;
+  static constexpr int LAUNCH_THREADS = SETS * SET_THREADS;
   static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
   static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
   static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
@@ -1038,21 +1050,28 @@ template <int NC, int SETS = 1> struct Reg3Cfg {
 // the body written directly in the kernel it put a vmcnt(0) in front of the first record read of every trip: the wave sat out the
 // gather it had just issued).
 // CLK (profiling build, -DCBA_PROFILING + CBA_SCHUR_CLOCK=1): per wave the shader clocks spent waiting for loads, in barriers, issuing, multiplying.
-template <int NC, int SPLIT, int SETS, bool CLK = false>
+// ILV: the gather of the next chunk is not issued in one burst before the pair loop but a few loads at a time BETWEEN the pair iterations: the CU's
+// address path takes a 64-lane gather every ~26 clocks, a burst of 4 x 9 of them (two workgroups: 8 x 9) queues the waves up at issue while the
+// FP64 pipes idle, and then the pipes work while the address path idles — interleaved, both are busy at once.
+template <int NC, int SPLIT, int SETS, int PW, bool CLK = false, bool ILV = false>
 __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
                                                 const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
                                                 const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr,
                                                 const double* __restrict__ tab = nullptr) {
-  using Cfg = Reg3Cfg<NC, SETS>;
+  using Cfg = Reg3Cfg<NC, SETS, PW>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
+  constexpr int SET_THREADS = Cfg::SET_THREADS;
   constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW, NWORD = Cfg::CODE_WAVES / 4;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
   constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
 
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
-  const int set = (SETS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / REG_BLOCK);
-  const int tid = (int)threadIdx.x % REG_BLOCK;  // thread of the set
+  const int set = (SETS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / SET_THREADS);
+  const int tid_set = (int)threadIdx.x % SET_THREADS;  // thread of the set
+  const int par = (PW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid_set / REG_BLOCK);  // which of the PW waves sharing a code wave's iterations
+  const int tid = tid_set % REG_BLOCK;  // its role among the set's blocks (and, par == 0, among its loaders)
+  const bool loader = par == 0;
   // the id this set works under (index into wg_first / ... and of its partial row).  One set: csrc/wg_binding.h, interleaved over the dispatch
   // order.  Two sets: physical workgroup B (XCD B mod 8) runs the logical workgroups 16 (B / 8) + B mod 8 and that + 8 — both ids keep
   // B mod 8, which is what the XCD-aware binding (bind_workgroups) goes by
@@ -1078,7 +1097,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int vt = (SPLIT == 1) ? tid : ct;
   const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
   const bool owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
-  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
+  double* dst = partial + (((long)wg * PW + par) * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
 
   // chunk range of this set; a workgroup's sets run the same number of trips (the barriers are the workgroup's), a set that is out of
   // chunks idles through the rest: it gathers its last chunk again and multiplies nothing
@@ -1088,7 +1107,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int first = own_trips ? tp.wg_first[wg] : max(ch_end - 1, 0);  // (no chunk of its own: somebody's valid chunk, never multiplied)
   int trips = own_trips;
   if (SETS == 2) trips = max(trips, trips_of(logical_of(set ^ 1)));
-  for (int k = tid; k < Cfg::NBUF * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
+  for (int k = tid_set; k < Cfg::NBUF * LST; k += SET_THREADS) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
   const int last = first + (own_trips ? (own_trips - 1) * stride : 0);  // last chunk of this set
   // Per trip every wave issues, in this order and WITHOUT waiting in between: the codes of the next chunk and the record indices
   // of the chunk after next (their addresses come from the iteration counts / offsets loaded a trip earlier), the counts and
@@ -1127,16 +1146,14 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     n_nx = __builtin_amdgcn_readfirstlane(mine);
     code_nx = (long)r.code_start + (long)pre * WAVE + lane;
 #pragma unroll
-    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + (long)(k * PW + par) * WAVE];  // iterations par, par + PW, ..; past the wave's last one: somebody else's codes, never used
   };
   // load k of this wave fills LDS pieces [k * 64, k * 64 + 64) of the wave's run: piece (k * 64 + lane) % LST of slot
   // (k * 64 + lane) / LST; the record index of the slot comes from the wave's index registers (ds_bpermute)
-  auto issue = [&](int buf, int idxA, int idxB) {
+  // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
+  // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
+  auto prepare = [&](int idxA, int idxB, const double2* (&g)[NLD]) {
     constexpr int Q = WAVE / LST, RM = WAVE % LST;
-    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
-    // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
-    // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
-    const double2* g[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       int piece = k * RM + lane % LST;
@@ -1148,16 +1165,30 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
       g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  auto fire = [&](int buf, const double2* (&g)[NLD], int k0, int k1) {  // loads k0 .. k1 - 1 of the wave's NLD
+    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
+      if (k >= k0 && k < k1)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
   };
-  auto pair = [&](const double2* bufp, unsigned code) {
+  auto issue = [&](int buf, int idxA, int idxB) {
+    const double2* g[NLD];
+    prepare(idxA, idxB, g);
+    fire(buf, g, 0, NLD);
+  };
+  // the two records of a pair (NC = 6): six 16-byte pieces each
+  struct Rec6 { double2 i[6], j[6]; };
+  auto load6 = [&](const double2* bufp, unsigned code, Rec6& R) {
     const double2* Ri = bufp + (code & 0xffffu);
     const double2* Rj = bufp + (code >> 16);
-    if constexpr (NC == 6) {
-      const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
-      const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { R.i[q] = Ri[q]; R.j[q] = Rj[q]; }
+  };
+  auto math6 = [&](const Rec6& R) {
+      const double2 i0 = R.i[0], i1 = R.i[1], i2 = R.i[2], i3 = R.i[3], i4 = R.i[4], i5 = R.i[5];
+      const double2 j0 = R.j[0], j1 = R.j[1], j2 = R.j[2], j3 = R.j[3], j4 = R.j[4], j5 = R.j[5];
       const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
       const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
       const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
@@ -1178,6 +1209,14 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
         acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
         acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
       }
+  };
+  auto pair = [&](const double2* bufp, unsigned code) {
+    const double2* Ri = bufp + (code & 0xffffu);
+    const double2* Rj = bufp + (code >> 16);
+    if constexpr (NC == 6) {
+      Rec6 R;
+      load6(bufp, code, R);
+      math6(R);
     } else {
       double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
       if (half == 2) {  // rows of T_intr,i
@@ -1198,13 +1237,19 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   int idxA = 0, idxB = 0;
   const int second = min(first + stride, last);
   Raw raw = load_raw(first, second);
-  load_indices(p_chunk_start[first], &idxA, &idxB);
-  issue(0, idxA, idxB);
+  if (loader) {
+    load_indices(p_chunk_start[first], &idxA, &idxB);
+    issue(0, idxA, idxB);
+  }
   load_codes(raw);                           // the first chunk's codes
-  load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
+  if (loader) load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
   raw = load_raw(second, min(second + stride, last));
   int buf = 0;
-  if (SETS == 2 && set == 1) __syncthreads();  // half a period behind set 0: its issue phase falls into set 0's pair phase and vice versa
+  // Phase barriers of the two-set form are BARE s_barrier instructions (inline asm): they align the sets' phases and order nothing — the data
+  // hazards are covered by the wait + __syncthreads at the top of every trip.  __syncthreads() here would bring its workgroup-scope fence, for
+  // which the compiler drains vmcnt: the set would sit out the gather it has just issued.
+  auto phase_barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+  if (SETS == 2 && set == 1) phase_barrier();  // half a period behind set 0: its issue phase falls into set 0's pair phase and vice versa
   for (int trip = 0; trip < trips; ++trip) {
     const int cur = min(first + trip * stride, last);
     // everything issued a trip ago has landed (the records of `cur` in `buf`, its codes, the counts and indices of the next
@@ -1236,20 +1281,49 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     const int nxt2 = min(min(cur + stride, last) + stride, last);
     load_codes(raw);                        // codes of the next chunk: addresses from registers, no wait
     int idxA_n = 0, idxB_n = 0;
-    load_indices(raw.obs_start, &idxA_n, &idxB_n);  // indices of the chunk after next
+    if (loader) load_indices(raw.obs_start, &idxA_n, &idxB_n);  // indices of the chunk after next
     const Raw raw_n = load_raw(nxt2, min(nxt2 + stride, last));
-    issue(buf ^ 1, idxA, idxB);             // records of the next chunk
+    const double2* gq[NLD];
+    if (ILV) prepare(idxA, idxB, gq);       // (ILV: one set, every wave loads)
+    else if (loader) issue(buf ^ 1, idxA, idxB); // records of the next chunk
     __builtin_amdgcn_sched_barrier(0);
     if (CLK) { tD = clock64(); __builtin_amdgcn_sched_barrier(0); }
-    if (SETS == 2) __syncthreads();         // phase boundary of the whole workgroup: the other set starts issuing, this one multiplies
+    if (SETS == 2) phase_barrier();         // phase boundary of the whole workgroup: the other set starts issuing, this one multiplies
     if (CLK) { tP = clock64(); __builtin_amdgcn_sched_barrier(0); }
     const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
     // (reading the records of pair it + 1 while pair it is multiplied — there would be registers for it in the NC = 6 kernel — measured
     // slower: 112k instead of 98k clocks per wave in the pair phase)
+    if constexpr (NC == 6 && SETS == 2 && PW == 1) {
+      // A set multiplies ALONE on its SIMDs (the other set is issuing): nobody hides the LDS latency of a pair's twelve reads, so the records of
+      // pair k + 1 are read while pair k is multiplied (+48 registers; with two workgroups per CU in the same phase — the one-set kernel — the
+      // other wave hides it and the prefetch measured slower, round 3).
+      static_assert(NCD % 2 == 0, "two alternating record sets");
+      Rec6 Ra, Rb;
+      load6(bufp, cc[0], Ra);
 #pragma unroll
-    for (int it = 0; it < NCD; ++it)
-      if (it < n_cur) pair(bufp, cc[it]);
-    for (int it = NCD; it < n_cur; ++it) pair(bufp, p_codes[code_cur + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
+      for (int k = 0; k < NCD; k += 2) {
+        if (k < n_cur) { load6(bufp, cc[k + 1], Rb); math6(Ra); }  // (a code beyond the wave's last iteration holds valid addresses: read, not used)
+        if (k + 1 < n_cur) { if (k + 2 < NCD) load6(bufp, cc[k + 2], Ra); math6(Rb); }
+      }
+    } else if constexpr (ILV) {
+      static_assert(!ILV || (SETS == 1 && PW == 1), "interleaved issue: the one-set kernel");
+      constexpr int QL = (NLD + 2) / 3;  // loads in front of each of the first three pair iterations (9 -> 3 + 3 + 3, 6 -> 2 + 2 + 2)
+#pragma unroll
+      for (int k = 0; k < NCD; ++k) {
+        if (k * QL < NLD) {
+          fire(buf ^ 1, gq, k * QL, min((k + 1) * QL, NLD));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k < n_cur) pair(bufp, cc[k]);
+        if (k * QL < NLD) __builtin_amdgcn_sched_barrier(0);
+      }
+      static_assert(NCD * ((NLD + 2) / 3) >= NLD, "every load is issued inside the unrolled part");
+    } else {
+#pragma unroll
+    for (int k = 0; k < NCD; ++k)
+      if (k * PW + par < n_cur) pair(bufp, cc[k]);
+    }
+    for (int it = NCD * PW + par; it < n_cur; it += PW) pair(bufp, p_codes[code_cur + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
     if (CLK) {
       __builtin_amdgcn_sched_barrier(0);
       const long long tE = clock64();
@@ -1258,9 +1332,9 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     raw = raw_n; idxA = idxA_n; idxB = idxB_n;
     buf ^= 1;
   }
-  if (SETS == 2 && set == 0) __syncthreads();  // (set 1's extra barrier at the top)
+  if (SETS == 2 && set == 0) phase_barrier();  // (set 1's extra barrier at the top)
   if (CLK && lane == 0 && clk) {
-    long long* o = clk + ((long)wg * Cfg::NWAVES + sw) * 8;
+    long long* o = clk + (((long)wg * PW + par) * Cfg::NWAVES + sw) * 8;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
     o[6] = clock64() - t_start;
@@ -1310,19 +1384,19 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
       if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
 }
 
-template <int NC, int SPLIT, int MINW, int SETS = 1>
-__global__ void __launch_bounds__((Reg3Cfg<NC, SETS>::LAUNCH_THREADS), MINW)
+template <int NC, int SPLIT, int MINW, int SETS = 1, int PW = 1, bool ILV = false>
+__global__ void __launch_bounds__((Reg3Cfg<NC, SETS, PW>::LAUNCH_THREADS), MINW)
 k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, SETS, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
+  schur_reg3_body<NC, SPLIT, SETS, PW, false, ILV>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
 }
 
 #ifdef CBA_PROFILING  // tools/build_profiling_lib.sh: the phase-clock build of the pair kernel is not part of the product library
-template <int NC, int SPLIT, int MINW, int SETS = 1>
-__global__ void __launch_bounds__((Reg3Cfg<NC, SETS>::LAUNCH_THREADS), MINW)
+template <int NC, int SPLIT, int MINW, int SETS = 1, int PW = 1, bool ILV = false>
+__global__ void __launch_bounds__((Reg3Cfg<NC, SETS, PW>::LAUNCH_THREADS), MINW)
 k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, SETS, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
+  schur_reg3_body<NC, SPLIT, SETS, PW, true, ILV>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
 }
 #endif
 
@@ -1344,7 +1418,7 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int g = tp.g, bsz = NCt * NCt;
   const int e = blockIdx.x * 64 + threadIdx.x;
-  const int w0 = tile_wg_begin[t] * tp.rep, w1 = tile_wg_begin[t + 1] * tp.rep;  // rep partial rows per workgroup
+  const int w0 = tile_wg_begin[t] * tp.rows_per_wg, w1 = tile_wg_begin[t + 1] * tp.rows_per_wg;  // partial rows per workgroup
   const bool diag = (ga == gb);
   long dst = -1;       // >= 0: Sacc index;  -2: park in red
   if (e < g * g * bsz) {

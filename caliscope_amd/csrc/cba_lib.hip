@@ -75,7 +75,7 @@ struct cba_problem {
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  bool schur_pp = false;   // k_schur_reg3<6, .., SETS = 2>: two sets of four waves per workgroup in anti-phase (one workgroup per CU) instead of two workgroups per CU
+  int schur_pp = 0;        // k_schur_reg3<6, .., SETS = 2>: two sets per workgroup in anti-phase (one workgroup per CU) instead of two workgroups per CU; 1: PW = 1, 2: PW = 2
   int cus = 256;           // compute units of the device
   double plan_lane_util = 0.0;  // share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
@@ -562,9 +562,11 @@ template <int NC> static bool build_camg(const cba_problem* p) {
   // (a second workgroup per CU when the table is what keeps it off; no choice at all when table + accumulators exceed the LDS)
   return !p->det_m && ((with_tab > 80 * 1024 && lds_build_camg<NC>(p) <= 80 * 1024) || with_tab > 160 * 1024);
 }
-template <int NC> static size_t lds_build_cs(const cba_problem* p, bool camg) {
-  return ((camg ? 0 : (size_t)p->C * CAMTAB_LDS) + (size_t)p->C * UPack<NC>::STRIDE + 12 * (size_t)p->cs.pmax + 8) * 8;
+template <int NC> static size_t lds_build_cs(const cba_problem* p, bool camg, bool uglob = false) {
+  return ((camg ? 0 : (size_t)p->C * CAMTAB_LDS) + (uglob ? 0 : (size_t)p->C * UPack<NC>::STRIDE) + 12 * (size_t)p->cs.pmax + 8) * 8;
 }
+// beyond ~650 six- / ~320 nine-parameter cameras the packed camera blocks do not fit the LDS: one global copy, FP64 global atomics (k_build_cs<.., UGLOB>)
+template <int NC> static bool build_cs_uglob(const cba_problem* p) { return lds_build_cs<NC>(p, true) > 160 * 1024; }
 // k_build_cs keeps the camera table in LDS while that leaves room for two workgroups per CU
 template <int NC> static bool build_cs_camg(const cba_problem* p) { return p->tab_global || lds_build_cs<NC>(p, false) > 80 * 1024; }
 template <int NC> static size_t lds_build(const cba_problem* p) {
@@ -719,7 +721,7 @@ static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Param
   TilePlan tp{};
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
   tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g;
-  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
+  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep; tp.rows_per_wg = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
   tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
   p->tp = tp;
   return CBA_OK;
@@ -735,10 +737,14 @@ static int install_reg2_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& p
   const int mb = p->plan_max_blocks;
   int rc = (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
   if (rc) return rc;
-  // Six-parameter cameras with more than one workgroup per CU: the two workgroups of a CU become the two anti-phased sets of ONE 8-wave workgroup
-  // (k_schur_reg3<6, .., SETS = 2>, cba_kernels.h).  A launch that does not fill the chip keeps the 4-wave workgroups: one per CU, nothing to de-phase.
-  p->schur_pp = p->nct == 6 && (p->tile_grid % 2) == 0 && p->tile_grid > p->cus;
-  if (const char* e = std::getenv("CBA_SCHUR_PP")) p->schur_pp = p->nct == 6 && (p->tile_grid % 2) == 0 && std::atoi(e) != 0;  // (A/B measurements)
+  // Six-parameter cameras with more than one workgroup per CU: the two workgroups of a CU become the two anti-phased sets of ONE 16-wave workgroup
+  // (k_schur_reg3<6, .., SETS = 2, PW = 2>, cba_kernels.h).  A launch that does not fill the chip keeps the 4-wave workgroups: one per CU, nothing to de-phase.
+  p->schur_pp = (p->nct == 6 && (p->tile_grid % 2) == 0 && p->tile_grid > p->cus) ? 1 : 0;
+  if (const char* e = std::getenv("CBA_SCHUR_PP")) p->schur_pp = (p->nct == 6 && (p->tile_grid % 2) == 0) ? std::atoi(e) : 0;  // (A/B measurements)
+  if (p->schur_pp == 2) {  // two waves share a code wave's pair iterations: one more partial row per workgroup
+    p->tp.rows_per_wg = 2 * std::max(prm.rep, 1);
+    p->reg_reduce_y = REG_REDUCE_Y_MAX;
+  }
   return CBA_OK;
 }
 
@@ -767,12 +773,18 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_cost<true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<false, true>, lds_cost(p)))) return rc;
   if ((rc = allow_lds(k_cost<true, true>, lds_cost(p)))) return rc;
-  if (p->cs.n_sc) {
-    if (lds_build_cs<NC>(p, build_cs_camg<NC>(p)) > 160 * 1024) p->cs.n_sc = 0;  // too many cameras for its LDS copy of the blocks: k_build
-    else if ((rc = build_cs_camg<NC>(p) ? allow_lds(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)) : allow_lds(k_build_cs<NC, false>, lds_build_cs<NC>(p, false)))) return rc;
+  const bool use_cs = p->cs.n_sc && !p->det_m && !p->n_heavy;  // (run_build_into's condition)
+  if (use_cs) {
+    if (build_cs_uglob<NC>(p)) rc = allow_lds(k_build_cs<NC, true, true>, lds_build_cs<NC>(p, true, true));
+    else rc = build_cs_camg<NC>(p) ? allow_lds(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)) : allow_lds(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
+    if (rc) return rc;
   }
-  if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
-  if ((rc = allow_lds(k_build<NC, 0, true>, lds_build<NC>(p)))) return rc;
+  if (!use_cs || !build_cs_uglob<NC>(p)) {  // the point-ordered kernel keeps the packed blocks in LDS: not with that many cameras
+    if ((rc = allow_lds(k_build<NC>, lds_build<NC>(p)))) return rc;
+    if ((rc = allow_lds(k_build<NC, 0, true>, lds_build<NC>(p)))) return rc;
+  } else if (p->eval_only) {
+    // (nothing: an evaluation-only handle runs k_cost only)
+  }
   if (p->det_m) {
     if ((rc = allow_lds(k_build<NC, 3>, lds_build<NC>(p)))) return rc;
     if ((rc = allow_lds(k_build<NC, 5>, lds_build<NC>(p)))) return rc;
@@ -786,9 +798,11 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 1, true>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2, true>, lds_jv(p, 2)))) return rc;
   if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
+  if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1, 1, true>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
   if constexpr (NC == 6) {
-    using PP = Reg3Cfg<6, 2>;
-    if ((rc = allow_lds(k_schur_reg3<6, 1, 2, 2>, PP::LDS_BYTES))) return rc;
+    using PP = Reg3Cfg<6, 2, 2>;
+    if ((rc = allow_lds(k_schur_reg3<6, 1, 4, 2, 2>, PP::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(k_schur_reg3<6, 1, 2, 2, 1>, PP::LDS_BYTES))) return rc;
   }
   if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
@@ -1078,7 +1092,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
-  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems);
+  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rows_per_wg, 1) * p->tp.tile_elems);
   TRY(dev_alloc(p, &p->partial, p->partial_capacity));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
@@ -1136,11 +1150,12 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 0;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
-  o->schur_wide = p->schur_pp ? 2 : 0;  // 2: the two-set (ping-pong) form of the pair kernel
+  o->schur_wide = p->schur_pp ? 2 : 0;  // 2: a two-set (anti-phase) form of the pair kernel
   {
     const bool cs = p->cs.n_sc && !p->det_m && !p->n_heavy;
     const bool camg = cs ? (p->nct == 6 ? build_cs_camg<6>(p) : build_cs_camg<9>(p)) : (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p));
-    o->build_camg = (camg ? 1 : 0) | (p->tab_global ? 2 : 0) | (cs ? 4 : 0);
+    const bool uglob = cs && (p->nct == 6 ? build_cs_uglob<6>(p) : build_cs_uglob<9>(p));
+    o->build_camg = (camg ? 1 : 0) | (p->tab_global ? 2 : 0) | (cs ? 4 : 0) | (uglob ? 8 : 0);
   }
   return CBA_OK;
 }
@@ -1236,7 +1251,11 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
         hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds, p->stream, p->cs, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
                            V, g, p->partial, p->partial1, p->flags + flag_slot, skip);
       };
-      if (build_cs_camg<NC>(p)) launch_cs(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)); else launch_cs(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
+      if (build_cs_uglob<NC>(p)) {
+        (void)hipMemsetAsync(p->partial, 0, (size_t)p->C * UPack<NC>::STRIDE * sizeof(double), p->stream);  // the ONE copy the atomics add to
+        launch_cs(k_build_cs<NC, true, true>, lds_build_cs<NC>(p, true, true));
+      } else if (build_cs_camg<NC>(p)) launch_cs(k_build_cs<NC, true>, lds_build_cs<NC>(p, true));
+      else launch_cs(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
     } else
     switch (p->det_m) {  // deterministic: fixed-order camera sums (k_build<NC, tasks per thread>)
       case 3: launch_build(k_build<NC, 3>); break;
@@ -1250,12 +1269,14 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
   {
     ScopedTimer t(p, T_BUILD_REDUCE);
     const int w = p->C * UPack<NC>::STRIDE;
+    // rows of per-workgroup partial blocks to sum; the global-atomics form of k_build_cs leaves ONE row
+    const int u_rows = (p->cs.n_sc && !p->det_m && !p->n_heavy && build_cs_uglob<NC>(p)) ? 1 : p->grid;
     if (compact) {  // single-rank fused step: gradient entries written by the row reduction, rho sum by k_publish
-      hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, Upacked, g,
+      hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, u_rows, w, Upacked, g,
                          (const int*)p->cam_off, (const int*)p->cam_np, (int)UPack<NC>::STRIDE, (int)UPack<NC>::TRI);
       return CBA_OK;
     }
-    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, p->grid, w, Upacked,
+    hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, u_rows, w, Upacked,
                        (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
     int rho_rows = p->grid;
     if (p->con.n_con) {  // constraint rows: f, u, their share of g_p and of the squared column norms
@@ -1459,7 +1480,7 @@ static int maybe_swap_plan(cba_problem* p) {
     const auto t0 = std::chrono::steady_clock::now();
     rc = install_reg2_plan(p, task->plan, task->prm);
     if (!rc) {
-      const size_t need = (size_t)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems;
+      const size_t need = (size_t)p->tile_grid * std::max(p->tp.rows_per_wg, 1) * p->tp.tile_elems;
       if (need > p->partial_capacity) {  // (the dealt plan has a few chunks more or fewer than the cheap one; small problems get a workgroup per chunk)
         rc = dev_alloc(p, &p->partial, need);
         if (!rc) p->partial_capacity = need;
@@ -1480,18 +1501,24 @@ template <int NC>
 static int run_pairs_clocked(cba_problem* p) {
   if constexpr (NC != 6) return fail(CBA_ERR_UNSUPPORTED, "CBA_SCHUR_CLOCK: six-parameter cameras only");
   else {
-    const int nw = Reg3Cfg<6>::NWAVES;
+    const int nw = Reg3Cfg<6>::NWAVES * (p->schur_pp == 2 ? 2 : 1);  // waves per logical workgroup
     const size_t n = (size_t)p->tile_grid * nw * 8;
     long long* d = nullptr;
     if (hipMalloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
     (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
     if (p->schur_pp) {
-      using PP = Reg3Cfg<6, 2>;
-      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 2>, PP::LDS_BYTES)) return CBA_ERR_HIP;
-      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+      using PP = Reg3Cfg<6, 2, 2>;
+      using P1 = Reg3Cfg<6, 2, 1>;
+      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 4, 2, 2>, PP::LDS_BYTES) || raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 2, 1>, P1::LDS_BYTES)) return CBA_ERR_HIP;
+      if (p->schur_pp == 1)
+        hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 2, 1>), dim3(p->tile_grid / 2), dim3(P1::LAUNCH_THREADS), P1::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+      else
+      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 4, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
     } else {
-      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 1>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
-      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+      const char* e = std::getenv("CBA_SCHUR_ILV");
+      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 1>, Reg3Cfg<6>::LDS_BYTES) || raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 1, 1, true>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
+      if (e && e[0] == '1') hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 1, 1, true>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+      else hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
     }
     std::vector<long long> h(n);
     (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
@@ -1563,11 +1590,17 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
 #endif
       if (p->schur_pp) {
         if constexpr (NC == 6) {
-          using PP = Reg3Cfg<6, 2>;
-          hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
+          using PP = Reg3Cfg<6, 2, 2>;
+          using P1 = Reg3Cfg<6, 2, 1>;
+          if (p->schur_pp == 1)
+            hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, 2, 1>), dim3(p->tile_grid / 2), dim3(P1::LAUNCH_THREADS), P1::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
+          else
+          hipLaunchKernelGGL((k_schur_reg3<6, 1, 4, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
         }
       } else {
-        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
+        static const bool ilv = [] { const char* e = std::getenv("CBA_SCHUR_ILV"); return e && e[0] == '1'; }();  // (A/B measurements)
+        if (ilv) hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, 1, 1, true>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
+        else hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
       }
     }
   }

@@ -77,6 +77,61 @@ def _case(name):
     return sc, par, x0, loss, fs
 
 
+def test_thousand_cameras_evaluation_and_step():
+    """The reference loops over any number of cameras (core/reprojection.py:75-119); rounds 1-3 stopped where the packed per-camera normal blocks
+    (27 doubles each) no longer fit the LDS (~650 six-parameter cameras).  Beyond that the linearisation adds a thread's register sums to ONE global
+    copy of the blocks by FP64 global atomics (k_build_cs<.., UGLOB>), every per-observation kernel reads the camera table through the vector cache,
+    the pair plan has 63 camera groups = 2016 tiles and the reduced system is 6000 x 6000.  Residuals, blocks, gradient and the damped step against the
+    oracle's SPARSE Jacobian (dense references of 15000 unknowns would take minutes): U_c block by block, V_p, g; the reduced system entry by entry
+    and the step against a Schur solve done in scipy.sparse + LAPACK."""
+    import scipy.sparse as sp
+
+    from caliscope_amd.hip_engine import HipEngine
+    from oracle.residuals import joint_jacobian, joint_residuals
+
+    sc, par, x0 = small_problem(n_cams=1000, n_points=3000, k=8)
+    cam, uv, obj = sc.camera_indices, sc.image_coords, sc.obj_indices
+    hip = HipEngine(BAProblem(par, cam, uv, obj))
+    assert hip.info()["build_camg"] & 8 and hip.info()["build_camg"] & 2 and hip.info()["schur_groups"] == 63
+    r_ref = joint_residuals(x0, par, cam, uv, obj)
+    r, cost = hip.residuals(x0)
+    assert _rel(r, r_ref) < 1e-12 and abs(cost - 0.5 * float(r_ref @ r_ref)) <= 1e-13 * cost
+    J = joint_jacobian(x0, par, cam, uv, obj).tocsr()
+    H = (J.T @ J).tocsr()
+    g = np.asarray(J.T @ r_ref).ravel()
+    U, V, gc, gp = hip.normal_blocks(x0)
+    ncp, P = par.n_camera_params, par.n_points
+    hscale = abs(H).max()
+    Hcc = H[:ncp, :ncp].tocsr()
+    for c in (0, 1, 17, 499, 998, 999):  # (block by block: a dense copy of the camera part is 288 MB)
+        ref = Hcc[6 * c:6 * c + 6, 6 * c:6 * c + 6].toarray()
+        assert np.abs(U[c, :6, :6] - ref).max() < 1e-11 * hscale, c
+    diag = H.diagonal()
+    assert np.abs(np.stack([U[c, k, k] for c in range(1000) for k in range(6)]) - diag[:ncp]).max() < 1e-11 * hscale
+    assert np.abs(V[:, [0, 3, 5]].reshape(-1) - diag[ncp:]).max() < 1e-11 * hscale
+    assert _rel(gc, g[:ncp]) < 1e-11 and np.abs(gp.reshape(-1) - g[ncp:]).max() < 1e-11 * np.abs(g).max()
+    hip.begin(x0)
+    hip.linearize()
+    lam = 1e-3
+    assert hip.newton_step(lam).ok
+    s_h = hip.get_vector(3)
+    # reference: the damped system (JtJ + lam D^2) s = -g (first linearisation: D^2 = the squared column norms = diag(JtJ)) with the points eliminated
+    # block by block in scipy.sparse and the 6000 x 6000 camera system solved densely by LAPACK (a sparse LU of the full system fills in: 10 minutes)
+    Hd = (H + lam * sp.diags(diag)).tocsr()
+    Hcp, Bpp = Hd[:ncp, ncp:].tocsr(), Hd[ncp:, ncp:].tobsr(blocksize=(3, 3))
+    assert Bpp.data.shape[0] == P and np.all(Bpp.indices == np.arange(P))
+    Binv = sp.bsr_matrix((np.linalg.inv(Bpp.data), Bpp.indices, Bpp.indptr), shape=(3 * P, 3 * P))
+    W = (Hcp @ Binv).tocsr()
+    S_ref = (Hd[:ncp, :ncp] - W @ Hcp.T).toarray()
+    dc = np.linalg.solve(S_ref, -g[:ncp] + W @ g[ncp:])
+    s_ref = np.concatenate([dc, -(Binv @ (g[ncp:] + Hcp.T @ dc))])
+    assert np.abs(Hd @ s_ref + g).max() < 1e-12 * np.abs(g).max()  # (the reference solves its own system)
+    assert np.abs(s_h - s_ref).max() < 1e-8 * np.abs(s_ref).max()
+    S, rhs = hip.reduced_system()
+    assert np.abs(S - S_ref).max() < 1e-9 * np.abs(S_ref).max()
+    hip.close()
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_evaluation_parity(name):
     _check_evaluation(name)
@@ -228,7 +283,9 @@ def _check_step(name, expect_camg=None):
         assert sh.ok and so.ok
         s_h = hip.get_vector(3)
         if loss == "linear":
-            assert np.abs(s_h - ora.s).max() < 1e-8 * np.abs(ora.s).max(), lam
+            # lam = 1e-7 leaves the gauge directions of the damped system almost singular: the last bits of the FP64 atomics' summation order (it
+            # changes from run to run) are amplified by ~1e8 there — measured between two runs of ONE kernel: up to 1.1e-8.  1e-8 at lam = 1e-3.
+            assert np.abs(s_h - ora.s).max() < (1e-8 if lam >= 1e-4 else 2e-8) * np.abs(ora.s).max(), lam
         else:  # leave out the parameters whose columns live at the sqrt(EPS) floor (see note above)
             ok = ora.scale_inv > 1e-4 * np.median(ora.scale_inv)
             assert ok.mean() > 0.9

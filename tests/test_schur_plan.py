@@ -45,28 +45,20 @@ def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_ch
     P = len(hps) - 1
     G = -(-n_cams // gmax)
     g = -(-n_cams // G)
-    threads = 1024 if layout == "wide" else 256
+    threads = 256
     rep = threads // (g * g) if (nc == 6 and g * g <= threads // 2) else 1
     rec = T.shape[1]
     # LDS layout of k_schur_reg3 (Reg3Cfg): 320 slots, 4 waves x 80, 7 pieces apart in runs of 576 (nc = 6); 384 slots, 12 x 32, 11
-    # apart in runs of 384 (nc = 9).  `layout` = "reg2": k_schur_reg2's 512 = 4 x 128 slots, unpadded runs.
-    if layout == "reg2":
-        epw, lst, wp, cap = (128, 7, 896, 512) if nc == 6 else (32, 11, 352, 384)
-    elif layout == "reg3_192":  # the experiment builds of k_schur_reg3<6> (CBA_SCHUNK6=192: three chunk buffers / producer wave): 4 waves x 48 slots, runs of 384 pieces
-        assert nc == 6
-        epw, lst, wp, cap = 48, 7, 384, 192
-    elif layout == "wide":  # Reg3Cfg<6, true>: 1024 blocks (16 code waves), 512 slots = 8 loading waves x 64, runs of 448 pieces
-        assert nc == 6
-        epw, lst, wp, cap = 64, 7, 448, 512
-    else:
-        epw, lst, wp, cap = (80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384)
+    # apart in runs of 384 (nc = 9)
+    assert layout == "reg3"
+    epw, lst, wp, cap = (80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384)
     if chunk_cap is None:
         chunk_cap = cap
     nT = G * (G + 1) // 2
     acc = np.zeros((nT, threads, nc * nc))
     stats = np.zeros(9, dtype=np.int64)
     if pair_cap is None:  # Reg3Cfg::PAIR_CAP
-        pair_cap = 2 if layout == "wide" else 0
+        pair_cap = 0
     rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, threads // 64, pair_cap, int(cheap), hcam.ctypes.data_as(I32P),
                          hps.ctypes.data_as(I32P), T.ctypes.data_as(F64P), acc.ctypes.data_as(F64P), stats.ctypes.data_as(I64P))
     assert rc == 0, rc
@@ -140,29 +132,6 @@ def test_pairs_reach_their_blocks_random_visibility(harness):
     _check(harness, rng, 8, 300, 2, 8, 6)             # one small group: rep = 4 threads per block
     _check(harness, rng, 20, 400, 1, 6, 6)            # ragged: two groups of 10, single-view points, rep = 2
     _check(harness, rng, 40, 500, 3, 9, 9)            # nine-parameter cameras
-    _check(harness, rng, 64, 600, 2, 10, 6, layout="reg2")
-    _check(harness, rng, 24, 300, 3, 9, 9, layout="reg2")
-
-
-def test_wide_tiles_of_the_1024_thread_kernel(harness):
-    """32 x 32 camera tiles, 16 waves (k_schur_reg3<6, ..., WIDE>): the same plan code with n_waves = 16."""
-    rng = np.random.default_rng(11)
-    _check(harness, rng, 64, 900, 2, 10, 6, gmax=32, layout="wide")     # two groups of 32: three tiles
-    _check(harness, rng, 32, 500, 2, 9, 6, gmax=32, layout="wide")      # one diagonal tile, 496 real blocks + 528 helpers
-    _check(harness, rng, 20, 400, 1, 6, 6, gmax=32, layout="wide")      # one group of 20: rep = 2 threads per block
-    _check(harness, rng, 100, 800, 3, 12, 6, gmax=32, layout="wide", duplicates=0.1, unobserved=0.05)  # four groups of 25
-    stats = _check(harness, rng, 64, 10000, 10, 10, 6, gmax=32, layout="wide")
-    print("wide: lane utilisation", stats[1] / stats[2], "LDS cycles per group", stats[6] / stats[5], "chunks", stats[0], "stream", stats[4])
-    assert stats[1] == 10000 * 55 and stats[1] / stats[2] > 0.42   # ~1 pair per block and chunk: the cap of 2 leaves half of the lane-iterations idle
-
-
-def test_192_slot_chunks_of_the_experiment_builds(harness):
-    """CBA_SCHUNK6=192 (csrc/cba_kernels.h): a wave stages 48 slots in a run padded to six load instructions."""
-    rng = np.random.default_rng(12)
-    _check(harness, rng, 64, 900, 2, 10, 6, layout="reg3_192")
-    _check(harness, rng, 20, 400, 1, 6, 6, layout="reg3_192", duplicates=0.1, unobserved=0.05)
-    stats = _check(harness, rng, 64, 6000, 10, 10, 6, layout="reg3_192", region_chunks=256)
-    assert stats[1] == 6000 * 55 and stats[1] / stats[2] > 0.6   # lane utilisation (0.75 with 320-slot chunks)
 
 
 def test_duplicate_rows_and_unobserved_points(harness):
@@ -186,7 +155,6 @@ def test_cheap_plan_sums_the_same_pairs(harness):
     _check(harness, rng, 20, 400, 1, 6, 6, cheap=True, duplicates=0.2, unobserved=0.1)
     _check(harness, rng, 40, 500, 3, 9, 9, cheap=True)
     _check(harness, rng, 48, 700, 2, 12, 6, chunk_cap=64, region_chunks=4, cheap=True)
-    _check(harness, rng, 64, 900, 2, 10, 6, gmax=32, layout="wide", cheap=True)  # (more than two pairs of a block per chunk: the kernel's in-loop code loads)
     stats = _check(harness, rng, 64, 10000, 10, 10, 6, cheap=True)
     assert stats[1] == 10000 * 55 and 0.3 < stats[1] / stats[2] < 0.68, stats[1] / stats[2]
 
@@ -223,7 +191,7 @@ def test_lane_utilisation_at_the_bench_shape(harness):
 
 @pytest.mark.parametrize("shape", [dict(n_cams=64, n_points=20000, k=10, max_blocks=512), dict(n_cams=64, n_points=20000, k=10, max_blocks=512, cost_a=-1.0),
                                    dict(n_cams=40, n_points=3000, k=8, max_blocks=512), dict(n_cams=128, n_points=6000, k=10, max_blocks=256, nc=9),
-                                   dict(n_cams=8, n_points=400, k=6, max_blocks=512), dict(n_cams=64, n_points=20000, k=10, max_blocks=512, layout="wide")])
+                                   dict(n_cams=8, n_points=400, k=6, max_blocks=512)])
 def test_workgroup_binding_covers_every_chunk_once(harness, shape):
     """csrc/wg_binding.h: the persistent workgroups of the pair kernel walk (first, first + stride, ... < end); every chunk of every tile must be
     walked by exactly one workgroup of that tile, and the workgroups are handed out in proportion to the tiles' estimated cost."""
@@ -231,18 +199,18 @@ def test_workgroup_binding_covers_every_chunk_once(harness, shape):
     nc, layout, cost_a, max_blocks = cfg.pop("nc", 6), cfg.pop("layout", "reg3"), cfg.pop("cost_a", 2.0), cfg.pop("max_blocks")
     rng = np.random.default_rng(12)
     hcam, hps = _visibility(rng, cfg["n_cams"], cfg["n_points"], cfg["k"], cfg["k"])
-    gmax = 32 if layout == "wide" else 16
+    gmax = 16
     G = -(-cfg["n_cams"] // gmax)
     g = -(-cfg["n_cams"] // G)
-    threads = 1024 if layout == "wide" else 256
+    threads = 256
     rep = threads // (g * g) if (nc == 6 and g * g <= threads // 2) else 1
-    epw, lst, wp, cap = (64, 7, 448, 512) if layout == "wide" else ((80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384))
-    n_waves, phys = (16, 8) if layout == "wide" else (4, 4)
+    epw, lst, wp, cap = (80, 7, 576, 320) if nc == 6 else (32, 11, 384, 384)
+    n_waves, phys = 4, 4
     nT = G * (G + 1) // 2
     cap_wg = max_blocks + nT
     wt, wf, we, ws = (np.zeros(cap_wg, dtype=np.int32) for _ in range(4))
     tcb, cost, xcd = np.zeros(nT + 1, dtype=np.int32), np.zeros(nT), np.zeros(1, dtype=np.int32)
-    grid = harness.bind_replay(cfg["n_cams"], len(hps) - 1, G, g, rep, cap, epw, lst, wp, 32, n_waves, 2 if layout == "wide" else 0, phys, cost_a, max_blocks, 1,
+    grid = harness.bind_replay(cfg["n_cams"], len(hps) - 1, G, g, rep, cap, epw, lst, wp, 32, n_waves, 0, phys, cost_a, max_blocks, 1,
                                hcam.ctypes.data_as(I32P), hps.ctypes.data_as(I32P), *(a.ctypes.data_as(I32P) for a in (wt, wf, we, ws, tcb)),
                                cost.ctypes.data_as(F64P), xcd.ctypes.data_as(I32P))
     assert 0 < grid <= cap_wg
