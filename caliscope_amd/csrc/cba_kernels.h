@@ -751,7 +751,6 @@ struct TilePlan {
   int tile_elems;                // width of one workgroup's partial row: 256 blocks of nc^2
   const int* obs;                // chunk slot -> observation (index into the T records)
   int rep;                       // threads per camera-pair block (256 / g^2 when the group is small), each takes every rep-th pair
-  int rows_per_wg;               // partial rows a (logical) workgroup writes: rep, times two in the two-set form (two waves share a wave's pair codes)
   const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_addr | j_addr << 16), LDS addresses in 16-byte pieces
   const int* code_start;         // [n_tile_chunks + 1] offsets into `codes`
   const unsigned* nit;           // [n_tile_chunks] iterations of waves 0..3, one byte each
@@ -1007,27 +1006,15 @@ __device__ __forceinline__ void pair_rows(double (*acc)[NC], const double* Rm, c
 //     addresses) into the buffer that is NOT being read (two buffers), so a trip is: wait for the loads issued a trip ago, one barrier, issue
 //     the next chunk's loads, multiply.  No staging registers.
 //
-// SETS = 2, PW = 2 (round 4, six-parameter cameras): the anti-phase form.  Phase clocks of the one-set kernel on cfg4 (two 4-wave workgroups per
-// CU), per trip and workgroup: issuing 1450 clocks, pair arithmetic 1900, barrier 680.  The pair phase is FP64 issue: 99 instructions of 4
-// clocks per pair iteration, ~830 clocks per iteration with TWO waves per SIMD multiplying — the pipe is full — while ONE wave alone on its
-// SIMD needs ~900 for the same iteration (measured with two 4-wave sets forced into anti-phase: no faster).  The issue phase is the CU's address
-// path: a 64-lane gather every ~26 clocks, 35 per chunk, whoever issues them.  The two phases use different units and never overlapped: the
-// CU's two workgroups drift into the same phase.  Here ONE 16-wave workgroup holds two SETS (own chunk sequence, own pair of LDS buffers — the
-// two workgroups of before), each made of PW = 2 waves per pair-code wave: the first four waves of a set gather, all eight multiply, wave
-// parity q taking the pair iterations it = q, q + 2, ... of its code wave into its own accumulators (one more partial row).  A bare s_barrier
-// of the WHOLE workgroup separates a set's issue phase from its pair phase and set 1 runs half a period behind set 0: while one set's eight
-// waves fill the FP64 pipes, the other set's four loaders keep the address path busy.
-template <int NC, int SETS = 1, int PW = 1> struct Reg3Cfg {
-  static_assert((SETS == 1 && PW == 1) || (SETS == 2 && (PW == 1 || PW == 2)), "one set, or two in anti-phase");
+template <int NC> struct Reg3Cfg {
   static constexpr int REC = SchurRec<NC>::REC, LST = SchurRec<NC>::LST;
   static constexpr int SPLIT = (NC == 9) ? 3 : 1;
   static constexpr int CODE_THREADS = BLOCK, CODE_WAVES = BLOCK / WAVE;             // blocks of a tile = pair-code streams
-  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;        // loading threads / waves of one set
-  static constexpr int SET_THREADS = REG_BLOCK * PW;                                // threads of one set
+  static constexpr int REG_BLOCK = BLOCK * SPLIT, NWAVES = REG_BLOCK / WAVE;        // threads / waves of a workgroup
   static constexpr int GROUP = 16;                                                  // cameras per group: GROUP^2 blocks <= CODE_THREADS
   // pair codes per block and chunk that travel in registers (a code beyond them is loaded inside the pair loop: a vmcnt(0) behind the record loads
   // in flight)
-  static constexpr int NCD = ((NC == 6 && SETS == 1) ? 8 : 4) / (SETS == 2 && PW == 2 ? 2 : 1);  // (two sets: the register file is full at four)
+  static constexpr int NCD = (NC == 6) ? 8 : 4;
   static constexpr int PAIR_CAP = 0;
   static constexpr int SCHUNK = (NC == 9) ? 384 : 320;                              // slots per chunk (per LDS buffer)
   static constexpr int EPW = SCHUNK / NWAVES;                                       // slots loaded by one wave (80 / 32)
@@ -1035,53 +1022,81 @@ template <int NC, int SETS = 1, int PW = 1> struct Reg3Cfg {
   static constexpr int WAVE_PIECES = NLD * WAVE;                                    // LDS pieces of one wave's run, padded to whole loads
   static constexpr int ZERO_PIECE = NWAVES * WAVE_PIECES;                           // all-zero record behind the chunk, in each buffer
   static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                           // (+1: keeps the second buffer 32-byte aligned)
-  static constexpr int NBUF = 2;                                                    // chunk buffers of a set: a gather is issued one trip before it is read
+  static constexpr int NBUF = 2;                                                    // chunk buffers: a gather is issued one trip before it is read
   static constexpr int SET_PIECES = NBUF * BUF_PIECES;
-  static constexpr size_t LDS_BYTES = (size_t)SETS * SET_PIECES * 16;
-  static constexpr int LAUNCH_THREADS = SETS * SET_THREADS;
+  static constexpr size_t LDS_BYTES = (size_t)SET_PIECES * 16;
+  static constexpr int LAUNCH_THREADS = REG_BLOCK;
   static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
   static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
   static_assert(CODE_WAVES % 4 == 0, "iteration counts: four waves per word");
-  static_assert(LDS_BYTES <= 160 * 1024 && LAUNCH_THREADS <= 1024, "one workgroup");
 };
+
+// primed pair product of six-parameter cameras, T'_i T'_j^T added to the thread's 6 x 6 accumulators: 99 FP64 instructions on 12 + 12 doubles
+__device__ __forceinline__ void pair6(double (&acc)[6][6], const double2* __restrict__ Ri, const double2* __restrict__ Rj) {
+  const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
+  const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
+  const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
+  const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
+  const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
+  double M[3][6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2)
+      M[a][3 + b2] = fma(Qi[3 * a + 2], Qj[3 * b2 + 2], fma(Qi[3 * a + 1], Qj[3 * b2 + 1], Qi[3 * a] * Qj[3 * b2]));
+    M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
+    M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
+    M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    acc[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], acc[0][c]));
+    acc[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], acc[1][c]));
+    acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
+    acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
+  }
+}
+
+// applies P_i^T (.) P_j, P = blockdiag(J_l, I), to the rows r0 .. r0 + RH - 1 a thread holds of a primed block (epilogue of the pair kernels)
+template <int NC, int RH>
+__device__ __forceinline__ void unprime_rows(double (&acc)[RH][NC], int r0, const double* __restrict__ Ji, const double* __restrict__ Jj) {
+  if (r0 == 0) {  // rows 0..2 <- J_i^T rows 0..2 (all columns)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double b0 = acc[0][c], b1 = acc[1][c], b2 = acc[2][c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) acc[r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {  // columns 0..2 <- (.) J_j, every row the thread owns
+    const double a0 = acc[r][0], a1 = acc[r][1], a2 = acc[r][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
+  }
+}
 
 // The body is a function of its own with `Trec` as a __restrict__ PARAMETER: inlined into the kernel, every access in it carries
 // alias-scope metadata, and only with that does the compiler's wait-count insertion let a ds_read pass a pending LDS-DMA load (with
 // the body written directly in the kernel it put a vmcnt(0) in front of the first record read of every trip: the wave sat out the
 // gather it had just issued).
 // CLK (profiling build, -DCBA_PROFILING + CBA_SCHUR_CLOCK=1): per wave the shader clocks spent waiting for loads, in barriers, issuing, multiplying.
-// ILV: the gather of the next chunk is not issued in one burst before the pair loop but a few loads at a time BETWEEN the pair iterations: the CU's
-// address path takes a 64-lane gather every ~26 clocks, a burst of 4 x 9 of them (two workgroups: 8 x 9) queues the waves up at issue while the
-// FP64 pipes idle, and then the pipes work while the address path idles — interleaved, both are busy at once.
-template <int NC, int SPLIT, int SETS, int PW, bool CLK = false, bool ILV = false>
+template <int NC, int SPLIT, bool CLK = false>
 __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
                                                 const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
                                                 const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk = nullptr,
                                                 const double* __restrict__ tab = nullptr) {
-  using Cfg = Reg3Cfg<NC, SETS, PW>;
+  using Cfg = Reg3Cfg<NC>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
-  constexpr int SET_THREADS = Cfg::SET_THREADS;
   constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW, NWORD = Cfg::CODE_WAVES / 4;
   constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
   constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
 
   const int nblk = tp.g * tp.g;
   const int rep = (SPLIT == 1) ? tp.rep : 1;
-  const int set = (SETS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / SET_THREADS);
-  const int tid_set = (int)threadIdx.x % SET_THREADS;  // thread of the set
-  const int par = (PW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid_set / REG_BLOCK);  // which of the PW waves sharing a code wave's iterations
-  const int tid = tid_set % REG_BLOCK;  // its role among the set's blocks (and, par == 0, among its loaders)
-  const bool loader = par == 0;
-  // the id this set works under (index into wg_first / ... and of its partial row).  One set: csrc/wg_binding.h, interleaved over the dispatch
-  // order.  Two sets: physical workgroup B (XCD B mod 8) runs the logical workgroups 16 (B / 8) + B mod 8 and that + 8 — both ids keep
-  // B mod 8, which is what the XCD-aware binding (bind_workgroups) goes by
-  const int n_logical = (int)gridDim.x * SETS;
-  auto logical_of = [&](int s) {
-    if (SETS == 1) return logical_workgroup((int)blockIdx.x, (int)gridDim.x);
-    return ((n_logical & 15) == 0) ? (((int)blockIdx.x >> 3) << 4) + ((int)blockIdx.x & 7) + 8 * s : (int)blockIdx.x * SETS + s;
-  };
-  const int wg = logical_of(set);
-  double2* sh_p = reinterpret_cast<double2*>(sh) + set * Cfg::SET_PIECES;  // this set's two chunk buffers, in 16-byte pieces
+  const int tid = (int)threadIdx.x;
+  const int wg = logical_workgroup((int)blockIdx.x, (int)gridDim.x);  // csrc/wg_binding.h: interleaved over the dispatch order
+  double2* sh_p = reinterpret_cast<double2*>(sh);  // two chunk buffers, in 16-byte pieces
   const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
   const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
   const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave of the set
@@ -1097,18 +1112,15 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int vt = (SPLIT == 1) ? tid : ct;
   const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
   const bool owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
-  double* dst = partial + (((long)wg * PW + par) * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
+  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
 
-  // chunk range of this set; a workgroup's sets run the same number of trips (the barriers are the workgroup's), a set that is out of
-  // chunks idles through the rest: it gathers its last chunk again and multiplies nothing
-  auto trips_of = [&](int w) { const int f = tp.wg_first[w], e = tp.wg_end[w], s = tp.wg_stride[w]; return f < e ? (e - 1 - f) / s + 1 : 0; };
+  // chunk range of this workgroup (one without chunks — more workgroups than chunks in the range — gathers somebody's valid chunk and multiplies nothing)
   const int stride = tp.wg_stride[wg], ch_end = tp.wg_end[wg];
-  const int own_trips = trips_of(wg);
-  const int first = own_trips ? tp.wg_first[wg] : max(ch_end - 1, 0);  // (no chunk of its own: somebody's valid chunk, never multiplied)
-  int trips = own_trips;
-  if (SETS == 2) trips = max(trips, trips_of(logical_of(set ^ 1)));
-  for (int k = tid_set; k < Cfg::NBUF * LST; k += SET_THREADS) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
-  const int last = first + (own_trips ? (own_trips - 1) * stride : 0);  // last chunk of this set
+  const int own_trips = tp.wg_first[wg] < ch_end ? (ch_end - 1 - tp.wg_first[wg]) / stride + 1 : 0;
+  const int first = own_trips ? tp.wg_first[wg] : max(ch_end - 1, 0);
+  const int trips = max(own_trips, 1);
+  for (int k = tid; k < Cfg::NBUF * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
+  const int last = first + (own_trips ? (own_trips - 1) * stride : 0);  // last chunk of this workgroup
   // Per trip every wave issues, in this order and WITHOUT waiting in between: the codes of the next chunk and the record indices
   // of the chunk after next (their addresses come from the iteration counts / offsets loaded a trip earlier), the counts and
   // offsets of the chunks behind those, the records of the next chunk; then it multiplies the current chunk while all of that
@@ -1146,14 +1158,16 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     n_nx = __builtin_amdgcn_readfirstlane(mine);
     code_nx = (long)r.code_start + (long)pre * WAVE + lane;
 #pragma unroll
-    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + (long)(k * PW + par) * WAVE];  // iterations par, par + PW, ..; past the wave's last one: somebody else's codes, never used
+    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
   };
   // load k of this wave fills LDS pieces [k * 64, k * 64 + 64) of the wave's run: piece (k * 64 + lane) % LST of slot
   // (k * 64 + lane) / LST; the record index of the slot comes from the wave's index registers (ds_bpermute)
-  // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
-  // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
-  auto prepare = [&](int idxA, int idxB, const double2* (&g)[NLD]) {
+  auto issue = [&](int buf, int idxA, int idxB) {
     constexpr int Q = WAVE / LST, RM = WAVE % LST;
+    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
+    // all index exchanges first, then the loads: written load by load the sequence was bpermute - wait - load, NLD LDS round trips in
+    // a row under the pair loops' LDS traffic (phase clocks: 40 % of a wave's time went into issuing)
+    const double2* g[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       int piece = k * RM + lane % LST;
@@ -1165,58 +1179,15 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
       g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-  };
-  auto fire = [&](int buf, const double2* (&g)[NLD], int k0, int k1) {  // loads k0 .. k1 - 1 of the wave's NLD
-    double2* wbase = sh_p + buf * Cfg::BUF_PIECES + sw * Cfg::WAVE_PIECES;
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
-      if (k >= k0 && k < k1)
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
-  };
-  auto issue = [&](int buf, int idxA, int idxB) {
-    const double2* g[NLD];
-    prepare(idxA, idxB, g);
-    fire(buf, g, 0, NLD);
-  };
-  // the two records of a pair (NC = 6): six 16-byte pieces each
-  struct Rec6 { double2 i[6], j[6]; };
-  auto load6 = [&](const double2* bufp, unsigned code, Rec6& R) {
-    const double2* Ri = bufp + (code & 0xffffu);
-    const double2* Rj = bufp + (code >> 16);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { R.i[q] = Ri[q]; R.j[q] = Rj[q]; }
-  };
-  auto math6 = [&](const Rec6& R) {
-      const double2 i0 = R.i[0], i1 = R.i[1], i2 = R.i[2], i3 = R.i[3], i4 = R.i[4], i5 = R.i[5];
-      const double2 j0 = R.j[0], j1 = R.j[1], j2 = R.j[2], j3 = R.j[3], j4 = R.j[4], j5 = R.j[5];
-      const double Yi[3] = {i0.x, i0.y, i1.x}, Yj[3] = {j0.x, j0.y, j1.x};
-      const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
-      const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
-      double M[3][NC];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2)
-          M[a][3 + b2] = fma(Qi[3 * a + 2], Qj[3 * b2 + 2], fma(Qi[3 * a + 1], Qj[3 * b2 + 1], Qi[3 * a] * Qj[3 * b2]));
-        M[a][0] = fma(Yj[1], M[a][5], -(Yj[2] * M[a][4]));
-        M[a][1] = fma(Yj[2], M[a][3], -(Yj[0] * M[a][5]));
-        M[a][2] = fma(Yj[0], M[a][4], -(Yj[1] * M[a][3]));
-      }
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        acc[0][c] = fma(Yi[1], M[2][c], fma(-Yi[2], M[1][c], acc[0][c]));
-        acc[1][c] = fma(Yi[2], M[0][c], fma(-Yi[0], M[2][c], acc[1][c]));
-        acc[2][c] = fma(Yi[0], M[1][c], fma(-Yi[1], M[0][c], acc[2][c]));
-        acc[3][c] += M[0][c]; acc[4][c] += M[1][c]; acc[5][c] += M[2][c];
-      }
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g[k], (void __attribute__((address_space(3)))*)(wbase + k * WAVE), 16, 0, 0);
   };
   auto pair = [&](const double2* bufp, unsigned code) {
     const double2* Ri = bufp + (code & 0xffffu);
     const double2* Rj = bufp + (code >> 16);
     if constexpr (NC == 6) {
-      Rec6 R;
-      load6(bufp, code, R);
-      math6(R);
+      pair6(acc, Ri, Rj);
     } else {
       double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
       if (half == 2) {  // rows of T_intr,i
@@ -1237,24 +1208,17 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   int idxA = 0, idxB = 0;
   const int second = min(first + stride, last);
   Raw raw = load_raw(first, second);
-  if (loader) {
-    load_indices(p_chunk_start[first], &idxA, &idxB);
-    issue(0, idxA, idxB);
-  }
+  load_indices(p_chunk_start[first], &idxA, &idxB);
+  issue(0, idxA, idxB);
   load_codes(raw);                           // the first chunk's codes
-  if (loader) load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
+  load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
   raw = load_raw(second, min(second + stride, last));
   int buf = 0;
-  // Phase barriers of the two-set form are BARE s_barrier instructions (inline asm): they align the sets' phases and order nothing — the data
-  // hazards are covered by the wait + __syncthreads at the top of every trip.  __syncthreads() here would bring its workgroup-scope fence, for
-  // which the compiler drains vmcnt: the set would sit out the gather it has just issued.
-  auto phase_barrier = [] { asm volatile("s_barrier" ::: "memory"); };
-  if (SETS == 2 && set == 1) phase_barrier();  // half a period behind set 0: its issue phase falls into set 0's pair phase and vice versa
   for (int trip = 0; trip < trips; ++trip) {
     const int cur = min(first + trip * stride, last);
     // everything issued a trip ago has landed (the records of `cur` in `buf`, its codes, the counts and indices of the next
     // chunk), and every wave is done reading the other buffer
-    long long tA = 0, tB = 0, tC = 0, tD = 0, tP = 0;
+    long long tA = 0, tB = 0, tC = 0, tD = 0;
     if (CLK) tA = clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (CLK) tB = clock64();
@@ -1281,60 +1245,28 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     const int nxt2 = min(min(cur + stride, last) + stride, last);
     load_codes(raw);                        // codes of the next chunk: addresses from registers, no wait
     int idxA_n = 0, idxB_n = 0;
-    if (loader) load_indices(raw.obs_start, &idxA_n, &idxB_n);  // indices of the chunk after next
+    load_indices(raw.obs_start, &idxA_n, &idxB_n);  // indices of the chunk after next
     const Raw raw_n = load_raw(nxt2, min(nxt2 + stride, last));
-    const double2* gq[NLD];
-    if (ILV) prepare(idxA, idxB, gq);       // (ILV: one set, every wave loads)
-    else if (loader) issue(buf ^ 1, idxA, idxB); // records of the next chunk
+    issue(buf ^ 1, idxA, idxB);             // records of the next chunk
     __builtin_amdgcn_sched_barrier(0);
     if (CLK) { tD = clock64(); __builtin_amdgcn_sched_barrier(0); }
-    if (SETS == 2) phase_barrier();         // phase boundary of the whole workgroup: the other set starts issuing, this one multiplies
-    if (CLK) { tP = clock64(); __builtin_amdgcn_sched_barrier(0); }
     const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
     // (reading the records of pair it + 1 while pair it is multiplied — there would be registers for it in the NC = 6 kernel — measured
     // slower: 112k instead of 98k clocks per wave in the pair phase)
-    if constexpr (NC == 6 && SETS == 2 && PW == 1) {
-      // A set multiplies ALONE on its SIMDs (the other set is issuing): nobody hides the LDS latency of a pair's twelve reads, so the records of
-      // pair k + 1 are read while pair k is multiplied (+48 registers; with two workgroups per CU in the same phase — the one-set kernel — the
-      // other wave hides it and the prefetch measured slower, round 3).
-      static_assert(NCD % 2 == 0, "two alternating record sets");
-      Rec6 Ra, Rb;
-      load6(bufp, cc[0], Ra);
 #pragma unroll
-      for (int k = 0; k < NCD; k += 2) {
-        if (k < n_cur) { load6(bufp, cc[k + 1], Rb); math6(Ra); }  // (a code beyond the wave's last iteration holds valid addresses: read, not used)
-        if (k + 1 < n_cur) { if (k + 2 < NCD) load6(bufp, cc[k + 2], Ra); math6(Rb); }
-      }
-    } else if constexpr (ILV) {
-      static_assert(!ILV || (SETS == 1 && PW == 1), "interleaved issue: the one-set kernel");
-      constexpr int QL = (NLD + 2) / 3;  // loads in front of each of the first three pair iterations (9 -> 3 + 3 + 3, 6 -> 2 + 2 + 2)
-#pragma unroll
-      for (int k = 0; k < NCD; ++k) {
-        if (k * QL < NLD) {
-          fire(buf ^ 1, gq, k * QL, min((k + 1) * QL, NLD));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (k < n_cur) pair(bufp, cc[k]);
-        if (k * QL < NLD) __builtin_amdgcn_sched_barrier(0);
-      }
-      static_assert(NCD * ((NLD + 2) / 3) >= NLD, "every load is issued inside the unrolled part");
-    } else {
-#pragma unroll
-    for (int k = 0; k < NCD; ++k)
-      if (k * PW + par < n_cur) pair(bufp, cc[k]);
-    }
-    for (int it = NCD * PW + par; it < n_cur; it += PW) pair(bufp, p_codes[code_cur + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
+    for (int it = 0; it < NCD; ++it)
+      if (it < n_cur) pair(bufp, cc[it]);
+    for (int it = NCD; it < n_cur; ++it) pair(bufp, p_codes[code_cur + (long)it * WAVE]);  // more pairs of one block in a chunk than travel in registers
     if (CLK) {
       __builtin_amdgcn_sched_barrier(0);
       const long long tE = clock64();
-      clk_sum[0] += tB - tA; clk_sum[1] += (tC - tB) + (tP - tD); clk_sum[2] += tD - tC; clk_sum[3] += tE - tP; clk_sum[4] += 1; clk_sum[5] += n_cur;
+      clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[3] += tE - tD; clk_sum[4] += 1; clk_sum[5] += n_cur;
     }
     raw = raw_n; idxA = idxA_n; idxB = idxB_n;
     buf ^= 1;
   }
-  if (SETS == 2 && set == 0) phase_barrier();  // (set 1's extra barrier at the top)
   if (CLK && lane == 0 && clk) {
-    long long* o = clk + (((long)wg * PW + par) * Cfg::NWAVES + sw) * 8;
+    long long* o = clk + ((long)wg * Cfg::NWAVES + sw) * 8;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
     o[6] = clock64() - t_start;
@@ -1360,20 +1292,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     if (ci >= 0) {
       const double* Ji = tab + (long)ci * CAMTAB_DOUBLES + 12;  // CamTab::Jl, row-major
       const double* Jj = tab + (long)cj * CAMTAB_DOUBLES + 12;
-      if (r0 == 0) {  // rows 0..2 <- J_i^T rows 0..2 (all columns)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const double b0 = acc[0][c], b1 = acc[1][c], b2 = acc[2][c];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) acc[r][c] = Ji[r] * b0 + Ji[3 + r] * b1 + Ji[6 + r] * b2;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < RH; ++r) {  // columns 0..2 <- (.) J_j, every row the thread owns
-        const double a0 = acc[r][0], a1 = acc[r][1], a2 = acc[r][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[r][c] = a0 * Jj[c] + a1 * Jj[3 + c] + a2 * Jj[6 + c];
-      }
+      unprime_rows<NC, RH>(acc, r0, Ji, Jj);
     }
   }
   if (!owner) return;
@@ -1384,19 +1303,291 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
       if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
 }
 
-template <int NC, int SPLIT, int MINW, int SETS = 1, int PW = 1, bool ILV = false>
-__global__ void __launch_bounds__((Reg3Cfg<NC, SETS, PW>::LAUNCH_THREADS), MINW)
+template <int NC, int SPLIT, int MINW>
+__global__ void __launch_bounds__((Reg3Cfg<NC>::LAUNCH_THREADS), MINW)
 k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, SETS, PW, false, ILV>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
+  schur_reg3_body<NC, SPLIT, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
 }
 
 #ifdef CBA_PROFILING  // tools/build_profiling_lib.sh: the phase-clock build of the pair kernel is not part of the product library
-template <int NC, int SPLIT, int MINW, int SETS = 1, int PW = 1, bool ILV = false>
-__global__ void __launch_bounds__((Reg3Cfg<NC, SETS, PW>::LAUNCH_THREADS), MINW)
+template <int NC, int SPLIT, int MINW>
+__global__ void __launch_bounds__((Reg3Cfg<NC>::LAUNCH_THREADS), MINW)
 k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk, const double* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_reg3_body<NC, SPLIT, SETS, PW, true, ILV>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
+  schur_reg3_body<NC, SPLIT, true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
+}
+#endif
+
+// k_schur_lc (round 4, six-parameter cameras, launches with more than one workgroup per CU): LOADER waves and COMPUTE waves.
+//
+// What the phase clocks of k_schur_reg3 say on cfg4 (two 4-wave workgroups per CU, per trip and workgroup): issuing the gather 1600 clocks,
+// pair arithmetic 1900, barrier 650, and nothing overlaps.  The pair phase is FP64 issue at its peak: 99 instructions per pair iteration,
+// 4.1 clocks each with TWO waves of a SIMD multiplying (one wave alone gets an instruction through every ~9 clocks: measured with two 4-wave sets
+// forced into anti-phase — no faster, with the next pair's records prefetched into registers — no faster).  The issue phase is the CU's address
+// path: a 64-lane LDS-DMA gather every ~26 clocks, 36 per chunk, and a wave BLOCKS at a load the path has no room for (issuing the loads a few
+// at a time between the pair iterations moved the stall into the pair loop and saved nothing).  Both of a CU's workgroups run the same code, so
+// their waves meet at the loads together and then multiply together.  Overlap needs waves that do nothing but load next to two waves per SIMD
+// that do nothing but multiply: one 12-wave workgroup per CU,
+//     waves 0-3 and 4-7:  compute sets 0 and 1 — the two logical workgroups of before (own tile, own chunk sequence, own accumulators);
+//     waves 8-11:         loaders — wave w gathers its 80-slot share of the NEXT chunk of both sets (18 loads per trip).
+// One barrier of the whole workgroup per trip: behind it the loaders' records of this trip are in LDS and the compute sets have finished with the
+// buffers of the previous one.  Four chunk buffers (two sets x two), 148 KB.
+struct SchurLc {
+  using Cfg = Reg3Cfg<6>;
+  static constexpr int SETS = 2;
+  static constexpr int COMPUTE_THREADS = SETS * BLOCK, LOADER_WAVES = Cfg::NWAVES, THREADS = COMPUTE_THREADS + LOADER_WAVES * WAVE;  // 768
+  static constexpr size_t LDS_BYTES = (size_t)SETS * Cfg::SET_PIECES * 16;
+  static_assert(LDS_BYTES <= 160 * 1024, "four chunk buffers");
+};
+
+template <bool CLK>
+__device__ __forceinline__ void schur_lc_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
+                                              const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
+                                              const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk,
+                                              const double* __restrict__ tab) {
+  using Cfg = Reg3Cfg<6>;
+  constexpr int NC = 6, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW, NWORD = Cfg::CODE_WAVES / 4, NCD = Cfg::NCD, SETS = SchurLc::SETS;
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / BLOCK);  // 0, 1: compute set; 2: loader
+  const int tid = (int)threadIdx.x % BLOCK;
+  const int lane = tid % WAVE, wv = __builtin_amdgcn_readfirstlane(tid / WAVE);  // wave of the set / loader wave
+  // logical workgroup of set s (index into wg_first / ... and of its partial row): physical workgroup B (XCD B mod 8) runs 16 (B / 8) + B mod 8
+  // and that + 8 — both keep B mod 8, which is what the XCD-aware binding goes by (csrc/wg_binding.h)
+  const int n_logical = (int)gridDim.x * SETS;
+  auto logical_of = [&](int s) {
+    return ((n_logical & 15) == 0) ? (((int)blockIdx.x >> 3) << 4) + ((int)blockIdx.x & 7) + 8 * s : (int)blockIdx.x * SETS + s;
+  };
+  struct Range { int first, stride, trips, last; };
+  auto range_of = [&](int w) {
+    const int f = tp.wg_first[w], e = tp.wg_end[w], s = tp.wg_stride[w];
+    Range r;
+    r.stride = s;
+    r.trips = f < e ? (e - 1 - f) / s + 1 : 0;
+    r.first = r.trips ? f : max(e - 1, 0);  // (no chunk of its own: somebody's valid chunk, gathered and never multiplied)
+    r.last = r.first + (r.trips ? (r.trips - 1) * s : 0);
+    return r;
+  };
+  const Range rg[SETS] = {range_of(logical_of(0)), range_of(logical_of(1))};
+  const int trips = max(max(rg[0].trips, rg[1].trips), 1);  // the barriers are the workgroup's: both sets and the loaders run the same number of trips
+  double2* sh_all = reinterpret_cast<double2*>(sh);
+  for (int k = (int)threadIdx.x; k < SETS * Cfg::NBUF * LST; k += SchurLc::THREADS)
+    sh_all[(k / (Cfg::NBUF * LST)) * Cfg::SET_PIECES + ((k / LST) % Cfg::NBUF) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
+  long long clk_sum[6] = {0, 0, 0, 0, 0, 0};
+  const long long t_start = CLK ? clock64() : 0;
+
+  if (role == SETS) {
+    // ---------------- loader wave wv: slots [wv * EPW, (wv + 1) * EPW) of every chunk of both sets ----------------
+    // Through REGISTERS, not by LDS-DMA: a wave gets a global_load ... lds through only every ~180 clocks (measured: four loader waves needed 3400
+    // clocks for the 72 loads of a trip), a plain global_load_dwordx4 issues in a few clocks and the ds_write_b128 behind it costs ~13.  The
+    // records of trip t + 1 are written into LDS during trip t from registers that were loaded during trip t - 1.
+    auto load_indices = [&](int obs_start, int* iA, int* iB) {
+      const int* src = p_obs + obs_start + wv * EPW;
+      *iA = src[lane];
+      if (EPW > WAVE) *iB = src[WAVE + (lane & (EPW - WAVE - 1))];
+    };
+    auto fetch = [&](int idxA, int idxB, double2 (&R)[NLD]) {  // this wave's share of a chunk: NLD loads of 64 pieces
+      constexpr int Q = WAVE / LST, RM = WAVE % LST;
+      const double2* g[NLD];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        int piece = k * RM + lane % LST;
+        int el = k * Q + lane / LST + piece / LST;
+        piece %= LST;
+        el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
+        const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
+        const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
+        g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) R[k] = *g[k];
+    };
+    auto park = [&](int s, int buf, const double2 (&R)[NLD]) {
+      double2* wbase = sh_all + s * Cfg::SET_PIECES + buf * Cfg::BUF_PIECES + wv * Cfg::WAVE_PIECES;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) wbase[k * WAVE + lane] = R[k];
+    };
+    // chunk of set s at trip t (clamped to the set's last chunk: a set that is out of chunks has its last one gathered again)
+    auto chunk_at = [&](int s, int t) { return min(rg[s].first + t * rg[s].stride, rg[s].last); };
+    double2 R[SETS][NLD];              // records of the chunk of trip t + 1 (in flight during trip t - 1 .. top of trip t)
+    int idxA[SETS], idxB[SETS], obs3[SETS];  // record indices of the chunk of trip t + 2, stream offset of the chunk of trip t + 3
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+      idxA[s] = idxB[s] = 0;
+      load_indices(p_chunk_start[chunk_at(s, 0)], &idxA[s], &idxB[s]);
+      fetch(idxA[s], idxB[s], R[s]);
+      park(s, 0, R[s]);                                                    // trip 0's records
+      load_indices(p_chunk_start[chunk_at(s, 1)], &idxA[s], &idxB[s]);
+      fetch(idxA[s], idxB[s], R[s]);                                       // trip 1's records: in flight
+      load_indices(p_chunk_start[chunk_at(s, 2)], &idxA[s], &idxB[s]);     // trip 2's indices
+      obs3[s] = p_chunk_start[chunk_at(s, 3)];
+    }
+    int buf = 0;
+    for (int trip = 0; trip < trips; ++trip) {
+      long long tA = 0, tB = 0, tC = 0;
+      if (CLK) tA = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records of the next trip (loaded a trip ago), the indices behind them, the offsets behind those
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { asm volatile("" : "+v"(R[s][k].x)); asm volatile("" : "+v"(R[s][k].y)); }
+        asm volatile("" : "+v"(idxA[s]));
+        if (EPW > WAVE) asm volatile("" : "+v"(idxB[s]));
+        asm volatile("" : "+v"(obs3[s]));
+      }
+      if (CLK) tB = clock64();
+      __syncthreads();  // the compute sets are done with the buffers of the previous trip; what was parked during it is theirs now
+      if (CLK) tC = clock64();
+      int nA[SETS], nB[SETS], nO[SETS];
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) {  // nothing loaded here feeds an address of this trip
+        park(s, buf ^ 1, R[s]);                                // records of trip t + 1 -> LDS
+        fetch(idxA[s], idxB[s], R[s]);                         // records of trip t + 2 -> registers
+        nA[s] = nB[s] = 0;
+        load_indices(obs3[s], &nA[s], &nB[s]);                 // indices of trip t + 3
+        nO[s] = p_chunk_start[chunk_at(s, trip + 4)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) { idxA[s] = nA[s]; idxB[s] = nB[s]; obs3[s] = nO[s]; }
+      buf ^= 1;
+      if (CLK) { const long long tD = clock64(); clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[4] += 1; }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (CLK && lane == 0 && clk) {
+      long long* o = clk + (((long)blockIdx.x * 3 + 2) * Cfg::NWAVES + wv) * 8;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
+      o[6] = clock64() - t_start;
+      o[7] = 0;
+    }
+    return;
+  }
+
+  // ---------------- compute set `role`: the block ownership and pair loop of k_schur_reg3, without its loads ----------------
+  const int set = role;
+  const Range R = rg[set];
+  const int wg = logical_of(set);
+  const double2* sh_p = sh_all + set * Cfg::SET_PIECES;
+  const int nblk = tp.g * tp.g, rep = tp.rep;
+  double acc[NC][NC];
+#pragma unroll
+  for (int r = 0; r < NC; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+  const int blk = (rep > 1) ? tid % nblk : tid, slot = (rep > 1) ? tid / nblk : 0;
+  const bool owner = slot < rep && blk < nblk;
+  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC;
+  struct Raw { unsigned nit[NWORD]; int code_start; };
+  auto load_raw = [&](int chunk) {
+    Raw r;
+#pragma unroll
+    for (int q = 0; q < NWORD; ++q) r.nit[q] = p_nit[(long)chunk * NWORD + q];
+    r.code_start = p_code_start[chunk];
+    return r;
+  };
+  unsigned cd[NCD];
+  int n_nx = 0;
+  long code_nx = 0;
+  auto load_codes = [&](const Raw& r) {
+    int pre = 0, mine = 0;
+#pragma unroll
+    for (int q = 0; q < NWORD; ++q) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int n = (int)((r.nit[q] >> (8 * w)) & 0xffu);
+        pre += (4 * q + w < wv) ? n : 0;
+        mine = (4 * q + w == wv) ? n : mine;
+      }
+    }
+    n_nx = __builtin_amdgcn_readfirstlane(mine);
+    code_nx = (long)r.code_start + (long)pre * WAVE + lane;
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
+  };
+  auto chunk_at = [&](int t) { return min(R.first + t * R.stride, R.last); };
+  Raw raw = load_raw(chunk_at(0));
+  load_codes(raw);              // trip 0's codes (the only load in this kernel whose address depends on a load of the same step: once)
+  raw = load_raw(chunk_at(1));
+  int buf = 0;
+  for (int trip = 0; trip < trips; ++trip) {
+    long long tA = 0, tB = 0, tC = 0, tD = 0;
+    if (CLK) tA = clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // codes of this trip, counts of the next (issued a trip ago)
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[k]));
+#pragma unroll
+    for (int q = 0; q < NWORD; ++q) asm volatile("" : "+v"(raw.nit[q]));
+    asm volatile("" : "+v"(raw.code_start));
+    if (CLK) tB = clock64();
+    __syncthreads();
+    if (CLK) tC = clock64();
+    unsigned cc[NCD];
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
+    const int n_cur = (trip < R.trips) ? n_nx : 0;
+    const long code_cur = code_nx;
+    load_codes(raw);                                 // codes of trip t + 1: addresses from registers, no wait
+    const Raw raw_n = load_raw(chunk_at(trip + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    if (CLK) { tD = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
+#pragma unroll
+    for (int it = 0; it < NCD; ++it)
+      if (it < n_cur) pair6(acc, bufp + (cc[it] & 0xffffu), bufp + (cc[it] >> 16));
+    for (int it = NCD; it < n_cur; ++it) {  // more pairs of one block in a chunk than travel in registers
+      const unsigned code = p_codes[code_cur + (long)it * WAVE];
+      pair6(acc, bufp + (code & 0xffffu), bufp + (code >> 16));
+    }
+    if (CLK) {
+      __builtin_amdgcn_sched_barrier(0);
+      const long long tE = clock64();
+      clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[3] += tE - tD; clk_sum[4] += 1; clk_sum[5] += n_cur;
+    }
+    raw = raw_n;
+    buf ^= 1;
+  }
+  if (CLK && lane == 0 && clk) {
+    long long* o = clk + (((long)blockIdx.x * 3 + set) * Cfg::NWAVES + wv) * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
+    o[6] = clock64() - t_start;
+    o[7] = 0;
+  }
+  // unprime (see k_schur_reg3) and store
+  if (blk < nblk) {
+    const int tile = tp.wg_tile[wg];
+    const int ga = tp.tile_a[tile], gb = tp.tile_b[tile];
+    const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+    const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+    const int li = blk / tp.g, lj = blk % tp.g;
+    int ci = -1, cj = -1;
+    if (ga == gb && lj <= li) {  // helper thread of a diagonal tile: the (i, i) items of one camera (schur_plan.h)
+      const int hk = li * (li + 1) / 2 + lj;
+      ci = cj = ca0 + hk % max(na, 1);
+    } else if (li < na && lj < nb) {
+      ci = ca0 + li; cj = cb0 + lj;
+    }
+    if (ci >= 0) unprime_rows<NC, NC>(acc, 0, tab + (long)ci * CAMTAB_DOUBLES + 12, tab + (long)cj * CAMTAB_DOUBLES + 12);
+  }
+  if (!owner) return;
+#pragma unroll
+  for (int r = 0; r < NC; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dst[r * NC + c] = acc[r][c];
+}
+
+__global__ void __launch_bounds__(SchurLc::THREADS, 3)
+k_schur_lc(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  schur_lc_body<false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
+}
+
+#ifdef CBA_PROFILING
+__global__ void __launch_bounds__(SchurLc::THREADS, 3)
+k_schur_lc_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk, const double* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  schur_lc_body<true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
 }
 #endif
 
@@ -1418,7 +1609,7 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
   const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
   const int g = tp.g, bsz = NCt * NCt;
   const int e = blockIdx.x * 64 + threadIdx.x;
-  const int w0 = tile_wg_begin[t] * tp.rows_per_wg, w1 = tile_wg_begin[t + 1] * tp.rows_per_wg;  // partial rows per workgroup
+  const int w0 = tile_wg_begin[t] * tp.rep, w1 = tile_wg_begin[t + 1] * tp.rep;  // rep partial rows per workgroup
   const bool diag = (ga == gb);
   long dst = -1;       // >= 0: Sacc index;  -2: park in red
   if (e < g * g * bsz) {

@@ -75,7 +75,7 @@ struct cba_problem {
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  int schur_pp = 0;        // k_schur_reg3<6, .., SETS = 2>: two sets per workgroup in anti-phase (one workgroup per CU) instead of two workgroups per CU; 1: PW = 1, 2: PW = 2
+  bool schur_lc = false;   // k_schur_lc: one 12-wave workgroup per CU (two compute sets + four loader waves) instead of two 4-wave workgroups of k_schur_reg3<6>
   int cus = 256;           // compute units of the device
   double plan_lane_util = 0.0;  // share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
@@ -721,7 +721,7 @@ static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Param
   TilePlan tp{};
   tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
   tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g;
-  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep; tp.rows_per_wg = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
+  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
   tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
   p->tp = tp;
   return CBA_OK;
@@ -737,14 +737,10 @@ static int install_reg2_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& p
   const int mb = p->plan_max_blocks;
   int rc = (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
   if (rc) return rc;
-  // Six-parameter cameras with more than one workgroup per CU: the two workgroups of a CU become the two anti-phased sets of ONE 16-wave workgroup
-  // (k_schur_reg3<6, .., SETS = 2, PW = 2>, cba_kernels.h).  A launch that does not fill the chip keeps the 4-wave workgroups: one per CU, nothing to de-phase.
-  p->schur_pp = (p->nct == 6 && (p->tile_grid % 2) == 0 && p->tile_grid > p->cus) ? 1 : 0;
-  if (const char* e = std::getenv("CBA_SCHUR_PP")) p->schur_pp = (p->nct == 6 && (p->tile_grid % 2) == 0) ? std::atoi(e) : 0;  // (A/B measurements)
-  if (p->schur_pp == 2) {  // two waves share a code wave's pair iterations: one more partial row per workgroup
-    p->tp.rows_per_wg = 2 * std::max(prm.rep, 1);
-    p->reg_reduce_y = REG_REDUCE_Y_MAX;
-  }
+  // Six-parameter cameras, more than one workgroup per CU: the two workgroups of a CU become the two compute sets of ONE 12-wave workgroup whose
+  // last four waves do the gathering (k_schur_lc, cba_kernels.h).  A launch that does not fill the chip keeps the 4-wave workgroups.
+  p->schur_lc = p->nct == 6 && (p->tile_grid % 2) == 0 && p->tile_grid > p->cus;
+  if (const char* e = std::getenv("CBA_SCHUR_LC")) p->schur_lc = p->nct == 6 && (p->tile_grid % 2) == 0 && std::atoi(e) != 0;  // (tests force it on small problems)
   return CBA_OK;
 }
 
@@ -797,13 +793,8 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 1, true>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2, true>, lds_jv(p, 2)))) return rc;
-  if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
-  if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW, 1, 1, true>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
-  if constexpr (NC == 6) {
-    using PP = Reg3Cfg<6, 2, 2>;
-    if ((rc = allow_lds(k_schur_reg3<6, 1, 4, 2, 2>, PP::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(k_schur_reg3<6, 1, 2, 2, 1>, PP::LDS_BYTES))) return rc;
-  }
+  if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
+  if (NC == 6 && (rc = allow_lds(k_schur_lc, SchurLc::LDS_BYTES))) return rc;
   if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
@@ -1092,7 +1083,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
-  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rows_per_wg, 1) * p->tp.tile_elems);
+  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems);
   TRY(dev_alloc(p, &p->partial, p->partial_capacity));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
@@ -1150,7 +1141,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 0;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
-  o->schur_wide = p->schur_pp ? 2 : 0;  // 2: a two-set (anti-phase) form of the pair kernel
+  o->schur_wide = p->schur_lc ? 2 : 0;  // 2: the loader / compute form of the pair kernel (k_schur_lc)
   {
     const bool cs = p->cs.n_sc && !p->det_m && !p->n_heavy;
     const bool camg = cs ? (p->nct == 6 ? build_cs_camg<6>(p) : build_cs_camg<9>(p)) : (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p));
@@ -1480,7 +1471,7 @@ static int maybe_swap_plan(cba_problem* p) {
     const auto t0 = std::chrono::steady_clock::now();
     rc = install_reg2_plan(p, task->plan, task->prm);
     if (!rc) {
-      const size_t need = (size_t)p->tile_grid * std::max(p->tp.rows_per_wg, 1) * p->tp.tile_elems;
+      const size_t need = (size_t)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems;
       if (need > p->partial_capacity) {  // (the dealt plan has a few chunks more or fewer than the cheap one; small problems get a workgroup per chunk)
         rc = dev_alloc(p, &p->partial, need);
         if (!rc) p->partial_capacity = need;
@@ -1501,53 +1492,43 @@ template <int NC>
 static int run_pairs_clocked(cba_problem* p) {
   if constexpr (NC != 6) return fail(CBA_ERR_UNSUPPORTED, "CBA_SCHUR_CLOCK: six-parameter cameras only");
   else {
-    const int nw = Reg3Cfg<6>::NWAVES * (p->schur_pp == 2 ? 2 : 1);  // waves per logical workgroup
-    const size_t n = (size_t)p->tile_grid * nw * 8;
+    const int nw = Reg3Cfg<6>::NWAVES;  // waves per logical workgroup (k_schur_lc: per role — sets 0, 1 and the loaders of a physical workgroup)
+    const int rows = p->schur_lc ? p->tile_grid / 2 * 3 : p->tile_grid;
+    const size_t n = (size_t)rows * nw * 8;
     long long* d = nullptr;
     if (hipMalloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
     (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
-    if (p->schur_pp) {
-      using PP = Reg3Cfg<6, 2, 2>;
-      using P1 = Reg3Cfg<6, 2, 1>;
-      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 4, 2, 2>, PP::LDS_BYTES) || raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 2, 1>, P1::LDS_BYTES)) return CBA_ERR_HIP;
-      if (p->schur_pp == 1)
-        hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 2, 1>), dim3(p->tile_grid / 2), dim3(P1::LAUNCH_THREADS), P1::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
-      else
-      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 4, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+    if (p->schur_lc) {
+      if (raise_lds_ceiling((const void*)k_schur_lc_clk, SchurLc::LDS_BYTES)) return CBA_ERR_HIP;
+      hipLaunchKernelGGL(k_schur_lc_clk, dim3(p->tile_grid / 2), dim3(SchurLc::THREADS), SchurLc::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
     } else {
-      const char* e = std::getenv("CBA_SCHUR_ILV");
-      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 1>, Reg3Cfg<6>::LDS_BYTES) || raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2, 1, 1, true>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
-      if (e && e[0] == '1') hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 1, 1, true>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
-      else hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
+      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
+      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
     }
     std::vector<long long> h(n);
     (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
     (void)hipStreamSynchronize(p->stream);
     (void)hipFree(d);
-    static const char* names[4] = {"wait for loads", "barriers", "issue", "pairs"};
-    double sum[8] = {0};
-    double tmax = 0.0;
-    size_t waves = 0;
-    for (size_t w = 0; w < n / 8; ++w) {
-      if (!h[w * 8 + 4]) continue;
-      ++waves;
-      for (int k = 0; k < 7; ++k) sum[k] += (double)h[w * 8 + k];
-      tmax = std::max(tmax, (double)h[w * 8 + 6]);
-    }
-    const double wv = (double)std::max<size_t>(waves, 1);
-    fprintf(stderr, "k_schur_reg3%s phases, mean clocks per wave (%zu waves, %.1f trips, %.1f pair iterations each):", p->schur_pp ? " (two sets)" : "", waves, sum[4] / wv, sum[5] / wv);
-    for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
-    fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
-    for (int t = 0; t + 1 < (int)p->h_tile_wg_begin.size(); ++t) {  // the kernel lasts as long as its slowest workgroup
-      double mean = 0.0, mx = 0.0, trips = 0.0, its = 0.0;
-      const int b0 = p->h_tile_wg_begin[t], b1 = p->h_tile_wg_begin[t + 1];
-      for (int b = b0; b < b1; ++b) {
-        double life = 0.0;
-        for (int w = 0; w < nw; ++w) life = std::max(life, (double)h[((size_t)b * nw + w) * 8 + 6]);
-        mean += life; mx = std::max(mx, life); trips += (double)h[(size_t)b * nw * 8 + 4]; its += (double)h[(size_t)b * nw * 8 + 5];
+    static const char* names[4] = {"wait for loads", "barrier", "issue", "pairs"};
+    auto report = [&](const char* who, auto pick) {
+      double sum[8] = {0}, tmax = 0.0;
+      size_t waves = 0;
+      for (size_t w = 0; w < n / 8; ++w) {
+        if (!h[w * 8 + 4] || !pick(w / nw)) continue;
+        ++waves;
+        for (int k = 0; k < 7; ++k) sum[k] += (double)h[w * 8 + k];
+        tmax = std::max(tmax, (double)h[w * 8 + 6]);
       }
-      const double nb = std::max(1, b1 - b0);
-      fprintf(stderr, "    tile %2d: %3d workgroups, %.1f trips and %.1f pair iterations (wave 0) each, lifetime mean %.0f max %.0f clocks\n", t, b1 - b0, trips / nb, its / nb, mean / nb, mx);
+      const double wv = (double)std::max<size_t>(waves, 1);
+      fprintf(stderr, "%s phases, mean clocks per wave (%zu waves, %.1f trips, %.1f pair iterations each):", who, waves, sum[4] / wv, sum[5] / wv);
+      for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
+      fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
+    };
+    if (p->schur_lc) {
+      report("k_schur_lc compute waves", [](size_t row) { return row % 3 != 2; });
+      report("k_schur_lc loader waves", [](size_t row) { return row % 3 == 2; });
+    } else {
+      report("k_schur_reg3", [](size_t) { return true; });
     }
     return CBA_OK;
   }
@@ -1588,20 +1569,10 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
         if (rcc) return rcc;
       } else
 #endif
-      if (p->schur_pp) {
-        if constexpr (NC == 6) {
-          using PP = Reg3Cfg<6, 2, 2>;
-          using P1 = Reg3Cfg<6, 2, 1>;
-          if (p->schur_pp == 1)
-            hipLaunchKernelGGL((k_schur_reg3<6, 1, 2, 2, 1>), dim3(p->tile_grid / 2), dim3(P1::LAUNCH_THREADS), P1::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
-          else
-          hipLaunchKernelGGL((k_schur_reg3<6, 1, 4, 2, 2>), dim3(p->tile_grid / 2), dim3(PP::LAUNCH_THREADS), PP::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
-        }
-      } else {
-        static const bool ilv = [] { const char* e = std::getenv("CBA_SCHUR_ILV"); return e && e[0] == '1'; }();  // (A/B measurements)
-        if (ilv) hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, 1, 1, true>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
-        else hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW, 1>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
-      }
+      if (p->schur_lc)
+        hipLaunchKernelGGL(k_schur_lc, dim3(p->tile_grid / 2), dim3(SchurLc::THREADS), SchurLc::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
+      else
+        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
     }
   }
   // single rank, nothing else adds to the diagonal camera blocks (heavy points, constraint rows) and the pair kernel has unprimed its sums: k_schur_finalize

@@ -222,11 +222,11 @@ def _check_evaluation(name, expect_camg=None):
 @pytest.mark.parametrize("shape", [dict(n_cams=24, n_points=600, k=10), dict(n_cams=20, n_points=500, k=7), dict(n_cams=40, n_points=800, k=9),
                                    dict(n_cams=64, n_points=1500, k=10), dict(n_cams=70, n_points=900, k=12, loss="huber", outliers=0.05),
                                    dict(n_cams=8, n_points=500, k=8), dict(n_cams=5, n_points=90, k=5)])
-def test_two_set_pair_kernel_matches_the_one_set_kernel(shape, monkeypatch):
-    """k_schur_reg3<6, .., SETS = 2> (one 8-wave workgroup per CU whose two 4-wave sets run in anti-phase; the default for six-parameter cameras once the
-    launch holds more than one workgroup per CU — forced here on small problems with CBA_SCHUR_PP=1: ragged groups of 24 and 20 cameras, several threads
-    per block, one to three groups, sets that run out of chunks early and idle through the other set's trips) against the one-set kernel: the same
-    partial sums in the same order, so the same reduced system bit for bit, and the same damped step."""
+def test_loader_compute_pair_kernel_matches_the_four_wave_kernel(shape, monkeypatch):
+    """k_schur_lc (one 12-wave workgroup per CU: two compute sets of four waves + four loader waves; the default for six-parameter cameras once the
+    launch holds more than one workgroup per CU — forced here on small problems with CBA_SCHUR_LC=1: ragged groups of 24 and 20 cameras, several
+    threads per block, one to three groups, sets that run out of chunks early and idle through the other set's trips) against k_schur_reg3: the
+    same partial sums in the same order, so the same reduced system, and the same damped step."""
     from caliscope_amd.hip_engine import HipEngine
 
     cfg = dict(shape)
@@ -235,10 +235,10 @@ def test_two_set_pair_kernel_matches_the_one_set_kernel(shape, monkeypatch):
     fs = sc.f_scale_1px() * 2.0 if loss != "linear" else 1.0
     steps, systems = [], []
     for pp in ("0", "1"):
-        monkeypatch.setenv("CBA_SCHUR_PP", pp)
+        monkeypatch.setenv("CBA_SCHUR_LC", pp)
         eng = HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs))
         info = eng.info()
-        if info["schur_grid"] % 2 == 0:  # (an odd number of logical workgroups keeps the one-set kernel)
+        if info["schur_grid"] % 2 == 0:  # (an odd number of logical workgroups keeps the four-wave kernel)
             assert info["schur_wide"] == (2 if pp == "1" else 0)
         eng.begin(x0)
         eng.linearize()
