@@ -1319,278 +1319,6 @@ k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restric
 }
 #endif
 
-// k_schur_lc (round 4, six-parameter cameras, launches with more than one workgroup per CU): LOADER waves and COMPUTE waves.
-//
-// What the phase clocks of k_schur_reg3 say on cfg4 (two 4-wave workgroups per CU, per trip and workgroup): issuing the gather 1600 clocks,
-// pair arithmetic 1900, barrier 650, and nothing overlaps.  The pair phase is FP64 issue at its peak: 99 instructions per pair iteration,
-// 4.1 clocks each with TWO waves of a SIMD multiplying (one wave alone gets an instruction through every ~9 clocks: measured with two 4-wave sets
-// forced into anti-phase — no faster, with the next pair's records prefetched into registers — no faster).  The issue phase is the CU's address
-// path: a 64-lane LDS-DMA gather every ~26 clocks, 36 per chunk, and a wave BLOCKS at a load the path has no room for (issuing the loads a few
-// at a time between the pair iterations moved the stall into the pair loop and saved nothing).  Both of a CU's workgroups run the same code, so
-// their waves meet at the loads together and then multiply together.  Overlap needs waves that do nothing but load next to two waves per SIMD
-// that do nothing but multiply: one 12-wave workgroup per CU,
-//     waves 0-3 and 4-7:  compute sets 0 and 1 — the two logical workgroups of before (own tile, own chunk sequence, own accumulators);
-//     waves 8-11:         loaders — wave w gathers its 80-slot share of the NEXT chunk of both sets (18 loads per trip).
-// One barrier of the whole workgroup per trip: behind it the loaders' records of this trip are in LDS and the compute sets have finished with the
-// buffers of the previous one.  Four chunk buffers (two sets x two), 148 KB.
-struct SchurLc {
-  using Cfg = Reg3Cfg<6>;
-  static constexpr int SETS = 2;
-  static constexpr int COMPUTE_THREADS = SETS * BLOCK, LOADER_WAVES = Cfg::NWAVES, THREADS = COMPUTE_THREADS + LOADER_WAVES * WAVE;  // 768
-  static constexpr size_t LDS_BYTES = (size_t)SETS * Cfg::SET_PIECES * 16;
-  static_assert(LDS_BYTES <= 160 * 1024, "four chunk buffers");
-};
-
-template <bool CLK>
-__device__ __forceinline__ void schur_lc_body(const TilePlan& tp, const unsigned* __restrict__ p_nit, const int* __restrict__ p_code_start,
-                                              const int* __restrict__ p_chunk_start, const unsigned* __restrict__ p_codes, const int* __restrict__ p_obs,
-                                              const double* __restrict__ Trec, double* __restrict__ partial, double* sh, long long* __restrict__ clk,
-                                              const double* __restrict__ tab) {
-  using Cfg = Reg3Cfg<6>;
-  constexpr int NC = 6, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW, NWORD = Cfg::CODE_WAVES / 4, NCD = Cfg::NCD, SETS = SchurLc::SETS;
-  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / BLOCK);  // 0, 1: compute set; 2: loader
-  const int tid = (int)threadIdx.x % BLOCK;
-  const int lane = tid % WAVE, wv = __builtin_amdgcn_readfirstlane(tid / WAVE);  // wave of the set / loader wave
-  // logical workgroup of set s (index into wg_first / ... and of its partial row): physical workgroup B (XCD B mod 8) runs 16 (B / 8) + B mod 8
-  // and that + 8 — both keep B mod 8, which is what the XCD-aware binding goes by (csrc/wg_binding.h)
-  const int n_logical = (int)gridDim.x * SETS;
-  auto logical_of = [&](int s) {
-    return ((n_logical & 15) == 0) ? (((int)blockIdx.x >> 3) << 4) + ((int)blockIdx.x & 7) + 8 * s : (int)blockIdx.x * SETS + s;
-  };
-  struct Range { int first, stride, trips, last; };
-  auto range_of = [&](int w) {
-    const int f = tp.wg_first[w], e = tp.wg_end[w], s = tp.wg_stride[w];
-    Range r;
-    r.stride = s;
-    r.trips = f < e ? (e - 1 - f) / s + 1 : 0;
-    r.first = r.trips ? f : max(e - 1, 0);  // (no chunk of its own: somebody's valid chunk, gathered and never multiplied)
-    r.last = r.first + (r.trips ? (r.trips - 1) * s : 0);
-    return r;
-  };
-  const Range rg[SETS] = {range_of(logical_of(0)), range_of(logical_of(1))};
-  const int trips = max(max(rg[0].trips, rg[1].trips), 1);  // the barriers are the workgroup's: both sets and the loaders run the same number of trips
-  double2* sh_all = reinterpret_cast<double2*>(sh);
-  for (int k = (int)threadIdx.x; k < SETS * Cfg::NBUF * LST; k += SchurLc::THREADS)
-    sh_all[(k / (Cfg::NBUF * LST)) * Cfg::SET_PIECES + ((k / LST) % Cfg::NBUF) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
-  long long clk_sum[6] = {0, 0, 0, 0, 0, 0};
-  const long long t_start = CLK ? clock64() : 0;
-
-  if (role == SETS) {
-    // ---------------- loader wave wv: slots [wv * EPW, (wv + 1) * EPW) of every chunk of both sets ----------------
-    // Through REGISTERS, not by LDS-DMA: a wave gets a global_load ... lds through only every ~180 clocks (measured: four loader waves needed 3400
-    // clocks for the 72 loads of a trip), a plain global_load_dwordx4 issues in a few clocks and the ds_write_b128 behind it costs ~13.  The
-    // records of trip t + 1 are written into LDS during trip t from registers that were loaded during trip t - 1.
-    auto load_indices = [&](int obs_start, int* iA, int* iB) {
-      const int* src = p_obs + obs_start + wv * EPW;
-      *iA = src[lane];
-      if (EPW > WAVE) *iB = src[WAVE + (lane & (EPW - WAVE - 1))];
-    };
-    auto fetch = [&](int idxA, int idxB, double2 (&R)[NLD]) {  // this wave's share of a chunk: NLD loads of 64 pieces
-      constexpr int Q = WAVE / LST, RM = WAVE % LST;
-      const double2* g[NLD];
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        int piece = k * RM + lane % LST;
-        int el = k * Q + lane / LST + piece / LST;
-        piece %= LST;
-        el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
-        const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
-        const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-        g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) R[k] = *g[k];
-    };
-    auto park = [&](int s, int buf, const double2 (&R)[NLD]) {
-      double2* wbase = sh_all + s * Cfg::SET_PIECES + buf * Cfg::BUF_PIECES + wv * Cfg::WAVE_PIECES;
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) wbase[k * WAVE + lane] = R[k];
-    };
-    // chunk of set s at trip t (clamped to the set's last chunk: a set that is out of chunks has its last one gathered again)
-    auto chunk_at = [&](int s, int t) { return min(rg[s].first + t * rg[s].stride, rg[s].last); };
-    double2 R[SETS][NLD];              // records of the chunk of trip t + 1 (in flight during trip t - 1 .. top of trip t)
-    int idxA[SETS], idxB[SETS], obs3[SETS];  // record indices of the chunk of trip t + 2, stream offset of the chunk of trip t + 3
-#pragma unroll
-    for (int s = 0; s < SETS; ++s) {
-      idxA[s] = idxB[s] = 0;
-      load_indices(p_chunk_start[chunk_at(s, 0)], &idxA[s], &idxB[s]);
-      fetch(idxA[s], idxB[s], R[s]);
-      park(s, 0, R[s]);                                                    // trip 0's records
-      load_indices(p_chunk_start[chunk_at(s, 1)], &idxA[s], &idxB[s]);
-      fetch(idxA[s], idxB[s], R[s]);                                       // trip 1's records: in flight
-      load_indices(p_chunk_start[chunk_at(s, 2)], &idxA[s], &idxB[s]);     // trip 2's indices
-      obs3[s] = p_chunk_start[chunk_at(s, 3)];
-    }
-    int buf = 0;
-    for (int trip = 0; trip < trips; ++trip) {
-      long long tA = 0, tB = 0, tC = 0;
-      if (CLK) tA = clock64();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records of the next trip (loaded a trip ago), the indices behind them, the offsets behind those
-#pragma unroll
-      for (int s = 0; s < SETS; ++s) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) { asm volatile("" : "+v"(R[s][k].x)); asm volatile("" : "+v"(R[s][k].y)); }
-        asm volatile("" : "+v"(idxA[s]));
-        if (EPW > WAVE) asm volatile("" : "+v"(idxB[s]));
-        asm volatile("" : "+v"(obs3[s]));
-      }
-      if (CLK) tB = clock64();
-      __syncthreads();  // the compute sets are done with the buffers of the previous trip; what was parked during it is theirs now
-      if (CLK) tC = clock64();
-      int nA[SETS], nB[SETS], nO[SETS];
-#pragma unroll
-      for (int s = 0; s < SETS; ++s) {  // nothing loaded here feeds an address of this trip
-        park(s, buf ^ 1, R[s]);                                // records of trip t + 1 -> LDS
-        fetch(idxA[s], idxB[s], R[s]);                         // records of trip t + 2 -> registers
-        nA[s] = nB[s] = 0;
-        load_indices(obs3[s], &nA[s], &nB[s]);                 // indices of trip t + 3
-        nO[s] = p_chunk_start[chunk_at(s, trip + 4)];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < SETS; ++s) { idxA[s] = nA[s]; idxB[s] = nB[s]; obs3[s] = nO[s]; }
-      buf ^= 1;
-      if (CLK) { const long long tD = clock64(); clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[4] += 1; }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (CLK && lane == 0 && clk) {
-      long long* o = clk + (((long)blockIdx.x * 3 + 2) * Cfg::NWAVES + wv) * 8;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
-      o[6] = clock64() - t_start;
-      o[7] = 0;
-    }
-    return;
-  }
-
-  // ---------------- compute set `role`: the block ownership and pair loop of k_schur_reg3, without its loads ----------------
-  const int set = role;
-  const Range R = rg[set];
-  const int wg = logical_of(set);
-  const double2* sh_p = sh_all + set * Cfg::SET_PIECES;
-  const int nblk = tp.g * tp.g, rep = tp.rep;
-  double acc[NC][NC];
-#pragma unroll
-  for (int r = 0; r < NC; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
-  const int blk = (rep > 1) ? tid % nblk : tid, slot = (rep > 1) ? tid / nblk : 0;
-  const bool owner = slot < rep && blk < nblk;
-  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC;
-  struct Raw { unsigned nit[NWORD]; int code_start; };
-  auto load_raw = [&](int chunk) {
-    Raw r;
-#pragma unroll
-    for (int q = 0; q < NWORD; ++q) r.nit[q] = p_nit[(long)chunk * NWORD + q];
-    r.code_start = p_code_start[chunk];
-    return r;
-  };
-  unsigned cd[NCD];
-  int n_nx = 0;
-  long code_nx = 0;
-  auto load_codes = [&](const Raw& r) {
-    int pre = 0, mine = 0;
-#pragma unroll
-    for (int q = 0; q < NWORD; ++q) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int n = (int)((r.nit[q] >> (8 * w)) & 0xffu);
-        pre += (4 * q + w < wv) ? n : 0;
-        mine = (4 * q + w == wv) ? n : mine;
-      }
-    }
-    n_nx = __builtin_amdgcn_readfirstlane(mine);
-    code_nx = (long)r.code_start + (long)pre * WAVE + lane;
-#pragma unroll
-    for (int k = 0; k < NCD; ++k) cd[k] = p_codes[code_nx + k * WAVE];  // past the wave's last iteration: somebody else's codes, never used
-  };
-  auto chunk_at = [&](int t) { return min(R.first + t * R.stride, R.last); };
-  Raw raw = load_raw(chunk_at(0));
-  load_codes(raw);              // trip 0's codes (the only load in this kernel whose address depends on a load of the same step: once)
-  raw = load_raw(chunk_at(1));
-  int buf = 0;
-  for (int trip = 0; trip < trips; ++trip) {
-    long long tA = 0, tB = 0, tC = 0, tD = 0;
-    if (CLK) tA = clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // codes of this trip, counts of the next (issued a trip ago)
-#pragma unroll
-    for (int k = 0; k < NCD; ++k) asm volatile("" : "+v"(cd[k]));
-#pragma unroll
-    for (int q = 0; q < NWORD; ++q) asm volatile("" : "+v"(raw.nit[q]));
-    asm volatile("" : "+v"(raw.code_start));
-    if (CLK) tB = clock64();
-    __syncthreads();
-    if (CLK) tC = clock64();
-    unsigned cc[NCD];
-#pragma unroll
-    for (int k = 0; k < NCD; ++k) cc[k] = cd[k];
-    const int n_cur = (trip < R.trips) ? n_nx : 0;
-    const long code_cur = code_nx;
-    load_codes(raw);                                 // codes of trip t + 1: addresses from registers, no wait
-    const Raw raw_n = load_raw(chunk_at(trip + 2));
-    __builtin_amdgcn_sched_barrier(0);
-    if (CLK) { tD = clock64(); __builtin_amdgcn_sched_barrier(0); }
-    const double2* bufp = sh_p + buf * Cfg::BUF_PIECES;
-#pragma unroll
-    for (int it = 0; it < NCD; ++it)
-      if (it < n_cur) pair6(acc, bufp + (cc[it] & 0xffffu), bufp + (cc[it] >> 16));
-    for (int it = NCD; it < n_cur; ++it) {  // more pairs of one block in a chunk than travel in registers
-      const unsigned code = p_codes[code_cur + (long)it * WAVE];
-      pair6(acc, bufp + (code & 0xffffu), bufp + (code >> 16));
-    }
-    if (CLK) {
-      __builtin_amdgcn_sched_barrier(0);
-      const long long tE = clock64();
-      clk_sum[0] += tB - tA; clk_sum[1] += tC - tB; clk_sum[2] += tD - tC; clk_sum[3] += tE - tD; clk_sum[4] += 1; clk_sum[5] += n_cur;
-    }
-    raw = raw_n;
-    buf ^= 1;
-  }
-  if (CLK && lane == 0 && clk) {
-    long long* o = clk + (((long)blockIdx.x * 3 + set) * Cfg::NWAVES + wv) * 8;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = clk_sum[k];
-    o[6] = clock64() - t_start;
-    o[7] = 0;
-  }
-  // unprime (see k_schur_reg3) and store
-  if (blk < nblk) {
-    const int tile = tp.wg_tile[wg];
-    const int ga = tp.tile_a[tile], gb = tp.tile_b[tile];
-    const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
-    const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
-    const int li = blk / tp.g, lj = blk % tp.g;
-    int ci = -1, cj = -1;
-    if (ga == gb && lj <= li) {  // helper thread of a diagonal tile: the (i, i) items of one camera (schur_plan.h)
-      const int hk = li * (li + 1) / 2 + lj;
-      ci = cj = ca0 + hk % max(na, 1);
-    } else if (li < na && lj < nb) {
-      ci = ca0 + li; cj = cb0 + lj;
-    }
-    if (ci >= 0) unprime_rows<NC, NC>(acc, 0, tab + (long)ci * CAMTAB_DOUBLES + 12, tab + (long)cj * CAMTAB_DOUBLES + 12);
-  }
-  if (!owner) return;
-#pragma unroll
-  for (int r = 0; r < NC; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) dst[r * NC + c] = acc[r][c];
-}
-
-__global__ void __launch_bounds__(SchurLc::THREADS, 3)
-k_schur_lc(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_lc_body<false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
-}
-
-#ifdef CBA_PROFILING
-__global__ void __launch_bounds__(SchurLc::THREADS, 3)
-k_schur_lc_clk(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, long long* __restrict__ clk, const double* __restrict__ tab) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  schur_lc_body<true>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, clk, tab);
-}
-#endif
-
 // Reduce the partials of k_schur_reg over the workgroups of each tile (fixed order).  blockDim = (64, Y): x walks the per-thread partial entries,
 // y splits the partial rows of the tile Y ways, Y = 4 or REG_REDUCE_Y_MAX = 16 (the caller's choice: a small rig has ONE tile and up to 500 partial
 // rows — with four ways that is 60 dependent load-add steps per thread, 13 us of cfg2's iteration, 7 with sixteen; cfg4 has 51 rows per tile and

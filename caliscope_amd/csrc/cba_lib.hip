@@ -75,7 +75,6 @@ struct cba_problem {
   VecLayout lay{};
   int n_chunks = 0, grid = 0, max_obs_per_point = 0;
   int G = 1, gsz = 1, n_tiles = 1, n_tile_chunks = 0, tile_grid = 0;
-  bool schur_lc = false;   // k_schur_lc: one 12-wave workgroup per CU (two compute sets + four loader waves) instead of two 4-wave workgroups of k_schur_reg3<6>
   int cus = 256;           // compute units of the device
   double plan_lane_util = 0.0;  // share of the lane-iterations of the pair loops that multiply a real pair
   long tile_stream_len = 0, n_pairs = 0;
@@ -732,16 +731,10 @@ static void drop_plan_task(cba_problem* p) {
   p->plan_task = nullptr;
 }
 
-// binds and uploads `plan`; decides the form of the pair kernel from the grid the binding chose
+// binds and uploads `plan`
 static int install_reg2_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm) {
   const int mb = p->plan_max_blocks;
-  int rc = (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
-  if (rc) return rc;
-  // Six-parameter cameras, more than one workgroup per CU: the two workgroups of a CU become the two compute sets of ONE 12-wave workgroup whose
-  // last four waves do the gathering (k_schur_lc, cba_kernels.h).  A launch that does not fill the chip keeps the 4-wave workgroups.
-  p->schur_lc = p->nct == 6 && (p->tile_grid % 2) == 0 && p->tile_grid > p->cus;
-  if (const char* e = std::getenv("CBA_SCHUR_LC")) p->schur_lc = p->nct == 6 && (p->tile_grid % 2) == 0 && std::atoi(e) != 0;  // (tests force it on small problems)
-  return CBA_OK;
+  return (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
 }
 
 // Camera groups of the pair kernel: host-only (camera count), decided before anything touches the device so that the plan can be dealt while
@@ -794,7 +787,6 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_jv<NC, 1, true>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2, true>, lds_jv(p, 2)))) return rc;
   if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
-  if (NC == 6 && (rc = allow_lds(k_schur_lc, SchurLc::LDS_BYTES))) return rc;
   if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
@@ -1141,7 +1133,7 @@ int cba_get_info(cba_problem* p, cba_info* o) {
   o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 0;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
-  o->schur_wide = p->schur_lc ? 2 : 0;  // 2: the loader / compute form of the pair kernel (k_schur_lc)
+  o->schur_wide = 0;  // (the wide-tile variant of rounds 2-3 is gone)
   {
     const bool cs = p->cs.n_sc && !p->det_m && !p->n_heavy;
     const bool camg = cs ? (p->nct == 6 ? build_cs_camg<6>(p) : build_cs_camg<9>(p)) : (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p));
@@ -1492,19 +1484,13 @@ template <int NC>
 static int run_pairs_clocked(cba_problem* p) {
   if constexpr (NC != 6) return fail(CBA_ERR_UNSUPPORTED, "CBA_SCHUR_CLOCK: six-parameter cameras only");
   else {
-    const int nw = Reg3Cfg<6>::NWAVES;  // waves per logical workgroup (k_schur_lc: per role — sets 0, 1 and the loaders of a physical workgroup)
-    const int rows = p->schur_lc ? p->tile_grid / 2 * 3 : p->tile_grid;
-    const size_t n = (size_t)rows * nw * 8;
+    const int nw = Reg3Cfg<6>::NWAVES;
+    const size_t n = (size_t)p->tile_grid * nw * 8;
     long long* d = nullptr;
     if (hipMalloc((void**)&d, n * sizeof(long long)) != hipSuccess) return fail(CBA_ERR_HIP, "debug buffer");
     (void)hipMemsetAsync(d, 0, n * sizeof(long long), p->stream);
-    if (p->schur_lc) {
-      if (raise_lds_ceiling((const void*)k_schur_lc_clk, SchurLc::LDS_BYTES)) return CBA_ERR_HIP;
-      hipLaunchKernelGGL(k_schur_lc_clk, dim3(p->tile_grid / 2), dim3(SchurLc::THREADS), SchurLc::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
-    } else {
-      if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
-      hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
-    }
+    if (raise_lds_ceiling((const void*)k_schur_reg3_clk<6, 1, 2>, Reg3Cfg<6>::LDS_BYTES)) return CBA_ERR_HIP;
+    hipLaunchKernelGGL((k_schur_reg3_clk<6, 1, 2>), dim3(p->tile_grid), dim3(Reg3Cfg<6>::LAUNCH_THREADS), Reg3Cfg<6>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, d, (const double*)p->tab);
     std::vector<long long> h(n);
     (void)hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, p->stream);
     (void)hipStreamSynchronize(p->stream);
@@ -1524,12 +1510,7 @@ static int run_pairs_clocked(cba_problem* p) {
       for (int k = 0; k < 4; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[k] / wv);
       fprintf(stderr, "  | in-loop total %.0f, wave lifetime mean %.0f max %.0f\n", (sum[0] + sum[1] + sum[2] + sum[3]) / wv, sum[6] / wv, tmax);
     };
-    if (p->schur_lc) {
-      report("k_schur_lc compute waves", [](size_t row) { return row % 3 != 2; });
-      report("k_schur_lc loader waves", [](size_t row) { return row % 3 == 2; });
-    } else {
-      report("k_schur_reg3", [](size_t) { return true; });
-    }
+    report("k_schur_reg3", [](size_t) { return true; });
     return CBA_OK;
   }
 }
@@ -1569,10 +1550,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
         if (rcc) return rcc;
       } else
 #endif
-      if (p->schur_lc)
-        hipLaunchKernelGGL(k_schur_lc, dim3(p->tile_grid / 2), dim3(SchurLc::THREADS), SchurLc::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
-      else
-        hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
+      hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
     }
   }
   // single rank, nothing else adds to the diagonal camera blocks (heavy points, constraint rows) and the pair kernel has unprimed its sums: k_schur_finalize

@@ -219,38 +219,6 @@ def _check_evaluation(name, expect_camg=None):
     hip.close()
 
 
-@pytest.mark.parametrize("shape", [dict(n_cams=24, n_points=600, k=10), dict(n_cams=20, n_points=500, k=7), dict(n_cams=40, n_points=800, k=9),
-                                   dict(n_cams=64, n_points=1500, k=10), dict(n_cams=70, n_points=900, k=12, loss="huber", outliers=0.05),
-                                   dict(n_cams=8, n_points=500, k=8), dict(n_cams=5, n_points=90, k=5)])
-def test_loader_compute_pair_kernel_matches_the_four_wave_kernel(shape, monkeypatch):
-    """k_schur_lc (one 12-wave workgroup per CU: two compute sets of four waves + four loader waves; the default for six-parameter cameras once the
-    launch holds more than one workgroup per CU — forced here on small problems with CBA_SCHUR_LC=1: ragged groups of 24 and 20 cameras, several
-    threads per block, one to three groups, sets that run out of chunks early and idle through the other set's trips) against k_schur_reg3: the
-    same partial sums in the same order, so the same reduced system, and the same damped step."""
-    from caliscope_amd.hip_engine import HipEngine
-
-    cfg = dict(shape)
-    loss = cfg.pop("loss", "linear")
-    sc, par, x0 = small_problem(loss=loss, **cfg)
-    fs = sc.f_scale_1px() * 2.0 if loss != "linear" else 1.0
-    steps, systems = [], []
-    for pp in ("0", "1"):
-        monkeypatch.setenv("CBA_SCHUR_LC", pp)
-        eng = HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices, loss=loss, f_scale=fs))
-        info = eng.info()
-        if info["schur_grid"] % 2 == 0:  # (an odd number of logical workgroups keeps the four-wave kernel)
-            assert info["schur_wide"] == (2 if pp == "1" else 0)
-        eng.begin(x0)
-        eng.linearize()
-        assert eng.newton_step(1e-4).ok
-        steps.append(eng.get_vector(3).copy())
-        systems.append(eng.reduced_system())
-        eng.close()
-    (S0, b0), (S1, b1) = systems
-    assert np.abs(S0 - S1).max() <= 1e-12 * np.abs(S0).max() and np.abs(b0 - b1).max() <= 1e-11 * np.abs(b0).max()
-    assert np.abs(steps[0] - steps[1]).max() <= 1e-9 * np.abs(steps[0]).max()
-
-
 # cauchy / arctan are non-convex: a sixth of the rows sits at scipy's sqrt(EPS) floor (rho' + 2 rho'' z < 0) and the damped step
 # is decided by those columns' rounding noise on both sides; their evaluation (residuals, robust scaling, J^T J blocks, gradient)
 # is compared in test_evaluation_parity, their converged solves in tests/test_trf_driver.py
