@@ -1796,6 +1796,156 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
 #undef CHOL_STAMP
 }
 
+// Small rigs (ncp <= SMALL_N: sixteen six-parameter cameras — every rig the reference's users have): the whole dense solve behind the pair
+// kernel in ONE workgroup with the matrix in LDS: S = U + lam D_c^2 + cam_diag - Sacc and the right-hand side formed as k_schur_finalize does,
+// blocked Cholesky (the 32-pivot wave factorisation of chol_factor_block per diagonal block, panel solves with its inverse, trailing updates; the
+// rhs rides along as row n), backward substitution with the blocks' inverses, x to `out`.  Replaces k_schur_finalize + ncp / 32 + 1 k_chol_step +
+// k_chol_apply: five launches of 4-9 us each on cfg2, where every launch — however small — occupies the device for ~4.5 us.
+constexpr int SMALL_N = 96;
+constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_LD = SMALL_N + 1;  // odd row stride
+template <int NC>
+__global__ void __launch_bounds__(SMALL_THREADS)
+k_small_solve(const double* __restrict__ Sacc, const double* __restrict__ bacc, const double* __restrict__ Upacked, const double* __restrict__ gvec,
+              const double* __restrict__ sinv, const int* __restrict__ param_cam, const int* __restrict__ param_loc, int n, double lam,
+              const double* __restrict__ lam_dev, const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
+              const double* __restrict__ red, int g, long tile_elems, const int* __restrict__ group_cam_begin, int* __restrict__ flags,
+              double* __restrict__ out) {
+  using UP = UPack<NC>;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double (*W)[SMALL_LD] = reinterpret_cast<double (*)[SMALL_LD]>(sh);                       // [n + 1][SMALL_LD]: S, then rhs^T
+  double (*D)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(sh + (SMALL_N + 1) * SMALL_LD);  // [2 NB][NB + 1]: chol_factor_block's block
+  double (*X)[NB][NB + 1] = reinterpret_cast<double (*)[NB][NB + 1]>(&D[2 * NB][0]);          // [nbk][NB][NB + 1]: inverses of the diagonal blocks
+  double* y = &X[(SMALL_N + NB - 1) / NB][0][0];                                              // [SMALL_N]
+  if (lam_dev) lam = *lam_dev;
+  const int tid = threadIdx.x, nbk = (n + NB - 1) / NB;
+  // 1. the reduced system (k_schur_finalize's arithmetic).  A thread handles several entries one after the other, so nothing a load's address
+  // depends on may come from global memory inside the loops (a chain of three dependent loads per entry was 25 of this kernel's first 42 us): the
+  // per-parameter tables go to LDS first, the off-block entries are four independent loads per trip, the few entries inside a camera's own block
+  // (they carry U_c, the damping and the folded helper sums) have a loop of their own.
+  int* pc = reinterpret_cast<int*>(y + SMALL_N);  // [n] camera of a parameter
+  int* pl = pc + SMALL_N;                         // [n] its index inside the camera's block
+  for (int i = tid; i < n; i += SMALL_THREADS) {
+    pc[i] = param_cam[i]; pl[i] = param_loc[i];
+    const double rv = -gvec[i] + bacc[i];
+    rhs[i] = rv;
+    W[n][i] = rv;
+  }
+  __syncthreads();
+  for (int base = tid; base < n * n; base += 4 * SMALL_THREADS) {
+    double v4[4];
+    int r4[4], c4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = base + u * SMALL_THREADS;
+      const int row = min(t, n * n - 1) / n, col = min(t, n * n - 1) % n;
+      const bool live = t < n * n && col > row && pc[row] != pc[col];
+      r4[u] = live ? row : -1; c4[u] = col;
+      v4[u] = -Sacc[(long)row * n + col];  // (unconditional, clamped: the four loads are in flight together)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r4[u] < 0) continue;
+      S[(long)r4[u] * n + c4[u]] = v4[u]; S[(long)c4[u] * n + r4[u]] = v4[u];
+      W[r4[u]][c4[u]] = v4[u]; W[c4[u]][r4[u]] = v4[u];
+    }
+  }
+  for (int q = tid; q < n * NC; q += SMALL_THREADS) {
+    const int row = q / NC, col = row - pl[row] + q % NC;
+    if (col < row || col >= n || pc[col] != pc[row]) continue;
+    const int cam = pc[row];
+    double v;
+    if (red) {
+      const int ga = cam / g, ca0 = group_cam_begin[ga], na = group_cam_begin[ga + 1] - ca0;
+      const double* src = red + (long)ga * tile_elems + pl[row] * NC + pl[col];
+      double sum = 0.0;
+      for (int k = cam - ca0; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj
+        int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
+        while (li * (li + 1) / 2 > k) --li;
+        while ((li + 1) * (li + 2) / 2 <= k) ++li;
+        const int lj = k - li * (li + 1) / 2;
+        sum += src[(long)(li * g + lj) * (NC * NC)];
+      }
+      v = -sum;
+    } else {
+      v = -Sacc[(long)row * n + col];
+    }
+    v += Upacked[cam * UP::STRIDE + UP::idx(pl[row], pl[col])];
+    if (row == col) v += lam * sinv[row] * sinv[row] + cam_diag[row];
+    S[(long)row * n + col] = v; S[(long)col * n + row] = v;
+    W[row][col] = v; W[col][row] = v;
+  }
+  __syncthreads();
+  // 2. blocked Cholesky in place (lower triangle), the rhs row as one more row of every panel
+  for (int k = 0; k < nbk; ++k) {
+    const int k0 = k * NB, nb = min(NB, n - k0);
+    for (int e = tid; e < NB * NB; e += SMALL_THREADS) {  // diagonal block, identity-padded
+      const int i = e / NB, j = e % NB;
+      D[i][j] = (i < nb && j < nb) ? W[k0 + max(i, j)][k0 + min(i, j)] : (i == j ? 1.0 : 0.0);  // (the trailing updates keep the lower triangle)
+    }
+    __syncthreads();
+    if (tid < WAVE) chol_factor_block(D, nb, flags);
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += SMALL_THREADS) {
+      const int i = e / NB, j = e % NB;
+      if (i < nb && j <= i) W[k0 + i][k0 + j] = D[i][j];
+      X[k][i][j] = D[NB + j][i];  // X_k = L_kk^-1, row-major (row NB + c of D holds column c)
+    }
+    __syncthreads();
+    // panel: L_bk = W_bk X_k^T for the rows below the block (and the rhs row): row r, column j <- sum_t W[r][k0 + t] X_k[j][t]
+    const int r_lo = k0 + nb, n_rows = n + 1 - r_lo;
+    double acc4[(SMALL_N + 1) * NB / SMALL_THREADS + 1];
+    {
+      int q = 0;
+      for (int e = tid; e < n_rows * NB; e += SMALL_THREADS, ++q) {
+        const int r = r_lo + e / NB, j = e % NB;
+        double a = 0.0;
+        if (j < nb)
+          for (int t = 0; t <= j; ++t) a = fma(W[r][k0 + t], X[k][j][t], a);  // (X_k = L_kk^-1 is lower triangular)
+        acc4[q] = a;
+      }
+    }
+    __syncthreads();
+    {
+      int q = 0;
+      for (int e = tid; e < n_rows * NB; e += SMALL_THREADS, ++q) {
+        const int r = r_lo + e / NB, j = e % NB;
+        if (j < nb) W[r][k0 + j] = acc4[q];
+      }
+    }
+    __syncthreads();
+    // trailing update: W[i][j] -= sum_t L[i][k0 + t] L[j][k0 + t] for r_lo <= j <= i (i up to the rhs row n)
+    const int m = n - r_lo;  // columns left
+    for (int e = tid; e < (m + 1) * m; e += SMALL_THREADS) {
+      const int i = r_lo + e / m, j = r_lo + e % m;
+      if (j > i) continue;
+      double a = W[i][j];
+      for (int t = 0; t < nb; ++t) a = fma(-W[i][k0 + t], W[j][k0 + t], a);
+      W[i][j] = a;
+    }
+    __syncthreads();
+  }
+  // 3. backward substitution L^T x = y (y^T = row n) with the blocks' inverses
+  for (int i = tid; i < n; i += SMALL_THREADS) y[i] = W[n][i];
+  __syncthreads();
+  for (int k = nbk - 1; k >= 0; --k) {
+    const int k0 = k * NB, nb = min(NB, n - k0);
+    double xv = 0.0;
+    if (tid < nb) {  // x_k = X_k^T y_k
+      for (int t = tid; t < nb; ++t) xv = fma(X[k][t][tid], y[k0 + t], xv);
+    }
+    __syncthreads();
+    if (tid < nb) { y[k0 + tid] = xv; out[k0 + tid] = xv; }
+    __syncthreads();
+    for (int i = tid; i < k0; i += SMALL_THREADS) {  // y_i -= sum_t L[k0 + t][i] x_t
+      double a = y[i];
+      for (int t = 0; t < nb; ++t) a = fma(-W[k0 + t][i], y[k0 + t], a);
+      y[i] = a;
+    }
+    __syncthreads();
+  }
+}
+
 // x = L^-T y = T y with the explicit T of the inverse role above: one workgroup per block row, 16 threads per row (coalesced 128-byte reads),
 // fixed summation order.  Replaces the serial chain of a backward substitution (33 us at n = 384, 139 us at n = 1152 in round 2) by a launch of a few microseconds.
 constexpr int APPLY_THREADS = 512;

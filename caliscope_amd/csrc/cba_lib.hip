@@ -585,6 +585,7 @@ template <int NC> static size_t lds_tprep(const cba_problem* p) {
   return ((size_t)SchurRec<NC>::STAGE_WAVES * WAVE * SchurRec<NC>::STAGE * 2 + lds_tab(p) + p->lay.ncp_pad) * 8;
 }
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
+constexpr size_t kSmallSolveLds = ((size_t)(SMALL_N + 1) * SMALL_LD + (size_t)2 * NB * (NB + 1) + (size_t)((SMALL_N + NB - 1) / NB) * NB * (NB + 1) + 2 * SMALL_N) * 8;  // k_small_solve
 static size_t lds_backsub(const cba_problem* p) { return (lds_tab(p) + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
@@ -793,6 +794,7 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_backsub<NC, true>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_apply, (size_t)p->ncp * 8))) return rc;
+  if (p->ncp <= SMALL_N && (rc = allow_lds(k_small_solve<NC>, kSmallSolveLds))) return rc;
   return CBA_OK;
 }
 
@@ -1553,6 +1555,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL((k_schur_reg3<NC, SP, MW>), dim3(p->tile_grid), dim3(Reg3Cfg<NC>::LAUNCH_THREADS), Reg3Cfg<NC>::LDS_BYTES, p->stream, p->tp, p->Trec, p->partial, (const double*)p->tab);
     }
   }
+  bool small_solve = false;
   // single rank, nothing else adds to the diagonal camera blocks (heavy points, constraint rows) and the pair kernel has unprimed its sums: k_schur_finalize
   // folds the helper-thread sums of the diagonal blocks itself, k_reg_fold is not launched
   const bool fold_in_finalize = !p->n_heavy && !p->con.n_con && !p->sharded();
@@ -1582,12 +1585,20 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 1);
     }
     const long nn = (long)ncp * ncp;
-    hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
-                       p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw,
-                       fold_in_finalize ? (const double*)p->red : (const double*)nullptr, p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin);
+    small_solve = ncp <= SMALL_N && !p->sharded() && !p->chol_trace;
+    if (!small_solve)
+      hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
+                         p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw,
+                         fold_in_finalize ? (const double*)p->red : (const double*)nullptr, p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin);
   }
-  int rc;
-  {
+  int rc = CBA_OK;
+  if (small_solve) {  // small rigs: reduced system, factorisation and both substitutions in one workgroup (k_small_solve)
+    RoctxRange r2("cba:cholesky");
+    ScopedTimer t(p, T_CHOLESKY);
+    hipLaunchKernelGGL((k_small_solve<NC>), dim3(1), dim3(SMALL_THREADS), kSmallSolveLds, p->stream, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv,
+                       p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, fold_in_finalize ? (const double*)p->red : (const double*)nullptr,
+                       p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin, p->flags, p->s);
+  } else {
     RoctxRange r2("cba:cholesky");
     rc = run_cholesky(p);
   }
