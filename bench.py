@@ -155,6 +155,9 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         else:                  # RCCL: rank 0's unique id travels over the host-side control plane
             uid = control.broadcast_bytes(eng.comm_unique_id() if control.rank == 0 else None, 128)
             eng.comm_init(uid, control.rank, control.world)
+    t_plan = time.perf_counter()
+    eng.plan_wait()  # large handles start on a quickly made Schur plan: the timed region runs on the balanced one (cba_plan_wait)
+    t_plan = time.perf_counter() - t_plan
     info = eng.info()
     eng.begin(x0)
     run_iterations(eng, max(warmup, 1), solve_kw)
@@ -193,7 +196,7 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         "nct": 9 if any(b.n_params == 9 for b in par.blocks) else 6, "loss": prob.loss, "elapsed": elapsed, "steps": steps,
         "solves": solves, "timers": tm, "final_rms_px": rms, "initial_rms_px": rms0, "full_nfev": full.nfev,
         "full_status": full.status, "full_cost": full.cost, "info": info, "t_generate_s": t_gen,
-        "scene": sc, "par": par, "x0": x0, "x_full": full.x, "setup_s": t_setup, "rank": control.rank, "mix": last.mix,
+        "scene": sc, "par": par, "x0": x0, "x_full": full.x, "setup_s": t_setup, "plan_wait_s": t_plan, "rank": control.rank, "mix": last.mix,
     }
 
 
@@ -503,7 +506,7 @@ def _also_block(a, name):
         "workload": f"{a['n_cams']} cams / {a['n_points']} points / {a['n_obs']} obs, {a['loss']} loss",
         "nfev": a["full_nfev"], "status": a["full_status"], "accepted_steps": a["full_njev"] - 1,
         "rejected_trials": a["full_nfev"] - a["full_njev"], "initial_rms_px": round(a["initial_rms_px"], 4),
-        "setup_ms": round(a["setup_s"] * 1e3, 1),
+        "setup_ms": round(a["setup_s"] * 1e3, 1), "plan_wait_ms": round(a["plan_wait_s"] * 1e3, 1),
         # cfg5 is the largest single-GPU configuration of BASELINE.json: its full roofline block, not a digest
         "roofline": rf if (rf is None or name == "cfg5") else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic")},
     }
@@ -679,7 +682,8 @@ def _run(argv):
         "rccl_ranks": world if exchange_backend == "rccl" else 0,
         # device time of the all-reduces per step (HIP events around every exchange on rank 0's stream, instrumented repeat); None on one GPU
         "comm_ms_per_step": round(comm[0] / max(m["steps"], 1), 4) if comm and comm[1] else None,
-        "setup_ms": round(m["setup_s"] * 1e3, 1),  # cba_create for this workload (sort, Schur plan, upload): once per problem structure, not in `value`
+        "setup_ms": round(m["setup_s"] * 1e3, 1),  # cba_create for this workload (sort, first Schur plan, upload): once per problem structure, not in `value`
+        "plan_wait_ms": round(m["plan_wait_s"] * 1e3, 1),  # ... and how much longer the balanced plan took (a solve would have started meanwhile)
         "final_rms_px": round(m["final_rms_px"], 6),
         "initial_rms_px": round(m["initial_rms_px"], 4),
         # accepted iterations re-linearise (njev - 1 of them after x0); the other trial points were rejected

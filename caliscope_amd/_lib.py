@@ -135,6 +135,7 @@ SIGNATURES = {
     "cba_normal_blocks": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "cba_reduced_system": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cba_set_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "cba_plan_wait": (C.c_int, [C.c_void_p]),
     "cba_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "cba_timer_count": (C.c_int, []),
     "cba_timer_name": (C.c_char_p, [C.c_int32]),

@@ -900,11 +900,17 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   // the Schur plan of the register kernels is dealt on its own thread from here on (declared after the vectors it reads: joined before they go)
   p->eval_only = opt && opt->evaluation_only != 0;
   choose_schur_groups(p);
-  // CBA_PLAN=swap (opt-in): start with the cheap plan, swap the dealt one in when its thread is done.  Not with fixed-order sums (the iteration the
-  // swap lands on would vary from run to run) nor with the profiling build (it wants the plan it profiles).
-  bool plan_two_stage = false;
+  // Two-stage plan: start with the CHEAP plan (a third of the host time, pair kernel 1.5-1.75x slower) and swap the dealt one in when its thread is
+  // done — the handle is ready 10 ms (cfg4) to half a second (cfg5) earlier and a solve of a handful of iterations may be over before the dealt plan
+  // would have been.  Default from kTwoStageObs observations on (below, the dealt plan is ready before the uploads are); CBA_PLAN=full / swap force
+  // one way, cba_plan_wait makes a handle final (benchmarks).  Not with fixed-order sums (the iteration the swap lands on would vary from run to run)
+  // nor with the profiling build (it wants the plan it profiles).
+  constexpr long kTwoStageObs = 500000;
   const char* plan_env = std::getenv("CBA_PLAN");
-  if (plan_env) plan_two_stage = std::strcmp(plan_env, "swap") == 0 && !(opt && opt->deterministic) && !p->schur_clock;
+  bool plan_two_stage = p->N >= kTwoStageObs;
+  if (plan_env && std::strcmp(plan_env, "swap") == 0) plan_two_stage = true;
+  if (plan_env && (std::strcmp(plan_env, "full") == 0 || std::strcmp(plan_env, "cheap") == 0)) plan_two_stage = false;
+  if ((opt && opt->deterministic) || p->schur_clock) plan_two_stage = false;
   if (!p->eval_only) {
     Reg2Params prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
     if (plan_env) prm.cheap = std::strcmp(plan_env, "cheap") == 0;  // (measurements: the cheap plan for good)
@@ -1117,6 +1123,14 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (plan_timing) fprintf(stderr, "cba_create: %.3f s in total\n", t_now() - t_enter);
   *out = p;
   return CBA_OK;
+}
+
+static int maybe_swap_plan(cba_problem* p, bool wait);
+
+int cba_plan_wait(cba_problem* p) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_plan_wait: null problem");
+  HIPCHK(hipSetDevice(p->device));
+  return maybe_swap_plan(p, true);
 }
 
 int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
@@ -1454,11 +1468,14 @@ static int run_step_scalars(cba_problem* p, bool formula_w, bool compact = false
   return exchange(p, SLOT(20), false);  // ||w||^2 and the flags
 }
 
-// CBA_PLAN=swap: the handle started with the cheap Schur plan; once the plan thread has the dealt one, the next damped step uploads it and goes on
-// with it (the cheap plan's buffers stay in the arena until the handle goes).  Called between iterations by the thread that drives the handle.
-static int maybe_swap_plan(cba_problem* p) {
+// Two-stage plan: the handle started with the cheap Schur plan; once the plan thread has the dealt one, the next damped step uploads it and goes on
+// with it (the cheap plan's buffers stay in the arena until the handle goes).  Called between iterations by the thread that drives the handle;
+// `wait`: block until the dealt plan is there (cba_plan_wait).
+static int maybe_swap_plan(cba_problem* p, bool wait) {
   PlanTask* task = p->plan_task;
-  if (!task || task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
+  if (!task) return CBA_OK;
+  if (wait) task->wait_stage(2);
+  if (task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
   int rc = CBA_OK;
   if (task->rc == 0) {
     const bool timing = plan_timing_on();
@@ -1523,7 +1540,7 @@ template <int NC>
 static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, bool compact = false) {
   const int ncp = p->ncp;
   if (p->plan_task) {
-    const int rcs = maybe_swap_plan(p);
+    const int rcs = maybe_swap_plan(p, false);
     if (rcs) return rcs;
   }
   RoctxRange range("cba:damped_step");

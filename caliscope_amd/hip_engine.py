@@ -237,6 +237,10 @@ class HipEngine:
         """Join an in-process device group (one host thread per member; returns when all have joined)."""
         self._check(self.lib.cba_group_join(self._h, group.handle, int(rank)), "cba_group_join")
 
+    def plan_wait(self) -> None:
+        """Block until the balanced Schur plan is installed (large handles start with a quickly made one): benchmarks call it before timing."""
+        self._check(self.lib.cba_plan_wait(self._h), "cba_plan_wait")
+
     def set_loss(self, loss: str, f_scale: float) -> None:
         """Another robust loss on the same observations (``cba_set_loss``): the Schur plan and the device buffers stay."""
         self._check(self.lib.cba_set_loss(self._h, LOSS_CODES[loss], float(f_scale)), "cba_set_loss")

@@ -192,6 +192,8 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   return CBA_OK;
 }
 
+int cba_plan_wait(cba_problem* p) { return p ? CBA_OK : failf(CBA_ERR_INVALID, "cba_plan_wait: null problem"); }  // (no plan in the dense test build)
+
 int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
   if (!p || !p->model) return failf(CBA_ERR_INVALID, "cba_set_loss: null problem");
   if (loss < CBA_LOSS_LINEAR || loss > CBA_LOSS_ARCTAN || (loss != CBA_LOSS_LINEAR && !(f_scale > 0.0))) return failf(CBA_ERR_INVALID, "cba_set_loss: bad loss / f_scale");

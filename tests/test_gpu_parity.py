@@ -77,6 +77,32 @@ def _case(name):
     return sc, par, x0, loss, fs
 
 
+def test_two_stage_plan_gives_the_same_solve(monkeypatch):
+    """Handles of 500k observations or more start on a quickly made Schur plan and swap the balanced one in when its host thread is done
+    (forced here on a small problem with CBA_PLAN=swap; CBA_PLAN=full is the one-stage route): the plan decides the ORDER of the pair sums and the
+    speed of the pair kernel, not the sums — same evaluations, same cost; cba_plan_wait makes a handle final."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0 = small_problem(n_cams=24, n_points=3000, k=8)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    out = {}
+    for mode in ("full", "swap"):
+        monkeypatch.setenv("CBA_PLAN", mode)
+        eng = HipEngine(prob)
+        first = eng.solve(x0)                 # (swap: starts on the cheap plan, picks the dealt one up between two iterations if it is ready)
+        eng.plan_wait()
+        second = eng.solve(x0)                # on the balanced plan for sure
+        eng.begin(x0); eng.linearize()
+        assert eng.newton_step(1e-4).ok
+        out[mode] = (first, second, eng.get_vector(3).copy(), eng.reduced_system()[0])
+        eng.close()
+    for k in (0, 1):
+        a, b = out["full"][k], out["swap"][k]
+        assert a.status == b.status and abs(a.nfev - b.nfev) <= 1 and abs(a.cost - b.cost) <= 1e-10 * a.cost
+    assert np.abs(out["full"][3] - out["swap"][3]).max() <= 1e-12 * np.abs(out["full"][3]).max()
+    assert np.abs(out["full"][2] - out["swap"][2]).max() <= 1e-9 * np.abs(out["full"][2]).max()
+
+
 def test_thousand_cameras_evaluation_and_step():
     """The reference loops over any number of cameras (core/reprojection.py:75-119); rounds 1-3 stopped where the packed per-camera normal blocks
     (27 doubles each) no longer fit the LDS (~650 six-parameter cameras).  Beyond that the linearisation adds a thread's register sums to ONE global
