@@ -586,6 +586,27 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
   if (bad) flags[0] = 1;
 }
 
+// set-up on the device (cba_create): the sorted observation coordinates and the camera-sorted copy of k_build_cs are GATHERED here from the caller's
+// array and a 4-byte permutation instead of being permuted on the host and uploaded (40 bytes per observation less over PCIe, no random 16-byte
+// reads on the host)
+__global__ void __launch_bounds__(256)
+k_gather_uv(const double* __restrict__ uv_raw, const int* __restrict__ order, long n, double* __restrict__ u, double* __restrict__ v) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double2 w = reinterpret_cast<const double2*>(uv_raw)[order[i]];
+    u[i] = w.x; v[i] = w.y;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_cs_fill(const int* __restrict__ perm, const int* __restrict__ sc_obs, const int* __restrict__ sc_p0, const double* __restrict__ u,
+          const double* __restrict__ v, const int* __restrict__ cam, const int* __restrict__ pt, double* __restrict__ cu, double* __restrict__ cv,
+          int* __restrict__ ccam, int* __restrict__ cptl) {
+  const int s = blockIdx.x, o0 = sc_obs[s], o1 = sc_obs[s + 1], p0 = sc_p0[s];
+  for (int j = o0 + threadIdx.x; j < o1; j += 256) {
+    const int i = perm[j];
+    cu[j] = u[i]; cv[j] = v[i]; ccam[j] = cam[i]; cptl[j] = pt[i] - p0;
+  }
+}
+
 // unpack the reduced camera blocks: gradient -> gvec camera part
 template <int NC>
 __global__ void k_unpack_camera_grad(const double* __restrict__ Upacked, const int* __restrict__ cam_off,

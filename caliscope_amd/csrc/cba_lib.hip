@@ -863,15 +863,13 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (nch < 0) return bail((int)nch);
   p->n_chunks = (int)nch;
   lap("sort by point, chunk table");
-  HostVec<double> hu(p->N), hv(p->N);
   HostVec<int> hcam(p->N), hpt(p->N), hord(p->N);
   std::vector<int> hps((size_t)p->P + 1), hcs((size_t)nch + 1);
   {  // gather into the sorted order, by a few host threads (1M observations: 6 ms on one)
     auto gather = [&](int64_t lo, int64_t hi) {
       for (int64_t i = lo; i < hi; ++i) {
         const int64_t o = order[i];
-        hu[i] = d->obs_uv[2 * o]; hv[i] = d->obs_uv[2 * o + 1];
-        hcam[i] = d->obs_cam[o]; hpt[i] = d->obs_pt[o]; hord[i] = (int)o;
+        hcam[i] = d->obs_cam[o]; hpt[i] = d->obs_pt[o]; hord[i] = (int)o;  // (the coordinates are gathered on the device: k_gather_uv)
       }
     };
     const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), p->N / 65536));
@@ -951,9 +949,14 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
   lap("reorder on host");
-  TRY(dev_upload(p, &p->obs_u, hu)); TRY(dev_upload(p, &p->obs_v, hv));
   TRY(dev_upload(p, &p->obs_cam, hcam)); TRY(dev_upload(p, &p->obs_pt, hpt));
   TRY(dev_upload(p, &p->order, hord)); TRY(dev_upload(p, &p->pt_start, hps)); TRY(dev_upload(p, &p->chunk_start, hcs));
+  {  // the caller's (u, v) pairs as they are, sorted on the device (the raw copy is scratch: v2's memory is not big enough, it stays in the arena)
+    double* uv_raw = nullptr;
+    TRY(dev_alloc(p, &uv_raw, (size_t)2 * p->N)); TRY(dev_alloc(p, &p->obs_u, (size_t)p->N)); TRY(dev_alloc(p, &p->obs_v, (size_t)p->N));
+    HIPBAIL(hipMemcpy(uv_raw, d->obs_uv, (size_t)2 * p->N * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gather_uv, dim3((int)std::min<long>((p->N + 255) / 256, 2048)), dim3(256), 0, p->stream, (const double*)uv_raw, (const int*)p->order, p->N, p->obs_u, p->obs_v);
+  }
   if (opt && opt->deterministic) {
     // fixed-order per-camera sums (k_build / k_tprep, det_round): per chunk the observation order by camera and the camera offsets
     const int need = (p->C * DET_ROUND + BLOCK - 1) / BLOCK;
@@ -1007,8 +1010,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
         q = e;
       }
       const int n_sc = (int)sc_p0.size();
-      HostVec<double> cu(p->N), cv(p->N);
-      HostVec<int> ccam(p->N), cptl(p->N);
+      HostVec<int> cperm(p->N);  // position in (super-chunk, camera, point) order -> sorted observation; the copy itself is made on the device (k_cs_fill)
       auto fill = [&](int s0, int s1) {
         std::vector<int> start((size_t)p->C + 1);
         for (int sidx = s0; sidx < s1; ++sidx) {
@@ -1017,8 +1019,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
           for (int i = o0; i < o1; ++i) start[(size_t)hcam[i] + 1]++;
           for (int c = 0; c < p->C; ++c) start[(size_t)c + 1] += start[c];
           for (int i = o0; i < o1; ++i) {  // stable: point order inside a camera
-            const int dst = o0 + start[hcam[i]]++;
-            cu[dst] = hu[i]; cv[dst] = hv[i]; ccam[dst] = hcam[i]; cptl[dst] = hpt[i] - sc_p0[sidx];
+            cperm[o0 + start[hcam[i]]++] = i;
           }
         }
       };
@@ -1031,8 +1032,12 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
       }
       double *dcu = nullptr, *dcv = nullptr;
       int *dcc = nullptr, *dcp = nullptr, *dso = nullptr, *dp0 = nullptr, *dnp = nullptr;
-      TRY(dev_upload(p, &dcu, cu)); TRY(dev_upload(p, &dcv, cv)); TRY(dev_upload(p, &dcc, ccam)); TRY(dev_upload(p, &dcp, cptl));
+      int* dperm = nullptr;
+      TRY(dev_upload(p, &dperm, cperm));
+      TRY(dev_alloc(p, &dcu, (size_t)p->N)); TRY(dev_alloc(p, &dcv, (size_t)p->N)); TRY(dev_alloc(p, &dcc, (size_t)p->N)); TRY(dev_alloc(p, &dcp, (size_t)p->N));
       TRY(dev_upload(p, &dso, sc_obs)); TRY(dev_upload(p, &dp0, sc_p0)); TRY(dev_upload(p, &dnp, sc_np));
+      hipLaunchKernelGGL(k_cs_fill, dim3(n_sc), dim3(256), 0, p->stream, (const int*)dperm, (const int*)dso, (const int*)dp0, (const double*)p->obs_u, (const double*)p->obs_v,
+                         (const int*)p->obs_cam, (const int*)p->obs_pt, dcu, dcv, dcc, dcp);
       p->cs = CsPlan{dcu, dcv, dcc, dcp, dso, dp0, dnp, n_sc, (pmax + 31) / 32 * 32};
     }
   }
