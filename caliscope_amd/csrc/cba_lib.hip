@@ -589,13 +589,6 @@ constexpr size_t kSmallSolveLds = ((size_t)(SMALL_N + 1) * SMALL_LD + (size_t)2 
 static size_t lds_backsub(const cba_problem* p) { return (lds_tab(p) + p->lay.ncp_pad + 3 * CHUNK) * 8; }
 
 
-// Workgroup -> tile binding shared by the tile plans (csrc/wg_binding.h): sets the grid of the tiled Schur kernel
-static WgBinding bind_workgroups(cba_problem* p, const std::vector<int>& TCB, int nT, int max_blocks, const std::vector<double>* tile_cost = nullptr) {
-  WgBinding out = cba::bind_workgroups(TCB, nT, max_blocks, true, tile_cost);
-  p->tile_grid = out.grid;
-  return out;
-}
-
 // Plan of the pair kernel (schur_plan.h builds it on the host).  The dealing is ~1 us of host work per observation and needs nothing but the
 // sorted camera indices, so cba_create starts it on a thread of its own as soon as those exist (PlanTask) and does its uploads, the camera-sorted
 // copy and the allocations meanwhile; finish_reg2_tile_plan then binds the workgroups and uploads the plan.
@@ -620,6 +613,110 @@ static Reg2Params reg2_params(const cba_problem* p) {
   return prm;
 }
 
+// A Schur plan bound to workgroups and resident on the device, ready to be made the handle's current one (apply_install: a few pointer copies).
+// Foreground (cba_create, the cheap or the only plan): device memory from the handle's arena.  Background (the dealt plan of a two-stage handle):
+// the PLAN THREAD allocates and uploads while the solve runs on the cheap plan — done on the solver's thread, in the middle of an iteration, the
+// allocations and the 46 MB upload of cfg4's plan held a 3 ms solve up for 30-60 ms.
+struct PlanInstall {
+  TilePlan tp{};
+  int tile_grid = 0, n_tile_chunks = 0, reg_reduce_y = 4;
+  long tile_stream_len = 0, n_pairs = 0;
+  double lane_util = 0.0;
+  int* tile_wg_begin = nullptr;
+  std::vector<int> h_wgb;
+  std::vector<std::pair<void*, size_t>> owned;  // background: its own hipMalloc'ed buffers (handed to the handle's allocation list by apply_install)
+  int rc = CBA_OK;
+};
+
+template <int NC, typename KCfg, typename Upload>
+static int prepare_install(const cba_problem* p, Reg2Plan& plan, const Reg2Params& prm, int max_blocks, Upload&& upload, PlanInstall& out) {
+  const int G = p->G, g = p->gsz, C = p->C;
+  const int nT = p->n_tiles;
+  const bool plan_timing = plan_timing_on();
+  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = t_now();
+  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
+  constexpr int CT = KCfg::CODE_THREADS;
+  out.n_tile_chunks = plan.tile_chunk_begin[nT];
+  out.tile_stream_len = (long)plan.obs.size() - 2 * KCfg::SCHUNK;
+  out.n_pairs = plan.n_pairs;
+  out.lane_util = plan.lane_iters > 0 ? (double)plan.n_pairs / (double)plan.lane_iters : 0.0;
+  if (plan_timing)
+    fprintf(stderr, "  plan: %d tiles x %d regions, %d chunks (%.1f slots each), %ld pairs, lane utilisation %.3f, LDS cycles per 16-lane read group %.2f (arrival order %.2f)\n",
+            nT, plan.n_regions, out.n_tile_chunks, out.n_tile_chunks ? (double)out.tile_stream_len / out.n_tile_chunks : 0.0, plan.n_pairs, out.lane_util,
+            plan.lds_groups ? (double)plan.lds_cycles / plan.lds_groups : 0.0, plan.lds_groups ? (double)plan.lds_cycles_arrival / plan.lds_groups : 0.0);
+  // cost of a chunk: gather + barrier (in units of one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its
+  // slowest wave
+  const double cost_a = 2.0;
+  const std::vector<double> tile_cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, KCfg::CODE_WAVES, KCfg::REG_BLOCK / KCfg::SPLIT / WAVE, cost_a);
+  const WgBinding bind = cba::bind_workgroups(plan.tile_chunk_begin, nT, max_blocks, true, &tile_cost);
+  out.tile_grid = bind.grid;
+  lap("workgroup binding");
+  std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
+  for (int a = 0; a <= G; ++a) {
+    gcam[a] = std::min(a * g, C);
+    gpar[a] = (gcam[a] < C) ? p->h_cam_off[gcam[a]] : p->ncp;
+  }
+  {
+    int t = 0;
+    for (int a = 0; a < G; ++a)
+      for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
+  }
+  int rc;
+  int *dob = nullptr, *dcs = nullptr, *dcode = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
+      *dgc = nullptr, *dgp = nullptr;
+  unsigned *dcodes = nullptr, *dnit = nullptr;
+#define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
+  TRYP(upload(&dob, plan.obs)); TRYP(upload(&dcs, plan.chunk_start)); TRYP(upload(&dcode, plan.code_start));
+  TRYP(upload(&dcodes, plan.codes)); TRYP(upload(&dnit, plan.nit));
+  TRYP(upload(&dwf, bind.wfirst)); TRYP(upload(&dwt, bind.wt)); TRYP(upload(&dwe, bind.wend)); TRYP(upload(&dws, bind.wstride));
+  TRYP(upload(&dta, ta)); TRYP(upload(&dtb, tb)); TRYP(upload(&dgc, gcam)); TRYP(upload(&dgp, gpar));
+  TRYP(upload(&out.tile_wg_begin, bind.wgb));
+#undef TRYP
+  out.h_wgb = bind.wgb;
+  {  // k_reg_reduce splits a tile's partial rows 4 or 16 ways
+    int rows = 0;
+    for (int t = 0; t < nT; ++t) rows = std::max(rows, (bind.wgb[t + 1] - bind.wgb[t]) * std::max(prm.rep, 1));
+    out.reg_reduce_y = rows > 96 ? REG_REDUCE_Y_MAX : 4;
+  }
+  lap("upload");
+  TilePlan tp{};
+  tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
+  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g;
+  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
+  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
+  out.tp = tp;
+  return CBA_OK;
+}
+
+// makes a prepared plan the handle's current one (the thread that drives the handle, between two iterations)
+static void apply_install(cba_problem* p, PlanInstall& in) {
+  p->tp = in.tp;
+  p->tile_grid = in.tile_grid; p->n_tile_chunks = in.n_tile_chunks; p->reg_reduce_y = in.reg_reduce_y;
+  p->tile_stream_len = in.tile_stream_len; p->n_pairs = in.n_pairs; p->plan_lane_util = in.lane_util;
+  p->tile_wg_begin = in.tile_wg_begin;
+  p->h_tile_wg_begin = std::move(in.h_wgb);
+  for (auto& o : in.owned) { p->allocs.push_back(o.first); p->alloc_bytes.push_back(o.second); p->device_bytes += (long)o.second; }
+  in.owned.clear();
+}
+
+// background (the plan thread of a two-stage handle): binds the dealt plan and uploads it into buffers of its own
+static int prepare_install_background(const cba_problem* p, Reg2Plan& plan, const Reg2Params& prm, PlanInstall& in) {
+  if (hipSetDevice(p->device) != hipSuccess) return CBA_ERR_HIP;
+  auto upload = [&](auto** out, const auto& h) -> int {
+    using T = typename std::remove_pointer<typename std::remove_pointer<decltype(out)>::type>::type;
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, bytes) != hipSuccess) return CBA_ERR_HIP;
+    in.owned.emplace_back(ptr, bytes);
+    if (!h.empty() && hipMemcpy(ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return CBA_ERR_HIP;
+    *out = static_cast<T*>(ptr);
+    return CBA_OK;
+  };
+  return (p->nct == 9) ? prepare_install<9, Reg3Cfg<9>>(p, plan, prm, p->plan_max_blocks, upload, in)
+                       : prepare_install<6, Reg3Cfg<6>>(p, plan, prm, p->plan_max_blocks, upload, in);
+}
+
 // The dealing on its own thread.  One stage (default): cba_create waits for the dealt plan before it returns.  Two stages (CBA_PLAN=swap): the thread
 // first makes the CHEAP plan (Reg2Params::cheap: a quarter of the host time), cba_create goes on with that one and returns; the dealt plan follows on
 // the same thread and the first damped step that finds it ready swaps it in (maybe_swap_plan).  The task then owns the two host arrays the thread
@@ -627,6 +724,8 @@ static Reg2Params reg2_params(const cba_problem* p) {
 struct PlanTask {
   Reg2Params prm;
   Reg2Plan cheap, plan;
+  PlanInstall install;                 // two stages: the dealt plan, bound and resident (made by the thread itself)
+  const cba_problem* handle = nullptr; // two stages: what the thread reads to bind the dealt plan (camera groups, offsets, budget: fixed before it starts)
   int rc_cheap = 0, rc = 0;
   double seconds_cheap = 0.0, seconds = 0.0;
   bool two_stage = false;
@@ -637,8 +736,9 @@ struct PlanTask {
   std::thread th;
   HostVec<int> hcam_keep;
   std::vector<int> hps_keep;
-  void start(const Reg2Params& params, const int* hcam, const int* hps, bool two) {
+  void start(const Reg2Params& params, const int* hcam, const int* hps, bool two, const cba_problem* h) {
     prm = params;
+    handle = h;
     prm.cancel = &cancel;
     two_stage = two;
     th = std::thread([this, hcam, hps] {
@@ -652,7 +752,15 @@ struct PlanTask {
         publish(1);
       }
       const auto t0 = std::chrono::steady_clock::now();
+      // second stage = background work beside a running solve: half of the CPUs the process may use (all of them would leave the thread that drives
+      // the GPU waiting for a core — or, under a cgroup quota, frozen with the rest of the process: usable_cpus)
+      if (two_stage && prm.threads == 0) prm.threads = (int)std::max(1u, std::min(32u, usable_cpus() / 2));
       rc = (two_stage && rc_cheap) ? rc_cheap : build_reg2_plan(prm, hcam, hps, plan);
+      if (two_stage && !rc && !cancel.load()) {  // allocate and upload HERE: the thread that drives the handle only swaps pointers (apply_install)
+        rc = prepare_install_background(handle, plan, prm, install);
+        if (rc) for (auto& o : install.owned) (void)hipFree(o.first);
+        if (rc) install.owned.clear();
+      }
       seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       publish(2);
     });
@@ -664,78 +772,24 @@ struct PlanTask {
   ~PlanTask() {
     cancel.store(true);
     if (th.joinable()) th.join();
+    for (auto& o : install.owned) (void)hipFree(o.first);  // (a prepared plan nobody took over)
   }
 };
-
-template <int NC, typename KCfg>
-static int finish_reg2_tile_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm, const std::vector<int>& cam_off, int max_blocks) {
-  const int G = p->G, g = p->gsz, C = p->C;
-  const int nT = p->n_tiles;
-  const bool plan_timing = plan_timing_on();
-  auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_mark = t_now();
-  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "  plan: %-34s %.3f s\n", what, t - t_mark); t_mark = t; } };
-  constexpr int CT = KCfg::CODE_THREADS;
-  p->n_tile_chunks = plan.tile_chunk_begin[nT];
-  p->tile_stream_len = (long)plan.obs.size() - 2 * KCfg::SCHUNK;
-  p->n_pairs = plan.n_pairs;
-  p->plan_lane_util = plan.lane_iters > 0 ? (double)plan.n_pairs / (double)plan.lane_iters : 0.0;
-  if (plan_timing)
-    fprintf(stderr, "  plan: %d tiles x %d regions, %d chunks (%.1f slots each), %ld pairs, lane utilisation %.3f, LDS cycles per 16-lane read group %.2f (arrival order %.2f)\n",
-            nT, plan.n_regions, p->n_tile_chunks, p->n_tile_chunks ? (double)p->tile_stream_len / p->n_tile_chunks : 0.0, plan.n_pairs, p->plan_lane_util,
-            plan.lds_groups ? (double)plan.lds_cycles / plan.lds_groups : 0.0, plan.lds_groups ? (double)plan.lds_cycles_arrival / plan.lds_groups : 0.0);
-  // cost of a chunk: gather + barrier (in units of one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its
-  // slowest wave
-  const double cost_a = 2.0;
-  const std::vector<double> tile_cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, KCfg::CODE_WAVES, KCfg::REG_BLOCK / KCfg::SPLIT / WAVE, cost_a);
-  const WgBinding bind = bind_workgroups(p, plan.tile_chunk_begin, nT, max_blocks, &tile_cost);
-  lap("workgroup binding");
-  std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
-  for (int a = 0; a <= G; ++a) {
-    gcam[a] = std::min(a * g, C);
-    gpar[a] = (gcam[a] < C) ? cam_off[gcam[a]] : p->ncp;
-  }
-  {
-    int t = 0;
-    for (int a = 0; a < G; ++a)
-      for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
-  }
-  int rc;
-  int *dob = nullptr, *dcs = nullptr, *dcode = nullptr, *dwf = nullptr, *dwt = nullptr, *dwe = nullptr, *dws = nullptr, *dta = nullptr, *dtb = nullptr,
-      *dgc = nullptr, *dgp = nullptr;
-  unsigned *dcodes = nullptr, *dnit = nullptr;
-#define TRYP(e) do { rc = (e); if (rc) return rc; } while (0)
-  TRYP(dev_upload(p, &dob, plan.obs)); TRYP(dev_upload(p, &dcs, plan.chunk_start)); TRYP(dev_upload(p, &dcode, plan.code_start));
-  TRYP(dev_upload(p, &dcodes, plan.codes)); TRYP(dev_upload(p, &dnit, plan.nit));
-  TRYP(dev_upload(p, &dwf, bind.wfirst)); TRYP(dev_upload(p, &dwt, bind.wt)); TRYP(dev_upload(p, &dwe, bind.wend)); TRYP(dev_upload(p, &dws, bind.wstride));
-  TRYP(dev_upload(p, &dta, ta)); TRYP(dev_upload(p, &dtb, tb)); TRYP(dev_upload(p, &dgc, gcam)); TRYP(dev_upload(p, &dgp, gpar));
-  TRYP(dev_upload(p, &p->tile_wg_begin, bind.wgb));
-#undef TRYP
-  p->h_tile_wg_begin = bind.wgb;
-  {  // k_reg_reduce splits a tile's partial rows 4 or 16 ways
-    int rows = 0;
-    for (int t = 0; t < nT; ++t) rows = std::max(rows, (bind.wgb[t + 1] - bind.wgb[t]) * std::max(prm.rep, 1));
-    p->reg_reduce_y = rows > 96 ? REG_REDUCE_Y_MAX : 4;
-  }
-  lap("upload");
-  TilePlan tp{};
-  tp.chunk_start = dcs; tp.wg_first = dwf; tp.wg_end = dwe; tp.wg_tile = dwt; tp.wg_stride = dws; tp.tile_a = dta; tp.tile_b = dtb;
-  tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g;
-  tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
-  tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
-  p->tp = tp;
-  return CBA_OK;
-}
 
 static void drop_plan_task(cba_problem* p) {
   delete p->plan_task;
   p->plan_task = nullptr;
 }
 
-// binds and uploads `plan`
+// foreground: binds `plan`, uploads it into the handle's arena and makes it current
 static int install_reg2_plan(cba_problem* p, Reg2Plan& plan, const Reg2Params& prm) {
-  const int mb = p->plan_max_blocks;
-  return (p->nct == 9) ? finish_reg2_tile_plan<9, Reg3Cfg<9>>(p, plan, prm, p->h_cam_off, mb) : finish_reg2_tile_plan<6, Reg3Cfg<6>>(p, plan, prm, p->h_cam_off, mb);
+  PlanInstall in;
+  auto upload = [&](auto** out, const auto& h) { return dev_upload(p, out, h); };
+  const int rc = (p->nct == 9) ? prepare_install<9, Reg3Cfg<9>>(p, plan, prm, p->plan_max_blocks, upload, in)
+                               : prepare_install<6, Reg3Cfg<6>>(p, plan, prm, p->plan_max_blocks, upload, in);
+  if (rc) return rc;
+  apply_install(p, in);
+  return CBA_OK;
 }
 
 // Camera groups of the pair kernel: host-only (camera count), decided before anything touches the device so that the plan can be dealt while
@@ -872,7 +926,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
         hcam[i] = d->obs_cam[o]; hpt[i] = d->obs_pt[o]; hord[i] = (int)o;  // (the coordinates are gathered on the device: k_gather_uv)
       }
     };
-    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), p->N / 65536));
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, usable_cpus()), p->N / 65536));
     std::vector<std::thread> pool;
     for (int t = 1; t < nth; ++t) pool.emplace_back(gather, p->N * t / nth, p->N * (t + 1) / nth);
     gather(0, p->N / nth);
@@ -913,7 +967,14 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     Reg2Params prm = (nct == 9) ? reg2_params<9, Reg3Cfg<9>>(p) : reg2_params<6, Reg3Cfg<6>>(p);
     if (plan_env) prm.cheap = std::strcmp(plan_env, "cheap") == 0;  // (measurements: the cheap plan for good)
     p->plan_task = new PlanTask();  // owned by the handle: cba_destroy (also through bail) cancels and joins it while the arrays it reads are alive
-    p->plan_task->start(prm, hcam.data(), hps.data(), plan_two_stage);
+    {  // the workgroup budget of the pair kernel, fixed before the plan thread may want it (two stages: it binds the dealt plan itself)
+      const int cus0 = n_cus > 0 ? n_cus : 256;
+      const size_t tile_lds = (nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES;
+      const int per_cu = std::min(std::max<int>(1, (int)((160 * 1024) / tile_lds)), (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // LDS, register budget
+      const int mb0 = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus0;
+      p->plan_max_blocks = std::min(cus0 * per_cu, std::max(mb0, cus0));  // no partial last round
+    }
+    p->plan_task->start(prm, hcam.data(), hps.data(), plan_two_stage, p);
   }
 
   {
@@ -1024,7 +1085,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
         }
       };
       {
-        const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n_sc / 64));
+        const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, usable_cpus()), n_sc / 64));
         std::vector<std::thread> pool;
         for (int t = 1; t < nth; ++t) pool.emplace_back(fill, (int)((int64_t)n_sc * t / nth), (int)((int64_t)n_sc * (t + 1) / nth));
         fill(0, (int)((int64_t)n_sc / nth));
@@ -1068,16 +1129,12 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (nct == 9) TRY(configure_kernels<9>(p)); else TRY(configure_kernels<6>(p));
   lap("reorder, upload, allocate");
   if (!p->eval_only) {
-    const size_t tile_lds = (nct == 9) ? Reg3Cfg<9>::LDS_BYTES : Reg3Cfg<6>::LDS_BYTES;
-    const int per_cu = std::min(std::max<int>(1, (int)((160 * 1024) / tile_lds)), (nct == 9) ? RegCfg<9>::PER_CU : RegCfg<6>::PER_CU);  // LDS, register budget
-    const int resident = cus * per_cu;  // no partial last round
     PlanTask& task = *p->plan_task;
     const double t_wait = t_now();
     task.wait_stage(task.two_stage ? 1 : 2);
     if (plan_timing)
       fprintf(stderr, "  plan: %s took %.3f s on its own threads, started before the uploads; waited %.3f s for it\n", task.two_stage ? "the cheap plan" : "dealt streams and codes",
               task.two_stage ? task.seconds_cheap : task.seconds, t_now() - t_wait);
-    p->plan_max_blocks = std::min(resident, std::max(max_blocks, cus));
     if (task.two_stage ? task.rc_cheap : task.rc)
       return bail(fail(CBA_ERR_UNSUPPORTED, "a world point has more observations inside one camera-group tile than a chunk of the pair plan holds (%d records)",
                        (nct == 9) ? Reg3Cfg<9>::SCHUNK : Reg3Cfg<6>::SCHUNK));
@@ -1088,7 +1145,8 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   lap("Schur plan (streams, pairs, upload)");
   const long w_build = (long)p->C * ustride;
   p->partial_width = w_build;
-  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems);
+  // (+ 1/8: the dealt plan of a two-stage handle has a few chunks — on small problems: workgroups — more or fewer than the cheap one)
+  p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)(p->tile_grid + p->tile_grid / 8 + 1) * std::max(p->tp.rep, 1) * p->tp.tile_elems);
   TRY(dev_alloc(p, &p->partial, p->partial_capacity));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
   TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
@@ -1483,20 +1541,16 @@ static int maybe_swap_plan(cba_problem* p, bool wait) {
   if (task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
   int rc = CBA_OK;
   if (task->rc == 0) {
-    const bool timing = plan_timing_on();
-    const auto t0 = std::chrono::steady_clock::now();
-    rc = install_reg2_plan(p, task->plan, task->prm);
-    if (!rc) {
-      const size_t need = (size_t)p->tile_grid * std::max(p->tp.rep, 1) * p->tp.tile_elems;
-      if (need > p->partial_capacity) {  // (the dealt plan has a few chunks more or fewer than the cheap one; small problems get a workgroup per chunk)
-        rc = dev_alloc(p, &p->partial, need);
-        if (!rc) p->partial_capacity = need;
-      }
+    const size_t need = (size_t)task->install.tile_grid * std::max(task->install.tp.rep, 1) * task->install.tp.tile_elems;
+    if (need > p->partial_capacity) {  // (the dealt plan has a few chunks more or fewer than the cheap one; cba_create leaves headroom: rare)
+      rc = dev_alloc(p, &p->partial, need);
+      if (!rc) p->partial_capacity = need;
     }
-    if (!rc) p->plan_is_cheap = false;
-    if (timing)
-      fprintf(stderr, "  plan: the dealt plan (%.3f s on its own threads) swapped in, %.3f s to bind and upload it\n", task->seconds,
-              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (!rc) {
+      apply_install(p, task->install);
+      p->plan_is_cheap = false;
+      if (plan_timing_on()) fprintf(stderr, "  plan: the dealt plan (%.3f s on its own threads, upload included) swapped in\n", task->seconds);
+    }
   }
   drop_plan_task(p);
   return rc;

@@ -30,6 +30,9 @@
 // records that want 16 different residues; a greedy pass plus two refinement sweeps assign residues, then slots.
 #pragma once
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <cstdint>
 #include <cmath>
@@ -56,6 +59,34 @@ struct RawVec {
   T* begin() { return p.get(); }
   T* end() { return p.get() + n; }
 };
+
+// CPUs this process may actually burn: the hardware count capped by the cgroup's CPU quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us).  A container
+// that shows 256 cores and is throttled to 16 CPUs of quota (the MI355X boxes of rounds 1-4) freezes EVERY thread of the process — the one driving the
+// GPU included — for the rest of the 100 ms period once 64 plan threads have used the quota up: measured, a cfg4 solve of 3 ms took 60 ms while the
+// dealt plan was being made in the background.
+inline unsigned usable_cpus() {
+  static const unsigned n = [] {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    auto read = [](const char* path, long long* a, long long* b) {
+      FILE* f = std::fopen(path, "r");
+      if (!f) return 0;
+      char x[64] = {0}, y[64] = {0};
+      const int got = std::fscanf(f, "%63s %63s", x, y);
+      std::fclose(f);
+      if (got >= 1) *a = std::strcmp(x, "max") == 0 ? -1 : std::atoll(x);
+      if (got >= 2) *b = std::atoll(y);
+      return got;
+    };
+    long long quota = -1, period = 100000;
+    if (read("/sys/fs/cgroup/cpu.max", &quota, &period) < 1) {
+      long long unused = 0;
+      if (read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, &unused) >= 1) (void)read("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, &unused);
+    }
+    if (quota > 0 && period > 0) hw = (unsigned)std::max<long long>(1, std::min<long long>(hw, quota / period));
+    return hw;
+  }();
+  return n;
+}
 
 struct Reg2Params {
   int C = 0, P = 0;       // cameras, world points
@@ -137,6 +168,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
       for (int b = a; b < G; ++b, ++t) { ta[t] = a; tb[t] = b; }
   }
   // (more than ~64 workers do not pay: a job is a few milliseconds, and starting a thread costs the main thread ~20 us)
+  // (foreground work may burst above a cgroup quota: 64 threads finish the plan of a 1M-observation problem in 15 ms, inside one accounting period)
   const unsigned n_threads = prm.threads > 0 ? (unsigned)prm.threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
   // observations of a point are sorted by camera => by group; pgb[q*(G+1) + a] .. [a+1] is group a's run
   RawVec<int> pgb;

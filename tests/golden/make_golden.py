@@ -10,7 +10,8 @@ Run in the build container (where /root/reference is mounted):  python tests/gol
       <- /root/reference/tests/sessions/post_optimization/...
       a real calibrated 4-camera session (BASELINE.json configs[0]); used by the reference in
       tests/test_reprojection_report.py and tests/test_capture_volume.py.
-  scipy_trajectories.json  <- tests/golden/make_scipy_golden.py (scipy run on the oracle, see there).
+  scipy_refs/*.npz  <- tests/golden/make_scipy_refs.py: solutions of the reference's scipy call (oracle callables) at BASELINE sizes, computed on the
+      CPU of the build container (minutes to an hour and a half each); consumers check the stored x0 digest against their own x0.
 """
 import shutil
 from pathlib import Path

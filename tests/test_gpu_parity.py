@@ -701,8 +701,9 @@ def test_non_finite_start_raises_like_scipy(refine):
 
 
 def test_limits_are_reported_not_crashed():
-    """Empty input, more cameras than the per-camera accumulators of the linearisation fit in LDS (800 six-parameter cameras; 320 — beyond
-    round 2's camera-table limit — now solve), calls out of order: clean errors with a message."""
+    """Empty input, what is still limited (fixed-order sums beyond 227 cameras), calls out of order: clean errors with a message.  800 six-parameter
+    cameras — beyond the LDS copy of the packed camera blocks, refused until round 3 — build a handle that picks the global-accumulator
+    linearisation; 320 — beyond round 2's camera-table limit — the vector-cache table."""
     from caliscope_amd.exceptions import BackendError
     from caliscope_amd.hip_engine import HipEngine
 
@@ -712,8 +713,10 @@ def test_limits_are_reported_not_crashed():
         HipEngine(empty)
     big = make_scene(n_cams=800, n_points=400, n_obs=1600)
     par_big = BundleParameterization.from_camera_array(big.cameras_init, n_points=400, refine_intrinsics=False)
-    with pytest.raises(BackendError, match="LDS|cameras|160 KiB"):
-        HipEngine(BAProblem(par_big, big.camera_indices, big.image_coords, big.obj_indices))
+    with HipEngine(BAProblem(par_big, big.camera_indices, big.image_coords, big.obj_indices)) as eng_big:
+        assert eng_big.info()["build_camg"] & 8 and eng_big.info()["build_camg"] & 2
+    with pytest.raises(BackendError, match="deterministic sums support up to"):
+        HipEngine(BAProblem(par_big, big.camera_indices, big.image_coords, big.obj_indices), deterministic=True)
     mid = make_scene(n_cams=320, n_points=400, n_obs=1600)
     par_mid = BundleParameterization.from_camera_array(mid.cameras_init, n_points=400, refine_intrinsics=False)
     with HipEngine(BAProblem(par_mid, mid.camera_indices, mid.image_coords, mid.obj_indices)) as eng_mid:
