@@ -152,7 +152,11 @@ struct cba_problem {
   bool begun = false, linearized = false, stepped = false, have_trial = false;
   double gh_sq = 0.0;
   std::vector<int> h_cam_off, h_cam_np;
-  std::vector<double> h_vec;  // staging for layout conversion
+  double* h_vec = nullptr;     // pinned staging for layout conversion (vectors in and out); pageable, a hipMemcpyAsync of cfg4's 4.8 MB x0 waited
+                               // 25-40 ms inside the runtime whenever the plan thread's workers were faulting their arrays in beside it
+  size_t h_vec_doubles = 0;
+  hipEvent_t h_vec_sent = nullptr;  // recorded behind an asynchronous copy OUT of h_vec: the next writer of h_vec waits for it (stage_wait)
+  bool h_vec_in_flight = false;
   // timers
   bool timers_on = false;
   std::vector<EventPair> pending[T_COUNT];
@@ -177,10 +181,12 @@ struct cba_problem {
 // 0.3 - 1 ms each; on the reference's own 4-camera session creating and destroying a handle took 3.5 + 2.4 ms next to a 0.7 ms solve.
 constexpr size_t kPoolChunk = (size_t)4 << 20;
 constexpr size_t kPoolKeep = 4;
+constexpr size_t kPoolStagingMax = (size_t)8 << 20;  // doubles: staging buffers above 64 MB are not kept
 struct DevicePool {
   std::vector<void*> chunks;
   std::vector<hipStream_t> streams;
   std::vector<std::pair<double*, size_t>> mail;  // (mapped host pointer, doubles)
+  std::vector<std::pair<double*, size_t>> staging;  // (pinned host pointer, doubles): h_vec
 };
 static std::mutex g_pool_mu;
 static std::map<int, DevicePool> g_pool;
@@ -224,6 +230,17 @@ static int dev_upload(cba_problem* p, T** out, const V& h) {  // V: any contiguo
   int rc = dev_alloc(p, out, h.size());
   if (rc) return rc;
   if (!h.empty()) HIPCHK(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return CBA_OK;
+}
+
+// h_vec is pinned: a hipMemcpyAsync out of it returns while the copy engine still reads it
+static int stage_wait(cba_problem* p) {
+  if (p->h_vec_in_flight) { HIPCHK(hipEventSynchronize(p->h_vec_sent)); p->h_vec_in_flight = false; }
+  return CBA_OK;
+}
+static int stage_sent(cba_problem* p) {
+  HIPCHK(hipEventRecord(p->h_vec_sent, p->stream));
+  p->h_vec_in_flight = true;
   return CBA_OK;
 }
 
@@ -506,6 +523,7 @@ void cba_destroy(cba_problem* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drain_timers(p);
   for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (p->h_vec_sent) (void)hipEventDestroy(p->h_vec_sent);
   if (ncclComm_t c = p->comm.exchange(nullptr)) (void)ncclCommDestroy(c);  // (an aborted communicator was taken out by cba_comm_abort)
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);  // (the stream is drained: nothing of this handle is in flight)
@@ -517,6 +535,10 @@ void cba_destroy(cba_problem* p) {
     if (p->h_scal) {  // (h_cam and h_flags live in the same allocation)
       if (pool.mail.size() < kPoolKeep) pool.mail.emplace_back(p->h_scal, p->mail_doubles);
       else (void)hipHostFree(p->h_scal);
+    }
+    if (p->h_vec) {
+      if (pool.staging.size() < kPoolKeep && p->h_vec_doubles <= kPoolStagingMax) pool.staging.emplace_back(p->h_vec, p->h_vec_doubles);
+      else (void)hipHostFree(p->h_vec);
     }
     if (p->stream) {
       if (pool.streams.size() < kPoolKeep) pool.streams.push_back(p->stream);
@@ -1171,7 +1193,21 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPBAIL(hipMemset(p->flags, 0, 4 * sizeof(int)));
   HIPBAIL(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
 #undef TRY
-  p->h_vec.resize((size_t)tot);
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    DevicePool& pool = g_pool[dev];
+    for (size_t i = 0; i < pool.staging.size(); ++i)
+      if (pool.staging[i].second >= (size_t)tot && pool.staging[i].second <= 4 * (size_t)tot + 4096) {
+        p->h_vec = pool.staging[i].first; p->h_vec_doubles = pool.staging[i].second;
+        pool.staging.erase(pool.staging.begin() + (long)i);
+        break;
+      }
+  }
+  HIPBAIL(hipEventCreateWithFlags(&p->h_vec_sent, hipEventDisableTiming));
+  if (!p->h_vec) {
+    p->h_vec_doubles = (size_t)tot;
+    HIPBAIL(hipHostMalloc((void**)&p->h_vec, p->h_vec_doubles * sizeof(double), hipHostMallocDefault));
+  }
   lap("solver buffers");
   HIPBAIL(hipDeviceSynchronize());
   lap("device synchronize");
@@ -1904,8 +1940,10 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
 int cba_begin(cba_problem* p, const double* x0, double* cost_out) {
   if (!p || !x0 || !cost_out) return fail(CBA_ERR_INVALID, "cba_begin: null argument");
   HIPCHK(hipSetDevice(p->device));
-  pack_host(p, x0, p->h_vec.data(), 0.0);
-  HIPCHK(hipMemcpyAsync(p->x0, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  { const int rcw = stage_wait(p); if (rcw) return rcw; }
+  pack_host(p, x0, p->h_vec, 0.0);
+  HIPCHK(hipMemcpyAsync(p->x0, p->h_vec, p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  { const int rcs = stage_sent(p); if (rcs) return rcs; }
   p->have_x0 = true;
   return begin_common(p, cost_out);
 }
@@ -1922,8 +1960,10 @@ int cba_begin_deferred(cba_problem* p, const double* x0) {
   if (!x0 && !p->have_x0) return fail(CBA_ERR_INVALID, "cba_begin_deferred: no x0 on the device yet");
   HIPCHK(hipSetDevice(p->device));
   if (x0) {
-    pack_host(p, x0, p->h_vec.data(), 0.0);
-    HIPCHK(hipMemcpyAsync(p->x0, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    { const int rcw = stage_wait(p); if (rcw) return rcw; }
+    pack_host(p, x0, p->h_vec, 0.0);
+    HIPCHK(hipMemcpyAsync(p->x0, p->h_vec, p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    { const int rcs = stage_sent(p); if (rcs) return rcs; }
     p->have_x0 = true;
   }
   return begin_common(p, nullptr, false);
@@ -2330,8 +2370,9 @@ int cba_get_vector(cba_problem* p, int32_t which, double* out) {
     default: return fail(CBA_ERR_INVALID, "cba_get_vector: unknown vector %d", which);
   }
   HIPCHK(hipStreamSynchronize(p->stream));
-  HIPCHK(hipMemcpy(p->h_vec.data(), src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
-  unpack_host(p, p->h_vec.data(), out);
+  { const int rcw = stage_wait(p); if (rcw) return rcw; }
+  HIPCHK(hipMemcpy(p->h_vec, src, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+  unpack_host(p, p->h_vec, out);
   return CBA_OK;
 }
 
@@ -2367,9 +2408,11 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   double* d_r = nullptr;
   const size_t n_rows = (size_t)2 * p->N + (size_t)p->con.n_con;  // reprojection rows, then the constraint rows
   HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
-  pack_host(p, x, p->h_vec.data(), 0.0);
+  { const int rcw = stage_wait(p); if (rcw) return rcw; }
+  pack_host(p, x, p->h_vec, 0.0);
   p->have_trial = false; p->trial_built = false;  // the evaluation borrows the trial point's camera table: a pending trial is gone
-  hipError_t e = hipMemcpyAsync(p->v2, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
+  hipError_t e = hipMemcpyAsync(p->v2, p->h_vec, p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) { e = hipEventRecord(p->h_vec_sent, p->stream); p->h_vec_in_flight = (e == hipSuccess); }
   if (e == hipSuccess) {
     launch_cam_prep(p, p->v2, p->tab_new);
     launch_cost(p, p->v2, p->tab_new, 24, d_r);
@@ -2397,8 +2440,9 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
   HIPCHK(hipMemcpy(saved.data(), p->x, saved.size() * sizeof(double), hipMemcpyDeviceToHost));
   const bool was_begun = p->begun;
   const bool first = p->first_scale;
-  pack_host(p, x, p->h_vec.data(), 0.0);
-  HIPCHK(hipMemcpy(p->x, p->h_vec.data(), p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
+  { const int rcw = stage_wait(p); if (rcw) return rcw; }
+  pack_host(p, x, p->h_vec, 0.0);
+  HIPCHK(hipMemcpy(p->x, p->h_vec, p->lay.total() * sizeof(double), hipMemcpyHostToDevice));
   launch_cam_prep(p, p->x, p->tab);
   DISPATCH_NC(p, run_build<6>(p), run_build<9>(p));
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));  // parity hook: no publish here, leave no flag behind
@@ -2432,8 +2476,9 @@ int cba_normal_blocks(cba_problem* p, const double* x, double* U, double* V, dou
       for (int k = 0; k < 6; ++k) V[(size_t)q * 6 + k] = hV[(size_t)k * p->lay.Ppad + q];
   }
   if (gp) {
-    HIPCHK(hipMemcpy(p->h_vec.data(), p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
-    const double* vx = p->h_vec.data() + p->lay.ncp_pad;
+    { const int rcw = stage_wait(p); if (rcw) return rcw; }
+    HIPCHK(hipMemcpy(p->h_vec, p->g, p->lay.total() * sizeof(double), hipMemcpyDeviceToHost));
+    const double* vx = p->h_vec + p->lay.ncp_pad;
     for (int q = 0; q < p->P; ++q) {
       gp[3 * q] = vx[q]; gp[3 * q + 1] = vx[p->lay.Ppad + q]; gp[3 * q + 2] = vx[2 * p->lay.Ppad + q];
     }

@@ -76,7 +76,7 @@ void minimize_quadratic_1d(double a, double b, double lo, double hi, double c, d
 
 // CBA_SOLVE_TRACE=1: host wall-clock per primitive (enqueue + whatever the call waits for), printed to stderr at the end of the solve
 struct CallTrace {
-  struct Row { const char* name; double s; long n; };
+  struct Row { const char* name; double s; long n; double longest; };
   bool on = std::getenv("CBA_SOLVE_TRACE") != nullptr;
   Row rows[24];
   int used = 0;
@@ -87,8 +87,9 @@ struct CallTrace {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     int i = 0;
     while (i < used && std::strcmp(rows[i].name, name) != 0) ++i;
-    if (i == used) { if (used == 24) return rc; rows[used++] = Row{name, 0.0, 0}; }
+    if (i == used) { if (used == 24) return rc; rows[used++] = Row{name, 0.0, 0, 0.0}; }
     rows[i].s += dt; ++rows[i].n;
+    if (dt > rows[i].longest) rows[i].longest = dt;
     return rc;
   }
   void print(double total_s, long iterations) const {
@@ -96,7 +97,7 @@ struct CallTrace {
     double sum = 0.0;
     for (int i = 0; i < used; ++i) sum += rows[i].s;
     std::fprintf(stderr, "cba_solve trace: %ld iterations, %.3f ms, of which %.3f ms inside the primitives\n", iterations, total_s * 1e3, sum * 1e3);
-    for (int i = 0; i < used; ++i) std::fprintf(stderr, "  %-22s %5ld calls %9.3f ms  %8.1f us each\n", rows[i].name, rows[i].n, rows[i].s * 1e3, rows[i].s * 1e6 / rows[i].n);
+    for (int i = 0; i < used; ++i) std::fprintf(stderr, "  %-22s %5ld calls %9.3f ms  %8.1f us each, longest %8.1f us\n", rows[i].name, rows[i].n, rows[i].s * 1e3, rows[i].s * 1e6 / rows[i].n, rows[i].longest * 1e6);
   }
 };
 
