@@ -298,6 +298,35 @@ def solution_parity(par, x_a, x_b, detail=False):
     return float(pos), float(ang)
 
 
+def weak_points(sc, par, x_product, x_ref, loss="linear", f_scale=1.0, limit=5):
+    """The points two converged answers place more than 1e-6 apart (gauge-aligned), and what the DATA say about each: the oracle's cost at the product's
+    answer with that one point moved to where the reference has it (brought into the product's gauge), relative to the cost.  A change below ~1e-13 means
+    double precision cannot tell the two positions apart — e.g. a point whose observations all sit in Huber's linear region is nearly free along its
+    rays — and neither solver's termination test can prefer one."""
+    pa, pb = x_ref[par.n_camera_params:].reshape(-1, 3), x_product[par.n_camera_params:].reshape(-1, 3)
+
+    def centres(x):
+        from caliscope_amd.cameras import rvec_to_matrix
+        return np.array([-rvec_to_matrix(x[o:o + 3]).T @ x[o + 3:o + 6] for o in par.camera_param_offsets])
+
+    s, R, t = _similarity(np.vstack([centres(x_ref), pa]), np.vstack([centres(x_product), pb]))  # reference -> the product's gauge
+    moved = s * pa @ R.T + t
+    extent = np.abs(np.vstack([centres(x_product), pb])).max()
+    dist = np.abs(moved - pb).max(axis=1) / extent
+    idx = np.argsort(-dist)[:limit]
+    idx = idx[dist[idx] > 1e-6]
+    cost0 = oracle_cost(sc, par, x_product, loss, f_scale)
+    out = []
+    for q in idx:
+        x_mod = np.array(x_product, dtype=float, copy=True)
+        x_mod[par.n_camera_params + 3 * q: par.n_camera_params + 3 * q + 3] = moved[q]
+        n_rows = int(np.sum(sc.obj_indices == q))
+        out.append({"point": int(q), "aligned_distance": float(dist[q]), "observations": n_rows,
+                    "rel_cost_change_if_moved_to_the_reference_position": (oracle_cost(sc, par, x_mod, loss, f_scale) - cost0) / cost0})
+    return {"points_above_1e-6": int(np.sum(dist > 1e-6)), "listed": out,
+            "all_listed_indistinguishable_at_1e-12_of_the_cost": bool(all(abs(o["rel_cost_change_if_moved_to_the_reference_position"]) <= 1e-12 for o in out))}
+
+
 def oracle_cost(sc, par, x, loss="linear", f_scale=1.0):
     """0.5 * sum rho(f) at x from the ORACLE's residuals and scipy's own loss functions (nothing of the product involved)."""
     from oracle.residuals import joint_residuals

@@ -21,7 +21,8 @@ for w in cfg4 cfg5; do
 done
 cd $GRAFT_REPO_ROOT
 for w in cfg4 cfg5 cfg23; do DB=$(find $O/trace_$w -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB $O/${w}_kernel_trace.md > /dev/null; done
-DB=$(find $O/trace_cfg23 -name "*.db" | head -1); [ -n "$DB" ] && python tools/trace_iteration.py $DB > $O/cfg2_iteration.txt 2>&1
+DB=$(find $O/trace_cfg23 -name "*.db" | head -1); [ -n "$DB" ] && python tools/trace_iteration.py $DB k_tprep 0.04 > $O/cfg2_iteration.txt 2>&1  # (cfg2 runs first: 48 of the ~640 iterations)
+[ -n "$DB" ] && python tools/trace_iteration.py $DB k_tprep 0.6 > $O/cfg3_iteration.txt 2>&1
 for w in cfg4 cfg5; do python tools/pmc_summary.py $O/pmc_fetch_$w $O/pmc_write_$w $O/pmc_$w.md $O/pmc_$w.json > /dev/null 2>&1; done
 find $O -name "*.db" -size +8M -delete; find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 P=$GRAFT_REPO_ROOT/caliscope_amd/libcaliscope_ba_prof.so

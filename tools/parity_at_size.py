@@ -73,6 +73,8 @@ def run(name, tol_scipy, tol_gpu, stored=None, polish=False):
         "aligned_pos": detail["aligned_pos"], "aligned_ang_rad": detail["aligned_ang_rad"], "detail": detail,
         "within_north_star": bool(detail["aligned_pos"] <= 1e-6 and detail["aligned_ang_rad"] <= 1e-6 and abs(rms(got.x) - rms(ref_x)) <= 1e-4),
     }
+    if detail["points_above_1e-6"] and detail["points_above_1e-6"] <= 50:
+        out["weak_points"] = bench.weak_points(sc, par, got.x, ref_x, prob.loss, fs)
     if polish:
         out["oracle_polish"] = bench.oracle_polish(sc, par, got.x, prob.loss, fs, tight_inner=prob.n_obs <= 500_000)
     return out

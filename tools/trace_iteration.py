@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The dispatches of ONE trust-region iteration from a rocpd kernel trace, in order, with their durations and the idle time in front of each:
-trace_iteration.py file.db [marker_kernel]   (an iteration = from one launch of the marker kernel to the next; taken from the middle of the run)"""
+trace_iteration.py file.db [marker_kernel [where]]   (an iteration = from one launch of the marker kernel to the next; `where` in 0..1 picks the
+iteration by its position in the run: 0.5 = the middle, the default; a trace of two workloads one after the other has the first one early)"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -11,7 +12,9 @@ marker = sys.argv[2] if len(sys.argv) > 2 else "k_tprep"
 idx = [i for i, r in enumerate(rows) if marker in r[0]]
 if len(idx) < 6:
     sys.exit("not enough iterations in the trace")
-lo, hi = idx[len(idx) // 2], idx[len(idx) // 2 + 1]
+where = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
+at = min(max(int(len(idx) * where), 0), len(idx) - 2)
+lo, hi = idx[at], idx[at + 1]
 busy = 0.0
 print(f"| # | kernel | workgroups x threads | us | idle before, us |\n|---|---|---|---|---|")
 for k, (name, st, en, grid, wg) in enumerate(rows[lo:hi]):
