@@ -2,6 +2,8 @@
 from kernel-family timers, and the committed end-of-round bench line against the JSON contract."""
 import importlib.util
 import json
+
+import pytest
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -87,21 +89,64 @@ def test_committed_bench_line_has_the_contract_fields():
     assert par["same_minimum_within_north_star"] is True and par["polish"]["same_minimum"]["aligned_pos"] <= 1e-6
 
 
+def _oracle_polish_ok(block):
+    """scipy restarted AT the product's converged x with 1e-15 tolerances: it must stop having moved less than 1e-6 and gained less than 1e-12."""
+    assert block["scipy_moves_within_1e-6_and_gains_within_1e-12"] is True
+    for leg in ("lsmr_default", "lsmr_tight"):
+        if block.get(leg):
+            assert block[leg]["moved"]["aligned_pos"] <= 1e-6 and block[leg]["moved"]["points_above_1e-6"] == 0 and block[leg]["rel_cost_gain"] <= 1e-12
+
+
+def test_round4_bench_line_closes_parity_from_the_oracle_side():
+    """Round 4: the bench line separates accepted steps from rejected trials, names the library sources it ran on, and shows parity in BOTH directions
+    (product against scipy from x0; scipy restarted at the product's answer does not move)."""
+    name, d = _latest_bench_line()
+    if name < "r04":
+        pytest.skip("no round-4 bench line committed yet")
+    for key in ("timed_region", "library_source_sha256", "plan_wait_ms"):
+        assert key in d, key
+    tr = d["timed_region"]
+    assert tr["accepted_steps"] + tr["rejected_trials"] >= d["steps"] and abs(tr["ms_per_accepted_step"] - d["ms_per_step"]) < 1e-9
+    _oracle_polish_ok(d["parity"]["oracle_polish"])
+    c5p = d["also"]["cfg5"]["parity"]
+    _oracle_polish_ok(c5p["oracle_polish"])
+    # cfg5 recipe against scipy run to ITS minimum (1e-15, inner LSMR 1e-14; tests/golden/scipy_refs): a plain comparison inside north_star
+    tight = c5p["tight_reference"]["detail"]
+    assert tight["aligned_pos"] <= 1e-6 and tight["aligned_ang_rad"] <= 1e-6 and tight["points_above_1e-6"] == 0
+    c3 = d["also"]["cfg3"]["timed_region"]  # Huber: rejected trials are timed on their own, not averaged into the step
+    assert c3["rejected_trials_timed"] > 0 and c3["ms_per_rejected_trial"] < c3["ms_per_accepted_step"]
+    # the parity file of the same run was written on the same library sources
+    par = json.loads((ROOT / "profiles" / "parity_r04.json").read_text())
+    assert par["library_source_sha256"] == d["library_source_sha256"]
+
+
 def test_committed_parity_at_size():
-    """profiles/parity_r03.json (tools/parity_at_size.py, written by the round's last GPU run): GPU against scipy on BASELINE-sized inputs."""
-    d = json.loads((ROOT / "profiles" / "parity_r03.json").read_text())
-    c2 = d["cfg2"]  # both at 1e-13: a plain comparison
-    assert abs(c2["d_rms_px"]) <= 1e-4 and c2["aligned_pos"] <= 1e-6 and c2["aligned_ang_rad"] <= 1e-6
+    """profiles/parity_r04.json (tools/parity_at_size.py, written by the round's last GPU run): GPU against scipy on BASELINE-sized inputs, both
+    directions of the converged-level protocol."""
+    d = json.loads((ROOT / "profiles" / "parity_r04.json").read_text())
+    for case in ("cfg2", "cfg3_tight"):  # both sides run to their minimum: a plain comparison, and scipy restarted at the product's answer stays put
+        c = d[case]
+        assert abs(c["d_rms_px"]) <= 1e-4 and c["aligned_ang_rad"] <= 1e-6 and c["detail"]["cameras_pos"] <= 1e-6 and abs(c["rel_cost"]) <= 1e-9, case
+        assert c["detail"]["points_pos_p999"] <= 1e-6, case
+        if c["detail"]["points_above_1e-6"]:
+            # Huber on 17 px of noise: a point whose observations all sit in the loss's linear region is nearly free along its rays.  Such a point may
+            # differ by more than 1e-6 only if the DATA cannot tell the two positions apart: moving it, alone, to the reference's position changes the
+            # oracle's cost by less than 1e-12 relative (bench.weak_points) — no termination test of either solver can prefer one position
+            assert c["detail"]["points_above_1e-6"] <= 3 and c["detail"]["points_pos_max"] <= 1e-5, case
+            assert c["weak_points"]["all_listed_indistinguishable_at_1e-12_of_the_cost"] is True, case
+        else:
+            assert c["within_north_star"] is True, case
+        _oracle_polish_ok(c["oracle_polish"])
     # cfg3 with the product's robust-stage settings (ftol 1e-4, max_nfev 60): the same trajectory, evaluation for evaluation
     c3p = d["cfg3_product"]
     assert c3p["scipy"]["nfev"] == c3p["gpu"]["nfev"] and c3p["scipy"]["njev"] == c3p["gpu"]["njev"] and abs(c3p["rel_cost"]) <= 1e-6
-    # cfg3 to scipy's own convergence (534 evaluations): Huber on 17 px of noise, the valley is flat — scipy stops 1.15e-6 of the cost above the
-    # minimum the product reaches; the RMS agrees within the 1e-4 px bar, and continued from scipy's answer the product ends where it ended from x0
-    c3 = d["cfg3_converged"]
+    # cfg3 at the reference's default tolerances: scipy's LSMR steps stop on ftol ~1e-6 of the cost above the minimum the product reaches (cfg3_tight
+    # is the comparison at the minimum); the RMS agrees within the 1e-4 px bar and the product's cost is not above scipy's
+    c3 = d["cfg3_default"]
     assert c3["scipy"]["status"] > 0 and c3["gpu"]["status"] > 0 and abs(c3["d_rms_px"]) <= 1e-4 and c3["rel_cost"] <= 1e-9
-    pol = d["cfg3_tight"]["polish"]
-    assert pol["minimum_from_x0_vs_minimum_from_scipy"]["aligned_pos"] <= 1e-6 and pol["minimum_from_x0_vs_minimum_from_scipy"]["points_above_1e-6"] == 0
-    assert 0.0 <= pol["rel_cost_scipy_above_minimum"] <= 1e-4 and abs(pol["rel_cost_gpu_above_minimum"]) <= 1e-9
-    c5 = d["cfg5_sample_1M"]
-    assert abs(c5["d_rms_px"]) <= 1e-4 and c5["rel_cost"] <= 1e-9 and c5["same_minimum_within_north_star"] is True
-    assert c5["polish"]["same_minimum"]["aligned_pos"] <= 1e-6 and c5["polish"]["same_minimum"]["points_above_1e-6"] == 0
+    for case in ("cfg5_sample_100k", "cfg5_sample_1M"):
+        c5 = d[case]
+        assert abs(c5["d_rms_px"]) <= 1e-4 and c5["rel_cost"] <= 1e-9 and c5["same_minimum_within_north_star"] is True, case
+        tight = c5["tight_reference"]["detail"]
+        assert tight["aligned_pos"] <= 1e-6 and tight["aligned_ang_rad"] <= 1e-6 and tight["points_above_1e-6"] == 0, case
+        _oracle_polish_ok(c5["oracle_polish"])
