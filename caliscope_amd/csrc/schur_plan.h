@@ -109,9 +109,10 @@ struct Reg2Params {
   bool cheap = false;     // the plan a handle starts with while the dealt one is being made: one open chunk filled in point order (no dealing), the
                           // records in arrival order (no colouring) — a quarter of the host time; the pair kernel then runs at ~0.5 lane utilisation
                           // and ~2.4 LDS cycles per read group instead of 0.7 / 1.4
+  bool cheap_lean = true; // (tests: false runs the cheap plan through the general path, which must produce the same arrays)
   const std::atomic<bool>* cancel = nullptr;  // set by the owner to make the workers stop between jobs (build_reg2_plan then returns -2)
   int colour_sweeps = 0;  // refinement sweeps of the slot colouring behind the greedy pass.  Two sweeps (round 2) buy 1.35 instead of 1.36 LDS cycles
-                          // per 16-lane read group on cfg4 and cost a quarter of the plan's time: off by default (CBA_PLAN_SWEEPS)
+                          // per 16-lane read group on cfg4 and cost a quarter of the plan's time: off
 };
 
 struct Reg2Plan {
@@ -212,7 +213,117 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
       j.q_end = (int)((long)P * (r + 1) / n_regions);
     }
 
+  // The cheap plan (one open chunk filled in point order, records in arrival order) needs none of the dealing's bookkeeping: one pass over the job's
+  // points, the pair codes written in their final form (LDS piece addresses from a table) into fixed-size per-thread lists, a transposing copy per
+  // chunk.  Same plan as the general path below produces with prm.cheap, bit for bit (tests/test_schur_plan.py compares digests), for 0.55 of its
+  // CPU time — the cheap plan is what a two-stage handle waits for in cba_create.  A chunk is also closed when a thread's list is half full
+  // (never on real data: ~1 pair per block and chunk); a list that would overflow hands the job to the general path.
+  constexpr int LCAP = 255;                  // (a byte per wave in `nit`)
+  std::vector<unsigned> piece_tab((size_t)R);
+  for (int s = 0; s < R; ++s) piece_tab[(size_t)s] = piece_of(s);
+  auto run_job_cheap = [&](Job& job) -> bool {
+    const int a = ta[job.tile], b = tb[job.tile];
+    const bool diag = (a == b);
+    const int na_t = gcam[a + 1] - gcam[a];
+    std::vector<std::vector<int>> helpers;
+    if (diag) {
+      helpers.assign(g, {});
+      int k = 0;
+      for (int li = 0; li < g; ++li)
+        for (int lj = 0; lj <= li; ++lj, ++k) helpers[k % std::max(na_t, 1)].push_back(li * g + lj);
+    }
+    long tot_rec = 0, tot_pairs = 0;
+    for (int q = job.q_begin; q < job.q_end; ++q) {  // sizes for the two reservations (upper bounds)
+      const int* gb = &pgb[(size_t)q * (G + 1)];
+      const int na = gb[a + 1] - gb[a], nb = diag ? 0 : gb[b + 1] - gb[b];
+      if (prm.heavy_obs > 0 && hps[q + 1] - hps[q] > prm.heavy_obs) continue;
+      if (na <= 0 || (!diag && nb <= 0)) continue;
+      if (na + nb > R) { job.rc = -1; return true; }
+      tot_rec += na + nb;
+      tot_pairs += diag ? (long)na * (na + 1) / 2 : (long)na * nb;
+    }
+    job.chunk_start.push_back(0);
+    job.code_start.push_back(0);
+    if (!tot_rec) return true;
+    job.obs.reserve((size_t)(tot_rec + tot_rec / 8) + 64);
+    job.codes.reserve((size_t)((double)tot_pairs * 3.6) + 256 * (size_t)NW);
+    const int NL = NW * 64;
+    std::vector<unsigned> lst((size_t)NL * LCAP);
+    std::vector<unsigned short> cnt((size_t)NL, 0);
+    std::vector<unsigned> rr((size_t)nblk, 0), rrc((size_t)g, 0), packed((size_t)NWORD, 0u);
+    int fill = 0, maxcnt = 0;
+    bool overflow = false;
+    auto flush = [&]() {
+      if (!fill) return;
+      std::fill(packed.begin(), packed.end(), 0u);
+      for (int w = 0; w < NW; ++w) {
+        int mx = 0;
+        for (int l = 0; l < 64; ++l) mx = std::max<int>(mx, cnt[(size_t)w * 64 + l]);
+        packed[w / 4] |= (unsigned)mx << (8 * (w % 4));
+        const size_t at = job.codes.size();
+        job.codes.resize(at + (size_t)mx * 64);
+        unsigned* dst = job.codes.data() + at;
+        for (int l = 0; l < 64; ++l) {
+          const unsigned* src = &lst[((size_t)w * 64 + l) * LCAP];
+          const int n = cnt[(size_t)w * 64 + l];
+          for (int it = 0; it < n; ++it) dst[(size_t)it * 64 + l] = src[it];
+          for (int it = n; it < mx; ++it) dst[(size_t)it * 64 + l] = ZERO;
+          job.n_pairs += n;
+        }
+        job.lane_iters += (long)mx * 64;
+      }
+      job.nit.insert(job.nit.end(), packed.begin(), packed.end());
+      job.chunk_start.push_back((int)job.obs.size());
+      job.code_start.push_back((int)job.codes.size());
+      std::fill(cnt.begin(), cnt.end(), (unsigned short)0);
+      std::fill(rr.begin(), rr.end(), 0u);
+      std::fill(rrc.begin(), rrc.end(), 0u);
+      fill = 0; maxcnt = 0;
+    };
+    auto emit = [&](int blk, unsigned code) {
+      const int slot = (int)(rr[blk]++ % (unsigned)rep);
+      const size_t li = (size_t)slot * nblk + blk;
+      if (cnt[li] >= LCAP) { overflow = true; return; }
+      lst[li * LCAP + cnt[li]] = code;
+      maxcnt = std::max<int>(maxcnt, ++cnt[li]);
+    };
+    for (int q = job.q_begin; q < job.q_end && !overflow; ++q) {
+      const int* gb = &pgb[(size_t)q * (G + 1)];
+      const int na = gb[a + 1] - gb[a], nb = diag ? 0 : gb[b + 1] - gb[b];
+      if (prm.heavy_obs > 0 && hps[q + 1] - hps[q] > prm.heavy_obs) continue;
+      if (na <= 0 || (!diag && nb <= 0)) continue;
+      if (fill + na + nb > R || maxcnt > LCAP / 2) flush();
+      const int base = fill;
+      for (int i = gb[a]; i < gb[a] + na; ++i) job.obs.push_back(i);
+      for (int i = gb[b]; !diag && i < gb[b] + nb; ++i) job.obs.push_back(i);
+      fill += na + nb;
+      for (int i = 0; i < na; ++i) {
+        const int li = hcam[gb[a] + i] - gcam[a];
+        const unsigned pi = piece_tab[(size_t)(base + i)];
+        const int j0 = diag ? i : na, j1 = diag ? na : na + nb;
+        for (int j = j0; j < j1; ++j) {
+          const int lj = diag ? hcam[gb[a] + j] - gcam[a] : hcam[gb[b] + (j - na)] - gcam[b];
+          const unsigned pj = piece_tab[(size_t)(base + j)];
+          if (diag && lj == li) {
+            const std::vector<int>& h = helpers[li];
+            emit(h[rrc[li]++ % h.size()], pi | (pj << 16));
+            if (j != i) emit(h[rrc[li]++ % h.size()], pj | (pi << 16));
+          } else {
+            emit(li * g + lj, pi | (pj << 16));
+          }
+        }
+      }
+    }
+    if (overflow) return false;
+    flush();
+    return true;
+  };
+
   auto run_job = [&](Job& job) {
+    if (prm.cheap && prm.cheap_lean) {
+      if (run_job_cheap(job)) return;
+      job = Job{job.tile, job.q_begin, job.q_end};  // (a thread's list overflowed: the general path has no such limit below 255 pairs per wave-iteration byte)
+    }
     const int a = ta[job.tile], b = tb[job.tile];
     const bool diag = (a == b);
     const int na_t = gcam[a + 1] - gcam[a];

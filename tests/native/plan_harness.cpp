@@ -10,7 +10,7 @@
 
 extern "C" {
 
-// acc_out: [n_tiles][64 n_waves][nc*nc] (thread = slot * g*g + block); stats_out: n_chunks, n_pairs, lane_iters, n_regions, stream entries
+// acc_out: [n_tiles][64 n_waves][nc*nc] (thread = slot * g*g + block); stats_out[10]: n_chunks, n_pairs, lane_iters, n_regions, stream entries, LDS read groups / cycles / cycles in arrival order, iterations over the cap, digest of the plan arrays
 int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_cap, int slots_per_wave, int lds_stride, int wave_pieces, int region_chunks,
                 int heavy_obs, int threads, int n_waves, int pair_cap, int cheap, const int* hcam, const int* hps, const double* T, double* acc_out, long* stats_out) {
   cba::Reg2Params prm;
@@ -21,6 +21,7 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
   prm.zero_piece = zero_piece;
   prm.region_chunks = region_chunks; prm.heavy_obs = heavy_obs; prm.threads = threads; prm.n_waves = n_waves; prm.pair_cap = pair_cap;
   prm.cheap = cheap != 0;  // the plan a handle starts with: one open chunk in point order, records in arrival order
+  prm.cheap_lean = cheap != 2;  // 2: the cheap plan through the general path (the lean path must produce the same arrays: stats_out[8] is their digest)
   const long N = hps[P];
   std::vector<int> vcam(hcam, hcam + N), vps(hps, hps + P + 1);
   cba::Reg2Plan plan;
@@ -80,6 +81,14 @@ int plan_replay(int C, int P, int G, int g, int rep, int nc, int rec, int chunk_
     stats_out[8] = over;
   }
   stats_out[5] = plan.lds_groups; stats_out[6] = plan.lds_cycles; stats_out[7] = plan.lds_cycles_arrival;
+  {  // FNV-1a over every array of the plan (63 bits: the caller's array is signed)
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const void* ptr, size_t bytes) { const unsigned char* c = static_cast<const unsigned char*>(ptr); for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; } };
+    mix(plan.obs.data(), plan.obs.size() * sizeof(int)); mix(plan.chunk_start.data(), plan.chunk_start.size() * sizeof(int));
+    mix(plan.code_start.data(), plan.code_start.size() * sizeof(int)); mix(plan.nit.data(), plan.nit.size() * sizeof(unsigned));
+    mix(plan.codes.data(), plan.codes.size() * sizeof(unsigned)); mix(plan.tile_chunk_begin.data(), plan.tile_chunk_begin.size() * sizeof(int));
+    stats_out[9] = (long)(h >> 1);
+  }
   return 0;
 }
 

@@ -56,7 +56,7 @@ def _replay(lib, n_cams, hcam, hps, T, nc, *, gmax=16, chunk_cap=None, region_ch
         chunk_cap = cap
     nT = G * (G + 1) // 2
     acc = np.zeros((nT, threads, nc * nc))
-    stats = np.zeros(9, dtype=np.int64)
+    stats = np.zeros(10, dtype=np.int64)
     if pair_cap is None:  # Reg3Cfg::PAIR_CAP
         pair_cap = 0
     rc = lib.plan_replay(n_cams, P, G, g, rep, nc, rec, chunk_cap, epw, lst, wp, region_chunks, heavy_obs, 4, threads // 64, pair_cap, int(cheap), hcam.ctypes.data_as(I32P),
@@ -157,6 +157,22 @@ def test_cheap_plan_sums_the_same_pairs(harness):
     _check(harness, rng, 48, 700, 2, 12, 6, chunk_cap=64, region_chunks=4, cheap=True)
     stats = _check(harness, rng, 64, 10000, 10, 10, 6, cheap=True)
     assert stats[1] == 10000 * 55 and 0.3 < stats[1] / stats[2] < 0.68, stats[1] / stats[2]
+
+
+def test_lean_cheap_path_builds_the_general_path_s_plan(harness):
+    """The cheap plan has a path of its own in build_reg2_plan (run_job_cheap, round 4: one pass, codes in final form, fixed-size lists — 0.6 of the CPU
+    time; it is what a two-stage handle waits for in cba_create).  It must produce, bit for bit, the arrays the general path produces with
+    prm.cheap: same digest over obs, chunk_start, code_start, nit, codes, tile_chunk_begin."""
+    rng = np.random.default_rng(33)
+    for n_cams, n_points, k_lo, k_hi, nc, kw in ((64, 2000, 2, 10, 6, {}), (8, 300, 2, 8, 6, {}), (20, 400, 1, 6, 6, dict(duplicates=0.2, unobserved=0.1)),
+                                                 (40, 500, 3, 9, 9, {}), (48, 700, 2, 12, 6, dict(chunk_cap=64, region_chunks=4)), (5, 200, 1, 5, 6, dict(duplicates=0.5, unobserved=0.3)),
+                                                 (128, 1500, 10, 10, 9, {})):
+        vis = dict(duplicates=kw.pop("duplicates", 0.0), unobserved=kw.pop("unobserved", 0.0))
+        hcam, hps = _visibility(rng, n_cams, n_points, k_lo, k_hi, **vis)
+        T = np.zeros((hps[-1], 18 if nc == 6 else 30))
+        _, lean, _ = _replay(harness, n_cams, hcam, hps, T, nc, cheap=1, **kw)
+        _, general, _ = _replay(harness, n_cams, hcam, hps, T, nc, cheap=2, **kw)
+        assert lean[9] == general[9] and list(lean[:5]) == list(general[:5]), (n_cams, n_points, nc)
 
 
 def test_heavy_points_are_left_to_their_own_kernel(harness):
