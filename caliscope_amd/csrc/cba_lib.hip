@@ -254,6 +254,14 @@ struct NoInitAlloc : std::allocator<T> {
   template <typename U, typename... A> void construct(U* ptr, A&&... args) {
     if constexpr (sizeof...(A) == 0) ::new ((void*)ptr) U; else ::new ((void*)ptr) U(std::forward<A>(args)...);
   }
+  // large arrays from the pool of huge-page blocks the plan's arrays use (schur_plan.h: a handle's set-up was paying for the page faults of ~100 MB of
+  // freshly mapped host memory per call)
+  T* allocate(size_t n) {
+    void* ptr = rawvec_detail::acquire_tracked(n * sizeof(T));
+    if (!ptr) throw std::bad_alloc();
+    return static_cast<T*>(ptr);
+  }
+  void deallocate(T* ptr, size_t n) noexcept { rawvec_detail::release_tracked(ptr, n * sizeof(T)); }
 };
 template <typename T> using HostVec = std::vector<T, NoInitAlloc<T>>;
 
@@ -1157,6 +1165,11 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     if (plan_timing)
       fprintf(stderr, "  plan: %s took %.3f s on its own threads, started before the uploads; waited %.3f s for it\n", task.two_stage ? "the cheap plan" : "dealt streams and codes",
               task.two_stage ? task.seconds_cheap : task.seconds, t_now() - t_wait);
+    if (plan_timing) {
+      const Reg2Plan& made = task.two_stage ? task.cheap : task.plan;
+      fprintf(stderr, "  plan: its phases: point runs %.4f s, jobs %.4f s, concatenation %.4f s (%.0f MB)\n", made.seconds_runs, made.seconds_jobs, made.seconds_concat,
+              (made.obs.size() + made.codes.size()) * 4e-6);
+    }
     if (task.two_stage ? task.rc_cheap : task.rc)
       return bail(fail(CBA_ERR_UNSUPPORTED, "a world point has more observations inside one camera-group tile than a chunk of the pair plan holds (%d records)",
                        (nct == 9) ? Reg3Cfg<9>::SCHUNK : Reg3Cfg<6>::SCHUNK));

@@ -34,30 +34,114 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <new>
+#include <type_traits>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
 namespace cba {
 
 // An array without value-initialisation: the worker threads that fill it are the first to touch its pages (a std::vector of the plan's 40+ MB would
-// be zero-filled, page by page, by the one thread that resizes it).
+// be zero-filled, page by page, by the one thread that resizes it).  Large arrays (>= 4 MB) come from a process-wide pool of 2 MB-aligned blocks
+// advised for transparent huge pages, and go back to it: measured on the MI355X boxes (CBA_PLAN_TIMING, round 4), half of the cheap plan's wall time
+// was the CONCATENATION of the jobs' arrays into freshly mapped memory — 5.4 of 12 ms for cfg4's 160 MB, 104 of 190 ms for cfg5's 946 MB: page
+// faults of 64 threads, not copying.  The pool keeps at most kKeepBlocks blocks / kKeepBytes (what a process that made a cfg5-sized plan holds on
+// to until it exits); a request takes the smallest kept block that fits and is at most twice as large.
+namespace rawvec_detail {
+constexpr size_t kPooledFrom = (size_t)4 << 20, kHuge = (size_t)2 << 20, kKeepBytes = (size_t)3 << 30;
+constexpr int kKeepBlocks = 32;
+struct Block { void* ptr; size_t bytes; };
+inline std::mutex& pool_mu() { static std::mutex m; return m; }
+inline std::vector<Block>& pool() { static std::vector<Block> v; return v; }
+inline void* acquire(size_t bytes, size_t* capacity) {
+  if (bytes < kPooledFrom) { *capacity = bytes; return std::malloc(std::max<size_t>(bytes, 1)); }
+  {
+    std::lock_guard<std::mutex> lock(pool_mu());
+    std::vector<Block>& v = pool();
+    int best = -1;
+    for (int i = 0; i < (int)v.size(); ++i)
+      if (v[i].bytes >= bytes && v[i].bytes <= 2 * bytes && (best < 0 || v[i].bytes < v[best].bytes)) best = i;
+    if (best >= 0) {
+      const Block b = v[best];
+      v.erase(v.begin() + best);
+      *capacity = b.bytes;
+      return b.ptr;
+    }
+  }
+  const size_t cap = (bytes + kHuge - 1) / kHuge * kHuge;
+  void* ptr = nullptr;
+  if (posix_memalign(&ptr, kHuge, cap) != 0) return nullptr;
+  (void)madvise(ptr, cap, MADV_HUGEPAGE);
+  *capacity = cap;
+  return ptr;
+}
+inline void release(void* ptr, size_t capacity) {
+  if (!ptr) return;
+  if (capacity >= kPooledFrom) {
+    std::lock_guard<std::mutex> lock(pool_mu());
+    std::vector<Block>& v = pool();
+    size_t kept = 0;
+    for (const Block& b : v) kept += b.bytes;
+    if ((int)v.size() < kKeepBlocks && kept + capacity <= kKeepBytes) { v.push_back(Block{ptr, capacity}); return; }
+  }
+  std::free(ptr);
+}
+// for containers that hand back (pointer, requested bytes) only — the std::vector allocator of cba_create's observation-sized host arrays: the
+// capacity of a pooled block is remembered beside the pool
+inline std::map<void*, size_t>& tracked() { static std::map<void*, size_t> m; return m; }
+inline void* acquire_tracked(size_t bytes) {
+  size_t cap = 0;
+  void* ptr = acquire(bytes, &cap);
+  if (ptr && cap >= kPooledFrom) { std::lock_guard<std::mutex> lock(pool_mu()); tracked()[ptr] = cap; }
+  return ptr;
+}
+inline void release_tracked(void* ptr, size_t bytes) {
+  size_t cap = bytes;
+  if (ptr && bytes >= kPooledFrom) {
+    std::lock_guard<std::mutex> lock(pool_mu());
+    auto it = tracked().find(ptr);
+    if (it != tracked().end()) { cap = it->second; tracked().erase(it); }
+  }
+  release(ptr, cap);
+}
+}  // namespace rawvec_detail
+
 template <typename T>
 struct RawVec {
-  std::unique_ptr<T[]> p;
-  size_t n = 0;
-  void resize_uninit(size_t m) { p.reset(new T[m]); n = m; }
-  T* data() { return p.get(); }
-  const T* data() const { return p.get(); }
+  static_assert(std::is_trivially_destructible<T>::value && std::is_trivially_default_constructible<T>::value, "plain data only");
+  T* p = nullptr;
+  size_t n = 0, capacity_bytes = 0;
+  RawVec() = default;
+  RawVec(const RawVec&) = delete;
+  RawVec& operator=(const RawVec&) = delete;
+  RawVec(RawVec&& o) noexcept : p(o.p), n(o.n), capacity_bytes(o.capacity_bytes) { o.p = nullptr; o.n = 0; o.capacity_bytes = 0; }
+  RawVec& operator=(RawVec&& o) noexcept {
+    if (this != &o) { rawvec_detail::release(p, capacity_bytes); p = o.p; n = o.n; capacity_bytes = o.capacity_bytes; o.p = nullptr; o.n = 0; o.capacity_bytes = 0; }
+    return *this;
+  }
+  ~RawVec() { rawvec_detail::release(p, capacity_bytes); }
+  void resize_uninit(size_t m) {
+    rawvec_detail::release(p, capacity_bytes);
+    p = static_cast<T*>(rawvec_detail::acquire(m * sizeof(T), &capacity_bytes));
+    if (!p && m) throw std::bad_alloc();
+    n = m;
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
   size_t size() const { return n; }
   bool empty() const { return n == 0; }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }
-  T* begin() { return p.get(); }
-  T* end() { return p.get() + n; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
 };
 
 // CPUs this process may actually burn: the hardware count capped by the cgroup's CPU quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us).  A container
@@ -128,6 +212,7 @@ struct Reg2Plan {
   long lds_cycles = 0;                // LDS cycles they take with the plan's slots (1 per group when conflict-free)
   long lds_cycles_arrival = 0;        // ... and with the records in arrival order, for comparison
   int n_regions = 1;
+  double seconds_runs = 0.0, seconds_jobs = 0.0, seconds_concat = 0.0;  // wall time of the three phases of build_reg2_plan (CBA_PLAN_TIMING prints them)
 };
 
 namespace reg2_detail {
@@ -155,6 +240,7 @@ inline int b128_group(int lane) {
 // Returns 0, or -1 when a single point does not fit a chunk.
 inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hps, Reg2Plan& out) {
   using namespace reg2_detail;
+  const auto t_begin = std::chrono::steady_clock::now();
   const int G = prm.G, g = prm.g, C = prm.C, P = prm.P, rep = std::max(1, prm.rep);
   const int nT = G * (G + 1) / 2, nblk = g * g, R = prm.chunk_cap;
   const int NW = std::max(4, prm.n_waves / 4 * 4), NWORD = NW / 4;
@@ -198,6 +284,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
     for (auto& th : pool) th.join();
     for (long v : part) stream_total += v;
   }
+  const auto t_phase0 = std::chrono::steady_clock::now();
   // regions: the same point ranges for every tile, about region_chunks chunks of an average tile each
   const long per_tile = std::max<long>(1, stream_total / std::max(nT, 1));
   int n_regions = (int)std::max<long>(1, (per_tile + (long)R * prm.region_chunks / 2) / ((long)R * std::max(prm.region_chunks, 1)));
@@ -693,6 +780,7 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
   if (prm.cancel && prm.cancel->load(std::memory_order_relaxed)) return -2;
   for (const Job& j : jobs)
     if (j.rc) return j.rc;
+  const auto t_phase1 = std::chrono::steady_clock::now();
 
   // concatenate in (tile, region) order: offsets first, then the copies by the worker threads
   size_t n_obs = 0, n_codes = 0, n_chunks = 0;
@@ -739,6 +827,9 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
   }
   const size_t ch = n_chunks;
   out.tile_chunk_begin[nT] = (int)ch;
+  out.seconds_runs = std::chrono::duration<double>(t_phase0 - t_begin).count();
+  out.seconds_jobs = std::chrono::duration<double>(t_phase1 - t_phase0).count();
+  out.seconds_concat = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase1).count();
   return 0;
 }
 
