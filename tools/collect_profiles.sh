@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 tail -1 $S/bench.json > $D/${R}_end_bench.json
 cp $S/parity.json $D/parity_${R}.json
 for w in cfg4 cfg5 cfg23; do cp $S/${w}_kernel_trace.md $D/${R}_${w}_kernel_trace.md; done
-for w in cfg2 cfg3; do [ -f $S/${w}_iteration.txt ] && cp $S/${w}_iteration.txt $D/${R}_${w}_iteration.txt; done
+for w in cfg2 cfg3 cfg4; do [ -f $S/${w}_iteration.txt ] && cp $S/${w}_iteration.txt $D/${R}_${w}_iteration.txt; done
 for w in cfg4 cfg5; do cp $S/pmc_$w.md $D/${R}_${w}_pmc.md; cp $S/pmc_$w.json $D/pmc_$w.json; done
 cp $S/schur_clock_cfg4.log $D/${R}_schur_phase_clocks.txt
 cp $S/chol_trace.log $D/${R}_chol_trace.txt

@@ -23,12 +23,13 @@ cd $GRAFT_REPO_ROOT
 for w in cfg4 cfg5 cfg23; do DB=$(find $O/trace_$w -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB $O/${w}_kernel_trace.md > /dev/null; done
 DB=$(find $O/trace_cfg23 -name "*.db" | head -1); [ -n "$DB" ] && python tools/trace_iteration.py $DB k_tprep 0.04 > $O/cfg2_iteration.txt 2>&1  # (cfg2 runs first: 48 of the ~640 iterations)
 [ -n "$DB" ] && python tools/trace_iteration.py $DB k_tprep 0.6 > $O/cfg3_iteration.txt 2>&1
+DB4=$(find $O/trace_cfg4 -name "*.db" | head -1); [ -n "$DB4" ] && python tools/trace_iteration.py $DB4 k_tprep 0.6 > $O/cfg4_iteration.txt 2>&1
 for w in cfg4 cfg5; do python tools/pmc_summary.py $O/pmc_fetch_$w $O/pmc_write_$w $O/pmc_$w.md $O/pmc_$w.json > /dev/null 2>&1; done
 find $O -name "*.db" -size +8M -delete; find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 P=$GRAFT_REPO_ROOT/caliscope_amd/libcaliscope_ba_prof.so
 CALISCOPE_BA_LIB=$P CBA_SCHUR_CLOCK=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/schur_clock_cfg4.log > /dev/null
 CALISCOPE_BA_LIB=$P CBA_CHOL_TRACE=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/chol_trace.log > /dev/null
-timeout 300 python tools/create_timing.py > $O/create_timing.log 2>&1
+timeout 400 python tools/create_timing.py > $O/create_timing.log 2>&1
 timeout 200 python tools/real_session_timing.py > $O/real_session.log 2>&1
 timeout 300 python bench.py --gpus 2 --devices 0,0 --xchg direct --no-cpu --also "" --steps 20 --warmup 4 > $O/two_ranks_cfg4.json 2> $O/two_ranks_cfg4.err
 timeout 600 python bench.py --gpus 2 --devices 0,0 --xchg direct --no-cpu --workload cfg5 --also "" --steps 8 --warmup 2 > $O/two_ranks_cfg5.json 2> $O/two_ranks_cfg5.err
