@@ -165,6 +165,12 @@ class CaptureVolume:
     def _matched_arrays(self):
         col = self.image_points.arrays()
         index_of = self.camera_array.posed_cam_id_to_index
+        # the volume is immutable apart from its camera array (a camera can be posed later): the arrays are kept per posed-camera set — optimize(),
+        # the reprojection report and the filters of one volume marshal the same 2M rows (cfg4: 20 ms each time)
+        key = tuple(sorted(index_of.items()))
+        kept = getattr(self, "_matched_cache", None)
+        if kept is not None and kept[0] == key:
+            return kept[1]
         cam_id = col["cam_id"]
         # cam_id -> position among the posed cameras through a dense table (ids are small non-negative integers)
         lo = min(int(cam_id.min()), min(index_of, default=0)) if cam_id.size else 0
@@ -180,10 +186,19 @@ class CaptureVolume:
             at = np.minimum(np.searchsorted(ids, cam_id), len(ids) - 1) if len(ids) else np.zeros(cam_id.shape, dtype=np.int64)
             cam_idx = np.where(ids[at] == cam_id, pos[at], -1).astype(np.int32) if len(ids) else np.full(cam_id.shape, -1, dtype=np.int32)
         mask = (self.img_to_obj_map >= 0) & (cam_idx >= 0)
-        camera_indices = cam_idx[mask]
-        image_coords = np.stack([col["img_loc_x"][mask], col["img_loc_y"][mask]], axis=1)
-        obj_indices = self.img_to_obj_map[mask].astype(np.int32)
-        return mask, camera_indices, image_coords, obj_indices
+        if mask.all():  # (the usual case after triangulation + filtering: nothing to select)
+            camera_indices, obj_indices = cam_idx, self.img_to_obj_map.astype(np.int32)  # (a copy: the map itself stays writable)
+            image_coords = np.empty((len(cam_idx), 2))
+            image_coords[:, 0] = col["img_loc_x"]; image_coords[:, 1] = col["img_loc_y"]
+        else:
+            camera_indices = cam_idx[mask]
+            image_coords = np.stack([col["img_loc_x"][mask], col["img_loc_y"][mask]], axis=1)
+            obj_indices = self.img_to_obj_map[mask].astype(np.int32)
+        for a in (mask, camera_indices, image_coords, obj_indices):
+            a.setflags(write=False)  # shared between calls
+        out = (mask, camera_indices, image_coords, obj_indices)
+        object.__setattr__(self, "_matched_cache", (key, out))
+        return out
 
     def pixel_f_scale(self, px: float = 1.0) -> float:
         focal = [cam.matrix[0, 0] for cam in self.camera_array.posed_cameras.values() if cam.matrix is not None]
