@@ -9,4 +9,4 @@ timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 cd $GRAFT_REPO_ROOT
 python tools/sq_counter_summary.py $O/sq_cfg4.md $O/passA $O/passB 2>&1 | tail -30
 find $O -name "*.csv" -size +3M -delete; find $O -name "*.db" -delete
-tail -3 $O/passA.err $O/passB.err | cut -c1-300
+
