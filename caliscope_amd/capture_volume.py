@@ -380,7 +380,8 @@ class CaptureVolume:
             {
                 "sync_index": col["sync_index"], "cam_id": col["cam_id"], "object_id": col["object_id"], "keypoint_id": col["keypoint_id"],
                 "error_x": err[:, 0], "error_y": err[:, 1], "euclidean_error": np.sqrt(sq),
-            }
+            },
+            copy=False,  # (the arrays are fresh: no need to copy them into consolidated blocks)
         )
         index_of = self.camera_array.posed_cam_id_to_index
         n_cam = len(index_of)

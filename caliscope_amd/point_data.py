@@ -66,6 +66,13 @@ def _fill_track_gaps(df: pd.DataFrame, track_keys: list, value_cols: list, max_g
     return out.sort_values(track_keys + ["sync_index"], kind="stable").reset_index(drop=True)
 
 
+def _take_rows(df: pd.DataFrame, rows) -> pd.DataFrame:
+    """Row subset (boolean mask or index array) re-indexed from 0, column by column: numpy selects 2M rows of one column in a few milliseconds, while
+    ``df[mask]`` on the consolidated frame takes every block apart and puts it together again (0.12 s of the 0.17 s of a filter pass on 2M observations)."""
+    rows = np.asarray(rows)
+    return pd.DataFrame({c: df[c].to_numpy()[rows] for c in df.columns}, copy=False)
+
+
 def _validated(df: pd.DataFrame, required: dict, optional: tuple, what: str) -> pd.DataFrame:
     df = df.copy()
     missing = [c for c in required if c not in df.columns]
@@ -93,7 +100,7 @@ class ImagePoints:
         """The rows selected by a boolean mask or an index array, re-indexed from 0.  A subset of a validated table is
         valid, so nothing is re-checked (the filters between solver passes use this)."""
         out = object.__new__(ImagePoints)
-        out._df = self._df[rows].reset_index(drop=True) if np.asarray(rows).dtype == bool else self._df.iloc[rows].reset_index(drop=True)
+        out._df = _take_rows(self._df, rows)
         out._arrays = None
         return out
 
@@ -166,7 +173,7 @@ class WorldPoints:
     def take(self, rows) -> "WorldPoints":
         """Row subset (boolean mask or index array) of a validated table, re-indexed from 0, without re-validation."""
         out = object.__new__(WorldPoints)
-        out._df = self._df[rows].reset_index(drop=True) if np.asarray(rows).dtype == bool else self._df.iloc[rows].reset_index(drop=True)
+        out._df = _take_rows(self._df, rows)
         sync = out._df["sync_index"].to_numpy()
         moving = sync[sync != STATIC_SYNC_INDEX]
         out.min_index = int(moving.min()) if moving.size else 0
