@@ -372,10 +372,11 @@ class CaptureVolume:
         if n_matched == 0:
             raise ValueError("No matched observations for reprojection error calculation")
         err = self._pixel_errors(camera_indices, image_coords, obj_indices, _engine_factory)
-        sq = np.sum(err * err, axis=1)
+        sq = np.einsum("ij,ij->i", err, err)
         all_df = self.image_points._df
         # columns as arrays: a boolean-indexed DataFrame copy of 2M rows costs more than everything else in this function
-        col = {c: all_df[c].to_numpy()[mask] for c in ("sync_index", "cam_id", "object_id", "keypoint_id")}
+        everything = n_matched == n_total  # (the usual case after triangulation and filtering: nothing to select)
+        col = {c: (all_df[c].to_numpy() if everything else all_df[c].to_numpy()[mask]) for c in ("sync_index", "cam_id", "object_id", "keypoint_id")}
         raw = pd.DataFrame(
             {
                 "sync_index": col["sync_index"], "cam_id": col["cam_id"], "object_id": col["object_id"], "keypoint_id": col["keypoint_id"],
@@ -398,7 +399,7 @@ class CaptureVolume:
         mean_sq = np.bincount(inv, weights=sq, minlength=keys.size) / np.maximum(np.bincount(inv, minlength=keys.size), 1)
         by_point = dict(zip(zip((keys // span).tolist(), (keys % span + kp_lo).tolist()), np.sqrt(mean_sq).tolist()))
         cams_all, inv_all = _group_index(all_df["cam_id"].to_numpy())
-        cams_ok, inv_ok = _group_index(col["cam_id"])
+        cams_ok, inv_ok = (cams_all, inv_all) if everything else _group_index(col["cam_id"])
         n_all, n_ok = np.bincount(inv_all, minlength=cams_all.size), np.bincount(inv_ok, minlength=cams_ok.size)
         total_by_cam, matched_by_cam = dict(zip(cams_all.tolist(), n_all.tolist())), dict(zip(cams_ok.tolist(), n_ok.tolist()))
         unmatched_by_camera = {

@@ -15,7 +15,7 @@ from caliscope_amd.engine import BAProblem  # noqa: E402
 from caliscope_amd.hip_engine import HipEngine  # noqa: E402
 from caliscope_amd.synthetic import make_config  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "cfg4"
 t = time.perf_counter()
 sc = make_config(name)
 print(f"{name}: scene generated in {time.perf_counter() - t:.2f} s ({len(sc.camera_indices)} observations)")
@@ -46,3 +46,8 @@ print(f"  marshalling DataFrames -> arrays {t_marshal:.3f} s | engine set-up (so
 print(f"reprojection_report (device residuals + group-bys): {t_rep:.3f} s, RMS {rep.overall_rmse:.4f} px")
 t = time.perf_counter(); flt = out.filter_by_percentile_error(2.5); t_flt = time.perf_counter() - t
 print(f"filter_by_percentile_error(2.5) on the cached report: {t_flt:.3f} s ({len(out.image_points) - len(flt.image_points)} observations removed)")
+if "--profile-report" in sys.argv:  # where the report's time goes (host group-bys against the device evaluation)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); out.compute_reprojection_report(); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+
