@@ -150,3 +150,35 @@ def test_committed_parity_at_size():
         tight = c5["tight_reference"]["detail"]
         assert tight["aligned_pos"] <= 1e-6 and tight["aligned_ang_rad"] <= 1e-6 and tight["points_above_1e-6"] == 0, case
         _oracle_polish_ok(c5["oracle_polish"])
+
+
+def test_weak_points_reports_what_the_data_say_about_a_displaced_point():
+    """bench.weak_points (parity_at_size.py, round 4): for every point two answers place more than 1e-6 apart it moves THAT point, alone, to the
+    reference's position in the product's gauge and reports the oracle's cost change.  A well-observed point moved by 3e-5 changes the cost visibly
+    (not "indistinguishable"); a gauge change of the whole reference (rotation, scale, shift) is aligned away and flags nothing."""
+    import numpy as np
+    from helpers import small_problem
+
+    bench = _bench()
+    sc, par, x0 = small_problem(n_cams=5, n_points=120, k=5)
+    n = par.n_camera_params
+    ref = x0.copy()
+    ref[n + 3 * 7: n + 3 * 7 + 3] += [3e-5, 0.0, 0.0]
+    out = bench.weak_points(sc, par, x0, ref, "linear", 1.0)
+    assert out["points_above_1e-6"] == 1 and out["listed"][0]["point"] == 7 and out["listed"][0]["observations"] >= 1
+    assert abs(out["listed"][0]["rel_cost_change_if_moved_to_the_reference_position"]) > 1e-9 and out["all_listed_indistinguishable_at_1e-12_of_the_cost"] is False  # (x0 is no minimum: either sign)
+    # the same answer in another gauge: points and camera centres rotated, scaled and shifted together
+    from caliscope_amd.cameras import matrix_to_rvec, rvec_to_matrix
+
+    Q = rvec_to_matrix(np.array([0.1, -0.2, 0.05]))
+    sc_g, t_g = 1.3, np.array([0.4, -0.1, 0.2])
+    moved = x0.copy()
+    moved[n:] = (sc_g * x0[n:].reshape(-1, 3) @ Q.T + t_g).ravel()
+    for off in par.camera_param_offsets:
+        R = rvec_to_matrix(x0[off:off + 3])
+        centre = -R.T @ x0[off + 3:off + 6]
+        R_new = R @ Q.T                                 # X_cam = R (X - c)  ->  R Q^T (X' - c'), X' = s Q X + t (up to the scale, which the alignment takes out)
+        moved[off:off + 3] = matrix_to_rvec(R_new)
+        moved[off + 3:off + 6] = -R_new @ (sc_g * Q @ centre + t_g)
+    same = bench.weak_points(sc, par, x0, moved, "linear", 1.0)
+    assert same["points_above_1e-6"] == 0 and same["listed"] == [] and same["all_listed_indistinguishable_at_1e-12_of_the_cost"] is True

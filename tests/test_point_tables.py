@@ -148,3 +148,65 @@ def test_marshalling_with_sparse_and_unposed_camera_ids():
         assert mask.tolist() == [True, False, True, True, False]
         assert cam_idx.tolist() == [0, 1, 1] and obj.tolist() == [0, 0, 1] and uv[:, 0].tolist() == [1.0, 3.0, 4.0]
         assert cam_idx.dtype == np.int32 and obj.dtype == np.int32
+
+
+def test_row_subsets_column_by_column_equal_the_frame_s_own():
+    """ImagePoints.take / WorldPoints.take build the subset column by column (round 4): same rows, columns, order, dtypes and a fresh 0..n-1 index as
+    ``df[mask].reset_index(drop=True)`` / ``df.iloc[idx].reset_index(drop=True)``, NaN columns included."""
+    import pandas as pd
+
+    from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+    rng = np.random.default_rng(5)
+    n = 500
+    img = ImagePoints(pd.DataFrame({"sync_index": rng.integers(0, 40, n), "cam_id": rng.integers(0, 6, n), "object_id": rng.integers(0, 3, n),
+                                    "keypoint_id": rng.integers(0, 20, n), "img_loc_x": rng.random(n) * 640, "img_loc_y": rng.random(n) * 480,
+                                    "frame_time": np.where(rng.random(n) < 0.3, np.nan, rng.random(n))}))
+    mask = rng.random(n) < 0.6
+    idx = rng.permutation(n)[:123]
+    for rows in (mask, idx, np.zeros(n, dtype=bool), np.ones(n, dtype=bool)):
+        got = img.take(rows)
+        want = img._df[rows].reset_index(drop=True) if rows.dtype == bool else img._df.iloc[rows].reset_index(drop=True)
+        pd.testing.assert_frame_equal(got._df, want)
+        assert len(got) == len(want) and set(got.arrays()) == set(img.arrays())
+        assert all(np.array_equal(got.arrays()[c], want[c].to_numpy()) for c in got.arrays())
+    world = WorldPoints(pd.DataFrame({"sync_index": np.r_[np.full(5, -1), rng.integers(3, 30, 95)], "object_id": rng.integers(0, 3, 100), "keypoint_id": np.arange(100),
+                                      "x_coord": rng.random(100), "y_coord": rng.random(100), "z_coord": rng.random(100)}))
+    keep = rng.random(100) < 0.5
+    sub = world.take(keep)
+    pd.testing.assert_frame_equal(sub._df, world._df[keep].reset_index(drop=True))
+    moving = sub._df["sync_index"].to_numpy()
+    moving = moving[moving != -1]
+    assert (sub.min_index, sub.max_index) == (int(moving.min()), int(moving.max()))
+    assert np.array_equal(sub.points, world.points[keep])
+
+
+def test_matched_arrays_are_kept_per_posed_camera_set():
+    """CaptureVolume._matched_arrays marshals once per volume (round 4) — and again when the set of posed cameras changes under it; the arrays it
+    hands out are read-only (they are shared between calls), the volume's own observation -> point map stays writable."""
+    import pandas as pd
+    import pytest
+
+    from caliscope_amd.cameras import CameraArray, CameraData
+    from caliscope_amd.capture_volume import CaptureVolume
+    from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+    K = np.array([[800.0, 0, 320], [0, 800.0, 240], [0, 0, 1]])
+
+    def cam(cid, posed=True):
+        return CameraData(cam_id=cid, size=(640, 480), matrix=K.copy(), distortions=np.zeros(5), rotation=np.eye(3) if posed else None,
+                          translation=np.array([0.0, 0.0, 2.0]) if posed else None)
+
+    array = CameraArray({0: cam(0), 1: cam(1), 2: cam(2, posed=False)})
+    img = ImagePoints(pd.DataFrame({"sync_index": 0, "cam_id": [0, 1, 2, 0], "object_id": 0, "keypoint_id": [0, 0, 0, 1], "img_loc_x": [1.0, 2.0, 3.0, 4.0], "img_loc_y": 0.5}))
+    world = WorldPoints(pd.DataFrame({"sync_index": 0, "object_id": 0, "keypoint_id": [0, 1], "x_coord": 0.0, "y_coord": 0.0, "z_coord": 0.0}))
+    vol = CaptureVolume(array, img, world)
+    first = vol._matched_arrays()
+    assert vol._matched_arrays() is first and first[0].tolist() == [True, True, False, True]
+    with pytest.raises(ValueError):
+        first[2][0, 0] = 9.0
+    vol.img_to_obj_map[0] = vol.img_to_obj_map[0]  # (still writable)
+    array.cameras[2].rotation, array.cameras[2].translation = np.eye(3), np.array([0.0, 0.0, 2.0])  # the third camera gets a pose
+    again = vol._matched_arrays()
+    assert again is not first and again[0].tolist() == [True, True, True, True] and again[1].tolist() == [0, 1, 2, 0]
+    assert again[2].shape == (4, 2) and again[2][:, 0].tolist() == [1.0, 2.0, 3.0, 4.0] and again[3].dtype == np.int32
