@@ -82,6 +82,9 @@ def _validated(df: pd.DataFrame, required: dict, optional: tuple, what: str) -> 
         if col not in df.columns:
             df[col] = np.nan
     for col, kind in required.items():
+        have = df[col].dtype
+        if (kind == "int" and have == np.int64) or (kind == "float" and have == np.float64 and not np.isnan(df[col].to_numpy()).any()):
+            continue  # already what validation would make of it (an int64 column has no nulls): no conversion pass over millions of rows
         num = pd.to_numeric(df[col], errors="coerce")
         if num.isna().any():
             raise ValueError(f"{what} validation failed: non-nullable column '{col}' contains {int(num.isna().sum())} null value(s)")
