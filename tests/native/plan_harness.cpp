@@ -1,5 +1,5 @@
 // CPU replay of the dealt Schur plan (caliscope_amd/csrc/schur_plan.h): walks the transposed pair codes exactly as
-// k_schur_reg2 does (chunk by chunk, wave by wave, iteration by iteration, lane by lane) and accumulates T_i T_j^T per
+// k_schur_reg3 does (chunk by chunk, wave by wave, iteration by iteration, lane by lane) and accumulates T_i T_j^T per
 // owner thread, so that tests/test_schur_plan.py can compare the per-block sums with a direct sum over the points.
 #include <cstdio>
 #include <cstdlib>

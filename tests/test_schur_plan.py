@@ -1,5 +1,5 @@
 """The dealt plan of the register Schur kernel (csrc/schur_plan.h) on the CPU: compiled by g++ with a replay harness
-(tests/native/plan_harness.cpp) that walks the transposed pair codes the way k_schur_reg2 does.  Every camera-pair block
+(tests/native/plan_harness.cpp) that walks the transposed pair codes the way k_schur_reg3 does.  Every camera-pair block
 must receive exactly the pairs of ``sum_p W_p V'^-1 W_p^T`` (the reference forms the same sums
 implicitly in ``J^T J``, core/reprojection.py:128-234), and the plan must keep the lanes busy."""
 import ctypes as C
