@@ -211,8 +211,7 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     }
 
 
-# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg3; k_schur_reg2 and
-# k_schur_tile are the fallbacks)
+# kernels of each timer family in the rocprofv3 summaries (the Schur pass is k_tprep + k_schur_reg3)
 PMC_KERNEL = {"schur": ("k_tprep", "k_schur_reg3"), "build": ("k_build",), "jv": ("k_jv",),
               "backsub": ("k_backsub",), "cost": ("k_cost<false>",)}
 
