@@ -56,15 +56,22 @@ class OptimizeResult(dict):
 def _make_strictly_feasible(x, lb, ub, rstep=1e-10):
     """scipy's ``make_strictly_feasible`` (common.py:437-463): nudge points sitting on a bound inside."""
     x = x.copy()
-    lower_thr = rstep * np.maximum(1, np.abs(lb))
-    upper_thr = rstep * np.maximum(1, np.abs(ub))
+    # only entries with a finite bound can move (here: the camera block — a few hundred of millions of parameters; the full-vector form cost more
+    # than a small solve)
+    at = np.flatnonzero(np.isfinite(lb) | np.isfinite(ub))
+    if at.size == 0:
+        return x
+    xs, lbs, ubs = x[at], lb[at], ub[at]
+    lower_thr = rstep * np.maximum(1, np.abs(lbs))
+    upper_thr = rstep * np.maximum(1, np.abs(ubs))
     with np.errstate(invalid="ignore"):
-        lo = np.isfinite(lb) & (x - lb <= np.minimum(ub - x, lower_thr))
-        hi = np.isfinite(ub) & (ub - x <= np.minimum(x - lb, upper_thr))
-    x[lo] = lb[lo] + lower_thr[lo]
-    x[hi] = ub[hi] - upper_thr[hi]
-    bad = (x < lb) | (x > ub)
-    x[bad] = 0.5 * (lb[bad] + ub[bad])
+        lo = np.isfinite(lbs) & (xs - lbs <= np.minimum(ubs - xs, lower_thr))
+        hi = np.isfinite(ubs) & (ubs - xs <= np.minimum(xs - lbs, upper_thr))
+    xs[lo] = lbs[lo] + lower_thr[lo]
+    xs[hi] = ubs[hi] - upper_thr[hi]
+    bad = (xs < lbs) | (xs > ubs)
+    xs[bad] = 0.5 * (lbs[bad] + ubs[bad])
+    x[at] = xs
     return x
 
 

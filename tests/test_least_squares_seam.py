@@ -118,3 +118,23 @@ def test_infeasible_trials_are_rejected_not_accepted():
     lo[off] = 0.99  # ... but it may not fall below 0.99 either: the optimum 0.971 is outside
     res = _call(par, sc, x0, bounds=(lo, hi), max_nfev=60)
     assert lo[off] < res.x[off] < hi[off]
+
+
+def test_strict_feasibility_equals_scipys_on_the_bounded_entries():
+    """least_squares._make_strictly_feasible touches only the entries that have a finite bound (the camera block: a few hundred of millions of
+    parameters); the result must be scipy's ``make_strictly_feasible`` (common.py:437-463) on the whole vector."""
+    import numpy as np
+    from scipy.optimize._lsq.common import make_strictly_feasible
+
+    from caliscope_amd.least_squares import _make_strictly_feasible
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = 60
+        lb = np.where(rng.random(n) < 0.5, -np.inf, rng.normal(size=n))
+        ub = np.where(rng.random(n) < 0.5, np.inf, np.clip(lb, -5, 5) + rng.random(n) + 1e-3)
+        x = np.where(np.isfinite(lb), lb, np.where(np.isfinite(ub), ub - 0.5, 0.0)) + np.where(rng.random(n) < 0.5, 0.0, rng.random(n) * 1e-11)
+        x = np.clip(x, lb, ub)
+        assert np.array_equal(_make_strictly_feasible(x, lb, ub), make_strictly_feasible(x, lb, ub, rstep=1e-10))
+    free = rng.normal(size=10)
+    assert np.array_equal(_make_strictly_feasible(free, np.full(10, -np.inf), np.full(10, np.inf)), free)
