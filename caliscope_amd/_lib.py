@@ -64,10 +64,10 @@ class StepInfo(C.Structure):
 class Info(C.Structure):
     _fields_ = [
         ("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_cam_params", C.c_int32), ("n_params", C.c_int32),
-        ("n_obs", C.c_int64), ("n_chunks", C.c_int32), ("grid_blocks", C.c_int32), ("schur_in_lds", C.c_int32),
+        ("n_obs", C.c_int64), ("n_chunks", C.c_int32), ("grid_blocks", C.c_int32), ("plan_state", C.c_int32),
         ("max_obs_per_point", C.c_int32), ("device_bytes", C.c_int64),
         ("schur_groups", C.c_int32), ("schur_tiles", C.c_int32), ("schur_grid", C.c_int32), ("n_heavy_points", C.c_int32),
-        ("schur_stream_len", C.c_int64), ("schur_pairs", C.c_int64), ("schur_wide", C.c_int32), ("build_camg", C.c_int32),
+        ("schur_stream_len", C.c_int64), ("schur_pairs", C.c_int64), ("plan_error", C.c_int32), ("build_camg", C.c_int32),
     ]
 
 
@@ -144,6 +144,7 @@ SIGNATURES = {
     "cba_enable_timers": (C.c_int, [C.c_void_p, C.c_int32]),
     "cba_host_plan": (C.c_int64, [C.c_int32, C.c_int64, c_int32_p, c_int32_p, C.c_int32, C.c_int32, c_int64_p, c_int64_p, c_int64_p]),
     "cba_triangulate": (C.c_int, [C.POINTER(TriangulateDesc), C.c_int32, c_double_p, c_double_p]),
+    "cba_trim": (C.c_int64, []),
     "cba_last_error": (C.c_char_p, []),
     "cba_set_error": (C.c_int, [C.c_int32, C.c_char_p]),
     "cba_version": (C.c_int, []),

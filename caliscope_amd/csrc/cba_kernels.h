@@ -151,10 +151,9 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
 // x indexes columns (coalesced), y splits the rows REDUCE_RY ways (two interleaved chains each) so that the chain of
 // dependent loads per thread stays short (512 rows: 16 loads deep); partial sums meet in LDS in a fixed order.
 constexpr int REDUCE_RY = 16;
-__global__ void __launch_bounds__(64 * REDUCE_RY)
-k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out,
-              double* __restrict__ grad_out = nullptr, const int* __restrict__ cam_off = nullptr, const int* __restrict__ cam_np = nullptr,
-              int stride = 1, int tri = 0) {
+__device__ __forceinline__ void reduce_rows_block(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out,
+                                                  double* __restrict__ grad_out, const int* __restrict__ cam_off, const int* __restrict__ cam_np,
+                                                  int stride, int tri) {
   __shared__ double sh[REDUCE_RY][64];
   const int j = blockIdx.x * 64 + threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -178,6 +177,46 @@ k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* _
       if (r >= 0 && r < cam_np[c]) grad_out[cam_off[c] + r] = tot;
     }
   }
+}
+__global__ void __launch_bounds__(64 * REDUCE_RY)
+k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out,
+              double* __restrict__ grad_out = nullptr, const int* __restrict__ cam_off = nullptr, const int* __restrict__ cam_np = nullptr,
+              int stride = 1, int tri = 0) {
+  reduce_rows_block(partial, nrow, width, out, grad_out, cam_off, cam_np, stride, tri);
+}
+// Single-rank fused iteration (round 5): the end-of-iteration packet (k_publish: one workgroup, 4-5 us + a launch gap) leaves with the LAST workgroup
+// of the launch that reduces the trial build's camera blocks — the packet needs none of that reduction's results (scalars, the trial cost rows and
+// the step-norm rows are all there before the launch), so the two run side by side.  Same packet as k_publish; the two column sums are taken by
+// 1024 threads in this kernel's own fixed order.
+struct PubArgs {
+  double* scal; int n_scal; int* flags; double* host_scal; int* host_flags; unsigned long long seq;
+  const double* part_a; int rows_a, slot_a; const double* part_b; int rows_b, slot_b;
+};
+__global__ void __launch_bounds__(64 * REDUCE_RY)
+k_reduce_rows_pub(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out, double* __restrict__ grad_out,
+                  const int* __restrict__ cam_off, const int* __restrict__ cam_np, int stride, int tri, PubArgs pub) {
+  if (blockIdx.x + 1 < gridDim.x) { reduce_rows_block(partial, nrow, width, out, grad_out, cam_off, cam_np, stride, tri); return; }
+  __shared__ double sh_w[2][REDUCE_RY];
+  const int t = threadIdx.y * 64 + threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int r = t; r < pub.rows_a; r += 64 * REDUCE_RY) a += pub.part_a[r];
+  for (int r = t; r < pub.rows_b; r += 64 * REDUCE_RY) b += pub.part_b[r];
+  a = wave_sum(a); b = wave_sum(b);
+  if (threadIdx.x == 0) { sh_w[0][threadIdx.y] = a; sh_w[1][threadIdx.y] = b; }
+  __syncthreads();
+  __shared__ double sh_tot[2];
+  if (t == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int i = 0; i < REDUCE_RY; ++i) { ta += sh_w[0][i]; tb += sh_w[1][i]; }
+    pub.scal[pub.slot_a] = ta; pub.scal[pub.slot_b] = tb;
+    sh_tot[0] = ta; sh_tot[1] = tb;
+  }
+  __syncthreads();
+  if (t < pub.n_scal) pub.host_scal[t] = (t == pub.slot_a) ? sh_tot[0] : (t == pub.slot_b) ? sh_tot[1] : pub.scal[t];
+  if (t < 4) { pub.host_flags[t] = pub.flags[t]; pub.flags[t] = 0; }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) reinterpret_cast<volatile unsigned long long*>(pub.host_scal)[63] = pub.seq;
 }
 // Sharded solves: every host-visible primitive ends with ONE all-reduce of the scalars it produced.  k_xpack gathers
 // the scal slots named by `mask`, the four flags (as 0/1 doubles) and, when asked, this rank's max |g| (scal[4]) in
@@ -492,11 +531,20 @@ struct CsPlan {
 // UGLOB (more cameras than the LDS holds packed blocks for: > ~650 six- / ~320 nine-parameter cameras; the reference has no limit,
 // core/reprojection.py:75-119): a thread's register sums go to ONE global copy of the blocks by FP64 global atomics (the caller zeroes it; a thread
 // flushes once per camera change, ~13 atomics per observation at 1000 cameras) instead of to the workgroup's LDS copy; partialU is that copy.
-template <int NC, bool CAMG = false, bool UGLOB = false>
+// TRIAL (single-rank fused iteration): the pass evaluates the TRIAL point and forms its point entries itself while staging a super-chunk's points —
+// x_new = x + alpha g / sinv^2 + beta s with (alpha, beta) from k_step_cam — writes them to x_new for the passes behind it and leaves its share of
+// ||step||^2 in step_partial[workgroup]: k_trial_update's pass over five vectors is gone (xvec is not read then).
+struct TrialSrc {
+  const double *x, *g, *sinv, *s;  // current point, gradient, scale, damped step
+  const double* ab;                // device: alpha, beta
+  double* x_new;
+  double* step_partial;            // [grid]
+};
+template <int NC, bool CAMG = false, bool UGLOB = false, bool TRIAL = false>
 __global__ void __launch_bounds__(BLOCK)
 k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams, int loss, double f_scale,
            double* __restrict__ Vblk, double* __restrict__ gvec, double* __restrict__ partialU, double* __restrict__ partial_cost,
-           int* __restrict__ flags, const double* __restrict__ skip) {
+           int* __restrict__ flags, const double* __restrict__ skip, TrialSrc trial = TrialSrc{}) {
   using UP = UPack<NC>;
   static_assert(!UGLOB || CAMG, "a camera count beyond the LDS copy of the blocks is beyond the LDS copy of the table as well");
   if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
@@ -512,14 +560,30 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
     for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) sh_U[i] = 0.0;
   const double* px = xvec + lay.ncp_pad;
   double* gp = gvec + lay.ncp_pad;
-  double cost = 0.0;
+  double cost = 0.0, step_sq = 0.0;
+  const double t_alpha = TRIAL ? trial.ab[0] : 0.0, t_beta = TRIAL ? trial.ab[1] : 0.0;
   bool bad = false;
   for (int s = blockIdx.x; s < cs.n_sc; s += gridDim.x) {
     const int o0 = cs.obs_start[s], o1 = cs.obs_start[s + 1], p0 = cs.pt_first[s], npts = cs.pt_count[s];
     __syncthreads();  // the previous super-chunk's sums have been written out (and, first pass, the table / U zeroing is done)
     for (int i = threadIdx.x; i < 9 * PM; i += BLOCK) sh_vg[i] = 0.0;
-    for (int i = threadIdx.x; i < npts; i += BLOCK) {
-      sh_x[i] = px[p0 + i]; sh_x[PM + i] = px[lay.Ppad + p0 + i]; sh_x[2 * PM + i] = px[2 * lay.Ppad + p0 + i];
+    if (TRIAL) {  // the point entries of the trial point are formed here (k_trial_update's work) and written out for the passes behind this one
+      for (int i = threadIdx.x; i < npts; i += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const long e = (long)lay.ncp_pad + (long)k * lay.Ppad + p0 + i;
+          const double si = trial.sinv[e];
+          const double st = t_alpha * trial.g[e] / (si * si) + t_beta * trial.s[e];
+          const double xn = trial.x[e] + st;
+          trial.x_new[e] = xn;
+          sh_x[k * PM + i] = xn;
+          step_sq = fma(st, st, step_sq);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < npts; i += BLOCK) {
+        sh_x[i] = px[p0 + i]; sh_x[PM + i] = px[lay.Ppad + p0 + i]; sh_x[2 * PM + i] = px[2 * lay.Ppad + p0 + i];
+      }
     }
     __syncthreads();
     const int R = (o1 - o0 + BLOCK - 1) / BLOCK;
@@ -583,6 +647,10 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
   }
   const double tot = block_sum(cost, sh_red);
   if (threadIdx.x == 0) partial_cost[blockIdx.x] = tot;
+  if (TRIAL) {
+    const double st = block_sum(step_sq, sh_red);
+    if (threadIdx.x == 0) trial.step_partial[blockIdx.x] = st;
+  }
   if (bad) flags[0] = 1;
 }
 
@@ -830,19 +898,80 @@ __device__ __forceinline__ void expand_record(const double* __restrict__ rec, co
   }
 }
 
-template <int NC, int DETM = 0, bool CAMG = false>
+// Single-rank fused iteration (round 5): the three reductions of the linearisation and the damping (k_lin_finish: one workgroup, 6 us + a launch
+// gap at the head of every iteration) are done by k_tprep's workgroups themselves — each sums the ~2 x 1024 partial rows (the same additions in the
+// same order everywhere: every workgroup gets the same bits), takes the damping from the radius the host has just chosen, and workgroup 0 leaves
+// the scalars where k_lin_finish left them (scal[0..4], [12..15], [40], [41], fz[0], fz[1]) for the kernels behind it and for k_publish.
+struct LinFin {
+  const double* partial_lin;  // [rows_lin][4]   k_scale_lin
+  const double* partial_max;  // [rows_lin]
+  const double* partial_jv;   // [rows_jv][4]    k_jv
+  int rows_lin, rows_jv;
+  double radius;
+  double* scal;
+  double* fz;
+};
+// returns the damping; every thread of the workgroup calls it (two barriers inside)
+__device__ __forceinline__ double lin_finish_block(const LinFin& lf, double (*sh_red)[BLOCK / WAVE], double* sh_out) {
+  double v[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) v[q] = 0.0;
+  for (int b = threadIdx.x; b < lf.rows_lin; b += BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += lf.partial_lin[(long)b * 4 + j];
+    v[4] = fmax(v[4], lf.partial_max[b]);
+  }
+  for (int b = threadIdx.x; b < lf.rows_jv; b += BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[5 + j] += lf.partial_jv[(long)b * 4 + j];
+  }
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double r = (q == 4) ? wave_max(v[q]) : wave_sum(v[q]);
+    if (lane == 0) sh_red[q][w] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      double r = 0.0;
+      for (int i = 0; i < BLOCK / WAVE; ++i) r = (q == 4) ? fmax(r, sh_red[q][i]) : r + sh_red[q][i];
+      tot[q] = r;
+    }
+    const double gh_sq = tot[0], jg_sq = tot[5], xs = sqrt(tot[1]);
+    const double radius = lf.radius > 0.0 ? lf.radius : (xs > 0.0 ? xs : 1.0);  // (fused_lam's rule)
+    const double lam = trf::damping(jg_sq, gh_sq, radius);
+    sh_out[0] = lam;
+    if (blockIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) lf.scal[q < 5 ? q : 12 + (q - 5)] = tot[q];
+      lf.fz[0] = lam; lf.fz[1] = radius;
+      lf.scal[40] = lam; lf.scal[41] = radius;
+    }
+  }
+  __syncthreads();
+  return sh_out[0];
+}
+
+template <int NC, int DETM = 0, bool CAMG = false, bool LINF = false>
 __global__ void __launch_bounds__(BLOCK)
 k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ chunk_start, int n_chunks,
         const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, const int* __restrict__ cam_off,
         int n_cams, int loss, double f_scale, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
-        double* __restrict__ partial_b, int* __restrict__ flags, DetPlan det = DetPlan{nullptr, nullptr}) {
+        double* __restrict__ partial_b, int* __restrict__ flags, DetPlan det = DetPlan{nullptr, nullptr}, LinFin lf = LinFin{}) {
   constexpr int REC = SchurRec<NC>::HREC, NP = REC / 2, SP = SchurRec<NC>::STAGE, SW = SchurRec<NC>::STAGE_WAVES;  // the records as they lie in HBM
   static_assert((BLOCK / WAVE) % SW == 0, "stage turns");
   constexpr bool DET = DETM > 0;
   static_assert(!(DET && CAMG), "the fixed-order sums keep the camera table in LDS");
-  if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam)
+  if (LINF) {
+    __shared__ double sh_lf_red[10][BLOCK / WAVE];
+    __shared__ double sh_lf_out[2];
+    lam = lin_finish_block(lf, sh_lf_red, sh_lf_out);
+  } else if (lam_dev) lam = *lam_dev;  // fused step: the damping was computed on the device (k_fused_lam / k_lin_finish)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double2* sh_stage = reinterpret_cast<double2*>(sh);        // [SW][WAVE * SP]  record transpose, per wave (of a turn)
   double* sh_tab = sh + (size_t)SW * WAVE * SP * 2;
@@ -1346,12 +1475,43 @@ k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restric
 // is 3 us faster with four).  Off-diagonal blocks go straight into Sacc; the helper-thread entries of diagonal tiles are parked in `red` and
 // folded per camera by k_reg_fold.
 constexpr int REG_REDUCE_Y_MAX = 16;
+constexpr int B_SLICES = 8;  // the rhs accumulator b is kept as B_SLICES rows of ncp_pad entries (k_reg_reduce); an entry is their sum, slice order
+__device__ __forceinline__ double b_entry(const double* __restrict__ bacc, int b_width, int i) {
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < B_SLICES; ++q) s += bacc[(long)q * b_width + i];
+  return s;
+}
 __global__ void __launch_bounds__(64 * REG_REDUCE_Y_MAX)
 k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial,
              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
-             double* __restrict__ Sacc, double* __restrict__ red) {
+             double* __restrict__ Sacc, double* __restrict__ red, int n_tiles, const double* __restrict__ partial_b = nullptr, int b_rows = 0,
+             int b_width = 0, double* __restrict__ b_out = nullptr) {
   const int Y = (int)blockDim.y;  // 4 or 16
   __shared__ double sh[REG_REDUCE_Y_MAX][64];
+  if ((int)blockIdx.y >= n_tiles) {
+    // grid rows n_tiles .. n_tiles + B_SLICES - 1 (round 5): the rhs rows k_tprep left per workgroup are summed HERE (fixed order), beside the tiles'
+    // partials, instead of by a k_reduce_rows launch of six workgroups between k_tprep and the pair kernel.  Slice s takes the rows
+    // [s R / B_SLICES, (s + 1) R / B_SLICES) and leaves ITS sum in b_out[s][.]: the consumers (k_schur_finalize, k_small_solve, k_tri_pack) add the
+    // B_SLICES values of an entry in slice order (one workgroup per column block summing all 512 rows took 22 us, three times the tiles' reduction).
+    const int sl = (int)blockIdx.y - n_tiles;
+    const int r0 = (int)((long)b_rows * sl / B_SLICES), r1 = (int)((long)b_rows * (sl + 1) / B_SLICES);
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    if (j < b_width) {
+      int b = r0 + threadIdx.y;
+      for (; b + Y < r1; b += 2 * Y) { a0 += partial_b[(long)b * b_width + j]; a1 += partial_b[(long)(b + Y) * b_width + j]; }
+      if (b < r1) a0 += partial_b[(long)b * b_width + j];
+    }
+    sh[threadIdx.y][threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.y == 0 && j < b_width) {
+      double tot = 0.0;
+      for (int y = 0; y < Y; ++y) tot += sh[y][threadIdx.x];
+      b_out[(long)sl * b_width + j] = tot;
+    }
+    return;
+  }
   const int t = blockIdx.y;
   const int ga = tp.tile_a[t], gb = tp.tile_b[t];
   const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
@@ -1414,12 +1574,18 @@ k_reg_fold(TilePlan tp, const double* __restrict__ red, const int* __restrict__ 
 // Sharded solves exchange the reduced camera system: only the upper triangle of Sacc carries data, so the all-reduce moves
 // ncp (ncp + 1) / 2 + ncp doubles (0.59 MB for cfg4) instead of ncp^2 + ncp.  dir = 0 packs [triangle | b], dir = 1 unpacks.
 __global__ void __launch_bounds__(256)
-k_tri_pack(double* __restrict__ Sacc, double* __restrict__ tri, int ncp, int dir) {
+k_tri_pack(double* __restrict__ Sacc, double* __restrict__ tri, int ncp, int dir, int b_width) {
   const long ntri = (long)ncp * (ncp + 1) / 2;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < (long)ncp * ncp + ncp; t += (long)gridDim.x * 256) {
-    if (t >= (long)ncp * ncp) {  // b
+    if (t >= (long)ncp * ncp) {  // b: the sum of its slices travels; the all-reduced value comes back as slice 0, the others are cleared
       const long k = t - (long)ncp * ncp;
-      if (dir == 0) tri[ntri + k] = Sacc[t]; else Sacc[t] = tri[ntri + k];
+      double* bacc = Sacc + (long)ncp * ncp;
+      if (dir == 0) tri[ntri + k] = b_entry(bacc, b_width, (int)k);
+      else {
+        bacc[k] = tri[ntri + k];
+#pragma unroll
+        for (int q = 1; q < B_SLICES; ++q) bacc[(long)q * b_width + k] = 0.0;
+      }
       continue;
     }
     const int row = (int)(t / ncp), col = (int)(t % ncp);
@@ -1437,7 +1603,7 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
                                  const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ lam_dev,
                                  const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
                                  double* __restrict__ W, int ldw, const double* __restrict__ red = nullptr, int g = 0, long tile_elems = 0,
-                                 const int* __restrict__ group_cam_begin = nullptr) {
+                                 const int* __restrict__ group_cam_begin = nullptr, int b_width = 0) {
   using UP = UPack<NC>;
   if (lam_dev) lam = *lam_dev;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1466,7 +1632,7 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
   if (same_cam) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
   if (row == col) {
     v += lam * sinv[row] * sinv[row] + cam_diag[row];  // cam_diag: zero unless the caller set a bound scaling
-    const double rv = -gvec[row] + bacc[row];
+    const double rv = -gvec[row] + b_entry(bacc, b_width, row);
     rhs[row] = rv;
     W[(long)ncp * ldw + row] = rv;  // rhs^T: last row of the Cholesky work matrix
   }
@@ -1831,7 +1997,7 @@ k_small_solve(const double* __restrict__ Sacc, const double* __restrict__ bacc, 
               const double* __restrict__ sinv, const int* __restrict__ param_cam, const int* __restrict__ param_loc, int n, double lam,
               const double* __restrict__ lam_dev, const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
               const double* __restrict__ red, int g, long tile_elems, const int* __restrict__ group_cam_begin, int* __restrict__ flags,
-              double* __restrict__ out) {
+              double* __restrict__ out, int b_width) {
   using UP = UPack<NC>;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double (*W)[SMALL_LD] = reinterpret_cast<double (*)[SMALL_LD]>(sh);                       // [n + 1][SMALL_LD]: S, then rhs^T
@@ -1848,7 +2014,7 @@ k_small_solve(const double* __restrict__ Sacc, const double* __restrict__ bacc, 
   int* pl = pc + SMALL_N;                         // [n] its index inside the camera's block
   for (int i = tid; i < n; i += SMALL_THREADS) {
     pc[i] = param_cam[i]; pl[i] = param_loc[i];
-    const double rv = -gvec[i] + bacc[i];
+    const double rv = -gvec[i] + b_entry(bacc, b_width, i);
     rhs[i] = rv;
     W[n][i] = rv;
   }
@@ -1992,14 +2158,17 @@ k_chol_apply(const double* __restrict__ Tinv, const double* __restrict__ W, int 
 
 // ------------------------------------------------------------------------------------------------
 // back-substitution:  dp = -V'^-1 (g_p + sum_i W_i^T dc_{c_i}),  W_i^T dc = B_i^T (A_i dc)
-template <int NC, bool CAMG = false>
+// SCAL (single-rank fused iteration): the point block's share of the step scalars — sum (s sinv)^2 and sum g s, what k_step_scalars would
+// read s, g and sinv a second time for — is accumulated by the threads that solve the points and leaves as one partial row per workgroup
+// (step_partial[b][0..3]); k_step_cam adds the camera block.
+template <int NC, bool CAMG = false, bool SCAL = false>
 __global__ void __launch_bounds__(BLOCK)
 k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
           const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
           const int* __restrict__ chunk_pts, int n_chunks, const double* __restrict__ xvec, VecLayout lay,
           const double* __restrict__ tab, const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
           const double* __restrict__ lam_dev, const double* __restrict__ Vblk, const double* __restrict__ gvec,
-          const double* __restrict__ sinv, double* __restrict__ svec) {
+          const double* __restrict__ sinv, double* __restrict__ svec, double* __restrict__ step_partial = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   if (lam_dev) lam = *lam_dev;
   double* sh_tab = sh;
@@ -2013,7 +2182,8 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
   const double* dp = sinv + lay.ncp_pad;
   double* sp = svec + lay.ncp_pad;
   // per-point solve of point p given the summed observation terms q (on top of g_p)
-  auto solve_point = [&](int p, double* q, const double* Vin, const double* din) {
+  double sc0 = 0.0, sc1 = 0.0;  // SCAL: sum (s sinv)^2, sum g s over the points this thread solves
+  auto solve_point = [&](int p, double* q, const double* Vin, const double* din, const double* gin) {
     double Vd[6], L[6], y[3], x[3];
 #pragma unroll
     for (int k = 0; k < 6; ++k) Vd[k] = Vin[k];
@@ -2027,6 +2197,10 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     sp[p] = -x[0];
     sp[lay.Ppad + p] = -x[1];
     sp[2 * lay.Ppad + p] = -x[2];
+    if (SCAL) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double ps = x[k] * din[k]; sc0 = fma(ps, ps, sc0); sc1 = fma(-gin[k], x[k], sc1); }
+    }
   };
   const int last_obs = max(chunk_start[n_chunks] - 1, 0);
   int ch = blockIdx.x;
@@ -2048,13 +2222,13 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     // working and three parked: 45 of the kernel's 96 us.
     const int pp = min(cp0 + (int)threadIdx.x, lay.P - 1);
     int pa = 0, pb = 0;
-    double Vp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, dpp[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
+    double Vp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, dpp[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0}, gq[3] = {0.0, 0.0, 0.0};
     if (threadIdx.x < WAVE) {
       pa = pt_start[pp] - o0; pb = pt_start[pp + 1] - o0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) Vp[k] = Vblk[(long)k * lay.Ppad + pp];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { dpp[k] = dp[(long)k * lay.Ppad + pp]; q[k] = gp[(long)k * lay.Ppad + pp]; }
+      for (int k = 0; k < 3; ++k) { dpp[k] = dp[(long)k * lay.Ppad + pp]; q[k] = gp[(long)k * lay.Ppad + pp]; gq[k] = q[k]; }
     }
     double t[3] = {0.0, 0.0, 0.0};
     if (i < o1) {
@@ -2083,23 +2257,29 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     }
     if (threadIdx.x < WAVE && (int)threadIdx.x < npts && pb > pa) {
       for (int j = pa; j < pb; ++j) { q[0] += sh_pt[j]; q[1] += sh_pt[CHUNK + j]; q[2] += sh_pt[2 * CHUNK + j]; }
-      solve_point(pp, q, Vp, dpp);
+      solve_point(pp, q, Vp, dpp, gq);
     }
     for (int lp = (threadIdx.x < WAVE ? threadIdx.x + BLOCK : threadIdx.x); lp < npts; lp += BLOCK) {  // points beyond the first 64
       const int p = cp0 + lp;
       const int a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
       if (b > a) {
         double q2[3] = {gp[p], gp[lay.Ppad + p], gp[2 * lay.Ppad + p]}, V2[6], d2[3];
+        const double g2[3] = {q2[0], q2[1], q2[2]};
         for (int j = a; j < b; ++j) { q2[0] += sh_pt[j]; q2[1] += sh_pt[CHUNK + j]; q2[2] += sh_pt[2 * CHUNK + j]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) V2[k] = Vblk[(long)k * lay.Ppad + p];
 #pragma unroll
         for (int k = 0; k < 3; ++k) d2[k] = dp[(long)k * lay.Ppad + p];
-        solve_point(p, q2, V2, d2);
+        solve_point(p, q2, V2, d2, g2);
       }
     }
     __syncthreads();
     cur = nx; o0 = no0; o1 = no1; ch = nxt;
+  }
+  if (SCAL) {  // (sh_pt is free: the loop ended behind a barrier)
+    double r;
+    r = block_sum(sc0, sh_pt); if (threadIdx.x == 0) step_partial[blockIdx.x * 4 + 0] = r;
+    r = block_sum(sc1, sh_pt); if (threadIdx.x == 0) { step_partial[blockIdx.x * 4 + 1] = r; step_partial[blockIdx.x * 4 + 2] = 0.0; step_partial[blockIdx.x * 4 + 3] = 0.0; }
   }
 }
 
@@ -2376,6 +2556,78 @@ k_step_small(const double* __restrict__ g, const double* __restrict__ sinv, cons
     for (int i = 0; i < STEP_SMALL_THREADS / WAVE; ++i) { a += sh_red[0][i]; b += sh_red[1][i]; }
     scal[16] = a; scal[17] = b; scal[18] = 0.0; scal[19] = 0.0;
     fused_subspace(scal, flags, fz);
+  }
+}
+
+// Single-rank fused iteration, camera-sorted build (round 5): what used to be k_step_scalars + k_step_finish + k_trial_update's camera share in ONE
+// workgroup.  The point block's step scalars arrive as per-workgroup partials of k_backsub<.., SCAL>; this kernel adds the camera block, takes the
+// subspace step (fused_subspace: alpha, beta -> fz[2], fz[3]), forms the camera entries of the trial point and its camera table (k_cam_prep's work),
+// and leaves the camera block's share of ||step||^2 in step_cam[0].  The point entries of the trial point are formed by the build pass that evaluates
+// it (k_build_cs<.., TRIAL>), which stages every point of its super-chunk anyway: no vector pass over x, g, sinv, s in between.
+// Dynamic LDS: ncp_pad doubles (the camera block of the trial point).
+__global__ void __launch_bounds__(BLOCK)
+k_step_cam(const double* __restrict__ partial, int rows, const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
+           const double* __restrict__ s, int ncp_pad, double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz,
+           double* __restrict__ x_new, double* __restrict__ step_cam, double* __restrict__ tab_out, const double* __restrict__ cam_const,
+           const int* __restrict__ cam_model, const int* __restrict__ cam_np, const int* __restrict__ cam_off, int n_cams) {
+  extern __shared__ __attribute__((aligned(16))) double sh_xc[];  // [ncp_pad]
+  __shared__ double sh_red[4][BLOCK / WAVE];
+  __shared__ double sh_ab[3];
+  double v[2] = {0.0, 0.0};
+  for (int b = threadIdx.x; b < rows; b += BLOCK) { v[0] += partial[(long)b * 4 + 0]; v[1] += partial[(long)b * 4 + 1]; }
+  for (int i = threadIdx.x; i < ncp_pad; i += BLOCK) {
+    const double si = s[i], ps = si * sinv[i];
+    v[0] = fma(ps, ps, v[0]);
+    v[1] = fma(g[i], si, v[1]);
+  }
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const double r = wave_sum(v[j]);
+    if (lane == 0) sh_red[j][w] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      double r = 0.0;
+      for (int i = 0; i < BLOCK / WAVE; ++i) r += sh_red[j][i];
+      scal[16 + j] = r;
+    }
+    scal[18] = 0.0; scal[19] = 0.0;
+    fused_subspace(scal, flags, fz);
+    sh_ab[0] = fz[2]; sh_ab[1] = fz[3]; sh_ab[2] = scal[42];
+  }
+  __syncthreads();
+  if (sh_ab[2] != 0.0) return;  // need_host: no trial point (the build pass behind this kernel skips itself)
+  const double alpha = sh_ab[0], beta = sh_ab[1];
+  double s0 = 0.0;
+  for (int i = threadIdx.x; i < ncp_pad; i += BLOCK) {
+    const double si = sinv[i];
+    const double st = alpha * g[i] / (si * si) + beta * s[i];
+    const double xn = x[i] + st;
+    x_new[i] = xn;
+    sh_xc[i] = xn;
+    s0 = fma(st, st, s0);
+  }
+  {
+    const double r = wave_sum(s0);
+    if (lane == 0) sh_red[2][w] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0;
+    for (int i = 0; i < BLOCK / WAVE; ++i) r += sh_red[2][i];
+    step_cam[0] = r;
+  }
+  for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
+    double xc[MAX_NC];
+    const int np = cam_np[c], off = cam_off[c];
+    for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? sh_xc[off + i] : 0.0;
+    CamTab t;
+    cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t);
+    const double* src = reinterpret_cast<const double*>(&t);
+    for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab_out[c * CAMTAB_DOUBLES + i] = src[i];
   }
 }
 

@@ -141,6 +141,8 @@ struct cba_problem {
   double* sinv2 = nullptr;
   bool spec_enqueued = false, spec_valid = false;
   int spec_rows_jv = 0;
+  bool lf_pending = false;  // the reductions of the linearisation and the damping are left to the next k_tprep (LinFin lf)
+  LinFin lf{};
   bool have_x0 = false;
   std::vector<int> h_tile_wg_begin;  // host copy (profiling print)
   struct PlanTask* plan_task = nullptr;  // two-stage plan: the thread still dealing the Schur plan while the handle works with the cheap one
@@ -148,6 +150,7 @@ struct cba_problem {
   int plan_max_blocks = 0;               // workgroup budget of the pair kernel (the dealt plan is bound with the same one when it is swapped in)
   size_t partial_capacity = 0;           // doubles behind `partial`
   bool plan_is_cheap = false;
+  int plan_error = 0;  // CBA_ERR_* of a failed background plan build (the handle keeps the quick plan)
   bool schur_clock = false;  // profiling build only (-DCBA_PROFILING, CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
   bool begun = false, linearized = false, stepped = false, have_trial = false;
   double gh_sq = 0.0;
@@ -513,6 +516,24 @@ int cba_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+int64_t cba_trim(void) {
+  int64_t bytes = (int64_t)rawvec_detail::trim();
+  std::map<int, DevicePool> pools;
+  { std::lock_guard<std::mutex> lock(g_pool_mu); pools.swap(g_pool); }
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  for (auto& kv : pools) {
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    DevicePool& pool = kv.second;
+    for (void* c : pool.chunks) { (void)hipFree(c); bytes += (int64_t)kPoolChunk; }
+    for (hipStream_t st : pool.streams) (void)hipStreamDestroy(st);
+    for (auto& m : pool.mail) { (void)hipHostFree(m.first); bytes += (int64_t)(m.second * sizeof(double)); }
+    for (auto& m : pool.staging) { (void)hipHostFree(m.first); bytes += (int64_t)(m.second * sizeof(double)); }
+  }
+  if (have_cur) (void)hipSetDevice(cur);
+  return bytes;
+}
+
 int cba_timer_count(void) { return T_COUNT; }
 const char* cba_timer_name(int32_t i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }
 
@@ -849,8 +870,9 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_cost<true, true>, lds_cost(p)))) return rc;
   const bool use_cs = p->cs.n_sc && !p->det_m && !p->n_heavy;  // (run_build_into's condition)
   if (use_cs) {
-    if (build_cs_uglob<NC>(p)) rc = allow_lds(k_build_cs<NC, true, true>, lds_build_cs<NC>(p, true, true));
-    else rc = build_cs_camg<NC>(p) ? allow_lds(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)) : allow_lds(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
+    if (build_cs_uglob<NC>(p)) { rc = allow_lds(k_build_cs<NC, true, true>, lds_build_cs<NC>(p, true, true)); if (!rc) rc = allow_lds(k_build_cs<NC, true, true, true>, lds_build_cs<NC>(p, true, true)); }
+    else if (build_cs_camg<NC>(p)) { rc = allow_lds(k_build_cs<NC, true>, lds_build_cs<NC>(p, true)); if (!rc) rc = allow_lds(k_build_cs<NC, true, false, true>, lds_build_cs<NC>(p, true)); }
+    else { rc = allow_lds(k_build_cs<NC, false>, lds_build_cs<NC>(p, false)); if (!rc) rc = allow_lds(k_build_cs<NC, false, false, true>, lds_build_cs<NC>(p, false)); }
     if (rc) return rc;
   }
   if (!use_cs || !build_cs_uglob<NC>(p)) {  // the point-ordered kernel keeps the packed blocks in LDS: not with that many cameras
@@ -874,10 +896,15 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_schur_reg3<NC, RegCfg<NC>::SPLIT, RegCfg<NC>::MINW>, Reg3Cfg<NC>::LDS_BYTES))) return rc;
   if ((rc = allow_lds(k_tprep<NC>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_tprep<NC, 0, true>, lds_tprep<NC>(p)))) return rc;
+  if ((rc = allow_lds(k_tprep<NC, 0, false, true>, lds_tprep<NC>(p)))) return rc;
+  if ((rc = allow_lds(k_tprep<NC, 0, true, true>, lds_tprep<NC>(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC, true>, lds_backsub(p)))) return rc;
+  if ((rc = allow_lds(k_backsub<NC, false, true>, lds_backsub(p)))) return rc;
+  if ((rc = allow_lds(k_backsub<NC, true, true>, lds_backsub(p)))) return rc;
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_apply, (size_t)p->ncp * 8))) return rc;
+  if ((rc = allow_lds(k_step_cam, (size_t)p->lay.ncp_pad * 8))) return rc;
   if (p->ncp <= SMALL_N && (rc = allow_lds(k_small_solve<NC>, kSmallSolveLds))) return rc;
   return CBA_OK;
 }
@@ -1184,7 +1211,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->partial_capacity = (size_t)std::max<long>((long)p->grid * w_build, (long)(p->tile_grid + p->tile_grid / 8 + 1) * std::max(p->tp.rep, 1) * p->tp.tile_elems);
   TRY(dev_alloc(p, &p->partial, p->partial_capacity));
   TRY(dev_alloc(p, &p->partial4, (size_t)2048 * 4)); TRY(dev_alloc(p, &p->partial1, (size_t)2048)); TRY(dev_alloc(p, &p->partial4b, (size_t)2048 * 4));  // obs rows + constraint rows
-  TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + p->lay.ncp_pad));
+  TRY(dev_alloc(p, &p->Sacc, (size_t)ncp * ncp + (size_t)B_SLICES * p->lay.ncp_pad));  // + the rhs accumulator b, B_SLICES rows (k_reg_reduce)
   TRY(dev_alloc(p, &p->tri, (size_t)ncp * (ncp + 1) / 2 + p->lay.ncp_pad));
   if (!p->eval_only) {
     TRY(dev_alloc(p, &p->red, (size_t)p->G * p->tp.tile_elems));
@@ -1204,7 +1231,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   HIPBAIL(hipMemset(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double))); HIPBAIL(hipMemset(p->g2, 0, (size_t)tot * sizeof(double)));
   HIPBAIL(hipMemset(p->scal, 0, 64 * sizeof(double)));
   HIPBAIL(hipMemset(p->flags, 0, 4 * sizeof(int)));
-  HIPBAIL(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + p->lay.ncp_pad) * sizeof(double)));
+  HIPBAIL(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + (size_t)B_SLICES * p->lay.ncp_pad) * sizeof(double)));
 #undef TRY
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -1258,10 +1285,10 @@ int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
 int cba_get_info(cba_problem* p, cba_info* o) {
   if (!p || !o) return fail(CBA_ERR_INVALID, "null argument");
   o->n_cams = p->C; o->n_points = p->P; o->n_cam_params = p->ncp; o->n_params = p->ncp + 3 * p->P; o->n_obs = p->N;
-  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid; o->schur_in_lds = 0;
+  o->n_chunks = p->n_chunks; o->grid_blocks = p->grid;
+  o->plan_state = !p->plan_is_cheap ? 0 : (p->plan_task ? 1 : 2); o->plan_error = p->plan_error;
   o->schur_groups = p->G; o->schur_tiles = p->n_tiles; o->schur_grid = p->tile_grid; o->schur_stream_len = p->tile_stream_len; o->schur_pairs = p->n_pairs;
   o->max_obs_per_point = p->max_obs_per_point; o->device_bytes = p->device_bytes; o->n_heavy_points = p->n_heavy;
-  o->schur_wide = 0;  // (the wide-tile variant of rounds 2-3 is gone)
   {
     const bool cs = p->cs.n_sc && !p->det_m && !p->n_heavy;
     const bool camg = cs ? (p->nct == 6 ? build_cs_camg<6>(p) : build_cs_camg<9>(p)) : (p->nct == 6 ? build_camg<6>(p) : build_camg<9>(p));
@@ -1342,10 +1369,17 @@ static int launch_cost(cba_problem* p, const double* xvec, const double* tab, in
   return CBA_OK;  // sharded solves: the caller's exchange() sums scal[slot] and the flags over the ranks
 }
 
+// Single-rank fused iteration over camera-sorted super-chunks: the step scalars of the point block come out of k_backsub, one workgroup
+// (k_step_cam) adds the camera block, takes the subspace step and prepares the trial point's cameras, and the trial build forms the point
+// entries of the trial point itself — k_step_scalars, k_step_finish / k_step_small and k_trial_update are not launched.
+static bool fused_trial(const cba_problem* p, bool compact) { return compact && p->cs.n_sc && !p->det_m && !p->n_heavy && !p->con.n_con; }
+
 // Build pass at xvec (camera table tab) into the given outputs; the rho sum lands in scal[cost_slot].
+// trial != nullptr (fused_trial): k_build_cs<.., TRIAL> forms the point entries of xvec = x_new from *trial while it stages them.
 template <int NC>
 static int run_build_into(cba_problem* p, const double* xvec, const double* tab, double* V, double* g, double* Upacked, int cost_slot,
-                          const double* skip = nullptr, bool defer_exchange = false, bool compact = false, int flag_slot = 0) {
+                          const double* skip = nullptr, bool defer_exchange = false, bool compact = false, int flag_slot = 0,
+                          const TrialSrc* trial = nullptr, const PubArgs* pub = nullptr) {
   RoctxRange range("cba:build");
   {
     ScopedTimer t(p, T_BUILD);
@@ -1358,15 +1392,22 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
                          V, g, p->partial, p->partial1, p->flags + flag_slot, skip, p->det);
     };
     if (p->cs.n_sc && !p->det_m && !p->n_heavy) {  // camera-sorted super-chunks: the camera blocks accumulate in registers
+      const TrialSrc tsrc = trial ? *trial : TrialSrc{};
       auto launch_cs = [&](auto kernel, size_t lds) {
         hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds, p->stream, p->cs, xvec, p->lay, tab, p->C, p->loss, p->f_scale,
-                           V, g, p->partial, p->partial1, p->flags + flag_slot, skip);
+                           V, g, p->partial, p->partial1, p->flags + flag_slot, skip, tsrc);
       };
       if (build_cs_uglob<NC>(p)) {
         (void)hipMemsetAsync(p->partial, 0, (size_t)p->C * UPack<NC>::STRIDE * sizeof(double), p->stream);  // the ONE copy the atomics add to
-        launch_cs(k_build_cs<NC, true, true>, lds_build_cs<NC>(p, true, true));
-      } else if (build_cs_camg<NC>(p)) launch_cs(k_build_cs<NC, true>, lds_build_cs<NC>(p, true));
-      else launch_cs(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
+        if (trial) launch_cs(k_build_cs<NC, true, true, true>, lds_build_cs<NC>(p, true, true));
+        else launch_cs(k_build_cs<NC, true, true>, lds_build_cs<NC>(p, true, true));
+      } else if (build_cs_camg<NC>(p)) {
+        if (trial) launch_cs(k_build_cs<NC, true, false, true>, lds_build_cs<NC>(p, true));
+        else launch_cs(k_build_cs<NC, true>, lds_build_cs<NC>(p, true));
+      } else {
+        if (trial) launch_cs(k_build_cs<NC, false, false, true>, lds_build_cs<NC>(p, false));
+        else launch_cs(k_build_cs<NC, false>, lds_build_cs<NC>(p, false));
+      }
     } else
     switch (p->det_m) {  // deterministic: fixed-order camera sums (k_build<NC, tasks per thread>)
       case 3: launch_build(k_build<NC, 3>); break;
@@ -1383,8 +1424,12 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
     // rows of per-workgroup partial blocks to sum; the global-atomics form of k_build_cs leaves ONE row
     const int u_rows = (p->cs.n_sc && !p->det_m && !p->n_heavy && build_cs_uglob<NC>(p)) ? 1 : p->grid;
     if (compact) {  // single-rank fused step: gradient entries written by the row reduction, rho sum by k_publish
-      hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, u_rows, w, Upacked, g,
-                         (const int*)p->cam_off, (const int*)p->cam_np, (int)UPack<NC>::STRIDE, (int)UPack<NC>::TRI);
+      if (pub)  // ... whose packet leaves with one more workgroup of this launch
+        hipLaunchKernelGGL(k_reduce_rows_pub, dim3((w + 63) / 64 + 1), dim3(64, REDUCE_RY), 0, p->stream, (const double*)p->partial, u_rows, w, Upacked, g,
+                           (const int*)p->cam_off, (const int*)p->cam_np, (int)UPack<NC>::STRIDE, (int)UPack<NC>::TRI, *pub);
+      else
+        hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, u_rows, w, Upacked, g,
+                           (const int*)p->cam_off, (const int*)p->cam_np, (int)UPack<NC>::STRIDE, (int)UPack<NC>::TRI);
       return CBA_OK;
     }
     hipLaunchKernelGGL(k_reduce_rows, dim3((w + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial, u_rows, w, Upacked,
@@ -1435,7 +1480,7 @@ static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr, const double*
 // device part of the linearisation (no host synchronisation): build unless the accepted trial brought its own, Jacobi
 // scale, scalars, ||J_h g_h||^2, the scalar exchange of a sharded solve
 template <int NC>
-static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = false, double radius = 0.0) {
+static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = false, double radius = 0.0, bool defer_finish = false) {
   RoctxRange range("cba:linearize");
   if (!p->have_build) {
     int rcb = run_build<NC>(p);
@@ -1448,6 +1493,11 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
     // the accepted trial was linearised speculatively behind the previous iteration's k_publish (run_step): scale, vector sums and
     // ||J_h g_h||^2 are there, only the damping depends on the radius the host has just decided
     p->spec_valid = false;
+    if (defer_finish) {  // (k_tprep sums the partial rows itself: no launch here)
+      p->lf = LinFin{p->partial4b, p->partial1, p->partial4, vec_grid(p->lay.total()), p->spec_rows_jv, radius, p->scal, p->fz};
+      p->lf_pending = true;
+      return CBA_OK;
+    }
     ScopedTimer t(p, T_SCALE_SCALARS);
     hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vec_grid(p->lay.total()), p->partial4, p->spec_rows_jv, radius,
                        p->scal, p->fz);
@@ -1470,6 +1520,11 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
       int rows_jv = 0;
       int rcj = run_jv<NC>(p, 1, &rows_jv);
       if (rcj) return rcj;
+      if (defer_finish) {
+        p->lf = LinFin{p->partial4b, p->partial1, p->partial4, vg, rows_jv, radius, p->scal, p->fz};
+        p->lf_pending = true;
+        return CBA_OK;
+      }
       hipLaunchKernelGGL(k_lin_finish, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4b, p->partial1, vg, p->partial4, rows_jv, radius,
                          p->scal, p->fz);
       return CBA_OK;
@@ -1589,6 +1644,13 @@ static int maybe_swap_plan(cba_problem* p, bool wait) {
   if (wait) task->wait_stage(2);
   if (task->stage.load(std::memory_order_acquire) < 2) return CBA_OK;
   int rc = CBA_OK;
+  if (task->rc != 0 && task->two_stage) {
+    // the background build (dealing, its hipMalloc / upload beside the running solve) failed: the handle keeps the quick plan — same sums to
+    // rounding, pair kernel 1.5-1.75x slower — and says so: cba_info.plan_state = 2, plan_error; cba_plan_wait returns the error
+    p->plan_error = task->rc;
+    fprintf(stderr, "caliscope_ba: the balanced Schur plan could not be built (error %d, %.3f s on its thread): the handle keeps the quick plan\n", task->rc, task->seconds);
+    if (wait) rc = fail(task->rc, "cba_plan_wait: the balanced Schur plan could not be built in the background (error %d); the handle keeps the quick plan", task->rc);
+  }
   if (task->rc == 0) {
     const size_t need = (size_t)task->install.tile_grid * std::max(task->install.tp.rep, 1) * task->install.tp.tile_elems;
     if (need > p->partial_capacity) {  // (the dealt plan has a few chunks more or fewer than the cheap one; cba_create leaves headroom: rare)
@@ -1656,19 +1718,23 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     RoctxRange r2("cba:schur");
     ScopedTimer t(p, T_SCHUR);
     {
+      const bool linf = p->lf_pending;  // (set by run_lin_chain(defer_finish) of the same cba_step: never in fixed-order mode)
+      p->lf_pending = false;
       auto launch_tprep = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(p->grid), dim3(BLOCK), lds_tprep<NC>(p), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                            p->chunk_start, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss, p->f_scale, lam, lam_dev, p->V, p->g,
-                           p->sinv, p->Trec, p->partial_b, p->flags, p->det);
+                           p->sinv, p->Trec, p->partial_b, p->flags, p->det, linf ? p->lf : LinFin{});
       };
       switch (p->det_m) {
         case 3: launch_tprep(k_tprep<NC, 3>); break;
         case 5: launch_tprep(k_tprep<NC, 5>); break;
         case 8: launch_tprep(k_tprep<NC, 8>); break;
-        default: if (p->tab_global) launch_tprep(k_tprep<NC, 0, true>); else launch_tprep(k_tprep<NC, 0>); break;
+        default:
+          if (linf) { if (p->tab_global) launch_tprep(k_tprep<NC, 0, true, true>); else launch_tprep(k_tprep<NC, 0, false, true>); }
+          else if (p->tab_global) launch_tprep(k_tprep<NC, 0, true>); else launch_tprep(k_tprep<NC, 0>);
+          break;
       }
-      hipLaunchKernelGGL(k_reduce_rows, dim3((p->lay.ncp_pad + 63) / 64), dim3(64, REDUCE_RY), 0, p->stream, p->partial_b, p->grid,
-                         p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp, (double*)nullptr, (const int*)nullptr, (const int*)nullptr, 1, 0);
+      // (the per-workgroup rhs rows k_tprep leaves in partial_b are summed by an extra grid row of k_reg_reduce, behind the pair kernel)
       ScopedTimer tpairs(p, T_SCHUR_PAIRS);  // nested in "schur": the pair kernel alone
       constexpr int SP = RegCfg<NC>::SPLIT, MW = RegCfg<NC>::MINW;
 #ifdef CBA_PROFILING
@@ -1689,8 +1755,9 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     // (fold + unprime + finalize as ONE kernel, a thread per camera pair, measured slower than the three launches: 42 instead of 31 us — 2080 threads
     // with 36 entries each against 147k threads with one)
     {
-      hipLaunchKernelGGL(k_reg_reduce, dim3((p->tp.tile_elems + 63) / 64, p->n_tiles), dim3(64, p->reg_reduce_y), 0, p->stream, p->tp,
-                         p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red);
+      hipLaunchKernelGGL(k_reg_reduce, dim3(std::max((p->tp.tile_elems + 63) / 64, (p->lay.ncp_pad + 63) / 64), p->n_tiles + B_SLICES), dim3(64, p->reg_reduce_y), 0,
+                         p->stream, p->tp, p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red, p->n_tiles,
+                         (const double*)p->partial_b, p->grid, p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
       if (!fold_in_finalize)
         hipLaunchKernelGGL(k_reg_fold, dim3((p->gsz * NC * NC + 63) / 64, p->G), dim3(64), 0, p->stream, p->tp, p->red,
                            p->cam_off, p->cam_np, NC, ncp, p->Sacc);
@@ -1704,17 +1771,18 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     if (p->sharded()) {  // reduced camera system: the one real exchange step — upper triangle and b, packed
       const size_t ntri = (size_t)ncp * (ncp + 1) / 2 + ncp;
       const int tg = (int)std::min<size_t>(((size_t)ncp * ncp + ncp + 255) / 256, 1024);
-      hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 0);
+      hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 0, p->lay.ncp_pad);
       int rcs = allreduce_sum(p, p->tri, ntri);
       if (rcs) return rcs;
-      hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 1);
+      hipLaunchKernelGGL(k_tri_pack, dim3(tg), dim3(256), 0, p->stream, p->Sacc, p->tri, ncp, 1, p->lay.ncp_pad);
     }
     const long nn = (long)ncp * ncp;
     small_solve = ncp <= SMALL_N && !p->sharded() && !p->chol_trace;
     if (!small_solve)
       hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
                          p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw,
-                         fold_in_finalize ? (const double*)p->red : (const double*)nullptr, p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin);
+                         fold_in_finalize ? (const double*)p->red : (const double*)nullptr, p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin,
+                         p->lay.ncp_pad);
   }
   int rc = CBA_OK;
   if (small_solve) {  // small rigs: reduced system, factorisation and both substitutions in one workgroup (k_small_solve)
@@ -1722,7 +1790,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     ScopedTimer t(p, T_CHOLESKY);
     hipLaunchKernelGGL((k_small_solve<NC>), dim3(1), dim3(SMALL_THREADS), kSmallSolveLds, p->stream, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv,
                        p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, fold_in_finalize ? (const double*)p->red : (const double*)nullptr,
-                       p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin, p->flags, p->s);
+                       p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin, p->flags, p->s, p->lay.ncp_pad);
   } else {
     RoctxRange r2("cba:cholesky");
     rc = run_cholesky(p);
@@ -1737,14 +1805,24 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     auto launch_backsub = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(p->grid_backsub), dim3(BLOCK), lds_backsub(p), p->stream, p->obs_u, p->obs_v, p->obs_cam,
                          p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
-                         p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s);
+                         p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s, p->partial4);
     };
-    if (p->tab_global) launch_backsub(k_backsub<NC, true>); else launch_backsub(k_backsub<NC>);
+    if (fused_trial(p, compact)) { if (p->tab_global) launch_backsub(k_backsub<NC, true, true>); else launch_backsub(k_backsub<NC, false, true>); }
+    else if (p->tab_global) launch_backsub(k_backsub<NC, true>); else launch_backsub(k_backsub<NC>);
     if (p->n_heavy)
       hipLaunchKernelGGL(k_heavy_finish, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->heavy_frag, p->n_heavy, p->lay, lam,
                          p->V, p->g, p->sinv, p->s);
     if (p->con.n_con)
       hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
+  }
+  if (fused_trial(p, compact)) {
+    // step scalars (the point block's share came out of k_backsub), subspace step, camera entries and camera table of the trial point: one workgroup
+    ScopedTimer t(p, T_VECTOR);
+    hipLaunchKernelGGL(k_step_cam, dim3(1), dim3(BLOCK), (size_t)p->lay.ncp_pad * sizeof(double), p->stream, (const double*)p->partial4, p->grid_backsub,
+                       (const double*)p->x, (const double*)p->g, (const double*)p->sinv, (const double*)p->s, p->lay.ncp_pad, p->scal, (const int*)p->flags, p->fz,
+                       p->x_new, p->partial4 + p->grid, p->tab_new, (const double*)p->cam_const, (const int*)p->cam_model, (const int*)p->cam_np,
+                       (const int*)p->cam_off, p->C);
+    return CBA_OK;
   }
   return run_step_scalars(p, lam_dev != nullptr, compact);
 }
@@ -1775,7 +1853,7 @@ static int run_newton(cba_problem* p, double lam, cba_newton_info* out) {
 // (compact), *waited: the non-compact route has already synchronised
 template <int NC>
 static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned long long* seq_out) {
-  int rc = run_lin_chain<NC>(p, true, compact, radius);
+  int rc = run_lin_chain<NC>(p, true, compact, radius, compact && !p->det_m);  // (single rank: k_tprep finishes the linearisation's sums itself)
   if (rc) return rc;
   if (!compact) hipLaunchKernelGGL(k_fused_lam, dim3(1), dim3(1), 0, p->stream, p->scal, radius, p->fz);
   rc = run_newton_chain<NC>(p, 0.0, p->fz, compact);
@@ -1783,7 +1861,8 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
   if (!compact) hipLaunchKernelGGL(k_fused_subspace, dim3(1), dim3(1), 0, p->stream, p->scal, p->flags, p->fz);
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
-  {
+  const bool ft = fused_trial(p, compact);
+  if (!ft) {
     ScopedTimer t(p, T_VECTOR);
     // (the camera table of the trial point is prepared by workgroup 0 of the same launch)
     hipLaunchKernelGGL(k_trial_update, dim3(vg), dim3(BLOCK), 0, p->stream, p->x, p->g, p->sinv, p->s, 0.0, 0.0, tot, p->lay.ncp_pad,
@@ -1791,10 +1870,17 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
                        (const double*)p->cam_const, (const int*)p->cam_model, (const int*)p->cam_np, (const int*)p->cam_off, p->C);
     if (!compact) hipLaunchKernelGGL(k_reduce_narrow<false>, dim3(1), dim3(BLOCK), 0, p->stream, p->partial4, vg, 1, p->scal + 28);
   }
-  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact);  // skipped when need_host
+  // fused_trial: k_step_cam (end of the damped step) has placed the camera entries and the camera table of the trial point; the build forms the rest
+  const TrialSrc tsrc{p->x, p->g, p->sinv, p->s, p->fz + 2, p->x_new, p->partial4};
+  // compact: the iteration's packet (scalars, trial cost rows -> slot 24, step-norm rows -> slot 28: one per workgroup of the trial build + the camera
+  // block's from k_step_cam, or k_trial_update's) leaves with the launch that reduces the trial build's camera blocks
+  const unsigned long long seq = compact ? ++p->publish_seq : 0;
+  const PubArgs pub{p->scal, 48, p->flags, p->d_hscal, p->d_hflags, seq, p->partial1, p->grid, 24, p->partial4, ft ? p->grid + 1 : vg, 28};
+  rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact, 0, ft ? &tsrc : nullptr,
+                          compact ? &pub : nullptr);  // (the build is skipped when need_host; the reduction and the packet are not)
   if (rc) return rc;
   if (!compact) return CBA_OK;
-  *seq_out = publish_enqueue(p, 48, p->partial1, p->grid, 24, p->partial4, vg, 28);
+  *seq_out = seq;
   // speculative linearisation of the trial point, enqueued BEHIND the publish: the device works on it while the host reads the packet,
   // decides and enqueues the next iteration (k_publish -> host -> first kernel of the next cba_step used to be an idle gap per iteration)
   p->spec_enqueued = false;
@@ -1984,10 +2070,12 @@ int cba_begin_deferred(cba_problem* p, const double* x0) {
 
 static int begin_common(cba_problem* p, double* cost_out, bool evaluate) {
   HIPCHK(hipMemcpyAsync(p->x, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  // (the fused trial build writes the points of its super-chunks only: points no observation refers to keep their x0 entries in BOTH buffers)
+  if (!p->eval_only && fused_trial(p, true)) HIPCHK(hipMemcpyAsync(p->x_new, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
   HIPCHK(hipMemsetAsync(p->cam_diag, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream));
   p->cam_scaled = false; p->cam_state_saved = false;
-  p->have_build = false; p->trial_built = false; p->cost_pending = false;
+  p->have_build = false; p->trial_built = false; p->cost_pending = false; p->lf_pending = false;
   hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
   launch_cam_prep(p, p->x, p->tab);
   p->first_scale = true;

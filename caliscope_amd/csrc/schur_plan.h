@@ -94,6 +94,14 @@ inline void release(void* ptr, size_t capacity) {
   }
   std::free(ptr);
 }
+// everything the pool keeps goes back to the allocator (cba_trim); returns the bytes released
+inline size_t trim() {
+  std::vector<Block> v;
+  { std::lock_guard<std::mutex> lock(pool_mu()); v.swap(pool()); }
+  size_t bytes = 0;
+  for (const Block& b : v) { bytes += b.bytes; std::free(b.ptr); }
+  return bytes;
+}
 // for containers that hand back (pointer, requested bytes) only — the std::vector allocator of cba_create's observation-sized host arrays: the
 // capacity of a pooled block is remembered beside the pool
 inline std::map<void*, size_t>& tracked() { static std::map<void*, size_t> m; return m; }
@@ -256,7 +264,11 @@ inline int build_reg2_plan(const Reg2Params& prm, const int* hcam, const int* hp
   }
   // (more than ~64 workers do not pay: a job is a few milliseconds, and starting a thread costs the main thread ~20 us)
   // (foreground work may burst above a cgroup quota: 64 threads finish the plan of a 1M-observation problem in 15 ms, inside one accounting period)
-  const unsigned n_threads = prm.threads > 0 ? (unsigned)prm.threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+  // Default cap (round 5): 16 workers below two million observations — the reference runs inside a desktop GUI process on a workstation, and 64
+  // threads bought a 1M-observation plan 3 ms of a 11 ms set-up; from 2M observations on (cfg4: 9-12 ms of wall on 64 threads) the burst stays.
+  const long n_obs_plan = (long)hps[P];
+  const unsigned n_threads = prm.threads > 0 ? (unsigned)prm.threads
+                                             : std::min(n_obs_plan >= 2000000 ? 64u : 16u, std::max(1u, std::thread::hardware_concurrency()));
   // observations of a point are sorted by camera => by group; pgb[q*(G+1) + a] .. [a+1] is group a's run
   RawVec<int> pgb;
   pgb.resize_uninit((size_t)P * (G + 1));

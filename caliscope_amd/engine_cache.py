@@ -117,12 +117,22 @@ def checkin(key, engine) -> None:
         e.close()
 
 
-def clear() -> None:
+def clear(trim: bool = True) -> int:
+    """Destroy the kept handle(s) and, `trim`, give back what the library pools between handles (``cba_trim``: arena chunks, streams, pinned
+    staging, the huge-page host blocks of the set-up).  Returns the bytes the library released."""
     with _lock:
         engines = list(_kept.values())
         _kept.clear()
     for e in engines:
         e.close()
+    if not trim:
+        return 0
+    try:
+        from caliscope_amd import _lib
+
+        return int(_lib.load().cba_trim())
+    except Exception:  # noqa: BLE001 - the library may be absent (interpreter exit on a box without it)
+        return 0
 
 
 atexit.register(clear)

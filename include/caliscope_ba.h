@@ -287,8 +287,11 @@ int cba_reduced_system(cba_problem* p, double* S, double* rhs);
 int cba_set_loss(cba_problem* p, int32_t loss, double f_scale);
 
 /* A handle of 500k observations or more starts with a quickly made Schur plan and swaps the balanced one in when the host thread dealing it is done
- * (a solve in progress picks it up between two iterations; results do not depend on which plan ran, the pair kernel's speed does).  cba_plan_wait
- * blocks until the balanced plan is installed: what a benchmark calls before its timed region.  No-op on a handle that is final already.
+ * (a solve in progress picks it up between two iterations).  The two plans add the same pair products in a DIFFERENT ORDER: the reduced system agrees
+ * to rounding (1e-13 relative), not bit for bit, and which iteration the swap lands on depends on host timing — a large default solve is therefore
+ * reproducible to summation order only (now and then one evaluation more or fewer); cba_options.deterministic = 1 builds the balanced plan inside
+ * cba_create and fixes every order.  cba_plan_wait blocks until the balanced plan is installed (what a benchmark calls before its timed region; no-op
+ * on a final handle) and returns the error of a background build that failed — the handle then stays usable on the quick plan (cba_info.plan_state 2).
  * (No counterpart in the reference: its solver has no set-up phase, core/capture_volume.py:387.) */
 int cba_plan_wait(cba_problem* p);
 
@@ -297,8 +300,9 @@ typedef struct {
   int32_t n_cams, n_points, n_cam_params, n_params;
   int64_t n_obs;
   int32_t n_chunks, grid_blocks;
-  int32_t schur_in_lds;   /* 0: Schur blocks accumulated in registers, one thread per camera-pair block (the default);
-                             1: LDS-atomic tile kernel (CBA_SCHUR=lds, or a point with > 2048 pairs in one tile) */
+  int32_t plan_state;     /* Schur plan of the pair kernel: 0 = the balanced ("dealt") plan, final; 1 = the quickly made plan of a two-stage handle, the
+                             balanced one still being built on its thread (cba_plan_wait / the next damped step installs it); 2 = the quick plan for
+                             good: CBA_PLAN=cheap, or the background build failed (plan_error) */
   int32_t max_obs_per_point;
   int64_t device_bytes;
   int32_t schur_groups;   /* G camera groups -> G(G+1)/2 tiles */
@@ -307,7 +311,8 @@ typedef struct {
   int32_t n_heavy_points; /* points with > 40 observations (static markers): per-camera Schur sums, split over chunks beyond 256 */
   int64_t schur_stream_len; /* total observations over all tile streams (recompute factor = this / n_obs) */
   int64_t schur_pairs;      /* observation pairs (blocks of W V^-1 W^T) formed per Schur pass */
-  int32_t schur_wide;       /* 1: 32 x 32 camera tiles, two blocks per thread (opt-in: CBA_SCHUR_WIDE=1) */
+  int32_t plan_error;       /* CBA_ERR_* of a failed background plan build (e.g. hipMalloc beside a large solve), else 0: the handle then keeps the
+                               quick plan (pair kernel 1.5-1.75x slower, same sums to rounding); cba_plan_wait returns it as an error */
   int32_t build_camg;       /* bit 0: the linearisation kernel reads the camera table through the vector cache instead of LDS (chosen when the
                                table is what keeps a second workgroup off the CU, ~100+ nine-parameter cameras; CBA_BUILD_CAMG=0/1 forces);
                                bit 1: EVERY per-observation kernel does (the LDS copy of the table would not fit: beyond ~230 six- / ~170
@@ -370,6 +375,12 @@ typedef struct {
 
 /* xyz_out [n_points][3]; undistorted_out [n_obs][2] or NULL.  device = HIP device ordinal. */
 int cba_triangulate(const cba_triangulate_desc* d, int32_t device, double* xyz_out, double* undistorted_out);
+
+/* Give back what the library keeps between handles: per device up to four 4 MB arena chunks, streams, mapped mailboxes and pinned staging buffers of
+ * destroyed handles, and the process-wide pool of huge-page host blocks the set-up's large arrays come from (up to 3 GB after a 10M-observation
+ * handle).  Live handles are not touched.  A long-lived host process (the reference's GUI session) calls it when a calibration is done:
+ * caliscope_amd.engine_cache.clear() does.  Returns the bytes released (host + device). */
+int64_t cba_trim(void);
 
 const char* cba_last_error(void);
 /* Sets the calling thread's error message and returns `code` (for drivers layered on the primitives, cba_solve). */

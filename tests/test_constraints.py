@@ -264,7 +264,7 @@ def test_heavy_static_points_step_and_solution(n_frames, with_constraints):
     kw = {} if con is None else dict(constraint_groups_a=con[0], constraint_groups_b=con[1], constraint_distances=con[2], constraint_weights=con[3])
     hip, ora = HipEngine(BAProblem(par, cam, uv, obj, **kw)), OracleEngine(par, cam, uv, obj, constraints=con)
     info = hip.info()
-    assert info["n_heavy_points"] == 12 and info["max_obs_per_point"] > (256 if n_frames == 80 else 100) and info["schur_in_lds"] == 0
+    assert info["n_heavy_points"] == 12 and info["max_obs_per_point"] > (256 if n_frames == 80 else 100) and info["plan_state"] == 0
     c_h, c_o = hip.begin(x0), ora.begin(x0)
     assert abs(c_h - c_o) <= 1e-13 * c_o
     hip.linearize(); ora.linearize()

@@ -13,14 +13,14 @@ for name, over in (("cfg2", {}), ("cfg4", dict(n_points=100_000, n_obs=1_000_000
     for rep in range(3):
         t = time.perf_counter(); e = HipEngine(prob); t1 = time.perf_counter(); e.close(); t2 = time.perf_counter()
         print(f"== {name} {over}: create {(t1 - t) * 1e3:.1f} ms, destroy {(t2 - t1) * 1e3:.1f} ms", flush=True)
-    engine_cache.clear()
+    engine_cache.clear(trim=False)
     t = time.perf_counter()
     r = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", method="trf", args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices))
     print(f"== {name} {over}: least_squares end to end {(time.perf_counter() - t) * 1e3:.1f} ms (set-up {r.setup_seconds * 1e3:.1f}, solve {r.solve_seconds * 1e3:.1f}, nfev {r.nfev})", flush=True)
-    engine_cache.clear()
+    engine_cache.clear(trim=False)
     for rep in range(4):  # the same seam call again in the warm process (host arrays from the pool)
         time.sleep(0.3)
         t = time.perf_counter()
         r = least_squares(None, x0, jac=None, bounds=par.bounds(), x_scale="jac", method="trf", args=(par, sc.camera_indices, sc.image_coords, sc.obj_indices))
         print(f"== {name} {over}: again: end to end {(time.perf_counter() - t) * 1e3:.1f} ms (set-up {r.setup_seconds * 1e3:.1f}, solve {r.solve_seconds * 1e3:.1f}, nfev {r.nfev})", flush=True)
-        engine_cache.clear()
+        engine_cache.clear(trim=False)
