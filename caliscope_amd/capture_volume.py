@@ -35,7 +35,7 @@ from caliscope_amd.exceptions import CalibrationError
 from caliscope_amd.least_squares import least_squares
 from caliscope_amd.constraints import ConstraintSet, ConstraintViolation, DistanceConstraint, RigidityReport
 from caliscope_amd.point_data import STATIC_SYNC_INDEX, ImagePoints, WorldPoints
-from caliscope_amd.trf import STATUS_REASONS
+from caliscope_amd.engine import STATUS_REASONS
 
 logger = logging.getLogger(__name__)
 

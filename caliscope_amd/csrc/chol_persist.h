@@ -48,7 +48,13 @@ struct CholP {
   int* sync;   // [0] F, [1] abort, then Pn[nbk + 1], Sn[nbk + 1], Un[(nbk + 1)^2], Tn[nbk^2]
   int n, ldw, nbk, base;
   int* flags;
+  long long* trace;  // profiling build (-DCBA_PROFILING, CBA_CHOL_TRACE=persist): [nbk + 1][8] stamps of the chain workgroup, 100 MHz; else nullptr
 };
+#ifdef CBA_PROFILING
+#define CP_STAMP(c, k, ph) do { if ((c).trace) (c).trace[(long)(k) * 8 + (ph)] = wall_clock64(); } while (0)
+#else
+#define CP_STAMP(c, k, ph) do { } while (0)
+#endif
 
 __device__ __forceinline__ int* cp_F(const CholP& c) { return c.sync; }
 __device__ __forceinline__ int* cp_abort(const CholP& c) { return c.sync + 1; }
@@ -58,21 +64,65 @@ __device__ __forceinline__ int* cp_Un(const CholP& c, int b, int j) { return c.s
 __device__ __forceinline__ int* cp_Tn(const CholP& c, int j, int i) { return c.sync + 2 + 2 * (c.nbk + 1) + (c.nbk + 1) * (c.nbk + 1) + j * c.nbk + i; }
 __host__ __device__ inline size_t cp_sync_ints(int nbk) { return 2 + 2 * (size_t)(nbk + 1) + (size_t)(nbk + 1) * (nbk + 1) + (size_t)nbk * nbk; }
 
-// one thread: wait until *p >= base + need.  false: aborted (by a peer, or by this wait's own time-out)
+// Polling.  A counter is written by a workgroup on another XCD; the reader polls it with RELAXED device-scope loads (they are served from the memory
+// side, not from this XCD's L2) and executes ONE acquire fence when the value is there.  Measured (profiles/r05_chol_persist.txt): with an acquire per
+// poll — an L2 invalidate each — 250 polling workgroups slowed every memory access of the device down so much that a step of the chain workgroup took
+// 50-90 us instead of 7; with relaxed polls every 0.1 us it took 17.  So polls are RARE: the first re-check after 0.25 us, then every 0.5 .. 2 us, and a
+// wait whose counter is still several steps of the chain away sleeps through them.
+__device__ __forceinline__ void cp_nap(unsigned spins, int far_steps) {
+  if (far_steps > 1) {  // the awaited value is >= 2 steps of the chain workgroup (~7 us each) away: ~3.4 us per s_sleep 127
+    for (int q = 0; q < min(far_steps - 1, 4); ++q) __builtin_amdgcn_s_sleep(127);
+    return;
+  }
+  if (spins < 2u) __builtin_amdgcn_s_sleep(9);        // 0.25 us
+  else if (spins < 6u) __builtin_amdgcn_s_sleep(18);  // 0.5 us
+  else if (spins < 12u) __builtin_amdgcn_s_sleep(36); // 1 us
+  else __builtin_amdgcn_s_sleep(72);                  // 2 us
+}
+// one thread: wait until *p >= base + need.  false: aborted (by a peer, or by this wait's own time-out).  The caller issues the acquire fence.
 __device__ __forceinline__ bool cp_wait(const CholP& c, const int* p, int need) {
+  if (need <= 0) return true;  // (nothing to wait for: counters of earlier solves lie below this solve's base)
   const int want = c.base + need;
-  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
   const long long t0 = wall_clock64();
-  for (unsigned spins = 1;; ++spins) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-    if ((spins & 31u) == 0u) {
+  for (unsigned spins = 0;; ++spins) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= want) return true;
+    if ((spins & 7u) == 7u) {
       if (__hip_atomic_load(cp_abort(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
       if (wall_clock64() - t0 > CP_TIMEOUT_TICKS) {
         __hip_atomic_store(cp_abort(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
     }
-    __builtin_amdgcn_s_sleep(1);
+    cp_nap(spins, 0);
+  }
+}
+// wave 0 of a task workgroup: up to 8 conditions *p[q] >= base + need[q], one per lane, polled TOGETHER (a FEED task has seven: one after the other
+// they cost seven memory round trips before the task even starts).  `far`: index of the condition that counts steps of the chain workgroup (F), or -1.
+// Returns false on abort / time-out.  All 64 lanes call it.
+struct CpWaits { const int* p[8]; int need[8]; int n; int far; };
+__device__ __forceinline__ bool cp_wait_many(const CholP& c, const CpWaits& w, int lane) {
+  const int* mine = nullptr;
+  int want = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q == lane && q < w.n && w.need[q] > 0) { mine = w.p[q]; want = c.base + w.need[q]; }
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 0;; ++spins) {
+    const int v = mine ? __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const bool ok = mine == nullptr || v >= want;
+    if (__all(ok)) return true;
+    if ((spins & 7u) == 7u) {
+      const bool stop = __hip_atomic_load(cp_abort(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (__any(stop)) return false;
+      if (wall_clock64() - t0 > CP_TIMEOUT_TICKS) {
+        if (lane == 0) __hip_atomic_store(cp_abort(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    int far_steps = 0;
+    if (w.far >= 0) far_steps = __shfl((lane == w.far && mine) ? want - v : 0, w.far < 0 ? 0 : w.far, WAVE);
+    cp_nap(spins, far_steps);
   }
 }
 __device__ __forceinline__ void cp_signal(const CholP& c, int* p, int value) {  // one thread, behind a barrier that ordered the workgroup's stores
@@ -138,6 +188,7 @@ __device__ __forceinline__ void cp_chain_job(const CholP& c, CpChainLds& s, int 
   ok = __shfl(ok ? 1 : 0, 0, WAVE) != 0;
   if (!ok) { if (lane == 0) s.abort_seen = 1; return; }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (lane == 0 && which == 0) CP_STAMP(c, k, 4);  // the mail is there
   const double* mail = c.mail + (long)b * 3 * NB * NB;
   cp_load_wave(s.scrA[which], mail, NB, rcb, nbk_k, lane);  // m0: block (b, k)
   cp_wave_sync();
@@ -166,6 +217,7 @@ __device__ __forceinline__ void cp_chain_job(const CholP& c, CpChainLds& s, int 
       else s.Dn[i][j] = (i < rcb && j < cols) ? old - v[r] : 0.0;
     }
   }
+  if (lane == 0) CP_STAMP(c, k, 5 + which);  // this wave's share of the job is done
 }
 
 __device__ __forceinline__ void cp_chain(const CholP& c, CpChainLds& s) {
@@ -187,15 +239,19 @@ __device__ __forceinline__ void cp_chain(const CholP& c, CpChainLds& s) {
   }
   for (int k = 0; k < nbk; ++k) {
     const int r0 = k * NB, rck = min(NB, n - r0);
-    // L_kk, X_k (and the diagonal block of T) to global memory for everybody else; X_k row-major for this workgroup's products
-    chol_factor_store(s.D, rck, c.Lm + (long)r0 * ldw + r0, ldw, c.Xinv + (long)k * NB * NB, tid, CP_THREADS, c.Tinv + (long)r0 * ldw + r0);
-#pragma unroll
-    for (int h = 0; h < NB * NB / CP_THREADS; ++h) {
-      const int i = (tid >> 5) + h * (CP_THREADS / NB), j = tid & 31;
-      s.X[i][j] = s.D[NB + j][i];
+    if (tid == 0) CP_STAMP(c, k, 0);  // D_k is factored
+    // X_k row-major for this workgroup's products (waves 0-6); L_kk, X_k and the diagonal block of T go to global memory for everybody else from WAVE 7
+    // ALONE, which then publishes F = k + 1 by itself: no barrier of the workgroup waits for global stores (0.5-1 us each step on the chain before)
+    if (wv < 7) {
+      for (int e = tid; e < NB * NB; e += 7 * WAVE) { const int i = e >> 5, j = e & 31; s.X[i][j] = s.D[NB + j][i]; }
+    } else {
+      chol_factor_store(s.D, rck, c.Lm + (long)r0 * ldw + r0, ldw, c.Xinv + (long)k * NB * NB, lane, WAVE, c.Tinv + (long)r0 * ldw + r0);
     }
-    __syncthreads();
-    if (tid == CP_THREADS - 1) cp_signal(c, cp_F(c), k + 1);  // (a lane of wave 7: waves 0-3 go straight on)
+    __syncthreads();  // (wave 7 has read D; its stores are in flight)
+    if (wv == 7) {
+      __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have left
+      if (lane == 0) { cp_signal(c, cp_F(c), k + 1); CP_STAMP(c, k, 1); }
+    }
     if (k + 1 >= nbk) break;
     const int rc1 = min(NB, n - (k + 1) * NB);
     if (wv < 4) {  // L_k+1,k = Bn X_k^T
@@ -218,7 +274,8 @@ __device__ __forceinline__ void cp_chain(const CholP& c, CpChainLds& s) {
       }
     }
     __syncthreads();
-    if (wv == 0) chol_factor_block(s.D, rc1, c.flags);
+    if (tid == 0) CP_STAMP(c, k, 2);  // the next diagonal block is in place
+    if (wv == 0) { chol_factor_block(s.D, rc1, c.flags); if (lane == 0) CP_STAMP(c, k, 3); }
     else if ((wv == 5 || wv == 6) && k + 2 < nbk) cp_chain_job(c, s, k + 2, k, wv, lane);
     __syncthreads();
     if (s.abort_seen) return;
@@ -232,13 +289,13 @@ struct CpTaskLds {
   unsigned long long ticket;
 };
 
-// thread 0 evaluates `cond` (a sequence of cp_wait calls), everybody learns the outcome; an acquire at agent scope follows
-#define CP_WAIT_ALL(cond)                                           \
-  do {                                                              \
-    if (tid == 0) s.ok = (cond) ? 1 : 0;                            \
-    __syncthreads();                                                \
-    if (!s.ok) return false;                                        \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              \
+// wave 0 waits for the conditions of `w` (cp_wait_many), everybody learns the outcome; an acquire at agent scope follows
+#define CP_WAIT_ALL(w)                                                          \
+  do {                                                                          \
+    if (wv == 0) { const bool ok_ = cp_wait_many(c, (w), lane); if (lane == 0) s.ok = ok_ ? 1 : 0; } \
+    __syncthreads();                                                            \
+    if (!s.ok) return false;                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                          \
   } while (0)
 
 __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const CholTask t) {
@@ -248,7 +305,8 @@ __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const 
   auto rc = [&](int b) { return b < nbk ? min(NB, n - b * NB) : 1; };     // its live rows
   const int k = t.k, b = t.b, j = t.j;
   if (t.kind == CT_PANEL) {  // L_bk = U_bk X_k^T
-    CP_WAIT_ALL(cp_wait(c, cp_F(c), k + 1) && cp_wait(c, cp_Un(c, b, k), k));
+    const CpWaits w{{cp_F(c), cp_Un(c, b, k)}, {k + 1, k}, 2, 0};
+    CP_WAIT_ALL(w);
     cp_load(s.A, c.W + (long)r0(b) * ldw + k * NB, ldw, rc(b), rc(k), tid);
     cp_load(s.B, c.Xinv + (long)k * NB * NB, NB, NB, NB, tid);
     __syncthreads();
@@ -269,8 +327,8 @@ __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const 
   if (t.kind == CT_UPD) {  // block (b, j) -= L_bk L_jk^T
     // (the three blocks a FEED task reads with panel b-4 applied wait for it before panel b-3 goes in)
     const bool after_feed = b < nbk && k == b - 3 && j >= b - 2;
-    CP_WAIT_ALL(cp_wait(c, cp_Pn(c, b), k + 1) && cp_wait(c, cp_Pn(c, j), k + 1) && cp_wait(c, cp_Un(c, b, j), k) &&
-                (!after_feed || cp_wait(c, cp_Sn(c, b), 1)));
+    const CpWaits w{{cp_Pn(c, b), cp_Pn(c, j), cp_Un(c, b, j), cp_Sn(c, b)}, {k + 1, k + 1, k, after_feed ? 1 : 0}, 4, 0};
+    CP_WAIT_ALL(w);
     cp_load(s.A, c.Lm + (long)r0(b) * ldw + k * NB, ldw, rc(b), rc(k), tid);
     cp_load(s.B, c.Lm + (long)r0(j) * ldw + k * NB, ldw, rc(j), rc(k), tid);
     __syncthreads();
@@ -292,8 +350,8 @@ __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const 
     // T = L^-T (upper block triangle, block (j, i) = M_ij^T, M = L^-1):  acc_ji += T_jm L_im^T for m = j .. i-1, then T_ji = -acc_ji X_i^T.
     // This task: block (j, i = b), term m = k - 1; i == k: the last term, finalised with X_k (published by the chain workgroup at the end of step k).
     const int i = b, m = k - 1;
-    CP_WAIT_ALL((m == j ? cp_wait(c, cp_F(c), j + 1) : cp_wait(c, cp_Tn(c, j, m), m - j + 1)) && cp_wait(c, cp_Pn(c, i), m + 1) &&
-                cp_wait(c, cp_Tn(c, j, i), m - j));
+    const CpWaits w{{m == j ? cp_F(c) : cp_Tn(c, j, m), cp_Pn(c, i), cp_Tn(c, j, i)}, {m == j ? j + 1 : m - j + 1, m + 1, m - j}, 3, 1};
+    CP_WAIT_ALL(w);
     const int rj = j * NB, ri = i * NB, rcj = rc(j), rci = rc(i), rcm = rc(m);
     cp_load(s.A, c.Tinv + (long)rj * ldw + m * NB, ldw, rcj, rcm, tid);
     cp_load(s.B, c.Lm + (long)ri * ldw + m * NB, ldw, rci, rcm, tid);
@@ -312,7 +370,8 @@ __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const 
       }
     }
     if (i == k) {
-      CP_WAIT_ALL(cp_wait(c, cp_F(c), k + 1));  // (the barrier inside also orders L0)
+      const CpWaits wf{{cp_F(c)}, {k + 1}, 1, 0};
+      CP_WAIT_ALL(wf);  // (the barrier inside also orders L0)
       cp_load(s.B, c.Xinv + (long)k * NB * NB, NB, NB, NB, tid);
       __syncthreads();
       if (wv < 4) {
@@ -335,7 +394,6 @@ __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const 
     double* mail = c.mail + (long)b * 3 * NB * NB;
     const int rcb = rc(b);
     if (k3 < 0) {  // b == 2: nothing to apply
-      CP_WAIT_ALL(true);
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int col = b - 2 + q;
@@ -349,9 +407,9 @@ __device__ __forceinline__ bool cp_run_task(const CholP& c, CpTaskLds& s, const 
       if (tid == 0) cp_signal(c, cp_Sn(c, b), 1);
       return true;
     }
-    CP_WAIT_ALL(cp_wait(c, cp_F(c), k3 + 1) && cp_wait(c, cp_Un(c, b, k3), k3) && cp_wait(c, cp_Un(c, b - 2, k3), k3) &&
-                cp_wait(c, cp_Un(c, b - 1, k3), k3) && cp_wait(c, cp_Un(c, b, b - 2), k3) && cp_wait(c, cp_Un(c, b, b - 1), k3) &&
-                cp_wait(c, cp_Un(c, b, b), k3));
+    const CpWaits w{{cp_F(c), cp_Un(c, b, k3), cp_Un(c, b - 2, k3), cp_Un(c, b - 1, k3), cp_Un(c, b, b - 2), cp_Un(c, b, b - 1), cp_Un(c, b, b)},
+                    {k3 + 1, k3, k3, k3, k3, k3, k3}, 7, 0};
+    CP_WAIT_ALL(w);
     cp_load(s.B, c.Xinv + (long)k3 * NB * NB, NB, NB, NB, tid);
     // the three L blocks of panel k3 this row's update needs, recomputed here: rows b, b-2, b-1
     CpBlk* Ls[3] = {&s.L0, &s.L1, &s.L2};
@@ -414,6 +472,29 @@ k_chol_persist(CholP c) {
     if (!cp_run_task(c, s, c.tasks[t])) return;  // aborted
     __syncthreads();
   }
+}
+
+// x = T y behind the persistent launch (k_chol_apply's body); an aborted launch (time-out) is reported as a failed factorisation: flags[2]
+__global__ void __launch_bounds__(APPLY_THREADS)
+k_chol_apply_checked(const double* __restrict__ Tinv, const double* __restrict__ Lm, int n, int ldw, double* __restrict__ out, const int* __restrict__ abort_word,
+                     int* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) double y[];  // n
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0 && *abort_word != 0) flags[2] = 1;
+  for (int i = tid; i < n; i += APPLY_THREADS) y[i] = Lm[(long)n * ldw + i];
+  __syncthreads();
+  const int r = tid >> 4, cl = tid & 15, row = blockIdx.x * NB + r;
+  double a0 = 0.0, a1 = 0.0;
+  if (row < n) {
+    const double* Tr = Tinv + (long)row * ldw;
+    int c = blockIdx.x * NB + cl;
+    for (; c + 16 < n; c += 32) { a0 = fma(Tr[c], y[c], a0); a1 = fma(Tr[c + 16], y[c + 16], a1); }
+    if (c < n) a0 = fma(Tr[c], y[c], a0);
+  }
+  double s = a0 + a1;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (cl == 0 && row < n) out[row] = s;
 }
 
 // ---- host: the task list in dependency order -----------------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ import numpy as np
 from caliscope_amd.engine import BAProblem
 from caliscope_amd.exceptions import BackendError
 from caliscope_amd.sharding import Shard, shard_problem
-from caliscope_amd.trf import TrfResult, trf_solve
+from caliscope_amd.engine import TrfResult
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -287,15 +287,9 @@ def solve_sharded(problem: BAProblem, x0: np.ndarray, control, *, device_id: int
         if tol.get("max_nfev") is None:
             # scipy's default 100 n refers to the whole problem; the shards have different sizes and must stop together
             tol["max_nfev"] = 100 * int(problem.n_params)
-        if hasattr(engine, "solve") and os.environ.get("CBA_HOST_LOOP", "native") != "python":
-            # the library's driver (cba_solve) on every rank: the scalars that steer it are identical everywhere
-            res = engine.solve(x_local, lb=np.ascontiguousarray(lb[:ncp]) if bounded else None,
-                               ub=np.ascontiguousarray(ub[:ncp]) if bounded else None, **tol)
-        else:
-            if bounded and os.environ.get("CBA_HOST_LOOP", "native") == "python" and hasattr(engine, "solve"):
-                raise BackendError("CBA_HOST_LOOP=python has no bounded (Coleman-Li) variant: free intrinsics need the native driver")
-            feasible = (lambda c: bool(np.all(c > lb[:ncp]) and np.all(c < ub[:ncp]))) if bounded else None
-            res = trf_solve(engine, x_local, feasible=feasible, **tol)
+        # the engine's solve() on every rank (the library's cba_solve for the device engine): the scalars that steer it are identical everywhere
+        res = engine.solve(x_local, lb=np.ascontiguousarray(lb[:ncp]) if bounded else None,
+                           ub=np.ascontiguousarray(ub[:ncp]) if bounded else None, **tol)
         res.x = gather_solution(shard, res.x, control)
     finally:
         close = getattr(engine, "close", None)

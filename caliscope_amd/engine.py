@@ -1,11 +1,11 @@
 """The contract between the trust-region driver (host, Python) and a BA engine (device).
 
-The driver in :mod:`caliscope_amd.trf` never sees a vector: every O(n) / O(N_obs) operation
-lives behind this interface and only scalars cross it.  The production implementation is
-:class:`caliscope_amd.hip_engine.HipEngine` (hand-written HIP kernels behind the C ABI of
-``include/caliscope_ba.h``).  The tests drive the very same driver with a numpy engine built on
-the oracle to validate the driver logic against scipy on CPU (``oracle/engine.py``; test
-infrastructure, never imported from this package).
+The driver — ``cba_solve`` in the library (``csrc/cba_solve.cpp``), the ONE driver of the package — never sees a vector: every
+O(n) / O(N_obs) operation lives behind this interface and only scalars cross it.  The production implementation is
+:class:`caliscope_amd.hip_engine.HipEngine` (hand-written HIP kernels behind the C ABI of ``include/caliscope_ba.h``); an engine
+is anything with these primitives and a ``solve()``.  The CPU tests plug in a numpy engine built on the oracle
+(``oracle/engine.py``) whose ``solve()`` runs a Python restatement of the same loop (``oracle/trf_driver.py``): test
+infrastructure, never imported from this package.
 
 Notation.  ``J`` and ``f`` are the robust-loss-scaled Jacobian and
 residuals at the current point ``x``; ``g = J^T f``; ``D = scale_inv`` are the Jacobi column norms
@@ -15,12 +15,47 @@ scaled space: ``g_h = d*g``, ``J_h = J diag(d)``.
 
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Protocol
 
 import numpy as np
 
 LOSS_CODES = {"linear": 0, "huber": 1, "soft_l1": 2, "cauchy": 3, "arctan": 4}
+
+# scipy's termination codes (least_squares.py:241 ff.), named as OptimizationStatus.termination_reason wants them (capture_volume.py:60-67)
+STATUS_REASONS = {
+    -1: "improper_input",
+    0: "max_evaluations",
+    1: "converged_gtol",
+    2: "converged_ftol",
+    3: "converged_xtol",
+    4: "converged_small_step",
+}
+
+
+@dataclass
+class TrfResult:
+    """What an engine's ``solve()`` returns (``cba_result`` + the solution)."""
+
+    x: np.ndarray
+    cost: float
+    optimality: float
+    nfev: int
+    njev: int
+    status: int
+    n_iterations: int = 0
+    seconds: float = 0.0            # wall time of the solve (cba_result.t_total_s)
+    rejected_seconds: float = 0.0   # of it: the separately evaluated trial points that were rejected (cba_result.t_rejected_s) ...
+    rejected_timed: int = 0         # ... and their number
+    trace: list = field(default_factory=list)  # per outer iteration: dict(cost, g_norm, Delta, lam, nfev)
+
+    @property
+    def message(self) -> str:
+        return STATUS_REASONS.get(self.status, f"unknown_{self.status}")
+
+    @property
+    def success(self) -> bool:
+        return self.status > 0
 
 
 @dataclass

@@ -152,10 +152,10 @@ class HipEngine:
 
     # -- the whole solve in the library (csrc/cba_solve.cpp) ---------------------------------------------
     def solve(self, x0, *, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, lb=None, ub=None, fetch_x=True):
-        """``cba_solve``: the trust-region loop of :mod:`caliscope_amd.trf` run natively.  ``x0=None`` restarts from the
+        """``cba_solve``: the whole trust-region loop inside the library (``csrc/cba_solve.cpp``).  ``x0=None`` restarts from the
         x0 already on the device; ``lb`` / ``ub`` bound the camera block (``n_cam_params`` entries).  Returns a
-        :class:`caliscope_amd.trf.TrfResult` (``x`` is None when ``fetch_x`` is False)."""
-        from caliscope_amd.trf import TrfResult
+        :class:`caliscope_amd.engine.TrfResult` (``x`` is None when ``fetch_x`` is False)."""
+        from caliscope_amd.engine import TrfResult
 
         keep = []
         opt = _lib.SolveOptions(ftol=float(ftol), xtol=float(xtol), gtol=float(gtol), max_nfev=0 if max_nfev is None else int(max_nfev),

@@ -18,9 +18,9 @@ Semantics kept from scipy 1.15.3: cost definition, robust losses, ``x_scale='jac
 non-finite initial residuals, constraint rows (the four trailing ``args``), finite bounds through scipy's
 bounded variant (Coleman-Li scaling, reflective steps).  Difference: the regularised
 Gauss-Newton step is exact (Schur complement) instead of LSMR at 1e-6.  The loop itself runs in the library
-(``cba_solve``); ``engine_factory`` / ``CBA_HOST_LOOP=python`` select the Python driver of
-:mod:`caliscope_amd.trf` on the engine primitives (the CPU tests plug the numpy engine in that way; that driver
-only guards bounds by rejecting infeasible trial points).
+(``cba_solve``, behind the engine's ``solve()``); ``engine_factory`` is the test hook through which the CPU tests plug in the numpy
+engine of ``oracle/engine.py`` (its ``solve()`` runs a Python restatement of the loop that only guards bounds by rejecting
+infeasible trial points).
 """
 
 from __future__ import annotations
@@ -34,7 +34,7 @@ import numpy as np
 from caliscope_amd.bundle_parameterization import n_params_of
 from caliscope_amd.engine import LOSS_CODES, BAProblem
 from caliscope_amd.exceptions import BackendError
-from caliscope_amd.trf import STATUS_REASONS, trf_solve
+from caliscope_amd.engine import STATUS_REASONS
 
 TERMINATION_MESSAGES = {
     -1: "Improper input parameters status returned from `leastsq`",
@@ -156,8 +156,6 @@ def least_squares(
         if devices is None:
             devices = devices_from_env()
         if devices is not None and len(devices) > 1:
-            if os.environ.get("CBA_HOST_LOOP", "native") == "python":
-                raise BackendError("CBA_HOST_LOOP=python drives one device; unset it to shard over several")
             ncp = parameterization.n_camera_params
             res = solve_multi_device(problem, x0, devices, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose,
                                      cam_bounds=(lb[:ncp], ub[:ncp]) if bounded else None)
@@ -180,27 +178,12 @@ def least_squares(
     solved = False
     t_solve = time.perf_counter()
     try:
-        feasible = None
-        if bounded:
-            ncp = parameterization.n_camera_params
-            lbc, ubc = lb[:ncp], ub[:ncp]
-
-            def feasible(cam_params):
-                return bool(np.all(cam_params > lbc) and np.all(cam_params < ubc))
-
-        if hasattr(engine, "solve") and os.environ.get("CBA_HOST_LOOP", "native") != "python":
-            # the whole loop in the library (cba_solve); CBA_HOST_LOOP=python keeps the Python driver on the primitives
-            ncp = parameterization.n_camera_params
-            res = engine.solve(x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose,
-                               lb=lb[:ncp] if bounded else None, ub=ub[:ncp] if bounded else None)
-            if res.status == -1:
-                raise ValueError("Residuals are not finite in the initial point.")
-        else:
-            if bounded and hasattr(engine, "solve"):
-                # the Python driver only rejects infeasible trial points; on the device that silently changes bounded behaviour
-                # (it stalls where scipy's Coleman-Li iteration converges)
-                raise BackendError("CBA_HOST_LOOP=python has no bounded (Coleman-Li) variant: solves with free intrinsics need the native driver")
-            res = trf_solve(engine, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
+        # the whole loop behind the engine's solve(): cba_solve in the library for the device engine (the one driver of the package)
+        ncp = parameterization.n_camera_params
+        res = engine.solve(x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose,
+                           lb=lb[:ncp] if bounded else None, ub=ub[:ncp] if bounded else None)
+        if res.status == -1:
+            raise ValueError("Residuals are not finite in the initial point.")
         solved = True
         t_solve = time.perf_counter() - t_solve
     finally:

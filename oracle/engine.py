@@ -1,6 +1,6 @@
 """numpy implementation of the BAEngine protocol on top of the oracle.  TEST INFRASTRUCTURE.
 
-Purpose: run the production trust-region driver (``caliscope_amd/trf.py``) on CPU so that its
+Purpose: run the trust-region loop (``oracle/trf_driver.py``, the Python restatement of ``csrc/cba_solve.cpp``) on CPU so that its
 logic can be compared with scipy's TRF without a GPU, and so that the point-sharded multi-rank
 protocol (what is all-reduced and when) can be exercised with ``gloo`` at world_size 2.  It also
 is the per-primitive oracle the HIP engine is compared with on the GPU (normal-equation blocks,
@@ -276,6 +276,22 @@ class OracleEngine:
     def accept(self):
         self.x = self.x_new
         self.f_raw = self.f_new
+
+    def solve(self, x0, *, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, lb=None, ub=None, fetch_x=True):
+        """The engine-level ``solve()`` the product calls (``HipEngine.solve`` = ``cba_solve``): here the Python restatement of the driver
+        (oracle/trf_driver.py) on this engine's primitives.  Bounds on the camera block: infeasible trial points are rejected (the CPU tests'
+        bounded cases converge inside their boxes; the Coleman-Li variant lives in ``cba_solve`` and is tested on the device and on the
+        dense CPU build of the ABI)."""
+        from oracle.trf_driver import trf_solve
+
+        feasible = None
+        if lb is not None and ub is not None and (np.any(np.isfinite(lb)) or np.any(np.isfinite(ub))):
+            lbc, ubc = np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64)
+
+            def feasible(cam_params):
+                return bool(np.all(cam_params > lbc) and np.all(cam_params < ubc))
+
+        return trf_solve(self, x0, ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, verbose=verbose, feasible=feasible)
 
     def current_x(self):
         """Full-layout x; non-owned points are filled by an all-reduce of zero-padded vectors."""

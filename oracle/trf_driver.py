@@ -1,7 +1,7 @@
-"""Trust-region driver of the MI355X bundle-adjustment solver (host side, scalars only) — the Python twin of
-``csrc/cba_solve.cpp``, which is what the product runs (one C call per solve, fused iterations, scipy's bounded
-variant).  This module drives any :class:`~caliscope_amd.engine.BAEngine` through the primitives: the numpy engine of
-the CPU tests, or the device engine with ``CBA_HOST_LOOP=python``.
+"""TEST INFRASTRUCTURE (round 5: moved out of the package, which has ONE driver: ``csrc/cba_solve.cpp``).  A Python restatement of that
+driver's unbounded loop on the engine primitives: what ``OracleEngine.solve()`` runs for the CPU tests, and what the GPU tests and the smoke
+check run on the device primitives to compare with ``cba_solve`` evaluation by evaluation (tests/test_gpu_parity.py).  No bounded
+(Coleman-Li) variant: with bounds it only rejects infeasible trial points.
 
 The reference hands the problem to ``scipy.optimize.least_squares(method="trf",
 x_scale="jac", jac=<sparse>)`` (``core/capture_volume.py:387-411``), i.e. scipy's Trust-Region-
@@ -35,43 +35,10 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from caliscope_amd.engine import BAEngine
+from caliscope_amd.engine import STATUS_REASONS, BAEngine, TrfResult  # noqa: F401 (re-exported for the tests)
 
 # ||w||^2 / ||p||^2 below which the subspace model is built from explicit J.v products
 SUBSPACE_EXPLICIT_BELOW = 1e-6
-
-STATUS_REASONS = {
-    -1: "improper_input",
-    0: "max_evaluations",
-    1: "converged_gtol",
-    2: "converged_ftol",
-    3: "converged_xtol",
-    4: "converged_small_step",
-}
-
-
-@dataclass
-class TrfResult:
-    x: np.ndarray
-    cost: float
-    optimality: float
-    nfev: int
-    njev: int
-    status: int
-    n_iterations: int = 0
-    seconds: float = 0.0            # wall time of the solve (cba_result.t_total_s)
-    rejected_seconds: float = 0.0   # of it: the separately evaluated trial points that were rejected (cba_result.t_rejected_s) ...
-    rejected_timed: int = 0         # ... and their number
-    trace: list = field(default_factory=list)  # per outer iteration: dict(cost, g_norm, Delta, lam, nfev)
-
-    @property
-    def message(self) -> str:
-        return STATUS_REASONS.get(self.status, f"unknown_{self.status}")
-
-    @property
-    def success(self) -> bool:
-        return self.status > 0
-
 
 DAMPING_FLOOR = 1e-13  # csrc/trf_math.h
 

@@ -103,6 +103,7 @@ def test_round4_bench_line_closes_parity_from_the_oracle_side():
     name, d = _latest_bench_line()
     if name < "r04":
         pytest.skip("no round-4 bench line committed yet")
+    parity_file = "parity_r04.json" if name < "r05" else _latest_parity_file()[0]
     for key in ("timed_region", "library_source_sha256", "plan_wait_ms"):
         assert key in d, key
     tr = d["timed_region"]
@@ -116,26 +117,47 @@ def test_round4_bench_line_closes_parity_from_the_oracle_side():
     c3 = d["also"]["cfg3"]["timed_region"]  # Huber: rejected trials are timed on their own, not averaged into the step
     assert c3["rejected_trials_timed"] > 0 and c3["ms_per_rejected_trial"] < c3["ms_per_accepted_step"]
     # the parity file of the same run was written on the same library sources
-    par = json.loads((ROOT / "profiles" / "parity_r04.json").read_text())
+    par = json.loads((ROOT / "profiles" / parity_file).read_text())
     assert par["library_source_sha256"] == d["library_source_sha256"]
 
 
+def _latest_parity_file():
+    files = sorted((ROOT / "profiles").glob("parity_r[0-9][0-9].json"))
+    assert files
+    return files[-1].name, json.loads(files[-1].read_text())
+
+
+# KNOWN PARITY GAP (recorded in DESIGN.md 6 and VERDICT r04): north_star's literal 1e-6 on every converged world point is NOT met on cfg3 (Huber, 5 %
+# outliers): one of its 50 000 points, all of whose observations sit in Huber's linear region, ends 1.5e-6 from scipy's position.  The suite does not
+# widen the bar for it: a case listed here must (a) say so itself (`within_north_star` false), (b) list EVERY point above 1e-6 in `weak_points` and
+# (c) show for each of them that moving it, alone, to the reference's position changes the ORACLE's cost by less than 1e-12 relative — i.e. the data
+# cannot tell the two positions apart.  Cameras, the 99.9 % quantile of the points, RMS and cost must still meet the bar.  Nothing else is excused.
+KNOWN_POINT_GAPS = {"cfg3_tight"}
+
+
+def _converged_case_ok(name, c):
+    assert abs(c["d_rms_px"]) <= 1e-4 and c["aligned_ang_rad"] <= 1e-6 and c["detail"]["cameras_pos"] <= 1e-6 and abs(c["rel_cost"]) <= 1e-9, name
+    assert c["detail"]["points_pos_p999"] <= 1e-6, name
+    n_above = c["detail"]["points_above_1e-6"]
+    if n_above == 0:
+        assert c["within_north_star"] is True, name
+        return
+    assert name in KNOWN_POINT_GAPS, f"{name}: {n_above} points above 1e-6 and the case is not a recorded gap"
+    assert c["within_north_star"] is False, name  # the file says it, too
+    wp = c["weak_points"]
+    assert wp["points_above_1e-6"] == n_above == len(wp["listed"]), name  # every one of them is listed ...
+    for pt in wp["listed"]:                                                # ... and indistinguishable to the data
+        assert abs(pt["rel_cost_change_if_moved_to_the_reference_position"]) <= 1e-12, (name, pt)
+
+
 def test_committed_parity_at_size():
-    """profiles/parity_r04.json (tools/parity_at_size.py, written by the round's last GPU run): GPU against scipy on BASELINE-sized inputs, both
-    directions of the converged-level protocol."""
-    d = json.loads((ROOT / "profiles" / "parity_r04.json").read_text())
+    """profiles/parity_r*.json, the newest (tools/parity_at_size.py, written by the round's last GPU run): GPU against scipy on BASELINE-sized inputs,
+    both directions of the converged-level protocol.  The 1e-6 bar is asserted as north_star states it; the one recorded exception is handled by
+    _converged_case_ok and by nothing looser."""
+    name, d = _latest_parity_file()
     for case in ("cfg2", "cfg3_tight"):  # both sides run to their minimum: a plain comparison, and scipy restarted at the product's answer stays put
         c = d[case]
-        assert abs(c["d_rms_px"]) <= 1e-4 and c["aligned_ang_rad"] <= 1e-6 and c["detail"]["cameras_pos"] <= 1e-6 and abs(c["rel_cost"]) <= 1e-9, case
-        assert c["detail"]["points_pos_p999"] <= 1e-6, case
-        if c["detail"]["points_above_1e-6"]:
-            # Huber on 17 px of noise: a point whose observations all sit in the loss's linear region is nearly free along its rays.  Such a point may
-            # differ by more than 1e-6 only if the DATA cannot tell the two positions apart: moving it, alone, to the reference's position changes the
-            # oracle's cost by less than 1e-12 relative (bench.weak_points) — no termination test of either solver can prefer one position
-            assert c["detail"]["points_above_1e-6"] <= 3 and c["detail"]["points_pos_max"] <= 1e-5, case
-            assert c["weak_points"]["all_listed_indistinguishable_at_1e-12_of_the_cost"] is True, case
-        else:
-            assert c["within_north_star"] is True, case
+        _converged_case_ok(case, c)
         _oracle_polish_ok(c["oracle_polish"])
     # cfg3 with the product's robust-stage settings (ftol 1e-4, max_nfev 60): the same trajectory, evaluation for evaluation
     c3p = d["cfg3_product"]
@@ -150,6 +172,33 @@ def test_committed_parity_at_size():
         tight = c5["tight_reference"]["detail"]
         assert tight["aligned_pos"] <= 1e-6 and tight["aligned_ang_rad"] <= 1e-6 and tight["points_above_1e-6"] == 0, case
         _oracle_polish_ok(c5["oracle_polish"])
+
+
+def test_round5_bench_line_says_what_a_caller_gets():
+    """Round 5: the line names the Schur plan its timed steps ran on and carries the same steps on the quickly made plan a FIRST
+    optimize() call runs on; the `also` workloads are timed over K ACCEPTED steps; cfg3 run to the minimum is compared with the stored scipy solve in the
+    driver's own line; stored scipy timings are marked as stored; the default-tolerance distance comes with its reading."""
+    name, d = _latest_bench_line()
+    if name < "r05":
+        pytest.skip("no round-5 bench line committed yet")
+    tr = d["timed_region"]
+    assert tr["plan"] == "dealt" and tr["counted"] == "trials" and tr["trial_points"] == d["steps"]
+    fc = tr["first_call"]
+    assert fc["plan"] == "cheap" and fc["ms_per_step"] >= 0.9 * d["ms_per_step"] and fc["value"] > 1e7  # (the quick plan's pair kernel is slower, never faster)
+    for wl, a in d["also"].items():
+        t = a["timed_region"]
+        assert t["counted"] == "accepted" and t["accepted_steps"] >= d["steps"], wl
+    c3 = d["also"]["cfg3"]["parity"]
+    assert c3["scipy_stored"] is True and c3["cameras_within_1e-6"] is True and abs(c3["d_rms_px"]) <= 1e-4 and abs(c3["rel_cost"]) <= 1e-9
+    _converged_case_ok("cfg3_tight", c3)
+    assert c3["oracle_polish"]["scipy_moves_within_1e-6_and_gains_within_1e-12"] is True
+    assert d["cpu_baseline"]["stored"] is False  # the headline's scipy leg is timed live on the box
+    c5 = d["also"]["cfg5"]["parity"]
+    assert c5["value_ratio_uses_stored_cpu_seconds"] is True
+    dist = d["parity"]["default_tolerance_distance"]
+    assert "reading" in dist and dist["scipy_rel_cost_above_the_minimum"] >= -1e-12 and dist["product_rel_cost_above_the_minimum"] <= 1e-9
+    par_name, par = _latest_parity_file()
+    assert par_name >= "parity_r05.json" and par["library_source_sha256"] == d["library_source_sha256"]
 
 
 def test_weak_points_reports_what_the_data_say_about_a_displaced_point():

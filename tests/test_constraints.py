@@ -278,7 +278,7 @@ def test_heavy_static_points_step_and_solution(n_frames, with_constraints):
         for fld in ("p_sq", "gh_dot_p", "w_sq"):
             assert abs(getattr(sh, fld) - getattr(so, fld)) <= 10 * tol * abs(getattr(so, fld)), (fld, lam)
     got = hip.solve(x0)
-    from caliscope_amd.trf import trf_solve
+    from oracle.trf_driver import trf_solve
 
     ref = trf_solve(ora, x0)
     assert got.status > 0 and ref.status > 0 and abs(got.cost - ref.cost) <= 1e-9 * ref.cost

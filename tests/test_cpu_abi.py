@@ -29,7 +29,6 @@ def cpu_lib(tmp_path_factory):
 def _run(cpu_lib, body: str, timeout=240):
     """Run `body` (which prints one JSON object as its last line) in a fresh interpreter bound to the CPU build."""
     env = dict(os.environ, CALISCOPE_BA_LIB=str(cpu_lib), PYTHONPATH=str(ROOT))
-    env.pop("CBA_HOST_LOOP", None)
     proc = subprocess.run([sys.executable, "-c", textwrap.dedent(body)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert proc.returncode == 0, proc.stderr[-3000:]
     return json.loads(proc.stdout.strip().splitlines()[-1])
@@ -389,7 +388,7 @@ def test_bench_under_the_launcher_one_process_per_rank(cpu_lib):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ, CALISCOPE_BA_LIB=str(cpu_lib), PYTHONPATH=str(ROOT))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CBA_HOST_LOOP", "CBA_CONTROL_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CBA_CONTROL_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            str(ROOT / "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "4", "--warmup", "1", "--no-cpu", "--also", ""]

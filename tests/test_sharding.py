@@ -90,7 +90,7 @@ def _worker(rank, world, port, loss, out_dir):
 
 @pytest.mark.parametrize("loss", ["linear", "soft_l1"])
 def test_two_rank_socket_solve_matches_single_rank(tmp_path, loss):
-    from caliscope_amd.trf import trf_solve
+    from oracle.trf_driver import trf_solve
     from oracle.engine import OracleEngine
 
     world = 2
@@ -168,7 +168,7 @@ def _con_worker(rank, world, port, out_dir):
 
 def test_two_rank_socket_solve_with_constraint_rows(tmp_path):
     """Constraint components stay on one rank; their share of the reduced camera system rides in the same all-reduce."""
-    from caliscope_amd.trf import trf_solve
+    from oracle.trf_driver import trf_solve
     from oracle.engine import OracleEngine
     from tests.constrained_scene import board_scene
     from tests.helpers import aligned_difference
@@ -191,7 +191,7 @@ def test_three_rank_thread_control_plane_matches_single_rank():
     import threading
 
     from caliscope_amd.distributed import ThreadControlPlane, _ThreadGroupState, solve_sharded
-    from caliscope_amd.trf import trf_solve
+    from oracle.trf_driver import trf_solve
     from oracle.engine import OracleEngine
     from tests.helpers import aligned_difference
 

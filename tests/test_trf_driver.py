@@ -1,4 +1,4 @@
-"""Production trust-region driver (caliscope_amd/trf.py) on the numpy oracle engine vs the reference's
+"""Production trust-region driver (oracle/trf_driver.py) on the numpy oracle engine vs the reference's
 scipy call (oracle/solver.py == capture_volume.py:387-411).  Three-tier parity protocol of SURVEY.md §7:
 cost / RMS equality, gauge-aligned converged state <= 1e-6 relative, RMS px within 1e-4."""
 import numpy as np
@@ -7,7 +7,7 @@ import pytest
 
 from caliscope_amd.bundle_parameterization import BundleParameterization
 from caliscope_amd.cameras import CameraArray
-from caliscope_amd.trf import solve_subspace_2d, trf_solve
+from oracle.trf_driver import solve_subspace_2d, trf_solve
 from oracle.engine import OracleEngine
 from oracle.solver import optimize_scipy, rms_reprojection_px
 from tests.helpers import aligned_difference, small_problem

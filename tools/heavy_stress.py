@@ -7,7 +7,7 @@ from tests.constrained_scene import marker_volume
 from caliscope_amd.engine import BAProblem
 from caliscope_amd.hip_engine import HipEngine
 from oracle.engine import OracleEngine
-from caliscope_amd.trf import trf_solve
+from oracle.trf_driver import trf_solve
 from tests.helpers import aligned_difference
 t=time.time(); vol, par = marker_volume(n_frames=600, n_markers=3, n_cams=6); print("scene", time.time()-t)
 _, cam, uv, obj = vol._matched_arrays()
