@@ -1063,6 +1063,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->cus = cus;
   const int max_blocks = (opt && opt->max_blocks > 0) ? opt->max_blocks : 2 * cus;  // two persistent workgroups per CU for the per-observation kernels
   p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
+  // (2 per CU also for k_backsub, whose 28 KB of LDS would admit five: swept in round 5, profiles/r05_occupancy_sweeps.txt — 64 us at 2, 69-83 at 3-5)
   p->grid_backsub = std::max(1, std::min(p->n_chunks, 2 * cus));
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
