@@ -125,6 +125,8 @@ SIGNATURES = {
     "cba_refresh_step_scalars": (C.c_int, [C.c_void_p, C.POINTER(NewtonInfo)]),
     "cba_step_supported": (C.c_int, [C.c_void_p]),
     "cba_set_camera_scaling": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(Linearization)]),
+    "cba_set_bounds": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "cba_step_camera_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "cba_subspace_gram_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.c_double, C.c_double, c_double_p, c_double_p]),
     "cba_trial_ex": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.POINTER(TrialInfo)]),
     "cba_solve": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(SolveOptions), c_double_p, C.POINTER(Result)]),

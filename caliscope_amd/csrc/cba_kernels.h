@@ -191,6 +191,9 @@ k_reduce_rows(const double* __restrict__ partial, int nrow, int width, double* _
 struct PubArgs {
   double* scal; int n_scal; int* flags; double* host_scal; int* host_flags; unsigned long long seq;
   const double* part_a; int rows_a, slot_a; const double* part_b; int rows_b, slot_b;
+  // bounded fused iteration: the camera blocks of x, g, the Jacobi scale and the damped step travel with the packet (the host driver keeps scipy's
+  // select_step and the later trials of the iteration; four vectors of <= 1152 doubles instead of three host round trips for them)
+  const double* cam_src[4]; double* cam_dst; int ncp;
 };
 __global__ void __launch_bounds__(64 * REDUCE_RY)
 k_reduce_rows_pub(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out, double* __restrict__ grad_out,
@@ -214,6 +217,8 @@ k_reduce_rows_pub(const double* __restrict__ partial, int nrow, int width, doubl
   __syncthreads();
   if (t < pub.n_scal) pub.host_scal[t] = (t == pub.slot_a) ? sh_tot[0] : (t == pub.slot_b) ? sh_tot[1] : pub.scal[t];
   if (t < 4) { pub.host_flags[t] = pub.flags[t]; pub.flags[t] = 0; }
+  if (pub.cam_dst)
+    for (int e = t; e < 4 * pub.ncp; e += 64 * REDUCE_RY) pub.cam_dst[e] = pub.cam_src[e / pub.ncp][e % pub.ncp];
   __threadfence_system();
   __syncthreads();
   if (t == 0) reinterpret_cast<volatile unsigned long long*>(pub.host_scal)[63] = pub.seq;
@@ -940,7 +945,7 @@ __device__ __forceinline__ double lin_finish_block(const LinFin& lf, double (*sh
       for (int i = 0; i < BLOCK / WAVE; ++i) r = (q == 4) ? fmax(r, sh_red[q][i]) : r + sh_red[q][i];
       tot[q] = r;
     }
-    const double gh_sq = tot[0], jg_sq = tot[5], xs = sqrt(tot[1]);
+    const double gh_sq = tot[0], jg_sq = tot[5] + tot[3], xs = sqrt(tot[1]);  // (+ C_gg, the Coleman-Li term of a bounded solve: zero otherwise)
     const double radius = lf.radius > 0.0 ? lf.radius : (xs > 0.0 ? xs : 1.0);  // (fused_lam's rule)
     const double lam = trf::damping(jg_sq, gh_sq, radius);
     sh_out[0] = lam;
@@ -2372,7 +2377,7 @@ __global__ void k_fused_subspace(double* __restrict__ scal, const int* __restric
 }
 
 __device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) {
-  const double gh_sq = scal[0], jg_sq = scal[12], xs = sqrt(scal[1]);
+  const double gh_sq = scal[0], jg_sq = scal[12] + scal[3], xs = sqrt(scal[1]);  // (scal[3]: C_gg of a bounded fused iteration, zero otherwise)
   const double radius = radius_in > 0.0 ? radius_in : (xs > 0.0 ? xs : 1.0);  // first iteration: Delta = ||x0 * scale_inv||
   const double lam = trf::damping(jg_sq, gh_sq, radius);
   fz[0] = lam; fz[1] = radius;
@@ -2380,7 +2385,7 @@ __device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radi
 }
 
 __device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
-  const double gh_sq = scal[0], jg_sq = scal[12], p_sq = scal[16], ghp = scal[17];
+  const double gh_sq = scal[0], jg_sq = scal[12] + scal[3], p_sq = scal[16], ghp = scal[17];  // H_gg = ||J_h g_h||^2 + C_gg
   const double lam = fz[0], radius = fz[1], gh_norm = sqrt(gh_sq);
   const double c = ghp / gh_sq;
   // ||w||^2 = ||p - c g_h||^2 = ||p||^2 - <g_h, p>^2 / ||g_h||^2: relative error ~ eps ||p||^2 / ||w||^2, so it is used
@@ -2411,22 +2416,57 @@ __device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const 
 // ~40 kernels of a few microseconds per iteration).  Same arithmetic and summation order as the separate kernels.
 
 // k_scale_update + k_lin_scalars in one pass over the vector
+// Bounded camera parameters inside the fused iteration (round 5; scipy trf_bounds, trf.py:283-296, common.py CL_scaling_vector): what
+// cba_get_camera_state + the host's Coleman-Li loop + cba_set_camera_scaling did in three host round trips.  For a camera entry the Jacobi scale
+// (monotone-max state, kept apart in state_out) is multiplied by 1 / sqrt(v), v = distance to the bound the gradient points at (times the scale),
+// cam_diag = diag_h scale_eff^2 with diag_h = g dv / scale is what k_schur_finalize adds to the diagonal of S, the sums are formed with the
+// effective scale, max |g| becomes max |g v| and the fourth partial column carries C_gg = sum diag_h g_h^2 (the Coleman-Li term of g_h^T (H + C) g_h).
+struct BoundArgs {
+  const double* lb;         // [ncp] or nullptr: no bounds, plain k_scale_lin
+  const double* ub;
+  const double* state_in;   // [ncp_pad] Jacobi scale of the camera block before this linearisation
+  double* state_out;        // [ncp_pad] ... after it
+  double* cam_diag_out;     // [ncp_pad]
+};
 template <int NC>
 __global__ void __launch_bounds__(BLOCK)
 k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk, const int* __restrict__ param_cam,
             const int* __restrict__ param_loc, VecLayout lay, int first, double* __restrict__ sinv, const double* __restrict__ cdiag,
             const double* __restrict__ x, const double* __restrict__ g, double* __restrict__ v1, double* __restrict__ partial,
-            double* __restrict__ partial_max, const double* __restrict__ sinv_in = nullptr) {
+            double* __restrict__ partial_max, const double* __restrict__ sinv_in = nullptr, BoundArgs bnd = BoundArgs{}) {
   // sinv_in != nullptr: the scale is read there and written to `sinv` (the speculative linearisation of a trial point leaves the current one alone)
   using UP = UPack<NC>;
   __shared__ double sh_red[BLOCK / WAVE];
   const long total = lay.total();
   const double* sin = sinv_in ? sinv_in : sinv;
-  double s0 = 0, s1 = 0, s2 = 0, m = 0;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0, m = 0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
     double si = sin[i];
     bool live = true;
     double v = 0.0;
+    if (bnd.lb && i < lay.ncp) {  // bounded camera entry: Jacobi scale from its own state, then the Coleman-Li factor
+      const int r = param_loc[i];
+      double sj = sqrt(Upacked[param_cam[i] * UP::STRIDE + UP::idx(r, r)]);
+      if (first) { if (sj == 0.0) sj = 1.0; } else sj = fmax(sj, bnd.state_in[i]);
+      bnd.state_out[i] = sj;
+      const double gi = g[i], xi = x[i], lo = bnd.lb[i], hi = bnd.ub[i];
+      double vv = 1.0, dv = 0.0;
+      if (gi < 0.0 && isfinite(hi)) { vv = hi - xi; dv = -1.0; }
+      else if (gi > 0.0 && isfinite(lo)) { vv = xi - lo; dv = 1.0; }
+      m = fmax(m, fabs(gi * vv));              // ||g v||_inf (trf.py:298)
+      if (dv != 0.0) vv *= sj;                 // v[dv != 0] *= scale_inv
+      const double se = sj / sqrt(vv);         // effective scale_inv = scale_inv / sqrt(v)
+      const double dh = gi * dv / sj;          // diag_h = g dv scale  (>= 0)
+      sinv[i] = se;
+      bnd.cam_diag_out[i] = dh * se * se;
+      const double gh = gi / se;
+      v1[i] = gh / se;
+      s0 += gh * gh;
+      s1 += (xi * se) * (xi * se);
+      s2 += xi * xi;
+      s3 += dh * gh * gh;
+      continue;
+    }
     if (i < lay.ncp_pad) {
       if (i >= lay.ncp) live = false;  // padding keeps scale 1
       else { const int r = param_loc[i]; v = Upacked[param_cam[i] * UP::STRIDE + UP::idx(r, r)]; }
@@ -2459,8 +2499,10 @@ k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
   r = block_sum(s0, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
   r = block_sum(s1, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
   r = block_sum(s2, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = r;
-  if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = 0.0;
+  r = block_sum(s3, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = r;  // C_gg (zero without bounds)
   r = block_max(m, sh_red); if (threadIdx.x == 0) partial_max[blockIdx.x] = r;
+  if (bnd.lb && blockIdx.x == 0)  // padding entries of the state carry over
+    for (int i = lay.ncp + threadIdx.x; i < lay.ncp_pad; i += BLOCK) { bnd.state_out[i] = 1.0; bnd.cam_diag_out[i] = 0.0; }
 }
 
 __device__ __forceinline__ double column_sum(const double* __restrict__ partial, int nrow, int width, int col, double* sh) {
@@ -2569,10 +2611,13 @@ __global__ void __launch_bounds__(BLOCK)
 k_step_cam(const double* __restrict__ partial, int rows, const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ sinv,
            const double* __restrict__ s, int ncp_pad, double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz,
            double* __restrict__ x_new, double* __restrict__ step_cam, double* __restrict__ tab_out, const double* __restrict__ cam_const,
-           const int* __restrict__ cam_model, const int* __restrict__ cam_np, const int* __restrict__ cam_off, int n_cams) {
+           const int* __restrict__ cam_model, const int* __restrict__ cam_np, const int* __restrict__ cam_off, int n_cams,
+           const double* __restrict__ lb = nullptr, const double* __restrict__ ub = nullptr, int ncp = 0) {
   extern __shared__ __attribute__((aligned(16))) double sh_xc[];  // [ncp_pad]
   __shared__ double sh_red[4][BLOCK / WAVE];
   __shared__ double sh_ab[3];
+  __shared__ int sh_outside;
+  if (threadIdx.x == 0) sh_outside = 0;
   double v[2] = {0.0, 0.0};
   for (int b = threadIdx.x; b < rows; b += BLOCK) { v[0] += partial[(long)b * 4 + 0]; v[1] += partial[(long)b * 4 + 1]; }
   for (int i = threadIdx.x; i < ncp_pad; i += BLOCK) {
@@ -2609,12 +2654,19 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
     x_new[i] = xn;
     sh_xc[i] = xn;
     s0 = fma(st, st, s0);
+    // bounded solve (trf.py:129-202, select_step): a trial point that is not STRICTLY inside the box goes back to the host, which chooses between the
+    // truncated step, its reflection and the scaled anti-gradient with the primitives — rare (the bounds of the reference are far from its solutions)
+    if (lb && i < ncp && !(xn > lb[i] && xn < ub[i])) sh_outside = 1;
   }
   {
     const double r = wave_sum(s0);
     if (lane == 0) sh_red[2][w] = r;
   }
   __syncthreads();
+  if (sh_outside) {
+    if (threadIdx.x == 0) scal[42] = 2.0;  // need_host (2: the step leaves the bounds); the build pass behind this kernel skips itself
+    return;
+  }
   if (threadIdx.x == 0) {
     double r = 0.0;
     for (int i = 0; i < BLOCK / WAVE; ++i) r += sh_red[2][i];

@@ -130,6 +130,11 @@ struct cba_problem {
   int* h_flags = nullptr;
   double* d_hscal = nullptr;
   double *h_cam = nullptr, *d_hcam = nullptr;  // pinned, mapped: camera blocks of up to three vectors + a sequence word
+  double *h_bcam = nullptr, *d_hbcam = nullptr;  // pinned, mapped: the four camera blocks a bounded fused iteration sends with its packet
+  // bounded fused iteration (cba_set_bounds): bounds of the camera block on the device, second copies of the Jacobi state and of the Coleman-Li
+  // diagonal for the speculative linearisation of the trial point
+  double *lb_dev = nullptr, *ub_dev = nullptr, *sinv_state_c2 = nullptr, *cam_diag2 = nullptr;
+  bool bounds_on = false;
   unsigned long long publish_seq = 0;
   bool spin_wait = true;  // CBA_SPIN=0: sleep in hipStreamSynchronize instead
   int* d_hflags = nullptr;
@@ -1036,7 +1041,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 
   {
     // one mapped host allocation for the three mailboxes: scalars (64 doubles), camera blocks (3 ncp + 8 doubles), flags (4 ints)
-    const size_t n_mail = 64 + ((size_t)3 * ncp + 8) + 2;
+    const size_t n_mail = 64 + ((size_t)3 * ncp + 8) + 2 + (size_t)4 * ncp;  // scalars | three camera blocks + sequence | flags | four camera blocks
     {
       std::lock_guard<std::mutex> lock(g_pool_mu);
       DevicePool& pool = g_pool[dev];
@@ -1050,14 +1055,15 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     }
     if (!p->stream) HIPBAIL(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     if (!p->h_scal) {
-      p->mail_doubles = std::max<size_t>(n_mail, 64 + 3 * 96 + 10);  // (room for 96 camera parameters: small rigs share mailboxes)
+      p->mail_doubles = std::max<size_t>(n_mail, 64 + 7 * 96 + 10);  // (room for 96 camera parameters: small rigs share mailboxes)
       HIPBAIL(hipHostMalloc((void**)&p->h_scal, p->mail_doubles * sizeof(double), hipHostMallocMapped));
     }
     HIPBAIL(hipHostGetDevicePointer((void**)&p->d_hscal, p->h_scal, 0));
     p->h_cam = p->h_scal + 64; p->d_hcam = p->d_hscal + 64;
     p->h_flags = reinterpret_cast<int*>(p->h_cam + ((size_t)3 * ncp + 8)); p->d_hflags = reinterpret_cast<int*>(p->d_hcam + ((size_t)3 * ncp + 8));
+    p->h_bcam = p->h_cam + ((size_t)3 * ncp + 8) + 2; p->d_hbcam = p->d_hcam + ((size_t)3 * ncp + 8) + 2;
   }
-  std::memset(p->h_scal, 0, (64 + ((size_t)3 * ncp + 8) + 2) * sizeof(double));
+  std::memset(p->h_scal, 0, (64 + ((size_t)3 * ncp + 8) + 2 + (size_t)4 * ncp) * sizeof(double));
 
   const int cus = n_cus > 0 ? n_cus : 256;
   p->cus = cus;
@@ -1175,7 +1181,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     TRY(dev_alloc(p, v, (size_t)tot));
     if (hipMemset(*v, 0, tot * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
-  for (double** v : {&p->sinv_state_c, &p->cam_diag, &p->cam_over1, &p->cam_over2}) {
+  for (double** v : {&p->sinv_state_c, &p->cam_diag, &p->cam_over1, &p->cam_over2, &p->lb_dev, &p->ub_dev, &p->sinv_state_c2, &p->cam_diag2}) {
     TRY(dev_alloc(p, v, (size_t)p->lay.ncp_pad));
     if (hipMemset(*v, 0, (size_t)p->lay.ncp_pad * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
@@ -1507,16 +1513,24 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
   p->spec_valid = false;
   const long tot = p->lay.total();
   const int vg = vec_grid(tot);
-  if (p->cam_scaled)  // the monotone-max rule of the Jacobi scale runs on the unmodified state of the camera block
+  const bool bnd = defer_finish && p->bounds_on;  // bounded fused iteration: the Coleman-Li scaling of the camera block happens inside k_scale_lin
+  // (cam_scaled: sinv holds the EFFECTIVE scale of the camera block and sinv_state_c its Jacobi state — after cba_set_camera_scaling and after a
+  // bounded fused linearisation alike, so the two routes can follow each other)
+  if (bnd && !p->first_scale && !p->cam_scaled)  // first bounded fused step after linearisations that never rescaled: sinv IS the state
+    HIPCHK(hipMemcpyAsync(p->sinv_state_c, p->sinv, (size_t)p->lay.ncp_pad * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  if (p->cam_scaled && !bnd)  // the monotone-max rule of the Jacobi scale runs on the unmodified state of the camera block
     HIPCHK(hipMemcpyAsync(p->sinv, p->sinv_state_c, (size_t)p->lay.ncp_pad * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   p->cam_state_saved = false;
   {
     ScopedTimer t(p, T_SCALE_SCALARS);
     if (compact) {
       // single-rank fused step: scale + scalars in one vector pass, the three reductions and the damping in one launch
+      // (bounded: the camera block's Jacobi state is read and written in place — sinv_state_c — and sinv takes the effective scale)
+      const BoundArgs ba = bnd ? BoundArgs{p->lb_dev, p->ub_dev, p->sinv_state_c, p->sinv_state_c, p->cam_diag} : BoundArgs{};
+      if (bnd) p->cam_scaled = true;
       hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc, p->lay,
                          p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr, p->x, p->g, p->v1,
-                         p->partial4b, p->partial1);
+                         p->partial4b, p->partial1, (const double*)nullptr, ba);
       p->first_scale = false;
       int rows_jv = 0;
       int rcj = run_jv<NC>(p, 1, &rows_jv);
@@ -1822,7 +1836,8 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     hipLaunchKernelGGL(k_step_cam, dim3(1), dim3(BLOCK), (size_t)p->lay.ncp_pad * sizeof(double), p->stream, (const double*)p->partial4, p->grid_backsub,
                        (const double*)p->x, (const double*)p->g, (const double*)p->sinv, (const double*)p->s, p->lay.ncp_pad, p->scal, (const int*)p->flags, p->fz,
                        p->x_new, p->partial4 + p->grid, p->tab_new, (const double*)p->cam_const, (const int*)p->cam_model, (const int*)p->cam_np,
-                       (const int*)p->cam_off, p->C);
+                       (const int*)p->cam_off, p->C, p->bounds_on ? (const double*)p->lb_dev : (const double*)nullptr,
+                       p->bounds_on ? (const double*)p->ub_dev : (const double*)nullptr, p->ncp);
     return CBA_OK;
   }
   return run_step_scalars(p, lam_dev != nullptr, compact);
@@ -1876,7 +1891,9 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
   // compact: the iteration's packet (scalars, trial cost rows -> slot 24, step-norm rows -> slot 28: one per workgroup of the trial build + the camera
   // block's from k_step_cam, or k_trial_update's) leaves with the launch that reduces the trial build's camera blocks
   const unsigned long long seq = compact ? ++p->publish_seq : 0;
-  const PubArgs pub{p->scal, 48, p->flags, p->d_hscal, p->d_hflags, seq, p->partial1, p->grid, 24, p->partial4, ft ? p->grid + 1 : vg, 28};
+  const bool bnd = compact && p->bounds_on;
+  const PubArgs pub{p->scal, 48, p->flags, p->d_hscal, p->d_hflags, seq, p->partial1, p->grid, 24, p->partial4, ft ? p->grid + 1 : vg, 28,
+                    {p->x, p->g, p->sinv_state_c, p->s}, bnd ? p->d_hbcam : (double*)nullptr, p->ncp};
   rc = run_build_into<NC>(p, p->x_new, p->tab_new, p->V2, p->g2, p->U2, 24, p->scal + 42, true, compact, 0, ft ? &tsrc : nullptr,
                           compact ? &pub : nullptr);  // (the build is skipped when need_host; the reduction and the packet are not)
   if (rc) return rc;
@@ -1888,8 +1905,9 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
   {
     {
       ScopedTimer t(p, T_SCALE_SCALARS);
+      const BoundArgs ba2 = bnd ? BoundArgs{p->lb_dev, p->ub_dev, p->sinv_state_c, p->sinv_state_c2, p->cam_diag2} : BoundArgs{};
       hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
-                         (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv);
+                         (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv, ba2);
       int rows_jv = 0;
       rc = run_jv<NC>(p, 1, &rows_jv, p->x_new, p->tab_new);
       p->spec_rows_jv = rows_jv;
@@ -1929,7 +1947,7 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
   read_linearization(p, &out->lin);
   read_newton(p, &out->newton);
   out->lam = p->h_scal[40]; out->radius = p->h_scal[41];
-  out->need_host = p->h_scal[42] != 0.0 ? 1 : 0;
+  out->need_host = (int)p->h_scal[42];  // 0; 1: failed factorisation / collinear step; 2: a bounded trial point that is not strictly inside its box
   out->p_s[0] = p->h_scal[43]; out->p_s[1] = p->h_scal[44]; out->predicted = p->h_scal[45];
   out->alpha = p->h_scal[46]; out->beta = p->h_scal[47];
   const double c = 0.5 * p->h_scal[24];
@@ -2147,6 +2165,29 @@ int cba_step(cba_problem* p, double radius, cba_step_info* out) {
   return CBA_OK;
 }
 
+int cba_set_bounds(cba_problem* p, const double* lb, const double* ub) {
+  if (!p) return fail(CBA_ERR_INVALID, "cba_set_bounds: null argument");
+  if (!lb || !ub) { p->bounds_on = false; return 0; }
+  // the fused bounded iteration exists for the single-rank route over camera-sorted super-chunks (what every handle without constraint rows, heavy
+  // points or fixed-order sums runs); everything else keeps scipy's bounded loop on the primitives
+  if (p->eval_only || p->sharded() || !fused_trial(p, true)) { p->bounds_on = false; return 0; }
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipMemcpyAsync(p->lb_dev, lb, (size_t)p->ncp * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipMemcpyAsync(p->ub_dev, ub, (size_t)p->ncp * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));  // (the caller's arrays may go away)
+  p->bounds_on = true;
+  return 1;
+}
+
+int cba_step_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale_inv_c, double* step_c) {
+  if (!p || !x_c || !g_c || !scale_inv_c || !step_c) return fail(CBA_ERR_INVALID, "cba_step_camera_state: null argument");
+  if (!p->bounds_on || !p->stepped) return fail(CBA_ERR_INVALID, "cba_step_camera_state: no bounded cba_step to report on");
+  const size_t n = (size_t)p->ncp;
+  std::memcpy(x_c, p->h_bcam, n * sizeof(double)); std::memcpy(g_c, p->h_bcam + n, n * sizeof(double));
+  std::memcpy(scale_inv_c, p->h_bcam + 2 * n, n * sizeof(double)); std::memcpy(step_c, p->h_bcam + 3 * n, n * sizeof(double));
+  return CBA_OK;
+}
+
 int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: null argument");
   if (!p->stepped) return fail(CBA_ERR_INVALID, "cba_refresh_step_scalars: no damped step to measure");
@@ -2161,7 +2202,7 @@ int cba_refresh_step_scalars(cba_problem* p, cba_newton_info* out) {
 }
 
 int cba_step_supported(cba_problem* p) {
-  return (p && !p->eval_only && !p->con.n_con && !p->n_heavy && !p->cam_scaled && !p->peer_needs_primitives) ? 1 : 0;
+  return (p && !p->eval_only && !p->con.n_con && !p->n_heavy && (!p->cam_scaled || (p->bounds_on && !p->sharded())) && !p->peer_needs_primitives) ? 1 : 0;
 }
 
 // camera-block override of a device vector: `host` [ncp] -> dev [ncp_pad] (padding stays zero)
@@ -2283,7 +2324,10 @@ int cba_accept(cba_problem* p) {
   if (p->trial_built) {  // the trial point came with its own build (cba_step): it becomes the linearisation point as it is
     std::swap(p->V, p->V2); std::swap(p->g, p->g2); std::swap(p->Upacked, p->U2);
     p->cost_x = p->trial_cost;
-    if (p->spec_enqueued) { std::swap(p->sinv, p->sinv2); p->spec_valid = true; }  // ... and so does its speculative linearisation
+    if (p->spec_enqueued) {  // ... and so does its speculative linearisation
+      std::swap(p->sinv, p->sinv2); p->spec_valid = true;
+      if (p->bounds_on) { std::swap(p->sinv_state_c, p->sinv_state_c2); std::swap(p->cam_diag, p->cam_diag2); }
+    }
   }
   p->spec_enqueued = false;
   p->have_build = p->trial_built;

@@ -155,8 +155,19 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
   // Fused iterations (cba_step): linearisation, damping, damped step, subspace step and first trial behind ONE host
   // synchronisation; the trial is evaluated by a build pass, so an accepted step needs no further pass.  A rejected
   // first trial costs a build instead of a cost pass: after one, the next iteration goes through the primitives.
-  const bool fused = !bounded && cba_step_supported(p);
+  // Bounded solves (round 5): cba_set_bounds hands the box to the device; where the engine can, cba_step then runs the bounded iteration behind
+  // one synchronisation too (Coleman-Li scaling on the device; a first trial point that leaves the box comes back as need_host = 2).
+  bool bounds_on_device = false;
+  if (bounded) {
+    const int rb = cba_set_bounds(p, cb.lb, cb.ub);
+    if (rb < 0) return rb;
+    bounds_on_device = rb == 1;
+  } else {
+    (void)cba_set_bounds(p, nullptr, nullptr);
+  }
+  bool fused = (!bounded || bounds_on_device) && cba_step_supported(p);
   bool fuse_next = fused;
+  int n_outside = 0;  // bounded fused steps whose first trial point left the box
   cba_linearization lin;
   cba_step_info si;
   bool lin_valid = false;    // `lin` describes the current x
@@ -173,6 +184,8 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         if ((rc = calls.run("step", [&] { return cba_step(p, std::isnan(radius) ? -1.0 : radius, &si); }))) return rc;
         lin = si.lin; have_step = true;
       } else if (bounded) {
+        fuse_next = false;  // (a bounded solve that has left the fused route stays on the primitives: the two keep the same scaling state, but
+                            // the iteration that sent it here — a trial on a bound — tends to repeat)
         if ((rc = calls.run("linearize_build", [&] { return cba_linearize_build(p); }))) return rc;  // the scalars follow from cba_set_camera_scaling below
       } else if ((rc = calls.run("linearize", [&] { return cba_linearize(p, &lin); }))) return rc;
       lin_valid = true;
@@ -181,9 +194,18 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         if (!std::isfinite(cost)) return not_finite_at_x0(cost);
       }
     }
+    if (bounded && have_step && si.need_host == 2) {
+      // the fused step's first trial point was not strictly inside the box: this iteration again, through the primitives (select_step).  A solve
+      // whose solution lies ON a bound would pay a wasted Schur pass per iteration: after the second time it stays on the primitives
+      lin_valid = false; fuse_next = false;
+      if (++n_outside >= 2) fused = false;
+      continue;
+    }
     if (bounded) {
       // Coleman-Li scaling vector of the camera block (common.py CL_scaling_vector) and what follows from it
-      if ((rc = calls.run("get_camera_state", [&] { return cba_get_camera_state(p, cb.x.data(), cb.g.data(), cb.sinv.data()); }))) return rc;  // sinv: the Jacobi scale (restored by the linearisation)
+      if (have_step) {  // the camera blocks came with the step's packet: x, g, the Jacobi scale, the damped step
+        if ((rc = cba_step_camera_state(p, cb.x.data(), cb.g.data(), cb.sinv.data(), cb.s.data()))) return rc;
+      } else if ((rc = calls.run("get_camera_state", [&] { return cba_get_camera_state(p, cb.x.data(), cb.g.data(), cb.sinv.data()); }))) return rc;  // sinv: the Jacobi scale (restored by the linearisation)
       double gv_max = 0.0;
       for (int i = 0; i < ncp; ++i) {
         double v = 1.0, dv = 0.0;
@@ -197,8 +219,8 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         cb.gh[i] = cb.g[i] * cb.d[i];
         C_gg += cb.diag_h[i] * cb.gh[i] * cb.gh[i];
       }
-      if ((rc = calls.run("set_camera_scaling", [&] { return cba_set_camera_scaling(p, cb.mult.data(), cb.diag_h.data(), &lin); }))) return rc;
-      g_norm = std::max(gv_max, lin.g_norm_inf);               // ||g * v||_inf: lin.g_norm_inf covers the point block (v = 1)
+      if (!have_step && (rc = calls.run("set_camera_scaling", [&] { return cba_set_camera_scaling(p, cb.mult.data(), cb.diag_h.data(), &lin); }))) return rc;
+      g_norm = std::max(gv_max, lin.g_norm_inf);               // ||g * v||_inf: lin.g_norm_inf covers the point block (v = 1; a fused step: both)
     } else {
       g_norm = lin.g_norm_inf;
     }
@@ -231,7 +253,7 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if ((rc = calls.run("newton_step", [&] { return cba_newton_step(p, lam, &st); }))) return rc;
       if (calls.on) std::fprintf(stderr, "    retry %d: lam %.3e ok %d\n", retries, lam, st.ok);
     }
-    if (bounded && (rc = calls.run("get_camera_params", [&] { return cba_get_camera_params(p, CBA_VEC_STEP, cb.s.data()); }))) return rc;
+    if (bounded && !have_step && (rc = calls.run("get_camera_params", [&] { return cba_get_camera_params(p, CBA_VEC_STEP, cb.s.data()); }))) return rc;
     // orthonormal basis of span{g_h, p}: q1 = g_h / ||g_h||, q2 = w / ||w||, w = p - c g_h
     const double c = st.gh_dot_p / gh_sq, w_sq = st.w_sq;
     const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * st.p_sq;

@@ -182,7 +182,7 @@ typedef struct {
   double lam, radius;        /* damping used, radius used                                          */
   double p_s[2], predicted;  /* subspace step in the basis (g_h / |g_h|, w / |w|), model decrease  */
   double alpha, beta;        /* trial step = alpha * g / scale_inv^2 + beta * s                    */
-  int32_t need_host, reserved;
+  int32_t need_host, reserved; /* need_host 1: failed factorisation / collinear step; 2: bounded trial point outside its box */
 } cba_step_info;
 int cba_step(cba_problem* p, double radius, cba_step_info* out);
 /* p_sq, gh_dot_p and w_sq of the current damped step measured again, w_sq by a pass of its own: cba_step derives w_sq
@@ -204,6 +204,18 @@ int cba_step_supported(cba_problem* p);
  * block in with its v).  Call after every cba_linearize of a bounded solve; the Jacobi scale's monotone-max state is
  * kept apart and is not disturbed. */
 int cba_set_camera_scaling(cba_problem* p, const double* mult, const double* diag_h, cba_linearization* out);
+
+/* The same loop with ONE host synchronisation per iteration (round 5): hand the bounds of the camera block (lb, ub [n_cam_params]; +-inf where a
+ * parameter is free) to the device once per solve; cba_step then computes the Coleman-Li scaling itself from x, g and the Jacobi scale (what
+ * cba_get_camera_state + the loop of trf.py:283-296 + cba_set_camera_scaling do in three round trips), forms the damped step with C = diag_h in the
+ * model, and evaluates the first trial point IF it lies strictly inside the box; a trial point on or beyond a bound comes back as need_host = 2 and the
+ * caller runs this iteration through the primitives (select_step of trf.py:129-202: truncated step, reflection, scaled anti-gradient).
+ * Returns 1 when bounded cba_step iterations are available on this handle, 0 when not (sharded solves, constraint rows, heavy points, fixed-order
+ * sums: use the primitives), < 0 on error.  lb == NULL switches it off.  In a bounded cba_step, lin.g_norm_inf is ||g v||_inf (trf.py:298).
+ * cba_step_camera_state: the camera blocks of x, g, the JACOBI scale (before the Coleman-Li factor) and the damped step of the last bounded cba_step,
+ * each [n_cam_params] — they travelled with the step's packet, no synchronisation: what the caller needs for the later trials of the iteration. */
+int cba_set_bounds(cba_problem* p, const double* lb, const double* ub);
+int cba_step_camera_state(cba_problem* p, double* x_c, double* g_c, double* scale_inv_c, double* step_c);
 
 /* cba_linearize without the scalars: build pass and Jacobi scale only, no host synchronisation.  For bounded solves,
  * which rescale the camera block before any scaled quantity is meaningful: cba_linearize_build, read the camera parts

@@ -201,7 +201,8 @@ int cba_set_loss(cba_problem* p, int32_t loss, double f_scale) {
   return CBA_OK;
 }
 
-int64_t cba_trim(void) { return 0; }  // (the dense test build keeps nothing between handles)
+int64_t cba_trim(void) { return 0; }
+// (cba_set_bounds / cba_step_camera_state: dense_engine.cpp — the dense test build has no fused bounded iteration)  // (the dense test build keeps nothing between handles)
 
 int cba_get_info(cba_problem* p, cba_info* out) {
   std::memset(out, 0, sizeof(*out));

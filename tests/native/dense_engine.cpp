@@ -299,6 +299,9 @@ int cba_trial(cba_problem* p, double alpha, double beta, cba_trial_info* out) { 
 
 // the fused iteration of the device engine, emulated with the primitives above and the same scalar code (trf_math.h)
 int cba_step_supported(cba_problem* p) { return p->cam_scaled ? 0 : 1; }
+// no fused bounded iteration in the dense test double: cba_solve keeps scipy's bounded loop on the primitives (the route these tests pin)
+int cba_set_bounds(cba_problem*, const double*, const double*) { return 0; }
+int cba_step_camera_state(cba_problem*, double*, double*, double*, double*) { g_err = "cba_step_camera_state: not available in the dense test build"; return CBA_ERR_UNSUPPORTED; }
 int cba_step(cba_problem* p, double radius_in, cba_step_info* out) {
   std::memset(out, 0, sizeof(*out));
   int rc = cba_linearize(p, &out->lin);
