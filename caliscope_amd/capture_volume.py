@@ -136,7 +136,7 @@ class CaptureVolume:
                 i[0] = np.where(np.isin(i[1], list(static_ids)), STATIC_SYNC_INDEX, i[0])
             lo = [min(int(a.min()), int(b.min())) for a, b in zip(w, i)]
             span = [max(int(a.max()), int(b.max())) - l + 1 for a, b, l in zip(w, i, lo)]
-            if span[0] * span[1] * span[2] <= max(1 << 22, 16 * len(wdf)) and span[0] * span[1] * span[2] <= 1 << 27:
+            if span[0] * span[1] * span[2] <= max(1 << 22, 16 * len(wdf)) and span[0] * span[1] * span[2] <= 1 << 25:  # (128 MB of int32 at most; wider key ranges take the merge)
                 fold = lambda k: ((k[0] - lo[0]) * span[1] + (k[1] - lo[1])) * span[2] + (k[2] - lo[2])  # noqa: E731
                 table = np.full(span[0] * span[1] * span[2], -1, dtype=np.int32)
                 table[fold(w)] = np.arange(len(wdf), dtype=np.int32)  # (a repeated key keeps the last row written: numpy assigns in order)
@@ -394,13 +394,15 @@ class CaptureVolume:
         all_df = self.image_points._df
         # columns as arrays: a boolean-indexed DataFrame copy of 2M rows costs more than everything else in this function
         everything = n_matched == n_total  # (the usual case after triangulation and filtering: nothing to select)
-        col = {c: (all_df[c].to_numpy() if everything else all_df[c].to_numpy()[mask]) for c in ("sync_index", "cam_id", "object_id", "keypoint_id")}
+        # (everything: to_numpy() hands out VIEWS of the ImagePoints table — copied, or writing to report.raw_errors would write through into the
+        # table and the cached matched arrays)
+        col = {c: (all_df[c].to_numpy().copy() if everything else all_df[c].to_numpy()[mask]) for c in ("sync_index", "cam_id", "object_id", "keypoint_id")}
         raw = pd.DataFrame(
             {
                 "sync_index": col["sync_index"], "cam_id": col["cam_id"], "object_id": col["object_id"], "keypoint_id": col["keypoint_id"],
                 "error_x": err[:, 0], "error_y": err[:, 1], "euclidean_error": np.sqrt(sq),
             },
-            copy=False,  # (the arrays are fresh: no need to copy them into consolidated blocks)
+            copy=False,  # (the arrays are this function's own: no need to copy them into consolidated blocks)
         )
         index_of = self.camera_array.posed_cam_id_to_index
         n_cam = len(index_of)

@@ -1004,7 +1004,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     if (hps[q + 1] - hps[q] > HEAVY_OBS) { heavy.push_back(q); heavy_frag.push_back(hps[q + 1] - hps[q] > CHUNK ? 1 : 0); }
   if ((long)heavy.size() > std::max<long>(64, p->P / 64)) {
     // not a few static points but a dense problem (every point seen by > HEAVY_OBS cameras): the per-point workgroup of
-    // k_heavy_schur is the wrong tool; keep the pair plan (LDS-tile fallback beyond PAIRCAP pairs per point)
+    // k_heavy_schur is the wrong tool; keep the pair plan (a point with more observations in one tile than a chunk holds is refused below)
     if (maxk > CHUNK) return bail(fail(CBA_ERR_UNSUPPORTED, "%zu world points have more than %d observations (one has %d); at most %ld such points are supported",
                                        heavy.size(), HEAVY_OBS, maxk, std::max<long>(64, p->P / 64)));
     heavy.clear(); heavy_frag.clear();
@@ -2154,7 +2154,7 @@ int cba_newton_step(cba_problem* p, double lam, cba_newton_info* out) {
 int cba_step(cba_problem* p, double radius, cba_step_info* out) {
   if (!p || !out) return fail(CBA_ERR_INVALID, "cba_step: null argument");
   if (!p->begun) return fail(CBA_ERR_INVALID, "cba_step: call cba_begin first");
-  if (!cba_step_supported(p)) return fail(CBA_ERR_UNSUPPORTED, "cba_step: not available for this problem (constraint rows, heavy points, bound scaling or the LDS Schur path): use the primitives");
+  if (!cba_step_supported(p)) return fail(CBA_ERR_UNSUPPORTED, "cba_step: not available for this problem (constraint rows, heavy points, or bound scaling without cba_set_bounds): use the primitives");
   HIPCHK(hipSetDevice(p->device));
   int rc = DISPATCH_NC(p, run_step<6>(p, radius, out), run_step<9>(p, radius, out));
   if (rc) return rc;
@@ -2366,7 +2366,7 @@ int cba_comm_init(cba_problem* p, const char* id128, int32_t rank, int32_t world
     p->comm.store(c);
   }
   // cba_step issues one collective more than the primitives (the camera blocks of the trial build): every rank must
-  // take the same route.  A rank whose shard needs the primitives (constraint rows, heavy points, LDS Schur path)
+  // take the same route.  A rank whose shard needs the primitives (constraint rows, heavy points)
   // switches the fused route off for all of them.
   {
     const double mine = cba_step_supported(p) ? 0.0 : 1.0;
@@ -2554,7 +2554,7 @@ int cba_residuals(cba_problem* p, const double* x, double* r_out, double* cost_o
   double* d_r = nullptr;
   const size_t n_rows = (size_t)2 * p->N + (size_t)p->con.n_con;  // reprojection rows, then the constraint rows
   HIPCHK(hipMalloc((void**)&d_r, n_rows * sizeof(double)));
-  { const int rcw = stage_wait(p); if (rcw) return rcw; }
+  { const int rcw = stage_wait(p); if (rcw) { (void)hipFree(d_r); return rcw; } }
   pack_host(p, x, p->h_vec, 0.0);
   p->have_trial = false; p->trial_built = false;  // the evaluation borrows the trial point's camera table: a pending trial is gone
   hipError_t e = hipMemcpyAsync(p->v2, p->h_vec, p->lay.total() * sizeof(double), hipMemcpyHostToDevice, p->stream);

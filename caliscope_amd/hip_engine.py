@@ -85,13 +85,19 @@ class HipEngine:
         # close() and comm_abort() exclude each other: a peer thread's abort (solve_multi_device, a failing rank) must never reach a handle that is
         # being destroyed.  The handle is taken out of the object BEFORE cba_destroy runs (ctypes releases the GIL inside it), so an abort that
         # waited for the lock finds nothing to abort.
+        # cba_destroy synchronises the handle's stream: with a collective still enqueued and a dead peer it would wait for ever while holding the lock the
+        # peer's comm_abort() needs.  So: the handle leaves the object under the lock, an abort that was REQUESTED meanwhile
+        # (comm_abort's non-blocking path) is carried out here, on this thread, and only then the handle is destroyed — outside the lock.
         lock = getattr(self, "_life", None)
         if lock is None:
             return
         with lock:
             h, self._h = getattr(self, "_h", None), None
-            if h is not None:
-                self.lib.cba_destroy(h)
+            abort_first = getattr(self, "_abort_requested", False)
+        if h is not None:
+            if abort_first:
+                self.lib.cba_comm_abort(h)
+            self.lib.cba_destroy(h)
 
     def __del__(self):
         try:
@@ -229,9 +235,14 @@ class HipEngine:
     def comm_abort(self) -> None:
         """``ncclCommAbort`` on this handle's communicator — from ANOTHER thread, when a peer rank failed: a collective this rank is
         blocked in returns an error instead of waiting for ever.  The handle is only good for ``close()`` afterwards."""
-        with self._life:  # not while close() destroys the handle, and not after it
+        self._abort_requested = True  # (a close() that has already taken the handle out honours it before it destroys)
+        if not self._life.acquire(blocking=False):
+            return  # close() is at work: it aborts on our behalf
+        try:
             if self._h:
                 self.lib.cba_comm_abort(self._h)
+        finally:
+            self._life.release()
 
     def group_join(self, group: "DeviceGroup", rank: int) -> None:
         """Join an in-process device group (one host thread per member; returns when all have joined)."""

@@ -174,7 +174,7 @@ int cba_accept(cba_problem* p);
  * need_host = 1: the factorisation failed or the step is nearly collinear with the gradient (explicit J.v model): no
  * trial was made, continue with the primitives (cba_newton_step / cba_subspace_gram / cba_trial) for this iteration.
  * A rejected first trial is retried with cba_trial as usual.  Not available (cba_step_supported() == 0) with constraint
- * rows, heavy points, after cba_set_camera_scaling, or on the LDS-tile Schur path. */
+ * rows, heavy points, or after cba_set_camera_scaling on a handle without cba_set_bounds. */
 typedef struct {
   cba_linearization lin;
   cba_newton_info newton;

@@ -681,6 +681,32 @@ def test_solution_on_an_intrinsic_bound_matches_scipy():
     assert pos < 1e-6 and ang < 1e-6, (pos, ang)
 
 
+def test_bounded_fused_iterations_follow_the_primitive_route(monkeypatch):
+    """Round 5: with finite bounds cba_solve runs its iterations through cba_step as well (cba_set_bounds: Coleman-Li scaling on the device, one host
+    synchronisation per iteration).  The same solve on a handle that cannot fuse (CBA_BUILD_CS=0: the point-ordered build; cba_set_bounds answers 0, the
+    driver keeps scipy's bounded loop on the primitives — the route rounds 2-4 ran and compared with scipy) must take the same evaluations to the same
+    cost and solution: nothing but the number of host round trips differs."""
+    from caliscope_amd import _lib
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0 = small_problem(n_cams=12, n_points=600, k=6, refine=True)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    ncp = par.n_camera_params
+    lb, ub = par.bounds()
+    kw = dict(lb=np.ascontiguousarray(lb[:ncp]), ub=np.ascontiguousarray(ub[:ncp]), ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)
+    with HipEngine(prob) as eng:
+        assert eng.lib.cba_set_bounds(eng._h, kw["lb"].ctypes.data_as(_lib.c_double_p), kw["ub"].ctypes.data_as(_lib.c_double_p)) == 1
+        fused = eng.solve(x0, **kw)
+    monkeypatch.setenv("CBA_BUILD_CS", "0")
+    with HipEngine(prob) as eng:
+        assert eng.lib.cba_set_bounds(eng._h, kw["lb"].ctypes.data_as(_lib.c_double_p), kw["ub"].ctypes.data_as(_lib.c_double_p)) == 0
+        prim = eng.solve(x0, **kw)
+    assert fused.status > 0 and prim.status > 0 and abs(fused.nfev - prim.nfev) <= 1, (fused.nfev, prim.nfev)
+    assert abs(fused.cost - prim.cost) <= 1e-11 * prim.cost
+    assert np.max(np.abs(fused.x - prim.x)) <= 1e-8 * np.max(np.abs(prim.x))
+    assert np.all(fused.x[:ncp] > lb[:ncp]) and np.all(fused.x[:ncp] < ub[:ncp])
+
+
 @pytest.mark.parametrize("refine", [False, True])
 def test_non_finite_start_raises_like_scipy(refine):
     """scipy: ValueError("Residuals are not finite in the initial point.").  Without bounds the driver leaves the evaluation
