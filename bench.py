@@ -150,8 +150,9 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
     if par.has_finite_bounds:  # free intrinsics: the bounds of BundleParameterization.bounds(), as CaptureVolume.optimize passes them
         lb, ub = par.bounds()
         solve_kw.update(lb=np.ascontiguousarray(lb[: par.n_camera_params]), ub=np.ascontiguousarray(ub[: par.n_camera_params]))
+    deterministic = os.environ.get("CBA_DETERMINISTIC", "0") not in ("", "0")  # (as the seam reads it: fixed-order sums, bit-identical runs)
     t_setup = time.perf_counter()
-    eng = HipEngine(prob, device_id=device_id)  # sort, Schur plan, upload, graph capture: paid once per problem structure, NOT part of `value`
+    eng = HipEngine(prob, device_id=device_id, deterministic=deterministic)  # sort, Schur plan, upload: paid once per problem structure, NOT part of `value`
     t_setup = time.perf_counter() - t_setup
     if on_engine is not None:
         on_engine(eng)  # (in-process ranks: a failing peer aborts this rank's communicator instead of leaving it in a collective)
@@ -240,7 +241,7 @@ def measure(name, steps, warmup, device_id=0, timers=True, seed=42, solve_kw=Non
         "solves": solves, "timers": tm, "final_rms_px": rms, "initial_rms_px": rms0, "full_nfev": full.nfev,
         "full_status": full.status, "full_cost": full.cost, "info": info, "t_generate_s": t_gen,
         "scene": sc, "par": par, "x0": x0, "x_full": full.x, "setup_s": t_setup, "setup_warm_s": t_setup_warm, "plan_wait_s": t_plan, "rank": control.rank, "mix": last.mix,
-        "two_stage": two_stage, "first_call": first_call, "count": count,
+        "two_stage": two_stage, "first_call": first_call, "count": count, "deterministic": deterministic,
     }
 
 
@@ -258,6 +259,31 @@ def pmc_traffic(workload, family):
     rows = json.loads(path.read_text())
     found = [row["hbm_bytes"] for name, row in rows.items() if name.startswith(PMC_KERNEL[family])]
     return round(sum(found)) if found else None
+
+
+# The roof that actually binds (SURVEY.md 8d caveat): FP64 VALU issue.  A wave-level VALU instruction holds its SIMD's vector
+# pipe for four clocks (64 lanes, 16 per clock); MI355X has 256 CUs x 4 SIMDs at 2.4 GHz.  profiles/sq_<workload>.json holds SQ_INSTS_VALU per launch of
+# the dominant kernels (rocprofv3 --pmc, tools/gpu_profile_run.sh -> tools/sq_valu_floor.py); launches per ACCEPTED iteration below.
+N_SIMD, SHADER_GHZ = 1024, 2.4
+
+
+def valu_floor(workload, ncp, rows=None):
+    """{kernel: issue-bound microseconds per accepted iteration} and their sum from the committed SQ counters; None if absent."""
+    if rows is None:
+        path = ROOT / "profiles" / f"sq_{workload}.json"
+        if not path.exists():
+            return None
+        rows = json.loads(path.read_text())
+    per_iter = {"k_tprep": 1, "k_schur_reg3": 1, "k_build_cs": 1, "k_jv": 1, "k_backsub": 1, "k_chol_step": (ncp + 31) // 32 + 1}
+    out = {}
+    for name, row in rows.items():
+        for prefix, n in per_iter.items():
+            if name.startswith(prefix) and "SQ_INSTS_VALU" in row:
+                out[prefix] = out.get(prefix, 0.0) + row["SQ_INSTS_VALU"] * 4.0 / N_SIMD / (SHADER_GHZ * 1e3) * n
+    if not out:
+        return None
+    return {"per_kernel_us": {k: round(v, 1) for k, v in out.items()}, "iteration_us": round(sum(out.values()), 1),
+            "how": "SQ_INSTS_VALU per launch x 4 clocks / 1024 SIMDs / 2.4 GHz x launches per accepted iteration (profiles/sq_*.json)"}
 
 
 def roofline_from(m):
@@ -289,8 +315,14 @@ def roofline_from(m):
                                      "frac": round(fl / t / 1e12 / 78.6, 4)})(
             int(m["info"]["schur_pairs"]) * 6 * m["nct"] ** 2, tm["schur"][0] / tm["schur"][1] * 1e-3) if "schur" in tm and tm["schur"][1] else None,
         # B_alg = 72 N + 312 P + 8 (nc C)^2 bytes per accepted LM iteration, over the measured step time
-        "iteration": (lambda b, t: {"alg_bytes": b, "GBps": round(b / t / 1e9, 1), "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4)})(
-            72 * m["n_obs"] + 312 * m["n_points"] + 8 * m["ncp"] ** 2, m["elapsed"] / max(m["steps"], 1)),
+        "iteration": (lambda b, t, vf: {"alg_bytes": b, "GBps": round(b / t / 1e9, 1), "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4),
+                                        # the two floors of one accepted iteration next to its measured time: HBM (algorithmic bytes at 8 TB/s) and FP64
+                                        # VALU issue (the roof that binds: SURVEY.md 8d caveat); frac_of_valu_floor = floor / measured
+                                        "measured_us": round(t * 1e6, 1), "hbm_floor_us": round(b / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+                                        "valu_floor_us": vf["iteration_us"] if vf else None, "valu_floor": vf,
+                                        "frac_of_valu_floor": round(vf["iteration_us"] / (t * 1e6), 3) if vf else None,
+                                        "binding_roof": "fp64 valu issue" if vf and vf["iteration_us"] > b / (HBM_PEAK_GBS * 1e9) * 1e6 else "hbm"})(
+            72 * m["n_obs"] + 312 * m["n_points"] + 8 * m["ncp"] ** 2, m["elapsed"] / max(m["steps"], 1), valu_floor(m["name"], m["ncp"])),
     }
 
 
@@ -816,6 +848,7 @@ def _run(argv):
             "parallelism": f"points sharded x{world} ({args.scaling if world > 1 else 'single GPU'}); all-reduce of camera blocks + reduced camera system per iteration; {route}"
                            + (f"; obs per rank {obs_per_rank}" if world > 1 else ""),
             "tolerances": "ftol=xtol=gtol=1e-8 (reference defaults)", "solves_in_timed_region": m["solves"],
+            "sums": "fixed order (CBA_DETERMINISTIC=1: bit-identical from run to run)" if m.get("deterministic") else "FP64 atomics (default)",
         },
         "rccl_ranks": world if exchange_backend == "rccl" else 0,
         # device time of the all-reduces per step (HIP events around every exchange on rank 0's stream, instrumented repeat); None on one GPU

@@ -703,7 +703,11 @@ def test_bounded_fused_iterations_follow_the_primitive_route(monkeypatch):
         prim = eng.solve(x0, **kw)
     assert fused.status > 0 and prim.status > 0 and abs(fused.nfev - prim.nfev) <= 1, (fused.nfev, prim.nfev)
     assert abs(fused.cost - prim.cost) <= 1e-11 * prim.cost
-    assert np.max(np.abs(fused.x - prim.x)) <= 1e-8 * np.max(np.abs(prim.x))
+    # (the two handles sum in different orders — camera-sorted against point-ordered build — and bundle adjustment leaves a 7-parameter gauge free:
+    # the raw vectors differ by 4e-7 along it; compared after alignment, and the gauge-free intrinsics directly)
+    pos, ang, _ = aligned_difference(par, fused.x, prim.x)
+    assert pos < 1e-7 and ang < 1e-7, (pos, ang)
+    assert np.abs(fused.x[:ncp].reshape(-1, 9)[:, 6:] - prim.x[:ncp].reshape(-1, 9)[:, 6:]).max() < 1e-7
     assert np.all(fused.x[:ncp] > lb[:ncp]) and np.all(fused.x[:ncp] < ub[:ncp])
 
 
