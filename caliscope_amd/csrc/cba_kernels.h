@@ -417,7 +417,7 @@ k_build(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
 #pragma unroll
       for (int k = 0; k < MAX_NC; ++k) { A[0][k] = 0.0; A[1][k] = 0.0; }
       sh_perm[threadIdx.x] = det.perm[(long)ch * CHUNK + threadIdx.x];
-      if ((int)threadIdx.x <= n_cams) sh_cs[threadIdx.x] = det.cstart[(long)ch * (n_cams + 1) + threadIdx.x];
+      for (int q = threadIdx.x; q <= n_cams; q += BLOCK) sh_cs[q] = det.cstart[(long)ch * (n_cams + 1) + q];
     }
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
@@ -1018,7 +1018,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     for (int q = 0; q < DET_ROUND; ++q) bval[q] = 0.0;
     if (DET) {
       sh_perm[threadIdx.x] = det.perm[(long)ch * CHUNK + threadIdx.x];
-      if ((int)threadIdx.x <= n_cams) sh_cs[threadIdx.x] = det.cstart[(long)ch * (n_cams + 1) + threadIdx.x];
+      for (int q = threadIdx.x; q <= n_cams; q += BLOCK) sh_cs[q] = det.cstart[(long)ch * (n_cams + 1) + q];
     }
     if (i < o1) {
       const int cam = cur.cam, pt = cur.pt;
@@ -2428,7 +2428,7 @@ struct BoundArgs {
   double* state_out;        // [ncp_pad] ... after it
   double* cam_diag_out;     // [ncp_pad]
 };
-template <int NC>
+template <int NC, bool BND = false>  // BND: the bounded variant (a kernel of its own: the plain pass measured 8.7 us without the branch, 10.0 with it)
 __global__ void __launch_bounds__(BLOCK)
 k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk, const int* __restrict__ param_cam,
             const int* __restrict__ param_loc, VecLayout lay, int first, double* __restrict__ sinv, const double* __restrict__ cdiag,
@@ -2444,7 +2444,7 @@ k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
     double si = sin[i];
     bool live = true;
     double v = 0.0;
-    if (bnd.lb && i < lay.ncp) {  // bounded camera entry: Jacobi scale from its own state, then the Coleman-Li factor
+    if (BND && i < lay.ncp) {  // bounded camera entry: Jacobi scale from its own state, then the Coleman-Li factor
       const int r = param_loc[i];
       double sj = sqrt(Upacked[param_cam[i] * UP::STRIDE + UP::idx(r, r)]);
       if (first) { if (sj == 0.0) sj = 1.0; } else sj = fmax(sj, bnd.state_in[i]);
@@ -2501,7 +2501,7 @@ k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
   r = block_sum(s2, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = r;
   r = block_sum(s3, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = r;  // C_gg (zero without bounds)
   r = block_max(m, sh_red); if (threadIdx.x == 0) partial_max[blockIdx.x] = r;
-  if (bnd.lb && blockIdx.x == 0)  // padding entries of the state carry over
+  if (BND && blockIdx.x == 0)  // padding entries of the state carry over
     for (int i = lay.ncp + threadIdx.x; i < lay.ncp_pad; i += BLOCK) { bnd.state_out[i] = 1.0; bnd.cam_diag_out[i] = 0.0; }
 }
 

@@ -102,7 +102,7 @@ struct cba_problem {
   double *Sacc = nullptr, *S = nullptr, *Lbuf = nullptr, *rhs = nullptr, *red = nullptr, *Trec = nullptr, *partial_b = nullptr;
   CsPlan cs{};              // camera-sorted super-chunks of the build pass (k_build_cs); cs.n_sc == 0: k_build (CBA_BUILD_CS=0, deterministic sums, fragments)
   bool tab_global = false;  // the per-observation kernels read the camera table from global memory (CAMG variants): its LDS copy would not fit
-  int det_m = 0;  // cba_options.deterministic: tasks per thread of the fixed-order camera sums (3, 5 or 8; 0: atomics)
+  int det_m = 0;  // cba_options.deterministic: tasks per thread of the fixed-order camera sums (3, 5, 8 or 16; 0: atomics)
   DetPlan det{nullptr, nullptr};
   double* tri = nullptr;   // packed upper triangle of Sacc + b for the exchange of a sharded solve
   double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
@@ -893,6 +893,10 @@ static int configure_kernels(cba_problem* p) {
     if ((rc = allow_lds(k_tprep<NC, 3>, lds_tprep<NC>(p)))) return rc;
     if ((rc = allow_lds(k_tprep<NC, 5>, lds_tprep<NC>(p)))) return rc;
     if ((rc = allow_lds(k_tprep<NC, 8>, lds_tprep<NC>(p)))) return rc;
+    if constexpr (NC == 6) {
+      if ((rc = allow_lds(k_build<NC, 16>, lds_build<NC>(p)))) return rc;
+      if ((rc = allow_lds(k_tprep<NC, 16>, lds_tprep<NC>(p)))) return rc;
+    }
   }
   if ((rc = allow_lds(k_jv<NC, 1>, lds_jv(p, 1)))) return rc;
   if ((rc = allow_lds(k_jv<NC, 2>, lds_jv(p, 2)))) return rc;
@@ -1085,8 +1089,12 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   if (opt && opt->deterministic) {
     // fixed-order per-camera sums (k_build / k_tprep, det_round): per chunk the observation order by camera and the camera offsets
     const int need = (p->C * DET_ROUND + BLOCK - 1) / BLOCK;
-    p->det_m = need <= 3 ? 3 : need <= 5 ? 5 : need <= 8 ? 8 : -1;
-    if (p->det_m < 0) return bail(fail(CBA_ERR_UNSUPPORTED, "deterministic sums support up to %d cameras, the problem has %d", 8 * BLOCK / DET_ROUND, p->C));
+    // tasks per thread of the fixed-order sums: 3, 5, 8 (<= 227 cameras) and, six-parameter cameras only, 16 (<= 455 by the task count; the LDS copy of
+    // the camera table next to the parking area admits ~370: configure_kernels reports the bytes beyond that).  Nine-parameter cameras stop at 227: six
+    // rounds of 16 running sums are 96 doubles per thread.
+    p->det_m = need <= 3 ? 3 : need <= 5 ? 5 : need <= 8 ? 8 : (nct == 6 && need <= 16) ? 16 : -1;
+    if (p->det_m < 0) return bail(fail(CBA_ERR_UNSUPPORTED, "deterministic sums support up to %d %s-parameter cameras, the problem has %d",
+                                       (nct == 6 ? 16 : 8) * BLOCK / DET_ROUND, nct == 6 ? "six" : "nine", p->C));
     std::vector<unsigned char> perm((size_t)std::max<int64_t>(nch, 1) * CHUNK, 0);
     std::vector<unsigned short> cst((size_t)std::max<int64_t>(nch, 1) * (p->C + 1), 0);
     for (int64_t c = 0; c < nch; ++c) {
@@ -1420,6 +1428,7 @@ static int run_build_into(cba_problem* p, const double* xvec, const double* tab,
       case 3: launch_build(k_build<NC, 3>); break;
       case 5: launch_build(k_build<NC, 5>); break;
       case 8: launch_build(k_build<NC, 8>); break;
+      case 16: { if constexpr (NC == 6) launch_build(k_build<NC, 16>); } break;
       default:
         if (build_camg<NC>(p)) launch_build(k_build<NC, 0, true>); else launch_build(k_build<NC, 0>);
         break;
@@ -1528,9 +1537,12 @@ static int run_lin_chain(cba_problem* p, bool scalars = true, bool compact = fal
       // (bounded: the camera block's Jacobi state is read and written in place — sinv_state_c — and sinv takes the effective scale)
       const BoundArgs ba = bnd ? BoundArgs{p->lb_dev, p->ub_dev, p->sinv_state_c, p->sinv_state_c, p->cam_diag} : BoundArgs{};
       if (bnd) p->cam_scaled = true;
-      hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc, p->lay,
-                         p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr, p->x, p->g, p->v1,
-                         p->partial4b, p->partial1, (const double*)nullptr, ba);
+      auto launch_sl = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(vg), dim3(BLOCK), 0, p->stream, p->Upacked, p->V, p->param_cam, p->param_loc, p->lay,
+                           p->first_scale ? 1 : 0, p->sinv, p->con.n_con ? (const double*)p->con.cdiag : (const double*)nullptr, p->x, p->g, p->v1,
+                           p->partial4b, p->partial1, (const double*)nullptr, ba);
+      };
+      if (bnd) launch_sl(k_scale_lin<NC, true>); else launch_sl(k_scale_lin<NC, false>);
       p->first_scale = false;
       int rows_jv = 0;
       int rcj = run_jv<NC>(p, 1, &rows_jv);
@@ -1744,6 +1756,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
         case 3: launch_tprep(k_tprep<NC, 3>); break;
         case 5: launch_tprep(k_tprep<NC, 5>); break;
         case 8: launch_tprep(k_tprep<NC, 8>); break;
+        case 16: { if constexpr (NC == 6) launch_tprep(k_tprep<NC, 16>); } break;
         default:
           if (linf) { if (p->tab_global) launch_tprep(k_tprep<NC, 0, true, true>); else launch_tprep(k_tprep<NC, 0, false, true>); }
           else if (p->tab_global) launch_tprep(k_tprep<NC, 0, true>); else launch_tprep(k_tprep<NC, 0>);
@@ -1906,8 +1919,11 @@ static int step_enqueue(cba_problem* p, double radius, bool compact, unsigned lo
     {
       ScopedTimer t(p, T_SCALE_SCALARS);
       const BoundArgs ba2 = bnd ? BoundArgs{p->lb_dev, p->ub_dev, p->sinv_state_c, p->sinv_state_c2, p->cam_diag2} : BoundArgs{};
-      hipLaunchKernelGGL((k_scale_lin<NC>), dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
-                         (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv, ba2);
+      auto launch_sl2 = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(vg), dim3(BLOCK), 0, p->stream, p->U2, p->V2, p->param_cam, p->param_loc, p->lay, 0, p->sinv2,
+                           (const double*)nullptr, p->x_new, p->g2, p->v1, p->partial4b, p->partial1, (const double*)p->sinv, ba2);
+      };
+      if (bnd) launch_sl2(k_scale_lin<NC, true>); else launch_sl2(k_scale_lin<NC, false>);
       int rows_jv = 0;
       rc = run_jv<NC>(p, 1, &rows_jv, p->x_new, p->tab_new);
       p->spec_rows_jv = rows_jv;
