@@ -285,7 +285,7 @@ class CaptureVolume:
             final_cost=float(result.cost),
             bound_warnings=par.bound_warnings(result.x),
         )
-        return CaptureVolume(
+        out = CaptureVolume(
             camera_array=new_cameras,
             image_points=self.image_points,
             world_points=self.world_points.with_points(new_points),
@@ -293,60 +293,75 @@ class CaptureVolume:
             _optimization_status=status,
             _known_map=self.img_to_obj_map,
         )
+        kept = getattr(self, "_constraint_cache", None)
+        if kept is not None:  # same world-point keys, same constraint set
+            object.__setattr__(out, "_constraint_cache", kept)
+        return out
 
     # -- constraint rows (reference :446-605) ----------------------------------------------------------------
-    def _constraint_instances(self):
-        """Every (constraint, sync index) at which all endpoint keypoints have a world point: yields
-        ``(constraint, sync_index, rows_a, rows_b)`` with four world-point rows per endpoint (a corner endpoint is its
-        row four times).  Static-static constraints fire once at ``STATIC_SYNC_INDEX``, mobile-mobile ones at every
-        shared sync index, mixed ones never (reference ``_firing_sync_indices`` :518-530)."""
+    def _constraint_blocks(self):
+        """Per constraint that fires: ``(constraint, sync indices (n,), rows_a (n, 4), rows_b (n, 4))`` — four world-point rows per endpoint (a corner
+        endpoint is its row four times) at every sync index at which all endpoint keypoints have a world point.  Static-static constraints fire once
+        at ``STATIC_SYNC_INDEX``, mobile-mobile ones at every shared sync index, mixed ones never (reference ``_firing_sync_indices`` :518-530).
+        The blocks depend on the KEYS of the world points and on the constraint set only, so they are built once per volume and handed to the
+        volumes ``optimize()`` returns (same keys, new coordinates): on the reference's 4-camera session with its board they were 5 of the call's 7 ms."""
+        kept = getattr(self, "_constraint_cache", None)
+        if kept is not None:
+            return kept
         con = self.constraints
-        if con is None or not (con.distances or con.centroid_distances):
-            return
-        df = self.world_points._df
-        order = np.lexsort((df["sync_index"].to_numpy(), df["keypoint_id"].to_numpy(), df["object_id"].to_numpy()))
-        obj, kp, sync = (df[c].to_numpy()[order] for c in ("object_id", "keypoint_id", "sync_index"))
-        # one slice of (sorted sync indices, world rows) per keypoint
-        start = np.flatnonzero(np.r_[True, (obj[1:] != obj[:-1]) | (kp[1:] != kp[:-1])]) if len(obj) else np.array([], dtype=np.int64)
-        end = np.r_[start[1:], len(obj)]
-        table = {(int(obj[s]), int(kp[s])): (sync[s:e], order[s:e]) for s, e in zip(start, end)}
-        empty = (np.array([], dtype=np.int64), np.array([], dtype=np.int64))
-        static_ids = con.static_object_ids
+        blocks = []
+        if con is not None and (con.distances or con.centroid_distances):
+            df = self.world_points._df
+            order = np.lexsort((df["sync_index"].to_numpy(), df["keypoint_id"].to_numpy(), df["object_id"].to_numpy()))
+            obj, kp, sync = (df[c].to_numpy()[order] for c in ("object_id", "keypoint_id", "sync_index"))
+            # one slice of (sorted sync indices, world rows) per keypoint
+            start = np.flatnonzero(np.r_[True, (obj[1:] != obj[:-1]) | (kp[1:] != kp[:-1])]) if len(obj) else np.array([], dtype=np.int64)
+            end = np.r_[start[1:], len(obj)]
+            table = {(int(obj[s]), int(kp[s])): (sync[s:e], order[s:e]) for s, e in zip(start, end)}
+            empty = (np.array([], dtype=np.int64), np.array([], dtype=np.int64))
+            static_ids = con.static_object_ids
 
-        def fire(endpoints, is_static):
-            syncs = endpoints[0][0]
-            for s, _ in endpoints[1:]:
-                syncs = np.intersect1d(syncs, s)
-            syncs = syncs[syncs == STATIC_SYNC_INDEX] if is_static else syncs[syncs != STATIC_SYNC_INDEX]
-            rows = [r[np.searchsorted(s, syncs)] for s, r in endpoints]  # keys are unique per keypoint (sorted slice)
-            return syncs, rows
+            def fire(endpoints, is_static):
+                syncs = endpoints[0][0]
+                for s, _ in endpoints[1:]:
+                    syncs = np.intersect1d(syncs, s)
+                syncs = syncs[syncs == STATIC_SYNC_INDEX] if is_static else syncs[syncs != STATIC_SYNC_INDEX]
+                return syncs, [r[np.searchsorted(s, syncs)] for s, r in endpoints]  # (sorted slice per keypoint)
 
-        for dc in con.distances:
-            a_static, b_static = dc.object_id_a in static_ids, dc.object_id_b in static_ids
-            if a_static != b_static:
-                continue
-            ends = [table.get((dc.object_id_a, dc.keypoint_id_a), empty), table.get((dc.object_id_b, dc.keypoint_id_b), empty)]
-            syncs, rows = fire(ends, a_static)
+            for dc in con.distances:
+                a_static, b_static = dc.object_id_a in static_ids, dc.object_id_b in static_ids
+                if a_static != b_static:
+                    continue
+                ends = [table.get((dc.object_id_a, dc.keypoint_id_a), empty), table.get((dc.object_id_b, dc.keypoint_id_b), empty)]
+                syncs, rows = fire(ends, a_static)
+                if len(syncs):
+                    blocks.append((dc, syncs, np.repeat(rows[0][:, None], 4, axis=1), np.repeat(rows[1][:, None], 4, axis=1)))
+            for cc in con.centroid_distances:
+                a_static, b_static = cc.object_id_a in static_ids, cc.object_id_b in static_ids
+                if a_static != b_static:
+                    continue
+                ends = [table.get((o, k), empty) for o in (cc.object_id_a, cc.object_id_b) for k in range(4)]
+                syncs, rows = fire(ends, a_static)
+                if len(syncs):
+                    blocks.append((cc, syncs, np.stack(rows[:4], axis=1), np.stack(rows[4:], axis=1)))
+        object.__setattr__(self, "_constraint_cache", blocks)
+        return blocks
+
+    def _constraint_instances(self):
+        """``(constraint, sync_index, rows_a, rows_b)`` per instance, in the order of ``_build_constraint_arrays``'s rows."""
+        for c, syncs, rows_a, rows_b in self._constraint_blocks():
             for i, si in enumerate(syncs):
-                yield dc, int(si), [int(rows[0][i])] * 4, [int(rows[1][i])] * 4
-        for cc in con.centroid_distances:
-            a_static, b_static = cc.object_id_a in static_ids, cc.object_id_b in static_ids
-            if a_static != b_static:
-                continue
-            ends = [table.get((o, k), empty) for o in (cc.object_id_a, cc.object_id_b) for k in range(4)]
-            syncs, rows = fire(ends, a_static)
-            for i, si in enumerate(syncs):
-                yield cc, int(si), [int(rows[k][i]) for k in range(4)], [int(rows[4 + k][i]) for k in range(4)]
+                yield c, int(si), rows_a[i].tolist(), rows_b[i].tolist()
 
     def _build_constraint_arrays(self):
         """``(groups_a (n, 4) int32, groups_b (n, 4) int32, distances (n,), sigmas (n,))`` or None."""
-        ga, gb, dist, sig = [], [], [], []
-        for c, _, rows_a, rows_b in self._constraint_instances():
-            ga.append(rows_a); gb.append(rows_b); dist.append(c.distance); sig.append(c.sigma)
-        if not ga:
+        blocks = self._constraint_blocks()
+        if not blocks:
             return None
-        return (np.array(ga, dtype=np.int32), np.array(gb, dtype=np.int32), np.array(dist, dtype=np.float64),
-                np.array(sig, dtype=np.float64))
+        n = [len(b[1]) for b in blocks]
+        return (np.concatenate([b[2] for b in blocks]).astype(np.int32), np.concatenate([b[3] for b in blocks]).astype(np.int32),
+                np.repeat(np.array([b[0].distance for b in blocks], dtype=np.float64), n),
+                np.repeat(np.array([b[0].sigma for b in blocks], dtype=np.float64), n))
 
     def rigidity_report(self) -> RigidityReport:
         """Measured distance of every constraint instance with the current world points (no optimisation)."""

@@ -218,6 +218,37 @@ def test_mobile_marker_fires_every_frame():
     assert ConstraintSet((), frozenset()) and _volume(*_rows([0], [(0, 0.0)]), ConstraintSet((), frozenset()))._build_constraint_arrays() is None
 
 
+def test_constraint_rows_are_built_once_per_volume_and_follow_optimize():
+    """The firing table depends on the world points' KEYS and the constraint set only: built once, kept, handed to the volume ``optimize()``
+    returns (same keys, new coordinates) — and equal to what a volume built from scratch over the same tables computes."""
+    from caliscope_amd.engine import TrfResult
+
+    cs = ConstraintSet.from_marker_set(MarkerSet({0: Marker(0, 1.0), 1: Marker(1, 0.5)}, links=[Link(0, 1, 2.0)]))
+    vol = _volume(*_rows([0, 1, 2, 5], [(0, 0.0), (1, 2.0)], present=lambda si, o, k: not (si == 2 and o == 1 and k == 1)), cs)
+    first = vol._build_constraint_arrays()
+    assert vol._constraint_blocks() is vol._constraint_blocks()
+    inst = list(vol._constraint_instances())
+    assert len(inst) == len(first[2]) and [i[2] for i in inst] == first[0].tolist() and [i[3] for i in inst] == first[1].tolist()
+    assert [i[0].distance for i in inst] == first[2].tolist() and all(isinstance(i[1], int) for i in inst)
+
+    class Shift:  # an engine that moves every point by a millimetre
+        def __init__(self, problem):
+            self.ncp = problem.parameterization.n_camera_params
+
+        def solve(self, x0, **kw):
+            x = x0.copy()
+            x[self.ncp:] += 1e-3
+            return TrfResult(x=x, cost=0.0, optimality=0.0, nfev=2, njev=2, status=2)
+
+    out = vol.optimize(_engine_factory=Shift)
+    assert out._constraint_blocks() is vol._constraint_blocks()
+    fresh = CaptureVolume(out.camera_array, out.image_points, WorldPoints(out.world_points.df), cs)
+    for a, b in zip(out._build_constraint_arrays(), fresh._build_constraint_arrays()):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert out.rigidity_report().rmse_mm == pytest.approx(fresh.rigidity_report().rmse_mm)
+    assert len(out.rigidity_report().violations) == len(first[2])
+
+
 def test_centroid_needs_all_eight_corners_and_static_fires_once():
     cs = ConstraintSet((), frozenset(), centroid_distances=(CentroidDistanceConstraint(0, 1, 2.0, 0.005),))
     vol = _volume(*_rows([0, 1, 2], [(0, 0.0), (1, 2.0)], present=lambda si, o, k: not (si == 1 and o == 1 and k == 3)), cs)

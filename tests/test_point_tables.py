@@ -109,6 +109,10 @@ def test_world_points_with_points_and_cached_columns():
     pts = moved.points
     pts[:] = -1.0
     assert np.array_equal(moved.points, xyz)  # `points` hands out copies
+    xyz[:] = 7.0  # the caller's array is not what the new table keeps
+    assert np.array_equal(moved.points, np.arange(9.0).reshape(3, 3)) and np.array_equal(moved.df["x_coord"].to_numpy(), [0.0, 3.0, 6.0])
+    again = moved.with_points(moved.points + 1.0).take(np.array([True, False, True]))  # tables built over shared key columns behave like any other
+    assert list(again.df["keypoint_id"]) == [0, 0] and np.array_equal(again.points, [[1.0, 2.0, 3.0], [7.0, 8.0, 9.0]])
     with pytest.raises(ValueError):
         world.with_points(np.zeros((2, 3)))
     with pytest.raises(ValueError, match="non-finite"):
@@ -243,3 +247,30 @@ def test_observation_to_point_map_by_table_equals_the_merge():
         if static:
             rows = np.flatnonzero((img._df["object_id"].to_numpy() == 4) & (by_merge >= 0))
             assert rows.size and np.all(world._df["sync_index"].to_numpy()[by_merge[rows]] == STATIC_SYNC_INDEX)
+
+
+def test_camera_copies_are_deep():
+    """``CaptureVolume.optimize`` deep-copies the camera array on every call: the field-wise ``CameraData.__deepcopy__`` must give what the generic
+    walk gave — equal values, no shared arrays, attributes a caller hung on the object included."""
+    from copy import deepcopy
+
+    from caliscope_amd.cameras import CameraArray, CameraData
+
+    cam = CameraData.from_intrinsics(3, (640, 480), 500.0, distortions=[0.1, 0.01, 0.0, 0.0, 0.0])
+    cam.rotation, cam.translation, cam.error, cam.fisheye = np.eye(3), np.array([0.1, 0.2, 0.3]), 0.25, False
+    cam.note = {"tags": ["a"]}
+    arr = CameraArray({3: cam, 4: CameraData(cam_id=4, size=(320, 240))})
+    twin = deepcopy(arr)
+    a, b = arr.cameras[3], twin.cameras[3]
+    assert a is not b  # (dataclass equality would compare arrays elementwise: checked field by field)
+    for name, value in a.__dict__.items():
+        other = b.__dict__[name]
+        if isinstance(value, np.ndarray):
+            assert np.array_equal(value, other) and not np.shares_memory(value, other), name
+        else:
+            assert value == other, name
+    assert b.note is not a.note and b.note["tags"] is not a.note["tags"] and b.size == (640, 480)
+    assert twin.cameras[4].matrix is None and twin.cameras[4].rotation is None and set(twin.cameras) == {3, 4}
+    b.translation[0] = 9.0
+    b.matrix[0, 0] = 1.0
+    assert a.translation[0] == 0.1 and a.matrix[0, 0] == 500.0
