@@ -62,7 +62,8 @@ static_assert(sizeof(CamTab) == 48 * sizeof(double), "CamTab must be 48 doubles"
 static_assert(offsetof(CamTab, pad) == 35 * sizeof(double), "35 live doubles (CAMTAB_LIVE in cba_kernels.h)");
 constexpr int CAMTAB_DOUBLES = 48;
 
-// x_cam: this camera's slice of the parameter vector (6 or 9 entries); cconst: cam_const row.
+// x_cam: this camera's slice of the parameter vector in an array of MAX_NC entries (all nine are read; those behind nparams are not used);
+// cconst: cam_const row.
 CBA_HD void cam_prepare(const double* x_cam, const double* cconst, int model, int nparams, CamTab* o) {
   const double rx = x_cam[0], ry = x_cam[1], rz = x_cam[2];
   const double th2 = rx * rx + ry * ry + rz * rz;
@@ -94,13 +95,14 @@ CBA_HD void cam_prepare(const double* x_cam, const double* cconst, int model, in
   const double fx0 = cconst[0], fy0 = cconst[1];
   o->fx0 = fx0; o->fy0 = fy0; o->inv_fx0 = 1.0 / fx0;
   o->cx = cconst[2]; o->cy = cconst[3];
-  for (int i = 0; i < 5; ++i) o->d[i] = cconst[4 + i];
-  if (nparams == 9) {  // free intrinsics: fx = s fx0, fy = s fy0, k1, k2 from x
-    o->fx = x_cam[6] * fx0; o->fy = x_cam[6] * fy0;
-    o->d[0] = x_cam[7]; o->d[1] = x_cam[8];
-  } else {
-    o->fx = fx0; o->fy = fy0;
-  }
+  // free intrinsics (nparams == 9): fx = s fx0, fy = s fy0, k1, k2 from x.  Selected by VALUE: written as stores under an `if`, the compiler merged
+  // the two branches' stores into one store through a selected address — 24 bytes of scratch per lane in every kernel that prepares a camera.
+  const bool free_intr = nparams == 9;
+  o->fx = free_intr ? x_cam[6] * fx0 : fx0;
+  o->fy = free_intr ? x_cam[6] * fy0 : fy0;
+  o->d[0] = free_intr ? x_cam[7] : cconst[4];
+  o->d[1] = free_intr ? x_cam[8] : cconst[5];
+  for (int i = 2; i < 5; ++i) o->d[i] = cconst[4 + i];
   o->model = (double)model;
   o->nparams = (double)nparams;
   for (int i = 0; i < 13; ++i) o->pad[i] = 0.0;

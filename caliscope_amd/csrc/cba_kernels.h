@@ -2836,9 +2836,10 @@ k_triangulate(long n_points, const long* __restrict__ pt_start, const int* __res
       }
   }
   int best = 0;
+  double smallest = M[0][0];  // (kept beside `best`: M[best][best] is a dynamic index and sent the whole matrix to scratch)
 #pragma unroll
   for (int k = 1; k < 4; ++k)
-    if (M[k][k] < M[best][best]) best = k;
+    if (M[k][k] < smallest) { smallest = M[k][k]; best = k; }
   double w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = (best == 0) ? V[k][0] : (best == 1) ? V[k][1] : (best == 2) ? V[k][2] : V[k][3];
@@ -2905,9 +2906,12 @@ k_heavy_schur(const int* __restrict__ heavy_pts, const int* __restrict__ pt_star
     const int cam = obs_cam[i], off = cam_off[cam], np = cam_np[cam];
     double T[3 * NC];
     expand_record<NC>(Trec + (long)i * REC, tab + (long)cam * CAMTAB_DOUBLES + 12, T);  // compact record -> true T (J_l of the camera)
-    for (int r = 0; r < np; ++r) {
-      lds_add(&W[(off + r) * 3 + 0], T[3 * r]); lds_add(&W[(off + r) * 3 + 1], T[3 * r + 1]); lds_add(&W[(off + r) * 3 + 2], T[3 * r + 2]);
-      seen[off + r] = 1;
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {  // (constant trip count: T stays in registers; `r < np` as a loop bound indexed it dynamically: 160 / 224 bytes of scratch)
+      if (r < np) {
+        lds_add(&W[(off + r) * 3 + 0], T[3 * r]); lds_add(&W[(off + r) * 3 + 1], T[3 * r + 1]); lds_add(&W[(off + r) * 3 + 2], T[3 * r + 2]);
+        seen[off + r] = 1;
+      }
     }
   }
   __syncthreads();
@@ -3166,7 +3170,9 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
         double T[3 * NC];
         expand_record<NC>(Trec + (long)i * REC, tab + (long)cam * CAMTAB_DOUBLES + 12, T);
         const int off = cam_off[cam], npar = cam_np[cam];
-        for (int r = 0; r < npar; ++r) G[(long)c * gw + off + r] += T[3 * r] * z[0] + T[3 * r + 1] * z[1] + T[3 * r + 2] * z[2];
+#pragma unroll
+        for (int r = 0; r < NC; ++r)  // (constant trip count: T stays in registers)
+          if (r < npar) G[(long)c * gw + off + r] += T[3 * r] * z[0] + T[3 * r + 1] * z[1] + T[3 * r + 2] * z[2];
       }
     }
   }

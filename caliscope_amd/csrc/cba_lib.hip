@@ -1090,7 +1090,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     // fixed-order per-camera sums (k_build / k_tprep, det_round): per chunk the observation order by camera and the camera offsets
     const int need = (p->C * DET_ROUND + BLOCK - 1) / BLOCK;
     // tasks per thread of the fixed-order sums: 3, 5, 8 (<= 227 cameras) and, six-parameter cameras only, 16 (<= 455 by the task count; the LDS copy of
-    // the camera table next to the parking area admits ~370: configure_kernels reports the bytes beyond that).  Nine-parameter cameras stop at 227: six
+    // the camera table next to k_tprep's staging and parking areas admits 385: configure_kernels reports the bytes beyond that).  Nine-parameter cameras stop at 227: six
     // rounds of 16 running sums are 96 doubles per thread.
     p->det_m = need <= 3 ? 3 : need <= 5 ? 5 : need <= 8 ? 8 : (nct == 6 && need <= 16) ? 16 : -1;
     if (p->det_m < 0) return bail(fail(CBA_ERR_UNSUPPORTED, "deterministic sums support up to %d %s-parameter cameras, the problem has %d",

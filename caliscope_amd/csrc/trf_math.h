@@ -41,13 +41,21 @@ TRF_HD inline double poly_eval(const double* c, int deg, double t) {
   return p;
 }
 
-// Real roots of c[0] t^deg + ... + c[deg], deg <= 4, c[0] != 0: the real roots of the derivative split the line into
+// Real roots of c[0] t^DEG + ... + c[DEG], DEG <= 4, c[0] != 0: the real roots of the derivative split the line into
 // monotone pieces; a sign change inside a piece is closed in by bisection (to the last bit) — no complex arithmetic.
 // Callers rank the roots by a model value, so a duplicate is harmless.  A root of even multiplicity (the graph touches
 // zero without crossing) is reported when a critical point itself is a root to rounding.
-TRF_HD inline int real_roots_monic_pieces(const double* c, int deg, double* out) {
-  if (deg == 1) { out[0] = -c[1] / c[0]; return 1; }
-  if (deg == 2) {
+// The degree is a template parameter: the derivative's roots come from the instance one degree lower, so nothing recurses at run time.  (Until
+// round 5 this was one function calling itself on `deg - 1`.  On the device a recursive function gives the kernel a DYNAMIC stack: the HIP runtime
+// then reserves hipLimitStackSize = 1 KB per lane for every wave slot of the device — 512 MB of HBM on an MI355X, allocated inside the first
+// launch of the one-workgroup step kernel and kept by the runtime for the life of the process; tools/device_memory_probe.py shows it.)
+template <int DEG>
+TRF_HD inline int real_roots_of_degree(const double* c, double* out) {
+  static_assert(DEG >= 1 && DEG <= 4, "quartics at most");
+  if constexpr (DEG == 1) {
+    out[0] = -c[1] / c[0];
+    return 1;
+  } else if constexpr (DEG == 2) {
     const double disc = c[1] * c[1] - 4.0 * c[0] * c[2];
     if (disc < 0.0) return 0;
     const double q = -0.5 * (c[1] + copysign(sqrt(disc), c[1]));
@@ -55,53 +63,59 @@ TRF_HD inline int real_roots_monic_pieces(const double* c, int deg, double* out)
     if (q != 0.0) { out[n++] = q / c[0]; out[n++] = c[2] / q; }
     else { out[n++] = 0.0; }
     return n;
-  }
-  double d[4], crit[3];
-  for (int i = 0; i < deg; ++i) d[i] = c[i] * (deg - i);
-  int nc = real_roots_monic_pieces(d, deg - 1, crit);
-  for (int i = 1; i < nc; ++i)  // sort (at most 3 values)
-    for (int j = i; j > 0 && crit[j] < crit[j - 1]; --j) { const double t = crit[j]; crit[j] = crit[j - 1]; crit[j - 1] = t; }
-  double bound = 0.0;  // Cauchy bound on |root|
-  for (int i = 1; i <= deg; ++i) bound = fmax(bound, fabs(c[i] / c[0]));
-  bound += 1.0;
-  double knots[5];
-  int nk = 0;
-  knots[nk++] = -bound;
-  for (int i = 0; i < nc; ++i)
-    if (crit[i] > -bound && crit[i] < bound) knots[nk++] = crit[i];
-  knots[nk++] = bound;
-  int n = 0;
-  double scale = 0.0;
-  for (int i = 0; i <= deg; ++i) scale = fmax(scale, fabs(c[i]));
-  for (int k = 0; k + 1 < nk; ++k) {
-    double a = knots[k], b = knots[k + 1];
-    double fa = poly_eval(c, deg, a), fb = poly_eval(c, deg, b);
-    if (fa == 0.0) { out[n++] = a; continue; }
-    if (k + 2 == nk && fb == 0.0) { out[n++] = b; continue; }
-    if ((fa < 0.0) == (fb < 0.0)) {
-      // no crossing; a touching root at an interior knot shows as a tiny |f| there
-      if (k > 0 && fabs(fa) <= 1e-14 * scale * fmax(1.0, pow(fabs(a), (double)deg))) out[n++] = a;
-      continue;
+  } else {
+    double d[DEG], crit[DEG - 1];
+    for (int i = 0; i < DEG; ++i) d[i] = c[i] * (DEG - i);
+    int nc = real_roots_of_degree<DEG - 1>(d, crit);
+    for (int i = 1; i < nc; ++i)  // sort (at most 3 values)
+      for (int j = i; j > 0 && crit[j] < crit[j - 1]; --j) { const double t = crit[j]; crit[j] = crit[j - 1]; crit[j - 1] = t; }
+    double bound = 0.0;  // Cauchy bound on |root|
+    for (int i = 1; i <= DEG; ++i) bound = fmax(bound, fabs(c[i] / c[0]));
+    bound += 1.0;
+    double knots[DEG + 1];
+    int nk = 0;
+    knots[nk++] = -bound;
+    for (int i = 0; i < nc; ++i)
+      if (crit[i] > -bound && crit[i] < bound) knots[nk++] = crit[i];
+    knots[nk++] = bound;
+    int n = 0;
+    double scale = 0.0;
+    for (int i = 0; i <= DEG; ++i) scale = fmax(scale, fabs(c[i]));
+    for (int k = 0; k + 1 < nk; ++k) {
+      double a = knots[k], b = knots[k + 1];
+      double fa = poly_eval(c, DEG, a), fb = poly_eval(c, DEG, b);
+      if (fa == 0.0) { out[n++] = a; continue; }
+      if (k + 2 == nk && fb == 0.0) { out[n++] = b; continue; }
+      if ((fa < 0.0) == (fb < 0.0)) {
+        // no crossing; a touching root at an interior knot shows as a tiny |f| there
+        if (k > 0 && fabs(fa) <= 1e-14 * scale * fmax(1.0, pow(fabs(a), (double)DEG))) out[n++] = a;
+        continue;
+      }
+      for (int it = 0; it < 200 && b - a > 0.0; ++it) {
+        const double m = 0.5 * (a + b);
+        if (m == a || m == b) break;
+        const double fm = poly_eval(c, DEG, m);
+        if (fm == 0.0) { a = b = m; break; }
+        if ((fm < 0.0) == (fa < 0.0)) { a = m; fa = fm; } else { b = m; }
+      }
+      out[n++] = 0.5 * (a + b);
+      if (n >= DEG) break;
     }
-    for (int it = 0; it < 200 && b - a > 0.0; ++it) {
-      const double m = 0.5 * (a + b);
-      if (m == a || m == b) break;
-      const double fm = poly_eval(c, deg, m);
-      if (fm == 0.0) { a = b = m; break; }
-      if ((fm < 0.0) == (fa < 0.0)) { a = m; fa = fm; } else { b = m; }
-    }
-    out[n++] = 0.5 * (a + b);
-    if (n >= 4) break;
+    return n;
   }
-  return n;
 }
 
+// c_in[0 .. n_coef - 1], n_coef <= 5, leading zeros allowed: the degree is what is left behind them
 TRF_HD inline int real_roots(const double* c_in, int n_coef, double* out) {
   int lead = 0;
   while (lead < n_coef && c_in[lead] == 0.0) ++lead;
-  const int deg = n_coef - 1 - lead;
-  if (deg <= 0) return 0;
-  return real_roots_monic_pieces(c_in + lead, deg, out);
+  switch (n_coef - 1 - lead) {
+    case 4: return real_roots_of_degree<4>(c_in + lead, out);
+    case 3: return real_roots_of_degree<3>(c_in + lead, out);
+    case 2: return real_roots_of_degree<2>(c_in + lead, out);
+    case 1: return real_roots_of_degree<1>(c_in + lead, out);
+    default: return 0;
+  }
 }
 
 // argmin 0.5 p^T B p + g^T p  s.t. ||p|| <= radius in two dimensions: the interior Newton point if B is positive

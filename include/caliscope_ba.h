@@ -72,7 +72,8 @@ typedef struct {
   int32_t deterministic; /* 1: the per-camera sums of the build and Schur passes are formed in a fixed order (parked in LDS, summed per
                             camera in the chunk's camera-sorted order) instead of by FP64 LDS atomics: two solves of one problem return
                             identical bits, as the reference's single-threaded scipy does (capture_volume.py:387).  Constraint rows and
-                            heavy points still add their few sums atomically. */
+                            heavy points still add their few sums atomically.  Up to 227 nine-parameter or 385 six-parameter cameras
+                            (tasks per thread; the LDS copy of the camera table): cba_create returns CBA_ERR_UNSUPPORTED beyond. */
   int32_t evaluation_only; /* 1: residuals / costs only (cba_residuals, cba_begin): the Schur plan and the solver's buffers are
                               not built — the reprojection report needs no more */
 } cba_options;

@@ -4,13 +4,20 @@
 // with the numpy oracle.  It is not a CPU fallback: nothing in caliscope_amd/ loads it.
 #include "ba_math.h"
 
+// cam_prepare reads MAX_NC entries of the camera's slice (the intrinsic ones are SELECTED, not branched on): callers hand over nparams
+static void prepare(const double* x_cam, const double* cconst, int model, int nparams, cba::CamTab* tab) {
+  double xc[cba::MAX_NC] = {0};
+  for (int i = 0; i < nparams && i < cba::MAX_NC; ++i) xc[i] = x_cam[i];
+  cba::cam_prepare(xc, cconst, model, nparams, tab);
+}
+
 extern "C" {
 
 // A_out: [2][9] row-major (unused columns zero), B_out: [2][3]
 void mh_project_full(const double* x_cam, const double* cconst, int model, int nparams, const double* X,
                      const double* uv, double* e_out, double* A_out, double* B_out) {
   cba::CamTab tab;
-  cba::cam_prepare(x_cam, cconst, model, nparams, &tab);
+  prepare(x_cam, cconst, model, nparams, &tab);
   double A[2][cba::MAX_NC] = {{0}}, B[2][3];
   cba::project_full(tab, X[0], X[1], X[2], uv[0], uv[1], e_out, A, B);
   for (int r = 0; r < 2; ++r) {
@@ -22,13 +29,13 @@ void mh_project_full(const double* x_cam, const double* cconst, int model, int n
 void mh_project_residual(const double* x_cam, const double* cconst, int model, int nparams, const double* X,
                          const double* uv, double* e_out) {
   cba::CamTab tab;
-  cba::cam_prepare(x_cam, cconst, model, nparams, &tab);
+  prepare(x_cam, cconst, model, nparams, &tab);
   cba::project_residual(tab, X[0], X[1], X[2], uv[0], uv[1], e_out);
 }
 
 void mh_cam_table(const double* x_cam, const double* cconst, int model, int nparams, double* out48) {
   cba::CamTab tab;
-  cba::cam_prepare(x_cam, cconst, model, nparams, &tab);
+  prepare(x_cam, cconst, model, nparams, &tab);
   const double* p = reinterpret_cast<const double*>(&tab);
   for (int i = 0; i < cba::CAMTAB_DOUBLES; ++i) out48[i] = p[i];
 }

@@ -124,3 +124,27 @@ def test_host_plan_rejects_bad_input(lib):
     assert list(cstart) == [0, 5, 261, 517, 705, 708, 964, 1220, 1221] and nch == 8
     nch, order, pstart, cstart = _plan(lib, 3, np.array([], dtype=np.int32), 256)
     assert nch == 0
+
+
+def test_no_kernel_asks_the_runtime_for_a_stack(lib, tmp_path):
+    """Private (scratch) memory of the kernels, read from the code object inside the built library.  A kernel with a DYNAMIC stack (a recursive
+    device function) makes the HIP runtime reserve hipLimitStackSize per lane for every wave slot of the device — 512 MB of HBM on an MI355X, taken
+    inside the kernel's first launch and kept for the life of the process (tools/device_memory_probe.py; round 5 found the one-workgroup step kernel
+    doing that through trf::real_roots calling itself).  Fixed-size scratch is tolerated only where it is known: the fixed-order (deterministic)
+    build of nine-parameter cameras, which parks six rounds of running sums per thread."""
+    import shutil
+    import subprocess
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    bundler, readelf, objcopy = llvm / "clang-offload-bundler", llvm / "llvm-readelf", shutil.which("objcopy") or str(llvm / "llvm-objcopy")
+    if not (bundler.exists() and readelf.exists() and Path(objcopy).exists()):
+        pytest.skip("LLVM binary utilities of the ROCm image not found")
+    fat, co = tmp_path / "fatbin.bin", tmp_path / "gfx950.co"
+    subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", str(build.OUT), str(fat)], check=True)
+    subprocess.run([str(bundler), "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    notes = subprocess.run([str(readelf), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    kernels = re.findall(r"\.name:\s+(\S+)\s+\.private_segment_fixed_size:\s+(\d+)", notes)  # (.name directly precedes the size in the metadata map)
+    assert len(kernels) > 100, len(kernels)
+    assert notes.count(".uses_dynamic_stack: false") == len(kernels) and ".uses_dynamic_stack: true" not in notes
+    with_scratch = {name: int(size) for name, size in kernels if int(size)}
+    assert all(name.startswith("_ZN3cba7k_buildILi9ELi") for name in with_scratch), with_scratch

@@ -12,6 +12,7 @@ cp $S/chol_trace.log $D/${R}_chol_trace.txt
 cp $S/create_timing.log $D/${R}_setup_timing.txt
 cp $S/real_session.log $D/${R}_real_session_timing.txt
 cp $S/soak.log $D/${R}_soak.txt
+for f in device_memory_probe end_to_end_cfg4 large_size_probe; do [ -s $S/$f.log ] && cp $S/$f.log $D/${R}_$f.txt; done
 for w in 2 8; do n=two; [ $w = 8 ] && n=eight; for c in cfg4 cfg5; do [ -s $S/ranks${w}_$c.json ] && tail -1 $S/ranks${w}_$c.json > $D/${R}_${n}_ranks_one_device_$c.json; done; done
 for c in cfg4 cfg5; do [ -s $S/shard_projection_$c.log ] && cp $S/shard_projection_$c.log $D/${R}_shard_projection_$c.txt; done
 { echo "GPU suite:"; tail -3 $S/tests.log; echo "smoke:"; tail -1 $S/smoke.log; echo "bench.py wall:"; cat $S/bench.time; echo "parity_at_size wall:"; cat $S/parity.time 2>/dev/null; } > $D/${R}_final_run.txt

@@ -4,13 +4,17 @@
 # the driver runs it (CPU baseline + parity legs), rocprofv3 kernel traces (cfg4, cfg5, cfg2+3) and the dispatch list of one iteration, HBM counters
 # (cfg4, cfg5; FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only), SQ counters (two passes each), phase clocks of the pair kernel and
 # stamps of the dense solve (profiling build), set-up timing, the reference's 4-camera session, the sharded protocol on one device (2 and 8 ranks,
-# cfg4 and cfg5), rank 0's shard alone for N = 1, 2, 4, 8 (tools/shard_projection.py), the soak (tools/soak.py) and LAST tools/parity_at_size.py.
+# cfg4 and cfg5), rank 0's shard alone for N = 1, 2, 4, 8 (tools/shard_projection.py), whose device memory it is (tools/device_memory_probe.py), a 40M-observation
+# solve (tools/large_size_probe.py), the soak (tools/soak.py); tools/parity_at_size.py runs right behind the bench line.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp PYTHONUNBUFFERED=1 CBA_GROUP_TIMEOUT_S=30
 O=$GRAFT_REPO_ROOT/gpurun_out/profile_run; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q --timeout=400 > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log; tail -4 $O/tests.log
 timeout 120 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 ( time timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err ) 2> $O/bench.time; tail -3 $O/bench.time; tail -c 300 $O/bench.json; echo
+# (parity_at_size right behind the bench line: the two carry the library digest that tests/test_bench_contract.py compares; a run cut short loses the tail, not these)
+[ "$1" = quick ] || ( time timeout 1500 python tools/parity_at_size.py $O/parity.json > $O/parity.log 2>&1 ) 2> $O/parity.time
+tail -3 $O/parity.time 2>/dev/null
 cd /tmp
 B=$GRAFT_REPO_ROOT/bench.py
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace_cfg4 -o t -- python $B --no-cpu --no-first-call --also "" --steps 20 --warmup 4 > $O/bench_cfg4.json 2> $O/trace_cfg4.err
@@ -38,6 +42,9 @@ CALISCOPE_BA_LIB=$P CBA_SCHUR_CLOCK=1 timeout 120 python tools/newton_probe.py c
 CALISCOPE_BA_LIB=$P CBA_CHOL_TRACE=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/chol_trace.log > /dev/null
 timeout 400 python tools/create_timing.py > $O/create_timing.log 2>&1
 timeout 200 python tools/real_session_timing.py > $O/real_session.log 2>&1
+timeout 200 python tools/device_memory_probe.py > $O/device_memory_probe.log 2>&1
+timeout 200 python tools/end_to_end.py cfg4 > $O/end_to_end_cfg4.log 2>&1
+timeout 400 python tools/large_size_probe.py > $O/large_size_probe.log 2>&1
 for w in 2 8; do
   devs=$(python -c "print(','.join(['0']*$w))")
   timeout 400 python bench.py --gpus $w --devices $devs --xchg direct --no-cpu --also "" --steps 20 --warmup 4 > $O/ranks${w}_cfg4.json 2> $O/ranks${w}_cfg4.err
@@ -46,5 +53,4 @@ done
 timeout 300 python tools/shard_projection.py cfg4 > $O/shard_projection_cfg4.log 2>&1
 timeout 600 python tools/shard_projection.py cfg5 > $O/shard_projection_cfg5.log 2>&1
 timeout 400 python tools/soak.py 60 > $O/soak.log 2>&1
-[ "$1" = quick ] || ( time timeout 1500 python tools/parity_at_size.py $O/parity.json > $O/parity.log 2>&1 ) 2> $O/parity.time
-tail -3 $O/parity.time 2>/dev/null; du -sh $O
+du -sh $O
