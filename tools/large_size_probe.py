@@ -40,7 +40,7 @@ _, last = bench.run_iterations(eng, steps, kw, "accepted")
 dt = time.perf_counter() - t
 acc = max(last.mix["accepted"], 1)
 print(f"{acc} accepted iterations ({last.mix['rejected']} rejected trials) in {dt * 1e3:.1f} ms: {dt / acc * 1e3:.2f} ms per iteration = "
-      f"{prob.n_obs / (dt / acc):.3e} observations/s per iteration (cfg5 at 10M: 4.48 ms = 2.23e9)", flush=True)
+      f"{prob.n_obs / (dt / acc):.3e} observations/s per iteration (cfg5 at 10M: 4.5 ms = 2.2e9)", flush=True)
 t = time.perf_counter()
 res = eng.solve(x0, **kw)
 dt = time.perf_counter() - t
