@@ -326,7 +326,8 @@ class CaptureVolume:
                 for s, _ in endpoints[1:]:
                     syncs = np.intersect1d(syncs, s)
                 syncs = syncs[syncs == STATIC_SYNC_INDEX] if is_static else syncs[syncs != STATIC_SYNC_INDEX]
-                return syncs, [r[np.searchsorted(s, syncs)] for s, r in endpoints]  # (sorted slice per keypoint)
+                # (sorted slice per keypoint; of duplicate world keys — the reference warns about them and goes on — the LAST row, as its dict of rows keeps)
+                return syncs, [r[np.searchsorted(s, syncs, side="right") - 1] for s, r in endpoints]
 
             for dc in con.distances:
                 a_static, b_static = dc.object_id_a in static_ids, dc.object_id_b in static_ids

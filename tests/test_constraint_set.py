@@ -318,3 +318,109 @@ def test_optimize_with_constraints_matches_scipy_on_the_oracle():
     assert pos < 1e-6 and ang < 1e-6 and abs(scale - 1) < 1e-6
     free = vol.optimize(use_constraints=False, _engine_factory=factory)
     assert out.rigidity_report().rmse_mm < free.rigidity_report().rmse_mm
+
+
+def _naive_constraint_rows(world_df, cs):
+    """The reference's rule restated with dicts and sets (core/capture_volume.py:446-531): a dict of rows per keypoint (a later row of the same key
+    overwrites an earlier one), a constraint fires at the sync indices all of its endpoint keypoints share — static-static ones at
+    STATIC_SYNC_INDEX only, mobile-mobile ones everywhere else, mixed ones never.  Returns {(kind, constraint index, sync): (rows_a, rows_b)}."""
+    lookup = {}
+    for row, (si, oid, kid) in enumerate(zip(world_df["sync_index"], world_df["object_id"], world_df["keypoint_id"])):
+        lookup.setdefault((int(oid), int(kid)), {})[int(si)] = row
+    static_ids, out = cs.static_object_ids, {}
+
+    def firing(is_static, tables):
+        if is_static:
+            return [STATIC_SYNC_INDEX] if all(STATIC_SYNC_INDEX in t for t in tables) else []
+        return [si for si in set.intersection(*(set(t) for t in tables)) if si != STATIC_SYNC_INDEX]
+
+    for n, dc in enumerate(cs.distances):
+        a_static, b_static = dc.object_id_a in static_ids, dc.object_id_b in static_ids
+        if a_static != b_static:
+            continue
+        ta, tb = lookup.get((dc.object_id_a, dc.keypoint_id_a), {}), lookup.get((dc.object_id_b, dc.keypoint_id_b), {})
+        for si in firing(a_static, (ta, tb)):
+            out[("d", n, si)] = ([ta[si]] * 4, [tb[si]] * 4)
+    for n, cc in enumerate(cs.centroid_distances):
+        a_static, b_static = cc.object_id_a in static_ids, cc.object_id_b in static_ids
+        if a_static != b_static:
+            continue
+        ca = [lookup.get((cc.object_id_a, k), {}) for k in range(4)]
+        cb = [lookup.get((cc.object_id_b, k), {}) for k in range(4)]
+        for si in firing(a_static, (*ca, *cb)):
+            out[("c", n, si)] = ([ca[k][si] for k in range(4)], [cb[k][si] for k in range(4)])
+    return out
+
+
+def _random_constraint_case(seed):
+    """Random objects (some static), frames with holes, shuffled rows, a few DUPLICATE world keys; distance and centroid constraints between random
+    keypoints, some of them mixing a static with a moving object, some naming keypoints that never appear."""
+    rng = np.random.default_rng(seed)
+    n_obj = int(rng.integers(2, 6))
+    static = {o for o in range(n_obj) if rng.random() < 0.3}
+    frames = sorted(rng.choice(40, size=int(rng.integers(3, 12)), replace=False).tolist())
+    world, img = [], []
+    for o in range(n_obj):
+        for k in range(4):
+            for si in ([STATIC_SYNC_INDEX] if o in static else frames):
+                if rng.random() < 0.2:
+                    continue  # a hole: the keypoint was not reconstructed here
+                for _ in range(2 if rng.random() < 0.05 else 1):  # now and then the same key twice
+                    world.append(dict(sync_index=si, object_id=o, keypoint_id=k, x_coord=rng.normal(), y_coord=rng.normal(), z_coord=rng.normal(),
+                                      frame_time=np.nan if o in static else si * 0.1))
+        for si in frames:  # every object is observed at every frame (static ones included: they look their point up at STATIC_SYNC_INDEX)
+            for k in range(4):
+                img.append(dict(sync_index=si, cam_id=0, object_id=o, keypoint_id=k, img_loc_x=200.0 + rng.normal(), img_loc_y=200.0 + rng.normal()))
+    order = rng.permutation(len(world))
+    world = [world[i] for i in order]
+    dist = tuple(DistanceConstraint(int(rng.integers(0, n_obj)), int(rng.integers(0, 5)), int(rng.integers(0, n_obj)), int(rng.integers(0, 5)),
+                                    float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.001, 0.01))) for _ in range(int(rng.integers(1, 12))))
+    cent = tuple(CentroidDistanceConstraint(int(a), int(b), float(rng.uniform(0.1, 2.0)), 0.005)
+                 for a, b in rng.integers(0, n_obj, size=(int(rng.integers(0, 4)), 2)) if a != b)
+    cs = ConstraintSet(dist, frozenset(static), centroid_distances=cent)
+    with _no_warning_filter():
+        return _volume(world, img, cs), cs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_firing_table_against_the_reference_rule_on_random_tables(seed):
+    vol, cs = _random_constraint_case(seed)
+    expected = _naive_constraint_rows(vol.world_points.df, cs)
+    got = {}
+    index_of = {id(c): ("d", n) for n, c in enumerate(cs.distances)} | {id(c): ("c", n) for n, c in enumerate(cs.centroid_distances)}
+    for c, si, rows_a, rows_b in vol._constraint_instances():
+        kind, n = index_of[id(c)]
+        assert (kind, n, si) not in got
+        got[(kind, n, si)] = (rows_a, rows_b)
+    assert got == expected
+    arrays = vol._build_constraint_arrays()
+    if not expected:
+        assert arrays is None
+        return
+    ga, gb, d, sig = arrays
+    assert ga.shape == gb.shape == (len(expected), 4) and ga.dtype == gb.dtype == np.int32
+    assert [r[2] for r in vol._constraint_instances()] == ga.tolist() and [r[3] for r in vol._constraint_instances()] == gb.tolist()
+    assert d.tolist() == [r[0].distance for r in vol._constraint_instances()] and sig.tolist() == [r[0].sigma for r in vol._constraint_instances()]
+
+
+def test_the_random_tables_exercise_something():
+    """Between them the twelve cases fire constraints, leave some silent and contain duplicate world keys."""
+    fired, dupes = [], 0
+    for seed in range(12):
+        vol, cs = _random_constraint_case(seed)
+        fired.append(len(_naive_constraint_rows(vol.world_points.df, cs)))
+        dupes += int(vol.world_points.df.duplicated(subset=["sync_index", "object_id", "keypoint_id"]).sum())
+    assert sum(fired) > 50 and dupes > 5, (fired, dupes)
+
+
+def _no_warning_filter():
+    import contextlib
+    import warnings
+
+    @contextlib.contextmanager
+    def ctx():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (duplicate keys are warned about by the tables, as in the reference)
+            yield
+
+    return ctx()
