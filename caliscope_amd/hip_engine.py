@@ -35,8 +35,9 @@ class HipEngine:
         """``evaluation_only``: residuals / costs only (``residuals``, ``begin``) — skips the Schur plan and the solver buffers.
         ``deterministic`` (default: the environment variable ``CBA_DETERMINISTIC=1``): the per-camera sums of the linearisation and of the
         Schur right-hand side are formed in a fixed order (the point-ordered k_build / k_tprep variants instead of the camera-sorted build), so
-        two solves of the same problem return the same bits, as the reference's single-threaded scipy does; ~15 % slower.  Limits, stated
-        rather than hidden: up to 227 cameras (``cba_create`` reports CBA_ERR_UNSUPPORTED beyond — it does not fall back silently), and
+        two solves of the same problem return the same bits, as the reference's single-threaded scipy does; 1.25x the default's time per iteration on
+        cfg4.  Limits, stated rather than hidden: up to 227 nine-parameter or 385 six-parameter cameras (``cba_create`` reports CBA_ERR_UNSUPPORTED
+        beyond — it does not fall back silently), and
         problems with constraint rows or heavy points (> 40 observations of one point) still add those few sums with FP64 atomics: they are
         reproducible to rounding, not bit for bit."""
         import os
@@ -88,6 +89,9 @@ class HipEngine:
         # cba_destroy synchronises the handle's stream: with a collective still enqueued and a dead peer it would wait for ever while holding the lock the
         # peer's comm_abort() needs.  So: the handle leaves the object under the lock, an abort that was REQUESTED meanwhile
         # (comm_abort's non-blocking path) is carried out here, on this thread, and only then the handle is destroyed — outside the lock.
+        # What this does NOT cover: an abort that is requested only after cba_destroy has begun finds no handle (touching it could be a use after
+        # free) — so owners abort BEFORE they close, which is the order solve_multi_device's failure path uses (a rank blocked in a collective is
+        # inside solve() and cannot be closing).
         lock = getattr(self, "_life", None)
         if lock is None:
             return
