@@ -27,7 +27,6 @@ import time
 import numpy as np
 
 from caliscope_amd.engine import BAProblem
-from caliscope_amd.exceptions import BackendError
 from caliscope_amd.sharding import Shard, shard_problem
 from caliscope_amd.engine import TrfResult
 

@@ -26,7 +26,6 @@ infeasible trial points).
 from __future__ import annotations
 
 import math
-import os
 import time
 
 import numpy as np

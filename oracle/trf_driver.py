@@ -31,8 +31,6 @@ observations is required.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-
 import numpy as np
 
 from caliscope_amd.engine import STATUS_REASONS, BAEngine, TrfResult  # noqa: F401 (re-exported for the tests)

@@ -12,8 +12,6 @@ import os
 import sys
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np
-
 hip = ctypes.CDLL("libamdhip64.so")
 last = [None]
 
