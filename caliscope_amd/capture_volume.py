@@ -364,6 +364,12 @@ class CaptureVolume:
                 np.repeat(np.array([b[0].distance for b in blocks], dtype=np.float64), n),
                 np.repeat(np.array([b[0].sigma for b in blocks], dtype=np.float64), n))
 
+    @property
+    def unique_sync_indices(self) -> np.ndarray:
+        """Sorted sync indices that have a world point (reference :933-941: the slider range of its viewers; STATIC_SYNC_INDEX included when
+        static points exist, as there)."""
+        return np.unique(self.world_points._df["sync_index"].to_numpy())
+
     def rigidity_report(self) -> RigidityReport:
         """Measured distance of every constraint instance with the current world points (no optimisation)."""
         xyz = self.world_points.points

@@ -1,0 +1,73 @@
+"""The host logic either side of the solve against OUTPUTS OF THE REFERENCE ITSELF: tests/golden/reference_host/case_*.npz hold random tables and
+what the reference's own ``CaptureVolume`` made of them in the build container (tests/golden/make_reference_host_fixtures.py runs its code
+unmodified, cv2 / rtoml stubbed because nothing on this path calls them) — the observation -> world-point map (core/capture_volume.py:119-139),
+the constraint rows (:446-516), the rigidity report (:532-605), the sync-index range.  Duplicate world keys, static objects, holes, observations
+without a point and constraints that cannot fire are all in the cases."""
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from caliscope_amd.cameras import CameraArray, CameraData
+from caliscope_amd.capture_volume import CaptureVolume
+from caliscope_amd.constraints import CentroidDistanceConstraint, ConstraintSet, DistanceConstraint
+from caliscope_amd.point_data import ImagePoints, WorldPoints
+
+CASES = sorted((Path(__file__).parent / "golden" / "reference_host").glob("case_*.npz"))
+WORLD_COLS = ["sync_index", "object_id", "keypoint_id", "x_coord", "y_coord", "z_coord", "frame_time"]
+IMG_COLS = ["sync_index", "cam_id", "object_id", "keypoint_id", "img_loc_x", "img_loc_y"]
+
+
+def _volume(ref):
+    wdf = pd.DataFrame(ref["world"], columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+    idf = pd.DataFrame(ref["image"], columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+    K = np.array([[400.0, 0.0, 200.0], [0.0, 400.0, 200.0], [0.0, 0.0, 1.0]])
+    cams = CameraArray({c: CameraData(cam_id=c, size=(400, 400), matrix=K.copy(), distortions=np.zeros(5), rotation=np.eye(3),
+                                      translation=np.array([0.1 * c, 0.0, 0.0])) for c in (0, 1)})
+    dist = tuple(DistanceConstraint(int(a), int(b), int(c), int(d), float(e), float(f)) for a, b, c, d, e, f in ref["distances"])
+    cent = tuple(CentroidDistanceConstraint(int(a), int(b), float(c), float(d)) for a, b, c, d in ref["centroids"])
+    cs = ConstraintSet(dist, frozenset(int(o) for o in ref["static_ids"]), centroid_distances=cent)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (duplicate keys and thin geometry are warned about, as in the reference)
+        return CaptureVolume(cams, ImagePoints(idf), WorldPoints(wdf), cs)
+
+
+def _sorted_rows(*columns):
+    n = len(columns[0])
+    if n == 0:
+        return np.zeros((0, 0))
+    rows = np.column_stack([np.asarray(c, dtype=np.float64).reshape(n, -1) for c in columns])
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def test_the_fixtures_are_there():
+    assert len(CASES) == 10
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.stem)
+def test_host_logic_equals_the_reference_s_own_output(path):
+    ref = np.load(path)
+    vol = _volume(ref)
+    # the tables keep the caller's row order (the map and the constraint rows are row numbers)
+    assert np.array_equal(vol.world_points.df[WORLD_COLS[:3]].to_numpy(), ref["world"][:, :3].astype(np.int64))
+    assert np.array_equal(vol.img_to_obj_map, ref["img_to_obj_map"])
+    arrays = vol._build_constraint_arrays()
+    assert (arrays is not None) == bool(ref["has_rows"])
+    if arrays is not None:
+        ga, gb, dist, sig = arrays
+        assert ga.dtype == gb.dtype == np.int32 and ga.shape == gb.shape == ref["groups_a"].shape
+        # the reference walks a SET of shared sync indices: the order of a constraint's rows is not defined there; the rows are
+        assert np.array_equal(_sorted_rows(ga, gb, dist, sig), _sorted_rows(ref["groups_a"], ref["groups_b"], ref["row_distance"], ref["row_sigma"]))
+    rep = vol.rigidity_report()
+    mine = np.array([[v.object_id_a, v.keypoint_id_a, v.object_id_b, v.keypoint_id_b, v.sync_index, 1 if v.kind == "centroid" else 0] for v in rep.violations],
+                    dtype=np.int64).reshape(-1, 6)
+    got = _sorted_rows(mine, [v.expected for v in rep.violations], [v.actual for v in rep.violations])
+    want = _sorted_rows(ref["violations"], ref["violation_expected"], ref["violation_actual"])
+    assert got.shape == want.shape
+    if len(got):
+        assert np.array_equal(got[:, :7], want[:, :7]) and np.allclose(got[:, 7], want[:, 7], rtol=0, atol=1e-12)
+    assert rep.rmse_mm == pytest.approx(float(ref["rmse_mm"]), abs=1e-9) and rep.max_violation_mm == pytest.approx(float(ref["max_violation_mm"]), abs=1e-9)
+    assert np.array_equal(vol.unique_sync_indices, ref["unique_sync_indices"])
+    assert (vol.world_points.min_index, vol.world_points.max_index) == tuple(int(v) for v in ref["world_min_max"])
