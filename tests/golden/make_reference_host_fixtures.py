@@ -10,7 +10,14 @@ Nothing of the reference is copied: the fixtures hold the random INPUT tables th
 
 Cases: two to five objects (some static), frames with holes, shuffled rows, now and then a DUPLICATE world key, observations without a world
 point, distance constraints between random keypoints (some mixing a static with a moving object, some naming keypoints that never appear)
-and centroid constraints.  Consumer: tests/test_reference_host_fixtures.py."""
+and centroid constraints.  Consumer: tests/test_reference_host_fixtures.py.
+
+Second family (``bundle_*.npz``): the reference's ``BundleParameterization`` (core/bundle_parameterization.py) on random camera arrays — sparse
+camera ids, unposed and ignored cameras, fisheye cameras beside pinhole ones, intrinsics locked or free: block table, offsets, ``pack``,
+``bounds``, ``unpack_into`` of a perturbed vector, ``bound_warnings``, ``intrinsic_estimates``, ``trial_projection_inputs``, the non-zero
+pattern of ``sparsity``.  ``CameraData.extrinsics_to_vector / extrinsics_from_vector`` (cameras/camera_array.py:115-133) call ``cv2.Rodrigues``;
+for this family the stub's ``Rodrigues`` is scipy's ``Rotation`` (rotation vector <-> matrix: the same map to ~1e-16, NOT OpenCV's code), so the
+rotation entries pin the LAYOUT of the vector and are compared at 1e-12, everything else exactly."""
 import sys
 import tempfile
 import types
@@ -32,6 +39,16 @@ def _stub_modules():
         raise AttributeError(f"cv2 stub: {name} (the fixture generator must not reach OpenCV)")
 
     cv2.__getattr__ = _missing
+
+    def rodrigues(a):  # (bundle_* family only: scipy's rotation-vector map in the place of OpenCV's, see the docstring)
+        from scipy.spatial.transform import Rotation
+
+        a = np.asarray(a, dtype=np.float64)
+        if a.shape == (3, 3):
+            return Rotation.from_matrix(a).as_rotvec().reshape(3, 1), None
+        return Rotation.from_rotvec(a.reshape(3)).as_matrix(), None
+
+    cv2.Rodrigues = rodrigues
     import tomli
 
     rtoml = types.ModuleType("rtoml")
@@ -118,5 +135,90 @@ def main():
               f"({int((out['img_to_obj_map'] < 0).sum())} unmatched), {len(dist)} + {len(cent)} constraints -> {len(out['row_distance'])} rows, static {static}")
 
 
+def random_camera_array(seed):
+    """Plain description of a camera array: list of dicts (cam_id, size, K, dist, fisheye, ignore, rvec / t or None)."""
+    rng = np.random.default_rng(5000 + seed)
+    ids = sorted(rng.choice(40, size=int(rng.integers(3, 8)), replace=False).tolist())
+    cams = []
+    for c in ids:
+        fisheye = bool(rng.random() < 0.25)
+        posed = bool(rng.random() < 0.85)
+        f = float(rng.uniform(300, 900))
+        cams.append(dict(cam_id=int(c), size=(int(rng.integers(320, 1920)), int(rng.integers(240, 1080))),
+                         K=[[f, 0.0, float(rng.uniform(100, 600))], [0.0, f * float(rng.uniform(0.98, 1.02)), float(rng.uniform(100, 400))], [0.0, 0.0, 1.0]],
+                         dist=rng.normal(0, 0.05, 4 if fisheye else 5).tolist(), fisheye=fisheye, ignore=bool(rng.random() < 0.15),
+                         rvec=rng.normal(0, 0.8, 3).tolist() if posed else None, t=rng.normal(0, 1.0, 3).tolist() if posed else None))
+    if sum(1 for c in cams if c["rvec"] is not None and not c["ignore"]) < 2:  # at least two cameras to optimise
+        for c in cams[:2]:
+            c["ignore"] = False
+            c["rvec"], c["t"] = rng.normal(0, 0.8, 3).tolist(), rng.normal(0, 1.0, 3).tolist()
+    return cams, bool(seed % 2), int(rng.integers(5, 30))
+
+
+def bundle_cases():
+    from scipy.spatial.transform import Rotation
+
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.bundle_parameterization import BundleParameterization
+
+    for case in range(8):
+        desc, refine, n_points = random_camera_array(case)
+        rng = np.random.default_rng(9000 + case)
+
+        def build():
+            return CameraArray({d["cam_id"]: CameraData(
+                cam_id=d["cam_id"], size=tuple(d["size"]), matrix=np.array(d["K"]), distortions=np.array(d["dist"]), fisheye=d["fisheye"], ignore=d["ignore"],
+                rotation=None if d["rvec"] is None else Rotation.from_rotvec(d["rvec"]).as_matrix(),
+                translation=None if d["t"] is None else np.array(d["t"])) for d in desc})
+
+        arr = build()
+        par = BundleParameterization.from_camera_array(arr, n_points, refine_intrinsics=refine)
+        pts = rng.normal(0, 1, (n_points, 3))
+        x0 = par.pack(arr, pts)
+        lb, ub = par.bounds()
+        x1 = x0 + rng.normal(0, 0.01, x0.size)
+        edge = []  # some free intrinsics onto / next to their bounds for bound_warnings
+        for i, b in enumerate(par.blocks):
+            if b.free_intrinsics:
+                off = par.camera_param_offsets[i] + 6
+                x1[off:off + 3] = [[0.5, 0.502, 1.0, 1.99, 2.0][int(rng.integers(0, 5))], [-1.0, -0.995, 0.3, 0.992, 1.0][int(rng.integers(0, 5))],
+                                   [-2.0, -1.991, 0.0, 1.995, 2.0][int(rng.integers(0, 5))]]
+                edge.append(i)
+        warns = par.bound_warnings(x1)
+        arr2 = build()
+        pts_back = par.unpack_into(arr2, x1.copy())
+        est = par.intrinsic_estimates(arr2)
+        n_obs = int(rng.integers(20, 60))
+        cam_idx = rng.integers(0, len(par.blocks), n_obs)
+        obj_idx = rng.integers(0, n_points, n_obs)
+        ga, gb = rng.integers(0, n_points, (4, 4)), rng.integers(0, n_points, (4, 4))
+        sp = par.sparsity(cam_idx, obj_idx, 4, ga, gb).tocoo()
+        trial = [par.trial_projection_inputs(x1, i) for i in range(len(par.blocks))]
+        blocks = np.array([[b.cam_id, int(b.free_intrinsics), b.fx_initial, b.fy_initial, b.cx, b.cy, int(b.fisheye), b.k1_initial, b.k2_initial, len(b.dist_fixed),
+                            *(list(b.dist_fixed) + [0.0] * (4 - len(b.dist_fixed)))] for b in par.blocks], dtype=np.float64)
+        opt_ids = [b.cam_id for b in par.blocks]
+        np.savez_compressed(
+            OUT / f"bundle_{case:02d}.npz",
+            cam_ids=np.array([d["cam_id"] for d in desc]), sizes=np.array([d["size"] for d in desc]), K=np.array([d["K"] for d in desc]),
+            dist=np.array([d["dist"] + [np.nan] * (5 - len(d["dist"])) for d in desc]), fisheye=np.array([d["fisheye"] for d in desc]),
+            ignore=np.array([d["ignore"] for d in desc]), posed=np.array([d["rvec"] is not None for d in desc]),
+            rvec=np.array([d["rvec"] if d["rvec"] is not None else [np.nan] * 3 for d in desc]), t=np.array([d["t"] if d["t"] is not None else [np.nan] * 3 for d in desc]),
+            refine=np.array(refine), n_points=np.array(n_points), points=pts,
+            blocks=blocks, offsets=np.array(par.camera_param_offsets), n_camera_params=np.array(par.n_camera_params), x0=x0, lb=lb, ub=ub, x1=x1,
+            warnings=np.array([[w.cam_id, {"f": 0, "k1": 1, "k2": 2}[w.parameter], {"lower": 0, "upper": 1}[w.bound], w.value] for w in warns], dtype=np.float64).reshape(-1, 4),
+            unpacked_R=np.array([arr2.cameras[c].rotation for c in opt_ids]), unpacked_t=np.array([np.ravel(arr2.cameras[c].translation) for c in opt_ids]),
+            unpacked_K=np.array([arr2.cameras[c].matrix for c in opt_ids]),
+            unpacked_dist=np.array([list(np.ravel(arr2.cameras[c].distortions)) + [np.nan] * (5 - np.size(arr2.cameras[c].distortions)) for c in opt_ids]),
+            points_back=np.asarray(pts_back),
+            estimates=np.array([[e.cam_id, e.f_recovered, e.k1_recovered, e.k2_recovered, e.f_initial, e.k1_initial, e.k2_initial] for e in est], dtype=np.float64).reshape(-1, 7),
+            cam_idx=cam_idx, obj_idx=obj_idx, groups_a=ga, groups_b=gb, sparsity_shape=np.array(sp.shape), sparsity_rows=sp.row[sp.data != 0], sparsity_cols=sp.col[sp.data != 0],
+            trial_rvec=np.array([t[0] for t in trial]), trial_tvec=np.array([t[1] for t in trial]), trial_K=np.array([t[2] for t in trial]),
+            trial_dist=np.array([list(t[3]) + [np.nan] * (5 - len(t[3])) for t in trial]),
+        )
+        print(f"bundle {case}: cameras {[d['cam_id'] for d in desc]} -> optimised {opt_ids}, refine {refine}, {par.n_camera_params} camera parameters, "
+              f"{len(warns)} bound warnings, {len(est)} estimates, sparsity {sp.shape} with {int((sp.data != 0).sum())} non-zeros")
+
+
 if __name__ == "__main__":
     main()
+    bundle_cases()

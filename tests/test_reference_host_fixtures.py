@@ -71,3 +71,70 @@ def test_host_logic_equals_the_reference_s_own_output(path):
     assert rep.rmse_mm == pytest.approx(float(ref["rmse_mm"]), abs=1e-9) and rep.max_violation_mm == pytest.approx(float(ref["max_violation_mm"]), abs=1e-9)
     assert np.array_equal(vol.unique_sync_indices, ref["unique_sync_indices"])
     assert (vol.world_points.min_index, vol.world_points.max_index) == tuple(int(v) for v in ref["world_min_max"])
+
+
+# ---- the parameterization (core/bundle_parameterization.py) on random camera arrays -----------------------------------------------------
+BUNDLES = sorted((Path(__file__).parent / "golden" / "reference_host").glob("bundle_*.npz"))
+
+
+def _camera_array(ref):
+    from caliscope_amd.cameras import rvec_to_matrix
+
+    cams = {}
+    for i, cid in enumerate(ref["cam_ids"]):
+        fisheye = bool(ref["fisheye"][i])
+        dist = ref["dist"][i][: 4 if fisheye else 5]
+        posed = bool(ref["posed"][i])
+        cams[int(cid)] = CameraData(cam_id=int(cid), size=(int(ref["sizes"][i][0]), int(ref["sizes"][i][1])), matrix=ref["K"][i].copy(), distortions=dist.copy(),
+                                    fisheye=fisheye, ignore=bool(ref["ignore"][i]), rotation=rvec_to_matrix(ref["rvec"][i]) if posed else None,
+                                    translation=ref["t"][i].copy() if posed else None)
+    return CameraArray(cams)
+
+
+def test_the_parameterization_fixtures_are_there():
+    assert len(BUNDLES) == 8
+
+
+@pytest.mark.parametrize("path", BUNDLES, ids=lambda p: p.stem)
+def test_parameterization_equals_the_reference_s_own_output(path):
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+
+    ref = np.load(path)
+    arr = _camera_array(ref)
+    par = BundleParameterization.from_camera_array(arr, int(ref["n_points"]), refine_intrinsics=bool(ref["refine"]))
+    blocks = np.array([[b.cam_id, int(b.free_intrinsics), b.fx_initial, b.fy_initial, b.cx, b.cy, int(b.fisheye), b.k1_initial, b.k2_initial, len(b.dist_fixed),
+                        *(list(b.dist_fixed) + [0.0] * (4 - len(b.dist_fixed)))] for b in par.blocks], dtype=np.float64)
+    assert np.array_equal(blocks, ref["blocks"])  # which cameras, in which order, what is free, every constant — exactly
+    assert np.array_equal(par.camera_param_offsets, ref["offsets"]) and par.n_camera_params == int(ref["n_camera_params"])
+    x0 = par.pack(arr, ref["points"])
+    assert x0.shape == ref["x0"].shape
+    rot = np.zeros(x0.size, dtype=bool)  # entries that went through a rotation-vector conversion (scipy's on the reference's side: docstring of the generator)
+    for off in par.camera_param_offsets:
+        rot[off:off + 3] = True
+    assert np.array_equal(x0[~rot], ref["x0"][~rot]) and np.allclose(x0[rot], ref["x0"][rot], rtol=0, atol=1e-12)
+    lb, ub = par.bounds()
+    assert np.array_equal(lb, ref["lb"]) and np.array_equal(ub, ref["ub"])
+    x1 = ref["x1"]
+    got = sorted((w.cam_id, {"f": 0, "k1": 1, "k2": 2}[w.parameter], {"lower": 0, "upper": 1}[w.bound], w.value) for w in par.bound_warnings(x1))
+    want = sorted(tuple(r) for r in ref["warnings"].tolist())
+    assert len(got) == len(want) and all(g[:3] == tuple(int(v) for v in w[:3]) and g[3] == w[3] for g, w in zip(got, want))
+    arr2 = _camera_array(ref)
+    pts_back = par.unpack_into(arr2, x1.copy())
+    assert np.array_equal(pts_back, ref["points_back"])
+    for k, b in enumerate(par.blocks):
+        cam = arr2.cameras[b.cam_id]
+        assert np.allclose(cam.rotation, ref["unpacked_R"][k], rtol=0, atol=1e-12) and np.array_equal(np.ravel(cam.translation), ref["unpacked_t"][k])
+        assert np.array_equal(cam.matrix, ref["unpacked_K"][k])
+        d = np.ravel(cam.distortions)
+        assert np.array_equal(d, ref["unpacked_dist"][k][: d.size]) and np.all(np.isnan(ref["unpacked_dist"][k][d.size:]))
+    est = np.array([[e.cam_id, e.f_recovered, e.k1_recovered, e.k2_recovered, e.f_initial, e.k1_initial, e.k2_initial] for e in par.intrinsic_estimates(arr2)],
+                   dtype=np.float64).reshape(-1, 7)
+    assert np.array_equal(est, ref["estimates"])
+    for k in range(len(par.blocks)):
+        rvec, tvec, K, dist = par.trial_projection_inputs(x1, k)
+        assert np.array_equal(rvec, ref["trial_rvec"][k]) and np.array_equal(tvec, ref["trial_tvec"][k]) and np.array_equal(K, ref["trial_K"][k])
+        assert np.array_equal(np.ravel(dist), ref["trial_dist"][k][: np.size(dist)]) and np.all(np.isnan(ref["trial_dist"][k][np.size(dist):]))
+    sp = par.sparsity(ref["cam_idx"], ref["obj_idx"], 4, ref["groups_a"], ref["groups_b"]).tocoo()
+    assert tuple(sp.shape) == tuple(int(v) for v in ref["sparsity_shape"])
+    mine = set(zip(sp.row[sp.data != 0].tolist(), sp.col[sp.data != 0].tolist()))
+    assert mine == set(zip(ref["sparsity_rows"].tolist(), ref["sparsity_cols"].tolist()))
