@@ -17,7 +17,10 @@ camera ids, unposed and ignored cameras, fisheye cameras beside pinhole ones, in
 ``bounds``, ``unpack_into`` of a perturbed vector, ``bound_warnings``, ``intrinsic_estimates``, ``trial_projection_inputs``, the non-zero
 pattern of ``sparsity``.  ``CameraData.extrinsics_to_vector / extrinsics_from_vector`` (cameras/camera_array.py:115-133) call ``cv2.Rodrigues``;
 for this family the stub's ``Rodrigues`` is scipy's ``Rotation`` (rotation vector <-> matrix: the same map to ~1e-16, NOT OpenCV's code), so the
-rotation entries pin the LAYOUT of the vector and are compared at 1e-12, everything else exactly."""
+rotation entries pin the LAYOUT of the vector and are compared at 1e-12, everything else exactly.
+
+Third family (``tables_*.npz``): the reference's point tables (core/point_data.py) on random tracks with holes: validation (column set and order,
+optional columns), ``fill_gaps`` at three gap sizes for image and world points, ``WorldPoints.smooth``, the CSV round trip, ``filter_to_objects``."""
 import sys
 import tempfile
 import types
@@ -219,6 +222,64 @@ def bundle_cases():
               f"{len(warns)} bound warnings, {len(est)} estimates, sparsity {sp.shape} with {int((sp.data != 0).sum())} non-zeros")
 
 
+def random_tracks(seed):
+    """(image rows, world rows) with tracks that have holes of one to six frames and single stray samples."""
+    rng = np.random.default_rng(7000 + seed)
+    frames = np.arange(int(rng.integers(25, 60)))
+    img, world = [], []
+    for obj in range(int(rng.integers(1, 3))):
+        for kp in range(int(rng.integers(2, 6))):
+            present = np.ones(frames.size, dtype=bool)
+            for _ in range(int(rng.integers(1, 5))):
+                a = int(rng.integers(0, frames.size - 1))
+                present[a:a + int(rng.integers(1, 7))] = False
+            track = np.cumsum(rng.normal(0, 0.02, (frames.size, 3)), axis=0) + rng.normal(0, 1, 3)
+            for f in frames[present]:
+                world.append((int(f), obj, kp, *track[f].tolist(), f / 30.0))
+            for cam in range(int(rng.integers(1, 4))):
+                seen = present & (rng.random(frames.size) < 0.9)
+                uv = np.cumsum(rng.normal(0, 1.5, (frames.size, 2)), axis=0) + rng.uniform(100, 500, 2)
+                for f in frames[seen]:
+                    img.append((int(f), cam, obj, kp, *uv[f].tolist()))
+    return [img[i] for i in rng.permutation(len(img))], [world[i] for i in rng.permutation(len(world))]
+
+
+def table_cases():
+    from caliscope.core.point_data import ImagePoints, WorldPoints
+
+    for case in range(6):
+        img, world = random_tracks(case)
+        idf = pd.DataFrame(img, columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        ip, wp = ImagePoints(idf), WorldPoints(wdf)
+        out = dict(image=idf.to_numpy(dtype=np.float64), world=wdf.to_numpy(dtype=np.float64))
+        out["image_columns"] = np.array(list(ip.df.columns))
+        out["world_columns"] = np.array(list(wp.df.columns))
+        out["image_validated"] = ip.df.to_numpy(dtype=np.float64)
+        out["world_validated"] = wp.df.to_numpy(dtype=np.float64)
+        for gap in (1, 3, 5):
+            fi, fw = ip.fill_gaps(gap).df, wp.fill_gaps(gap).df  # (the reference's filled frames carry its helper column `gap_size` along)
+            out[f"image_filled_{gap}"], out[f"image_filled_{gap}_columns"] = fi.to_numpy(dtype=np.float64), np.array(list(fi.columns))
+            out[f"world_filled_{gap}"], out[f"world_filled_{gap}_columns"] = fw.to_numpy(dtype=np.float64), np.array(list(fw.columns))
+        out["world_smoothed"] = wp.smooth(fps=30.0, cutoff_freq=6.0, order=2).df.to_numpy(dtype=np.float64)
+        out["world_smoothed_o3"] = wp.smooth(fps=60.0, cutoff_freq=4.0, order=3).df.to_numpy(dtype=np.float64)
+        # (smooth() of a gap-filled table raises inside the reference — its filled frame keeps a repeated index —, so that chain is not a fixture)
+        with tempfile.TemporaryDirectory() as tmp:
+            ip.to_csv(Path(tmp) / "xy.csv")
+            wp.to_csv(Path(tmp) / "xyz.csv")
+            out["image_csv"] = np.array((Path(tmp) / "xy.csv").read_text())
+            out["world_csv"] = np.array((Path(tmp) / "xyz.csv").read_text())
+            out["image_csv_back"] = ImagePoints.from_csv(Path(tmp) / "xy.csv").df.to_numpy(dtype=np.float64)
+            out["world_csv_back"] = WorldPoints.from_csv(Path(tmp) / "xyz.csv").df.to_numpy(dtype=np.float64)
+        keep = sorted(set(int(o) for o in idf["object_id"]))[:1]
+        out["kept_objects"] = np.array(keep)
+        out["image_filtered"] = ip.filter_to_objects(keep).df.to_numpy(dtype=np.float64)
+        np.savez_compressed(OUT / f"tables_{case:02d}.npz", **out)
+        print(f"tables {case}: {len(idf)} observations -> {len(out['image_filled_3'])} filled (gap 3), {len(wdf)} world rows -> {len(out['world_filled_3'])}; "
+              f"columns {list(ip.df.columns)} / {list(wp.df.columns)}")
+
+
 if __name__ == "__main__":
     main()
     bundle_cases()
+    table_cases()

@@ -138,3 +138,48 @@ def test_parameterization_equals_the_reference_s_own_output(path):
     assert tuple(sp.shape) == tuple(int(v) for v in ref["sparsity_shape"])
     mine = set(zip(sp.row[sp.data != 0].tolist(), sp.col[sp.data != 0].tolist()))
     assert mine == set(zip(ref["sparsity_rows"].tolist(), ref["sparsity_cols"].tolist()))
+
+
+# ---- the point tables (core/point_data.py) on random tracks with holes --------------------------------------------------------------------
+TABLES = sorted((Path(__file__).parent / "golden" / "reference_host").glob("tables_*.npz"))
+
+
+def _same_table(df, want, columns):
+    """Same columns in the same order, same rows in the same order; NaN equals NaN."""
+    assert list(df.columns) == list(columns), (list(df.columns), list(columns))
+    got = df.to_numpy(dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True), float(np.nanmax(np.abs(got - want)))
+
+
+def test_the_table_fixtures_are_there():
+    assert len(TABLES) == 6
+
+
+@pytest.mark.parametrize("path", TABLES, ids=lambda p: p.stem)
+def test_point_tables_equal_the_reference_s_own_output(path, tmp_path):
+    ref = np.load(path)
+    icols, wcols = [str(c) for c in ref["image_columns"]], [str(c) for c in ref["world_columns"]]
+    idf = pd.DataFrame(ref["image"], columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+    wdf = pd.DataFrame(ref["world"], columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+    ip, wp = ImagePoints(idf), WorldPoints(wdf)
+    _same_table(ip.df, ref["image_validated"], icols)  # optional columns added, column order
+    _same_table(wp.df, ref["world_validated"], wcols)
+    for gap in (1, 3, 5):
+        for mine, key, cols in ((ip.fill_gaps(gap).df, f"image_filled_{gap}", icols), (wp.fill_gaps(gap).df, f"world_filled_{gap}", wcols)):
+            theirs = [str(c) for c in ref[key + "_columns"]]
+            assert set(theirs) - set(cols) <= {"gap_size"}  # the reference's filled frame drags its helper column along; the schema columns are compared
+            _same_table(mine, ref[key][:, [theirs.index(c) for c in cols]], cols)
+    _same_table(wp.smooth(fps=30.0, cutoff_freq=6.0, order=2).df, ref["world_smoothed"], wcols)
+    _same_table(wp.smooth(fps=60.0, cutoff_freq=4.0, order=3).df, ref["world_smoothed_o3"], wcols)
+    _same_table(ip.filter_to_objects([int(o) for o in ref["kept_objects"]]).df, ref["image_filtered"], icols)
+    # on-disk format: what the reference wrote is read back to the same table, and what this package writes is what the reference wrote
+    (tmp_path / "ref_xy.csv").write_text(str(ref["image_csv"]))
+    (tmp_path / "ref_xyz.csv").write_text(str(ref["world_csv"]))
+    _same_table(ImagePoints.from_csv(tmp_path / "ref_xy.csv").df, ref["image_csv_back"], icols)
+    _same_table(WorldPoints.from_csv(tmp_path / "ref_xyz.csv").df, ref["world_csv_back"], wcols)
+    ip.to_csv(tmp_path / "xy.csv")
+    wp.to_csv(tmp_path / "xyz.csv")
+    assert (tmp_path / "xy.csv").read_text() == str(ref["image_csv"])
+    assert (tmp_path / "xyz.csv").read_text() == str(ref["world_csv"])
