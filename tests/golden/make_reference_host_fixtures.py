@@ -20,7 +20,11 @@ for this family the stub's ``Rodrigues`` is scipy's ``Rotation`` (rotation vecto
 rotation entries pin the LAYOUT of the vector and are compared at 1e-12, everything else exactly.
 
 Third family (``tables_*.npz``): the reference's point tables (core/point_data.py) on random tracks with holes: validation (column set and order,
-optional columns), ``fill_gaps`` at three gap sizes for image and world points, ``WorldPoints.smooth``, the CSV round trip, ``filter_to_objects``."""
+optional columns), ``fill_gaps`` at three gap sizes for image and world points, ``WorldPoints.smooth``, the CSV round trip, ``filter_to_objects``.
+
+Fourth family (``interop_*.npz``): on-disk formats in the direction a user migrates — directories written by THIS package's ``CaptureVolume.save()``
+(camera_array.toml, image_points.csv, world_points.csv, constraints.toml) read by the reference's ``CaptureVolume.load()``; the fixture holds the
+file texts and every field the reference's loaders returned (rotation vectors through the same scipy ``Rodrigues`` as above)."""
 import sys
 import tempfile
 import types
@@ -279,7 +283,86 @@ def table_cases():
               f"columns {list(ip.df.columns)} / {list(wp.df.columns)}")
 
 
+def interop_cases():
+    """A directory written by THIS package's ``CaptureVolume.save()`` and read by the REFERENCE's ``CaptureVolume.load()`` (core/capture_volume.py:253-267:
+    ``CameraArray.from_toml``, the two CSV readers, ``ConstraintSet.from_toml``): the file texts and what the reference made of them."""
+    sys.path.insert(0, str(HERE.parent.parent))
+    from scipy.spatial.transform import Rotation
+
+    import caliscope_amd.cameras as my_cam
+    import caliscope_amd.capture_volume as my_cv
+    import caliscope_amd.constraints as my_con
+    import caliscope_amd.point_data as my_pd
+    from caliscope.core.capture_volume import CaptureVolume as RefVolume
+
+    for case in range(6):
+        desc, _, _ = random_camera_array(100 + case)
+        rng = np.random.default_rng(11000 + case)
+        for d in desc[:2]:  # the volume needs posed cameras 0 / 1 of the random tables: rename the first two, posed and active
+            d["ignore"] = False
+            if d["rvec"] is None:
+                d["rvec"], d["t"] = rng.normal(0, 0.5, 3).tolist(), rng.normal(0, 1, 3).tolist()
+        desc[0]["cam_id"], desc[1]["cam_id"] = 0, 1
+        extras = {d["cam_id"]: dict(rotation_count=int(rng.integers(0, 4)), error=[None, float(rng.uniform(0.1, 2))][int(rng.integers(0, 2))],
+                                    exposure=[None, int(rng.integers(-8, 0))][int(rng.integers(0, 2))], grid_count=[None, int(rng.integers(5, 60))][int(rng.integers(0, 2))])
+                  for d in desc}
+        cams = my_cam.CameraArray({d["cam_id"]: my_cam.CameraData(
+            cam_id=d["cam_id"], size=tuple(d["size"]), matrix=np.array(d["K"]), distortions=np.array(d["dist"]), fisheye=d["fisheye"], ignore=d["ignore"],
+            rotation=None if d["rvec"] is None else Rotation.from_rotvec(d["rvec"]).as_matrix(), translation=None if d["t"] is None else np.array(d["t"]),
+            **extras[d["cam_id"]]) for d in desc})
+        world, img, dist, cent, static = random_tables(200 + case)
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        idf = pd.DataFrame(img, columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+        remaps = tuple(my_con.PointRemap(int(rng.integers(0, 3)), int(rng.integers(0, 4)), int(rng.integers(3, 6)), int(rng.integers(0, 4)),
+                                         float(rng.normal()), float(rng.normal()), 0.0) for _ in range(int(rng.integers(0, 3))))
+        cs = my_con.ConstraintSet(tuple(my_con.DistanceConstraint(*d) for d in dist), frozenset(static),
+                                  centroid_distances=tuple(my_con.CentroidDistanceConstraint(*c) for c in cent), point_remaps=remaps,
+                                  back_face_thickness_m=[None, 0.004][case % 2]) if case != 3 else None  # (one volume without constraints: no file)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mine = my_cv.CaptureVolume(cams, my_pd.ImagePoints(idf), my_pd.WorldPoints(wdf), cs)
+            with tempfile.TemporaryDirectory() as tmp:
+                mine.save(tmp)
+                files = {f.name: f.read_text() for f in sorted(Path(tmp).iterdir())}
+                ref = RefVolume.load(tmp)
+        ids = sorted(ref.camera_array.cameras)
+        nan3, nan5 = [np.nan] * 3, [np.nan] * 5
+
+        def opt(v):
+            return np.nan if v is None else float(v)
+
+        out = dict(
+            file_names=np.array(list(files)), file_texts=np.array(list(files.values())),
+            cam_ids=np.array(ids), sizes=np.array([ref.camera_array.cameras[c].size for c in ids]),
+            rotation_count=np.array([ref.camera_array.cameras[c].rotation_count for c in ids]),
+            error=np.array([opt(ref.camera_array.cameras[c].error) for c in ids]), exposure=np.array([opt(ref.camera_array.cameras[c].exposure) for c in ids]),
+            grid_count=np.array([opt(ref.camera_array.cameras[c].grid_count) for c in ids]),
+            ignore=np.array([bool(ref.camera_array.cameras[c].ignore) for c in ids]), fisheye=np.array([bool(ref.camera_array.cameras[c].fisheye) for c in ids]),
+            K=np.array([ref.camera_array.cameras[c].matrix for c in ids]),
+            dist=np.array([list(np.ravel(ref.camera_array.cameras[c].distortions)) + [np.nan] * (5 - np.size(ref.camera_array.cameras[c].distortions)) for c in ids]),
+            posed=np.array([ref.camera_array.cameras[c].rotation is not None for c in ids]),
+            R=np.array([ref.camera_array.cameras[c].rotation if ref.camera_array.cameras[c].rotation is not None else np.full((3, 3), np.nan) for c in ids]),
+            t=np.array([np.ravel(ref.camera_array.cameras[c].translation) if ref.camera_array.cameras[c].translation is not None else nan3 for c in ids]),
+            image=ref.image_points.df.to_numpy(dtype=np.float64), image_columns=np.array(list(ref.image_points.df.columns)),
+            world=ref.world_points.df.to_numpy(dtype=np.float64), world_columns=np.array(list(ref.world_points.df.columns)),
+            img_to_obj_map=np.asarray(ref.img_to_obj_map, dtype=np.int64), has_constraints=np.array(ref.constraints is not None),
+        )
+        if ref.constraints is not None:
+            rc = ref.constraints
+            out.update(
+                distances=np.array([[d.object_id_a, d.keypoint_id_a, d.object_id_b, d.keypoint_id_b, d.distance, d.sigma] for d in rc.distances], dtype=np.float64).reshape(-1, 6),
+                centroids=np.array([[c.object_id_a, c.object_id_b, c.distance, c.sigma] for c in rc.centroid_distances], dtype=np.float64).reshape(-1, 4),
+                static_ids=np.array(sorted(rc.static_object_ids), dtype=np.int64),
+                remaps=np.array([[r.object_id_from, r.keypoint_id_from, r.object_id_to, r.keypoint_id_to, r.obj_loc_x, r.obj_loc_y, r.obj_loc_z] for r in rc.point_remaps],
+                                dtype=np.float64).reshape(-1, 7),
+                thickness=np.array(np.nan if rc.back_face_thickness_m is None else rc.back_face_thickness_m))
+        np.savez_compressed(OUT / f"interop_{case:02d}.npz", **out)
+        print(f"interop {case}: files {list(files)}, cameras {ids} ({int(out['posed'].sum())} posed), {len(out['image'])} observations, "
+              f"{'no constraints' if ref.constraints is None else str(len(out['distances'])) + ' + ' + str(len(out['centroids'])) + ' constraints, ' + str(len(out['remaps'])) + ' remaps'}")
+
+
 if __name__ == "__main__":
     main()
     bundle_cases()
     table_cases()
+    interop_cases()

@@ -183,3 +183,77 @@ def test_point_tables_equal_the_reference_s_own_output(path, tmp_path):
     wp.to_csv(tmp_path / "xyz.csv")
     assert (tmp_path / "xy.csv").read_text() == str(ref["image_csv"])
     assert (tmp_path / "xyz.csv").read_text() == str(ref["world_csv"])
+
+
+# ---- on-disk formats: directories written by this package, read by the reference's CaptureVolume.load() ---------------------------------------
+INTEROP = sorted((Path(__file__).parent / "golden" / "reference_host").glob("interop_*.npz"))
+
+
+def test_the_interop_fixtures_are_there():
+    assert len(INTEROP) == 6
+
+
+@pytest.mark.parametrize("path", INTEROP, ids=lambda p: p.stem)
+def test_saved_volumes_read_as_the_reference_read_them(path, tmp_path):
+    """The fixture's files were written by ``CaptureVolume.save()`` of this package and loaded by the reference's ``CaptureVolume.load()``; here the
+    same files go through this package's loader, which must return what the reference's returned, field by field — and saving the loaded volume
+    again must reproduce the files byte for byte."""
+    ref = np.load(path)
+    src = tmp_path / "saved"
+    src.mkdir()
+    for name, text in zip(ref["file_names"], ref["file_texts"]):
+        (src / str(name)).write_text(str(text))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vol = CaptureVolume.load(src)
+    ids = sorted(vol.camera_array.cameras)
+    assert ids == ref["cam_ids"].tolist()
+
+    def opt(v):
+        return np.nan if v is None else float(v)
+
+    for k, c in enumerate(ids):
+        cam = vol.camera_array.cameras[c]
+        assert tuple(cam.size) == tuple(ref["sizes"][k]) and cam.rotation_count == ref["rotation_count"][k]
+        for mine, theirs in ((opt(cam.error), ref["error"][k]), (opt(cam.exposure), ref["exposure"][k]), (opt(cam.grid_count), ref["grid_count"][k])):
+            assert (np.isnan(mine) and np.isnan(theirs)) or mine == theirs
+        assert bool(cam.ignore) == bool(ref["ignore"][k]) and bool(cam.fisheye) == bool(ref["fisheye"][k])
+        assert np.array_equal(cam.matrix, ref["K"][k])
+        d = np.ravel(cam.distortions)
+        assert np.array_equal(d, ref["dist"][k][: d.size]) and np.all(np.isnan(ref["dist"][k][d.size:]))
+        assert (cam.rotation is not None) == bool(ref["posed"][k])
+        if cam.rotation is not None:
+            assert np.allclose(cam.rotation, ref["R"][k], rtol=0, atol=1e-12) and np.array_equal(np.ravel(cam.translation), ref["t"][k])
+    _same_table(vol.image_points.df, ref["image"], [str(c) for c in ref["image_columns"]])
+    _same_table(vol.world_points.df, ref["world"], [str(c) for c in ref["world_columns"]])
+    assert np.array_equal(vol.img_to_obj_map, ref["img_to_obj_map"])
+    assert (vol.constraints is not None) == bool(ref["has_constraints"])
+    if vol.constraints is not None:
+        cs = vol.constraints
+        mine = np.array([[d.object_id_a, d.keypoint_id_a, d.object_id_b, d.keypoint_id_b, d.distance, d.sigma] for d in cs.distances], dtype=np.float64).reshape(-1, 6)
+        assert np.array_equal(mine, ref["distances"])
+        mine = np.array([[c.object_id_a, c.object_id_b, c.distance, c.sigma] for c in cs.centroid_distances], dtype=np.float64).reshape(-1, 4)
+        assert np.array_equal(mine, ref["centroids"])
+        assert sorted(cs.static_object_ids) == ref["static_ids"].tolist()
+        mine = np.array([[r.object_id_from, r.keypoint_id_from, r.object_id_to, r.keypoint_id_to, r.obj_loc_x, r.obj_loc_y, r.obj_loc_z] for r in cs.point_remaps],
+                        dtype=np.float64).reshape(-1, 7)
+        assert np.array_equal(mine, ref["remaps"])
+        assert (cs.back_face_thickness_m is None and np.isnan(ref["thickness"])) or cs.back_face_thickness_m == float(ref["thickness"])
+    again = tmp_path / "again"
+    vol.save(again)
+    assert sorted(f.name for f in again.iterdir()) == sorted(str(n) for n in ref["file_names"])
+    for name, text in zip(ref["file_names"], ref["file_texts"]):
+        if str(name) == "camera_array.toml":  # (rotations go matrix -> vector -> matrix -> vector: equal to rounding, compared as numbers below)
+            continue
+        assert (again / str(name)).read_text() == str(text), str(name)
+    import tomli
+
+    a, b = tomli.loads((again / "camera_array.toml").read_text()), tomli.loads(str(ref["file_texts"][list(ref["file_names"]).index("camera_array.toml")]))
+    assert a.keys() == b.keys() and a["cameras"].keys() == b["cameras"].keys()
+    for cid, entry in b["cameras"].items():
+        assert a["cameras"][cid].keys() == entry.keys()
+        for key, value in entry.items():
+            if isinstance(value, list):
+                assert np.allclose(np.array(a["cameras"][cid][key], dtype=np.float64), np.array(value, dtype=np.float64), rtol=0, atol=1e-12), (cid, key)
+            else:
+                assert a["cameras"][cid][key] == value, (cid, key)
