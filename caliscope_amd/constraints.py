@@ -107,10 +107,12 @@ class ConstraintSet:
     @staticmethod
     def _truss_distance_constraints(corners, spacing: float, sigma_m: float, object_id: int = 0) -> tuple[DistanceConstraint, ...]:
         """Distance rows of one grid face (reference ``constraints.py:217-308``)."""
-        corners = np.asarray(corners, dtype=np.float64)
-        edges = _grid_edges(corners, spacing)
-        length = np.linalg.norm(corners[edges[:, 0]] - corners[edges[:, 1]], axis=1)
-        return tuple(DistanceConstraint(object_id, int(a), object_id, int(b), float(d), sigma_m) for (a, b), d in zip(edges, length))
+        given = np.asarray(corners)
+        edges = _grid_edges(np.asarray(given, dtype=np.float64), spacing)
+        # lengths in the corners' OWN precision, pair by pair, as the reference forms them (:299): OpenCV boards and Chessboard.get_object_points hand
+        # over float32 corners, and a float64 norm of the same numbers differs in the eighth digit (a nanometre — but the compiled set is compared, and
+        # persisted, as numbers: tests/golden/reference_host/compilers_*.npz)
+        return tuple(DistanceConstraint(object_id, int(a), object_id, int(b), float(np.linalg.norm(given[a] - given[b])), sigma_m) for a, b in edges)
 
     @staticmethod
     def _cross_face_constraints(corners, spacing: float, thickness_m: float, sigma_m: float) -> tuple[DistanceConstraint, ...]:

@@ -24,7 +24,10 @@ optional columns), ``fill_gaps`` at three gap sizes for image and world points, 
 
 Fourth family (``interop_*.npz``): on-disk formats in the direction a user migrates — directories written by THIS package's ``CaptureVolume.save()``
 (camera_array.toml, image_points.csv, world_points.csv, constraints.toml) read by the reference's ``CaptureVolume.load()``; the fixture holds the
-file texts and every field the reference's loaders returned (rotation vectors through the same scipy ``Rodrigues`` as above)."""
+file texts and every field the reference's loaders returned (rotation vectors through the same scipy ``Rodrigues`` as above).
+
+Fifth family (``compilers_*.npz``): the constraint compilers ``ConstraintSet.from_marker_set`` and ``from_chessboard`` on random marker sets and boards
+(see ``compiler_cases``)."""
 import sys
 import tempfile
 import types
@@ -361,8 +364,109 @@ def interop_cases():
               f"{'no constraints' if ref.constraints is None else str(len(out['distances'])) + ' + ' + str(len(out['centroids'])) + ' constraints, ' + str(len(out['remaps'])) + ' remaps'}")
 
 
+def _rows_sorted(a):
+    return a[np.lexsort(a.T[::-1])] if len(a) else a
+
+
+def _constraint_set_arrays(cs):
+    """The set as arrays, rows sorted (the order of the rows of a constraint set carries no meaning; the reference and this package list a grid's
+    diagonals in different orders)."""
+    out = _constraint_set_arrays_unsorted(cs)
+    return {k: (_rows_sorted(v) if v.ndim == 2 else v) for k, v in out.items()}
+
+
+def _constraint_set_arrays_unsorted(cs):
+    return dict(
+        distances=np.array([[d.object_id_a, d.keypoint_id_a, d.object_id_b, d.keypoint_id_b, d.distance, d.sigma] for d in cs.distances], dtype=np.float64).reshape(-1, 6),
+        centroids=np.array([[c.object_id_a, c.object_id_b, c.distance, c.sigma] for c in cs.centroid_distances], dtype=np.float64).reshape(-1, 4),
+        static_ids=np.array(sorted(cs.static_object_ids), dtype=np.int64),
+        remaps=np.array([[r.object_id_from, r.keypoint_id_from, r.object_id_to, r.keypoint_id_to, r.obj_loc_x, r.obj_loc_y, r.obj_loc_z] for r in cs.point_remaps],
+                        dtype=np.float64).reshape(-1, 7),
+        thickness=np.array(np.nan if cs.back_face_thickness_m is None else cs.back_face_thickness_m))
+
+
+def compiler_cases():
+    """``ConstraintSet.from_marker_set`` (core/constraints.py:84-190) on random marker sets — sizes, static markers, centre and corner links, mirror
+    pairs of zero and of positive thickness — and ``from_chessboard`` (:397-418).  ``ArucoMarkerSet`` checks its ids against the capacity of an OpenCV
+    dictionary: the stub's ``cv2.aruco.getPredefinedDictionary`` answers with 250 entries and nothing else.  The fixture stores what the compilers read
+    from the reference's objects (corners, flags, the derived ``is_center`` / ``corner_mapping`` / ``is_zero_thickness``) and the compiled sets; at
+    generation time this package's compiler is also run on the reference's OWN objects and must return the same set."""
+    sys.path.insert(0, str(HERE.parent.parent))
+    import cv2
+
+    cv2.aruco = types.SimpleNamespace(getPredefinedDictionary=lambda d: types.SimpleNamespace(bytesList=[None] * 250))
+    import caliscope_amd.constraints as my_con
+    from caliscope.core.aruco_marker import ArucoMarker, ArucoMarkerSet, DistanceLink, MirrorPair
+    from caliscope.core.chessboard import Chessboard
+    from caliscope.core.constraints import ConstraintSet
+
+    for case in range(8):
+        rng = np.random.default_rng(13000 + case)
+        ids = sorted(rng.choice(40, size=int(rng.integers(2, 8)), replace=False).tolist())
+        static = {m for m in ids if rng.random() < 0.3}
+        size = {m: float(rng.uniform(0.03, 0.3)) for m in ids}
+        pairs = []  # mirror pairs first: the two markers of a pair share their size and are both static or both mobile
+        free = list(ids)
+        for _ in range(int(rng.integers(0, 3))):
+            if len(free) < 2:
+                break
+            a, b = (int(v) for v in rng.choice(free, size=2, replace=False))
+            free.remove(a); free.remove(b)
+            size[b] = size[a]
+            if (a in static) != (b in static):
+                static.discard(a); static.discard(b)
+            pairs.append((a, b))
+        markers = {m: ArucoMarker(int(m), size[m], static=m in static) for m in ids}
+        links, seen = [], set()
+        for _ in range(int(rng.integers(0, 6))):
+            a, b = (int(v) for v in rng.choice(ids, size=2, replace=False))
+            if (a in static) != (b in static):
+                continue
+            corner = None if rng.random() < 0.5 else (int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+            key = frozenset([(a, None if corner is None else corner[0]), (b, None if corner is None else corner[1])])
+            if key in seen:
+                continue
+            seen.add(key)
+            links.append(DistanceLink(a, b, float(rng.uniform(0.1, 2.0)), *(corner if corner else (None, None)), sigma_m=[None, 0.003][int(rng.integers(0, 2))]))
+        mirrors = [MirrorPair(a, b, int(rng.integers(0, 4)), int(rng.integers(0, 4)), [0.0, 0.006][int(rng.integers(0, 2))], sigma_m=[None, 0.001][int(rng.integers(0, 2))])
+                   for a, b in pairs]
+        try:
+            ms = ArucoMarkerSet(0, markers, tuple(links), tuple(mirrors))
+        except ValueError as exc:  # (a random combination the reference's own validation refuses: no mirror pairs then)
+            print(f"compilers {case}: marker set refused by the reference ({exc}); mirror pairs dropped")
+            mirrors = []
+            ms = ArucoMarkerSet(0, markers, tuple(links), ())
+        sig, csig = float(rng.uniform(0.001, 0.004)), float(rng.uniform(0.003, 0.008))
+        ref = ConstraintSet.from_marker_set(ms, sigma_m=sig, center_sigma_m=csig)
+        mine = my_con.ConstraintSet.from_marker_set(ms, sigma_m=sig, center_sigma_m=csig)  # this package's compiler on the reference's own objects
+        a, b = _constraint_set_arrays(ref), _constraint_set_arrays(mine)
+        same = all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+        rows, cols = int(rng.integers(3, 9)), int(rng.integers(3, 9))
+        board = Chessboard(rows, cols, float(rng.uniform(1.0, 6.0)))
+        bsig = float(rng.uniform(0.001, 0.004))
+        ref_b = ConstraintSet.from_chessboard(board, sigma_m=bsig)
+        same_b = all(np.array_equal(v, _constraint_set_arrays(my_con.ConstraintSet.from_chessboard(board, sigma_m=bsig))[k], equal_nan=True)
+                     for k, v in _constraint_set_arrays(ref_b).items())
+        out = {f"set_{k}": v for k, v in a.items()}
+        out.update({f"board_{k}": v for k, v in _constraint_set_arrays(ref_b).items()})
+        out.update(
+            marker_ids=np.array(ids), marker_static=np.array([m in static for m in ids]), marker_size=np.array([markers[m].size_m for m in ids]),
+            marker_corners=np.array([markers[m].corners for m in ids], dtype=np.float64),
+            links=np.array([[lk.marker_a, lk.marker_b, lk.distance_m, -1 if lk.corner_a is None else lk.corner_a, -1 if lk.corner_b is None else lk.corner_b,
+                             np.nan if lk.sigma_m is None else lk.sigma_m, int(lk.is_center)] for lk in links], dtype=np.float64).reshape(-1, 7),
+            mirrors=np.array([[mp.marker_a, mp.marker_b, mp.anchor_corner_a, mp.anchor_corner_b, mp.thickness_m, np.nan if mp.sigma_m is None else mp.sigma_m,
+                               int(mp.is_zero_thickness), *np.ravel(mp.corner_mapping)] for mp in mirrors], dtype=np.float64).reshape(-1, 15),
+            sigma=np.array([sig, csig]), board=np.array([rows, cols, board.square_size_cm, bsig]), board_points=np.asarray(board.get_object_points(), dtype=np.float64),
+            same_on_reference_objects=np.array([same, same_b]))
+        np.savez_compressed(OUT / f"compilers_{case:02d}.npz", **out)
+        print(f"compilers {case}: markers {ids} (static {sorted(static)}), {len(links)} links, {len(mirrors)} mirror pairs -> {len(a['distances'])} + {len(a['centroids'])} "
+              f"constraints, {len(a['remaps'])} remaps; board {rows} x {cols} -> {len(out['board_distances'])}; this package's compilers on the reference's objects: "
+              f"{'identical' if same and same_b else 'DIFFERENT'}")
+
+
 if __name__ == "__main__":
     main()
     bundle_cases()
     table_cases()
     interop_cases()
+    compiler_cases()

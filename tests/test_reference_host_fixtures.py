@@ -257,3 +257,50 @@ def test_saved_volumes_read_as_the_reference_read_them(path, tmp_path):
                 assert np.allclose(np.array(a["cameras"][cid][key], dtype=np.float64), np.array(value, dtype=np.float64), rtol=0, atol=1e-12), (cid, key)
             else:
                 assert a["cameras"][cid][key] == value, (cid, key)
+
+
+# ---- the constraint compilers (core/constraints.py:84-190 from_marker_set, :397-418 from_chessboard) -------------------------------------------
+COMPILERS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("compilers_*.npz"))
+
+
+def _set_arrays(cs):
+    def rows(a):
+        return a[np.lexsort(a.T[::-1])] if len(a) else a
+
+    return dict(
+        distances=rows(np.array([[d.object_id_a, d.keypoint_id_a, d.object_id_b, d.keypoint_id_b, d.distance, d.sigma] for d in cs.distances], dtype=np.float64).reshape(-1, 6)),
+        centroids=rows(np.array([[c.object_id_a, c.object_id_b, c.distance, c.sigma] for c in cs.centroid_distances], dtype=np.float64).reshape(-1, 4)),
+        static_ids=np.array(sorted(cs.static_object_ids), dtype=np.int64),
+        remaps=rows(np.array([[r.object_id_from, r.keypoint_id_from, r.object_id_to, r.keypoint_id_to, r.obj_loc_x, r.obj_loc_y, r.obj_loc_z] for r in cs.point_remaps],
+                             dtype=np.float64).reshape(-1, 7)),
+        thickness=np.array(np.nan if cs.back_face_thickness_m is None else cs.back_face_thickness_m))
+
+
+def test_the_compiler_fixtures_are_there():
+    assert len(COMPILERS) == 8
+
+
+@pytest.mark.parametrize("path", COMPILERS, ids=lambda p: p.stem)
+def test_constraint_compilers_equal_the_reference_s_own_output(path):
+    """Stand-ins carrying exactly what the compilers read from the reference's objects (stored by the generator, which also ran this package's
+    compilers on the reference's OWN ``ArucoMarkerSet`` / ``Chessboard`` objects and recorded that the results were identical)."""
+    from types import SimpleNamespace
+
+    ref = np.load(path)
+    assert ref["same_on_reference_objects"].all()
+    markers = {int(m): SimpleNamespace(marker_id=int(m), size_m=float(sz), static=bool(st), corners=c)
+               for m, sz, st, c in zip(ref["marker_ids"], ref["marker_size"], ref["marker_static"], ref["marker_corners"])}
+    links = [SimpleNamespace(marker_a=int(a), marker_b=int(b), distance_m=float(d), corner_a=None if ca < 0 else int(ca), corner_b=None if cb < 0 else int(cb),
+                             sigma_m=None if np.isnan(sg) else float(sg), is_center=bool(ic)) for a, b, d, ca, cb, sg, ic in ref["links"]]
+    mirrors = [SimpleNamespace(marker_a=int(r[0]), marker_b=int(r[1]), anchor_corner_a=int(r[2]), anchor_corner_b=int(r[3]), thickness_m=float(r[4]),
+                               sigma_m=None if np.isnan(r[5]) else float(r[5]), is_zero_thickness=bool(r[6]),
+                               corner_mapping=tuple((int(r[7 + 2 * k]), int(r[8 + 2 * k])) for k in range(4))) for r in ref["mirrors"]]
+    cs = ConstraintSet.from_marker_set(SimpleNamespace(markers=markers, links=tuple(links), mirror_pairs=tuple(mirrors)),
+                                       sigma_m=float(ref["sigma"][0]), center_sigma_m=float(ref["sigma"][1]))
+    for key, value in _set_arrays(cs).items():
+        assert np.array_equal(value, ref[f"set_{key}"], equal_nan=True), key
+    rows, cols, size_cm, sigma = ref["board"]
+    pts = ref["board_points"].astype(np.float32)  # (Chessboard.get_object_points returns float32: chessboard.py:31-50)
+    board = SimpleNamespace(rows=int(rows), columns=int(cols), square_size_cm=float(size_cm), get_object_points=lambda: pts)
+    for key, value in _set_arrays(ConstraintSet.from_chessboard(board, sigma_m=float(sigma))).items():
+        assert np.array_equal(value, ref[f"board_{key}"], equal_nan=True), key
