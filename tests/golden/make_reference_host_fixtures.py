@@ -27,7 +27,9 @@ Fourth family (``interop_*.npz``): on-disk formats in the direction a user migra
 file texts and every field the reference's loaders returned (rotation vectors through the same scipy ``Rodrigues`` as above).
 
 Fifth family (``compilers_*.npz``): the constraint compilers ``ConstraintSet.from_marker_set`` and ``from_chessboard`` on random marker sets and boards
-(see ``compiler_cases``)."""
+(see ``compiler_cases``).
+
+Sixth family (``filter_*.npz``): the outlier filters between the solver passes, on an injected report (see ``filter_cases``)."""
 import sys
 import tempfile
 import types
@@ -464,9 +466,76 @@ def compiler_cases():
               f"{'identical' if same and same_b else 'DIFFERENT'}")
 
 
+def filter_cases():
+    """``filter_by_percentile_error`` / ``filter_by_absolute_error`` (core/capture_volume.py:607-753) with an INJECTED report: the reference computes
+    its reprojection report through ``cv2.projectPoints``, which is not available here, and the filters read nothing of it but ``raw_errors`` — so a
+    report object of the reference's own class is put in the place of the cached property, with random errors for the matched observations.  What is
+    pinned is the logic between the solver passes of ``calibrate_extrinsics``: per-camera / overall percentiles, the safety floor, which
+    observations survive, which world points are pruned (static ones re-attached)."""
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.capture_volume import CaptureVolume
+    from caliscope.core.constraints import ConstraintSet
+    from caliscope.core.point_data import ImagePoints, WorldPoints
+    from caliscope.core.reprojection_report import ReprojectionReport
+
+    K = np.array([[400.0, 0.0, 200.0], [0.0, 400.0, 200.0], [0.0, 0.0, 1.0]])
+    for case in range(6):
+        world, img, _, _, static = random_tables(300 + case)
+        rng = np.random.default_rng(17000 + case)
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        wdf = wdf.drop_duplicates(subset=WORLD_COLS[:3]).reset_index(drop=True)  # (duplicate keys multiply rows in the reference's merges: not what is pinned here)
+        idf = pd.DataFrame(img, columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+        cams = CameraArray({c: CameraData(cam_id=c, size=(400, 400), matrix=K.copy(), distortions=np.zeros(5), rotation=np.eye(3),
+                                          translation=np.array([0.1 * c, 0.0, 0.0])) for c in (0, 1)})
+        cs = ConstraintSet((), frozenset(static)) if static else None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vol = CaptureVolume(cams, ImagePoints(idf), WorldPoints(wdf), cs)
+        matched = vol.img_to_obj_map >= 0
+        idf_kept = vol.image_points.df[matched]
+        err = np.abs(rng.normal(0, 1.0, (int(matched.sum()), 2))) * rng.choice([1.0, 1.0, 1.0, 8.0], size=(int(matched.sum()), 1))
+        err[idf_kept["cam_id"].to_numpy() == 1] *= 6.0  # camera 1 is the bad one: thresholds taken from camera 0 leave it below the floor alone
+        raw = pd.DataFrame({"sync_index": idf_kept["sync_index"].to_numpy(), "cam_id": idf_kept["cam_id"].to_numpy(), "object_id": idf_kept["object_id"].to_numpy(),
+                            "keypoint_id": idf_kept["keypoint_id"].to_numpy(), "error_x": err[:, 0], "error_y": err[:, 1], "euclidean_error": np.hypot(err[:, 0], err[:, 1])})
+        report = ReprojectionReport(overall_rmse=0.0, by_camera={}, by_point={}, n_unmatched_observations=int((~matched).sum()), unmatched_rate=0.0, unmatched_by_camera={},
+                                    raw_errors=raw, n_observations_matched=int(matched.sum()), n_observations_total=len(matched), n_cameras=2, n_points=len(wdf))
+        vol.__dict__["reprojection_report"] = report  # (the cached property's slot)
+        out = dict(world=vol.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64), image=vol.image_points.df[IMG_COLS].to_numpy(dtype=np.float64),
+                   static_ids=np.array(static, dtype=np.int64), raw_errors=raw.to_numpy(dtype=np.float64), n_runs=np.array(0))
+        runs = [("percentile", 2.5, "per_camera", 10), ("percentile", 30.0, "per_camera", 10), ("percentile", 20.0, "overall", 10),
+                ("percentile", 90.0, "per_camera", int(rng.integers(20, 60))), ("percentile", 100.0, "overall", 5),
+                ("absolute", float(np.percentile(raw["euclidean_error"], 60)), "", 10), ("absolute", 0.05, "", int(rng.integers(15, 40))),
+                ("absolute", float(np.percentile(raw["euclidean_error"][raw["cam_id"] == 0], 80)), "", int(0.5 * min((raw["cam_id"] == 0).sum(), (raw["cam_id"] == 1).sum()))),
+                ("percentile", 40.0, "overall", int(0.45 * min((raw["cam_id"] == 0).sum(), (raw["cam_id"] == 1).sum())))]
+        for n, (kind, value, scope, floor) in enumerate(runs):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                f = vol.filter_by_percentile_error(value, scope=scope, min_per_camera=floor) if kind == "percentile" else vol.filter_by_absolute_error(value, min_per_camera=floor)
+            out[f"run{n}_args"] = np.array([0.0 if kind == "percentile" else 1.0, value, {"per_camera": 0.0, "overall": 1.0, "": -1.0}[scope], float(floor)])
+            # how many cameras the safety floor has to top up in this run (plain numpy on the injected errors): with two or more, the reference under
+            # pandas 2.3.3 (its lock file's version, and this container's) tops up only the FIRST as documented — its `keep_mask[camera_idx] = ...`
+            # turns the boolean mask into an object column ("Setting an item of incompatible dtype" FutureWarning), `~keep_mask` is then true
+            # everywhere, and every later camera gets the n-th smallest of ALL its errors as threshold instead of the n-th smallest of the dropped
+            # ones: it ends below the floor it was asked for.  The consumer compares those runs for what they are.
+            e, c = raw["euclidean_error"].to_numpy(), raw["cam_id"].to_numpy()
+            if kind == "percentile" and scope == "per_camera":
+                thr = {k: float(np.percentile(e[c == k], 100 - value)) for k in (0, 1) if (c == k).any()}
+            else:
+                thr = {k: (float(np.percentile(e, 100 - value)) if kind == "percentile" else value) for k in (0, 1)}
+            out[f"run{n}_floor_cameras"] = np.array(sum(1 for k in thr if ((e[c == k] <= thr[k]).sum() < min(floor, (c == k).sum()))))
+            out[f"run{n}_image"] = f.image_points.df[IMG_COLS].to_numpy(dtype=np.float64)
+            out[f"run{n}_world"] = f.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64)
+            out[f"run{n}_map"] = np.asarray(f.img_to_obj_map, dtype=np.int64)
+        out["n_runs"] = np.array(len(runs))
+        np.savez_compressed(OUT / f"filter_{case:02d}.npz", **out)
+        print(f"filter {case}: {len(idf)} observations ({int(matched.sum())} matched), static {static}: kept "
+              + ", ".join(str(len(out[f'run{n}_image'])) + '/' + str(len(out[f'run{n}_world'])) for n in range(len(runs))))
+
+
 if __name__ == "__main__":
     main()
     bundle_cases()
     table_cases()
     interop_cases()
     compiler_cases()
+    filter_cases()
