@@ -29,7 +29,9 @@ file texts and every field the reference's loaders returned (rotation vectors th
 Fifth family (``compilers_*.npz``): the constraint compilers ``ConstraintSet.from_marker_set`` and ``from_chessboard`` on random marker sets and boards
 (see ``compiler_cases``).
 
-Sixth family (``filter_*.npz``): the outlier filters between the solver passes, on an injected report (see ``filter_cases``)."""
+Sixth family (``filter_*.npz``): the outlier filters between the solver passes, on an injected report (see ``filter_cases``).
+
+Seventh family (``report_*.npz``): the bookkeeping of the reprojection report around injected pixel errors (see ``report_cases``)."""
 import sys
 import tempfile
 import types
@@ -532,6 +534,63 @@ def filter_cases():
               + ", ".join(str(len(out[f'run{n}_image'])) + '/' + str(len(out[f'run{n}_world'])) for n in range(len(runs))))
 
 
+def report_cases():
+    """The bookkeeping of ``CaptureVolume.reprojection_report`` (core/capture_volume.py:151-236) around the pixel errors: which observations count
+    (matched AND seen by a posed, non-ignored camera), the per-camera / per-point / overall RMS, the unmatched counts per camera.  The errors
+    themselves come from ``cv2.projectPoints`` in the reference; here the module-level ``reprojection_errors`` the property calls is replaced by a
+    function that hands back pre-drawn random errors (one row per counted observation), so what is pinned is everything the reference does in
+    pandas around them.  Camera arrays with an unposed and an ignored camera that both have observations."""
+    import caliscope.core.capture_volume as ref_cv
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.constraints import ConstraintSet
+    from caliscope.core.point_data import ImagePoints, WorldPoints
+
+    K = np.array([[400.0, 0.0, 200.0], [0.0, 400.0, 200.0], [0.0, 0.0, 1.0]])
+    for case in range(6):
+        world, img, _, _, static = random_tables(400 + case)
+        rng = np.random.default_rng(19000 + case)
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        idf = pd.DataFrame(img, columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+        other = rng.random(len(idf))  # a fifth of the rows each go to an unposed camera (5) and to an ignored one (9); camera 12 has no observations
+        idf.loc[other < 0.2, "cam_id"] = 5
+        idf.loc[other > 0.8, "cam_id"] = 9
+        idf = idf.drop_duplicates(subset=IMG_COLS[:4]).reset_index(drop=True)
+
+        def cam(c, posed=True, ignore=False):
+            return CameraData(cam_id=c, size=(400, 400), matrix=K.copy(), distortions=np.zeros(5), ignore=ignore,
+                              rotation=np.eye(3) if posed else None, translation=np.array([0.1 * c, 0.0, 0.0]) if posed else None)
+
+        cams = CameraArray({0: cam(0), 1: cam(1), 5: cam(5, posed=False), 9: cam(9, ignore=True), 12: cam(12)})
+        cs = ConstraintSet((), frozenset(static)) if static else None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vol = ref_cv.CaptureVolume(cams, ImagePoints(idf), WorldPoints(wdf), cs)
+        drawn = {}
+
+        def fake_errors(camera_array, camera_indices, image_coords, world_coords):
+            e = rng.normal(0, 1.0, (len(camera_indices), 2)) * (1.0 + np.asarray(camera_indices)[:, None])
+            drawn["errors"], drawn["camera_indices"] = e, np.asarray(camera_indices).copy()
+            return e
+
+        real, ref_cv.reprojection_errors = ref_cv.reprojection_errors, fake_errors
+        try:
+            rep = vol.reprojection_report
+        finally:
+            ref_cv.reprojection_errors = real
+        out = dict(
+            world=vol.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64), image=vol.image_points.df[IMG_COLS].to_numpy(dtype=np.float64),
+            static_ids=np.array(static, dtype=np.int64), errors=drawn["errors"], camera_indices=drawn["camera_indices"].astype(np.int64),
+            overall_rmse=np.array(rep.overall_rmse), by_camera=np.array(sorted(rep.by_camera.items()), dtype=np.float64).reshape(-1, 2),
+            by_point=np.array(sorted((o, k, v) for (o, k), v in rep.by_point.items()), dtype=np.float64).reshape(-1, 3),
+            n_unmatched=np.array(rep.n_unmatched_observations), unmatched_rate=np.array(rep.unmatched_rate),
+            unmatched_by_camera=np.array(sorted(rep.unmatched_by_camera.items()), dtype=np.int64).reshape(-1, 2),
+            raw_errors=rep.raw_errors.to_numpy(dtype=np.float64), raw_columns=np.array(list(rep.raw_errors.columns)),
+            counts=np.array([rep.n_observations_matched, rep.n_observations_total, rep.n_cameras, rep.n_points], dtype=np.int64))
+        np.savez_compressed(OUT / f"report_{case:02d}.npz", **out)
+        print(f"report {case}: {len(idf)} observations, {rep.n_observations_matched} counted, unmatched by camera {dict(sorted(rep.unmatched_by_camera.items()))}, "
+              f"{len(rep.by_point)} points, cameras in by_camera {sorted(rep.by_camera)}")
+
+
 if __name__ == "__main__":
     main()
     bundle_cases()
@@ -539,3 +598,4 @@ if __name__ == "__main__":
     interop_cases()
     compiler_cases()
     filter_cases()
+    report_cases()

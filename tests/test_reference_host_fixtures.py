@@ -370,3 +370,52 @@ def test_outlier_filters_equal_the_reference_s_own_output(path):
         assert np.array_equal(_sorted_rows(out.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64)), _sorted_rows(ref[f"run{n}_world"]), equal_nan=True), n
         theirs_w, theirs_m = ref[f"run{n}_world"][:, :3].astype(np.int64), ref[f"run{n}_map"]
         assert np.array_equal(world_key_of_rows(out), np.where(theirs_m[:, None] >= 0, theirs_w[np.maximum(theirs_m, 0)], -7)), n
+
+
+# ---- the bookkeeping of the reprojection report (core/capture_volume.py:151-236) around injected pixel errors ----------------------------------
+REPORTS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("report_*.npz"))
+
+
+def test_the_report_fixtures_are_there():
+    assert len(REPORTS) == 6
+
+
+@pytest.mark.parametrize("path", REPORTS, ids=lambda p: p.stem)
+def test_report_bookkeeping_equals_the_reference_s_own_output(path, monkeypatch):
+    """Camera array with an unposed camera (5) and an ignored one (9) that both have observations, and a posed camera (12) without any.  The pixel
+    errors are the ones the generator handed to the reference in the place of its ``reprojection_errors`` (one row per counted observation, in the
+    order the reference asked for them); they replace this package's device evaluation the same way."""
+    ref = np.load(path)
+    wdf = pd.DataFrame(ref["world"], columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+    idf = pd.DataFrame(ref["image"], columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+    K = np.array([[400.0, 0.0, 200.0], [0.0, 400.0, 200.0], [0.0, 0.0, 1.0]])
+
+    def cam(c, posed=True, ignore=False):
+        return CameraData(cam_id=c, size=(400, 400), matrix=K.copy(), distortions=np.zeros(5), ignore=ignore,
+                          rotation=np.eye(3) if posed else None, translation=np.array([0.1 * c, 0.0, 0.0]) if posed else None)
+
+    cams = CameraArray({0: cam(0), 1: cam(1), 5: cam(5, posed=False), 9: cam(9, ignore=True), 12: cam(12)})
+    static = frozenset(int(o) for o in ref["static_ids"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vol = CaptureVolume(cams, ImagePoints(idf), WorldPoints(wdf), ConstraintSet((), static) if static else None)
+    asked = {}
+
+    def stored_errors(self, camera_indices, image_coords, obj_indices, _engine_factory=None):
+        asked["camera_indices"] = np.asarray(camera_indices).copy()
+        return ref["errors"].copy()
+
+    monkeypatch.setattr(CaptureVolume, "_pixel_errors", stored_errors)
+    rep = vol.compute_reprojection_report()
+    assert np.array_equal(asked["camera_indices"], ref["camera_indices"])  # the same observations, in the same order, with the same camera numbering
+    assert rep.overall_rmse == pytest.approx(float(ref["overall_rmse"]), rel=1e-14)
+    mine = np.array(sorted(rep.by_camera.items()), dtype=np.float64).reshape(-1, 2)
+    assert np.array_equal(mine[:, 0], ref["by_camera"][:, 0]) and np.allclose(mine[:, 1], ref["by_camera"][:, 1], rtol=1e-14, atol=0)
+    mine = np.array(sorted((o, k, v) for (o, k), v in rep.by_point.items()), dtype=np.float64).reshape(-1, 3)
+    assert np.array_equal(mine[:, :2], ref["by_point"][:, :2]) and np.allclose(mine[:, 2], ref["by_point"][:, 2], rtol=1e-14, atol=0)
+    assert rep.n_unmatched_observations == int(ref["n_unmatched"]) and rep.unmatched_rate == pytest.approx(float(ref["unmatched_rate"]), rel=1e-15)
+    assert np.array_equal(np.array(sorted(rep.unmatched_by_camera.items()), dtype=np.int64).reshape(-1, 2), ref["unmatched_by_camera"])
+    assert list(rep.raw_errors.columns) == [str(c) for c in ref["raw_columns"]]
+    got = rep.raw_errors.to_numpy(dtype=np.float64)
+    assert np.array_equal(got[:, :6], ref["raw_errors"][:, :6]) and np.allclose(got[:, 6], ref["raw_errors"][:, 6], rtol=1e-15, atol=0)
+    assert [rep.n_observations_matched, rep.n_observations_total, rep.n_cameras, rep.n_points] == ref["counts"].tolist()
