@@ -31,7 +31,10 @@ Fifth family (``compilers_*.npz``): the constraint compilers ``ConstraintSet.fro
 
 Sixth family (``filter_*.npz``): the outlier filters between the solver passes, on an injected report (see ``filter_cases``).
 
-Seventh family (``report_*.npz``): the bookkeeping of the reprojection report around injected pixel errors (see ``report_cases``)."""
+Seventh family (``report_*.npz``): the bookkeeping of the reprojection report around injected pixel errors (see ``report_cases``).
+
+Eighth family (``seam_*.npz``): the seam itself — what the reference's ``optimize()`` hands to ``least_squares`` and what it makes of the result
+(see ``seam_cases``)."""
 import sys
 import tempfile
 import types
@@ -591,6 +594,108 @@ def report_cases():
               f"{len(rep.by_point)} points, cameras in by_camera {sorted(rep.by_camera)}")
 
 
+def seam_cases():
+    """THE SEAM: the reference's ``CaptureVolume.optimize()`` (core/capture_volume.py:322-444) run with ``least_squares`` replaced by a
+    recorder that returns a scripted result.  Stored: everything the reference hands to scipy at :387-411 — ``x0``, the eight ``args``, ``bounds``
+    and the keyword arguments — and everything it makes of the result — the new cameras, the new points, ``OptimizationStatus`` (reason strings,
+    bound warnings), the ``CalibrationError`` of a strict call that did not converge.  Camera arrays with sparse ids, an unposed and an ignored
+    camera that have observations, fisheye cameras, locked and free intrinsics; tables with static objects; distance and centroid constraints;
+    every termination status.  (Rotation vectors through the scipy ``Rodrigues`` stub, as in the bundle_* family.)"""
+    from scipy.spatial.transform import Rotation
+
+    import caliscope.core.capture_volume as ref_cv
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.constraints import CentroidDistanceConstraint, ConstraintSet, DistanceConstraint
+    from caliscope.core.point_data import ImagePoints, WorldPoints
+    from caliscope.exceptions import CalibrationError
+
+    for case in range(10):
+        rng = np.random.default_rng(23000 + case)
+        world, img, dist, cent, static = random_tables(500 + case)
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        wdf = wdf.drop_duplicates(subset=WORLD_COLS[:3]).reset_index(drop=True)
+        idf = pd.DataFrame(img, columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+        ids = [0, 1, 4, 7, 11]  # 4 unposed, 7 ignored, 11 fisheye; observations spread over all of them
+        idf["cam_id"] = rng.choice(ids, size=len(idf), p=[0.3, 0.3, 0.1, 0.1, 0.2])
+        idf = idf.drop_duplicates(subset=IMG_COLS[:4]).reset_index(drop=True)
+        desc = []
+        for c in ids:
+            f = float(rng.uniform(300, 900))
+            desc.append(dict(cam_id=c, size=(int(rng.integers(320, 1920)), int(rng.integers(240, 1080))), fisheye=c == 11, ignore=c == 7,
+                             K=[[f, 0.0, float(rng.uniform(100, 600))], [0.0, f * 1.01, float(rng.uniform(100, 400))], [0.0, 0.0, 1.0]],
+                             dist=rng.normal(0, 0.05, 4 if c == 11 else 5).tolist(), rvec=None if c == 4 else rng.normal(0, 0.6, 3).tolist(),
+                             t=None if c == 4 else rng.normal(0, 1.0, 3).tolist()))
+        cams = CameraArray({d["cam_id"]: CameraData(cam_id=d["cam_id"], size=tuple(d["size"]), matrix=np.array(d["K"]), distortions=np.array(d["dist"]), fisheye=d["fisheye"],
+                                                    ignore=d["ignore"], rotation=None if d["rvec"] is None else Rotation.from_rotvec(d["rvec"]).as_matrix(),
+                                                    translation=None if d["t"] is None else np.array(d["t"])) for d in desc})
+        cs = ConstraintSet(tuple(DistanceConstraint(*d) for d in dist), frozenset(static), centroid_distances=tuple(CentroidDistanceConstraint(*c) for c in cent)) if case % 4 != 3 else None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vol = ref_cv.CaptureVolume(cams, ImagePoints(idf), WorldPoints(wdf), cs)
+        status = [2, 1, 3, 4, 0, 2, 0, 2, 3, 2][case]
+        kw = dict(ftol=[1e-8, 1e-10, 1e-6][case % 3], max_nfev=[None, 50, 7][case % 3], verbose=[0, 0, 1][case % 3], strict=case != 4,
+                  use_constraints=case % 5 != 2, pixel_sigma=[1.0, 0.5, 2.0][case % 3], refine_intrinsics=bool(case % 2),
+                  loss=["linear", "huber", "soft_l1", "cauchy"][case % 4], f_scale=[1.0, 0.002, 0.01][case % 3])
+        seen = {}
+
+        def recorder(fun, x0, args=(), jac=None, **kwargs):
+            seen.update(fun=getattr(fun, "__name__", str(fun)), jac=getattr(jac, "__name__", str(jac)), x0=np.array(x0, dtype=np.float64), args=args, kwargs=kwargs)
+            x = np.array(x0, dtype=np.float64) + 0.01 * np.sin(np.arange(len(x0)) * 0.7)
+            par = args[0]
+            for i, b in enumerate(par.blocks):  # free intrinsics now and then next to a bound: the status must carry the warning
+                if b.free_intrinsics and i % 2 == 0:
+                    x[par.camera_param_offsets[i] + 6] = 0.5025
+                    x[par.camera_param_offsets[i] + 8] = 1.995
+            seen["x"] = x
+            return types.SimpleNamespace(x=x, status=status, nfev=int(rng.integers(3, 40)), cost=float(rng.uniform(0.1, 5.0)), optimality=1e-9, success=status > 0)
+
+        real, ref_cv.least_squares = ref_cv.least_squares, recorder
+        error = ""
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = vol.optimize(**kw)
+        except CalibrationError as exc:
+            out, error = None, str(exc)
+        finally:
+            ref_cv.least_squares = real
+        par, cam_idx, uv, obj_idx, ga, gb, cd, cw = seen["args"]
+        lb, ub = seen["kwargs"]["bounds"]
+        fix = dict(
+            world=vol.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64), image=vol.image_points.df[IMG_COLS].to_numpy(dtype=np.float64),
+            static_ids=np.array(static, dtype=np.int64), has_constraints=np.array(cs is not None),
+            distances=np.array(dist, dtype=np.float64).reshape(-1, 6), centroids=np.array(cent, dtype=np.float64).reshape(-1, 4),
+            cam_ids=np.array(ids), sizes=np.array([d["size"] for d in desc]), K=np.array([d["K"] for d in desc]),
+            dist=np.array([d["dist"] + [np.nan] * (5 - len(d["dist"])) for d in desc]), fisheye=np.array([d["fisheye"] for d in desc]), ignore=np.array([d["ignore"] for d in desc]),
+            rvec=np.array([d["rvec"] if d["rvec"] is not None else [np.nan] * 3 for d in desc]), t=np.array([d["t"] if d["t"] is not None else [np.nan] * 3 for d in desc]),
+            call=np.array([kw["ftol"], -1 if kw["max_nfev"] is None else kw["max_nfev"], kw["verbose"], kw["strict"], kw["use_constraints"], kw["pixel_sigma"], kw["refine_intrinsics"],
+                           kw["f_scale"]], dtype=np.float64), loss=np.array(kw["loss"]),
+            fun=np.array(seen["fun"]), jac=np.array(seen["jac"]), x0=seen["x0"], camera_indices=np.asarray(cam_idx, dtype=np.int64), image_coords=np.asarray(uv, dtype=np.float64),
+            obj_indices=np.asarray(obj_idx, dtype=np.int64), has_rows=np.array(ga is not None),
+            groups_a=np.zeros((0, 4), np.int64) if ga is None else np.asarray(ga, dtype=np.int64), groups_b=np.zeros((0, 4), np.int64) if gb is None else np.asarray(gb, dtype=np.int64),
+            row_distance=np.zeros(0) if cd is None else np.asarray(cd, dtype=np.float64), row_weight=np.zeros(0) if cw is None else np.asarray(cw, dtype=np.float64),
+            lb=np.asarray(lb), ub=np.asarray(ub), offsets=np.array(par.camera_param_offsets), n_camera_params=np.array(par.n_camera_params),
+            kwargs_keys=np.array(sorted(k for k in seen["kwargs"] if k != "bounds")),
+            kwargs_values=np.array([str(seen["kwargs"][k]) for k in sorted(seen["kwargs"]) if k != "bounds"]),
+            x_result=seen["x"], result_status=np.array(status), error=np.array(error), returned=np.array(out is not None))
+        if out is not None:
+            st = out.optimization_status
+            fix.update(
+                out_R=np.array([out.camera_array.cameras[c].rotation if out.camera_array.cameras[c].rotation is not None else np.full((3, 3), np.nan) for c in ids]),
+                out_t=np.array([np.ravel(out.camera_array.cameras[c].translation) if out.camera_array.cameras[c].translation is not None else [np.nan] * 3 for c in ids]),
+                out_K=np.array([out.camera_array.cameras[c].matrix for c in ids]),
+                out_dist=np.array([list(np.ravel(out.camera_array.cameras[c].distortions)) + [np.nan] * (5 - np.size(out.camera_array.cameras[c].distortions)) for c in ids]),
+                out_world=out.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64), out_map=np.asarray(out.img_to_obj_map, dtype=np.int64),
+                status_fields=np.array([st.converged, st.iterations, st.final_cost], dtype=np.float64), status_reason=np.array(st.termination_reason),
+                status_warnings=np.array([[w.cam_id, {"f": 0, "k1": 1, "k2": 2}[w.parameter], {"lower": 0, "upper": 1}[w.bound], w.value] for w in st.bound_warnings],
+                                         dtype=np.float64).reshape(-1, 4),
+                source_untouched=np.array(all(np.array_equal(vol.camera_array.cameras[d["cam_id"]].matrix, np.array(d["K"])) for d in desc)))
+        np.savez_compressed(OUT / f"seam_{case:02d}.npz", **fix)
+        print(f"seam {case}: {len(cam_idx)} of {len(idf)} observations handed over, {par.n_camera_params} camera parameters (refine {kw['refine_intrinsics']}), "
+              f"{0 if ga is None else len(ga)} constraint rows, loss {kw['loss']}, status {status} -> "
+              + (f"error: {error.splitlines()[0]}" if out is None else f"{out.optimization_status.termination_reason}, {len(out.optimization_status.bound_warnings)} bound warnings"))
+
+
 if __name__ == "__main__":
     main()
     bundle_cases()
@@ -599,3 +704,4 @@ if __name__ == "__main__":
     compiler_cases()
     filter_cases()
     report_cases()
+    seam_cases()

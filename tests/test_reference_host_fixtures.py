@@ -419,3 +419,99 @@ def test_report_bookkeeping_equals_the_reference_s_own_output(path, monkeypatch)
     got = rep.raw_errors.to_numpy(dtype=np.float64)
     assert np.array_equal(got[:, :6], ref["raw_errors"][:, :6]) and np.allclose(got[:, 6], ref["raw_errors"][:, 6], rtol=1e-15, atol=0)
     assert [rep.n_observations_matched, rep.n_observations_total, rep.n_cameras, rep.n_points] == ref["counts"].tolist()
+
+
+# ---- the seam: what optimize() hands to least_squares and what it makes of the result (core/capture_volume.py:322-444) ---------------------------
+SEAMS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("seam_*.npz"))
+
+
+def test_the_seam_fixtures_are_there():
+    assert len(SEAMS) == 10
+
+
+@pytest.mark.parametrize("path", SEAMS, ids=lambda p: p.stem)
+def test_optimize_hands_over_and_takes_back_what_the_reference_does(path, monkeypatch):
+    """The generator ran the reference's ``optimize()`` with ``least_squares`` replaced by a recorder returning a scripted result.  Here this
+    package's ``optimize()`` runs on the same volume with ITS ``least_squares`` replaced the same way (returning the stored result vector): the
+    call must carry what the reference's carried — ``x0``, the observation arrays, the constraint rows with their weights, the bounds, every keyword —
+    and the returned volume must be the one the reference built: cameras, points, ``OptimizationStatus`` with its reason string and bound
+    warnings, or the same ``CalibrationError`` text for a strict call that did not converge."""
+    import caliscope_amd.capture_volume as cv_mod
+    from caliscope_amd.cameras import rvec_to_matrix
+    from caliscope_amd.exceptions import CalibrationError
+
+    ref = np.load(path)
+    wdf = pd.DataFrame(ref["world"], columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+    idf = pd.DataFrame(ref["image"], columns=IMG_COLS).astype({c: "int64" for c in IMG_COLS[:4]})
+    cams = {}
+    for i, cid in enumerate(ref["cam_ids"]):
+        fisheye, posed = bool(ref["fisheye"][i]), not np.isnan(ref["rvec"][i]).any()
+        cams[int(cid)] = CameraData(cam_id=int(cid), size=(int(ref["sizes"][i][0]), int(ref["sizes"][i][1])), matrix=ref["K"][i].copy(),
+                                    distortions=ref["dist"][i][: 4 if fisheye else 5].copy(), fisheye=fisheye, ignore=bool(ref["ignore"][i]),
+                                    rotation=rvec_to_matrix(ref["rvec"][i]) if posed else None, translation=ref["t"][i].copy() if posed else None)
+    cs = None
+    if bool(ref["has_constraints"]):
+        cs = ConstraintSet(tuple(DistanceConstraint(int(a), int(b), int(c), int(d), float(e), float(f)) for a, b, c, d, e, f in ref["distances"]),
+                           frozenset(int(o) for o in ref["static_ids"]),
+                           centroid_distances=tuple(CentroidDistanceConstraint(int(a), int(b), float(c), float(d)) for a, b, c, d in ref["centroids"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vol = CaptureVolume(CameraArray(cams), ImagePoints(idf), WorldPoints(wdf), cs)
+    ftol, max_nfev, verbose, strict, use_constraints, pixel_sigma, refine, f_scale = ref["call"]
+    seen = {}
+
+    def recorder(fun, x0, args=(), jac=None, **kwargs):
+        seen.update(x0=np.array(x0, dtype=np.float64), args=args, kwargs=kwargs)
+        return SimpleNamespace(x=ref["x_result"].copy(), status=int(ref["result_status"]), nfev=17, cost=1.25, optimality=1e-9, success=int(ref["result_status"]) > 0)
+
+    from types import SimpleNamespace
+
+    monkeypatch.setattr(cv_mod, "least_squares", recorder)
+    kw = dict(ftol=float(ftol), max_nfev=None if max_nfev < 0 else int(max_nfev), verbose=int(verbose), strict=bool(strict), use_constraints=bool(use_constraints),
+              pixel_sigma=float(pixel_sigma), refine_intrinsics=bool(refine), loss=str(ref["loss"]), f_scale=float(f_scale))
+    error, out = "", None
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = vol.optimize(**kw)
+    except CalibrationError as exc:
+        error = str(exc)
+    # -- what was handed over
+    par, cam_idx, uv, obj_idx, ga, gb, cd, cw = seen["args"][:8]
+    assert np.array_equal(par.camera_param_offsets, ref["offsets"]) and par.n_camera_params == int(ref["n_camera_params"])
+    rot = np.zeros(seen["x0"].size, dtype=bool)
+    for off in par.camera_param_offsets:
+        rot[off:off + 3] = True
+    assert seen["x0"].shape == ref["x0"].shape and np.array_equal(seen["x0"][~rot], ref["x0"][~rot]) and np.allclose(seen["x0"][rot], ref["x0"][rot], rtol=0, atol=1e-12)
+    assert np.array_equal(np.asarray(cam_idx, dtype=np.int64), ref["camera_indices"]) and np.array_equal(np.asarray(uv, dtype=np.float64), ref["image_coords"])
+    assert np.array_equal(np.asarray(obj_idx, dtype=np.int64), ref["obj_indices"])
+    assert (ga is not None) == bool(ref["has_rows"])
+    if ga is not None:
+        # (the reference walks a set of sync indices: the order of the rows is not defined there; a row keeps its distance and its weight)
+        assert np.array_equal(_sorted_rows(ga, gb, cd, cw), _sorted_rows(ref["groups_a"], ref["groups_b"], ref["row_distance"], ref["row_weight"]))
+    lb, ub = seen["kwargs"]["bounds"]
+    assert np.array_equal(np.asarray(lb), ref["lb"]) and np.array_equal(np.asarray(ub), ref["ub"])
+    theirs = dict(zip((str(k) for k in ref["kwargs_keys"]), (str(v) for v in ref["kwargs_values"])))
+    mine = {k: str(v) for k, v in seen["kwargs"].items() if k not in ("bounds", "engine_factory")}
+    assert mine == theirs, (mine, theirs)
+    # -- what was made of the result
+    assert error == str(ref["error"]) and (out is not None) == bool(ref["returned"])
+    if out is None:
+        return
+    for k, cid in enumerate(ref["cam_ids"]):
+        cam, src = out.camera_array.cameras[int(cid)], vol.camera_array.cameras[int(cid)]
+        assert cam is not src and np.array_equal(src.matrix, ref["K"][k])  # the source volume's cameras are not touched
+        if np.isnan(ref["out_R"][k]).any():
+            assert cam.rotation is None and cam.translation is None
+        else:
+            assert np.allclose(cam.rotation, ref["out_R"][k], rtol=0, atol=1e-12) and np.array_equal(np.ravel(cam.translation), ref["out_t"][k])
+        assert np.array_equal(cam.matrix, ref["out_K"][k])
+        d = np.ravel(cam.distortions)
+        assert np.array_equal(d, ref["out_dist"][k][: d.size]) and np.all(np.isnan(ref["out_dist"][k][d.size:]))
+    assert np.array_equal(out.world_points.df[WORLD_COLS].to_numpy(dtype=np.float64), ref["out_world"], equal_nan=True)
+    assert np.array_equal(out.img_to_obj_map, ref["out_map"]) and out.image_points is vol.image_points
+    st = out.optimization_status
+    assert bool(st.converged) == bool(ref["status_fields"][0]) and st.termination_reason == str(ref["status_reason"])
+    assert st.iterations == 17 and st.final_cost == 1.25
+    got = np.array([[w.cam_id, {"f": 0, "k1": 1, "k2": 2}[w.parameter], {"lower": 0, "upper": 1}[w.bound], w.value] for w in st.bound_warnings], dtype=np.float64).reshape(-1, 4)
+    assert np.array_equal(_sorted_rows(got), _sorted_rows(ref["status_warnings"]))
