@@ -34,7 +34,9 @@ Sixth family (``filter_*.npz``): the outlier filters between the solver passes, 
 Seventh family (``report_*.npz``): the bookkeeping of the reprojection report around injected pixel errors (see ``report_cases``).
 
 Eighth family (``seam_*.npz``): the seam itself — what the reference's ``optimize()`` hands to ``least_squares`` and what it makes of the result
-(see ``seam_cases``)."""
+(see ``seam_cases``).
+
+Ninth family (``conrows_*.npz``): the constraint rows of the reference's own ``joint_residuals`` / ``joint_jacobian`` (see ``constraint_row_cases``)."""
 import sys
 import tempfile
 import types
@@ -696,8 +698,45 @@ def seam_cases():
               + (f"error: {error.splitlines()[0]}" if out is None else f"{out.optimization_status.termination_reason}, {len(out.optimization_status.bound_warnings)} bound warnings"))
 
 
+def constraint_row_cases():
+    """The constraint rows of the reference's OWN ``joint_residuals`` / ``joint_jacobian`` (core/reprojection.py:112-117, :207-226).  Those two functions
+    reach OpenCV only inside their per-camera loops, which skip a camera without observations — so called with EMPTY observation arrays they return
+    exactly the constraint rows, computed by the reference's numpy code: corner endpoints (a row repeated four times), centroid endpoints (four
+    distinct rows), endpoints that share rows, coincident endpoints (the zero subgradient), random weights.  Consumer: the oracle
+    (oracle/residuals.py), which the device rows are compared with."""
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.bundle_parameterization import BundleParameterization
+    from caliscope.core.reprojection import joint_jacobian, joint_residuals
+
+    K = np.array([[400.0, 0.0, 200.0], [0.0, 400.0, 200.0], [0.0, 0.0, 1.0]])
+    for case in range(6):
+        rng = np.random.default_rng(29000 + case)
+        n_cams, refine = int(rng.integers(2, 5)), bool(case % 2)
+        cams = CameraArray({c: CameraData(cam_id=c, size=(400, 400), matrix=K.copy(), distortions=np.zeros(5), rotation=np.eye(3), translation=np.zeros(3)) for c in range(n_cams)})
+        n_points = int(rng.integers(12, 40))
+        par = BundleParameterization.from_camera_array(cams, n_points, refine_intrinsics=refine)
+        x = np.concatenate([rng.normal(0, 0.3, par.n_camera_params), rng.normal(0, 1.0, 3 * n_points)])
+        m = int(rng.integers(6, 20))
+        ga, gb = np.empty((m, 4), dtype=np.int32), np.empty((m, 4), dtype=np.int32)
+        for i in range(m):
+            for g in (ga, gb):
+                g[i] = rng.integers(0, n_points) if rng.random() < 0.6 else rng.choice(n_points, size=4, replace=False)
+        ga[0], gb[0] = 3, 3                      # coincident endpoints: the norm is not differentiable there
+        gb[1] = ga[1]                            # the same group on both sides
+        if m > 3:
+            gb[2, :2] = ga[2, :2]                # groups that share rows
+        dist, wgt = rng.uniform(0.05, 2.0, m), rng.uniform(10.0, 2000.0, m)
+        none_i, none_uv = np.zeros(0, dtype=np.int16), np.zeros((0, 2))
+        r = joint_residuals(x, par, none_i, none_uv, np.zeros(0, dtype=np.int32), ga, gb, dist, wgt)
+        J = joint_jacobian(x, par, none_i, none_uv, np.zeros(0, dtype=np.int32), ga, gb, dist, wgt)
+        np.savez_compressed(OUT / f"conrows_{case:02d}.npz", n_cams=np.array(n_cams), refine=np.array(refine), n_points=np.array(n_points), x=x, groups_a=ga, groups_b=gb,
+                            distances=dist, weights=wgt, residuals=np.asarray(r), jacobian=np.asarray(J.todense()))
+        print(f"conrows {case}: {m} rows over {n_points} points, {par.n_camera_params} camera parameters: |r| {np.linalg.norm(r):.3f}, {J.nnz} non-zeros in {J.shape}")
+
+
 if __name__ == "__main__":
     main()
+    constraint_row_cases()
     bundle_cases()
     table_cases()
     interop_cases()

@@ -515,3 +515,58 @@ def test_optimize_hands_over_and_takes_back_what_the_reference_does(path, monkey
     assert st.iterations == 17 and st.final_cost == 1.25
     got = np.array([[w.cam_id, {"f": 0, "k1": 1, "k2": 2}[w.parameter], {"lower": 0, "upper": 1}[w.bound], w.value] for w in st.bound_warnings], dtype=np.float64).reshape(-1, 4)
     assert np.array_equal(_sorted_rows(got), _sorted_rows(ref["status_warnings"]))
+
+
+# ---- the constraint rows of the reference's own joint_residuals / joint_jacobian (core/reprojection.py:112-117, :207-226) ----------------------
+CONROWS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("conrows_*.npz"))
+
+
+def _conrow_parameterization(ref):
+    from caliscope_amd.bundle_parameterization import BundleParameterization
+
+    K = np.array([[400.0, 0.0, 200.0], [0.0, 400.0, 200.0], [0.0, 0.0, 1.0]])
+    cams = CameraArray({c: CameraData(cam_id=c, size=(400, 400), matrix=K.copy(), distortions=np.zeros(5), rotation=np.eye(3), translation=np.zeros(3))
+                        for c in range(int(ref["n_cams"]))})
+    return BundleParameterization.from_camera_array(cams, int(ref["n_points"]), refine_intrinsics=bool(ref["refine"]))
+
+
+def test_the_constraint_row_fixtures_are_there():
+    assert len(CONROWS) == 6
+
+
+@pytest.mark.parametrize("path", CONROWS, ids=lambda p: p.stem)
+def test_oracle_constraint_rows_equal_the_reference_s_own(path):
+    """The fixtures hold what the reference's OWN ``joint_residuals`` / ``joint_jacobian`` returned when called without observations (their
+    per-camera loops, the only place they reach OpenCV, then do nothing): the constraint rows and their Jacobian from the reference's numpy code.
+    The oracle — what the device rows are compared with — must reproduce them."""
+    from oracle.residuals import joint_jacobian, joint_residuals
+
+    ref = np.load(path)
+    par = _conrow_parameterization(ref)
+    none_i, none_uv = np.zeros(0, dtype=np.int32), np.zeros((0, 2))
+    args = (ref["x"], par, none_i, none_uv, none_i, ref["groups_a"], ref["groups_b"], ref["distances"], ref["weights"])
+    r = joint_residuals(*args)
+    scale = np.abs(ref["residuals"]).max()
+    assert r.shape == ref["residuals"].shape and np.allclose(r, ref["residuals"], rtol=0, atol=1e-13 * scale)
+    J = np.asarray(joint_jacobian(*args).todense())
+    assert J.shape == ref["jacobian"].shape and np.allclose(J, ref["jacobian"], rtol=0, atol=1e-13 * np.abs(ref["jacobian"]).max())
+    assert np.array_equal(J != 0, ref["jacobian"] != 0)  # the same pattern: zero subgradient at coincident endpoints, shared rows folded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CONROWS, ids=lambda p: p.stem)
+def test_device_constraint_rows_equal_the_reference_s_own(path):
+    """The same stored rows against the device: the residual hook appends the constraint rows behind the reprojection rows of a (here: two-row)
+    observation list; rows in the caller's order."""
+    from caliscope_amd.engine import BAProblem
+    from caliscope_amd.hip_engine import HipEngine
+
+    ref = np.load(path)
+    par = _conrow_parameterization(ref)
+    cam_idx, uv, obj = np.array([0, 1], dtype=np.int32), np.array([[200.0, 200.0], [210.0, 190.0]]), np.array([0, 1], dtype=np.int32)
+    prob = BAProblem(par, cam_idx, uv, obj, constraint_groups_a=ref["groups_a"], constraint_groups_b=ref["groups_b"], constraint_distances=ref["distances"],
+                     constraint_weights=ref["weights"])
+    with HipEngine(prob, evaluation_only=True) as eng:
+        r, _ = eng.residuals(ref["x"])
+    assert r.size == 4 + ref["residuals"].size
+    assert np.allclose(r[4:], ref["residuals"], rtol=0, atol=1e-12 * np.abs(ref["residuals"]).max())
