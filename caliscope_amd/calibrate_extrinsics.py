@@ -222,11 +222,23 @@ def calibrate_extrinsics(
                 "link, so calibration would be arbitrary."
             )
     check_cancelled()
+    # static-marker guard as the reference runs it (:146-203): decide on the first triangulation, then START AGAIN without the dropped markers —
+    # fresh copies of the caller's cameras, the 20 % progress mark, a second bootstrap (the reference's pose network could change without the bad
+    # marker; here the poses are the caller's, so the second triangulation only loses the marker's points) — pinned against the reference's own
+    # run of this function with the heavy calls scripted (tests/golden/reference_host/driver_03.npz)
+    guarded, dropped = apply_static_marker_guard(volume)
+    if dropped:
+        report(20, "Re-bootstrapping after dropping markers")
+        cameras = deepcopy(camera_array)
+        for cam in cameras.cameras.values():
+            if not cam.ignore and cam.cam_id in synthesized:
+                cam.synthesize_default_intrinsics()
+        volume = CaptureVolume.bootstrap(guarded.image_points, cameras, constraints=guarded.constraints, _triangulate=_triangulate)
+    check_cancelled()
     run = refine_calibration(volume, refine_intrinsics=refine_intrinsics, filter_percentile=filter_percentile,
-                             cancellation_token=cancellation_token, progress=progress, _engine_factory=_engine_factory)
+                             cancellation_token=cancellation_token, progress=progress, _engine_factory=_engine_factory, _guard=False)
     estimates = _intrinsic_estimates(run.capture_volume, anchors)
-    return CalibrationRun(run.capture_volume, estimates, frozenset(synthesized), run.dropped_static_markers,
-                          run.intrinsic_refinement_gated)
+    return CalibrationRun(run.capture_volume, estimates, frozenset(synthesized), tuple(dropped), run.intrinsic_refinement_gated)
 
 
 def refine_calibration(
@@ -237,8 +249,9 @@ def refine_calibration(
     cancellation_token=None,
     progress: Callable[[int, str], None] | None = None,
     _engine_factory=None,
+    _guard: bool = True,
 ) -> CalibrationRun:
-    """Stages 5-9 of ``calibrate_extrinsics`` on a bootstrapped volume."""
+    """Stages 5-9 of ``calibrate_extrinsics`` on a bootstrapped volume (``_guard=False``: the caller has run the static-marker guard)."""
 
     def check_cancelled():
         if cancellation_token is not None and getattr(cancellation_token, "is_cancelled", False):
@@ -256,7 +269,9 @@ def refine_calibration(
 
     kw = {} if _engine_factory is None else {"_engine_factory": _engine_factory}
     check_cancelled()
-    capture_volume, dropped = apply_static_marker_guard(capture_volume)
+    dropped = ()
+    if _guard:
+        capture_volume, dropped = apply_static_marker_guard(capture_volume)
     check_cancelled()
     report(40, "Optimizing")
     cv = capture_volume.optimize(refine_intrinsics=False, **kw)

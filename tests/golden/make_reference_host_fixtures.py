@@ -36,7 +36,9 @@ Seventh family (``report_*.npz``): the bookkeeping of the reprojection report ar
 Eighth family (``seam_*.npz``): the seam itself — what the reference's ``optimize()`` hands to ``least_squares`` and what it makes of the result
 (see ``seam_cases``).
 
-Ninth family (``conrows_*.npz``): the constraint rows of the reference's own ``joint_residuals`` / ``joint_jacobian`` (see ``constraint_row_cases``)."""
+Ninth family (``conrows_*.npz``): the constraint rows of the reference's own ``joint_residuals`` / ``joint_jacobian`` (see ``constraint_row_cases``).
+
+Tenth family (``driver_*.npz``): the stage driver ``calibrate_extrinsics`` with its three heavy calls scripted (see ``driver_cases``)."""
 import sys
 import tempfile
 import types
@@ -734,8 +736,85 @@ def constraint_row_cases():
         print(f"conrows {case}: {m} rows over {n_points} points, {par.n_camera_params} camera parameters: |r| {np.linalg.norm(r):.3f}, {J.nnz} non-zeros in {J.shape}")
 
 
+def driver_cases():
+    """``calibrate_extrinsics`` (core/calibrate_extrinsics.py:44-261) with its three heavy calls scripted (tests/driver_script.py: bootstrap hands back
+    a given "triangulation", optimize and the filter record their arguments) and everything else real: blind intrinsics, anchors, the static-marker
+    guard, the depth-ratio gate, the stage sequence, the progress marks, the ``CalibrationRun``."""
+    sys.path.insert(0, str(HERE.parent.parent))
+    import caliscope.core.calibrate_extrinsics as ref_drv
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.capture_volume import CaptureVolume
+    from caliscope.core.constraints import ConstraintSet, DistanceConstraint, PointRemap
+    from caliscope.core.point_data import ImagePoints, WorldPoints
+    from caliscope.exceptions import CalibrationError
+    from tests.driver_script import scripted
+
+    corners = np.array([[-0.5, 0.5, 0.0], [0.5, 0.5, 0.0], [0.5, -0.5, 0.0], [-0.5, -0.5, 0.0]])
+    for case in range(8):
+        rng = np.random.default_rng(31000 + case)
+        shallow, deformed, blind, no_obj_loc, refine, remap = case == 1, case == 3, case in (4, 5), case == 5, case != 6, case == 7
+        n_obj = 3 if not remap else 4
+        static = [2] if case in (2, 3) else []
+        size = {o: float(rng.uniform(0.1, 0.3)) for o in range(n_obj)}
+        frames = list(range(int(rng.integers(6, 12))))
+        world, img = [], []
+        for o in range(n_obj):
+            for si in ([-1] if o in static else frames):
+                centre = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(4.0, 5.0) if shallow else rng.uniform(1.0, 6.0)])
+                for k in range(4):
+                    p = centre + size[o] * corners[k] + (rng.normal(0, 0.6 * size[o], 3) if (deformed and o in static) else 0.0)
+                    world.append((si, o, k, *p.tolist(), float("nan") if o in static else si / 30.0))
+            for si in frames:
+                for k in range(4):
+                    for cam in (0, 1, 3):
+                        if rng.random() < 0.9:
+                            loc = [float("nan")] * 3 if no_obj_loc else (size[o] * corners[k]).tolist()
+                            img.append((si, cam, o, k, float(200 + rng.normal(0, 40)), float(200 + rng.normal(0, 40)), *loc))
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        idf = pd.DataFrame(img, columns=IMG_COLS + ["obj_loc_x", "obj_loc_y", "obj_loc_z"]).astype({c: "int64" for c in IMG_COLS[:4]})
+        desc = []
+        for c in (0, 1, 3, 6):
+            f = float(rng.uniform(300, 900))
+            desc.append(dict(cam_id=c, size=(int(rng.integers(320, 1920)), int(rng.integers(240, 1080))), ignore=c == 6, has_intrinsics=not (blind and c == 3),
+                             K=[[f, 0.0, 320.0], [0.0, f, 240.0], [0.0, 0.0, 1.0]], dist=rng.normal(0, 0.05, 5).tolist(), t=[0.2 * c, 0.0, 0.0]))
+        cams = CameraArray({d["cam_id"]: CameraData(cam_id=d["cam_id"], size=tuple(d["size"]), matrix=np.array(d["K"]) if d["has_intrinsics"] else None,
+                                                    distortions=np.array(d["dist"]) if d["has_intrinsics"] else None, ignore=d["ignore"], rotation=np.eye(3),
+                                                    translation=np.array(d["t"])) for d in desc})
+        dist = [(o, i, o, j, float(size[o] * np.linalg.norm(corners[i] - corners[j])), 0.002) for o in range(n_obj if not remap else 3) for i in range(4) for j in range(i + 1, 4)]
+        remaps = [(3, k, 0, (k + 1) % 4, *(size[0] * corners[(k + 1) % 4]).tolist()) for k in range(4)] if remap else []
+        cs = None if case == 0 else ConstraintSet(tuple(DistanceConstraint(*d) for d in dist), frozenset(static), point_remaps=tuple(PointRemap(*r) for r in remaps))
+        trace, error, run = [], "", None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with scripted(CaptureVolume, WorldPoints, wdf, trace):
+                try:
+                    run = ref_drv.calibrate_extrinsics(ImagePoints(idf), cams, cs, refine_intrinsics=refine, filter_percentile=[2.5, 5.0][case % 2],
+                                                       progress=lambda pct, msg: trace.append(("progress", int(pct), str(msg))))
+                except CalibrationError as exc:
+                    error = str(exc)
+        out = dict(world=wdf.to_numpy(dtype=np.float64), image=idf.to_numpy(dtype=np.float64), static_ids=np.array(static, dtype=np.int64), has_constraints=np.array(cs is not None),
+                   distances=np.array(dist, dtype=np.float64).reshape(-1, 6), remaps=np.array(remaps, dtype=np.float64).reshape(-1, 7),
+                   cam_ids=np.array([d["cam_id"] for d in desc]), sizes=np.array([d["size"] for d in desc]), K=np.array([d["K"] for d in desc]), dist=np.array([d["dist"] for d in desc]),
+                   ignore=np.array([d["ignore"] for d in desc]), has_intrinsics=np.array([d["has_intrinsics"] for d in desc]), t=np.array([d["t"] for d in desc]),
+                   refine=np.array(refine), filter_percentile=np.array([2.5, 5.0][case % 2]), trace=np.array(repr(trace)), error_type=np.array("CalibrationError" if error else ""),
+                   error_mentions=np.array(sorted(c for c in (0, 1, 3, 6) if error and str(c) in error.split("cameras")[1].split("have")[0]) if error else [], dtype=np.int64),
+                   returned=np.array(run is not None))
+        if run is not None:
+            out.update(synthesized=np.array(sorted(run.synthesized_cam_ids), dtype=np.int64), dropped=np.array(run.dropped_static_markers, dtype=np.int64),
+                       gated=np.array(run.intrinsic_refinement_gated),
+                       estimates=np.array([[e.cam_id, e.f_recovered, e.k1_recovered, e.k2_recovered, e.f_initial, e.k1_initial, e.k2_initial] for e in run.intrinsic_estimates],
+                                          dtype=np.float64).reshape(-1, 7),
+                       final_counts=np.array([len(run.capture_volume.image_points.df), len(run.capture_volume.world_points.df)], dtype=np.int64),
+                       final_image_keys=run.capture_volume.image_points.df[IMG_COLS[:4]].to_numpy(dtype=np.int64))
+        np.savez_compressed(OUT / f"driver_{case:02d}.npz", **out)
+        print(f"driver {case}: " + (f"error ({error.splitlines()[0][:70]}...)" if run is None else
+                                   f"synthesized {sorted(run.synthesized_cam_ids)}, dropped {list(run.dropped_static_markers)}, gated {run.intrinsic_refinement_gated}, "
+                                   f"{len(run.intrinsic_estimates)} estimates") + f"; {len(trace)} trace entries: " + " ".join(t[0][0] + (str(t[1]) if t[0] == "progress" else "") for t in trace))
+
+
 if __name__ == "__main__":
     main()
+    driver_cases()
     constraint_row_cases()
     bundle_cases()
     table_cases()

@@ -570,3 +570,59 @@ def test_device_constraint_rows_equal_the_reference_s_own(path):
         r, _ = eng.residuals(ref["x"])
     assert r.size == 4 + ref["residuals"].size
     assert np.allclose(r[4:], ref["residuals"], rtol=0, atol=1e-12 * np.abs(ref["residuals"]).max())
+
+
+# ---- the stage driver calibrate_extrinsics (core/calibrate_extrinsics.py:44-261) with its three heavy calls scripted ---------------------------
+DRIVERS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("driver_*.npz"))
+
+
+def test_the_driver_fixtures_are_there():
+    assert len(DRIVERS) == 8
+
+
+@pytest.mark.parametrize("path", DRIVERS, ids=lambda p: p.stem)
+def test_stage_driver_does_what_the_reference_s_does(path):
+    """``CaptureVolume.bootstrap`` hands back a stored "triangulation", ``optimize`` and the filter record their arguments (tests/driver_script.py,
+    the same stand-ins the generator put on the reference's class); the rest of the driver is real.  The trace — progress marks, what bootstrap
+    received (again after a dropped static marker), every ``optimize`` call's keywords, the filter's percentile — and the ``CalibrationRun`` must be the
+    reference's: blind intrinsics, the static-marker guard on the rigidity report, the depth-ratio gate on intrinsic refinement, the estimates."""
+    import ast
+
+    from caliscope_amd.calibrate_extrinsics import calibrate_extrinsics
+    from caliscope_amd.constraints import PointRemap
+    from caliscope_amd.exceptions import CalibrationError
+    from tests.driver_script import scripted
+
+    ref = np.load(path)
+    wdf = pd.DataFrame(ref["world"], columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+    idf = pd.DataFrame(ref["image"], columns=IMG_COLS + ["obj_loc_x", "obj_loc_y", "obj_loc_z"]).astype({c: "int64" for c in IMG_COLS[:4]})
+    cams = CameraArray({int(c): CameraData(cam_id=int(c), size=(int(sz[0]), int(sz[1])), matrix=K.copy() if has else None, distortions=d.copy() if has else None,
+                                           ignore=bool(ig), rotation=np.eye(3), translation=t.copy())
+                        for c, sz, K, d, ig, has, t in zip(ref["cam_ids"], ref["sizes"], ref["K"], ref["dist"], ref["ignore"], ref["has_intrinsics"], ref["t"])})
+    cs = None
+    if bool(ref["has_constraints"]):
+        cs = ConstraintSet(tuple(DistanceConstraint(int(a), int(b), int(c), int(d), float(e), float(f)) for a, b, c, d, e, f in ref["distances"]),
+                           frozenset(int(o) for o in ref["static_ids"]),
+                           point_remaps=tuple(PointRemap(int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]), float(r[5]), float(r[6])) for r in ref["remaps"]))
+    trace, run, error = [], None, None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with scripted(CaptureVolume, WorldPoints, wdf, trace):
+            try:
+                run = calibrate_extrinsics(ImagePoints(idf), cams, cs, refine_intrinsics=bool(ref["refine"]), filter_percentile=float(ref["filter_percentile"]),
+                                           progress=lambda pct, msg: trace.append(("progress", int(pct), str(msg))))
+            except CalibrationError as exc:
+                error = exc
+    want = ast.literal_eval(str(ref["trace"]))
+    assert trace == want, "\n".join(f"{a}\n{b}" for a, b in zip(trace, want) if a != b)
+    assert (run is not None) == bool(ref["returned"]) and ("CalibrationError" if error is not None else "") == str(ref["error_type"])
+    if run is None:
+        assert all(str(int(c)) in str(error) for c in ref["error_mentions"])  # (the message names the cameras that fell back to blind intrinsics; its wording is this package's)
+        return
+    assert sorted(run.synthesized_cam_ids) == ref["synthesized"].tolist() and list(run.dropped_static_markers) == ref["dropped"].tolist()
+    assert bool(run.intrinsic_refinement_gated) == bool(ref["gated"])
+    est = np.array([[e.cam_id, e.f_recovered, e.k1_recovered, e.k2_recovered, e.f_initial, e.k1_initial, e.k2_initial] for e in run.intrinsic_estimates],
+                   dtype=np.float64).reshape(-1, 7)
+    assert np.array_equal(est, ref["estimates"])
+    assert [len(run.capture_volume.image_points.df), len(run.capture_volume.world_points.df)] == ref["final_counts"].tolist()
+    assert np.array_equal(run.capture_volume.image_points.df[IMG_COLS[:4]].to_numpy(dtype=np.int64), ref["final_image_keys"])
