@@ -38,7 +38,9 @@ Eighth family (``seam_*.npz``): the seam itself — what the reference's ``optim
 
 Ninth family (``conrows_*.npz``): the constraint rows of the reference's own ``joint_residuals`` / ``joint_jacobian`` (see ``constraint_row_cases``).
 
-Tenth family (``driver_*.npz``): the stage driver ``calibrate_extrinsics`` with its three heavy calls scripted (see ``driver_cases``)."""
+Tenth family (``driver_*.npz``): the stage driver ``calibrate_extrinsics`` with its three heavy calls scripted (see ``driver_cases``).
+
+Eleventh family (``dlt_*.npz``): the reference's batched SVD triangulation, a plain numpy function (see ``dlt_cases``)."""
 import sys
 import tempfile
 import types
@@ -812,8 +814,42 @@ def driver_cases():
                                    f"{len(run.intrinsic_estimates)} estimates") + f"; {len(trace)} trace entries: " + " ".join(t[0][0] + (str(t[1]) if t[0] == "progress" else "") for t in trace))
 
 
+def dlt_cases():
+    """``triangulate_image_points`` (core/point_data.py:121-232): the reference's batched SVD triangulation is a module-level numpy function — no OpenCV,
+    no stub.  Random rigs, points seen by two to all cameras (and by one: not triangulated), noisy normalised coordinates, several objects and
+    frames.  Consumer: the oracle's restatement (oracle/triangulation.py), which the device triangulation is compared with on the GPU."""
+    from scipy.spatial.transform import Rotation
+
+    from caliscope.core.point_data import triangulate_image_points
+
+    for case in range(6):
+        rng = np.random.default_rng(37000 + case)
+        n_cams = int(rng.integers(2, 8))
+        cam_ids = sorted(rng.choice(30, size=n_cams, replace=False).tolist())
+        P = {}
+        for c in cam_ids:
+            R = Rotation.from_rotvec(rng.normal(0, 0.4, 3)).as_matrix()
+            P[int(c)] = np.hstack([R, (rng.normal(0, 0.5, 3) + [0, 0, 4.0]).reshape(3, 1)])
+        sync, cam, obj, kp, xy = [], [], [], [], []
+        for f in range(int(rng.integers(2, 6))):
+            for o in range(int(rng.integers(1, 4))):
+                for k in range(int(rng.integers(1, 6))):
+                    X = np.append(rng.normal(0, 0.6, 3), 1.0)
+                    for c in rng.choice(cam_ids, size=int(rng.integers(1, n_cams + 1)), replace=False):
+                        h = P[int(c)] @ X
+                        sync.append(f); cam.append(int(c)); obj.append(o); kp.append(k)
+                        xy.append(h[:2] / h[2] + rng.normal(0, 1e-3, 2))
+        order = rng.permutation(len(sync))
+        sync, cam, obj, kp, xy = (np.asarray(a)[order] for a in (sync, cam, obj, kp, xy))
+        o_sync, o_obj, o_kp, o_xyz = triangulate_image_points(P, sync, cam, obj, kp, xy)
+        np.savez_compressed(OUT / f"dlt_{case:02d}.npz", cam_ids=np.array(cam_ids), P=np.array([P[int(c)] for c in cam_ids]), sync=sync, cam=cam, obj=obj, kp=kp, xy=xy,
+                            out_sync=o_sync, out_obj=o_obj, out_kp=o_kp, out_xyz=o_xyz)
+        print(f"dlt {case}: {n_cams} cameras, {len(sync)} observations -> {len(o_xyz)} points")
+
+
 if __name__ == "__main__":
     main()
+    dlt_cases()
     driver_cases()
     constraint_row_cases()
     bundle_cases()

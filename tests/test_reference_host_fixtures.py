@@ -626,3 +626,42 @@ def test_stage_driver_does_what_the_reference_s_does(path):
     assert np.array_equal(est, ref["estimates"])
     assert [len(run.capture_volume.image_points.df), len(run.capture_volume.world_points.df)] == ref["final_counts"].tolist()
     assert np.array_equal(run.capture_volume.image_points.df[IMG_COLS[:4]].to_numpy(dtype=np.int64), ref["final_image_keys"])
+
+
+# ---- the reference's batched SVD triangulation (core/point_data.py:121-232), a plain numpy function ---------------------------------------------
+DLTS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("dlt_*.npz"))
+
+
+def test_the_triangulation_fixtures_are_there():
+    assert len(DLTS) == 6
+
+
+@pytest.mark.parametrize("path", DLTS, ids=lambda p: p.stem)
+def test_oracle_triangulation_equals_the_reference_s_own(path):
+    """``triangulate_image_points`` of the reference needs no OpenCV: its output on random rigs (points seen by one camera are left out, the rest
+    solved by SVD per camera set) against the oracle's restatement — the function the device triangulation is compared with on the GPU
+    (tests/test_triangulation.py).  Same points (set of keys), coordinates to 1e-9."""
+    from oracle import triangulation as otri
+
+    ref = np.load(path)
+    P = {int(c): p for c, p in zip(ref["cam_ids"], ref["P"])}
+    sync, obj, kp, xyz = otri.triangulate_image_points(P, ref["sync"], ref["cam"], ref["obj"], ref["kp"], ref["xy"])
+    mine = _sorted_rows(np.column_stack([sync, obj, kp]), xyz)
+    want = _sorted_rows(np.column_stack([ref["out_sync"], ref["out_obj"], ref["out_kp"]]), ref["out_xyz"])
+    assert mine.shape == want.shape and np.array_equal(mine[:, :3], want[:, :3])
+    assert np.allclose(mine[:, 3:], want[:, 3:], rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", DLTS, ids=lambda p: p.stem)
+def test_device_triangulation_equals_the_reference_s_own(path):
+    """The same stored output against ``cba_triangulate`` (no undistortion: the fixture's coordinates are normalised already)."""
+    from caliscope_amd.triangulation import triangulate_image_points
+
+    ref = np.load(path)
+    P = {int(c): p for c, p in zip(ref["cam_ids"], ref["P"])}
+    sync, obj, kp, xyz = triangulate_image_points(P, ref["sync"], ref["cam"], ref["obj"], ref["kp"], ref["xy"])
+    mine = _sorted_rows(np.column_stack([sync, obj, kp]), xyz)
+    want = _sorted_rows(np.column_stack([ref["out_sync"], ref["out_obj"], ref["out_kp"]]), ref["out_xyz"])
+    assert mine.shape == want.shape and np.array_equal(mine[:, :3], want[:, :3])
+    assert np.allclose(mine[:, 3:], want[:, 3:], rtol=0, atol=1e-9)
