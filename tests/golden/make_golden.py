@@ -10,6 +10,10 @@ Run in the build container (where /root/reference is mounted):  python tests/gol
       <- /root/reference/tests/sessions/post_optimization/...
       a real calibrated 4-camera session (BASELINE.json configs[0]); used by the reference in
       tests/test_reprojection_report.py and tests/test_capture_volume.py.
+  reference_host/*.npz  <- tests/golden/make_reference_host_fixtures.py: random inputs and what the REFERENCE'S OWN host code returned for them in the
+      build container (eleven families: tables, parameterization, constraint compilers and rows, filters, report bookkeeping, on-disk formats,
+      the optimize() seam, the stage driver, triangulation); its docstring says what was stubbed (cv2 / rtoml imports) and why that does not
+      touch the code under test.  Regenerating reproduces the committed files byte for byte.
   scipy_refs/*.npz  <- tests/golden/make_scipy_refs.py: solutions of the reference's scipy call (oracle callables) at BASELINE sizes, computed on the
       CPU of the build container (minutes to an hour and a half each); consumers check the stored x0 digest against their own x0.
 """
