@@ -40,7 +40,9 @@ Ninth family (``conrows_*.npz``): the constraint rows of the reference's own ``j
 
 Tenth family (``driver_*.npz``): the stage driver ``calibrate_extrinsics`` with its three heavy calls scripted (see ``driver_cases``).
 
-Eleventh family (``dlt_*.npz``): the reference's batched SVD triangulation, a plain numpy function (see ``dlt_cases``)."""
+Eleventh family (``dlt_*.npz``): the reference's batched SVD triangulation, a plain numpy function (see ``dlt_cases``).
+
+Twelfth family (``triangulate_*.npz``): ``ImagePoints.triangulate`` for cameras without lens distortion (see ``triangulate_cases``)."""
 import sys
 import tempfile
 import types
@@ -847,8 +849,73 @@ def dlt_cases():
         print(f"dlt {case}: {n_cams} cameras, {len(sync)} observations -> {len(o_xyz)} points")
 
 
+def triangulate_cases():
+    """``ImagePoints.triangulate(camera_array, static_object_ids)`` (core/point_data.py:416-560) for cameras WITHOUT lens distortion: which cameras take
+    part (posed, not ignored), static objects pooled over all frames into one point at STATIC_SYNC_INDEX, points seen once left out, the mean frame
+    time per sync index, the table that comes back.  The reference undistorts through ``cv2.undistortPoints`` on float32 copies of the pixel
+    coordinates; for zero distortion coefficients that function is the linear map (u - cx) / fx, (v - cy) / fy evaluated in double and returned as
+    float32 — which is what the stub does here (it refuses any non-zero coefficient).  The triangulation itself is the reference's numpy code."""
+    import cv2
+    from scipy.spatial.transform import Rotation
+
+    from caliscope.cameras.camera_array import CameraArray, CameraData
+    from caliscope.core.point_data import ImagePoints
+
+    def undistort_zero(points, K, dist, P=None):
+        assert not np.any(np.asarray(dist)), "the stub stands for OpenCV only where OpenCV is the identity"
+        assert P is not None and np.array_equal(np.asarray(P), np.identity(3))
+        pts = np.asarray(points)
+        assert pts.dtype == np.float32
+        out = np.empty_like(pts)
+        out[..., 0] = ((pts[..., 0].astype(np.float64) - K[0, 2]) / K[0, 0]).astype(np.float32)
+        out[..., 1] = ((pts[..., 1].astype(np.float64) - K[1, 2]) / K[1, 1]).astype(np.float32)
+        return out
+
+    cv2.undistortPoints = undistort_zero
+    for case in range(6):
+        rng = np.random.default_rng(41000 + case)
+        ids = sorted(rng.choice(20, size=int(rng.integers(3, 7)), replace=False).tolist())
+        desc = []
+        for n, c in enumerate(ids):
+            f = float(rng.uniform(500, 1200))
+            desc.append(dict(cam_id=int(c), K=[[f, 0.0, float(rng.uniform(300, 700))], [0.0, f * 1.01, float(rng.uniform(200, 500))], [0.0, 0.0, 1.0]],
+                             rvec=rng.normal(0, 0.3, 3).tolist(), t=(rng.normal(0, 0.4, 3) + [0, 0, 4.0]).tolist(),
+                             posed=not (n == len(ids) - 1 and case % 2 == 0), ignore=(n == 0 and case % 3 == 0)))
+        cams = CameraArray({d["cam_id"]: CameraData(cam_id=d["cam_id"], size=(1280, 720), matrix=np.array(d["K"]), distortions=np.zeros(5), ignore=d["ignore"],
+                                                    rotation=Rotation.from_rotvec(d["rvec"]).as_matrix() if d["posed"] else None,
+                                                    translation=np.array(d["t"]) if d["posed"] else None) for d in desc})
+        static = [5] if case % 2 else []
+        rows = []
+        frames = list(range(int(rng.integers(2, 6))))
+        for o in (0, 3, 5):
+            fixed = {k: rng.normal(0, 0.5, 3) for k in range(4)}
+            for f in frames:
+                for k in range(4):
+                    X = fixed[k] if o in static else rng.normal(0, 0.5, 3)
+                    for d in desc:
+                        if rng.random() < 0.7:
+                            R = Rotation.from_rotvec(d["rvec"]).as_matrix()
+                            h = R @ X + np.array(d["t"])
+                            K = np.array(d["K"])
+                            rows.append((f, d["cam_id"], o, k, float(K[0, 0] * h[0] / h[2] + K[0, 2] + rng.normal(0, 0.3)), float(K[1, 1] * h[1] / h[2] + K[1, 2] + rng.normal(0, 0.3)),
+                                         f / 30.0 + 0.001 * d["cam_id"]))
+        rows = [rows[i] for i in rng.permutation(len(rows))]
+        idf = pd.DataFrame(rows, columns=IMG_COLS + ["frame_time"]).astype({c: "int64" for c in IMG_COLS[:4]})
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wp = ImagePoints(idf).triangulate(cams, static_object_ids=frozenset(static))
+        out = wp.df
+        np.savez_compressed(OUT / f"triangulate_{case:02d}.npz", image=idf.to_numpy(dtype=np.float64), cam_ids=np.array(ids), K=np.array([d["K"] for d in desc]),
+                            rvec=np.array([d["rvec"] for d in desc]), t=np.array([d["t"] for d in desc]), posed=np.array([d["posed"] for d in desc]),
+                            ignore=np.array([d["ignore"] for d in desc]), static_ids=np.array(static, dtype=np.int64),
+                            world=out[WORLD_COLS].to_numpy(dtype=np.float64), world_columns=np.array(list(out.columns)))
+        print(f"triangulate {case}: cameras {ids} (unposed {[d['cam_id'] for d in desc if not d['posed']]}, ignored {[d['cam_id'] for d in desc if d['ignore']]}), "
+              f"{len(idf)} observations, static {static} -> {len(out)} world points ({int((out['sync_index'] == -1).sum())} static)")
+
+
 if __name__ == "__main__":
     main()
+    triangulate_cases()
     dlt_cases()
     driver_cases()
     constraint_row_cases()

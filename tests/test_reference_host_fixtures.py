@@ -665,3 +665,70 @@ def test_device_triangulation_equals_the_reference_s_own(path):
     want = _sorted_rows(np.column_stack([ref["out_sync"], ref["out_obj"], ref["out_kp"]]), ref["out_xyz"])
     assert mine.shape == want.shape and np.array_equal(mine[:, :3], want[:, :3])
     assert np.allclose(mine[:, 3:], want[:, 3:], rtol=0, atol=1e-9)
+
+
+# ---- ImagePoints.triangulate (core/point_data.py:416-560) for cameras without lens distortion ------------------------------------------------------
+TRIANGULATES = sorted((Path(__file__).parent / "golden" / "reference_host").glob("triangulate_*.npz"))
+
+
+def _oracle_run(cam_P, starts, cam_index, xy, *, cam_model=None, cam_intr=None, float32_io=True, device_id=0, want_undistorted=False):
+    """What ``caliscope_amd.triangulation._run`` asks of the device (undistort every observation with its camera's table, one DLT per group), from the
+    oracle (oracle/triangulation.py): the CPU stand-in for ``cba_triangulate``, which has its own device-against-oracle tests."""
+    from oracle import triangulation as otri
+
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    und = xy.copy()
+    if cam_intr is not None:
+        for c in np.unique(cam_index):
+            m = cam_index == c
+            fx, fy, cx, cy = cam_intr[c, :4]
+            K = np.array([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+            und[m] = otri.undistort_points(xy[m], K, cam_intr[c, 4:9] if not cam_model[c] else cam_intr[c, 4:8], bool(cam_model[c]), float32_io=float32_io)
+    xyz = np.full((len(starts) - 1, 3), np.nan)
+    for g in range(len(starts) - 1):
+        a, b = int(starts[g]), int(starts[g + 1])
+        if b - a >= 2:
+            xyz[g] = otri.triangulate_point([np.asarray(cam_P[cam_index[i]]).reshape(3, 4) for i in range(a, b)], und[a:b])
+    return xyz, (und if want_undistorted else None)
+
+
+def test_the_high_level_triangulation_fixtures_are_there():
+    assert len(TRIANGULATES) == 6
+
+
+def _triangulate_fixture(path, monkeypatch=None):
+    import caliscope_amd.triangulation as tri
+    from caliscope_amd.cameras import rvec_to_matrix
+
+    ref = np.load(path)
+    idf = pd.DataFrame(ref["image"], columns=IMG_COLS + ["frame_time"]).astype({c: "int64" for c in IMG_COLS[:4]})
+    cams = CameraArray({int(c): CameraData(cam_id=int(c), size=(1280, 720), matrix=K.copy(), distortions=np.zeros(5), ignore=bool(ig),
+                                           rotation=rvec_to_matrix(rv) if p else None, translation=t.copy() if p else None)
+                        for c, K, rv, t, p, ig in zip(ref["cam_ids"], ref["K"], ref["rvec"], ref["t"], ref["posed"], ref["ignore"])})
+    if monkeypatch is not None:
+        monkeypatch.setattr(tri, "_run", _oracle_run)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wp = ImagePoints(idf).triangulate(cams, static_object_ids=frozenset(int(o) for o in ref["static_ids"]))
+    out = wp.df
+    assert [c for c in ref["world_columns"] if c in WORLD_COLS] == [c for c in out.columns if c in WORLD_COLS]
+    mine, want = _sorted_rows(out[WORLD_COLS].to_numpy(dtype=np.float64)), _sorted_rows(ref["world"])
+    assert mine.shape == want.shape and np.array_equal(mine[:, :3], want[:, :3])
+    assert np.allclose(mine[:, 3:6], want[:, 3:6], rtol=0, atol=1e-8)
+    assert np.array_equal(np.isnan(mine[:, 6]), np.isnan(want[:, 6])) and np.allclose(mine[:, 6], want[:, 6], rtol=0, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", TRIANGULATES, ids=lambda p: p.stem)
+def test_triangulate_on_the_device_equals_the_reference_s_own_output(path):
+    """The same fixtures through ``cba_triangulate`` itself (undistortion of float32 pixel input and DLT on the device)."""
+    _triangulate_fixture(path)
+
+
+@pytest.mark.parametrize("path", TRIANGULATES, ids=lambda p: p.stem)
+def test_triangulate_host_logic_equals_the_reference_s_own_output(path, monkeypatch):
+    """Which cameras take part (posed and not ignored), static objects pooled into one point at STATIC_SYNC_INDEX, points seen once left out,
+    frame times, float32 pixel input, the table that comes back — against the reference's own ``ImagePoints.triangulate`` (zero-distortion
+    cameras: the generator says what stood in for ``cv2.undistortPoints``).  The device call is replaced by the oracle here; the device has its own
+    tests against the same oracle and against the reference's numpy triangulation (above)."""
+    _triangulate_fixture(path, monkeypatch)
