@@ -222,8 +222,14 @@ def bundle_cases():
         blocks = np.array([[b.cam_id, int(b.free_intrinsics), b.fx_initial, b.fy_initial, b.cx, b.cy, int(b.fisheye), b.k1_initial, b.k2_initial, len(b.dist_fixed),
                             *(list(b.dist_fixed) + [0.0] * (4 - len(b.dist_fixed)))] for b in par.blocks], dtype=np.float64)
         opt_ids = [b.cam_id for b in par.blocks]
+        # the flattening this package hands to the C ABI, computed from the REFERENCE'S OWN parameterization object (the seam is
+        # duck-typed — the one-line patch passes the reference's class, not this package's)
+        sys.path.insert(0, str(HERE.parent.parent))
+        from caliscope_amd.bundle_parameterization import device_tables, n_params_of
+
+        tabs = device_tables(par)
         np.savez_compressed(
-            OUT / f"bundle_{case:02d}.npz",
+            OUT / f"bundle_{case:02d}.npz", n_params_of=np.array(n_params_of(par)), **{f"device_{k}": np.asarray(v) for k, v in tabs.items()},
             cam_ids=np.array([d["cam_id"] for d in desc]), sizes=np.array([d["size"] for d in desc]), K=np.array([d["K"] for d in desc]),
             dist=np.array([d["dist"] + [np.nan] * (5 - len(d["dist"])) for d in desc]), fisheye=np.array([d["fisheye"] for d in desc]),
             ignore=np.array([d["ignore"] for d in desc]), posed=np.array([d["rvec"] is not None for d in desc]),

@@ -134,6 +134,14 @@ def test_parameterization_equals_the_reference_s_own_output(path):
         rvec, tvec, K, dist = par.trial_projection_inputs(x1, k)
         assert np.array_equal(rvec, ref["trial_rvec"][k]) and np.array_equal(tvec, ref["trial_tvec"][k]) and np.array_equal(K, ref["trial_K"][k])
         assert np.array_equal(np.ravel(dist), ref["trial_dist"][k][: np.size(dist)]) and np.all(np.isnan(ref["trial_dist"][k][np.size(dist):]))
+    # the tables the C ABI receives: the generator flattened the REFERENCE'S OWN parameterization object with this package's device_tables (the
+    # one-line patch passes the reference's class through the duck-typed seam); this package's class must flatten to the same
+    from caliscope_amd.bundle_parameterization import device_tables, n_params_of
+
+    tabs = device_tables(par)
+    assert n_params_of(par) == int(ref["n_params_of"]) and {f"device_{k}" for k in tabs} == {k for k in ref.files if k.startswith("device_")}
+    for k, v in tabs.items():
+        assert np.array_equal(np.asarray(v), ref[f"device_{k}"]), k
     sp = par.sparsity(ref["cam_idx"], ref["obj_idx"], 4, ref["groups_a"], ref["groups_b"]).tocoo()
     assert tuple(sp.shape) == tuple(int(v) for v in ref["sparsity_shape"])
     mine = set(zip(sp.row[sp.data != 0].tolist(), sp.col[sp.data != 0].tolist()))
