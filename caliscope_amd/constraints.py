@@ -202,10 +202,11 @@ class ConstraintSet:
 
         df = image_points.df
         obj, kp = df["object_id"].to_numpy().copy(), df["keypoint_id"].to_numpy().copy()
-        src_obj, src_kp = obj.copy(), kp.copy()
         loc = {c: df[c].to_numpy(dtype=np.float64).copy() for c in ("obj_loc_x", "obj_loc_y", "obj_loc_z") if c in df.columns}
         for r in self.point_remaps:
-            hit = (src_obj == r.object_id_from) & (src_kp == r.keypoint_id_from)
+            # one after the other on the identities AS THEY ARE BY NOW, as the reference's loop over the same frame does: an observation whose new
+            # identity is the source of a later remap moves again (tests/golden/reference_host/remap_*.npz)
+            hit = (obj == r.object_id_from) & (kp == r.keypoint_id_from)
             obj[hit], kp[hit] = r.object_id_to, r.keypoint_id_to
             for c, v in zip(("obj_loc_x", "obj_loc_y", "obj_loc_z"), (r.obj_loc_x, r.obj_loc_y, r.obj_loc_z)):
                 if c in loc:

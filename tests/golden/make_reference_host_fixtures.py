@@ -42,7 +42,9 @@ Tenth family (``driver_*.npz``): the stage driver ``calibrate_extrinsics`` with 
 
 Eleventh family (``dlt_*.npz``): the reference's batched SVD triangulation, a plain numpy function (see ``dlt_cases``).
 
-Twelfth family (``triangulate_*.npz``): ``ImagePoints.triangulate`` for cameras without lens distortion (see ``triangulate_cases``)."""
+Twelfth family (``triangulate_*.npz``): ``ImagePoints.triangulate`` for cameras without lens distortion (see ``triangulate_cases``).
+
+Thirteenth family (``remap_*.npz``): ``ConstraintSet.remap_image_points`` with arbitrary, also chained, remaps (see ``remap_cases``)."""
 import sys
 import tempfile
 import types
@@ -919,8 +921,41 @@ def triangulate_cases():
               f"{len(idf)} observations, static {static} -> {len(out)} world points ({int((out['sync_index'] == -1).sum())} static)")
 
 
+def remap_cases():
+    """``ConstraintSet.remap_image_points`` (core/constraints.py:192-214) with arbitrary ``PointRemap`` tuples — also ones whose target is the source of
+    a LATER remap (the reference applies them one after the other on the same frame, so such observations move twice) and ones nothing matches."""
+    from caliscope.core.constraints import ConstraintSet, PointRemap
+    from caliscope.core.point_data import ImagePoints
+
+    for case in range(6):
+        rng = np.random.default_rng(43000 + case)
+        rows = []
+        for f in range(int(rng.integers(3, 8))):
+            for o in range(5):
+                for k in range(4):
+                    for cam in range(3):
+                        if rng.random() < 0.6:
+                            rows.append((f, cam, o, k, float(rng.normal(300, 50)), float(rng.normal(300, 50)), *(rng.normal(0, 0.1, 3).tolist() if rng.random() < 0.8 else [float("nan")] * 3)))
+        rows = [rows[i] for i in rng.permutation(len(rows))]
+        idf = pd.DataFrame(rows, columns=IMG_COLS + ["obj_loc_x", "obj_loc_y", "obj_loc_z"]).astype({c: "int64" for c in IMG_COLS[:4]})
+        remaps = [(int(rng.integers(0, 6)), int(rng.integers(0, 4)), int(rng.integers(0, 5)), int(rng.integers(0, 4)), *rng.normal(0, 0.1, 3).tolist()) for _ in range(int(rng.integers(1, 9)))]
+        if case % 2 == 0 and len(remaps) >= 2:  # a chain: the second remap picks up what the first produced
+            a = remaps[0]
+            remaps[1] = (a[2], a[3], int(rng.integers(0, 5)), int(rng.integers(0, 4)), *rng.normal(0, 0.1, 3).tolist())
+        cs = ConstraintSet((), frozenset(), point_remaps=tuple(PointRemap(*r) for r in remaps))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = cs.remap_image_points(ImagePoints(idf.copy())).df
+            same_object = ConstraintSet((), frozenset()).remap_image_points(ip := ImagePoints(idf.copy())) is ip
+        np.savez_compressed(OUT / f"remap_{case:02d}.npz", image=idf.to_numpy(dtype=np.float64), remaps=np.array(remaps, dtype=np.float64).reshape(-1, 7),
+                            out=out.to_numpy(dtype=np.float64), out_columns=np.array(list(out.columns)), no_remaps_returns_the_input=np.array(same_object))
+        moved = int(((out[["object_id", "keypoint_id"]].to_numpy() != idf[["object_id", "keypoint_id"]].to_numpy()).any(axis=1)).sum()) if len(out) == len(idf) else -1
+        print(f"remap {case}: {len(idf)} observations, {len(remaps)} remaps -> {moved} observations renamed")
+
+
 if __name__ == "__main__":
     main()
+    remap_cases()
     triangulate_cases()
     dlt_cases()
     driver_cases()

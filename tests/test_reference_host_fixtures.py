@@ -740,3 +740,29 @@ def test_triangulate_host_logic_equals_the_reference_s_own_output(path, monkeypa
     cameras: the generator says what stood in for ``cv2.undistortPoints``).  The device call is replaced by the oracle here; the device has its own
     tests against the same oracle and against the reference's numpy triangulation (above)."""
     _triangulate_fixture(path, monkeypatch)
+
+
+# ---- ConstraintSet.remap_image_points (core/constraints.py:192-214) ------------------------------------------------------------------------------
+REMAPS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("remap_*.npz"))
+
+
+def test_the_remap_fixtures_are_there():
+    assert len(REMAPS) == 6
+
+
+@pytest.mark.parametrize("path", REMAPS, ids=lambda p: p.stem)
+def test_observation_remaps_equal_the_reference_s_own_output(path):
+    """Arbitrary remap tuples — some chained (the target of one is the source of a later one: the reference applies them in turn on the same frame),
+    some matching nothing; identity and board coordinates rewritten, everything else of the row kept; no remaps: the input object itself."""
+    from caliscope_amd.constraints import PointRemap
+
+    ref = np.load(path)
+    cols = IMG_COLS + ["obj_loc_x", "obj_loc_y", "obj_loc_z"]
+    idf = pd.DataFrame(ref["image"], columns=cols).astype({c: "int64" for c in IMG_COLS[:4]})
+    cs = ConstraintSet((), frozenset(), point_remaps=tuple(PointRemap(int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]), float(r[5]), float(r[6])) for r in ref["remaps"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = cs.remap_image_points(ImagePoints(idf.copy())).df
+        ip = ImagePoints(idf.copy())
+        assert (ConstraintSet((), frozenset()).remap_image_points(ip) is ip) == bool(ref["no_remaps_returns_the_input"])
+    _same_table(out, ref["out"], [str(c) for c in ref["out_columns"]])
