@@ -44,7 +44,9 @@ Eleventh family (``dlt_*.npz``): the reference's batched SVD triangulation, a pl
 
 Twelfth family (``triangulate_*.npz``): ``ImagePoints.triangulate`` for cameras without lens distortion (see ``triangulate_cases``).
 
-Thirteenth family (``remap_*.npz``): ``ConstraintSet.remap_image_points`` with arbitrary, also chained, remaps (see ``remap_cases``)."""
+Thirteenth family (``remap_*.npz``): ``ConstraintSet.remap_image_points`` with arbitrary, also chained, remaps (see ``remap_cases``).
+
+Fourteenth (``camtoml_00.npz``): ``CameraArray.from_toml`` on camera files of the reference's side (see ``camera_toml_cases``)."""
 import sys
 import tempfile
 import types
@@ -953,8 +955,71 @@ def remap_cases():
         print(f"remap {case}: {len(idf)} observations, {len(remaps)} remaps -> {moved} observations renamed")
 
 
+def camera_toml_cases():
+    """``CameraArray.from_toml`` (cameras/camera_array.py:377-441) on files the reference's side wrote: the real session's ``camera_array.toml`` (3 x 3
+    rotation matrices, an extra key) and hand-made variants of the shapes its loader accepts — rotation as a 3-vector (through the scipy
+    ``Rodrigues`` stub), the string "null" for a missing value, absent optional keys, an unposed camera, a fisheye camera, an empty file."""
+    from caliscope.cameras.camera_array import CameraArray
+
+    texts = {
+        "session": (HERE / "post_optimization" / "camera_array.toml").read_text(),
+        "variants": """
+[cameras.3]
+cam_id = 3
+size = [640, 480]
+matrix = [[500.0, 0.0, 320.0], [0.0, 501.0, 240.0], [0.0, 0.0, 1.0]]
+distortions = [0.01, -0.02, 0.0, 0.0, 0.003]
+rotation = [0.1, -0.2, 0.3]
+translation = [0.5, 0.25, 2.0]
+error = "null"
+exposure = "null"
+
+[cameras.11]
+cam_id = 11
+size = [1920, 1080]
+rotation_count = 2
+fisheye = true
+ignore = true
+grid_count = 17
+matrix = [[700.0, 0.0, 960.0], [0.0, 700.0, 540.0], [0.0, 0.0, 1.0]]
+distortions = [0.05, -0.01, 0.003, -0.001]
+rotation = [[0.0], [0.0], [0.5]]
+translation = [0.0, 0.0, 1.0]
+
+[cameras.7]
+cam_id = 7
+size = [800, 600]
+""",
+        "empty": "",
+    }
+    out = {}
+    for name, text in texts.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            path = Path(tmp) / "camera_array.toml"
+            path.write_text(text)
+            arr = CameraArray.from_toml(path)
+        ids = sorted(arr.cameras)
+
+        def opt(v):
+            return np.nan if v is None else float(v)
+
+        out[f"{name}_text"] = np.array(text)
+        out[f"{name}_ids"] = np.array(ids, dtype=np.int64)
+        out[f"{name}_scalars"] = np.array([[arr.cameras[c].size[0], arr.cameras[c].size[1], arr.cameras[c].rotation_count, opt(arr.cameras[c].error), opt(arr.cameras[c].exposure),
+                                             opt(arr.cameras[c].grid_count), float(bool(arr.cameras[c].ignore)), float(bool(arr.cameras[c].fisheye))] for c in ids], dtype=np.float64).reshape(-1, 8)
+        out[f"{name}_K"] = np.array([arr.cameras[c].matrix if arr.cameras[c].matrix is not None else np.full((3, 3), np.nan) for c in ids]).reshape(-1, 3, 3)
+        out[f"{name}_dist"] = np.array([list(np.ravel(arr.cameras[c].distortions)) + [np.nan] * (5 - np.size(arr.cameras[c].distortions)) if arr.cameras[c].distortions is not None
+                                        else [np.nan] * 5 for c in ids]).reshape(-1, 5)
+        out[f"{name}_n_dist"] = np.array([-1 if arr.cameras[c].distortions is None else np.size(arr.cameras[c].distortions) for c in ids], dtype=np.int64)
+        out[f"{name}_R"] = np.array([arr.cameras[c].rotation if arr.cameras[c].rotation is not None else np.full((3, 3), np.nan) for c in ids]).reshape(-1, 3, 3)
+        out[f"{name}_t"] = np.array([np.ravel(arr.cameras[c].translation) if arr.cameras[c].translation is not None else [np.nan] * 3 for c in ids]).reshape(-1, 3)
+        print(f"camera toml '{name}': cameras {ids}, posed {[c for c in ids if arr.cameras[c].rotation is not None]}")
+    np.savez_compressed(OUT / "camtoml_00.npz", names=np.array(list(texts)), **out)
+
+
 if __name__ == "__main__":
     main()
+    camera_toml_cases()
     remap_cases()
     triangulate_cases()
     dlt_cases()

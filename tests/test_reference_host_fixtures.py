@@ -766,3 +766,33 @@ def test_observation_remaps_equal_the_reference_s_own_output(path):
         ip = ImagePoints(idf.copy())
         assert (ConstraintSet((), frozenset()).remap_image_points(ip) is ip) == bool(ref["no_remaps_returns_the_input"])
     _same_table(out, ref["out"], [str(c) for c in ref["out_columns"]])
+
+
+# ---- CameraArray.from_toml (cameras/camera_array.py:377-441) on camera files of the reference's side ---------------------------------------------
+def test_camera_files_load_as_the_reference_loads_them(tmp_path):
+    """The real session's ``camera_array.toml`` (3 x 3 rotations, a key this package does not know), and the shapes the reference's loader accepts:
+    rotation as a 3-vector or a 3 x 1 column, the string "null" for a missing value, absent optional keys, a camera with nothing but its size, a
+    fisheye camera, an empty file."""
+    ref = np.load(Path(__file__).parent / "golden" / "reference_host" / "camtoml_00.npz")
+
+    def opt(v):
+        return np.nan if v is None else float(v)
+
+    for name in (str(n) for n in ref["names"]):
+        path = tmp_path / f"{name}.toml"
+        path.write_text(str(ref[f"{name}_text"]))
+        arr = CameraArray.from_toml(path)
+        ids = sorted(arr.cameras)
+        assert ids == ref[f"{name}_ids"].tolist(), name
+        for k, c in enumerate(ids):
+            cam = arr.cameras[c]
+            mine = np.array([cam.size[0], cam.size[1], cam.rotation_count, opt(cam.error), opt(cam.exposure), opt(cam.grid_count), float(bool(cam.ignore)), float(bool(cam.fisheye))])
+            assert np.array_equal(mine, ref[f"{name}_scalars"][k], equal_nan=True), (name, c, mine, ref[f"{name}_scalars"][k])
+            n_dist = int(ref[f"{name}_n_dist"][k])
+            assert (cam.distortions is None) == (n_dist < 0) and (cam.matrix is None) == bool(np.isnan(ref[f"{name}_K"][k]).all())
+            if cam.matrix is not None:
+                assert np.array_equal(cam.matrix, ref[f"{name}_K"][k]) and np.array_equal(np.ravel(cam.distortions), ref[f"{name}_dist"][k][:n_dist])
+            posed = not np.isnan(ref[f"{name}_R"][k]).any()
+            assert (cam.rotation is not None) == posed and (cam.translation is not None) == (not np.isnan(ref[f"{name}_t"][k]).any())
+            if posed:
+                assert np.allclose(cam.rotation, ref[f"{name}_R"][k], rtol=0, atol=1e-12) and np.array_equal(np.ravel(cam.translation), ref[f"{name}_t"][k])
