@@ -472,8 +472,24 @@ def compiler_cases():
         ref_b = ConstraintSet.from_chessboard(board, sigma_m=bsig)
         same_b = all(np.array_equal(v, _constraint_set_arrays(my_con.ConstraintSet.from_chessboard(board, sigma_m=bsig))[k], equal_nan=True)
                      for k, v in _constraint_set_arrays(ref_b).items())
+        # from_charuco (:359-395) reads charuco.board.getChessboardCorners() / .getSquareLength() and charuco.thickness_m: a stand-in with a float32
+        # corner grid (interior corners of a cols x rows board, some cases shuffled: the compiler recovers the grid from coordinates, not ids) goes
+        # through the REFERENCE's compiler — thin boards and two-sided ones with a substrate (back face = object 1, ties and braces)
+        ccols, crows, sq = int(rng.integers(3, 8)), int(rng.integers(3, 8)), float(rng.uniform(0.02, 0.06))
+        grid = np.array([[(i + 1) * sq, (j + 1) * sq, 0.0] for j in range(crows) for i in range(ccols)], dtype=np.float32)
+        if case % 3 == 0:
+            grid = grid[rng.permutation(len(grid))]
+        thick = [0.0, 0.005, 0.012][case % 3]
+        stand_in = types.SimpleNamespace(board=types.SimpleNamespace(getChessboardCorners=lambda g=grid: g, getSquareLength=lambda q=sq: q), thickness_m=thick)
+        ch_sig, ch_tsig = float(rng.uniform(0.001, 0.004)), float(rng.uniform(0.0003, 0.001))
+        ref_c = ConstraintSet.from_charuco(stand_in, sigma_m=ch_sig, thickness_sigma_m=ch_tsig)
+        same_c = all(np.array_equal(v, _constraint_set_arrays(my_con.ConstraintSet.from_charuco(stand_in, sigma_m=ch_sig, thickness_sigma_m=ch_tsig))[k], equal_nan=True)
+                     for k, v in _constraint_set_arrays(ref_c).items())
+        same_b = same_b and same_c
         out = {f"set_{k}": v for k, v in a.items()}
         out.update({f"board_{k}": v for k, v in _constraint_set_arrays(ref_b).items()})
+        out.update({f"charuco_{k}": v for k, v in _constraint_set_arrays(ref_c).items()})
+        out.update(charuco_corners=grid, charuco=np.array([sq, thick, ch_sig, ch_tsig]))
         out.update(
             marker_ids=np.array(ids), marker_static=np.array([m in static for m in ids]), marker_size=np.array([markers[m].size_m for m in ids]),
             marker_corners=np.array([markers[m].corners for m in ids], dtype=np.float64),

@@ -312,6 +312,13 @@ def test_constraint_compilers_equal_the_reference_s_own_output(path):
     board = SimpleNamespace(rows=int(rows), columns=int(cols), square_size_cm=float(size_cm), get_object_points=lambda: pts)
     for key, value in _set_arrays(ConstraintSet.from_chessboard(board, sigma_m=float(sigma))).items():
         assert np.array_equal(value, ref[f"board_{key}"], equal_nan=True), key
+    # from_charuco: thin boards and two-sided ones with a substrate (back face as object 1, ties at the thickness, braces) — the reference's compiler
+    # was given the same stand-in (it reads board.getChessboardCorners(), board.getSquareLength() and thickness_m, nothing else)
+    sq, thick, csig, tsig = (float(v) for v in ref["charuco"])
+    grid = ref["charuco_corners"].astype(np.float32)
+    ch = SimpleNamespace(board=SimpleNamespace(getChessboardCorners=lambda: grid, getSquareLength=lambda: sq), thickness_m=thick)
+    for key, value in _set_arrays(ConstraintSet.from_charuco(ch, sigma_m=csig, thickness_sigma_m=tsig)).items():
+        assert np.array_equal(value, ref[f"charuco_{key}"], equal_nan=True), key
 
 
 # ---- the outlier filters between the solver passes (core/capture_volume.py:607-753), on an injected report ---------------------------------------
