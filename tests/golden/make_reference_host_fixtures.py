@@ -780,6 +780,65 @@ def driver_cases():
     from tests.driver_script import scripted
 
     corners = np.array([[-0.5, 0.5, 0.0], [0.5, 0.5, 0.0], [0.5, -0.5, 0.0], [-0.5, -0.5, 0.0]])
+    for case in range(8, 11):
+        # two-sided charuco board with a substrate (object 0 = front face, 1 = back face): the extraction check (:328-370), the count of firing
+        # cross-face rows (:373-391) and the error when the two faces are never triangulated at the same instant.  8: all well; 9: the faces are never
+        # seen together; 10: the extraction carries another thickness than the configuration.
+        rng = np.random.default_rng(31000 + case)
+        sq, thick = 0.04, 0.006
+        grid = np.array([[(i + 1) * sq, (j + 1) * sq, 0.0] for j in range(3) for i in range(4)], dtype=np.float32)
+        stand_in = types.SimpleNamespace(board=types.SimpleNamespace(getChessboardCorners=lambda g=grid: g, getSquareLength=lambda q=sq: q), thickness_m=thick)
+        cs = ConstraintSet.from_charuco(stand_in)
+        frames = list(range(8))
+        world, img = [], []
+        for si in frames:
+            centre = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(1.0, 6.0)])
+            for o in (0, 1):
+                if case == 9 and (si % 2) != o:
+                    continue  # front face on even frames only, back face on odd ones: no common instant
+                for k in range(len(grid)):
+                    p = centre + grid[k].astype(np.float64) + [0.0, 0.0, thick * o]
+                    world.append((si, o, k, *p.tolist(), si / 30.0))
+                    for cam in (0, 1, 3):
+                        if rng.random() < 0.9:
+                            img.append((si, cam, o, k, float(200 + rng.normal(0, 40)), float(200 + rng.normal(0, 40)), float(grid[k][0]), float(grid[k][1]),
+                                        (0.004 if case == 10 else thick) * o))
+        wdf = pd.DataFrame(world, columns=WORLD_COLS).astype({"sync_index": "int64", "object_id": "int64", "keypoint_id": "int64"})
+        idf = pd.DataFrame(img, columns=IMG_COLS + ["obj_loc_x", "obj_loc_y", "obj_loc_z"]).astype({c: "int64" for c in IMG_COLS[:4]})
+        desc = []
+        for c in (0, 1, 3):
+            f = float(rng.uniform(300, 900))
+            desc.append(dict(cam_id=c, size=(1280, 720), ignore=False, has_intrinsics=True, K=[[f, 0.0, 320.0], [0.0, f, 240.0], [0.0, 0.0, 1.0]], dist=rng.normal(0, 0.05, 5).tolist(),
+                             t=[0.2 * c, 0.0, 0.0]))
+        cams = CameraArray({d["cam_id"]: CameraData(cam_id=d["cam_id"], size=tuple(d["size"]), matrix=np.array(d["K"]), distortions=np.array(d["dist"]), rotation=np.eye(3),
+                                                    translation=np.array(d["t"])) for d in desc})
+        trace, error, run = [], "", None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with scripted(CaptureVolume, WorldPoints, wdf, trace):
+                try:
+                    run = ref_drv.calibrate_extrinsics(ImagePoints(idf), cams, cs, refine_intrinsics=True, filter_percentile=2.5,
+                                                       progress=lambda pct, msg: trace.append(("progress", int(pct), str(msg))))
+                except CalibrationError as exc:
+                    error = str(exc)
+        dist = [(d.object_id_a, d.keypoint_id_a, d.object_id_b, d.keypoint_id_b, d.distance, d.sigma) for d in cs.distances]
+        out = dict(world=wdf.to_numpy(dtype=np.float64), image=idf.to_numpy(dtype=np.float64), static_ids=np.zeros(0, dtype=np.int64), has_constraints=np.array(True),
+                   distances=np.array(dist, dtype=np.float64).reshape(-1, 6), remaps=np.zeros((0, 7)), thickness=np.array(thick),
+                   cam_ids=np.array([d["cam_id"] for d in desc]), sizes=np.array([d["size"] for d in desc]), K=np.array([d["K"] for d in desc]), dist=np.array([d["dist"] for d in desc]),
+                   ignore=np.array([d["ignore"] for d in desc]), has_intrinsics=np.array([d["has_intrinsics"] for d in desc]), t=np.array([d["t"] for d in desc]),
+                   refine=np.array(True), filter_percentile=np.array(2.5), trace=np.array(repr(trace)), error_type=np.array("CalibrationError" if error else ""),
+                   error_mentions=np.zeros(0, dtype=np.int64), error_words=np.array([w for w in ("cross-face", "thickness") if w in error.lower()]), returned=np.array(run is not None),
+                   firing=np.array(ref_drv._count_firing_cross_face_rows(wdf, cs.distances)))
+        if run is not None:
+            out.update(synthesized=np.array(sorted(run.synthesized_cam_ids), dtype=np.int64), dropped=np.array(run.dropped_static_markers, dtype=np.int64),
+                       gated=np.array(run.intrinsic_refinement_gated),
+                       estimates=np.array([[e.cam_id, e.f_recovered, e.k1_recovered, e.k2_recovered, e.f_initial, e.k1_initial, e.k2_initial] for e in run.intrinsic_estimates],
+                                          dtype=np.float64).reshape(-1, 7),
+                       final_counts=np.array([len(run.capture_volume.image_points.df), len(run.capture_volume.world_points.df)], dtype=np.int64),
+                       final_image_keys=run.capture_volume.image_points.df[IMG_COLS[:4]].to_numpy(dtype=np.int64))
+        np.savez_compressed(OUT / f"driver_{case:02d}.npz", **out)
+        print(f"driver {case} (two-sided board, {int(out['firing'])} cross-face rows firing): " + (f"error ({error.splitlines()[0][:80]}...)" if run is None else "ran")
+              + f"; {len(trace)} trace entries")
     for case in range(8):
         rng = np.random.default_rng(31000 + case)
         shallow, deformed, blind, no_obj_loc, refine, remap = case == 1, case == 3, case in (4, 5), case == 5, case != 6, case == 7

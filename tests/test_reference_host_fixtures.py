@@ -592,7 +592,7 @@ DRIVERS = sorted((Path(__file__).parent / "golden" / "reference_host").glob("dri
 
 
 def test_the_driver_fixtures_are_there():
-    assert len(DRIVERS) == 8
+    assert len(DRIVERS) == 11
 
 
 @pytest.mark.parametrize("path", DRIVERS, ids=lambda p: p.stem)
@@ -618,7 +618,12 @@ def test_stage_driver_does_what_the_reference_s_does(path):
     if bool(ref["has_constraints"]):
         cs = ConstraintSet(tuple(DistanceConstraint(int(a), int(b), int(c), int(d), float(e), float(f)) for a, b, c, d, e, f in ref["distances"]),
                            frozenset(int(o) for o in ref["static_ids"]),
-                           point_remaps=tuple(PointRemap(int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]), float(r[5]), float(r[6])) for r in ref["remaps"]))
+                           point_remaps=tuple(PointRemap(int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]), float(r[5]), float(r[6])) for r in ref["remaps"]),
+                           back_face_thickness_m=float(ref["thickness"]) if "thickness" in ref.files else None)
+    if "firing" in ref.files:  # two-sided board: the count of cross-face rows that fire on the stored triangulation
+        from caliscope_amd.calibrate_extrinsics import _count_firing_cross_face_rows
+
+        assert _count_firing_cross_face_rows(wdf, cs.distances) == int(ref["firing"])
     trace, run, error = [], None, None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -633,6 +638,8 @@ def test_stage_driver_does_what_the_reference_s_does(path):
     assert (run is not None) == bool(ref["returned"]) and ("CalibrationError" if error is not None else "") == str(ref["error_type"])
     if run is None:
         assert all(str(int(c)) in str(error) for c in ref["error_mentions"])  # (the message names the cameras that fell back to blind intrinsics; its wording is this package's)
+        if "error_words" in ref.files:  # (two-sided board: which of the two guards spoke)
+            assert all(str(w) in str(error).lower() for w in ref["error_words"]) and len(ref["error_words"])
         return
     assert sorted(run.synthesized_cam_ids) == ref["synthesized"].tolist() and list(run.dropped_static_markers) == ref["dropped"].tolist()
     assert bool(run.intrinsic_refinement_gated) == bool(ref["gated"])
