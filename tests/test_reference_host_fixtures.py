@@ -475,11 +475,11 @@ def test_optimize_hands_over_and_takes_back_what_the_reference_does(path, monkey
     ftol, max_nfev, verbose, strict, use_constraints, pixel_sigma, refine, f_scale = ref["call"]
     seen = {}
 
+    from types import SimpleNamespace
+
     def recorder(fun, x0, args=(), jac=None, **kwargs):
         seen.update(x0=np.array(x0, dtype=np.float64), args=args, kwargs=kwargs)
         return SimpleNamespace(x=ref["x_result"].copy(), status=int(ref["result_status"]), nfev=17, cost=1.25, optimality=1e-9, success=int(ref["result_status"]) > 0)
-
-    from types import SimpleNamespace
 
     monkeypatch.setattr(cv_mod, "least_squares", recorder)
     kw = dict(ftol=float(ftol), max_nfev=None if max_nfev < 0 else int(max_nfev), verbose=int(verbose), strict=bool(strict), use_constraints=bool(use_constraints),
