@@ -331,3 +331,37 @@ def test_thin_footage_ends_in_the_same_local_minimum_as_scipy(kind):
                          constraints=(ga, gb, dist, (1.0 / f_median) / sigma))
     assert ref.status > 0 and abs(got.final_cost - ref.cost) <= 1e-6 * ref.cost, (got.final_cost, ref.cost)
     assert abs(got.iterations - ref.nfev) <= 2, (got.iterations, ref.nfev)
+
+
+def test_a_static_marker_that_moved_is_dropped_and_the_driver_starts_again():
+    """Marker 11 is declared static but was turned by 180 degrees half-way through the recording (its corner k is then seen where corner k + 2 was):
+    pooled over all frames its corners triangulate to a collapsed, non-rigid quadrilateral.  The driver must decide that on the first
+    triangulation, drop the marker, and — as the reference does (core/calibrate_extrinsics.py:146-203; trace pinned in
+    tests/golden/reference_host/driver_03.npz) — start again: fresh copies of the caller's cameras, the 20 % progress mark, a second
+    bootstrap without the marker's observations and constraints; then the three solver passes.  The REAL bootstrap and passes run here (oracle
+    triangulation and numpy engine in the device's place)."""
+    from caliscope_amd.calibrate_extrinsics import calibrate_extrinsics
+    from caliscope_amd.point_data import ImagePoints
+    from tests.constrained_scene import marker_volume
+
+    vol, _ = marker_volume(n_frames=6)
+    df = vol.image_points.df
+    turned = (df["object_id"] == 11) & (df["sync_index"] >= 3)
+    df.loc[turned, "keypoint_id"] = (df.loc[turned, "keypoint_id"] + 2) % 4
+    calls, marks = [], []
+
+    def counting_triangulate(image_points, cameras, static_ids):
+        calls.append((sorted(int(o) for o in image_points.df["object_id"].unique()), sorted(static_ids)))
+        return _oracle_triangulate(image_points, cameras, static_ids)
+
+    kw = _engine_kwargs("numpy")
+    kw["_triangulate"] = counting_triangulate
+    run = calibrate_extrinsics(ImagePoints(df), vol.camera_array, vol.constraints, refine_intrinsics=False, progress=lambda p, m: marks.append((p, m)), **kw)
+    assert run.dropped_static_markers == (11,)
+    assert [p for p, _ in marks] == [5, 15, 20, 40, 55, 75, 90, 100] and marks[2][1] == "Re-bootstrapping after dropping markers"
+    assert calls == [([0, 10, 11, 12], [10, 11, 12]), ([0, 10, 12], [10, 12])]  # triangulated twice: with the marker, then without it
+    out = run.capture_volume
+    assert 11 not in set(out.image_points.df["object_id"]) and 11 not in set(out.world_points.df["object_id"])
+    assert out.constraints.static_object_ids == frozenset({10, 12}) and out.constraints.centroid_distances == ()
+    assert all(11 not in (d.object_id_a, d.object_id_b) for d in out.constraints.distances)
+    assert out.optimization_status.converged and out.rigidity_report().rmse_mm < 5.0
