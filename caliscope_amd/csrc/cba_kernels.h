@@ -40,6 +40,34 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = WAVE / 2; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
   return v;
 }
+// Device-side stamps of the kernels of one fused iteration (profiling build only: -DCBA_PROFILING, CBA_STAMPS=1).  A kernel trace under rocprofv3
+// perturbs exactly what is asked about — the time BETWEEN dependent launches — so every workgroup of an instrumented kernel leaves the 100 MHz
+// wall clock at its entry and every wave at its exit; the host takes min / max per kernel when the handle goes (cba_lib.hip: dump_stamps).
+#ifdef CBA_PROFILING
+constexpr int STAMP_SLOTS = 96, STAMP_BLOCKS = 1024, STAMP_WAVES = 16, STAMP_ROW = 1 + STAMP_WAVES;
+__device__ long long* g_cba_stamps = nullptr;  // [STAMP_SLOTS][STAMP_BLOCKS][STAMP_ROW]
+struct StampScope {
+  long long* row;
+  __device__ __forceinline__ explicit StampScope(int slot) : row(nullptr) {
+    long long* base = g_cba_stamps;
+    const int b = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (base && slot < STAMP_SLOTS && b < STAMP_BLOCKS) {
+      row = base + ((long)slot * STAMP_BLOCKS + b) * STAMP_ROW;
+      if (threadIdx.x == 0 && threadIdx.y == 0) row[0] = wall_clock64();
+    }
+  }
+  __device__ __forceinline__ ~StampScope() {
+    const int t = (int)(threadIdx.y * blockDim.x + threadIdx.x);
+    if (row && (t & (WAVE - 1)) == 0 && t / WAVE < STAMP_WAVES) row[1 + t / WAVE] = wall_clock64();
+  }
+};
+#define CBA_STAMP(slot) StampScope cba_stamp_scope_(slot)
+#else
+#define CBA_STAMP(slot) ((void)0)
+#endif
+enum StampId { ST_TPREP = 0, ST_PAIRS, ST_REG_REDUCE, ST_FINALIZE, ST_CHOL_APPLY, ST_BACKSUB, ST_STEP_CAM, ST_BUILD, ST_REDUCE_PUB, ST_SCALE_LIN, ST_JV,
+               ST_SMALL_SOLVE, ST_CHOL_STEP /* + k + 1 */ };
+
 // Sum over the workgroup; result valid in thread 0.  `sh` holds BLOCK/WAVE doubles.
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   v = wave_sum(v);
@@ -198,6 +226,7 @@ struct PubArgs {
 __global__ void __launch_bounds__(64 * REDUCE_RY)
 k_reduce_rows_pub(const double* __restrict__ partial, int nrow, int width, double* __restrict__ out, double* __restrict__ grad_out,
                   const int* __restrict__ cam_off, const int* __restrict__ cam_np, int stride, int tri, PubArgs pub) {
+  CBA_STAMP(ST_REDUCE_PUB);
   if (blockIdx.x + 1 < gridDim.x) { reduce_rows_block(partial, nrow, width, out, grad_out, cam_off, cam_np, stride, tri); return; }
   __shared__ double sh_w[2][REDUCE_RY];
   const int t = threadIdx.y * 64 + threadIdx.x;
@@ -550,6 +579,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, int n_cams, int loss, double f_scale,
            double* __restrict__ Vblk, double* __restrict__ gvec, double* __restrict__ partialU, double* __restrict__ partial_cost,
            int* __restrict__ flags, const double* __restrict__ skip, TrialSrc trial = TrialSrc{}) {
+  CBA_STAMP(ST_BUILD);
   using UP = UPack<NC>;
   static_assert(!UGLOB || CAMG, "a camera count beyond the LDS copy of the blocks is beyond the LDS copy of the table as well");
   if (skip && *skip != 0.0) return;  // fused step without a trial (k_fused_subspace handed the iteration to the host)
@@ -775,6 +805,7 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
      const int* __restrict__ obs_pt, long n_obs, const double* __restrict__ xvec, VecLayout lay,
      const double* __restrict__ tab, const int* __restrict__ cam_off, int n_cams, int loss, double f_scale,
      const double* __restrict__ v1, const double* __restrict__ v2, double* __restrict__ partial) {
+  CBA_STAMP(ST_JV);
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* sh_tab = sh;
   double* sh_v = sh_tab + (CAMG ? 0 : n_cams * CAMTAB_LDS);  // NV * ncp_pad
@@ -968,6 +999,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
         int n_cams, int loss, double f_scale, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
         const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ Trec,
         double* __restrict__ partial_b, int* __restrict__ flags, DetPlan det = DetPlan{nullptr, nullptr}, LinFin lf = LinFin{}) {
+  CBA_STAMP(ST_TPREP);
   constexpr int REC = SchurRec<NC>::HREC, NP = REC / 2, SP = SchurRec<NC>::STAGE, SW = SchurRec<NC>::STAGE_WAVES;  // the records as they lie in HBM
   static_assert((BLOCK / WAVE) % SW == 0, "stage turns");
   constexpr bool DET = DETM > 0;
@@ -1461,6 +1493,7 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
 template <int NC, int SPLIT, int MINW>
 __global__ void __launch_bounds__((Reg3Cfg<NC>::LAUNCH_THREADS), MINW)
 k_schur_reg3(TilePlan tp, const double* __restrict__ Trec, double* __restrict__ partial, const double* __restrict__ tab) {
+  CBA_STAMP(ST_PAIRS);
   extern __shared__ __attribute__((aligned(16))) double sh[];
   schur_reg3_body<NC, SPLIT, false>(tp, tp.nit, tp.code_start, tp.chunk_start, tp.codes, tp.obs, Trec, partial, sh, nullptr, tab);
 }
@@ -1492,6 +1525,7 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
              const int* __restrict__ cam_off, const int* __restrict__ cam_np, int NCt, int ncp,
              double* __restrict__ Sacc, double* __restrict__ red, int n_tiles, const double* __restrict__ partial_b = nullptr, int b_rows = 0,
              int b_width = 0, double* __restrict__ b_out = nullptr) {
+  CBA_STAMP(ST_REG_REDUCE);
   const int Y = (int)blockDim.y;  // 4 or 16
   __shared__ double sh[REG_REDUCE_Y_MAX][64];
   if ((int)blockIdx.y >= n_tiles) {
@@ -1609,6 +1643,7 @@ __global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* 
                                  const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
                                  double* __restrict__ W, int ldw, const double* __restrict__ red = nullptr, int g = 0, long tile_elems = 0,
                                  const int* __restrict__ group_cam_begin = nullptr, int b_width = 0) {
+  CBA_STAMP(ST_FINALIZE);
   using UP = UPack<NC>;
   if (lam_dev) lam = *lam_dev;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1795,6 +1830,7 @@ __device__ __forceinline__ void chol_rank_nb(const double* __restrict__ A, int r
 __global__ void __launch_bounds__(CHOL_THREADS)
 k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ flags, long long* __restrict__ trace, double* __restrict__ Xinv,
             double* __restrict__ Tinv = nullptr) {
+  CBA_STAMP(ST_CHOL_STEP + k + 1);
   __shared__ double sh_red[4][16][17];
   __shared__ double sh_U[NB][NB + 1], sh_X[NB][NB + 1], sh_D[2 * NB][NB + 1];
   __shared__ __attribute__((aligned(16))) double sh_L[NB][NB + 2];  // even row stride: pairs of coefficients are 16-byte aligned
@@ -2003,6 +2039,7 @@ k_small_solve(const double* __restrict__ Sacc, const double* __restrict__ bacc, 
               const double* __restrict__ lam_dev, const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
               const double* __restrict__ red, int g, long tile_elems, const int* __restrict__ group_cam_begin, int* __restrict__ flags,
               double* __restrict__ out, int b_width) {
+  CBA_STAMP(ST_SMALL_SOLVE);
   using UP = UPack<NC>;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double (*W)[SMALL_LD] = reinterpret_cast<double (*)[SMALL_LD]>(sh);                       // [n + 1][SMALL_LD]: S, then rhs^T
@@ -2143,6 +2180,7 @@ k_small_solve(const double* __restrict__ Sacc, const double* __restrict__ bacc, 
 constexpr int APPLY_THREADS = 512;
 __global__ void __launch_bounds__(APPLY_THREADS)
 k_chol_apply(const double* __restrict__ Tinv, const double* __restrict__ W, int n, int ldw, double* __restrict__ out) {
+  CBA_STAMP(ST_CHOL_APPLY);
   extern __shared__ __attribute__((aligned(16))) double y[];  // n
   const int tid = threadIdx.x;
   for (int i = tid; i < n; i += APPLY_THREADS) y[i] = W[(long)n * ldw + i];
@@ -2174,6 +2212,7 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
           const double* __restrict__ tab, const int* __restrict__ cam_off, int n_cams, int loss, double f_scale, double lam,
           const double* __restrict__ lam_dev, const double* __restrict__ Vblk, const double* __restrict__ gvec,
           const double* __restrict__ sinv, double* __restrict__ svec, double* __restrict__ step_partial = nullptr) {
+  CBA_STAMP(ST_BACKSUB);
   extern __shared__ __attribute__((aligned(16))) double sh[];
   if (lam_dev) lam = *lam_dev;
   double* sh_tab = sh;
@@ -2286,6 +2325,217 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     r = block_sum(sc0, sh_pt); if (threadIdx.x == 0) step_partial[blockIdx.x * 4 + 0] = r;
     r = block_sum(sc1, sh_pt); if (threadIdx.x == 0) { step_partial[blockIdx.x * 4 + 1] = r; step_partial[blockIdx.x * 4 + 2] = 0.0; step_partial[blockIdx.x * 4 + 3] = 0.0; }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Back-substitution from the T records (round 6).  k_tprep has just written T_i = A_i^T B_i L^-T per observation, in the very order this pass
+// walks, so nothing is linearised again (reference arithmetic replaced: core/reprojection.py:186-187, the point block by the chain rule):
+//     dp = -L^-T ( L^-1 g_p + sum_i T_i^T dc_{c_i} ),      T_i^T dc = Q_i^T (w_c x Y_i + dt_c) + T_intr,i^T di_c,     w_c = J_l,c dc_r
+// (Y = R X, Q = rows 3..5 of T, T_intr = rows 6..8: the compact record of SchurRec; dc = (dc_r, dt, di) the camera's step).  Per observation
+// 18 (27) FP64 instructions on a 96 (176) byte record instead of obs_linearize's ~250, no camera table, no point gather.
+//   * per camera (w, dt, di) once per workgroup into LDS (6 / 9 doubles per camera);
+//   * the 64 records of a wave are one contiguous run of Trec: the wave fetches them HBM -> LDS by LDS-DMA, 1 KB per instruction, into its own
+//     quarter of ONE buffer — a lane copies its record to registers, the wave issues the next chunk's DMA into the same place and computes
+//     while that is in flight (no workgroup barrier guards the records: a wave only ever reads what it loaded itself);
+//   * the point phase runs ONE CHUNK BEHIND: the per-observation terms go to one of two LDS buffers, the points of the previous chunk are solved
+//     from the other — by threads spread over all four waves — in the same barrier interval, so one barrier per chunk and no wave waits for
+//     a serial point phase (k_backsub: one wave solved the points of a chunk while three were parked: SQ_WAIT_ANY 68 %).
+// The body is a function with Trec as a __restrict__ PARAMETER for the reason given at schur_reg3_body (LDS reads may pass the pending DMA).
+constexpr int BSR_PT = 3 * CHUNK;  // doubles of one buffer of per-observation terms
+template <int NC> struct BsrCfg {
+  static constexpr int NP = SchurRec<NC>::NPH;       // 16-byte pieces of a record in HBM (6 / 11)
+  static constexpr int CS = (NC == 9) ? 9 : 6;       // doubles of a camera's step entry
+  static constexpr int CSS = CS;                     // its stride in LDS (an odd stride would spread the banks; 40 000 bytes per workgroup let four share a CU)
+  static constexpr size_t lds_bytes(int n_cams) { return ((size_t)BLOCK * NP * 2 + 2 * BSR_PT + (size_t)n_cams * CSS + 8) * sizeof(double); }
+};
+template <int NC, bool SCAL>
+__device__ __forceinline__ void backsub_rec_body(const double* __restrict__ Trec, const int* __restrict__ obs_cam, const int* __restrict__ pt_start,
+                                                 const int* __restrict__ chunk_start, const int* __restrict__ chunk_pts, int n_chunks, VecLayout lay,
+                                                 const double* __restrict__ tab, const int* __restrict__ cam_off, const int* __restrict__ cam_np,
+                                                 int n_cams, double lam, const double* __restrict__ Vblk, const double* __restrict__ gp,
+                                                 const double* __restrict__ dp, const double* __restrict__ s_cam, double* __restrict__ sp,
+                                                 double* __restrict__ step_partial, double* sh) {
+  using Cfg = BsrCfg<NC>;
+  constexpr int NP = Cfg::NP, CSS = Cfg::CSS;
+  double2* sh_rec = reinterpret_cast<double2*>(sh);          // [BLOCK][NP] pieces, wave w owns [w * 64 * NP, (w + 1) * 64 * NP)
+  double* sh_pt = sh + (size_t)BLOCK * NP * 2;               // [2][3][CHUNK]
+  double* sh_step = sh_pt + 2 * BSR_PT;                      // [n_cams][CSS]
+  const int tid = (int)threadIdx.x, lane = tid % WAVE;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  for (int idx = tid; idx < n_cams * 3; idx += BLOCK) {
+    const int c = idx / 3, a = idx % 3, off = cam_off[c];
+    const double* Jl = tab + (long)c * CAMTAB_DOUBLES + 12;
+    sh_step[c * CSS + a] = fma(Jl[3 * a + 2], s_cam[off + 2], fma(Jl[3 * a + 1], s_cam[off + 1], Jl[3 * a] * s_cam[off]));
+    sh_step[c * CSS + 3 + a] = s_cam[off + 3 + a];
+    if (NC == 9) sh_step[c * CSS + 6 + a] = (cam_np[c] == 9) ? s_cam[off + 6 + a] : 0.0;
+  }
+  const int n_obs = chunk_start[n_chunks];
+  const int last_obs = max(n_obs - 1, 0);
+  const long last_piece = (long)max(n_obs, 1) * NP - 1;
+  const double2* rec_g = reinterpret_cast<const double2*>(Trec);
+  double2* wrec = sh_rec + wv * (WAVE * NP);
+  auto issue = [&](int o0) {  // this wave's 64 records of the chunk that starts at observation o0
+    const long base = ((long)o0 + wv * WAVE) * NP + lane;
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rec_g + min(base + k * WAVE, last_piece)),
+                                       (void __attribute__((address_space(3)))*)(wrec + k * WAVE), 16, 0, 0);
+  };
+  // inputs of the point phase of one chunk: thread t takes local point (t % 64) * 4 + t / 64 — consecutive points alternate between the waves
+  // (a, b are kept as loaded — offsets into the sorted observations — and turned into chunk-local positions where they are used, an iteration
+  // later: arithmetic on a loaded value in the iteration that loads it is a wait behind the DMA just issued)
+  struct PtIn { int p, a, b, on; double V[6], d[3], g[3]; };
+  const int lp0 = lane * 4 + wv;
+  auto load_point = [&](int cp0, int npts) {
+    PtIn q;
+    q.on = lp0 < npts;
+    q.p = min(cp0 + min(lp0, max(npts - 1, 0)), lay.P - 1);  // (clamped: the loads are unconditional)
+    q.a = pt_start[q.p]; q.b = pt_start[q.p + 1];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q.V[k] = Vblk[(long)k * lay.Ppad + q.p];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { q.d[k] = dp[(long)k * lay.Ppad + q.p]; q.g[k] = gp[(long)k * lay.Ppad + q.p]; }
+    return q;
+  };
+  double sc0 = 0.0, sc1 = 0.0;
+  auto solve_point = [&](int p, const double* Vin, const double* din, const double* gin, const double* q) {
+    double Vd[6], L[6], y[3], x[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Vd[k] = Vin[k];
+    Vd[0] = fma(lam * din[0], din[0], Vd[0]); Vd[3] = fma(lam * din[1], din[1], Vd[3]); Vd[5] = fma(lam * din[2], din[2], Vd[5]);
+    if (chol3(Vd, L)) {
+      chol3_fwd(L, gin, y);
+      y[0] += q[0]; y[1] += q[1]; y[2] += q[2];
+      chol3_bwd(L, y, x);
+    } else {
+      x[0] = x[1] = x[2] = 0.0;  // flagged by the Schur pass already
+    }
+    sp[p] = -x[0];
+    sp[lay.Ppad + p] = -x[1];
+    sp[2 * lay.Ppad + p] = -x[2];
+    if (SCAL) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double ps = x[k] * din[k]; sc0 = fma(ps, ps, sc0); sc1 = fma(-gin[k], x[k], sc1); }
+    }
+  };
+  auto point_phase = [&](const PtIn& q, const double* pt, int cp0, int npts, int o0) {
+    if (q.on && q.b > q.a) {
+      double acc[3] = {0.0, 0.0, 0.0};
+      for (int j = q.a - o0; j < q.b - o0; ++j) { acc[0] += pt[j]; acc[1] += pt[CHUNK + j]; acc[2] += pt[2 * CHUNK + j]; }
+      solve_point(q.p, q.V, q.d, q.g, acc);
+    }
+    for (int lp = tid + BLOCK; lp < npts; lp += BLOCK) {  // a chunk's range with more than 256 points (most of them unobserved): rare
+      const int p = cp0 + lp, a = pt_start[p] - o0, b = pt_start[p + 1] - o0;
+      if (b > a) {
+        double acc[3] = {0.0, 0.0, 0.0}, V2[6], d2[3], g2[3];
+        for (int j = a; j < b; ++j) { acc[0] += pt[j]; acc[1] += pt[CHUNK + j]; acc[2] += pt[2 * CHUNK + j]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V2[k] = Vblk[(long)k * lay.Ppad + p];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d2[k] = dp[(long)k * lay.Ppad + p]; g2[k] = gp[(long)k * lay.Ppad + p]; }
+        solve_point(p, V2, d2, g2, acc);
+      }
+    }
+  };
+
+  int ch = blockIdx.x;
+  if (ch >= n_chunks) {
+    if (SCAL && tid == 0) { step_partial[blockIdx.x * 4 + 0] = 0.0; step_partial[blockIdx.x * 4 + 1] = 0.0; step_partial[blockIdx.x * 4 + 2] = 0.0; step_partial[blockIdx.x * 4 + 3] = 0.0; }
+    return;
+  }
+  // table entries of a chunk: (first observation, end, first point, points).  Nothing loaded in an iteration feeds an address of the same
+  // iteration (the wait for it would be a vmcnt(0) behind the DMA just issued): the entries of chunk ch + 2 grid are loaded while chunk ch is
+  // processed, the camera index of an observation and the inputs of a chunk's points one iteration ahead.
+  struct Ent { int o0, o1, cp0, npts; };
+  auto load_ent = [&](int c) { Ent e; e.o0 = chunk_start[c]; e.o1 = chunk_start[c + 1]; e.cp0 = chunk_pts[2 * c]; e.npts = chunk_pts[2 * c + 1]; return e; };
+  const int stride = (int)gridDim.x, last_chunk = n_chunks - 1;
+  Ent cur = load_ent(ch), nx = load_ent(min(ch + stride, last_chunk));
+  int cam = obs_cam[min(cur.o0 + tid, last_obs)];
+  issue(cur.o0);
+  PtIn pprev;  // the chunk whose points are still to be solved: none yet
+  pprev.p = 0; pprev.a = 0; pprev.b = 0; pprev.on = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pprev.V[k] = 1.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pprev.d[k] = 0.0; pprev.g[k] = 0.0; }
+  Ent eprev{0, 0, 0, 0};
+  int buf = 0;
+  __syncthreads();  // sh_step
+  while (true) {
+    // everything issued an iteration ago has landed: this wave's records of `ch`, the table entries, the camera index, the inputs of the previous chunk's points
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (values whose loads sit behind the loop's back edge pass through an empty asm: the compiler cannot see the wait above and would put a
+    // vmcnt(0) of its own at their first use — behind the DMA this iteration issues)
+    asm volatile("" : "+v"(cam));
+    asm volatile("" : "+v"(nx.o0)); asm volatile("" : "+v"(nx.o1)); asm volatile("" : "+v"(nx.cp0)); asm volatile("" : "+v"(nx.npts));
+    asm volatile("" : "+v"(pprev.a)); asm volatile("" : "+v"(pprev.b));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(pprev.V[k]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { asm volatile("" : "+v"(pprev.d[k])); asm volatile("" : "+v"(pprev.g[k])); }
+    double2 rec[NP];
+    const double2* mine = wrec + lane * NP;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) rec[k] = mine[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the record is in registers before the next DMA may overwrite it
+#pragma unroll
+    for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(rec[k].x), "+v"(rec[k].y));
+    const bool more = ch + stride < n_chunks;
+    if (more) issue(nx.o0);
+    const int ncam = obs_cam[min(nx.o0 + tid, last_obs)];
+    const Ent nn = load_ent(min(ch + 2 * stride, last_chunk));
+    const PtIn pcur = load_point(cur.cp0, cur.npts);
+    __builtin_amdgcn_sched_barrier(0);
+    // this observation's term T_i^T dc
+    double t0, t1, t2;
+    {
+      const double* cs = sh_step + cam * CSS;
+      const double w0 = cs[0], w1 = cs[1], w2 = cs[2];
+      const double Y0 = rec[0].x, Y1 = rec[0].y, Y2 = rec[1].x;
+      const double m0 = fma(w1, Y2, fma(-w2, Y1, cs[3]));
+      const double m1 = fma(w2, Y0, fma(-w0, Y2, cs[4]));
+      const double m2 = fma(w0, Y1, fma(-w1, Y0, cs[5]));
+      // Q row-major behind Y: entries 3..11 of the record
+      t0 = fma(rec[4].y, m2, fma(rec[3].x, m1, rec[1].y * m0));
+      t1 = fma(rec[5].x, m2, fma(rec[3].y, m1, rec[2].x * m0));
+      t2 = fma(rec[5].y, m2, fma(rec[4].x, m1, rec[2].y * m0));
+      if constexpr (NC == 9) {  // T_intr row-major: entries 12..20
+        const double i0 = cs[6], i1 = cs[7], i2 = cs[8];
+        t0 = fma(rec[9].x, i2, fma(rec[7].y, i1, fma(rec[6].x, i0, t0)));
+        t1 = fma(rec[9].y, i2, fma(rec[8].x, i1, fma(rec[6].y, i0, t1)));
+        t2 = fma(rec[10].x, i2, fma(rec[8].y, i1, fma(rec[7].x, i0, t2)));
+      }
+      if (cur.o0 + tid >= cur.o1) { t0 = 0.0; t1 = 0.0; t2 = 0.0; }  // (a lane without an observation read somebody's record: select, do not multiply)
+    }
+    double* pt = sh_pt + buf * BSR_PT;
+    pt[tid] = t0; pt[CHUNK + tid] = t1; pt[2 * CHUNK + tid] = t2;
+    point_phase(pprev, sh_pt + (buf ^ 1) * BSR_PT, eprev.cp0, eprev.npts, eprev.o0);
+    __syncthreads();
+    pprev = pcur; eprev = cur;
+    buf ^= 1;
+    if (!more) break;
+    cam = ncam; cur = nx; nx = nn; ch += stride;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  point_phase(pprev, sh_pt + (buf ^ 1) * BSR_PT, eprev.cp0, eprev.npts, eprev.o0);
+  if (SCAL) {
+    __syncthreads();  // (sh_pt is free behind it)
+    double r;
+    r = block_sum(sc0, sh_pt); if (tid == 0) step_partial[blockIdx.x * 4 + 0] = r;
+    r = block_sum(sc1, sh_pt); if (tid == 0) { step_partial[blockIdx.x * 4 + 1] = r; step_partial[blockIdx.x * 4 + 2] = 0.0; step_partial[blockIdx.x * 4 + 3] = 0.0; }
+  }
+}
+template <int NC, bool SCAL = false>
+__global__ void __launch_bounds__(BLOCK)
+k_backsub_rec(const double* __restrict__ Trec, const int* __restrict__ obs_cam, const int* __restrict__ pt_start, const int* __restrict__ chunk_start,
+              const int* __restrict__ chunk_pts, int n_chunks, VecLayout lay, const double* __restrict__ tab, const int* __restrict__ cam_off,
+              const int* __restrict__ cam_np, int n_cams, double lam, const double* __restrict__ lam_dev, const double* __restrict__ Vblk,
+              const double* __restrict__ gvec, const double* __restrict__ sinv, double* __restrict__ svec, double* __restrict__ step_partial) {
+  CBA_STAMP(ST_BACKSUB);
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  if (lam_dev) lam = *lam_dev;
+  backsub_rec_body<NC, SCAL>(Trec, obs_cam, pt_start, chunk_start, chunk_pts, n_chunks, lay, tab, cam_off, cam_np, n_cams, lam, Vblk,
+                             gvec + lay.ncp_pad, sinv + lay.ncp_pad, svec, svec + lay.ncp_pad, step_partial, sh);
 }
 
 // scalars of the Newton step: partial[b][0] = sum (s sinv)^2, [1] = sum g s
@@ -2434,6 +2684,7 @@ k_scale_lin(const double* __restrict__ Upacked, const double* __restrict__ Vblk,
             const int* __restrict__ param_loc, VecLayout lay, int first, double* __restrict__ sinv, const double* __restrict__ cdiag,
             const double* __restrict__ x, const double* __restrict__ g, double* __restrict__ v1, double* __restrict__ partial,
             double* __restrict__ partial_max, const double* __restrict__ sinv_in = nullptr, BoundArgs bnd = BoundArgs{}) {
+  CBA_STAMP(ST_SCALE_LIN);
   // sinv_in != nullptr: the scale is read there and written to `sinv` (the speculative linearisation of a trial point leaves the current one alone)
   using UP = UPack<NC>;
   __shared__ double sh_red[BLOCK / WAVE];
@@ -2613,6 +2864,7 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
            double* __restrict__ x_new, double* __restrict__ step_cam, double* __restrict__ tab_out, const double* __restrict__ cam_const,
            const int* __restrict__ cam_model, const int* __restrict__ cam_np, const int* __restrict__ cam_off, int n_cams,
            const double* __restrict__ lb = nullptr, const double* __restrict__ ub = nullptr, int ncp = 0) {
+  CBA_STAMP(ST_STEP_CAM);
   extern __shared__ __attribute__((aligned(16))) double sh_xc[];  // [ncp_pad]
   __shared__ double sh_red[4][BLOCK / WAVE];
   __shared__ double sh_ab[3];

@@ -121,6 +121,8 @@ struct cba_problem {
   double cost_x = 0.0;       // cost at the current x
   double trial_cost = 0.0;   // cost at the pending trial point
   int grid_backsub = 1;  // k_backsub keeps 34 KB of LDS (cfg4): more resident workgroups than the 57-65 KB kernels sharing p->grid
+  bool has_fragments = false;  // some chunk is a fragment of a point with more than CHUNK observations (k_backsub adds its sums by atomics)
+  bool backsub_rec = false;    // the back-substitution streams the T records (k_backsub_rec) instead of linearising every observation again
   int n_heavy = 0; int* heavy_pts = nullptr; int* heavy_frag = nullptr; double* heavy_W = nullptr;  // heavy points (k_heavy_schur)
   std::vector<int> h_heavy_pts;
   ConPlan con{};           // rigid-distance constraint rows (cba_set_constraints); con.n_con == 0: none
@@ -157,6 +159,7 @@ struct cba_problem {
   bool plan_is_cheap = false;
   int plan_error = 0;  // CBA_ERR_* of a failed background plan build (the handle keeps the quick plan)
   bool schur_clock = false;  // profiling build only (-DCBA_PROFILING, CBA_SCHUR_CLOCK=1): phase clocks of k_schur_reg3
+  long long* stamps = nullptr;  // profiling build only (CBA_STAMPS=1): device-side entry / exit stamps of the kernels of the last fused iteration
   bool begun = false, linearized = false, stepped = false, have_trial = false;
   double gh_sq = 0.0;
   std::vector<int> h_cam_off, h_cam_np;
@@ -550,11 +553,68 @@ int64_t cba_host_plan(int32_t n_points, int64_t n_obs, const int32_t* obs_pt, co
 
 static void drop_plan_task(cba_problem* p);  // (PlanTask is defined with the plans further down)
 
+#ifdef CBA_PROFILING
+// CBA_STAMPS=1 (profiling build): the kernels of the LAST fused iteration in the order they started, with the device's own clock — duration from the
+// first workgroup's entry to the last wave's exit, and the idle time in front of each (previous kernel's last exit -> this kernel's first entry).
+static void dump_stamps(cba_problem* p) {
+  static const char* names[] = {"k_tprep", "k_schur_reg3", "k_reg_reduce", "k_schur_finalize", "k_chol_apply", "k_backsub", "k_step_cam", "k_build_cs",
+                                "k_reduce_rows_pub", "k_scale_lin", "k_jv", "k_small_solve"};
+  const size_t n = (size_t)STAMP_SLOTS * STAMP_BLOCKS * STAMP_ROW;
+  std::vector<long long> h(n);
+  long long* null_ptr = nullptr;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cba_stamps), &null_ptr, sizeof(null_ptr));
+  if (hipMemcpy(h.data(), p->stamps, n * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+  struct Row { int slot; long long t0, t1, first_exit, last_entry; int blocks; double life_sum; long long life_min, life_max; };
+  std::vector<Row> rows;
+  for (int s = 0; s < STAMP_SLOTS; ++s) {
+    Row r{s, 0, 0, 0, 0, 0, 0.0, 0, 0};
+    for (int b = 0; b < STAMP_BLOCKS; ++b) {
+      const long long* q = &h[((size_t)s * STAMP_BLOCKS + b) * STAMP_ROW];
+      if (!q[0]) continue;
+      r.blocks++;
+      r.t0 = r.t0 ? std::min(r.t0, q[0]) : q[0];
+      long long e = 0;
+      for (int w = 0; w < STAMP_WAVES; ++w) e = std::max(e, q[1 + w]);
+      r.t1 = std::max(r.t1, e);
+      r.first_exit = r.first_exit ? std::min(r.first_exit, e) : e;
+      r.last_entry = std::max(r.last_entry, q[0]);
+      const long long life = e - q[0];
+      r.life_sum += (double)life; r.life_min = r.life_min ? std::min(r.life_min, life) : life; r.life_max = std::max(r.life_max, life);
+    }
+    if (r.blocks) rows.push_back(r);
+  }
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.t0 < b.t0; });
+  // the last iteration: from the last k_tprep on
+  size_t first = 0;
+  for (size_t i = 0; i < rows.size(); ++i) if (rows[i].slot == ST_TPREP) first = i;
+  fprintf(stderr, "device stamps of the last fused iteration (100 MHz wall clock; blocks = workgroups seen, at most %d):\n", STAMP_BLOCKS);
+  fprintf(stderr, "| # | kernel | workgroups | first entry -> last exit, us | last entry after the first, us | workgroup lifetime min / mean / max, us | idle before, us |\n|---|---|---|---|---|---|---|\n");
+  double busy = 0.0, idle = 0.0;
+  for (size_t i = first; i < rows.size(); ++i) {
+    const Row& r = rows[i];
+    char nm[48];
+    if (r.slot >= ST_CHOL_STEP) snprintf(nm, sizeof nm, "k_chol_step k=%d", r.slot - ST_CHOL_STEP - 1); else snprintf(nm, sizeof nm, "%s", names[r.slot]);
+    const double gap = i > first ? (r.t0 - rows[i - 1].t1) * 0.01 : 0.0;
+    busy += (r.t1 - r.t0) * 0.01; if (i > first) idle += gap;
+    fprintf(stderr, "| %zu | %s | %d | %.2f | %.2f | %.2f / %.2f / %.2f | %.2f |\n", i - first + 1, nm, r.blocks, (r.t1 - r.t0) * 0.01, (r.last_entry - r.t0) * 0.01,
+            r.life_min * 0.01, r.life_sum / r.blocks * 0.01, r.life_max * 0.01, gap);
+  }
+  if (first < rows.size())
+    fprintf(stderr, "%zu kernels, %.1f us inside kernels, %.1f us between them, %.1f us from the first entry to the last exit\n", rows.size() - first, busy, idle,
+            (rows.back().t1 - rows[first].t0) * 0.01);
+  (void)hipFree(p->stamps);
+  p->stamps = nullptr;
+}
+#endif
+
 void cba_destroy(cba_problem* p) {
   if (!p) return;
   drop_plan_task(p);  // a plan thread still dealing: cancelled and joined before anything it could look at goes away
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+#ifdef CBA_PROFILING
+  if (p->stamps) dump_stamps(p);
+#endif
   drain_timers(p);
   for (auto& ev : p->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (p->h_vec_sent) (void)hipEventDestroy(p->h_vec_sent);
@@ -643,6 +703,7 @@ template <int NC> static size_t lds_tprep(const cba_problem* p) {
 constexpr int kSchurRegMaxGroup = 16;  // g*g blocks <= 256 threads
 constexpr size_t kSmallSolveLds = ((size_t)(SMALL_N + 1) * SMALL_LD + (size_t)2 * NB * (NB + 1) + (size_t)((SMALL_N + NB - 1) / NB) * NB * (NB + 1) + 2 * SMALL_N) * 8;  // k_small_solve
 static size_t lds_backsub(const cba_problem* p) { return (lds_tab(p) + p->lay.ncp_pad + 3 * CHUNK) * 8; }
+template <int NC> static size_t lds_backsub_rec(const cba_problem* p) { return BsrCfg<NC>::lds_bytes(p->C); }
 
 
 // Plan of the pair kernel (schur_plan.h builds it on the host).  The dealing is ~1 us of host work per observation and needs nothing but the
@@ -911,6 +972,18 @@ static int configure_kernels(cba_problem* p) {
   if ((rc = allow_lds(k_backsub<NC, true>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC, false, true>, lds_backsub(p)))) return rc;
   if ((rc = allow_lds(k_backsub<NC, true, true>, lds_backsub(p)))) return rc;
+  // back-substitution from the T records: whenever no chunk is a fragment of a very large point (those add their sums by atomics in k_backsub) and the
+  // per-camera step entries fit the LDS next to the record buffer (~2400 six- / ~1000 nine-parameter cameras); CBA_BACKSUB_REC=0: the old kernel (A/B)
+  {
+    const char* e = std::getenv("CBA_BACKSUB_REC");
+    // nine-parameter cameras keep k_backsub: their records are 176 bytes, and streaming them costs more than linearising again (cfg5, round 6: 394 us
+    // against 326; six-parameter cameras, cfg4: 48 against 64)
+    p->backsub_rec = (NC == 6 || (e && e[0] == '1')) && !p->eval_only && !p->has_fragments && lds_backsub_rec<NC>(p) <= 150 * 1024 && !(e && e[0] == '0');
+    if (p->backsub_rec) {
+      if ((rc = allow_lds(k_backsub_rec<NC, false>, lds_backsub_rec<NC>(p)))) return rc;
+      if ((rc = allow_lds(k_backsub_rec<NC, true>, lds_backsub_rec<NC>(p)))) return rc;
+    }
+  }
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_apply, (size_t)p->ncp * 8))) return rc;
   if ((rc = allow_lds(k_step_cam, (size_t)p->lay.ncp_pad * 8))) return rc;
@@ -946,6 +1019,13 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 #ifdef CBA_PROFILING
   p->schur_clock = std::getenv("CBA_SCHUR_CLOCK") != nullptr;
   p->want_chol_trace = std::getenv("CBA_CHOL_TRACE") != nullptr;
+  if (std::getenv("CBA_STAMPS")) {
+    const size_t n = (size_t)STAMP_SLOTS * STAMP_BLOCKS * STAMP_ROW;
+    if (hipMalloc((void**)&p->stamps, n * sizeof(long long)) == hipSuccess) {
+      (void)hipMemset(p->stamps, 0, n * sizeof(long long));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cba_stamps), &p->stamps, sizeof(p->stamps));
+    }
+  }
 #endif
   int rc = CBA_OK;
   auto bail = [&](int code) { cba_destroy(p); return code; };
@@ -1075,6 +1155,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->grid = std::max(1, std::min(p->n_chunks, max_blocks));
   // (2 per CU also for k_backsub, whose 28 KB of LDS would admit five: swept in round 5, profiles/r05_occupancy_sweeps.txt — 64 us at 2, 69-83 at 3-5)
   p->grid_backsub = std::max(1, std::min(p->n_chunks, 2 * cus));
+  if (const char* e = std::getenv("CBA_BACKSUB_WGS")) p->grid_backsub = std::max(1, std::min(p->n_chunks, std::min(std::max(std::atoi(e), 1), 8) * cus));  // occupancy sweeps
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
   lap("reorder on host");
@@ -1114,7 +1195,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
     for (int64_t q = 0; q < nch; ++q) {
       hcp[2 * q] = hpt[hcs[q]];
       hcp[2 * q + 1] = hpt[hcs[q + 1] - 1] - hpt[hcs[q]] + 1;
-      if (hps[hpt[hcs[q]] + 1] - hps[hpt[hcs[q]]] > CHUNK) hcp[2 * q + 1] = -1;  // fragment of a point larger than a chunk
+      if (hps[hpt[hcs[q]] + 1] - hps[hpt[hcs[q]]] > CHUNK) { hcp[2 * q + 1] = -1; p->has_fragments = true; }  // fragment of a point larger than a chunk
     }
     TRY(dev_upload(p, &p->chunk_pts, hcp));
     // camera-sorted super-chunks for k_build_cs: consecutive chunks while observations <= CS_MAX_OBS and points <= CS_MAX_PTS, their observations
@@ -1835,7 +1916,14 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
                          p->obs_pt, p->pt_start, p->chunk_start, p->chunk_pts, p->n_chunks, p->x, p->lay, p->tab, p->cam_off, p->C, p->loss,
                          p->f_scale, lam, lam_dev, p->V, p->g, p->sinv, p->s, p->partial4);
     };
-    if (fused_trial(p, compact)) { if (p->tab_global) launch_backsub(k_backsub<NC, true, true>); else launch_backsub(k_backsub<NC, false, true>); }
+    auto launch_backsub_rec = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(p->grid_backsub), dim3(BLOCK), lds_backsub_rec<NC>(p), p->stream, (const double*)p->Trec, (const int*)p->obs_cam,
+                         (const int*)p->pt_start, (const int*)p->chunk_start, (const int*)p->chunk_pts, p->n_chunks, p->lay, (const double*)p->tab,
+                         (const int*)p->cam_off, (const int*)p->cam_np, p->C, lam, lam_dev, (const double*)p->V, (const double*)p->g,
+                         (const double*)p->sinv, p->s, p->partial4);
+    };
+    if (p->backsub_rec) { if (fused_trial(p, compact)) launch_backsub_rec(k_backsub_rec<NC, true>); else launch_backsub_rec(k_backsub_rec<NC, false>); }
+    else if (fused_trial(p, compact)) { if (p->tab_global) launch_backsub(k_backsub<NC, true, true>); else launch_backsub(k_backsub<NC, false, true>); }
     else if (p->tab_global) launch_backsub(k_backsub<NC, true>); else launch_backsub(k_backsub<NC>);
     if (p->n_heavy)
       hipLaunchKernelGGL(k_heavy_finish, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->heavy_frag, p->n_heavy, p->lay, lam,
