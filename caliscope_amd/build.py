@@ -45,12 +45,21 @@ def source_digest() -> str:
     return h.hexdigest()
 
 
+def built_digest(path: Path = OUT) -> str | None:
+    """The source digest the library at `path` was compiled with (the string csrc/cba_lib.hip keeps in the binary), or None."""
+    import re
+
+    m = re.search(rb"CBA_SOURCE_DIGEST=([0-9a-f]{64})", path.read_bytes())
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
-    if not force and not needs_build():
+    if not force and not needs_build() and built_digest() == source_digest():
         return OUT
     cmd = [
         hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
-        "-Wall", "-Wno-unused-function", *map(str, SOURCES), "-o", str(OUT), "-pthread", "-lrccl", "-lrocprofiler-sdk-roctx",
+        "-Wall", "-Wno-unused-function", f'-DCBA_SOURCE_DIGEST="{source_digest()}"', *map(str, SOURCES), "-o", str(OUT), "-pthread", "-lrccl",
+        "-lrocprofiler-sdk-roctx",
     ]
     if verbose:
         print("[caliscope_amd.build]", " ".join(cmd), flush=True)

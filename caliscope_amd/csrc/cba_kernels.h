@@ -2916,7 +2916,9 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
   }
   __syncthreads();
   if (sh_outside) {
-    if (threadIdx.x == 0) scal[42] = 2.0;  // need_host (2: the step leaves the bounds); the build pass behind this kernel skips itself
+    // need_host (2: the step leaves the bounds); the build pass behind this kernel skips itself.  x_new's camera entries are undefined from here on;
+    // the step-norm row is zeroed so that the packet's slot 28 does not sum a stale value (the host ignores trial and step_norm when need_host != 0)
+    if (threadIdx.x == 0) { scal[42] = 2.0; step_cam[0] = 0.0; }
     return;
   }
   if (threadIdx.x == 0) {

@@ -36,6 +36,13 @@
 
 using namespace cba;
 
+// sha256 over the sources this library was built from (caliscope_amd/build.py: source_digest), as a string inside the binary:
+// __graft_entry__.smoke() and tests/test_library_abi.py look for it, so a stale .so next to newer sources is the driver's finding.
+#ifndef CBA_SOURCE_DIGEST
+#define CBA_SOURCE_DIGEST "unknown"
+#endif
+extern "C" __attribute__((used, visibility("hidden"))) const char cba_source_digest_marker[] = "CBA_SOURCE_DIGEST=" CBA_SOURCE_DIGEST;
+
 // ---------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
@@ -2054,6 +2061,16 @@ static int run_step(cba_problem* p, double radius, cba_step_info* out) {
   out->need_host = (int)p->h_scal[42];  // 0; 1: failed factorisation / collinear step; 2: a bounded trial point that is not strictly inside its box
   out->p_s[0] = p->h_scal[43]; out->p_s[1] = p->h_scal[44]; out->predicted = p->h_scal[45];
   out->alpha = p->h_scal[46]; out->beta = p->h_scal[47];
+  // test hook (tests/test_gpu_parity.py): CBA_TEST_FAIL_FUSED_STEP=k reports the k-th fused step of the process as one whose factorisation failed and
+  // poisons the step's camera block in the packet, so that the driver's retry route (cba_solve.cpp: larger damping through cba_newton_step, then the
+  // step's camera block fetched again) can be exercised — rounding on a gauge-singular problem is the only other way to get there
+  if (const char* e = std::getenv("CBA_TEST_FAIL_FUSED_STEP")) {
+    static std::atomic<long> n_fused{0};
+    if (++n_fused == std::atol(e)) {
+      out->newton.ok = 0; out->need_host = 1;
+      if (p->bounds_on) for (int i = 0; i < p->ncp; ++i) p->h_bcam[(size_t)3 * p->ncp + i] = NAN;
+    }
+  }
   const double c = 0.5 * p->h_scal[24];
   out->trial.finite = (bad_residual == 0 && std::isfinite(c)) ? 1 : 0;
   out->trial.cost = out->trial.finite ? c : NAN;

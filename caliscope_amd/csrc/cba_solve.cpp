@@ -184,8 +184,8 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
         if ((rc = calls.run("step", [&] { return cba_step(p, std::isnan(radius) ? -1.0 : radius, &si); }))) return rc;
         lin = si.lin; have_step = true;
       } else if (bounded) {
-        fuse_next = false;  // (a bounded solve that has left the fused route stays on the primitives: the two keep the same scaling state, but
-                            // the iteration that sent it here — a trial on a bound — tends to repeat)
+        fuse_next = false;  // (THIS iteration runs on the primitives — the two routes keep the same scaling state; the first trial decides below
+                            // whether the next one is fused again, and after two trial points on a bound the solve stays here: n_outside)
         if ((rc = calls.run("linearize_build", [&] { return cba_linearize_build(p); }))) return rc;  // the scalars follow from cba_set_camera_scaling below
       } else if ((rc = calls.run("linearize", [&] { return cba_linearize(p, &lin); }))) return rc;
       lin_valid = true;
@@ -245,15 +245,17 @@ extern "C" int cba_solve(cba_problem* p, const double* x0, const cba_solve_optio
       if (si.need_host && st.ok && (rc = calls.run("refresh_step_scalars", [&] { return cba_refresh_step_scalars(p, &st); }))) return rc;
     } else if ((rc = calls.run("newton_step", [&] { return cba_newton_step(p, lam, &st); }))) return rc;
     bool first_trial_ready = have_step && st.ok && !si.need_host;
+    bool refetch_step = !have_step;  // bounded: the camera block of the damped step is needed on the host (a fused step's came with the packet)
     if (calls.on) std::fprintf(stderr, "  iteration %ld: lam %.3e radius %.3e ok %d%s\n", iteration, lam, radius, st.ok, have_step ? " (fused)" : "");
     for (int retries = 0; !st.ok;) {
       // positive definite in exact arithmetic; rounding on a gauge-singular problem can still break the factorisation
       if (++retries > max_retries) return cba_set_error(CBA_ERR_NUMERIC, "cba_solve: normal equations could not be factorised even with heavy damping");
       lam = std::max(lam * 10.0, 1e-14 * std::pow(10.0, retries));
       if ((rc = calls.run("newton_step", [&] { return cba_newton_step(p, lam, &st); }))) return rc;
+      refetch_step = true;  // (the packet's step is the one whose factorisation failed: possibly not finite, and not the one on the device now)
       if (calls.on) std::fprintf(stderr, "    retry %d: lam %.3e ok %d\n", retries, lam, st.ok);
     }
-    if (bounded && !have_step && (rc = calls.run("get_camera_params", [&] { return cba_get_camera_params(p, CBA_VEC_STEP, cb.s.data()); }))) return rc;
+    if (bounded && refetch_step && (rc = calls.run("get_camera_params", [&] { return cba_get_camera_params(p, CBA_VEC_STEP, cb.s.data()); }))) return rc;
     // orthonormal basis of span{g_h, p}: q1 = g_h / ||g_h||, q2 = w / ||w||, w = p - c g_h
     const double c = st.gh_dot_p / gh_sq, w_sq = st.w_sq;
     const bool two_d = w_sq > 0.0 && w_sq > 1e-30 * st.p_sq;

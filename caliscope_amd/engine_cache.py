@@ -130,7 +130,9 @@ def clear(trim: bool = True) -> int:
     try:
         from caliscope_amd import _lib
 
-        return int(_lib.load().cba_trim())
+        if _lib._lib is None:  # never loaded in this process (interpreter exit without a solve): nothing pooled, and loading it would start the runtime
+            return 0
+        return int(_lib._lib.cba_trim())
     except Exception:  # noqa: BLE001 - the library may be absent (interpreter exit on a box without it)
         return 0
 

@@ -99,7 +99,9 @@ class HipEngine:
             h, self._h = getattr(self, "_h", None), None
             abort_first = getattr(self, "_abort_requested", False)
         if h is not None:
-            if abort_first:
+            # (read again OUTSIDE the lock: a comm_abort() that set the flag after the read above found the lock taken, left it at the request and
+            # returned — ADVICE r05; self._h is None already, so nobody else touches the handle from here on)
+            if abort_first or getattr(self, "_abort_requested", False):
                 self.lib.cba_comm_abort(h)
             self.lib.cba_destroy(h)
 

@@ -10,8 +10,8 @@
  * iteration it is built from (the arithmetic of core/reprojection.py:75-119 `joint_residuals` and :128-234
  * `joint_jacobian`, of scipy's `scale_for_robust_loss_function`, `compute_grad`, `compute_jac_scale` and of the
  * regularised Gauss-Newton step that scipy gets from LSMR), and parity hooks that expose intermediate results.
- * The trust-region control flow runs on the host inside the library (csrc/cba_solve.cpp; caliscope_amd/trf.py is the
- * same loop in Python on the primitives) and sees scalars only.
+ * The trust-region control flow runs on the host inside the library (csrc/cba_solve.cpp — the only driver of the package; oracle/trf_driver.py,
+ * test infrastructure, restates its unbounded loop in Python on the primitives) and sees scalars only.
  *
  * Conventions
  *  - all pointers are caller-owned host memory, C-contiguous, valid for the duration of the call only;

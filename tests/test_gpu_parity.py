@@ -736,6 +736,49 @@ def test_bounded_fused_iterations_follow_the_primitive_route(monkeypatch):
     assert np.all(fused.x[:ncp] > lb[:ncp]) and np.all(fused.x[:ncp] < ub[:ncp])
 
 
+def test_failed_factorisation_on_the_bounded_fused_route_refetches_the_step():
+    """when the factorisation of a bounded FUSED step fails, the driver forms the step again with more damping through the primitives; the
+    camera block of the step it then reads must be the new one, not the failed one that came with the packet.  CBA_TEST_FAIL_FUSED_STEP makes the
+    library report the second fused step as failed and leaves NaNs where the packet's step was: the solve must still arrive where the undisturbed
+    one does (a driver that kept the packet's step builds non-finite trial points and shrinks its radius until max_nfev).  Child interpreters: the
+    hook counts the fused steps of a process."""
+    import subprocess
+    import sys
+
+    code = (
+        "import json, numpy as np\n"
+        "from caliscope_amd import _lib\n"
+        "from caliscope_amd.engine import BAProblem\n"
+        "from caliscope_amd.hip_engine import HipEngine\n"
+        "from tests.helpers import small_problem\n"
+        "sc, par, x0 = small_problem(n_cams=8, n_points=300, k=5, refine=True)\n"
+        "ncp = par.n_camera_params\n"
+        "lb, ub = par.bounds()\n"
+        "kw = dict(lb=np.ascontiguousarray(lb[:ncp]), ub=np.ascontiguousarray(ub[:ncp]), ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=200)\n"
+        "with HipEngine(BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)) as eng:\n"
+        "    assert eng.lib.cba_set_bounds(eng._h, kw['lb'].ctypes.data_as(_lib.c_double_p), kw['ub'].ctypes.data_as(_lib.c_double_p)) == 1\n"
+        "    r = eng.solve(x0, **kw)\n"
+        "print(json.dumps(dict(status=int(r.status), nfev=int(r.nfev), cost=float(r.cost), x=[float(v) for v in r.x[:ncp]])))\n"
+    )
+
+    def run(env_extra):
+        import json
+        import os
+
+        env = dict(os.environ, **env_extra)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+    plain, _ = run({})
+    hooked, trace = run({"CBA_TEST_FAIL_FUSED_STEP": "2", "CBA_SOLVE_TRACE": "1"})
+    assert "retry 1" in trace, trace[-1500:]
+    assert plain["status"] > 0 and hooked["status"] > 0 and hooked["nfev"] <= plain["nfev"] + 3, (plain["nfev"], hooked["nfev"])
+    assert abs(hooked["cost"] - plain["cost"]) <= 1e-9 * plain["cost"]
+    assert np.abs(np.array(hooked["x"]) - np.array(plain["x"])).max() < 1e-5  # (raw vectors: the gauge may drift by a different path)
+
+
 @pytest.mark.parametrize("refine", [False, True])
 def test_non_finite_start_raises_like_scipy(refine):
     """scipy: ValueError("Residuals are not finite in the initial point.").  Without bounds the driver leaves the evaluation
