@@ -158,18 +158,37 @@ k_cost(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const
   const double* px = xvec + lay.ncp_pad;
   double acc = 0.0;
   bool bad = false;
-  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
-    const int cam = obs_cam[i], pt = obs_pt[i];
+  // two-stage software pipeline, as in k_jv: the record of trip i + 2 and the point of trip i + 1 are in flight while trip i is evaluated (the residual
+  // hook's stores, WRITE_R, are waited for with them: that variant runs once per report, not per iteration)
+  struct Rec { int cam, pt; double u, v; long o; };
+  const long stride = (long)gridDim.x * BLOCK, last = n_obs - 1;
+  auto load_rec = [&](long i) {
+    Rec r; const long k = min(i, last);
+    r.cam = obs_cam[k]; r.pt = obs_pt[k]; r.u = obs_u[k]; r.v = obs_v[k]; r.o = WRITE_R ? (long)order[k] : 0;
+    return r;
+  };
+  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  Rec rc = load_rec(i), rn = load_rec(i + stride);
+  double X = px[rc.pt], Y = px[lay.Ppad + rc.pt], Z = px[2 * lay.Ppad + rc.pt];
+  for (; i < n_obs; i += stride) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(rc.cam), "+v"(rc.pt), "+v"(rc.u), "+v"(rc.v), "+v"(rc.o));
+    asm volatile("" : "+v"(rn.cam), "+v"(rn.pt), "+v"(rn.u), "+v"(rn.v), "+v"(rn.o));
+    asm volatile("" : "+v"(X), "+v"(Y), "+v"(Z));
+    const double Xn = px[rn.pt], Yn = px[lay.Ppad + rn.pt], Zn = px[2 * lay.Ppad + rn.pt];
+    const Rec rnn = load_rec(i + 2 * stride);
+    __builtin_amdgcn_sched_barrier(0);
     double e[2];
-    project_residual(cam_of<CAMG>(sh_tab, tab, cam), px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], e);
+    project_residual(cam_of<CAMG>(sh_tab, tab, rc.cam), X, Y, Z, rc.u, rc.v, e);
     if (!(isfinite(e[0]) && isfinite(e[1]))) bad = true;
     acc += robust_cost_one(loss, f_scale, e[0]) + robust_cost_one(loss, f_scale, e[1]);
     if (WRITE_R) {
-      const long o = order[i];
-      r_out[2 * o] = e[0];
-      r_out[2 * o + 1] = e[1];
+      r_out[2 * rc.o] = e[0];
+      r_out[2 * rc.o + 1] = e[1];
     }
+    rc = rn; rn = rnn; X = Xn; Y = Yn; Z = Zn;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (bad) flags[0] = 1;
   const double tot = block_sum(acc, sh_red);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -642,9 +661,18 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
 #pragma unroll
       for (int q = 0; q < UP::STRIDE; ++q) acc[q] = 0.0;
     };
+    // the record of observation j + 1 is in flight while j is linearised (round 6: read at the head of every trip, its ~1 us round trip was serial time
+    // eight times per super-chunk and thread); one explicit wait per trip, the loaded values laundered for the reason given in k_jv
+    const int jl = max(o1 - 1, 0);
+    int n_cam = cs.cam[min(j0, jl)], n_pl = cs.ptl[min(j0, jl)];
+    double n_u = cs.u[min(j0, jl)], n_v = cs.v[min(j0, jl)];
     for (int j = j0; j < j1; ++j) {
-      const int cam = cs.cam[j], pl = cs.ptl[j];
-      const double u = cs.u[j], v = cs.v[j];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(n_cam), "+v"(n_pl), "+v"(n_u), "+v"(n_v));
+      const int cam = n_cam, pl = n_pl;
+      const double u = n_u, v = n_v;
+      n_cam = cs.cam[min(j + 1, jl)]; n_pl = cs.ptl[min(j + 1, jl)]; n_u = cs.u[min(j + 1, jl)]; n_v = cs.v[min(j + 1, jl)];
+      __builtin_amdgcn_sched_barrier(0);
       if (cam != cur_cam) { flush(); cur_cam = cam; cur_np = (int)cam_of<CAMG>(sh_tab, tab, cam).nparams; }
       double e[2], A[2][MAX_NC], B[2][3];
       cost += obs_linearize<NC>(cam_of<CAMG>(sh_tab, tab, cam), sh_x[pl], sh_x[PM + pl], sh_x[2 * PM + pl], u, v, loss, f_scale, e, A, B);
@@ -820,30 +848,60 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
   const double* p1 = v1 + lay.ncp_pad;
   const double* p2 = (NV == 2) ? v2 + lay.ncp_pad : nullptr;
   double s11 = 0, s12 = 0, s22 = 0;
-  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_obs; i += (long)gridDim.x * BLOCK) {
-    const int cam = obs_cam[i], pt = obs_pt[i];
+  // Two-stage software pipeline (round 6).  An observation needs its record (camera, point, u, v) and then six gathers keyed by the point (the point and
+  // its entries of v): two dependent memory round trips, ~2 us, in front of ~1 us of arithmetic — written as a plain grid-stride loop a workgroup spent
+  // its 8 trips mostly parked (SQ_WAIT_ANY 59 %, lifetime 22 us).  Here trip i issues the RECORD of trip i + 2 and the GATHERS of trip i + 1 (whose record
+  // was issued a trip ago) and only then works on trip i, whose operands were issued one and two trips ago: every load has a whole trip to land.
+  // One explicit wait per trip, at its top; the loaded values pass through an empty asm so that the compiler, which cannot see that wait, does not put a
+  // vmcnt(0) of its own at their first use — behind the loads the trip has just issued (the rule found at schur_reg3_body).
+  struct Rec { int cam, pt; double u, v; };
+  struct Gat { double X, Y, Z, a, b, c, d, e, f; };
+  const long stride = (long)gridDim.x * BLOCK, last = n_obs - 1;
+  auto load_rec = [&](long i) { Rec r; const long k = min(i, last); r.cam = obs_cam[k]; r.pt = obs_pt[k]; r.u = obs_u[k]; r.v = obs_v[k]; return r; };
+  auto load_gat = [&](int pt) {
+    Gat g;
+    g.X = px[pt]; g.Y = px[lay.Ppad + pt]; g.Z = px[2 * lay.Ppad + pt];
+    g.a = p1[pt]; g.b = p1[lay.Ppad + pt]; g.c = p1[2 * lay.Ppad + pt];
+    if (NV == 2) { g.d = p2[pt]; g.e = p2[lay.Ppad + pt]; g.f = p2[2 * lay.Ppad + pt]; } else { g.d = g.e = g.f = 0.0; }
+    return g;
+  };
+  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  Rec rc = load_rec(i), rn = load_rec(i + stride);
+  Gat gc = load_gat(rc.pt);
+  for (; i < n_obs; i += stride) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(rc.cam), "+v"(rc.pt), "+v"(rc.u), "+v"(rc.v));
+    asm volatile("" : "+v"(rn.cam), "+v"(rn.pt), "+v"(rn.u), "+v"(rn.v));
+    asm volatile("" : "+v"(gc.X), "+v"(gc.Y), "+v"(gc.Z), "+v"(gc.a), "+v"(gc.b), "+v"(gc.c));
+    if (NV == 2) asm volatile("" : "+v"(gc.d), "+v"(gc.e), "+v"(gc.f));
+    const Gat gn = load_gat(rn.pt);           // gathers of the next trip
+    const Rec rnn = load_rec(i + 2 * stride);  // record of the trip after next
+    __builtin_amdgcn_sched_barrier(0);
+    const int cam = rc.cam;
     double e[2], A[2][MAX_NC], B[2][3];
     const CamTab& ctj = cam_of<CAMG>(sh_tab, tab, cam);
-    obs_linearize<NC>(ctj, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], obs_u[i], obs_v[i], loss, f_scale, e, A, B);
+    obs_linearize<NC>(ctj, gc.X, gc.Y, gc.Z, rc.u, rc.v, loss, f_scale, e, A, B);
     const int np = (int)ctj.nparams;
     const double* vc = sh_v + cam_off[cam];
-    double a0 = B[0][0] * p1[pt] + B[0][1] * p1[lay.Ppad + pt] + B[0][2] * p1[2 * lay.Ppad + pt];
-    double a1 = B[1][0] * p1[pt] + B[1][1] * p1[lay.Ppad + pt] + B[1][2] * p1[2 * lay.Ppad + pt];
+    double a0 = B[0][0] * gc.a + B[0][1] * gc.b + B[0][2] * gc.c;
+    double a1 = B[1][0] * gc.a + B[1][1] * gc.b + B[1][2] * gc.c;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
       if (k < np) { a0 += A[0][k] * vc[k]; a1 += A[1][k] * vc[k]; }
     s11 += a0 * a0 + a1 * a1;
     if (NV == 2) {
       const double* wc = vc + lay.ncp_pad;
-      double b0 = B[0][0] * p2[pt] + B[0][1] * p2[lay.Ppad + pt] + B[0][2] * p2[2 * lay.Ppad + pt];
-      double b1 = B[1][0] * p2[pt] + B[1][1] * p2[lay.Ppad + pt] + B[1][2] * p2[2 * lay.Ppad + pt];
+      double b0 = B[0][0] * gc.d + B[0][1] * gc.e + B[0][2] * gc.f;
+      double b1 = B[1][0] * gc.d + B[1][1] * gc.e + B[1][2] * gc.f;
 #pragma unroll
       for (int k = 0; k < NC; ++k)
         if (k < np) { b0 += A[0][k] * wc[k]; b1 += A[1][k] * wc[k]; }
       s12 += a0 * b0 + a1 * b1;
       s22 += b0 * b0 + b1 * b1;
     }
+    rc = rn; rn = rnn; gc = gn;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads of the trips that do not exist)
   double r;
   r = block_sum(s11, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = r;
   r = block_sum(s12, sh_red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = r;
@@ -992,7 +1050,7 @@ __device__ __forceinline__ double lin_finish_block(const LinFin& lf, double (*sh
 }
 
 template <int NC, int DETM = 0, bool CAMG = false, bool LINF = false>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, DETM == 0 ? 2 : 1)  // (two workgroups per CU = two waves per SIMD: 256 registers; the fixed-order variants take more and run one)
 k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
         const int* __restrict__ obs_pt, const int* __restrict__ chunk_start, int n_chunks,
         const double* __restrict__ xvec, VecLayout lay, const double* __restrict__ tab, const int* __restrict__ cam_off,
@@ -1030,17 +1088,76 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   double2* stage = sh_stage + (wv % SW) * WAVE * SP;
   bool fail = false;
   const int last_obs = max(chunk_start[n_chunks] - 1, 0);
+  // Two-stage software pipeline (round 6).  An observation's operands are its record (u, v, camera, point) and fifteen gathers keyed by the point (the
+  // point, its V block, scale and gradient): two dependent round trips in front of the arithmetic.  Through round 5 only the record of the next chunk was
+  // in flight while a chunk was processed; the gathers were issued and waited for at the head of every chunk (SQ_WAIT_ANY 54 %, 16 chunks of ~5 us per
+  // workgroup).  Now chunk n issues the RECORD of chunk n + 2 and the GATHERS of chunk n + 1 before it computes, and waits for them only in front of its
+  // own record stores (what the wait covers was issued before the previous chunk's stores, which are therefore never waited for).
+  // Not with fixed-order sums (PIPE: those variants read their per-chunk tables in between).  Nine-parameter cameras send only the POINT ahead (!FULL), and
+  // of the record two chunks ahead only its point index: the body has no 30 registers to spare at two workgroups per CU (with all fifteen values in
+  // flight it asked for 280 and spilled when capped).  V, scale and gradient are then issued at the head of the chunk, in FRONT of the prefetches — the
+  // wait for them leaves those in flight — and are not needed before the ~250 instructions of the linearisation.
+  constexpr bool PIPE = DETM == 0, FULL = NC == 6;
+  struct PtOps { double X, Y, Z, V[6], d[3], g[3]; };
+  auto load_rest = [&](PtOps& q, int pt) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q.V[k] = Vblk[(long)k * lay.Ppad + pt];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { q.d[k] = dp[(long)k * lay.Ppad + pt]; q.g[k] = gp[(long)k * lay.Ppad + pt]; }
+  };
+  auto load_xyz = [&](PtOps& q, int pt) { q.X = px[pt]; q.Y = px[lay.Ppad + pt]; q.Z = px[2 * lay.Ppad + pt]; };
+  auto load_ops = [&](int pt) {  // what travels a chunk ahead
+    PtOps q;
+    load_xyz(q, pt);
+    if constexpr (FULL) load_rest(q, pt);
+    return q;
+  };
+  auto launder_obs = [](ObsRec& r) { asm volatile("" : "+v"(r.u), "+v"(r.v), "+v"(r.cam), "+v"(r.pt)); };
+  auto launder_ops = [](PtOps& q) {
+    asm volatile("" : "+v"(q.X), "+v"(q.Y), "+v"(q.Z));
+    if constexpr (FULL) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(q.V[k]));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(q.d[k]), "+v"(q.g[k]));
+    }
+  };
+  const int stride = (int)gridDim.x, last_chunk = n_chunks - 1;
   int ch = blockIdx.x;
-  int o0 = 0, o1 = 0;
-  ObsRec cur = {0.0, 0.0, 0, 0};
+  int o0 = 0, o1 = 0, no0 = 0, no1 = 0;
+  ObsRec cur = {0.0, 0.0, 0, 0}, nx = cur;
+  PtOps ops;
   if (ch < n_chunks) {
     o0 = chunk_start[ch]; o1 = chunk_start[ch + 1];
+    const int c1 = min(ch + stride, last_chunk);
+    no0 = chunk_start[c1]; no1 = chunk_start[c1 + 1];
     cur = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(o0 + (int)threadIdx.x, last_obs));
+    if constexpr (PIPE) {
+      if constexpr (FULL) nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
+      else nx.pt = obs_pt[min(no0 + (int)threadIdx.x, last_obs)];
+      ops = load_ops(cur.pt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      launder_obs(cur); launder_obs(nx); launder_ops(ops);
+    }
   }
   while (ch < n_chunks) {
-    const int nxt = ch + gridDim.x, nc = min(nxt, n_chunks - 1);
-    const int no0 = chunk_start[nc], no1 = chunk_start[nc + 1];
-    const ObsRec nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
+    const int nxt = ch + stride, c2 = min(ch + 2 * stride, last_chunk);
+    const int nno0 = chunk_start[c2], nno1 = chunk_start[c2 + 1];
+    PtOps ops_n;
+    if constexpr (!PIPE) { load_xyz(ops, cur.pt); load_rest(ops, cur.pt); }  // this chunk's own, waited for where they are used
+    else {
+      if constexpr (!FULL) load_rest(ops, cur.pt);  // (in front of the prefetches: the wait for them leaves those in flight)
+      ops_n = load_ops(nx.pt);                      // gathers of the next chunk
+    }
+    ObsRec nn = {0.0, 0.0, 0, 0};
+    if constexpr (PIPE && !FULL) {  // the rest of the next chunk's record, and the point index of the chunk after next
+      const int k1 = min(no0 + (int)threadIdx.x, last_obs);
+      nx.u = obs_u[k1]; nx.v = obs_v[k1]; nx.cam = obs_cam[k1];
+      nn.pt = obs_pt[min(nno0 + (int)threadIdx.x, last_obs)];
+    } else {
+      nn = load_obs(obs_u, obs_v, obs_cam, obs_pt, min((PIPE ? nno0 : no0) + (int)threadIdx.x, last_obs));  // record of the chunk after next (PIPE) / of the next
+    }
+    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
     const int i = o0 + threadIdx.x;
     double rec[REC];
 #pragma unroll
@@ -1053,16 +1170,16 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       for (int q = threadIdx.x; q <= n_cams; q += BLOCK) sh_cs[q] = det.cstart[(long)ch * (n_cams + 1) + q];
     }
     if (i < o1) {
-      const int cam = cur.cam, pt = cur.pt;
+      const int cam = cur.cam;
       const CamTab& ct = cam_of<CAMG>(sh_tab, tab, cam);
-      const double X = px[pt], Yw = px[lay.Ppad + pt], Zw = px[2 * lay.Ppad + pt];
+      const double X = ops.X, Yw = ops.Y, Zw = ops.Z;
       double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
       obs_linearize<NC>(ct, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);
       const int np = (int)ct.nparams;
       double Vd[6], L[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) Vd[q] = Vblk[(long)q * lay.Ppad + pt];
-      const double d0 = dp[pt], d1 = dp[lay.Ppad + pt], d2 = dp[2 * lay.Ppad + pt];
+      for (int q = 0; q < 6; ++q) Vd[q] = ops.V[q];
+      const double d0 = ops.d[0], d1 = ops.d[1], d2 = ops.d[2];
       Vd[0] += lam * d0 * d0; Vd[3] += lam * d1 * d1; Vd[5] += lam * d2 * d2;
       if (!chol3(Vd, L)) {
         fail = true;
@@ -1070,7 +1187,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       }
       chol3_fwd(L, B[0], Z[0]);
       chol3_fwd(L, B[1], Z[1]);
-      const double gpt[3] = {gp[pt], gp[lay.Ppad + pt], gp[2 * lay.Ppad + pt]};
+      const double gpt[3] = {ops.g[0], ops.g[1], ops.g[2]};
       double y[3];
       chol3_fwd(L, gpt, y);
       double* bc = sh_b + cam_off[cam];
@@ -1092,6 +1209,12 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
     // The 64 records of a wave are one contiguous run of Trec.  A lane storing its own record issues 16-byte stores one
     // record apart (64 cache lines per instruction: the store path stalled, 45 % issue-stall cycles); so the wave transposes
     // through LDS and every store instruction writes 1 KB contiguous.
+    // what this chunk issued ahead has had the chunk's arithmetic to land; behind this wait come the record stores, which nothing waits for
+    if constexpr (PIPE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (FULL) launder_obs(nn); else { launder_obs(nx); asm volatile("" : "+v"(nn.pt)); }
+      launder_ops(ops_n);
+    }
     const int w0 = o0 + wv * WAVE;                       // first observation of this wave
     const int n_pieces = max(0, min(WAVE, o1 - w0)) * NP;  // live pieces of this wave
     double2* dst = reinterpret_cast<double2*>(Trec + (long)w0 * REC);
@@ -1119,7 +1242,10 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       __syncthreads();
       det_round<DM>(bval, sh_b, sh_perm, sh_cs, n_cams, dacc);
     }
-    cur = nx; o0 = no0; o1 = no1; ch = nxt;
+    if constexpr (PIPE && FULL) { cur = nx; nx = nn; ops = ops_n; }
+    else if constexpr (PIPE) { cur = nx; nx.pt = nn.pt; ops.X = ops_n.X; ops.Y = ops_n.Y; ops.Z = ops_n.Z; }
+    else { cur = nn; }
+    o0 = no0; o1 = no1; no0 = nno0; no1 = nno1; ch = nxt;
   }
   if (fail) flags[1] = 1;
   __syncthreads();

@@ -128,6 +128,7 @@ struct cba_problem {
   double cost_x = 0.0;       // cost at the current x
   double trial_cost = 0.0;   // cost at the pending trial point
   int grid_backsub = 1;  // k_backsub keeps 34 KB of LDS (cfg4): more resident workgroups than the 57-65 KB kernels sharing p->grid
+  int jv_grid = 0;       // workgroups of k_jv: what the device holds at once (its 150 registers per thread admit three 256-thread workgroups per CU)
   bool has_fragments = false;  // some chunk is a fragment of a point with more than CHUNK observations (k_backsub adds its sums by atomics)
   bool backsub_rec = false;    // the back-substitution streams the T records (k_backsub_rec) instead of linearising every observation again
   int n_heavy = 0; int* heavy_pts = nullptr; int* heavy_frag = nullptr; double* heavy_W = nullptr;  // heavy points (k_heavy_schur)
@@ -673,6 +674,17 @@ static int allow_lds(K kernel, size_t bytes) {
   return raise_lds_ceiling(reinterpret_cast<const void*>(kernel), bytes);
 }
 
+// Workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) one CU holds at once, as the runtime computes it from the code object's registers
+// and LDS.  Grid-stride kernels are launched with cus x this many workgroups: a grid beyond what is resident runs as a second, partly filled batch
+// (device stamps, round 6: k_jv's 1024 workgroups entered in two batches 24.5 us apart — its real allocation is 150 registers, not the 76 the
+// kernel trace shows — and took 43.5 us where one batch takes ~30).
+template <typename K>
+static int resident_per_cu(K kernel, size_t lds, int fallback) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, lds) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fallback; }
+  return std::min(n, 8);
+}
+
 static size_t lds_tab(const cba_problem* p) { return p->tab_global ? 0 : (size_t)p->C * CAMTAB_LDS; }  // doubles of the LDS copy of the camera table
 static size_t lds_cost(const cba_problem* p) { return (lds_tab(p) + 8) * 8; }
 // k_build<NC, 0, true> reads the camera table from global memory: chosen when the table is what keeps a second workgroup off the CU
@@ -989,7 +1001,15 @@ static int configure_kernels(cba_problem* p) {
     if (p->backsub_rec) {
       if ((rc = allow_lds(k_backsub_rec<NC, false>, lds_backsub_rec<NC>(p)))) return rc;
       if ((rc = allow_lds(k_backsub_rec<NC, true>, lds_backsub_rec<NC>(p)))) return rc;
+      if (!std::getenv("CBA_BACKSUB_WGS"))  // as many workgroups as are resident at once (cfg4: four per CU, 40 000 bytes of LDS each: 48 us against 53 at two)
+        p->grid_backsub = std::max(1, std::min(p->n_chunks, p->cus * resident_per_cu(k_backsub_rec<NC, true>, lds_backsub_rec<NC>(p), 2)));
     }
+  }
+  {
+    int per_cu = p->tab_global ? resident_per_cu(k_jv<NC, 1, true>, lds_jv(p, 1), 2) : resident_per_cu(k_jv<NC, 1>, lds_jv(p, 1), 2);
+    if (const char* e = std::getenv("CBA_JV_WGS")) per_cu = std::max(1, std::min(std::atoi(e), 8));
+    p->jv_grid = (int)std::max<long>(1, std::min<long>((p->N + BLOCK - 1) / BLOCK, (long)p->cus * per_cu));
+    p->jv_grid = std::min(p->jv_grid, 2048);  // (rows of partial4)
   }
   if (p->n_heavy && (rc = allow_lds(k_heavy_schur<NC>, (size_t)p->ncp * 3 * sizeof(double) + (size_t)p->ncp * sizeof(int)))) return rc;
   if ((rc = allow_lds(k_chol_apply, (size_t)p->ncp * 8))) return rc;
@@ -1218,17 +1238,47 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
       // ones (54 values per camera change: longer runs pay; measured on cfg4 / cfg5: 59 / 72 / 120 us at 2048 / 3072 / 4096, 545 / 530 / 508 us).
       const int64_t s_cap = (nct == 9) ? 4096 : 2048;
       const int64_t wgs = std::max(1, p->grid);  // the persistent workgroups of the launch
-      const int64_t rounds = std::max<int64_t>(1, (p->N + wgs * s_cap - 1) / (wgs * s_cap));
-      const int64_t s_target = std::max<int64_t>(CHUNK, (p->N + wgs * rounds - 1) / (wgs * rounds));
-      std::vector<int> sc_chunk{0}, sc_obs{0}, sc_p0, sc_np;
+      int64_t rounds = std::max<int64_t>(1, (p->N + wgs * s_cap - 1) / (wgs * s_cap));
+      std::vector<int> sc_chunk, sc_obs, sc_p0, sc_np;
       int pmax = 0;
-      for (int64_t q = 0; q < nch;) {
-        int64_t e = q + 1;
-        while (e < nch && hcs[e + 1] - hcs[q] <= s_target && hcp[2 * e] + hcp[2 * e + 1] - hcp[2 * q] <= CS_MAX_PTS) ++e;
-        sc_chunk.push_back((int)e); sc_obs.push_back(hcs[e]);
-        sc_p0.push_back(hcp[2 * q]); sc_np.push_back(hcp[2 * (e - 1)] + hcp[2 * (e - 1) + 1] - hcp[2 * q]);
-        pmax = std::max(pmax, sc_np.back());
-        q = e;
+      // Round 6: the super-chunks are cut at the chunk boundaries nearest to k N / (rounds * workgroups), so that there are EXACTLY rounds * workgroups of
+      // them (fewer on a small problem) and workgroup w, which takes super-chunks w, w + grid, ..., gets `rounds` of about the same size.  Until round 5 they
+      // were filled greedily up to N / (rounds * workgroups) observations: whole chunks leave each a little short of that, cfg4 ended with 1143 super-chunks
+      // of 1750 observations for 1024 slots, and 119 of the 512 workgroups walked three of them while the others walked two (device stamps, round 6:
+      // workgroup lifetimes 42 / 53 / 63 us min / mean / max; cfg5 236 / 273 / 337).  A cut that would exceed the caps (observations, points of the LDS
+      // stage) asks for one more round.
+      for (int attempt = 0; attempt < 8; ++attempt, ++rounds) {
+        const int64_t n_target = std::min<int64_t>(std::max<int64_t>(1, wgs * rounds), nch);
+        sc_chunk.assign(1, 0); sc_obs.assign(1, 0); sc_p0.clear(); sc_np.clear();
+        pmax = 0;
+        bool fits = true;
+        int64_t q = 0;
+        for (int64_t k = 0; k < n_target && q < nch; ++k) {
+          const int64_t goal = (p->N * (k + 1) + n_target - 1) / n_target;  // observations behind super-chunk k
+          int64_t e = q + 1;
+          while (e < nch && (k + 1 == n_target || hcs[e + 1] <= goal || (hcs[e] < goal && goal - hcs[e] > hcs[e + 1] - goal))) ++e;  // nearest boundary
+          if (k + 1 == n_target) e = nch;
+          const int np_here = hcp[2 * (e - 1)] + hcp[2 * (e - 1) + 1] - hcp[2 * q];
+          if (hcs[e] - hcs[q] > s_cap + CHUNK || np_here > CS_MAX_PTS) { fits = false; break; }
+          sc_chunk.push_back((int)e); sc_obs.push_back(hcs[e]);
+          sc_p0.push_back(hcp[2 * q]); sc_np.push_back(np_here);
+          pmax = std::max(pmax, np_here);
+          q = e;
+        }
+        if (fits && q == nch) break;
+        if (attempt == 7) {  // (irregular point sizes: the greedy fill of rounds 3-5, which always fits)
+          const int64_t s_target = std::max<int64_t>(CHUNK, (p->N + wgs * rounds - 1) / (wgs * rounds));
+          sc_chunk.assign(1, 0); sc_obs.assign(1, 0); sc_p0.clear(); sc_np.clear();
+          pmax = 0;
+          for (int64_t qq = 0; qq < nch;) {
+            int64_t e = qq + 1;
+            while (e < nch && hcs[e + 1] - hcs[qq] <= s_target && hcp[2 * e] + hcp[2 * e + 1] - hcp[2 * qq] <= CS_MAX_PTS) ++e;
+            sc_chunk.push_back((int)e); sc_obs.push_back(hcs[e]);
+            sc_p0.push_back(hcp[2 * qq]); sc_np.push_back(hcp[2 * (e - 1)] + hcp[2 * (e - 1) + 1] - hcp[2 * qq]);
+            pmax = std::max(pmax, sc_np.back());
+            qq = e;
+          }
+        }
       }
       const int n_sc = (int)sc_p0.size();
       HostVec<int> cperm(p->N);  // position in (super-chunk, camera, point) order -> sorted observation; the copy itself is made on the device (k_cs_fill)
@@ -1563,7 +1613,7 @@ template <int NC>
 static int run_jv(cba_problem* p, int nv, int* rows_out = nullptr, const double* xvec = nullptr, const double* tab = nullptr) {
   ScopedTimer t(p, T_JV);
   if (!xvec) { xvec = p->x; tab = p->tab; }  // (the speculative linearisation evaluates the trial point: x_new, tab_new)
-  const int grid = (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
+  const int grid = nv == 1 ? p->jv_grid : (int)std::min<long>((p->N + BLOCK - 1) / BLOCK, 1024);
   auto launch_jv = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_jv(p, nv), p->stream, p->obs_u, p->obs_v, p->obs_cam, p->obs_pt,
                        p->N, xvec, p->lay, tab, p->cam_off, p->C, p->loss, p->f_scale, p->v1, p->v2, p->partial4);
