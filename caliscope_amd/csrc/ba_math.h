@@ -56,15 +56,15 @@ struct CamTab {
   double fx0, fy0, inv_fx0;
   double model;   // 0 pinhole, 1 fisheye   (stored as double to keep the table homogeneous)
   double nparams; // 6 or 9
-  double pad[13];
+  double pad[13]; // pad[0]: index of the camera's first parameter in the parameter vector (as a double: the table is homogeneous); the rest unused
 };
 static_assert(sizeof(CamTab) == 48 * sizeof(double), "CamTab must be 48 doubles");
-static_assert(offsetof(CamTab, pad) == 35 * sizeof(double), "35 live doubles (CAMTAB_LIVE in cba_kernels.h)");
+static_assert(offsetof(CamTab, pad) == 35 * sizeof(double), "35 doubles + pad[0] are live (CAMTAB_LIVE = 36 in cba_kernels.h)");
 constexpr int CAMTAB_DOUBLES = 48;
 
 // x_cam: this camera's slice of the parameter vector in an array of MAX_NC entries (all nine are read; those behind nparams are not used);
 // cconst: cam_const row.
-CBA_HD void cam_prepare(const double* x_cam, const double* cconst, int model, int nparams, CamTab* o) {
+CBA_HD void cam_prepare(const double* x_cam, const double* cconst, int model, int nparams, CamTab* o, int param_off = 0) {
   const double rx = x_cam[0], ry = x_cam[1], rz = x_cam[2];
   const double th2 = rx * rx + ry * ry + rz * rz;
   const double th = sqrt(th2);
@@ -105,7 +105,9 @@ CBA_HD void cam_prepare(const double* x_cam, const double* cconst, int model, in
   for (int i = 2; i < 5; ++i) o->d[i] = cconst[4 + i];
   o->model = (double)model;
   o->nparams = (double)nparams;
-  for (int i = 0; i < 13; ++i) o->pad[i] = 0.0;
+  o->pad[0] = (double)param_off;  // (the per-observation kernels take a camera's slice of a vector from here: an index table in global memory cost them a
+                                  // dependent load per observation, in the middle of their software pipelines)
+  for (int i = 1; i < 13; ++i) o->pad[i] = 0.0;
 }
 
 // Lens model: normalised (x, y) -> distorted (xd, yd) and its 2x2 derivative dd = d(xd,yd)/d(x,y).

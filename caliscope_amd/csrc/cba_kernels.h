@@ -97,8 +97,8 @@ __device__ __forceinline__ void lds_add(double* addr, double v) { unsafeAtomicAd
 // LDS copy of the camera table.  Rows are padded to 49 doubles: with the natural stride of 48 doubles
 // (96 dwords == 32 mod 64 banks) the lanes of a wave, each reading the same field of a different camera,
 // would land on two bank pairs (32-way conflict); an odd stride spreads 32 cameras over all bank pairs.
-constexpr int CAMTAB_LIVE = 35;               // doubles of a CamTab row in use (everything before the padding)
-constexpr int CAMTAB_LDS = CAMTAB_LIVE + 2;    // 37: the padding stays in HBM (49 doubles per camera cost k_build / k_tprep their third workgroup per CU)
+constexpr int CAMTAB_LIVE = 36;               // doubles of a CamTab row in use (everything up to and including pad[0], the camera's parameter offset)
+constexpr int CAMTAB_LDS = CAMTAB_LIVE + 1;    // 37 (odd): the padding stays in HBM (49 doubles per camera cost k_build / k_tprep their third workgroup per CU)
 // The per-observation kernels walk their chunks with the NEXT chunk's observation record already in flight:
 // registers for (u, v, camera, point) of chunk n + 1 are loaded (unconditionally, index clamped) before chunk n is
 // processed, so each workgroup sees the streaming-load latency once instead of once per chunk.
@@ -137,7 +137,7 @@ __global__ void k_cam_prep(const double* __restrict__ xvec, const double* __rest
   const int np = cam_np[c];
   for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? xvec[cam_off[c] + i] : 0.0;
   CamTab t;
-  cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t);
+  cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t, cam_off[c]);
   const double* src = reinterpret_cast<const double*>(&t);
   for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab[c * CAMTAB_DOUBLES + i] = src[i];
 }
@@ -848,14 +848,17 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
   const double* p1 = v1 + lay.ncp_pad;
   const double* p2 = (NV == 2) ? v2 + lay.ncp_pad : nullptr;
   double s11 = 0, s12 = 0, s22 = 0;
-  // Two-stage software pipeline (round 6).  An observation needs its record (camera, point, u, v) and then six gathers keyed by the point (the point and
-  // its entries of v): two dependent memory round trips, ~2 us, in front of ~1 us of arithmetic — written as a plain grid-stride loop a workgroup spent
-  // its 8 trips mostly parked (SQ_WAIT_ANY 59 %, lifetime 22 us).  Here trip i issues the RECORD of trip i + 2 and the GATHERS of trip i + 1 (whose record
-  // was issued a trip ago) and only then works on trip i, whose operands were issued one and two trips ago: every load has a whole trip to land.
-  // One explicit wait per trip, at its top; the loaded values pass through an empty asm so that the compiler, which cannot see that wait, does not put a
-  // vmcnt(0) of its own at their first use — behind the loads the trip has just issued (the rule found at schur_reg3_body).
+  // Software pipeline (round 6).  An observation needs its record (camera, point, u, v) and then six gathers keyed by the point (the point and its
+  // entries of v): two dependent memory round trips, ~2 us, in front of ~0.8 us of arithmetic — written as a plain grid-stride loop a workgroup spent its
+  // 8 trips mostly parked (SQ_WAIT_ANY 59 %, lifetime 22 us at 1024 workgroups).  Here trip i issues the RECORD of trip i + 4 and the GATHERS of trip
+  // i + 2 (whose record was issued two trips ago) and only then works on trip i: every load has TWO trips to land (with one, 33 us; the kernel's 174
+  // registers leave two workgroups per CU, so the depth has to come from the pipeline).  One explicit wait per trip, at its top: vmcnt(LOADS) lets the
+  // loads of the previous trip stay in flight (vector-memory operations return in order, and the loop issues nothing else); the values that become due
+  // pass through an empty asm so that the compiler, which cannot see that wait, does not put a vmcnt(0) of its own at their first use — behind the
+  // loads the trip has just issued (the rule found at schur_reg3_body).
   struct Rec { int cam, pt; double u, v; };
   struct Gat { double X, Y, Z, a, b, c, d, e, f; };
+  constexpr int LOADS = 4 + (NV == 2 ? 9 : 6);  // vector-memory instructions a trip issues
   const long stride = (long)gridDim.x * BLOCK, last = n_obs - 1;
   auto load_rec = [&](long i) { Rec r; const long k = min(i, last); r.cam = obs_cam[k]; r.pt = obs_pt[k]; r.u = obs_u[k]; r.v = obs_v[k]; return r; };
   auto load_gat = [&](int pt) {
@@ -865,24 +868,29 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
     if (NV == 2) { g.d = p2[pt]; g.e = p2[lay.Ppad + pt]; g.f = p2[2 * lay.Ppad + pt]; } else { g.d = g.e = g.f = 0.0; }
     return g;
   };
+  auto launder_rec = [](Rec& r) { asm volatile("" : "+v"(r.cam), "+v"(r.pt), "+v"(r.u), "+v"(r.v)); };
+  auto launder_gat = [](Gat& g) {
+    asm volatile("" : "+v"(g.X), "+v"(g.Y), "+v"(g.Z), "+v"(g.a), "+v"(g.b), "+v"(g.c));
+    if (NV == 2) asm volatile("" : "+v"(g.d), "+v"(g.e), "+v"(g.f));
+  };
   long i = (long)blockIdx.x * BLOCK + threadIdx.x;
-  Rec rc = load_rec(i), rn = load_rec(i + stride);
-  Gat gc = load_gat(rc.pt);
+  Rec rc = load_rec(i), r1 = load_rec(i + stride), r2 = load_rec(i + 2 * stride), r3 = load_rec(i + 3 * stride);
+  Gat gc = load_gat(rc.pt), g1 = load_gat(r1.pt);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  launder_rec(rc); launder_rec(r1); launder_rec(r2); launder_rec(r3); launder_gat(gc); launder_gat(g1);
   for (; i < n_obs; i += stride) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(rc.cam), "+v"(rc.pt), "+v"(rc.u), "+v"(rc.v));
-    asm volatile("" : "+v"(rn.cam), "+v"(rn.pt), "+v"(rn.u), "+v"(rn.v));
-    asm volatile("" : "+v"(gc.X), "+v"(gc.Y), "+v"(gc.Z), "+v"(gc.a), "+v"(gc.b), "+v"(gc.c));
-    if (NV == 2) asm volatile("" : "+v"(gc.d), "+v"(gc.e), "+v"(gc.f));
-    const Gat gn = load_gat(rn.pt);           // gathers of the next trip
-    const Rec rnn = load_rec(i + 2 * stride);  // record of the trip after next
+    // everything but the previous trip's loads has landed: the gathers of this trip (issued two trips ago) and the record of trip i + 2
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    launder_gat(gc); launder_rec(r2);
+    const Gat g2 = load_gat(r2.pt);            // gathers of trip i + 2
+    const Rec r4 = load_rec(i + 4 * stride);   // record of trip i + 4
     __builtin_amdgcn_sched_barrier(0);
     const int cam = rc.cam;
     double e[2], A[2][MAX_NC], B[2][3];
     const CamTab& ctj = cam_of<CAMG>(sh_tab, tab, cam);
     obs_linearize<NC>(ctj, gc.X, gc.Y, gc.Z, rc.u, rc.v, loss, f_scale, e, A, B);
     const int np = (int)ctj.nparams;
-    const double* vc = sh_v + cam_off[cam];
+    const double* vc = sh_v + (int)ctj.pad[0];  // (= cam_off[cam], from the table row that is being read anyway)
     double a0 = B[0][0] * gc.a + B[0][1] * gc.b + B[0][2] * gc.c;
     double a1 = B[1][0] * gc.a + B[1][1] * gc.b + B[1][2] * gc.c;
 #pragma unroll
@@ -899,7 +907,7 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
       s12 += a0 * b0 + a1 * b1;
       s22 += b0 * b0 + b1 * b1;
     }
-    rc = rn; rn = rnn; gc = gn;
+    rc = r1; r1 = r2; r2 = r3; r3 = r4; gc = g1; g1 = g2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads of the trips that do not exist)
   double r;
@@ -1190,7 +1198,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       const double gpt[3] = {ops.g[0], ops.g[1], ops.g[2]};
       double y[3];
       chol3_fwd(L, gpt, y);
-      double* bc = sh_b + cam_off[cam];
+      double* bc = sh_b + (int)ct.pad[0];  // (= cam_off[cam])
       // rotated point Y = R X (the record's first three entries)
       rec[0] = fma(ct.R[2], Zw, fma(ct.R[1], Yw, ct.R[0] * X));
       rec[1] = fma(ct.R[5], Zw, fma(ct.R[4], Yw, ct.R[3] * X));
@@ -2376,14 +2384,26 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
   int ch = blockIdx.x;
   int o0 = 0, o1 = 0;
   ObsRec cur = {0.0, 0.0, 0, 0};
+  // (round 6) the point of the NEXT chunk's observation travels one chunk ahead as well, keyed by a point index loaded two chunks ahead: the gather
+  // used to be issued and waited for at the head of every chunk, behind the record it depends on
+  int pt_next = 0;
+  double X = 0.0, Yw = 0.0, Zw = 0.0;
   if (ch < n_chunks) {
     o0 = chunk_start[ch]; o1 = chunk_start[ch + 1];
     cur = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(o0 + (int)threadIdx.x, last_obs));
+    pt_next = obs_pt[min(chunk_start[min(ch + (int)gridDim.x, n_chunks - 1)] + (int)threadIdx.x, last_obs)];
+    X = px[cur.pt]; Yw = px[lay.Ppad + cur.pt]; Zw = px[2 * lay.Ppad + cur.pt];
   }
   while (ch < n_chunks) {
     const int nxt = ch + gridDim.x, nc = min(nxt, n_chunks - 1);
     const int no0 = chunk_start[nc], no1 = chunk_start[nc + 1];
-    const ObsRec nx = load_obs(obs_u, obs_v, obs_cam, obs_pt, min(no0 + (int)threadIdx.x, last_obs));
+    ObsRec nx;
+    {
+      const int k1 = min(no0 + (int)threadIdx.x, last_obs);
+      nx.u = obs_u[k1]; nx.v = obs_v[k1]; nx.cam = obs_cam[k1]; nx.pt = pt_next;
+    }
+    const double Xn = px[pt_next], Yn = px[lay.Ppad + pt_next], Zn = px[2 * lay.Ppad + pt_next];
+    const int pt_nn = obs_pt[min(chunk_start[min(nxt + (int)gridDim.x, n_chunks - 1)] + (int)threadIdx.x, last_obs)];
     const int cp0 = chunk_pts[2 * ch], npts = chunk_pts[2 * ch + 1];
     const int i = o0 + threadIdx.x;
     // Inputs of the per-point phase, fetched now and consumed after the barrier: wave 0 takes points cp0 .. cp0 + 63
@@ -2405,9 +2425,9 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
       const int cam = cur.cam, pt = cur.pt;
       double e[2], A[2][MAX_NC], B[2][3];
       const CamTab& ctb = cam_of<CAMG>(sh_tab, tab, cam);
-      obs_linearize<NC>(ctb, px[pt], px[lay.Ppad + pt], px[2 * lay.Ppad + pt], cur.u, cur.v, loss, f_scale, e, A, B);
+      obs_linearize<NC>(ctb, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);
       const int np = (int)ctb.nparams;
-      const double* dc = sh_dc + cam_off[cam];
+      const double* dc = sh_dc + (int)ctb.pad[0];  // (= cam_off[cam])
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k)
@@ -2445,6 +2465,7 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     }
     __syncthreads();
     cur = nx; o0 = no0; o1 = no1; ch = nxt;
+    pt_next = pt_nn; X = Xn; Yw = Yn; Zw = Zn;
   }
   if (SCAL) {  // (sh_pt is free: the loop ended behind a barrier)
     double r;
@@ -2735,7 +2756,7 @@ k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const
       const int np = cam_np[c];
       for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? __builtin_nontemporal_load(&x_new[cam_off[c] + i]) : 0.0;
       CamTab t;
-      cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t);
+      cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t, cam_off[c]);
       const double* src = reinterpret_cast<const double*>(&t);
       for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab_out[c * CAMTAB_DOUBLES + i] = src[i];
     }
@@ -3057,7 +3078,7 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
     const int np = cam_np[c], off = cam_off[c];
     for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? sh_xc[off + i] : 0.0;
     CamTab t;
-    cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t);
+    cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t, cam_off[c]);
     const double* src = reinterpret_cast<const double*>(&t);
     for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab_out[c * CAMTAB_DOUBLES + i] = src[i];
   }
