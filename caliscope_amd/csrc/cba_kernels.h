@@ -203,16 +203,17 @@ __device__ __forceinline__ void reduce_rows_block(const double* __restrict__ par
                                                   int stride, int tri) {
   __shared__ double sh[REDUCE_RY][64];
   const int j = blockIdx.x * 64 + threadIdx.x;
-  double s0 = 0.0, s1 = 0.0;
+  // eight independent chains per thread (round 6: with two, 512 rows were sixteen dependent load-add steps, ~8 us of latency for 7 MB)
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (j < width) {
     int b = threadIdx.y;
-    for (; b + REDUCE_RY < nrow; b += 2 * REDUCE_RY) {
-      s0 += partial[(long)b * width + j];
-      s1 += partial[(long)(b + REDUCE_RY) * width + j];
+    for (; b + 7 * REDUCE_RY < nrow; b += 8 * REDUCE_RY) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += partial[(long)(b + q * REDUCE_RY) * width + j];
     }
-    if (b < nrow) s0 += partial[(long)b * width + j];
+    for (; b < nrow; b += REDUCE_RY) acc[0] += partial[(long)b * width + j];
   }
-  sh[threadIdx.y][threadIdx.x] = s0 + s1;
+  sh[threadIdx.y][threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (threadIdx.y == 0 && j < width) {
     double tot = 0.0;
@@ -1768,54 +1769,6 @@ k_tri_pack(double* __restrict__ Sacc, double* __restrict__ tri, int ncp, int dir
   }
 }
 
-// S = U + lam D_c^2 + cam_diag - Sacc (symmetric, both triangles written), rhs = -g_c + b
-template <int NC>
-__global__ void k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,
-                                 const double* __restrict__ Upacked, const double* __restrict__ gvec,
-                                 const double* __restrict__ sinv, const int* __restrict__ param_cam,
-                                 const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ lam_dev,
-                                 const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
-                                 double* __restrict__ W, int ldw, const double* __restrict__ red = nullptr, int g = 0, long tile_elems = 0,
-                                 const int* __restrict__ group_cam_begin = nullptr, int b_width = 0) {
-  CBA_STAMP(ST_FINALIZE);
-  using UP = UPack<NC>;
-  if (lam_dev) lam = *lam_dev;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)ncp * ncp) return;
-  const int row = (int)(t / ncp), col = (int)(t % ncp);
-  if (col < row) return;
-  const bool same_cam = param_cam[row] == param_cam[col];
-  double v;
-  if (red && same_cam) {
-    // red != nullptr (single rank, no heavy points, no constraint rows): the diagonal camera blocks are folded HERE from the helper-thread sums
-    // k_reg_reduce parked in `red` (what k_reg_fold does — one launch less; Sacc's diagonal blocks are then never written nor read)
-    const int cam = param_cam[row], ga = cam / g, ca0 = group_cam_begin[ga], na = group_cam_begin[ga + 1] - ca0;
-    const double* src = red + (long)ga * tile_elems + param_loc[row] * NC + param_loc[col];
-    double sum = 0.0;
-    for (int k = cam - ca0; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj
-      int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
-      while (li * (li + 1) / 2 > k) --li;
-      while ((li + 1) * (li + 2) / 2 <= k) ++li;
-      const int lj = k - li * (li + 1) / 2;
-      sum += src[(long)(li * g + lj) * (NC * NC)];
-    }
-    v = -sum;
-  } else {
-    v = -Sacc[(long)row * ncp + col];
-  }
-  if (same_cam) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
-  if (row == col) {
-    v += lam * sinv[row] * sinv[row] + cam_diag[row];  // cam_diag: zero unless the caller set a bound scaling
-    const double rv = -gvec[row] + b_entry(bacc, b_width, row);
-    rhs[row] = rv;
-    W[(long)ncp * ldw + row] = rv;  // rhs^T: last row of the Cholesky work matrix
-  }
-  S[(long)row * ncp + col] = v;
-  S[(long)col * ncp + row] = v;
-  W[(long)row * ldw + col] = v;
-  W[(long)col * ldw + row] = v;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Dense solve of the reduced camera system  S dc = rhs  (n <= 1152) by blocked Cholesky, NB = 32.
 // The work matrix is (n+1) x ldw, row-major: rows 0..n-1 hold S, row n holds rhs^T.  Row n is "below" every
@@ -1909,6 +1862,84 @@ __device__ __forceinline__ void chol_factor_store(double (*D)[NB + 1], int nb, d
     xinv[e] = x;
     if (tdiag && i < nb && c < nb) tdiag[(long)c * ldw + i] = x;  // T_kk[c][i] = X[i][c]
   }
+}
+
+// S = U + lam D_c^2 + cam_diag - Sacc (symmetric, both triangles written), rhs = -g_c + b
+// entry (row, col), col >= row, of S
+template <int NC>
+__device__ __forceinline__ double schur_entry(int row, int col, const double* __restrict__ Sacc, const double* __restrict__ Upacked,
+                                              const double* __restrict__ sinv, const int* __restrict__ param_cam, const int* __restrict__ param_loc,
+                                              int ncp, double lam, const double* __restrict__ cam_diag, const double* __restrict__ red, int g,
+                                              long tile_elems, const int* __restrict__ group_cam_begin) {
+  using UP = UPack<NC>;
+  const bool same_cam = param_cam[row] == param_cam[col];
+  double v;
+  if (red && same_cam) {
+    // red != nullptr (single rank, no heavy points, no constraint rows): the diagonal camera blocks are folded HERE from the helper-thread sums
+    // k_reg_reduce parked in `red` (what k_reg_fold does — one launch less; Sacc's diagonal blocks are then never written nor read)
+    const int cam = param_cam[row], ga = cam / g, ca0 = group_cam_begin[ga], na = group_cam_begin[ga + 1] - ca0;
+    const double* src = red + (long)ga * tile_elems + param_loc[row] * NC + param_loc[col];
+    double sum = 0.0;
+    for (int k = cam - ca0; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj
+      int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
+      while (li * (li + 1) / 2 > k) --li;
+      while ((li + 1) * (li + 2) / 2 <= k) ++li;
+      const int lj = k - li * (li + 1) / 2;
+      sum += src[(long)(li * g + lj) * (NC * NC)];
+    }
+    v = -sum;
+  } else {
+    v = -Sacc[(long)row * ncp + col];
+  }
+  if (same_cam) v += Upacked[param_cam[row] * UP::STRIDE + UP::idx(param_loc[row], param_loc[col])];
+  if (row == col) v += lam * sinv[row] * sinv[row] + cam_diag[row];  // cam_diag: zero unless the caller set a bound scaling
+  return v;
+}
+// Xinv != nullptr (round 6): ONE MORE workgroup, the last of the grid, forms the first diagonal block of S itself and factors it — what step k = -1 of the
+// dense solve did in a launch of its own (one workgroup, 9.5 us + a launch gap at the head of the serial chain); the regular threads then leave that
+// block of the work matrix alone.
+template <int NC>
+__global__ void __launch_bounds__(256)
+k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,
+                 const double* __restrict__ Upacked, const double* __restrict__ gvec,
+                 const double* __restrict__ sinv, const int* __restrict__ param_cam,
+                 const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ lam_dev,
+                 const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
+                 double* __restrict__ W, int ldw, const double* __restrict__ red = nullptr, int g = 0, long tile_elems = 0,
+                 const int* __restrict__ group_cam_begin = nullptr, int b_width = 0, int* __restrict__ flags = nullptr,
+                 double* __restrict__ Xinv = nullptr, double* __restrict__ Tinv = nullptr) {
+  CBA_STAMP(ST_FINALIZE);
+  if (lam_dev) lam = *lam_dev;
+  const int nb0 = min(NB, ncp);
+  if (Xinv && blockIdx.x + 1 == gridDim.x) {
+    __shared__ double sh_D[2 * NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e / NB, j = e % NB;
+      sh_D[i][j] = (i < nb0 && j < nb0) ? schur_entry<NC>(min(i, j), max(i, j), Sacc, Upacked, sinv, param_cam, param_loc, ncp, lam, cam_diag, red, g, tile_elems, group_cam_begin)
+                                        : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid < WAVE) chol_factor_block(sh_D, nb0, flags);
+    __syncthreads();
+    chol_factor_store(sh_D, nb0, W, ldw, Xinv, tid, 256, Tinv);  // L_00, X_0, T_00
+    return;
+  }
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)ncp * ncp) return;
+  const int row = (int)(t / ncp), col = (int)(t % ncp);
+  if (col < row) return;
+  const double v = schur_entry<NC>(row, col, Sacc, Upacked, sinv, param_cam, param_loc, ncp, lam, cam_diag, red, g, tile_elems, group_cam_begin);
+  if (row == col) {
+    const double rv = -gvec[row] + b_entry(bacc, b_width, row);
+    rhs[row] = rv;
+    W[(long)ncp * ldw + row] = rv;  // rhs^T: last row of the Cholesky work matrix
+  }
+  S[(long)row * ncp + col] = v;
+  S[(long)col * ncp + row] = v;
+  if (Xinv && col < nb0) return;  // (block (0, 0) of the work matrix belongs to the factoring workgroup)
+  W[(long)row * ldw + col] = v;
+  W[(long)col * ldw + row] = v;
 }
 
 // One launch per panel (right-looking with look-ahead).  Work matrix W: (n + 1) rows, row stride ldw (multiple of
