@@ -3388,6 +3388,11 @@ struct ConPlan {
   const double* heavy_W;
   int n_heavy;
   double* big;            // 9 doubles per component point (offset 9 comp_pt[k]): per-point scratch of the components that do not fit the LDS copy; else nullptr
+  // small components (round 6): every component has at most CON_SMALL_M rows and its dense blocks fit `small_lds` bytes of LDS — k_con_schur_small /
+  // k_con_backsub_small run, and `M` holds the INVERSE of each component's Cholesky factor (row-major m x m) instead of the factor
+  int small;
+  int small_lds;          // dynamic LDS of k_con_schur_small (bytes)
+  int max_m, max_np;      // rows / points of the largest component
 };
 
 __device__ __forceinline__ void con_geometry(const ConPlan& cp, int c, const double* __restrict__ px, VecLayout lay, double* unit,
@@ -3643,6 +3648,248 @@ k_con_schur(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vb
       if (c2 < ncp) unsafeAtomicAdd(&Sacc[(long)r * ncp + c2], -acc);
       else unsafeAtomicAdd(&bacc[r], -acc);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small components (round 6): the rows of ONE board in ONE frame — 35 rows on 12 points in the reference's own sessions (core/constraints.py:68-81,
+// docs/scripting.md:168-174).  k_con_schur above walks global memory (z, the slot tables, M, G) and factors M column by column with two barriers per
+// column: 215-238 us per launch, 41 % of the kernel time of an optimize() call on that session.  Here everything of a component is a dense block in
+// LDS and every step is a small matrix product of all 256 threads:
+//     Z  (m x 3 np)   Z[c][3 p + k] = sum over the slots of c on point p of  L_p^-1 (+-1/4 u_c)      (a repeated point collects its slots)
+//     M  = I + Z Z^T,   h = Z y   (y = L^-1 g_p stacked),   Wst (3 np x ncp) = the points' sum_i T_i^T at their cameras' columns,   G = Z Wst
+//     M  = L L^T by 32-pivot blocks (chol_factor_block: the dense solve's wave factorisation, which also leaves X = L^-1 of a block), the inverse of
+//          the whole factor assembled from the blocks' inverses (m <= 64: two blocks);   Y = L^-1 [G | h] = X [G | h]: a product, not a substitution
+//     Sacc -= Y^T Y,  bacc -= Y^T y_h   as before.
+// X goes to global memory in M's place: k_con_backsub_small needs w = M^-1 u = X^T (X u), two matrix-vector products instead of 2 m barrier pairs.
+constexpr int CON_SMALL_M = 2 * NB;
+struct ConSmallLayout {  // offsets in doubles into the dynamic LDS; ZL / GW / ML: odd row strides
+  int ZL, GW, ML, oL, oY, oZ, oW, oG, oM, oX, oT, oR, total;
+  __host__ __device__ ConSmallLayout(int m, int np, int ncp) {
+    ZL = (3 * np) | 1; GW = (ncp + 1) | 1; ML = m | 1;
+    oL = 2 * NB * (NB + 1); oY = oL + 6 * np; oZ = oY + 3 * np; oW = oZ + m * ZL; oG = oW + 3 * np * GW; oM = oG + m * GW; oX = oM + m * ML;
+    oT = oX + m * ML; oR = oT + NB * NB;  // a block of scratch for the panel / inverse products, and Y = X [G | h]
+    total = oR + m * GW;
+  }
+};
+template <int NC>
+__global__ void __launch_bounds__(BLOCK)
+k_con_schur_small(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vblk, const double* __restrict__ gvec,
+                  const double* __restrict__ sinv, const double* __restrict__ Trec, const double* __restrict__ tab, const int* __restrict__ pt_start,
+                  const int* __restrict__ obs_cam, const int* __restrict__ cam_off, const int* __restrict__ cam_np, int ncp,
+                  double* __restrict__ Sacc, double* __restrict__ bacc, int* __restrict__ flags) {
+  constexpr int REC = SchurRec<NC>::HREC;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int c0 = cp.comp_con[k], m = cp.comp_con[k + 1] - c0;
+  const int p0 = cp.comp_pt[k], np = cp.comp_pt[k + 1] - p0;
+  const ConSmallLayout lo(cp.max_m, cp.max_np, ncp);
+  double (*sh_D)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(sh);
+  double *pL = sh + lo.oL, *py = sh + lo.oY, *Z = sh + lo.oZ, *Wst = sh + lo.oW, *G = sh + lo.oG, *M = sh + lo.oM, *X = sh + lo.oX, *tmp = sh + lo.oT;
+  const int ZL = lo.ZL, GW = lo.GW, ML = lo.ML, gw = ncp + 1, nz = 3 * np;
+  const double* gp = gvec + lay.ncp_pad;
+  const double* dp = sinv + lay.ncp_pad;
+  // 1. per point: factor of V~_p, y_p = L^-1 g_p; zero Z, Wst
+  for (int lp = tid; lp < np; lp += BLOCK) {
+    const int p = cp.comp_pts[p0 + lp];
+    double L[6];
+    if (!con_point_factor(Vblk, dp, lay, p, lam, L)) flags[1] = 1;
+    const double g3[3] = {gp[p], gp[lay.Ppad + p], gp[2 * lay.Ppad + p]};
+    double y[3];
+    chol3_fwd(L, g3, y);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pL[lp * 6 + q] = L[q];
+    py[lp * 3] = y[0]; py[lp * 3 + 1] = y[1]; py[lp * 3 + 2] = y[2];
+  }
+  for (int e = tid; e < m * ZL; e += BLOCK) Z[e] = 0.0;
+  for (int e = tid; e < nz * GW; e += BLOCK) Wst[e] = 0.0;
+  __syncthreads();
+  // 2. z of every (constraint, slot) — kept in global memory for k_con_backsub_small — summed into Z; the points' T^T blocks into Wst
+  for (int e = tid; e < m * 8; e += BLOCK) {
+    const int c = c0 + e / 8, sl = e % 8;
+    const double q = (sl < 4) ? 0.25 : -0.25;
+    const double j3[3] = {q * cp.u[c * 3], q * cp.u[c * 3 + 1], q * cp.u[c * 3 + 2]};
+    const int lp = cp.lp[c * 8 + sl];
+    double z[3];
+    chol3_fwd(pL + lp * 6, j3, z);
+    cp.z[(long)(c * 8 + sl) * 3] = z[0]; cp.z[(long)(c * 8 + sl) * 3 + 1] = z[1]; cp.z[(long)(c * 8 + sl) * 3 + 2] = z[2];
+    double* zr = Z + (e / 8) * ZL + 3 * lp;
+    lds_add(&zr[0], z[0]); lds_add(&zr[1], z[1]); lds_add(&zr[2], z[2]);
+  }
+  // (point, observation) pairs: sixteen observation lanes per point at a time
+  for (int lp = tid / 16; lp < np; lp += BLOCK / 16) {
+    const int p = cp.comp_pts[p0 + lp];
+    for (int i = pt_start[p] + (tid % 16); i < pt_start[p + 1]; i += 16) {
+      const int cam = obs_cam[i];
+      double T[3 * NC];
+      expand_record<NC>(Trec + (long)i * REC, tab + (long)cam * CAMTAB_DOUBLES + 12, T);
+      const int off = cam_off[cam], npar = cam_np[cam];
+#pragma unroll
+      for (int r = 0; r < NC; ++r)  // (constant trip count: T stays in registers)
+        if (r < npar) {
+          lds_add(&Wst[(3 * lp + 0) * GW + off + r], T[3 * r]);
+          lds_add(&Wst[(3 * lp + 1) * GW + off + r], T[3 * r + 1]);
+          lds_add(&Wst[(3 * lp + 2) * GW + off + r], T[3 * r + 2]);
+        }
+    }
+  }
+  __syncthreads();
+  // 3. M = I + Z Z^T (both triangles), G = Z Wst, h = Z y in G's last column
+  for (int e = tid; e < m * m; e += BLOCK) {
+    const int a = e / m, b = e % m;
+    const double *za = Z + a * ZL, *zb = Z + b * ZL;
+    double acc = (a == b) ? 1.0 : 0.0;
+    for (int q = 0; q < nz; ++q) acc = fma(za[q], zb[q], acc);
+    M[a * ML + b] = acc;
+  }
+  for (int e = tid; e < m * gw; e += BLOCK) {
+    const int c = e / gw, col = e % gw;
+    const double* zc = Z + c * ZL;
+    double acc = 0.0;
+    if (col < ncp) for (int q = 0; q < nz; ++q) acc = fma(zc[q], Wst[q * GW + col], acc);
+    else for (int q = 0; q < nz; ++q) acc = fma(zc[q], py[q], acc);
+    G[c * GW + col] = acc;
+  }
+  for (int e = tid; e < m * m; e += BLOCK) X[(e / m) * ML + e % m] = 0.0;
+  __syncthreads();
+  // 4. Cholesky of M by 32-pivot blocks, X = L^-1 assembled block by block: X_bb = X_b;  X_bj = -X_b sum_{j <= t < b} L_bt X_tj  (j < b)
+  const int nblk = (m + NB - 1) / NB;
+  for (int b = 0; b < nblk; ++b) {
+    const int r0 = b * NB, rc = min(NB, m - r0);
+    // D_b = M_bb - sum_{t < b} L_bt L_bt^T (L_bt kept in M's lower blocks)
+    for (int e = tid; e < NB * NB; e += BLOCK) {
+      const int i = e / NB, j = e % NB;
+      double v = (i == j) ? 1.0 : 0.0;
+      if (i < rc && j < rc) {
+        v = M[(r0 + i) * ML + r0 + j];
+        for (int t = 0; t < r0; ++t) v = fma(-M[(r0 + i) * ML + t], M[(r0 + j) * ML + t], v);
+      }
+      sh_D[i][j] = v;
+    }
+    __syncthreads();
+    if (tid < WAVE) chol_factor_block(sh_D, rc, flags);
+    __syncthreads();
+    // L_bb and X_bb out of the factoring buffer (row NB + c of sh_D holds column c of X_b)
+    for (int e = tid; e < rc * rc; e += BLOCK) {
+      const int i = e / rc, j = e % rc;
+      M[(r0 + i) * ML + r0 + j] = (j <= i) ? sh_D[i][j] : 0.0;
+      X[(r0 + i) * ML + r0 + j] = sh_D[NB + j][i];
+    }
+    __syncthreads();
+    // panel below: L_ib = (M_ib - sum_{t < b} L_it L_bt^T) X_b^T for the rows i behind this block
+    const int rest = m - (r0 + rc);
+    for (int e = tid; e < rest * rc; e += BLOCK) {
+      const int i = r0 + rc + e / rc, j = e % rc;  // entry (i, r0 + j) of the panel, before the multiplication with X_b^T
+      double v = M[i * ML + r0 + j];
+      for (int t = 0; t < r0; ++t) v = fma(-M[i * ML + t], M[(r0 + j) * ML + t], v);
+      tmp[(e / rc) * rc + j] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < rest * rc; e += BLOCK) {
+      const int i = r0 + rc + e / rc, j = e % rc;
+      double v = 0.0;
+      for (int t = 0; t <= j; ++t) v = fma(tmp[(e / rc) * rc + t], X[(r0 + j) * ML + r0 + t], v);  // (U X_b^T)_ij = sum_t U_it X_jt, X lower triangular
+      M[i * ML + r0 + j] = v;
+    }
+    __syncthreads();
+    // X_bj for the column blocks j < b:  -X_b (sum_{t} L_bt X_tj), t over the rows before this block
+    for (int e = tid; e < rc * r0; e += BLOCK) {
+      const int i = e / r0, j = e % r0;
+      double v = 0.0;
+      for (int t = j; t < r0; ++t) v = fma(M[(r0 + i) * ML + t], X[t * ML + j], v);
+      tmp[i * r0 + j] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < rc * r0; e += BLOCK) {
+      const int i = e / r0, j = e % r0;
+      double v = 0.0;
+      for (int t = 0; t <= i; ++t) v = fma(X[(r0 + i) * ML + r0 + t], tmp[t * r0 + j], v);
+      X[(r0 + i) * ML + j] = -v;
+    }
+    __syncthreads();
+  }
+  // 5. X to global memory in M's place (k_con_backsub_small), Y = X [G | h], then the update
+  double* Mg = cp.M + cp.comp_m[k];
+  for (int e = tid; e < m * m; e += BLOCK) Mg[e] = X[(e / m) * ML + e % m];
+  double* Y = sh + lo.oR;  // m x GW
+  for (int e = tid; e < m * gw; e += BLOCK) {
+    const int c = e / gw, col = e % gw;
+    double acc = 0.0;
+    for (int t = 0; t <= c; ++t) acc = fma(X[c * ML + t], G[t * GW + col], acc);
+    Y[c * GW + col] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < ncp * gw; e += BLOCK) {
+    const int r = e / gw, c2 = e % gw;
+    if (c2 < r) continue;
+    double acc = 0.0;
+    for (int c = 0; c < m; ++c) acc = fma(Y[c * GW + r], Y[c * GW + c2], acc);
+    if (acc != 0.0) {
+      if (c2 < ncp) unsafeAtomicAdd(&Sacc[(long)r * ncp + c2], -acc);
+      else unsafeAtomicAdd(&bacc[r], -acc);
+    }
+  }
+}
+
+// point steps of a small component: as k_con_backsub, with w = M^-1 u = X^T (X u) from the inverse factor k_con_schur_small left in M's place
+__global__ void __launch_bounds__(BLOCK)
+k_con_backsub_small(ConPlan cp, VecLayout lay, double lam, const double* __restrict__ Vblk, const double* __restrict__ sinv, double* __restrict__ svec) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int c0 = cp.comp_con[k], m = cp.comp_con[k + 1] - c0;
+  const int p0 = cp.comp_pt[k], np = cp.comp_pt[k + 1] - p0;
+  double *pL = sh, *pq = pL + 6 * cp.max_np, *u = pq + 3 * cp.max_np, *t1 = u + cp.max_m;  // [np][6], [np][3], [m], [m]
+  const double* Xg = cp.M + cp.comp_m[k];
+  const double* dp = sinv + lay.ncp_pad;
+  double* sp = svec + lay.ncp_pad;
+  for (int lp = tid; lp < np; lp += BLOCK) {
+    const int p = cp.comp_pts[p0 + lp];
+    double L[6];
+    con_point_factor(Vblk, dp, lay, p, lam, L);
+    const double d0[3] = {-sp[p], -sp[lay.Ppad + p], -sp[2 * lay.Ppad + p]};
+    double yq[3];
+    chol3_lt_mul(L, d0, yq);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pL[lp * 6 + q] = L[q];
+    pq[lp * 3] = yq[0]; pq[lp * 3 + 1] = yq[1]; pq[lp * 3 + 2] = yq[2];
+  }
+  __syncthreads();
+  for (int c = tid; c < m; c += BLOCK) {
+    double acc = 0.0;
+    for (int sl = 0; sl < 8; ++sl) {
+      const double* z = cp.z + (long)((c0 + c) * 8 + sl) * 3;
+      const double* y = pq + (long)cp.lp[(c0 + c) * 8 + sl] * 3;
+      acc += z[0] * y[0] + z[1] * y[1] + z[2] * y[2];
+    }
+    u[c] = acc;
+  }
+  __syncthreads();
+  for (int c = tid; c < m; c += BLOCK) {  // t1 = X u (X lower triangular)
+    double acc = 0.0;
+    for (int t = 0; t <= c; ++t) acc = fma(Xg[(long)c * m + t], u[t], acc);
+    t1[c] = acc;
+  }
+  __syncthreads();
+  for (int c = tid; c < m; c += BLOCK) {  // w = X^T t1
+    double acc = 0.0;
+    for (int t = c; t < m; ++t) acc = fma(Xg[(long)t * m + c], t1[t], acc);
+    u[c] = acc;
+  }
+  for (int lp = tid; lp < np; lp += BLOCK) { pq[lp * 3] = 0.0; pq[lp * 3 + 1] = 0.0; pq[lp * 3 + 2] = 0.0; }
+  __syncthreads();
+  for (int e = tid; e < m * 8; e += BLOCK) {
+    const int c = e / 8, sl = e % 8;
+    const double* z = cp.z + (long)((c0 + c) * 8 + sl) * 3;
+    const double w = u[c];
+    double* a = pq + (long)cp.lp[(c0 + c) * 8 + sl] * 3;
+    lds_add(&a[0], z[0] * w); lds_add(&a[1], z[1] * w); lds_add(&a[2], z[2] * w);
+  }
+  __syncthreads();
+  for (int lp = tid; lp < np; lp += BLOCK) {
+    const int p = cp.comp_pts[p0 + lp];
+    double t[3];
+    chol3_bwd(pL + lp * 6, pq + lp * 3, t);
+    sp[p] += t[0]; sp[lay.Ppad + p] += t[1]; sp[2 * lay.Ppad + p] += t[2];
   }
 }
 

@@ -1930,9 +1930,14 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
       if (p->n_heavy)  // per-camera sums of the heavy points, one workgroup each (the pair plan skips them)
         hipLaunchKernelGGL((k_heavy_schur<NC>), dim3(p->n_heavy), dim3(BLOCK), (size_t)ncp * 3 * sizeof(double) + (size_t)ncp * sizeof(int), p->stream,
                            p->heavy_pts, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Trec, p->tab, p->heavy_W, p->Sacc);
-      if (p->con.n_con)  // Woodbury correction of S and b for the constraint rows, one workgroup per component
-        hipLaunchKernelGGL((k_con_schur<NC>), dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->g, p->sinv,
-                           p->Trec, p->tab, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
+      if (p->con.n_con) {  // Woodbury correction of S and b for the constraint rows, one workgroup per component
+        if (p->con.small)
+          hipLaunchKernelGGL((k_con_schur_small<NC>), dim3(p->con.n_comp), dim3(BLOCK), (size_t)p->con.small_lds, p->stream, p->con, p->lay, lam, p->V, p->g,
+                             p->sinv, p->Trec, p->tab, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
+        else
+          hipLaunchKernelGGL((k_con_schur<NC>), dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->g, p->sinv,
+                             p->Trec, p->tab, p->pt_start, p->obs_cam, p->cam_off, p->cam_np, ncp, p->Sacc, p->Sacc + (size_t)ncp * ncp, p->flags);
+      }
     }
     if (p->sharded()) {  // reduced camera system: the one real exchange step — upper triangle and b, packed
       const size_t ntri = (size_t)ncp * (ncp + 1) / 2 + ncp;
@@ -1991,8 +1996,13 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     if (p->n_heavy)
       hipLaunchKernelGGL(k_heavy_finish, dim3((p->n_heavy + 63) / 64), dim3(64), 0, p->stream, p->heavy_pts, p->heavy_frag, p->n_heavy, p->lay, lam,
                          p->V, p->g, p->sinv, p->s);
-    if (p->con.n_con)
-      hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
+    if (p->con.n_con) {
+      if (p->con.small)
+        hipLaunchKernelGGL(k_con_backsub_small, dim3(p->con.n_comp), dim3(BLOCK), (size_t)(9 * p->con.max_np + 2 * p->con.max_m) * sizeof(double), p->stream,
+                           p->con, p->lay, lam, p->V, p->sinv, p->s);
+      else
+        hipLaunchKernelGGL(k_con_backsub, dim3(p->con.n_comp), dim3(BLOCK), 0, p->stream, p->con, p->lay, lam, p->V, p->sinv, p->s);
+    }
   }
   if (fused_trial(p, compact)) {
     // step scalars (the point block's share came out of k_backsub), subspace step, camera entries and camera table of the trial point: one workgroup
@@ -2226,6 +2236,19 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   TRYC(dev_alloc(p, &cp.cdiag, (size_t)3 * p->lay.Ppad)); TRYC(dev_alloc(p, &cp.w, (size_t)n_con));
   if (max_pts > CON_LDS_POINTS) TRYC(dev_alloc(p, &cp.big, comp_pts.size() * 9));
 #undef TRYC
+  {
+    // small components (one board in one frame: the reference's own sessions): dense blocks in LDS, k_con_schur_small / k_con_backsub_small
+    cp.max_m = (int)max_m; cp.max_np = max_pts;
+    const ConSmallLayout lo((int)max_m, max_pts, p->ncp);
+    cp.small_lds = lo.total * (int)sizeof(double);
+    const char* e = std::getenv("CBA_CON_SMALL");
+    cp.small = (max_m <= CON_SMALL_M && !p->n_heavy && cp.small_lds <= 120 * 1024 && !(e && e[0] == '0')) ? 1 : 0;
+    if (cp.small) {
+      int rcl = (p->nct == 9) ? allow_lds(k_con_schur_small<9>, (size_t)cp.small_lds) : allow_lds(k_con_schur_small<6>, (size_t)cp.small_lds);
+      if (!rcl) rcl = allow_lds(k_con_backsub_small, (size_t)(9 * max_pts + 2 * max_m) * sizeof(double));
+      if (rcl) return rcl;
+    }
+  }
   HIPCHK(hipMemset(cp.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double)));
   p->con = cp;
   p->con_grid = std::max(1, std::min((n_con + BLOCK - 1) / BLOCK, 1024));
