@@ -1415,14 +1415,14 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
 
   const int nblk = tp.g * tp.g;
-  const int rep = (SPLIT == 1) ? tp.rep : 1;
+  const int rep = tp.rep;  // (round 6: nine-parameter cameras too — a 4-camera rig with free intrinsics ran its 300 pairs per block on 16 code threads: 53 us)
   const int tid = (int)threadIdx.x;
   const int wg = logical_workgroup((int)blockIdx.x, (int)gridDim.x);  // csrc/wg_binding.h: interleaved over the dispatch order
   double2* sh_p = reinterpret_cast<double2*>(sh);  // two chunk buffers, in 16-byte pieces
   const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
   const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
   const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave of the set
-  const int half = (rep > 1) ? 0 : tid / BLOCK;
+  const int half = tid / BLOCK;  // which SPLIT-th of the block's rows (0 when SPLIT == 1)
   const int r0 = half * RH;
   double acc[RH][NC];
 #pragma unroll

@@ -186,6 +186,9 @@ struct cba_problem {
   std::vector<size_t> alloc_bytes;
   size_t mail_doubles = 0;     // capacity of the mapped host mailbox (h_scal)
   char* arena_cur = nullptr; size_t arena_left = 0, arena_next = (size_t)4 << 20;
+  // small uploads of cba_create / cba_set_constraints go through a pooled pinned buffer and the handle's stream (one wait at the end) instead of ~40
+  // synchronous hipMemcpy calls of 10-20 us each: most of the millisecond a handle for the reference's own 4-camera session took to build
+  char* up_stage = nullptr; size_t up_cap = 0, up_used = 0;
   // sharded solve (points partitioned over ranks, cameras replicated): RCCL over xGMI
   std::atomic<ncclComm_t> comm{nullptr};
   std::atomic<bool> comm_aborted{false};  // cba_comm_abort was called (from another thread): every collective of this handle fails from now on
@@ -206,7 +209,9 @@ struct DevicePool {
   std::vector<hipStream_t> streams;
   std::vector<std::pair<double*, size_t>> mail;  // (mapped host pointer, doubles)
   std::vector<std::pair<double*, size_t>> staging;  // (pinned host pointer, doubles): h_vec
+  std::vector<char*> upstage;                      // pinned buffers of kUpStage bytes for small uploads
 };
+constexpr size_t kUpStage = (size_t)256 << 10, kUpStageMax = (size_t)64 << 10;
 static std::mutex g_pool_mu;
 static std::map<int, DevicePool> g_pool;
 
@@ -248,8 +253,35 @@ static int dev_upload(cba_problem* p, T** out, const V& h) {  // V: any contiguo
   static_assert(std::is_same<typename std::remove_cv<typename std::remove_pointer<decltype(h.data())>::type>::type, T>::value, "element type");
   int rc = dev_alloc(p, out, h.size());
   if (rc) return rc;
-  if (!h.empty()) HIPCHK(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  const size_t bytes = h.size() * sizeof(T);
+  if (bytes && p->up_stage && p->stream && bytes <= kUpStageMax && p->up_used + bytes <= p->up_cap) {
+    std::memcpy(p->up_stage + p->up_used, h.data(), bytes);
+    HIPCHK(hipMemcpyAsync(*out, p->up_stage + p->up_used, bytes, hipMemcpyHostToDevice, p->stream));
+    p->up_used += (bytes + 63) & ~(size_t)63;
+  } else if (bytes) {
+    HIPCHK(hipMemcpy(*out, h.data(), bytes, hipMemcpyHostToDevice));
+  }
   return CBA_OK;
+}
+// a pinned buffer for the small uploads of one set-up call (cba_create, cba_set_constraints); given back — after the stream has been waited for — by
+// upload_stage_release
+static void upload_stage_acquire(cba_problem* p) {
+  if (p->up_stage) return;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    DevicePool& pool = g_pool[p->device];
+    if (!pool.upstage.empty()) { p->up_stage = pool.upstage.back(); pool.upstage.pop_back(); }
+  }
+  if (!p->up_stage && hipHostMalloc((void**)&p->up_stage, kUpStage, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p->up_stage = nullptr; }
+  p->up_cap = p->up_stage ? kUpStage : 0;
+  p->up_used = 0;
+}
+static void upload_stage_release(cba_problem* p) {  // the caller has synchronised the stream (or the device)
+  if (!p->up_stage) return;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  DevicePool& pool = g_pool[p->device];
+  if (pool.upstage.size() < kPoolKeep) pool.upstage.push_back(p->up_stage); else (void)hipHostFree(p->up_stage);
+  p->up_stage = nullptr; p->up_cap = p->up_used = 0;
 }
 
 // h_vec is pinned: a hipMemcpyAsync out of it returns while the copy engine still reads it
@@ -545,6 +577,7 @@ int64_t cba_trim(void) {
     for (hipStream_t st : pool.streams) (void)hipStreamDestroy(st);
     for (auto& m : pool.mail) { (void)hipHostFree(m.first); bytes += (int64_t)(m.second * sizeof(double)); }
     for (auto& m : pool.staging) { (void)hipHostFree(m.first); bytes += (int64_t)(m.second * sizeof(double)); }
+    for (char* u : pool.upstage) { (void)hipHostFree(u); bytes += (int64_t)kUpStage; }
   }
   if (have_cur) (void)hipSetDevice(cur);
   return bytes;
@@ -610,6 +643,36 @@ static void dump_stamps(cba_problem* p) {
   if (first < rows.size())
     fprintf(stderr, "%zu kernels, %.1f us inside kernels, %.1f us between them, %.1f us from the first entry to the last exit\n", rows.size() - first, busy, idle,
             (rows.back().t1 - rows[first].t0) * 0.01);
+  if (!p->h_tile_wg_begin.empty() && p->tile_grid <= STAMP_BLOCKS) {  // the pair kernel's workgroups by tile and by XCD
+    const std::vector<int>& wgb = p->h_tile_wg_begin;
+    const int nT = (int)wgb.size() - 1;
+    std::vector<double> life(p->tile_grid, 0.0);
+    for (int b = 0; b < p->tile_grid; ++b) {
+      const long long* q = &h[((size_t)ST_PAIRS * STAMP_BLOCKS + b) * STAMP_ROW];
+      long long e = 0;
+      for (int w = 0; w < STAMP_WAVES; ++w) e = std::max(e, q[1 + w]);
+      life[logical_workgroup(b, p->tile_grid)] = q[0] ? (e - q[0]) * 0.01 : 0.0;
+    }
+    fprintf(stderr, "k_schur_reg3 workgroup lifetimes by tile (us): tile: workgroups min / mean / max\n");
+    for (int t = 0; t < nT; ++t) {
+      double mn = 1e300, mx = 0.0, sm = 0.0;
+      for (int b = wgb[t]; b < wgb[t + 1]; ++b) { mn = std::min(mn, life[b]); mx = std::max(mx, life[b]); sm += life[b]; }
+      fprintf(stderr, "  %d: %d  %.1f / %.1f / %.1f\n", t, wgb[t + 1] - wgb[t], mn, sm / std::max(1, wgb[t + 1] - wgb[t]), mx);
+    }
+    fprintf(stderr, "... by XCD (logical id mod 8): min / mean / max\n");
+    for (int x = 0; x < 8; ++x) {
+      double mn = 1e300, mx = 0.0, sm = 0.0; int n = 0;
+      for (int b = x; b < p->tile_grid; b += 8) { mn = std::min(mn, life[b]); mx = std::max(mx, life[b]); sm += life[b]; ++n; }
+      fprintf(stderr, "  XCD %d: %.1f / %.1f / %.1f\n", x, mn, sm / std::max(1, n), mx);
+    }
+    fprintf(stderr, "... by dispatch order (hardware workgroup id, eighths of the grid): mean\n ");
+    for (int o = 0; o < 8; ++o) {
+      double sm = 0.0; int n = 0;
+      for (int b = o * p->tile_grid / 8; b < (o + 1) * p->tile_grid / 8; ++b) { sm += life[logical_workgroup(b, p->tile_grid)]; ++n; }
+      fprintf(stderr, " %.1f", sm / std::max(1, n));
+    }
+    fprintf(stderr, "\n");
+  }
   (void)hipFree(p->stamps);
   p->stamps = nullptr;
 }
@@ -620,6 +683,7 @@ void cba_destroy(cba_problem* p) {
   drop_plan_task(p);  // a plan thread still dealing: cancelled and joined before anything it could look at goes away
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  upload_stage_release(p);  // (a set-up call that bailed out)
 #ifdef CBA_PROFILING
   if (p->stamps) dump_stamps(p);
 #endif
@@ -739,7 +803,7 @@ static Reg2Params reg2_params(const cba_problem* p) {
   const int g = p->gsz;
   prm.C = p->C; prm.P = p->P; prm.G = p->G; prm.g = g;
   constexpr int CT = KCfg::CODE_THREADS;
-  prm.rep = (NC == 6 && g * g <= CT / 2) ? CT / (g * g) : 1;  // small groups: several threads per block
+  prm.rep = (g * g <= CT / 2) ? CT / (g * g) : 1;  // small groups: several threads per block
   prm.n_waves = KCfg::CODE_WAVES;
   prm.pair_cap = KCfg::PAIR_CAP;
   prm.chunk_cap = KCfg::SCHUNK;
@@ -784,8 +848,15 @@ static int prepare_install(const cba_problem* p, Reg2Plan& plan, const Reg2Param
   // cost of a chunk: gather + barrier (in units of one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its
   // slowest wave
   const double cost_a = 2.0;
-  const std::vector<double> tile_cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, KCfg::CODE_WAVES, KCfg::REG_BLOCK / KCfg::SPLIT / WAVE, cost_a);
-  const WgBinding bind = cba::bind_workgroups(plan.tile_chunk_begin, nT, max_blocks, true, &tile_cost);
+  std::vector<float> chunk_cost;
+  const std::vector<double> tile_cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, KCfg::CODE_WAVES, KCfg::REG_BLOCK / KCfg::SPLIT / WAVE, cost_a, &chunk_cost);
+  // CBA_BIND=fine: workgroup counts per tile to ONE workgroup and cost-proportional XCD slices (wg_binding.h).  Measured in round 6 and not the default:
+  // it narrows the PLANNED cost per workgroup from 193 / 226 / 247 to 218 / 226 / 233 (min / mean / max), but the pair kernel got no faster (stamps 134
+  // against 128 us, HIP-event timer 140 against 132): the slices of different tiles no longer cover the same point ranges on an XCD, and what spreads
+  // the lifetimes is not the plan — inside EVERY tile they run from ~100 to ~125 us, and the workgroups dispatched second to a CU take 120 us where the
+  // first take 104 (profiles/r06_pair_lifetimes.txt)
+  const char* bind_env = std::getenv("CBA_BIND");
+  const WgBinding bind = cba::bind_workgroups(plan.tile_chunk_begin, nT, max_blocks, true, &tile_cost, &chunk_cost, bind_env && bind_env[0] == 'f');
   out.tile_grid = bind.grid;
   lap("workgroup binding");
   std::vector<int> gcam(G + 1), gpar(G + 1), ta(nT), tb(nT);
@@ -1082,7 +1153,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const bool plan_timing = plan_timing_on();
   auto t_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = t_now();
-  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "cba_create: %-28s %.3f s\n", what, t - t_mark); t_mark = t; } };
+  auto lap = [&](const char* what) { if (plan_timing) { const double t = t_now(); fprintf(stderr, "cba_create: %-28s %.6f s\n", what, t - t_mark); t_mark = t; } };
   // plan: sort by point, chunk table
   HostVec<int64_t> order(p->N), pstart((size_t)p->P + 1), cstart((size_t)p->N + 2);  // (written by cba_host_plan: order and pstart in full, cstart up to the chunk count)
   // (cba_host_plan checks the point and camera indices of every observation)
@@ -1186,12 +1257,22 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
 
 #define TRY(e) do { rc = (e); if (rc) return bail(rc); } while (0)
   lap("reorder on host");
+  upload_stage_acquire(p);
   TRY(dev_upload(p, &p->obs_cam, hcam)); TRY(dev_upload(p, &p->obs_pt, hpt));
   TRY(dev_upload(p, &p->order, hord)); TRY(dev_upload(p, &p->pt_start, hps)); TRY(dev_upload(p, &p->chunk_start, hcs));
   {  // the caller's (u, v) pairs as they are, sorted on the device (the raw copy is scratch: v2's memory is not big enough, it stays in the arena)
     double* uv_raw = nullptr;
     TRY(dev_alloc(p, &uv_raw, (size_t)2 * p->N)); TRY(dev_alloc(p, &p->obs_u, (size_t)p->N)); TRY(dev_alloc(p, &p->obs_v, (size_t)p->N));
-    HIPBAIL(hipMemcpy(uv_raw, d->obs_uv, (size_t)2 * p->N * sizeof(double), hipMemcpyHostToDevice));
+    {
+      const size_t bytes = (size_t)2 * p->N * sizeof(double);
+      if (p->up_stage && bytes <= kUpStageMax && p->up_used + bytes <= p->up_cap) {
+        std::memcpy(p->up_stage + p->up_used, d->obs_uv, bytes);
+        HIPBAIL(hipMemcpyAsync(uv_raw, p->up_stage + p->up_used, bytes, hipMemcpyHostToDevice, p->stream));
+        p->up_used += (bytes + 63) & ~(size_t)63;
+      } else {
+        HIPBAIL(hipMemcpy(uv_raw, d->obs_uv, bytes, hipMemcpyHostToDevice));
+      }
+    }
     hipLaunchKernelGGL(k_gather_uv, dim3((int)std::min<long>((p->N + 255) / 256, 2048)), dim3(256), 0, p->stream, (const double*)uv_raw, (const int*)p->order, p->N, p->obs_u, p->obs_v);
   }
   if (opt && opt->deterministic) {
@@ -1325,14 +1406,14 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   const long tot = p->lay.total();
   for (double** v : {&p->x0, &p->x, &p->x_new, &p->g, &p->s, &p->sinv, &p->v1, &p->v2, &p->sinv2}) {
     TRY(dev_alloc(p, v, (size_t)tot));
-    if (hipMemset(*v, 0, tot * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
+    if (hipMemsetAsync(*v, 0, tot * sizeof(double), p->stream) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
   for (double** v : {&p->sinv_state_c, &p->cam_diag, &p->cam_over1, &p->cam_over2, &p->lb_dev, &p->ub_dev, &p->sinv_state_c2, &p->cam_diag2}) {
     TRY(dev_alloc(p, v, (size_t)p->lay.ncp_pad));
-    if (hipMemset(*v, 0, (size_t)p->lay.ncp_pad * sizeof(double)) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
+    if (hipMemsetAsync(*v, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream) != hipSuccess) return bail(fail(CBA_ERR_HIP, "hipMemset failed"));
   }
   TRY(dev_alloc(p, &p->V, (size_t)6 * p->lay.Ppad));
-  HIPBAIL(hipMemset(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double)));
+  HIPBAIL(hipMemsetAsync(p->V, 0, (size_t)6 * p->lay.Ppad * sizeof(double), p->stream));
   const int ustride = (nct == 9) ? UPack<9>::STRIDE : UPack<6>::STRIDE;
   TRY(dev_alloc(p, &p->Upacked, (size_t)p->C * ustride + 128));  // + room for the scalars that ride with the blocks (exchange_at)
   lap("allocate vectors");
@@ -1376,15 +1457,15 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   TRY(dev_alloc(p, &p->Lbuf, (size_t)(ncp + 1) * p->ldw));
   TRY(dev_alloc(p, &p->Xinv, (size_t)((ncp + NB - 1) / NB + 1) * NB * NB));
   TRY(dev_alloc(p, &p->Tinv, (size_t)ncp * p->ldw));
-  HIPBAIL(hipMemset(p->Tinv, 0, (size_t)ncp * p->ldw * sizeof(double)));
+  HIPBAIL(hipMemsetAsync(p->Tinv, 0, (size_t)ncp * p->ldw * sizeof(double), p->stream));
   TRY(dev_alloc(p, &p->rhs, (size_t)p->lay.ncp_pad));
   TRY(dev_alloc(p, &p->scal, 64)); TRY(dev_alloc(p, &p->flags, 4)); TRY(dev_alloc(p, &p->xbuf, 128));
   TRY(dev_alloc(p, &p->fz, 8)); TRY(dev_alloc(p, &p->V2, (size_t)6 * p->lay.Ppad)); TRY(dev_alloc(p, &p->g2, (size_t)tot));
   TRY(dev_alloc(p, &p->U2, (size_t)p->C * ustride + 128));
-  HIPBAIL(hipMemset(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double))); HIPBAIL(hipMemset(p->g2, 0, (size_t)tot * sizeof(double)));
-  HIPBAIL(hipMemset(p->scal, 0, 64 * sizeof(double)));
-  HIPBAIL(hipMemset(p->flags, 0, 4 * sizeof(int)));
-  HIPBAIL(hipMemset(p->Sacc, 0, ((size_t)ncp * ncp + (size_t)B_SLICES * p->lay.ncp_pad) * sizeof(double)));
+  HIPBAIL(hipMemsetAsync(p->V2, 0, (size_t)6 * p->lay.Ppad * sizeof(double), p->stream)); HIPBAIL(hipMemsetAsync(p->g2, 0, (size_t)tot * sizeof(double), p->stream));
+  HIPBAIL(hipMemsetAsync(p->scal, 0, 64 * sizeof(double), p->stream));
+  HIPBAIL(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
+  HIPBAIL(hipMemsetAsync(p->Sacc, 0, ((size_t)ncp * ncp + (size_t)B_SLICES * p->lay.ncp_pad) * sizeof(double), p->stream));
 #undef TRY
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -1403,6 +1484,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   }
   lap("solver buffers");
   HIPBAIL(hipDeviceSynchronize());
+  upload_stage_release(p);
   lap("device synchronize");
   if (p->plan_task) {
     if (p->plan_task->two_stage) {  // the thread goes on dealing: it reads these two arrays
@@ -2220,6 +2302,7 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
                 "camera coupling (%d rows x %d camera parameters); the limits are 2 GB and 4 GB - use fewer rows per object and frame (DESIGN.md 2.2)",
                 comp_m[K] * 8e-9, comp_m[K], (double)n_con * (p->ncp + 1) * 8e-9, n_con, p->ncp);
   int rc;
+  upload_stage_acquire(p);
   int *dpt = nullptr, *dlp = nullptr, *dorder = nullptr, *dcc = nullptr, *dcp = nullptr, *dcps = nullptr;
   long* dcm = nullptr;
   double *ddist = nullptr, *dw = nullptr;
@@ -2249,7 +2332,9 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
       if (rcl) return rcl;
     }
   }
-  HIPCHK(hipMemset(cp.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double)));
+  HIPCHK(hipMemsetAsync(cp.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double), p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));  // (the staged uploads: the caller's arrays and the pinned buffer are free again)
+  upload_stage_release(p);
   p->con = cp;
   p->con_grid = std::max(1, std::min((n_con + BLOCK - 1) / BLOCK, 1024));
   return CBA_OK;

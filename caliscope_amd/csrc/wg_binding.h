@@ -35,8 +35,10 @@ struct WgBinding {
   bool xcd_mode = false;
 };
 
-// TCB: first chunk of every tile ([nT + 1]); tile_cost: optional, default the chunk counts; reg: the register kernels (XCD-aware binding).
-inline WgBinding bind_workgroups(const std::vector<int>& TCB, int nT, int max_blocks, bool reg, const std::vector<double>* tile_cost = nullptr) {
+// TCB: first chunk of every tile ([nT + 1]); tile_cost: optional, default the chunk counts; reg: the register kernels (XCD-aware binding);
+// chunk_cost: optional, per chunk (what tile_cost sums): the XCD slices of a tile are then cut in proportion to COST, not to chunk counts.
+inline WgBinding bind_workgroups(const std::vector<int>& TCB, int nT, int max_blocks, bool reg, const std::vector<double>* tile_cost = nullptr,
+                                 const std::vector<float>* chunk_cost = nullptr, bool fine = false) {
   WgBinding out;
   const int n_tile_chunks = TCB[nT] - TCB[0];
   std::vector<long> nch(nT);
@@ -73,28 +75,63 @@ inline WgBinding bind_workgroups(const std::vector<int>& TCB, int nT, int max_bl
     return nwg;
   };
   const int budget = std::max(nT, std::min(max_blocks, std::max(1, n_tile_chunks)));
-  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD gets the same share of every
-  // tile and walks one eighth of the point range, so the G tiles that gather a given T record do so through the
-  // same L2 at about the same time; HBM then serves each record once instead of G times.
+  // XCD-aware binding (register kernel): workgroup b runs on XCD b mod 8.  Every XCD walks its own slice of every tile's chunk range (the point
+  // range), so the G tiles that gather a given T record do so through the same L2 at about the same time; HBM then serves each record once
+  // instead of G times.
+  // Round 6, `fine` (an option, not the default — see prepare_install in cba_lib.hip for what it measured): a tile's workgroup count is not a multiple of eight.  With 512 workgroups over 10 tiles that rounding left the tiles 5-8 units of
+  // eight each — up to +-8 % off their share — and the planned cost per workgroup spread 193 / 226 / 247 (min / mean / max), which is what the device
+  // stamps show (lifetimes 80 / 107 / 126 us: the kernel lasts as long as its slowest workgroup).  Now the counts follow the cost to one workgroup, a
+  // tile's workgroups keep contiguous ids (k_reg_reduce relies on it), workgroup id b sits on XCD b mod 8 — so a tile holds w_x = 6 or 7 workgroups
+  // on XCD x — and the tile's chunk range is cut into eight slices in proportion to w_x (by cost when the caller gives chunk costs): planned spread
+  // 218 / 226 / 233.
   constexpr int XCDS = 8;
   const bool xcd_mode = reg && budget % XCDS == 0 && nT <= budget / XCDS && n_tile_chunks >= 4 * budget;
-  std::vector<int> nwg = allocate(xcd_mode ? budget / XCDS : budget), wgb(nT + 1, 0);
-  if (xcd_mode) for (int& w : nwg) w *= XCDS;
+  std::vector<int> nwg = allocate((xcd_mode && !fine) ? budget / XCDS : budget), wgb(nT + 1, 0);
+  if (xcd_mode && !fine) for (int& w : nwg) w *= XCDS;  // (rounds 2-5: multiples of eight, equal eighths of the chunk range)
   for (int t = 0; t < nT; ++t) wgb[t + 1] = wgb[t] + nwg[t];
   const int grid = wgb[nT];
   std::vector<int> wt(grid), wfirst(grid), wend(grid), wstride(grid);
-  for (int t = 0; t < nT; ++t)
-    for (int r = 0; r < nwg[t]; ++r) {
-      const int b = wgb[t] + r;
-      wt[b] = t;
-      if (xcd_mode) {
-        const int x = r % XCDS, s = r / XCDS;
-        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
-        wfirst[b] = TCB[t] + (int)lo + s; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
-      } else {
-        wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t];
-      }
+  for (int t = 0; t < nT; ++t) {
+    if (!xcd_mode) {
+      for (int r = 0; r < nwg[t]; ++r) { const int b = wgb[t] + r; wt[b] = t; wfirst[b] = TCB[t] + r; wend[b] = TCB[t + 1]; wstride[b] = nwg[t]; }
+      continue;
     }
+    if (!fine) {
+      for (int r = 0; r < nwg[t]; ++r) {
+        const int b = wgb[t] + r, x = r % XCDS, sidx = r / XCDS;
+        const long lo = nch[t] * x / XCDS, hi = nch[t] * (x + 1) / XCDS;
+        wt[b] = t; wfirst[b] = TCB[t] + (int)lo + sidx; wend[b] = TCB[t] + (int)hi; wstride[b] = nwg[t] / XCDS;
+      }
+      continue;
+    }
+    int w[XCDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < nwg[t]; ++r) w[(wgb[t] + r) % XCDS]++;
+    int last_x = 0;
+    for (int x = 0; x < XCDS; ++x) if (w[x] > 0) last_x = x;
+    // slice boundaries: cumulative cost (or count) nearest to the XCD's cumulative share of the tile's workgroups
+    const long n = nch[t];
+    std::vector<double> pre((size_t)n + 1, 0.0);
+    for (long c = 0; c < n; ++c) pre[(size_t)c + 1] = pre[(size_t)c] + (chunk_cost ? (double)(*chunk_cost)[(size_t)TCB[t] + c] : 1.0);
+    long lo_x[XCDS], hi_x[XCDS];
+    long lo = 0;
+    int wcum = 0;
+    for (int x = 0; x < XCDS; ++x) {
+      wcum += w[x];
+      long hi = lo;
+      if (w[x] > 0) {
+        const double goal = pre[(size_t)n] * wcum / nwg[t];
+        while (hi < n && (pre[(size_t)hi + 1] <= goal || goal - pre[(size_t)hi] > pre[(size_t)hi + 1] - goal)) ++hi;
+        if (x == last_x) hi = n;
+      }
+      lo_x[x] = lo; hi_x[x] = hi;
+      lo = hi;
+    }
+    for (int r = 0; r < nwg[t]; ++r) {
+      const int b = wgb[t] + r, x = b % XCDS, sidx = r / XCDS;  // (the s-th workgroup of this tile on XCD x: ids on one XCD are eight apart)
+      wt[b] = t;
+      wfirst[b] = TCB[t] + (int)lo_x[x] + sidx; wend[b] = TCB[t] + (int)hi_x[x]; wstride[b] = w[x];
+    }
+  }
   out.wgb = std::move(wgb); out.wt = std::move(wt); out.wfirst = std::move(wfirst); out.wend = std::move(wend); out.wstride = std::move(wstride);
   out.grid = grid; out.xcd_mode = xcd_mode;
   return out;
@@ -104,8 +141,9 @@ inline WgBinding bind_workgroups(const std::vector<int>& TCB, int nT, int max_bl
 // one pair iteration; phase clocks on cfg4: ~2200 against ~830 clocks) + the pair iterations of its slowest PHYSICAL wave (a physical wave
 // runs `code_waves / phys_waves` of the plan's waves one after the other: their iterations add up).
 inline std::vector<double> tile_costs(const std::vector<unsigned>& nit, const std::vector<int>& tile_chunk_begin, int nT, int code_waves, int phys_waves,
-                                      double cost_a) {
+                                      double cost_a, std::vector<float>* chunk_cost_out = nullptr) {
   std::vector<double> cost(nT, 0.0);
+  if (chunk_cost_out) chunk_cost_out->assign((size_t)tile_chunk_begin[nT], 0.0f);
   const int nword = code_waves / 4, vb = std::max(1, code_waves / std::max(phys_waves, 1));
   const int pw = code_waves / vb;
   for (int t = 0; t < nT; ++t)
@@ -117,6 +155,7 @@ inline std::vector<double> tile_costs(const std::vector<unsigned>& nit, const st
         mx = std::max(mx, its);
       }
       cost[t] += cost_a + mx;
+      if (chunk_cost_out) (*chunk_cost_out)[(size_t)ch] = (float)(cost_a + mx);
     }
   return cost;
 }

@@ -108,8 +108,9 @@ int bind_replay(int C, int P, int G, int g, int rep, int chunk_cap, int slots_pe
   const int rc = cba::build_reg2_plan(prm, vcam, vps, plan);
   if (rc) return rc;
   const int nT = G * (G + 1) / 2;
-  const std::vector<double> cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, n_waves, phys_waves, cost_a);
-  const cba::WgBinding b = cba::bind_workgroups(plan.tile_chunk_begin, nT, max_blocks, reg != 0, cost_a >= 0.0 ? &cost : nullptr);
+  std::vector<float> chunk_cost;
+  const std::vector<double> cost = cba::tile_costs(plan.nit, plan.tile_chunk_begin, nT, n_waves, phys_waves, cost_a, &chunk_cost);
+  const cba::WgBinding b = cba::bind_workgroups(plan.tile_chunk_begin, nT, max_blocks, reg != 0, cost_a >= 0.0 ? &cost : nullptr, cost_a >= 0.0 ? &chunk_cost : nullptr, std::getenv("PLAN_BIND_FINE") != nullptr);
   for (int i = 0; i < b.grid; ++i) { wt[i] = b.wt[i]; wfirst[i] = b.wfirst[i]; wend[i] = b.wend[i]; wstride[i] = b.wstride[i]; }
   for (int t = 0; t <= nT; ++t) tcb_out[t] = plan.tile_chunk_begin[t];
   for (int t = 0; t < nT; ++t) cost_out[t] = cost[t];

@@ -207,12 +207,14 @@ def test_lane_utilisation_at_the_bench_shape(harness):
 
 @pytest.mark.parametrize("shape", [dict(n_cams=64, n_points=20000, k=10, max_blocks=512), dict(n_cams=64, n_points=20000, k=10, max_blocks=512, cost_a=-1.0),
                                    dict(n_cams=40, n_points=3000, k=8, max_blocks=512), dict(n_cams=128, n_points=6000, k=10, max_blocks=256, nc=9),
-                                   dict(n_cams=8, n_points=400, k=6, max_blocks=512)])
-def test_workgroup_binding_covers_every_chunk_once(harness, shape):
+                                   dict(n_cams=8, n_points=400, k=6, max_blocks=512), dict(n_cams=64, n_points=20000, k=10, max_blocks=512, fine=True)])
+def test_workgroup_binding_covers_every_chunk_once(harness, shape, monkeypatch):
     """csrc/wg_binding.h: the persistent workgroups of the pair kernel walk (first, first + stride, ... < end); every chunk of every tile must be
     walked by exactly one workgroup of that tile, and the workgroups are handed out in proportion to the tiles' estimated cost."""
     cfg = dict(shape)
     nc, layout, cost_a, max_blocks = cfg.pop("nc", 6), cfg.pop("layout", "reg3"), cfg.pop("cost_a", 2.0), cfg.pop("max_blocks")
+    if cfg.pop("fine", False):  # CBA_BIND=fine: counts per tile to one workgroup, cost-proportional XCD slices (an option of the library)
+        monkeypatch.setenv("PLAN_BIND_FINE", "1")
     rng = np.random.default_rng(12)
     hcam, hps = _visibility(rng, cfg["n_cams"], cfg["n_points"], cfg["k"], cfg["k"])
     gmax = 16
@@ -241,8 +243,18 @@ def test_workgroup_binding_covers_every_chunk_once(harness, shape):
         seen[walk] += 1
     assert np.all(seen == 1), (int((seen == 0).sum()), int((seen > 1).sum()))
     assert np.all(per_tile >= 1) and np.all(np.diff(wt[:grid]) >= 0)  # tiles own contiguous runs of workgroups (k_reg_reduce relies on it)
-    if xcd[0]:
-        assert grid % 8 == 0 and np.all(per_tile % 8 == 0)
+    if xcd[0]:  # workgroup b sits on XCD b mod 8; the workgroups of a tile on one XCD share one slice of its chunk range, and the slices follow the XCD order
+        assert grid % 8 == 0
+        for t in range(nT):
+            ids = np.flatnonzero(wt[:grid] == t)
+            ends = []
+            for x in range(8):
+                on_x = ids[ids % 8 == x]
+                if len(on_x):
+                    assert len(set(we[on_x])) == 1 and np.all(ws[on_x] == len(on_x)) and sorted(wf[on_x] - wf[on_x].min()) == list(range(len(on_x)))
+                    ends.append((x, int(wf[on_x].min()), int(we[on_x][0])))
+            assert all(a[2] == b[1] for a, b in zip(ends, ends[1:])) and ends[0][1] == tcb[t] and ends[-1][2] == tcb[t + 1]
+            assert per_tile[t] < 8 or np.ptp([len(ids[ids % 8 == x]) for x in range(8)]) <= 1
     if grid >= 4 * nT:  # enough workgroups to balance: cost per workgroup within a quarter of the mean
         weight = cost if cost_a >= 0 else np.diff(tcb).astype(float)
         load = weight / per_tile
