@@ -946,6 +946,7 @@ struct TilePlan {
   const unsigned* codes;         // per chunk and wave: nit iterations x 64 lanes of (i_addr | j_addr << 16), LDS addresses in 16-byte pieces
   const int* code_start;         // [n_tile_chunks + 1] offsets into `codes`
   const unsigned* nit;           // [n_tile_chunks] iterations of waves 0..3, one byte each
+  int prio_shift;                // >= 0: the workgroups of the two halves of the dispatch order raise their wave priority in alternate groups of 2^prio_shift trips
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1536,7 +1537,14 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   load_indices(raw.obs_start, &idxA, &idxB); // the second chunk's indices
   raw = load_raw(second, min(second + stride, last));
   int buf = 0;
+  // The two workgroups of a CU are arbitrated by priority, then AGE: the one dispatched first wins every contested issue slot, finishes at ~104 us and
+  // leaves the other, alone and at the one-wave issue rate, to finish at ~120 (device stamps, round 6: profiles/r06_pair_lifetimes.txt).  With
+  // prio_shift >= 0 the halves of the dispatch order take the higher priority in alternate groups of trips, so that both make the same progress.
+  const int young = ((int)blockIdx.x >= (int)gridDim.x / 2) ? 1 : 0;
   for (int trip = 0; trip < trips; ++trip) {
+    if (tp.prio_shift >= 0) {
+      if (((trip >> tp.prio_shift) + young) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
     const int cur = min(first + trip * stride, last);
     // everything issued a trip ago has landed (the records of `cur` in `buf`, its codes, the counts and indices of the next
     // chunk), and every wave is done reading the other buffer

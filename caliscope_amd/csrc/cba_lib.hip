@@ -892,6 +892,10 @@ static int prepare_install(const cba_problem* p, Reg2Plan& plan, const Reg2Param
   tp.group_cam_begin = dgc; tp.group_par_begin = dgp; tp.g = g;
   tp.tile_elems = CT * p->nct * p->nct; tp.obs = dob; tp.rep = prm.rep;  // stride of a workgroup's partial row (>= g^2 blocks)
   tp.codes = dcodes; tp.code_start = dcode; tp.nit = dnit;
+  // six-parameter cameras (two workgroups per CU): the halves of the dispatch order take the higher wave priority in alternate trips — cfg4 127 -> 120 us,
+  // the means of the two halves 100 / 118 -> 105 / 111 us; the nine-parameter kernel (one 12-wave workgroup per CU) measured 4 % SLOWER with it: off
+  tp.prio_shift = (NC == 6) ? 0 : -1;
+  if (const char* e = std::getenv("CBA_PAIR_PRIO")) tp.prio_shift = std::atoi(e);  // (-1: off; k >= 0: alternate every 2^k trips)
   out.tp = tp;
   return CBA_OK;
 }
