@@ -212,6 +212,41 @@ CBA_HD void project_full(const CamTab& c, double X, double Y, double Z, double u
   }
 }
 
+// Residual + the FACTORS of the Jacobian blocks (round 6).  The camera block is A = G [C | I | A_intr] with C = -[Y]x J_l (Y = R X), so its rotation
+// columns are A_rot = (Y x G_r)^T J_l per row r: the per-camera constant J_l can be applied once per camera to whatever the rows are summed into
+// (normal-equation blocks, right-hand sides, J v) instead of once per observation — the per-observation kernels then never read J_l (9 of the 36
+// doubles of a camera row, all of which come out of LDS per observation) and skip the 36 flops of the rotation columns.
+//   G (2 x 3) = d(pixel)/dX_c / fx0,   Yr (3) = R X,   B (2 x 3) = G R,   Aint (2 x 3): the free-intrinsics columns (zero unless nparams == 9)
+CBA_HD void project_factors(const CamTab& c, double X, double Y, double Z, double u, double v,
+                            double* e, double (*G)[3], double* Yr, double (*Aint)[3], double (*B)[3]) {
+  const double Y0 = c.R[0] * X + c.R[1] * Y + c.R[2] * Z;
+  const double Y1 = c.R[3] * X + c.R[4] * Y + c.R[5] * Z;
+  const double Y2 = c.R[6] * X + c.R[7] * Y + c.R[8] * Z;
+  Yr[0] = Y0; Yr[1] = Y1; Yr[2] = Y2;
+  const double Zc = Y2 + c.t[2];
+  const double iz = 1.0 / Zc;
+  const double x = (Y0 + c.t[0]) * iz, y = (Y1 + c.t[1]) * iz;
+  Lens L;
+  if (c.model != 0.0) lens_fisheye(c.d, x, y, &L); else lens_pinhole(c.d, x, y, &L);
+  const double s = c.inv_fx0;
+  e[0] = ((c.cx - u) + c.fx * L.xd) * s;
+  e[1] = ((c.cy - v) + c.fy * L.yd) * s;
+  const double fxs = c.fx * s, fys = c.fy * s;
+  const double g00 = fxs * L.dxx * iz, g01 = fxs * L.dxy * iz;
+  const double g10 = fys * L.dyx * iz, g11 = fys * L.dyy * iz;
+  G[0][0] = g00; G[0][1] = g01; G[0][2] = -(g00 * x + g01 * y);
+  G[1][0] = g10; G[1][1] = g11; G[1][2] = -(g10 * x + g11 * y);
+  for (int r = 0; r < 2; ++r) {
+    B[r][0] = G[r][0] * c.R[0] + G[r][1] * c.R[3] + G[r][2] * c.R[6];
+    B[r][1] = G[r][0] * c.R[1] + G[r][1] * c.R[4] + G[r][2] * c.R[7];
+    B[r][2] = G[r][0] * c.R[2] + G[r][1] * c.R[5] + G[r][2] * c.R[8];
+  }
+  const bool free_intr = c.nparams == 9.0;
+  Aint[0][0] = free_intr ? c.fx0 * L.xd * s : 0.0; Aint[1][0] = free_intr ? c.fy0 * L.yd * s : 0.0;
+  Aint[0][1] = free_intr ? fxs * L.xr2 : 0.0;      Aint[1][1] = free_intr ? fys * L.yr2 : 0.0;
+  Aint[0][2] = free_intr ? fxs * L.xr4 : 0.0;      Aint[1][2] = free_intr ? fys * L.yr4 : 0.0;
+}
+
 // scipy's robust-loss treatment of ONE scalar residual r (least_squares.py:169-237, common.py:720-731).
 // Returns rho0 * f_scale^2 (so that cost = 0.5 * sum); *row_scale multiplies the Jacobian row,
 // *r_scaled replaces the residual.

@@ -342,6 +342,36 @@ __device__ __forceinline__ double obs_linearize(const CamTab& c_lds, double X, d
   return rho;
 }
 
+// The same front end in FACTORED form (ba_math.h: project_factors): G, Y = R X, B = G R and the intrinsic columns, robust-loss scaling applied to the
+// rows; the camera row is copied from LDS WITHOUT its J_l (27 of 36 doubles: the table reads of the per-observation kernels are random gathers into the
+// LDS banks, ~2.5 cycles per access group, and were 19 of k_jv's and 38 of k_tprep's microseconds of LDS time on cfg4 — r05 SQ counters).
+__device__ __forceinline__ double obs_factors(const CamTab& c_lds, double X, double Y, double Z, double u, double v, int loss, double f_scale, double* e,
+                                              double (*G)[3], double* Yr, double (*Aint)[3], double (*B)[3]) {
+  CamTab c;
+  {
+    const double* src = reinterpret_cast<const double*>(&c_lds);
+    double* dst = reinterpret_cast<double*>(&c);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dst[i] = src[i];          // R, t
+#pragma unroll
+    for (int i = 21; i < 35; ++i) dst[i] = src[i];         // fx .. nparams (J_l, entries 12..20, is not read)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  project_factors(c, X, Y, Z, u, v, e, G, Yr, Aint, B);
+  double rho = 0.0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double rs, er;
+    rho += robust_one(loss, f_scale, e[r], &rs, &er);
+    e[r] = er;
+    if (loss != LOSS_LINEAR) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { G[r][k] *= rs; B[r][k] *= rs; Aint[r][k] *= rs; }
+    }
+  }
+  return rho;
+}
+
 template <int NC> struct UPack {
   static constexpr int TRI = NC * (NC + 1) / 2;
   static constexpr int STRIDE = TRI + NC;  // upper triangle + gradient
@@ -675,8 +705,27 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
       n_cam = cs.cam[min(j + 1, jl)]; n_pl = cs.ptl[min(j + 1, jl)]; n_u = cs.u[min(j + 1, jl)]; n_v = cs.v[min(j + 1, jl)];
       __builtin_amdgcn_sched_barrier(0);
       if (cam != cur_cam) { flush(); cur_cam = cam; cur_np = (int)cam_of<CAMG>(sh_tab, tab, cam).nparams; }
+      // factored linearisation (round 6): the rows of A' = [Y x G_r | G_r | A_intr,r] are summed; A = A' P with P = blockdiag(J_l, I) per camera, so
+      // U = P^T U' P and g = P^T g' are formed ONCE per camera when the workgroup writes its blocks out (UGLOB adds to a global copy: true rows there)
       double e[2], A[2][MAX_NC], B[2][3];
-      cost += obs_linearize<NC>(cam_of<CAMG>(sh_tab, tab, cam), sh_x[pl], sh_x[PM + pl], sh_x[2 * PM + pl], u, v, loss, f_scale, e, A, B);
+      {
+        double G[2][3], Yr[3], Aint[2][3];
+        const CamTab& ctc = cam_of<CAMG>(sh_tab, tab, cam);
+        cost += obs_factors(ctc, sh_x[pl], sh_x[PM + pl], sh_x[2 * PM + pl], u, v, loss, f_scale, e, G, Yr, Aint, B);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const double p0 = Yr[1] * G[r][2] - Yr[2] * G[r][1], p1 = Yr[2] * G[r][0] - Yr[0] * G[r][2], p2 = Yr[0] * G[r][1] - Yr[1] * G[r][0];
+          if constexpr (UGLOB) {
+            A[r][0] = ctc.Jl[0] * p0 + ctc.Jl[3] * p1 + ctc.Jl[6] * p2;
+            A[r][1] = ctc.Jl[1] * p0 + ctc.Jl[4] * p1 + ctc.Jl[7] * p2;
+            A[r][2] = ctc.Jl[2] * p0 + ctc.Jl[5] * p1 + ctc.Jl[8] * p2;
+          } else {
+            A[r][0] = p0; A[r][1] = p1; A[r][2] = p2;
+          }
+          A[r][3] = G[r][0]; A[r][4] = G[r][1]; A[r][5] = G[r][2];
+          A[r][6] = Aint[r][0]; A[r][7] = Aint[r][1]; A[r][8] = Aint[r][2];
+        }
+      }
       if (!isfinite(e[0] + e[1])) bad = true;
 #pragma unroll
       for (int r = 0; r < NC; ++r) {
@@ -706,6 +755,35 @@ k_build_cs(CsPlan cs, const double* __restrict__ xvec, VecLayout lay, const doub
   }
   __syncthreads();
   if (!UGLOB) {
+    // U = P^T U' P, g = P^T g' per camera (P = blockdiag(J_l, I)): a thread per camera, in place
+    for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
+      const double* Jl = tab + (long)c * CAMTAB_DOUBLES + 12;  // row-major
+      double* Uc = sh_U + (long)c * UP::STRIDE;
+      double M[3][3], T[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M[r][q] = Uc[UP::idx(min(r, q), max(r, q))];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)  // T = J_l^T M
+#pragma unroll
+        for (int q = 0; q < 3; ++q) T[r][q] = Jl[r] * M[0][q] + Jl[3 + r] * M[1][q] + Jl[6 + r] * M[2][q];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)  // upper triangle of T J_l
+#pragma unroll
+        for (int q = r; q < 3; ++q) Uc[UP::idx(r, q)] = T[r][0] * Jl[q] + T[r][1] * Jl[3 + q] + T[r][2] * Jl[6 + q];
+#pragma unroll
+      for (int q = 3; q <= NC; ++q) {  // columns 3 .. NC - 1 of the top rows, then (q == NC) the gradient's top entries
+        double* v0 = (q < NC) ? &Uc[UP::idx(0, q)] : &Uc[UP::TRI + 0];
+        double* v1 = (q < NC) ? &Uc[UP::idx(1, q)] : &Uc[UP::TRI + 1];
+        double* v2 = (q < NC) ? &Uc[UP::idx(2, q)] : &Uc[UP::TRI + 2];
+        const double a0 = *v0, a1 = *v1, a2 = *v2;
+        *v0 = Jl[0] * a0 + Jl[3] * a1 + Jl[6] * a2;
+        *v1 = Jl[1] * a0 + Jl[4] * a1 + Jl[7] * a2;
+        *v2 = Jl[2] * a0 + Jl[5] * a1 + Jl[8] * a2;
+      }
+    }
+    __syncthreads();
     double* dst = partialU + (long)blockIdx.x * n_cams * UP::STRIDE;
     for (int i = threadIdx.x; i < n_cams * UP::STRIDE; i += BLOCK) dst[i] = sh_U[i];
   }
@@ -845,6 +923,20 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
     if (NV == 2) sh_v[lay.ncp_pad + i] = v2[i];
   }
   __syncthreads();
+  // (round 6) J v in factored form: a camera's share is G (w x Y + v_t) + A_intr v_i with w = J_l v_r — formed HERE, once per camera, in the place of v_r
+  for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
+    const double* row = tab + (long)c * CAMTAB_DOUBLES;
+    const int off = (int)row[35];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      double* vq = sh_v + q * lay.ncp_pad + off;
+      const double r0 = vq[0], r1 = vq[1], r2 = vq[2];
+      vq[0] = row[12] * r0 + row[13] * r1 + row[14] * r2;
+      vq[1] = row[15] * r0 + row[16] * r1 + row[17] * r2;
+      vq[2] = row[18] * r0 + row[19] * r1 + row[20] * r2;
+    }
+  }
+  __syncthreads();
   const double* px = xvec + lay.ncp_pad;
   const double* p1 = v1 + lay.ncp_pad;
   const double* p2 = (NV == 2) ? v2 + lay.ncp_pad : nullptr;
@@ -887,24 +979,30 @@ k_jv(const double* __restrict__ obs_u, const double* __restrict__ obs_v, const i
     const Rec r4 = load_rec(i + 4 * stride);   // record of trip i + 4
     __builtin_amdgcn_sched_barrier(0);
     const int cam = rc.cam;
-    double e[2], A[2][MAX_NC], B[2][3];
+    double e[2], G[2][3], Yr[3], Aint[2][3], B[2][3];
     const CamTab& ctj = cam_of<CAMG>(sh_tab, tab, cam);
-    obs_linearize<NC>(ctj, gc.X, gc.Y, gc.Z, rc.u, rc.v, loss, f_scale, e, A, B);
-    const int np = (int)ctj.nparams;
-    const double* vc = sh_v + (int)ctj.pad[0];  // (= cam_off[cam], from the table row that is being read anyway)
-    double a0 = B[0][0] * gc.a + B[0][1] * gc.b + B[0][2] * gc.c;
-    double a1 = B[1][0] * gc.a + B[1][1] * gc.b + B[1][2] * gc.c;
-#pragma unroll
-    for (int k = 0; k < NC; ++k)
-      if (k < np) { a0 += A[0][k] * vc[k]; a1 += A[1][k] * vc[k]; }
+    obs_factors(ctj, gc.X, gc.Y, gc.Z, rc.u, rc.v, loss, f_scale, e, G, Yr, Aint, B);
+    const double* vc = sh_v + (int)ctj.pad[0];  // (= cam_off[cam], from the table row that is being read anyway): w (3), v_t (3), v_i (3, nine-parameter cameras)
+    auto jv = [&](const double* q, double px0, double px1, double px2, double* o0, double* o1) {
+      // m = w x Y + v_t;  row r: G_r . m + B_r . v_p (+ A_intr,r . v_i)
+      const double m0 = fma(q[1], Yr[2], fma(-q[2], Yr[1], q[3]));
+      const double m1 = fma(q[2], Yr[0], fma(-q[0], Yr[2], q[4]));
+      const double m2 = fma(q[0], Yr[1], fma(-q[1], Yr[0], q[5]));
+      double a0 = B[0][0] * px0 + B[0][1] * px1 + B[0][2] * px2, a1 = B[1][0] * px0 + B[1][1] * px1 + B[1][2] * px2;
+      a0 = fma(G[0][2], m2, fma(G[0][1], m1, fma(G[0][0], m0, a0)));
+      a1 = fma(G[1][2], m2, fma(G[1][1], m1, fma(G[1][0], m0, a1)));
+      if (NC == 9 && ctj.nparams == 9.0) {
+        a0 = fma(Aint[0][2], q[8], fma(Aint[0][1], q[7], fma(Aint[0][0], q[6], a0)));
+        a1 = fma(Aint[1][2], q[8], fma(Aint[1][1], q[7], fma(Aint[1][0], q[6], a1)));
+      }
+      *o0 = a0; *o1 = a1;
+    };
+    double a0, a1;
+    jv(vc, gc.a, gc.b, gc.c, &a0, &a1);
     s11 += a0 * a0 + a1 * a1;
     if (NV == 2) {
-      const double* wc = vc + lay.ncp_pad;
-      double b0 = B[0][0] * gc.d + B[0][1] * gc.e + B[0][2] * gc.f;
-      double b1 = B[1][0] * gc.d + B[1][1] * gc.e + B[1][2] * gc.f;
-#pragma unroll
-      for (int k = 0; k < NC; ++k)
-        if (k < np) { b0 += A[0][k] * wc[k]; b1 += A[1][k] * wc[k]; }
+      double b0, b1;
+      jv(vc + lay.ncp_pad, gc.d, gc.e, gc.f, &b0, &b1);
       s12 += a0 * b0 + a1 * b1;
       s22 += b0 * b0 + b1 * b1;
     }
@@ -1107,7 +1205,7 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   // of the record two chunks ahead only its point index: the body has no 30 registers to spare at two workgroups per CU (with all fifteen values in
   // flight it asked for 280 and spilled when capped).  V, scale and gradient are then issued at the head of the chunk, in FRONT of the prefetches — the
   // wait for them leaves those in flight — and are not needed before the ~250 instructions of the linearisation.
-  constexpr bool PIPE = DETM == 0, FULL = NC == 6;
+  constexpr bool PIPE = DETM == 0, FULL = true;  // (the factored linearisation freed the registers: all fifteen values travel ahead for nine-parameter cameras too; the light form stays for reference)
   struct PtOps { double X, Y, Z, V[6], d[3], g[3]; };
   auto load_rest = [&](PtOps& q, int pt) {
 #pragma unroll
@@ -1183,8 +1281,10 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       const int cam = cur.cam;
       const CamTab& ct = cam_of<CAMG>(sh_tab, tab, cam);
       const double X = ops.X, Yw = ops.Y, Zw = ops.Z;
-      double e[2], A[2][MAX_NC], B[2][3], Z[2][3];
-      obs_linearize<NC>(ct, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);
+      // factored linearisation (round 6): T = A^T Z = [J_l^T [Y]x Q ; Q ; T_intr] with Q = G^T Z — the record never held the top rows, and their share
+      // of the right-hand side, J_l^T (Y x (Q y)), is accumulated WITHOUT its J_l^T (applied once per camera when the workgroup writes its row out)
+      double e[2], G[2][3], Yr[3], Aint[2][3], B[2][3], Z[2][3];
+      obs_factors(ct, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, G, Yr, Aint, B);
       const int np = (int)ct.nparams;
       double Vd[6], L[6];
 #pragma unroll
@@ -1202,18 +1302,29 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       chol3_fwd(L, gpt, y);
       double* bc = sh_b + (int)ct.pad[0];  // (= cam_off[cam])
       // rotated point Y = R X (the record's first three entries)
-      rec[0] = fma(ct.R[2], Zw, fma(ct.R[1], Yw, ct.R[0] * X));
-      rec[1] = fma(ct.R[5], Zw, fma(ct.R[4], Yw, ct.R[3] * X));
-      rec[2] = fma(ct.R[8], Zw, fma(ct.R[7], Yw, ct.R[6] * X));
+      rec[0] = Yr[0]; rec[1] = Yr[1]; rec[2] = Yr[2];
+      double qy[3];  // Q y
 #pragma unroll
-      for (int r = 0; r < NC; ++r) {
+      for (int r = 3; r < NC; ++r) {  // rows 3..5: Q = G^T Z; rows 6..8: T_intr = A_intr^T Z
         const bool live = r < np;
+        const double a0 = (r < 6) ? G[0][r - 3] : Aint[0][(r - 6) % 3], a1 = (r < 6) ? G[1][r - 3] : Aint[1][(r - 6) % 3];
         double t[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t[k] = live ? A[0][r] * Z[0][k] + A[1][r] * Z[1][k] : 0.0;
-        if (DET) bval[r] = live ? t[0] * y[0] + t[1] * y[1] + t[2] * y[2] : 0.0;
-        else if (live) lds_add(&bc[r], t[0] * y[0] + t[1] * y[1] + t[2] * y[2]);
-        if (r >= 3) { rec[3 * r - 6] = t[0]; rec[3 * r - 5] = t[1]; rec[3 * r - 4] = t[2]; }  // rows 3.. : Q, then T_intr
+        for (int k = 0; k < 3; ++k) t[k] = live ? a0 * Z[0][k] + a1 * Z[1][k] : 0.0;
+        const double ty = t[0] * y[0] + t[1] * y[1] + t[2] * y[2];
+        if (r < 6) qy[r - 3] = ty;
+        if (DET) bval[r] = live ? ty : 0.0;
+        else if (live) lds_add(&bc[r], ty);
+        rec[3 * r - 6] = t[0]; rec[3 * r - 5] = t[1]; rec[3 * r - 4] = t[2];
+      }
+      {  // rows 0..2 of the right-hand side: J_l^T c, c = Y x (Q y)
+        const double c0 = Yr[1] * qy[2] - Yr[2] * qy[1], c1 = Yr[2] * qy[0] - Yr[0] * qy[2], c2 = Yr[0] * qy[1] - Yr[1] * qy[0];
+        if (DET) {  // (the fixed-order sums are formed per (camera, row) task: they take the true rows)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) bval[r] = ct.Jl[r] * c0 + ct.Jl[3 + r] * c1 + ct.Jl[6 + r] * c2;
+        } else {
+          lds_add(&bc[0], c0); lds_add(&bc[1], c1); lds_add(&bc[2], c2);
+        }
       }
     }
     // The 64 records of a wave are one contiguous run of Trec.  A lane storing its own record issues 16-byte stores one
@@ -1269,6 +1380,15 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
       if (task < n_cams * DET_ROUND && q < (int)cam_at(sh_tab, c).nparams) brow[cam_off[c] + q] = dacc[m];
     }
   } else {
+    // the rotation entries were summed without their camera's J_l^T: applied here, once per camera and workgroup
+    for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
+      const double* row = tab + (long)c * CAMTAB_DOUBLES;
+      double* b3 = sh_b + (int)row[35];
+      const double c0 = b3[0], c1 = b3[1], c2 = b3[2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) b3[r] = row[12 + r] * c0 + row[15 + r] * c1 + row[18 + r] * c2;
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) brow[i] = sh_b[i];
   }
 }
@@ -2461,7 +2581,7 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     }
     double t[3] = {0.0, 0.0, 0.0};
     if (i < o1) {
-      const int cam = cur.cam, pt = cur.pt;
+      const int cam = cur.cam;
       double e[2], A[2][MAX_NC], B[2][3];
       const CamTab& ctb = cam_of<CAMG>(sh_tab, tab, cam);
       obs_linearize<NC>(ctb, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);

@@ -26,6 +26,24 @@ void mh_project_full(const double* x_cam, const double* cconst, int model, int n
   }
 }
 
+// The factored form the per-observation kernels use since round 6 (ba_math.h project_factors): A is rebuilt from the factors — rotation columns
+// (Y x G_r)^T J_l, translation columns G_r, intrinsic columns A_intr — so that the test can hold it against project_full and the oracle.
+void mh_project_factors(const double* x_cam, const double* cconst, int model, int nparams, const double* X,
+                        const double* uv, double* e_out, double* A_out, double* B_out) {
+  cba::CamTab tab;
+  prepare(x_cam, cconst, model, nparams, &tab);
+  double G[2][3], Yr[3], Aint[2][3], B[2][3];
+  cba::project_factors(tab, X[0], X[1], X[2], uv[0], uv[1], e_out, G, Yr, Aint, B);
+  for (int r = 0; r < 2; ++r) {
+    const double p[3] = {Yr[1] * G[r][2] - Yr[2] * G[r][1], Yr[2] * G[r][0] - Yr[0] * G[r][2], Yr[0] * G[r][1] - Yr[1] * G[r][0]};
+    for (int c = 0; c < cba::MAX_NC; ++c) A_out[r * cba::MAX_NC + c] = 0.0;
+    for (int j = 0; j < 3; ++j) A_out[r * cba::MAX_NC + j] = tab.Jl[j] * p[0] + tab.Jl[3 + j] * p[1] + tab.Jl[6 + j] * p[2];
+    for (int j = 0; j < 3; ++j) A_out[r * cba::MAX_NC + 3 + j] = G[r][j];
+    for (int j = 0; j < 3 && nparams == 9; ++j) A_out[r * cba::MAX_NC + 6 + j] = Aint[r][j];
+    for (int c = 0; c < 3; ++c) B_out[r * 3 + c] = B[r][c];
+  }
+}
+
 void mh_project_residual(const double* x_cam, const double* cconst, int model, int nparams, const double* X,
                          const double* uv, double* e_out) {
   cba::CamTab tab;

@@ -50,6 +50,10 @@ def _native_blocks(mh, par, x, cam_idx, uv, obj_idx):
         o = np.ascontiguousarray(uv[i])
         mh.mh_project_full(_p(xc), _p(cc), int(t["cam_model"][c]), int(t["cam_n_params"][c]), _p(X), _p(o),
                            _p(E[i]), _p(A[i].reshape(-1)), _p(B[i].reshape(-1)))
+        Ef, Af, Bf = np.zeros(2), np.zeros((2, 9)), np.zeros((2, 3))  # the factored form of the same blocks (round 6)
+        mh.mh_project_factors(_p(xc), _p(cc), int(t["cam_model"][c]), int(t["cam_n_params"][c]), _p(X), _p(o), _p(Ef), _p(Af.reshape(-1)), _p(Bf.reshape(-1)))
+        assert np.allclose(Ef, E[i], rtol=0, atol=1e-15) and np.allclose(Bf, B[i], rtol=1e-13, atol=1e-15)
+        assert np.allclose(Af, A[i], rtol=1e-12, atol=1e-14 * max(1.0, np.abs(A[i]).max()))
         e2 = np.zeros(2)
         mh.mh_project_residual(_p(xc), _p(cc), int(t["cam_model"][c]), int(t["cam_n_params"][c]), _p(X), _p(o), _p(e2))
         assert np.allclose(e2, E[i], rtol=0, atol=1e-15)
