@@ -62,6 +62,8 @@ def algorithmic_bytes(n_obs, n_points, n_cams, ncp, nct):
         "build": 24 * N + 24 * P + 72 * P + 8 * n_cams * ustride,
         "jv": 24 * N + 24 * P + 24 * P,
         "schur": 24 * N + 24 * P + 48 * P + 24 * P + 24 * P + 8 * ncp * ncp + 8 * ncp,
+        # (SURVEY.md 8d's storage model.  Since round 6 six-parameter cameras stream the 96-byte T records k_tprep has just written instead of linearising
+        # again: 100 bytes per observation actually move — `traffic` has the counters — the ALGORITHMIC figure stays the model's)
         "backsub": 24 * N + 24 * P + 48 * P + 24 * P + 24 * P + 24 * P,
     }
 

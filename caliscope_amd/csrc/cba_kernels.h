@@ -2514,6 +2514,16 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
   if (!CAMG) stage_camtab(sh_tab, tab, n_cams);
   for (int i = threadIdx.x; i < lay.ncp_pad; i += BLOCK) sh_dc[i] = svec[i];
   __syncthreads();
+  // (round 6) factored form, as in k_jv: A dc = G (w x Y + dt) + A_intr di with w = J_l dc_r, formed once per camera in the place of dc_r
+  for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
+    const double* row = tab + (long)c * CAMTAB_DOUBLES;
+    double* d3 = sh_dc + (int)row[35];
+    const double r0 = d3[0], r1 = d3[1], r2 = d3[2];
+    d3[0] = row[12] * r0 + row[13] * r1 + row[14] * r2;
+    d3[1] = row[15] * r0 + row[16] * r1 + row[17] * r2;
+    d3[2] = row[18] * r0 + row[19] * r1 + row[20] * r2;
+  }
+  __syncthreads();
   const double* px = xvec + lay.ncp_pad;
   const double* gp = gvec + lay.ncp_pad;
   const double* dp = sinv + lay.ncp_pad;
@@ -2582,15 +2592,18 @@ k_backsub(const double* __restrict__ obs_u, const double* __restrict__ obs_v, co
     double t[3] = {0.0, 0.0, 0.0};
     if (i < o1) {
       const int cam = cur.cam;
-      double e[2], A[2][MAX_NC], B[2][3];
+      double e[2], G[2][3], Yr[3], Aint[2][3], B[2][3];
       const CamTab& ctb = cam_of<CAMG>(sh_tab, tab, cam);
-      obs_linearize<NC>(ctb, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, A, B);
-      const int np = (int)ctb.nparams;
-      const double* dc = sh_dc + (int)ctb.pad[0];  // (= cam_off[cam])
-      double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < NC; ++k)
-        if (k < np) { a0 += A[0][k] * dc[k]; a1 += A[1][k] * dc[k]; }
+      obs_factors(ctb, X, Yw, Zw, cur.u, cur.v, loss, f_scale, e, G, Yr, Aint, B);
+      const double* dc = sh_dc + (int)ctb.pad[0];  // (= cam_off[cam]): w (3), dt (3), di (3)
+      const double m0 = fma(dc[1], Yr[2], fma(-dc[2], Yr[1], dc[3]));
+      const double m1 = fma(dc[2], Yr[0], fma(-dc[0], Yr[2], dc[4]));
+      const double m2 = fma(dc[0], Yr[1], fma(-dc[1], Yr[0], dc[5]));
+      double a0 = fma(G[0][2], m2, fma(G[0][1], m1, G[0][0] * m0)), a1 = fma(G[1][2], m2, fma(G[1][1], m1, G[1][0] * m0));
+      if (NC == 9 && ctb.nparams == 9.0) {
+        a0 = fma(Aint[0][2], dc[8], fma(Aint[0][1], dc[7], fma(Aint[0][0], dc[6], a0)));
+        a1 = fma(Aint[1][2], dc[8], fma(Aint[1][1], dc[7], fma(Aint[1][0], dc[6], a1)));
+      }
       t[0] = B[0][0] * a0 + B[1][0] * a1;
       t[1] = B[0][1] * a0 + B[1][1] * a1;
       t[2] = B[0][2] * a0 + B[1][2] * a1;

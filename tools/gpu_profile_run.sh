@@ -38,6 +38,11 @@ for w in cfg4 cfg5; do
 done
 find $O -name "*.db" -size +8M -delete; find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 P=$GRAFT_REPO_ROOT/caliscope_amd/libcaliscope_ba_prof.so
+# device-side stamps of one fused iteration (round 6: what sits between the kernels without a profiler attached; per-tile / XCD / dispatch-order lifetimes of the pair kernel)
+for w in cfg2 cfg3 cfg4 cfg5; do
+  CALISCOPE_BA_LIB=$P CBA_STAMPS=1 CBA_PLAN=full timeout 300 python bench.py --no-cpu --no-first-call --workload $w --also "" --steps 12 --warmup 4 > /dev/null 2> $O/stamps_$w.raw
+  awk '/device stamps of the last fused iteration/{n++} n==1' $O/stamps_$w.raw > $O/stamps_$w.txt
+done
 CALISCOPE_BA_LIB=$P CBA_SCHUR_CLOCK=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/schur_clock_cfg4.log > /dev/null
 CALISCOPE_BA_LIB=$P CBA_CHOL_TRACE=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/chol_trace.log > /dev/null
 timeout 400 python tools/create_timing.py > $O/create_timing.log 2>&1

@@ -103,7 +103,7 @@ if __name__ == "__main__":
         t0 = time.perf_counter()
         out["cfg5_sample_1M"] = bench.cfg5_sample_parity(n_points=100_000)
         out["cfg5_sample_1M"]["wall_seconds"] = round(time.perf_counter() - t0, 1)
-    path = argv[0] if argv else "profiles/parity_r05.json"
+    path = argv[0] if argv else "profiles/parity_r06.json"
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
