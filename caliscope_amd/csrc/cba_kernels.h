@@ -1393,45 +1393,76 @@ k_tprep(const double* __restrict__ obs_u, const double* __restrict__ obs_v, cons
   }
 }
 
-// Primed pair product of a thread that owns three rows (NC = 9): with Rm = Q_i (or T_intr,i) the three rows are
-//   Rm T'_j^T = [ (Rm Q_j^T) [Y_j]x^T | Rm Q_j^T | Rm T_intr,j^T ],   and [Y_i]x times that for the rows of [Y_i]x Q_i.
-// Column group by column group, so that few values are live at a time (the kernel has 168 registers per thread).
-template <int NC, bool CROSS_I>
-__device__ __forceinline__ void pair_rows(double (*acc)[NC], const double* Rm, const double* Yi, const double2* __restrict__ Rj) {
-  auto put = [&](int c, double m0, double m1, double m2) {
-    if (CROSS_I) {  // ([Y_i]x M)[r][c] = (Y_i x M[:, c])_r, two FMAs each
-      acc[0][c] = fma(Yi[1], m2, fma(-Yi[2], m1, acc[0][c]));
-      acc[1][c] = fma(Yi[2], m0, fma(-Yi[0], m2, acc[1][c]));
-      acc[2][c] = fma(Yi[0], m1, fma(-Yi[1], m0, acc[2][c]));
-    } else {
-      acc[0][c] += m0; acc[1][c] += m1; acc[2][c] += m2;
-    }
-  };
-  double D[3][3];
-  double Yj[3];
+// Round 6: the three threads of a nine-parameter block split it by SUB-BLOCK instead of by rows, so that no product is formed twice.  With
+// T' = [[Y]x Q ; Q ; I] (I = T_intr) and D = Q_i Q_j^T, E = Q_i I_j^T, F = I_i Q_j^T, H = I_i I_j^T the primed block is
+//     [ [Y_i]x D [Y_j]x^T   [Y_i]x D   [Y_i]x E ]        role 0: the 6 x 6 corner — pair6 on the (Y, Q) parts, 99 FP64 instructions
+//     [       D [Y_j]x^T         D          E    ]        role 1: columns 6..8 — E, [Y_i]x E, H: 81
+//     [       F [Y_j]x^T         F          H    ]        role 2: rows 6..8 of columns 0..5 — F, F [Y_j]x^T: 54
+// 234 instructions per pair where the split by rows took 324 (each row third formed D or F, its product with [Y_j]x and its E or H), and 39
+// instead of 50 16-byte LDS reads.  Accumulators: 36 / 27 / 18 doubles.
+// role 0: pair6's arithmetic column by column (D = Q_i Q_j^T, then three values per column), so that 18 instead of 36 doubles sit beside the accumulators:
+// the nine-parameter kernel has 168 registers per thread
+__device__ __forceinline__ void pair9_corner(double (&acc)[6][6], const double2* __restrict__ Ri, const double2* __restrict__ Rj) {
+  double D[3][3], Yi[3], Yj[3];
   {
+    const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
     const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
-    Yj[0] = j0.x; Yj[1] = j0.y; Yj[2] = j1.x;
+    Yi[0] = i0.x; Yi[1] = i0.y; Yi[2] = i1.x; Yj[0] = j0.x; Yj[1] = j0.y; Yj[2] = j1.x;
+    const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
     const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b2 = 0; b2 < 3; ++b2) D[a][b2] = fma(Rm[3 * a + 2], Qj[3 * b2 + 2], fma(Rm[3 * a + 1], Qj[3 * b2 + 1], Rm[3 * a] * Qj[3 * b2]));
+      for (int b = 0; b < 3; ++b) D[a][b] = fma(Qi[3 * a + 2], Qj[3 * b + 2], fma(Qi[3 * a + 1], Qj[3 * b + 1], Qi[3 * a] * Qj[3 * b]));
   }
+  auto put = [&](int c, double m0, double m1, double m2) {
+    acc[0][c] = fma(Yi[1], m2, fma(-Yi[2], m1, acc[0][c]));
+    acc[1][c] = fma(Yi[2], m0, fma(-Yi[0], m2, acc[1][c]));
+    acc[2][c] = fma(Yi[0], m1, fma(-Yi[1], m0, acc[2][c]));
+    acc[3][c] += m0; acc[4][c] += m1; acc[5][c] += m2;
+  };
 #pragma unroll
-  for (int b2 = 0; b2 < 3; ++b2) put(3 + b2, D[0][b2], D[1][b2], D[2][b2]);
-  // (D [Y_j]x^T)[a][c] = (Y_j x D[a, :])_c
+  for (int b = 0; b < 3; ++b) put(3 + b, D[0][b], D[1][b], D[2][b]);
   put(0, fma(Yj[1], D[0][2], -(Yj[2] * D[0][1])), fma(Yj[1], D[1][2], -(Yj[2] * D[1][1])), fma(Yj[1], D[2][2], -(Yj[2] * D[2][1])));
   put(1, fma(Yj[2], D[0][0], -(Yj[0] * D[0][2])), fma(Yj[2], D[1][0], -(Yj[0] * D[1][2])), fma(Yj[2], D[2][0], -(Yj[0] * D[2][2])));
   put(2, fma(Yj[0], D[0][1], -(Yj[1] * D[0][0])), fma(Yj[0], D[1][1], -(Yj[1] * D[1][0])), fma(Yj[0], D[2][1], -(Yj[1] * D[2][0])));
-  if constexpr (NC == 9) {
-    const double2 j6 = Rj[6], j7 = Rj[7], j8 = Rj[8], j9 = Rj[9], j10 = Rj[10];
-    const double Ij[9] = {j6.x, j6.y, j7.x, j7.y, j8.x, j8.y, j9.x, j9.y, j10.x};
+}
+__device__ __forceinline__ void pair9_cols(double* __restrict__ acc /* [9][3] */, const double2* __restrict__ Ri, const double2* __restrict__ Rj) {
+  const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5], i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
+  const double2 j6 = Rj[6], j7 = Rj[7], j8 = Rj[8], j9 = Rj[9], j10 = Rj[10];
+  const double Yi[3] = {i0.x, i0.y, i1.x};
+  const double Qi[9] = {i1.y, i2.x, i2.y, i3.x, i3.y, i4.x, i4.y, i5.x, i5.y};
+  const double Ii[9] = {i6.x, i6.y, i7.x, i7.y, i8.x, i8.y, i9.x, i9.y, i10.x};
+  const double Ij[9] = {j6.x, j6.y, j7.x, j7.y, j8.x, j8.y, j9.x, j9.y, j10.x};
 #pragma unroll
-    for (int b2 = 0; b2 < 3; ++b2)
-      put(6 + b2, fma(Rm[2], Ij[3 * b2 + 2], fma(Rm[1], Ij[3 * b2 + 1], Rm[0] * Ij[3 * b2])),
-          fma(Rm[5], Ij[3 * b2 + 2], fma(Rm[4], Ij[3 * b2 + 1], Rm[3] * Ij[3 * b2])),
-          fma(Rm[8], Ij[3 * b2 + 2], fma(Rm[7], Ij[3 * b2 + 1], Rm[6] * Ij[3 * b2])));
+  for (int b = 0; b < 3; ++b) {
+    const double e0 = fma(Qi[2], Ij[3 * b + 2], fma(Qi[1], Ij[3 * b + 1], Qi[0] * Ij[3 * b]));
+    const double e1 = fma(Qi[5], Ij[3 * b + 2], fma(Qi[4], Ij[3 * b + 1], Qi[3] * Ij[3 * b]));
+    const double e2 = fma(Qi[8], Ij[3 * b + 2], fma(Qi[7], Ij[3 * b + 1], Qi[6] * Ij[3 * b]));
+    acc[0 * 3 + b] = fma(Yi[1], e2, fma(-Yi[2], e1, acc[0 * 3 + b]));
+    acc[1 * 3 + b] = fma(Yi[2], e0, fma(-Yi[0], e2, acc[1 * 3 + b]));
+    acc[2 * 3 + b] = fma(Yi[0], e1, fma(-Yi[1], e0, acc[2 * 3 + b]));
+    acc[3 * 3 + b] += e0; acc[4 * 3 + b] += e1; acc[5 * 3 + b] += e2;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      acc[(6 + a) * 3 + b] = fma(Ii[3 * a + 2], Ij[3 * b + 2], fma(Ii[3 * a + 1], Ij[3 * b + 1], fma(Ii[3 * a], Ij[3 * b], acc[(6 + a) * 3 + b])));
+  }
+}
+__device__ __forceinline__ void pair9_rows(double* __restrict__ acc /* [3][6] */, const double2* __restrict__ Ri, const double2* __restrict__ Rj) {
+  const double2 i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
+  const double2 j0 = Rj[0], j1 = Rj[1], j2 = Rj[2], j3 = Rj[3], j4 = Rj[4], j5 = Rj[5];
+  const double Ii[9] = {i6.x, i6.y, i7.x, i7.y, i8.x, i8.y, i9.x, i9.y, i10.x};
+  const double Yj[3] = {j0.x, j0.y, j1.x};
+  const double Qj[9] = {j1.y, j2.x, j2.y, j3.x, j3.y, j4.x, j4.y, j5.x, j5.y};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double f0 = fma(Ii[3 * a + 2], Qj[2], fma(Ii[3 * a + 1], Qj[1], Ii[3 * a] * Qj[0]));
+    const double f1 = fma(Ii[3 * a + 2], Qj[5], fma(Ii[3 * a + 1], Qj[4], Ii[3 * a] * Qj[3]));
+    const double f2 = fma(Ii[3 * a + 2], Qj[8], fma(Ii[3 * a + 1], Qj[7], Ii[3 * a] * Qj[6]));
+    acc[a * 6 + 3] += f0; acc[a * 6 + 4] += f1; acc[a * 6 + 5] += f2;
+    acc[a * 6 + 0] = fma(Yj[1], f2, fma(-Yj[2], f1, acc[a * 6 + 0]));  // (F [Y_j]x^T)[a][c] = (Y_j x F[a, :])_c
+    acc[a * 6 + 1] = fma(Yj[2], f0, fma(-Yj[0], f2, acc[a * 6 + 1]));
+    acc[a * 6 + 2] = fma(Yj[0], f1, fma(-Yj[1], f0, acc[a * 6 + 2]));
   }
 }
 
@@ -1467,7 +1498,13 @@ template <int NC> struct Reg3Cfg {
   static constexpr int BUF_PIECES = ZERO_PIECE + LST + 1;                           // (+1: keeps the second buffer 32-byte aligned)
   static constexpr int NBUF = 2;                                                    // chunk buffers: a gather is issued one trip before it is read
   static constexpr int SET_PIECES = NBUF * BUF_PIECES;
-  static constexpr size_t LDS_BYTES = (size_t)SET_PIECES * 16;
+  // NC = 9: the per-lane constants of the gather (record of the wave's run and piece of the record a lane fetches with load k) live in a table behind
+  // the buffers and are read back every trip: as loop invariants they are twelve 64-bit base addresses and six shuffle addresses per lane, and with
+  // the 36 accumulators of the corner role (pair9_corner) the kernel's 168 registers no longer held them (spilled, and reloaded in the middle of the
+  // issue sequence behind a vmcnt(0))
+  static constexpr bool LANE_TABLE = (NC == 9);
+  static constexpr int TABLE_PIECES = LANE_TABLE ? (NLD * WAVE * 4 + 15) / 16 : 0;
+  static constexpr size_t LDS_BYTES = (size_t)(SET_PIECES + TABLE_PIECES) * 16;
   static constexpr int LAUNCH_THREADS = REG_BLOCK;
   static_assert(SCHUNK % NWAVES == 0 && EPW % 16 == 0 && EPW <= 2 * WAVE && (LST & 1) == 1, "staging layout");
   static_assert(ZERO_PIECE + LST < 65536, "piece addresses are 16 bit");
@@ -1532,7 +1569,6 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   using Cfg = Reg3Cfg<NC>;
   static_assert(SPLIT == Cfg::SPLIT, "split");
   constexpr int REG_BLOCK = Cfg::REG_BLOCK, LST = Cfg::LST, NLD = Cfg::NLD, EPW = Cfg::EPW, NWORD = Cfg::CODE_WAVES / 4;
-  constexpr int RH = (NC + SPLIT - 1) / SPLIT;  // rows of the block per thread
   constexpr int NCD = Cfg::NCD;                 // codes of a chunk (and block) that travel in registers
 
   const int nblk = tp.g * tp.g;
@@ -1543,19 +1579,19 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int ct = tid % BLOCK;                   // code thread: the SPLIT parts of a block multiply the same pairs
   const int pw = __builtin_amdgcn_readfirstlane(ct / WAVE), lane = ct % WAVE;
   const int sw = __builtin_amdgcn_readfirstlane(tid / WAVE);  // loading wave of the set
-  const int half = tid / BLOCK;  // which SPLIT-th of the block's rows (0 when SPLIT == 1)
-  const int r0 = half * RH;
-  double acc[RH][NC];
+  const int half = tid / BLOCK;  // role of the thread in its block (NC = 9: sub-block 0, 1 or 2, see pair9_cols; 0 when SPLIT == 1)
+  double acc[6][6];              // NC = 6 and role 0: the 6 x 6 block; role 1: [9][3], role 2: [3][6] in the same registers
+  double* const accf = &acc[0][0];
 #pragma unroll
-  for (int r = 0; r < RH; ++r)
+  for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+    for (int c = 0; c < 6; ++c) acc[r][c] = 0.0;
 
   // this thread's block: virtual thread vt of the plan; rep > 1: vt = slot * nblk + block
   const int vt = (SPLIT == 1) ? tid : ct;
   const int blk = (rep > 1) ? vt % nblk : vt, slot = (rep > 1) ? vt / nblk : 0;
   const bool owner = slot < rep && blk < nblk;  // threads beyond the tile's blocks (ragged groups) only help to load
-  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC + r0 * NC;
+  double* dst = partial + ((long)wg * rep + min(slot, rep - 1)) * tp.tile_elems + (long)min(blk, nblk - 1) * NC * NC;
 
   // chunk range of this workgroup (one without chunks — more workgroups than chunks in the range — gathers somebody's valid chunk and multiplies nothing)
   const int stride = tp.wg_stride[wg], ch_end = tp.wg_end[wg];
@@ -1563,6 +1599,18 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
   const int first = own_trips ? tp.wg_first[wg] : max(ch_end - 1, 0);
   const int trips = max(own_trips, 1);
   for (int k = tid; k < Cfg::NBUF * LST; k += REG_BLOCK) sh_p[(k / LST) * Cfg::BUF_PIECES + Cfg::ZERO_PIECE + k % LST] = make_double2(0.0, 0.0);
+  int* const lane_table = reinterpret_cast<int*>(sh_p + Cfg::SET_PIECES);  // [NLD][WAVE]: el | piece << 16 (Cfg::LANE_TABLE)
+  if constexpr (Cfg::LANE_TABLE) {
+    constexpr int Q = WAVE / LST, RM = WAVE % LST;
+    for (int e = tid; e < NLD * WAVE; e += REG_BLOCK) {
+      const int k = e / WAVE, l = e % WAVE;
+      int piece = k * RM + l % LST;
+      const int el = min(k * Q + l / LST + piece / LST, EPW - 1);
+      piece = min(piece % LST, SchurRec<NC>::NPH - 1);
+      lane_table[e] = el | (piece << 16);
+    }
+    __syncthreads();
+  }
   const int last = first + (own_trips ? (own_trips - 1) * stride : 0);  // last chunk of this workgroup
   // Per trip every wave issues, in this order and WITHOUT waiting in between: the codes of the next chunk and the record indices
   // of the chunk after next (their addresses come from the iteration counts / offsets loaded a trip earlier), the counts and
@@ -1613,13 +1661,19 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     const double2* g[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      int piece = k * RM + lane % LST;
-      int el = k * Q + lane / LST + piece / LST;
-      piece %= LST;
-      el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
+      int piece, el;
+      if constexpr (Cfg::LANE_TABLE) {
+        const int e = lane_table[k * WAVE + lane];
+        el = e & 0xffff; piece = e >> 16;
+      } else {
+        piece = k * RM + lane % LST;
+        el = k * Q + lane / LST + piece / LST;
+        piece = min(piece % LST, SchurRec<NC>::NPH - 1);
+        el = min(el, EPW - 1);  // tail lanes of the last load: a valid record, landing in the padding of the wave's run
+      }
       const bool useB = EPW > WAVE && k * WAVE >= WAVE * LST;
       const int idx = useB ? __shfl(idxB, el - WAVE, WAVE) : __shfl(idxA, el, WAVE);
-      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + min(piece, SchurRec<NC>::NPH - 1);
+      g[k] = reinterpret_cast<const double2*>(Trec + (long)idx * SchurRec<NC>::HREC) + piece;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1632,17 +1686,9 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     if constexpr (NC == 6) {
       pair6(acc, Ri, Rj);
     } else {
-      double Yi[3] = {0.0, 0.0, 0.0}, Rm[9];
-      if (half == 2) {  // rows of T_intr,i
-        const double2 i6 = Ri[6], i7 = Ri[7], i8 = Ri[8], i9 = Ri[9], i10 = Ri[10];
-        Rm[0] = i6.x; Rm[1] = i6.y; Rm[2] = i7.x; Rm[3] = i7.y; Rm[4] = i8.x; Rm[5] = i8.y; Rm[6] = i9.x; Rm[7] = i9.y; Rm[8] = i10.x;
-      } else {
-        const double2 i0 = Ri[0], i1 = Ri[1], i2 = Ri[2], i3 = Ri[3], i4 = Ri[4], i5 = Ri[5];
-        Yi[0] = i0.x; Yi[1] = i0.y; Yi[2] = i1.x;
-        Rm[0] = i1.y; Rm[1] = i2.x; Rm[2] = i2.y; Rm[3] = i3.x; Rm[4] = i3.y; Rm[5] = i4.x; Rm[6] = i4.y; Rm[7] = i5.x; Rm[8] = i5.y;
-      }
-      if (half == 0) pair_rows<NC, true>(acc, Rm, Yi, Rj);
-      else pair_rows<NC, false>(acc, Rm, Yi, Rj);
+      if (half == 0) pair9_corner(acc, Ri, Rj);
+      else if (half == 1) pair9_cols(accf, Ri, Rj);
+      else pair9_rows(accf, Ri, Rj);
     }
   };
 
@@ -1742,15 +1788,60 @@ __device__ __forceinline__ void schur_reg3_body(const TilePlan& tp, const unsign
     if (ci >= 0) {
       const double* Ji = tab + (long)ci * CAMTAB_DOUBLES + 12;  // CamTab::Jl, row-major
       const double* Jj = tab + (long)cj * CAMTAB_DOUBLES + 12;
-      unprime_rows<NC, RH>(acc, r0, Ji, Jj);
+      if constexpr (NC == 6) {
+        unprime_rows<6, 6>(acc, 0, Ji, Jj);
+      } else {
+        // (the second matrix is read after the first is done with: all eighteen entries beside 36 accumulators do not fit the kernel's registers)
+        if (half != 2) {  // rows 0..2 <- J_i^T rows 0..2
+          const double j0 = Ji[0], j1 = Ji[1], j2 = Ji[2], j3 = Ji[3], j4 = Ji[4], j5 = Ji[5], j6 = Ji[6], j7 = Ji[7], j8 = Ji[8];
+          if (half == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              const double b0 = acc[0][c], b1 = acc[1][c], b2 = acc[2][c];
+              acc[0][c] = j0 * b0 + j3 * b1 + j6 * b2; acc[1][c] = j1 * b0 + j4 * b1 + j7 * b2; acc[2][c] = j2 * b0 + j5 * b1 + j8 * b2;
+            }
+            asm volatile("; role 0 rows" ::: "memory");
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const double b0 = accf[c], b1 = accf[3 + c], b2 = accf[6 + c];
+              accf[c] = j0 * b0 + j3 * b1 + j6 * b2; accf[3 + c] = j1 * b0 + j4 * b1 + j7 * b2; accf[6 + c] = j2 * b0 + j5 * b1 + j8 * b2;
+            }
+            asm volatile("; role 1 rows" ::: "memory");
+          }
+        }
+        if (half != 1) {  // columns 0..2 <- (.) J_j
+          const double j0 = Jj[0], j1 = Jj[1], j2 = Jj[2], j3 = Jj[3], j4 = Jj[4], j5 = Jj[5], j6 = Jj[6], j7 = Jj[7], j8 = Jj[8];
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+            if (r < 3 || half == 0) {
+              const double a0 = acc[r][0], a1 = acc[r][1], a2 = acc[r][2];
+              acc[r][0] = a0 * j0 + a1 * j3 + a2 * j6; acc[r][1] = a0 * j1 + a1 * j4 + a2 * j7; acc[r][2] = a0 * j2 + a1 * j5 + a2 * j8;
+            }
+        }
+      }
     }
   }
   if (!owner) return;
+  if (NC == 6 || half == 0) {
 #pragma unroll
-  for (int r = 0; r < RH; ++r)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-      if (r0 + r < NC) dst[r * NC + c] = acc[r][c];
+      for (int c = 0; c < 6; ++c) dst[r * NC + c] = acc[r][c];
+    asm volatile("; corner stored" ::: "memory");  // (the three store sequences stay three: merged by the compiler they become one with 36 selected offsets in registers)
+  } else if (half == 1) {
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dst[r * NC + 6 + c] = accf[r * 3 + c];
+    asm volatile("; columns stored" ::: "memory");
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[(6 + r) * NC + c] = accf[r * 6 + c];
+    asm volatile("; rows stored" ::: "memory");
+  }
 }
 
 template <int NC, int SPLIT, int MINW>

@@ -2246,6 +2246,8 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   if (n_con <= 0) return CBA_OK;
   if (!groups_a || !groups_b || !distances || !weights) return fail(CBA_ERR_INVALID, "cba_set_constraints: null array");
   HIPCHK(hipSetDevice(p->device));
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto lap_ms = [&](std::chrono::steady_clock::time_point since) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - since).count(); };
   const int P = p->P;
   for (long e = 0; e < (long)n_con * 4; ++e)
     if (groups_a[e] < 0 || groups_a[e] >= P || groups_b[e] < 0 || groups_b[e] >= P)
@@ -2306,6 +2308,8 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
                 "camera coupling (%d rows x %d camera parameters); the limits are 2 GB and 4 GB - use fewer rows per object and frame (DESIGN.md 2.2)",
                 comp_m[K] * 8e-9, comp_m[K], (double)n_con * (p->ncp + 1) * 8e-9, n_con, p->ncp);
   int rc;
+  const double ms_graph = lap_ms(t_enter);
+  const auto t_up = std::chrono::steady_clock::now();
   upload_stage_acquire(p);
   int *dpt = nullptr, *dlp = nullptr, *dorder = nullptr, *dcc = nullptr, *dcp = nullptr, *dcps = nullptr;
   long* dcm = nullptr;
@@ -2323,6 +2327,8 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
   TRYC(dev_alloc(p, &cp.cdiag, (size_t)3 * p->lay.Ppad)); TRYC(dev_alloc(p, &cp.w, (size_t)n_con));
   if (max_pts > CON_LDS_POINTS) TRYC(dev_alloc(p, &cp.big, comp_pts.size() * 9));
 #undef TRYC
+  const double ms_upload = lap_ms(t_up);
+  const auto t_attr = std::chrono::steady_clock::now();
   {
     // small components (one board in one frame: the reference's own sessions): dense blocks in LDS, k_con_schur_small / k_con_backsub_small
     cp.max_m = (int)max_m; cp.max_np = max_pts;
@@ -2336,9 +2342,14 @@ int cba_set_constraints(cba_problem* p, int32_t n_con, const int32_t* groups_a, 
       if (rcl) return rcl;
     }
   }
+  const double ms_attr = lap_ms(t_attr);
+  const auto t_sync = std::chrono::steady_clock::now();
   HIPCHK(hipMemsetAsync(cp.cdiag, 0, (size_t)3 * p->lay.Ppad * sizeof(double), p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));  // (the staged uploads: the caller's arrays and the pinned buffer are free again)
   upload_stage_release(p);
+  if (plan_timing_on())
+    fprintf(stderr, "  cba_set_constraints: %d rows, %d components: graph %.3f ms, uploads + allocations %.3f, kernel attributes %.3f, memset + sync %.3f\n", n_con, K,
+            ms_graph, ms_upload, ms_attr, lap_ms(t_sync));
   p->con = cp;
   p->con_grid = std::max(1, std::min((n_con + BLOCK - 1) / BLOCK, 1024));
   return CBA_OK;

@@ -239,6 +239,11 @@ def test_round5_bench_line_says_what_a_caller_gets():
     assert "reading" in dist and dist["scipy_rel_cost_above_the_minimum"] >= -1e-12 and dist["product_rel_cost_above_the_minimum"] <= 1e-9
     par_name, par = _latest_parity_file()
     assert par_name >= "parity_r05.json" and par["library_source_sha256"] == d["library_source_sha256"]
+    full = par.get("cfg5_full_linear_algebra")  # (round 6) FULL cfg5 through size-independent properties against the oracle's rows and sparse Jacobian
+    if full is not None:
+        assert "10000000 obs" in full["workload"] and full["step_ok"] is True
+        assert full["residual_rows_max_abs_diff"] <= 1e-11 and full["cost_rel_diff"] <= 1e-12 and full["gradient_rel_inf"] <= 1e-10
+        assert full["jacobi_scale_rel_max"] <= 1e-10 and full["normal_equation_residual_of_the_device_step_rel_inf"] <= 1e-8
 
 
 def test_weak_points_reports_what_the_data_say_about_a_displaced_point():

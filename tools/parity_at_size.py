@@ -18,6 +18,10 @@ cfg3_product    32 cams / 50k points / 400k obs, 5 % outliers, Huber at 1 px, ft
 cfg3_default    the same arrays, both solvers at the reference's default tolerances
 cfg3_tight      the product at 1e-13 against scipy at 1e-15 with tight inner solves, + oracle_polish
 cfg5_sample_*   bench.cfg5_sample_parity: the cfg5 recipe (128 cameras, free intrinsics, the reference's bounds) at 100k and 1M observations
+cfg5_full_linear_algebra   FULL cfg5 (10M observations) through size-independent properties, the oracle's rows and sparse Jacobian taken half a million
+                observations at a time: residual rows, cost, gradient J^T f and Jacobi scale of the device against the oracle's, and the device's damped
+                step s put into the oracle's normal equations: ||(J^T J + lam D^2) s + g||_inf / ||g||_inf (the whole Schur route — records, pair
+                products, dense solve, back-substitution — checked without a second solver; --skip-cfg5-full leaves it out)
 (full cfg4 is compared in every bench.py run: ``parity`` in its JSON line)
 """
 import json
@@ -31,7 +35,7 @@ import numpy as np
 import bench
 from caliscope_amd.build import source_digest
 from caliscope_amd.least_squares import least_squares
-from oracle.residuals import joint_residuals
+from oracle.residuals import joint_jacobian, joint_residuals
 from oracle.solver import optimize_scipy
 
 TIGHT_GPU = dict(ftol=1e-13, xtol=1e-13, gtol=1e-13, max_nfev=20000)
@@ -80,6 +84,48 @@ def run(name, tol_scipy, tol_gpu, stored=None, polish=False):
     return out
 
 
+def full_size_linear_algebra(name="cfg5", lam=1e-3, chunk=500_000):
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0, prob, cfg = bench.build_problem(name)
+    assert prob.loss == "linear"  # (a robust loss would need scipy's row scaling in the oracle leg)
+    t0 = time.perf_counter()
+    with HipEngine(prob) as eng:
+        r_dev, cost_dev = eng.residuals(x0)
+        eng.begin(x0)
+        eng.linearize()
+        g_dev, d_dev = eng.get_vector(2), eng.get_vector(4)
+        ok = eng.newton_step(lam).ok
+        s_dev = eng.get_vector(3)
+    t_dev = time.perf_counter() - t0
+    n_obs, n = prob.n_obs, len(x0)
+    g, d2, JtJs = np.zeros(n), np.zeros(n), np.zeros(n)
+    cost, rows_diff = 0.0, 0.0
+    t0 = time.perf_counter()
+    for a in range(0, n_obs, chunk):
+        sl = slice(a, min(a + chunk, n_obs))
+        args = (par, sc.camera_indices[sl], sc.image_coords[sl], sc.obj_indices[sl])
+        r = joint_residuals(x0, *args)
+        J = joint_jacobian(x0, *args)
+        rows_diff = max(rows_diff, float(np.abs(r - r_dev[2 * sl.start:2 * sl.stop]).max()))
+        cost += 0.5 * float(r @ r)
+        g += J.T @ r
+        d2 += np.asarray(J.multiply(J).sum(axis=0)).ravel()
+        JtJs += J.T @ (J @ s_dev)
+    t_orc = time.perf_counter() - t0
+    d = np.sqrt(d2)
+    d[d == 0] = 1.0  # scipy's compute_jac_scale: an all-zero column keeps scale 1
+    lin_res = JtJs + lam * d * d * s_dev + g
+    return {
+        "workload": f"{name}, FULL: {len(par.blocks)} cams / {par.n_points} points / {n_obs} obs, free intrinsics, x0, lam = {lam:g}",
+        "residual_rows_max_abs_diff": rows_diff, "cost_rel_diff": abs(cost_dev - cost) / cost,
+        "gradient_rel_inf": float(np.abs(g_dev - g).max() / np.abs(g).max()), "jacobi_scale_rel_max": float(np.abs(d_dev / d - 1.0).max()),
+        "step_ok": bool(ok), "step_norm_inf": float(np.abs(s_dev).max()),
+        "normal_equation_residual_of_the_device_step_rel_inf": float(np.abs(lin_res).max() / np.abs(g).max()),
+        "seconds": {"device_incl_set_up": round(t_dev, 2), "oracle_chunks": round(t_orc, 1)},
+    }
+
+
 if __name__ == "__main__":
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     default = dict(ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None)
@@ -103,6 +149,8 @@ if __name__ == "__main__":
         t0 = time.perf_counter()
         out["cfg5_sample_1M"] = bench.cfg5_sample_parity(n_points=100_000)
         out["cfg5_sample_1M"]["wall_seconds"] = round(time.perf_counter() - t0, 1)
+    if "--skip-cfg5-full" not in sys.argv:
+        out["cfg5_full_linear_algebra"] = full_size_linear_algebra("cfg5")
     path = argv[0] if argv else "profiles/parity_r06.json"
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -34,6 +34,34 @@ def _recording_seam(*a, **k):  # the seam's own split of a call: handle set-up (
 
 
 _cv.least_squares = _recording_seam
+if "--breakdown" in sys.argv:  # wall time of the host stages of ONE first call with the board (fresh volume, no kept handle): where optimize() spends what is not set-up or solve
+    import caliscope_amd.engine_cache as _ec
+    import caliscope_amd.hip_engine as _he
+    import caliscope_amd.bundle_parameterization as _bp
+    import caliscope_amd.point_data as _pd
+    spent = {}
+
+    def timed(owner, name, label=None):
+        f = getattr(owner, name)
+
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return f(*a, **k)
+            finally:
+                spent[label or name] = spent.get(label or name, 0.0) + time.perf_counter() - t0
+        setattr(owner, name, w)
+
+    timed(CaptureVolume, "_build_constraint_arrays"); timed(CaptureVolume, "_matched_arrays"); timed(_ec, "fingerprint"); timed(_ec, "checkin")
+    timed(_he.HipEngine, "__init__", "HipEngine()"); timed(_he.HipEngine, "solve", "HipEngine.solve"); timed(_bp.BundleParameterization, "pack")
+    timed(_bp.BundleParameterization, "unpack_into"); timed(_bp.BundleParameterization, "from_camera_array"); timed(_pd.WorldPoints, "with_points")
+    plain.optimize()
+    for rep in range(3):
+        _ec.clear(trim=False); spent.clear()
+        vol = CaptureVolume(cams, img, world, ConstraintSet.from_grid(grid, pitch))
+        t = time.perf_counter(); vol.optimize(); dt = time.perf_counter() - t
+        print(f"first call with the board: {dt * 1e3:.2f} ms = " + ", ".join(f"{k} {v * 1e3:.2f}" for k, v in sorted(spent.items(), key=lambda kv: -kv[1])) + f", rest {(dt - sum(spent.values())) * 1e3:.2f}")
+    sys.exit(0)
 plain.optimize()  # HIP start-up, code paths warm
 for label, vol, kw in (("no constraints", plain, {}), ("board constraints", board, {}), ("board constraints + free intrinsics", board, {"refine_intrinsics": True})):
     t = time.perf_counter(); out = vol.optimize(**kw); dt = time.perf_counter() - t
