@@ -810,6 +810,7 @@ static Reg2Params reg2_params(const cba_problem* p) {
   prm.slots_per_wave = KCfg::EPW; prm.wave_pieces = KCfg::WAVE_PIECES; prm.rec_pieces = KCfg::LST;
   prm.zero_piece = KCfg::ZERO_PIECE;
   prm.heavy_obs = p->n_heavy ? HEAVY_OBS : 0;
+  if (const char* e = std::getenv("CBA_PLAN_REGION")) prm.region_chunks = std::max(1, std::min(std::atoi(e), 1024));  // (sweeps: chunks dealt together, schur_plan.h)
   return prm;
 }
 
