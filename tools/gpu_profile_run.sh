@@ -47,6 +47,7 @@ CALISCOPE_BA_LIB=$P CBA_SCHUR_CLOCK=1 timeout 120 python tools/newton_probe.py c
 CALISCOPE_BA_LIB=$P CBA_CHOL_TRACE=1 timeout 120 python tools/newton_probe.py cfg4 1 2> $O/chol_trace.log > /dev/null
 timeout 400 python tools/create_timing.py > $O/create_timing.log 2>&1
 timeout 200 python tools/real_session_timing.py > $O/real_session.log 2>&1
+timeout 200 python tools/real_session_timing.py --breakdown >> $O/real_session.log 2>&1
 timeout 200 python tools/device_memory_probe.py > $O/device_memory_probe.log 2>&1
 timeout 200 python tools/end_to_end.py cfg4 > $O/end_to_end_cfg4.log 2>&1
 timeout 400 python tools/large_size_probe.py > $O/large_size_probe.log 2>&1
