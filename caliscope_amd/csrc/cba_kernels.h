@@ -2161,6 +2161,124 @@ k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bac
   W[(long)col * ldw + row] = v;
 }
 
+// Round 6: k_reg_reduce and k_schur_finalize as ONE launch for the route on which nothing else adds to the reduced system between them (single rank, no
+// heavy points, no constraint rows; not the one-workgroup solve of small rigs): the sums over a tile's partial rows leave as entries of S and of the
+// Cholesky work matrix at once — a launch boundary and a pass over Sacc less per iteration; Sacc and `red` are not written.  blockDim = (64, 16), a
+// one-dimensional grid; roles in dispatch order, the ones with the longest chains first:
+//   G x fold_x workgroups   the diagonal camera blocks of group ga: entry (r <= c) of camera cam = U - sum over the camera's helpers AND the diagonal tile's
+//                           partial rows (+ lam D^2 + cam_diag on the diagonal), sixteen ways (k_reg_reduce parked the helper entries for
+//                           k_schur_finalize's fold);
+//   rhs_x workgroups        the right-hand side: -g + the rhs rows k_tprep left per workgroup, sixteen ways; also row n of the work matrix;
+//   n_tiles x tile_x        a tile: `ysplit` (4 or 16, k_reg_reduce's choice) threads share an entry's partial rows, 16 / ysplit blocks of 64 entries per
+//                           workgroup.  Entries of two different cameras are final: S_rc = S_cr = -sum.
+// The pass reads the pair kernel's 38 MB of partial blocks (cfg4) once: ~9 us at the rate HBM delivers them is its floor.
+// Fixed summation order in every role (not the order of the two-launch route: partial rows before helpers there, the rhs in eight slices).
+template <int NC>
+__global__ void __launch_bounds__(64 * REG_REDUCE_Y_MAX)
+k_reg_finalize(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* __restrict__ partial, const int* __restrict__ cam_off,
+               const int* __restrict__ cam_np, int ncp, int n_tiles, int G, int ysplit, int fold_x, int rhs_x, int tile_x,
+               const double* __restrict__ partial_b, int b_rows, int b_width,
+               const double* __restrict__ Upacked, const double* __restrict__ gvec, const double* __restrict__ sinv, double lam,
+               const double* __restrict__ lam_dev, const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
+               double* __restrict__ W, int ldw) {
+  CBA_STAMP(ST_REG_REDUCE);
+  using UP = UPack<NC>;
+  constexpr int YM = REG_REDUCE_Y_MAX;
+  __shared__ double sh[YM][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int g = tp.g, bsz = NC * NC;
+  auto put = [&](int row, int col, double v) {
+    S[(long)row * ncp + col] = v; S[(long)col * ncp + row] = v;
+    W[(long)row * ldw + col] = v; W[(long)col * ldw + row] = v;
+  };
+  const int bid = (int)blockIdx.x;
+  if (bid >= G * fold_x && bid < G * fold_x + rhs_x) {  // right-hand side
+    const int j = (bid - G * fold_x) * 64 + tx;
+    double a0 = 0.0, a1 = 0.0;
+    if (j < b_width) {
+      int b = ty;
+      for (; b + YM < b_rows; b += 2 * YM) { a0 += partial_b[(long)b * b_width + j]; a1 += partial_b[(long)(b + YM) * b_width + j]; }
+      if (b < b_rows) a0 += partial_b[(long)b * b_width + j];
+    }
+    sh[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && j < ncp) {
+      double tot = 0.0;
+#pragma unroll
+      for (int y = 0; y < YM; ++y) tot += sh[y][tx];
+      const double rv = -gvec[j] + tot;
+      rhs[j] = rv;
+      W[(long)ncp * ldw + j] = rv;
+    }
+    return;
+  }
+  if (bid < G * fold_x) {  // diagonal camera blocks of one group
+    if (lam_dev) lam = *lam_dev;
+    const int ga = bid / fold_x, bx = bid % fold_x;
+    const int t = ga * G - ga * (ga - 1) / 2;  // tiles are numbered (a, b >= a), a outermost: the diagonal tile of group ga
+    const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+    const int q = bx * 64 + tx;
+    const int cl = q / bsz, r = (q % bsz) / NC, c = (q % bsz) % NC;
+    const bool live = q < g * bsz && cl < na && c >= r && c < cam_np[ca0 + min(cl, max(na - 1, 0))];
+    double s0 = 0.0, s1 = 0.0;
+    if (live) {
+      const int w0 = tile_wg_begin[t] * tp.rep, w1 = tile_wg_begin[t + 1] * tp.rep;
+      for (int k = cl; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj (schur_entry)
+        int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
+        while (li * (li + 1) / 2 > k) --li;
+        while ((li + 1) * (li + 2) / 2 <= k) ++li;
+        const int lj = k - li * (li + 1) / 2;
+        const double* src = partial + (long)(li * g + lj) * bsz + r * NC + c;
+        int w = w0 + ty;
+        for (; w + YM < w1; w += 2 * YM) { s0 += src[(long)w * tp.tile_elems]; s1 += src[(long)(w + YM) * tp.tile_elems]; }
+        if (w < w1) s0 += src[(long)w * tp.tile_elems];
+      }
+    }
+    sh[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty != 0 || !live) return;
+    double tot = 0.0;
+#pragma unroll
+    for (int y = 0; y < YM; ++y) tot += sh[y][tx];
+    const int cam = ca0 + cl, row = cam_off[cam] + r, col = cam_off[cam] + c;
+    double v = Upacked[cam * UP::STRIDE + UP::idx(r, c)] - tot;
+    if (r == c) v += lam * sinv[row] * sinv[row] + cam_diag[row];
+    put(row, col, v);
+    return;
+  }
+  // a tile
+  const int t = (bid - G * fold_x - rhs_x) / tile_x, bx = (bid - G * fold_x - rhs_x) % tile_x;
+  const int ga = tp.tile_a[t], gb = tp.tile_b[t];
+  const int ca0 = tp.group_cam_begin[ga], na = tp.group_cam_begin[ga + 1] - ca0;
+  const int cb0 = tp.group_cam_begin[gb], nb = tp.group_cam_begin[gb + 1] - cb0;
+  const int per = YM / ysplit, sub = ty / ysplit, yy = ty % ysplit;
+  const int e = (bx * per + sub) * 64 + tx;
+  const int w0 = tile_wg_begin[t] * tp.rep, w1 = tile_wg_begin[t + 1] * tp.rep;
+  int row = -1, col = -1;
+  if (e < g * g * bsz) {
+    const int beta = e / bsz, rc = e % bsz;
+    const int li = beta / g, lj = beta % g, r = rc / NC, c = rc % NC;
+    if (!(ga == gb && lj <= li) && li < na && lj < nb && r < cam_np[ca0 + li] && c < cam_np[cb0 + lj]) {
+      row = cam_off[ca0 + li] + r; col = cam_off[cb0 + lj] + c;
+    }
+  }
+  double s0 = 0.0, s1 = 0.0;
+  if (row >= 0) {
+    int w = w0 + yy;
+    for (; w + ysplit < w1; w += 2 * ysplit) {
+      s0 += partial[(long)w * tp.tile_elems + e];
+      s1 += partial[(long)(w + ysplit) * tp.tile_elems + e];
+    }
+    if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
+  }
+  sh[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (yy != 0 || row < 0) return;
+  double tot = 0.0;
+  for (int y = 0; y < ysplit; y += 4) tot += (sh[ty + y][tx] + sh[ty + y + 1][tx]) + (sh[ty + y + 2][tx] + sh[ty + y + 3][tx]);
+  put(row, col, -tot);
+}
+
 // One launch per panel (right-looking with look-ahead).  Work matrix W: (n + 1) rows, row stride ldw (multiple of
 // 4), rows 0..n-1 = S (both triangles on entry), row n = rhs^T.  Row blocks of NB rows; the rhs row is a block of
 // its own.  Step k >= 0 (panel columns k0 = NB k .., L_kk already factored by step k - 1) has two kinds of workgroup:

@@ -114,6 +114,7 @@ struct cba_problem {
   double* tri = nullptr;   // packed upper triangle of Sacc + b for the exchange of a sharded solve
   double* Xinv = nullptr;  // inverses of the diagonal blocks of the Cholesky factor, [blocks][NB][NB] (k_chol_step)
   double* Tinv = nullptr;  // T = L^-T, built block by block next to the factorisation (inverse role of k_chol_step)
+  bool fuse_reg_finalize = true;  // k_reg_finalize in the place of k_reg_reduce + k_schur_finalize where the route allows (CBA_REG_FINALIZE=0: off)
   double* scal = nullptr;  // device scalars
   double* xbuf = nullptr;  // staging of the one all-reduce per primitive (sharded solves)
   double *sinv_state_c = nullptr, *cam_diag = nullptr, *cam_over1 = nullptr, *cam_over2 = nullptr;  // [ncp_pad] each (cba_set_camera_scaling)
@@ -598,7 +599,7 @@ static void drop_plan_task(cba_problem* p);  // (PlanTask is defined with the pl
 // CBA_STAMPS=1 (profiling build): the kernels of the LAST fused iteration in the order they started, with the device's own clock — duration from the
 // first workgroup's entry to the last wave's exit, and the idle time in front of each (previous kernel's last exit -> this kernel's first entry).
 static void dump_stamps(cba_problem* p) {
-  static const char* names[] = {"k_tprep", "k_schur_reg3", "k_reg_reduce", "k_schur_finalize", "k_chol_apply", "k_backsub", "k_step_cam", "k_build_cs",
+  static const char* names[] = {"k_tprep", "k_schur_reg3", "k_reg_reduce (or k_reg_finalize)", "k_schur_finalize", "k_chol_apply", "k_backsub", "k_step_cam", "k_build_cs",
                                 "k_reduce_rows_pub", "k_scale_lin", "k_jv", "k_small_solve"};
   const size_t n = (size_t)STAMP_SLOTS * STAMP_BLOCKS * STAMP_ROW;
   std::vector<long long> h(n);
@@ -1119,6 +1120,7 @@ int cba_create(const cba_problem_desc* d, const cba_options* opt, cba_problem** 
   p->device = dev;
   p->C = d->n_cams; p->P = d->n_points; p->N = d->n_obs;
   p->loss = d->loss; p->f_scale = d->f_scale;
+  if (const char* e = std::getenv("CBA_REG_FINALIZE")) p->fuse_reg_finalize = e[0] != '0';
 #ifdef CBA_PROFILING
   p->schur_clock = std::getenv("CBA_SCHUR_CLOCK") != nullptr;
   p->want_chol_trace = std::getenv("CBA_CHOL_TRACE") != nullptr;
@@ -2007,7 +2009,15 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     ScopedTimer t(p, T_SCHUR_REDUCE);
     // (fold + unprime + finalize as ONE kernel, a thread per camera pair, measured slower than the three launches: 42 instead of 31 us — 2080 threads
     // with 36 entries each against 147k threads with one)
-    {
+    // one launch for the reduction and the finalisation where nothing comes between them (k_reg_finalize; CBA_REG_FINALIZE=0: the two launches)
+    const bool fused_finalize = fold_in_finalize && !(ncp <= SMALL_N && !p->chol_trace) && p->fuse_reg_finalize;
+    if (fused_finalize) {
+      const int per = REG_REDUCE_Y_MAX / p->reg_reduce_y;
+      const int tile_x = (p->gsz * p->gsz * NC * NC + 64 * per - 1) / (64 * per), fold_x = (p->gsz * NC * NC + 63) / 64, rhs_x = (p->lay.ncp_pad + 63) / 64;
+      hipLaunchKernelGGL((k_reg_finalize<NC>), dim3(p->G * fold_x + rhs_x + p->n_tiles * tile_x), dim3(64, REG_REDUCE_Y_MAX), 0, p->stream, p->tp, p->tile_wg_begin, p->partial,
+                         p->cam_off, p->cam_np, ncp, p->n_tiles, p->G, p->reg_reduce_y, fold_x, rhs_x, tile_x, (const double*)p->partial_b, p->grid, p->lay.ncp_pad, p->Upacked, p->g,
+                         p->sinv, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw);
+    } else {
       hipLaunchKernelGGL(k_reg_reduce, dim3(std::max((p->tp.tile_elems + 63) / 64, (p->lay.ncp_pad + 63) / 64), p->n_tiles + B_SLICES), dim3(64, p->reg_reduce_y), 0,
                          p->stream, p->tp, p->tile_wg_begin, p->partial, p->cam_off, p->cam_np, NC, ncp, p->Sacc, p->red, p->n_tiles,
                          (const double*)p->partial_b, p->grid, p->lay.ncp_pad, p->Sacc + (size_t)ncp * ncp);
@@ -2036,7 +2046,7 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     }
     const long nn = (long)ncp * ncp;
     small_solve = ncp <= SMALL_N && !p->sharded() && !p->chol_trace;
-    if (!small_solve) {
+    if (!small_solve && !fused_finalize) {
       // (+ 1 workgroup that factors the first diagonal block: step k = -1 of the dense solve without a launch of its own; the traced solve of the
       // profiling build keeps that launch for its stamps)
       // (round 6, measured and switched off: the factoring workgroup forms its 1024 entries four per thread, each a chain of dependent global loads —
