@@ -2436,86 +2436,84 @@ k_chol_step(double* __restrict__ W, int n, int ldw, int k, int* __restrict__ fla
     const int i = i0 + h * ISTEP;
     d_ij[h] = (has_diag && i < rc && j < rc) ? Wb[(long)i * ldw + rb + j] : (i == j ? 1.0 : 0.0);
   }
+  // Step k = -1 (one workgroup: D_0 as loaded) and the look-ahead of every later step run the SAME factorisation code below: two inlined copies were
+  // two cold instruction streams per iteration (the first pivot chain through a copy took 8.6 us instead of 5.6)
   if (k < 0) {
 #pragma unroll
     for (int h = 0; h < EPT; ++h) sh_D[i0 + h * ISTEP][j] = d_ij[h];
-    __syncthreads();
-    if (tid < WAVE) chol_factor_block(sh_D, rc, flags);
-    __syncthreads();
-    chol_factor_store(sh_D, rc, Wb + rb, ldw, Xinv, tid, CHOL_THREADS, Tinv ? Tinv + (long)rb * ldw + rb : nullptr);  // L_00, X_0
-    return;
-  }
-  const int k0 = k * NB, nbp = min(NB, n - k0);
+  } else {
+    const int k0 = k * NB, nbp = min(NB, n - k0);
 #pragma unroll
-  for (int h = 0; h < EPT; ++h) {
-    const int i = i0 + h * ISTEP;
-    m_ij[h] = (i < rc && j < nbp) ? Wb[(long)i * ldw + k0 + j] : 0.0;
-    l_ij[h] = Xinv[(long)k * NB * NB + i * NB + j];  // X_k = L_kk^-1 (identity-padded), written by the factorisation of D_k
-  }
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      m_ij[h] = (i < rc && j < nbp) ? Wb[(long)i * ldw + k0 + j] : 0.0;
+      l_ij[h] = Xinv[(long)k * NB * NB + i * NB + j];  // X_k = L_kk^-1 (identity-padded), written by the factorisation of D_k
+    }
 
-  CHOL_STAMP(1);
-  // 1. pending update of this block's panel columns by panel k - 1 (all earlier panels were applied by the trailing
-  // workgroups of earlier steps)
-  if (k >= 1) chol_rank_nb(Wb + (k0 - NB), rc, W + (long)k0 * ldw + (k0 - NB), nbp, ldw, sh_red, wv, lane);
-  __syncthreads();
-  CHOL_STAMP(2);
+    CHOL_STAMP(1);
+    // 1. pending update of this block's panel columns by panel k - 1 (all earlier panels were applied by the trailing
+    // workgroups of earlier steps)
+    if (k >= 1) chol_rank_nb(Wb + (k0 - NB), rc, W + (long)k0 * ldw + (k0 - NB), nbp, ldw, sh_red, wv, lane);
+    __syncthreads();
+    CHOL_STAMP(2);
 #pragma unroll
-  for (int h = 0; h < EPT; ++h) {
-    const int i = i0 + h * ISTEP;
-    const double upd = (k >= 1) ? sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15] : 0.0;
-    sh_U[i][j] = m_ij[h] - upd;
-    sh_L[i][j] = l_ij[h];
-  }
-  __syncthreads();
-  CHOL_STAMP(3);
-  // 2. panel solve  L_bk = U L_kk^-T = U X_k^T: a 32 x 32 x 32 product on the matrix cores (four 16 x 16 tiles, one per
-  // wave 0..3).  History: a triangular solve by wave 0, one row of U per thread, was 2.8 us of the 13 us of a step.
-  if (wv < 4) {
-    const int ti = wv >> 1, tj = wv & 1;
-    v4f64 c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NB / 4; ++t) {
-      const int q = 4 * t + (lane >> 4);
-      c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_U[ti * 16 + (lane & 15)][q], sh_L[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      const double upd = (k >= 1) ? sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15] : 0.0;
+      sh_U[i][j] = m_ij[h] - upd;
+      sh_L[i][j] = l_ij[h];
     }
+    __syncthreads();
+    CHOL_STAMP(3);
+    // 2. panel solve  L_bk = U L_kk^-T = U X_k^T: a 32 x 32 x 32 product on the matrix cores (four 16 x 16 tiles, one per
+    // wave 0..3).  History: a triangular solve by wave 0, one row of U per thread, was 2.8 us of the 13 us of a step.
+    if (wv < 4) {
+      const int ti = wv >> 1, tj = wv & 1;
+      v4f64 c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ti * 16 + (lane >> 4) + 4 * r, jj = tj * 16 + (lane & 15);
-      sh_X[i][jj] = (jj < nbp && i < rc) ? c[r] : 0.0;
+      for (int t = 0; t < NB / 4; ++t) {
+        const int q = 4 * t + (lane >> 4);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_U[ti * 16 + (lane & 15)][q], sh_L[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + (lane >> 4) + 4 * r, jj = tj * 16 + (lane & 15);
+        sh_X[i][jj] = (jj < nbp && i < rc) ? c[r] : 0.0;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int h = 0; h < EPT; ++h) {
-    const int i = i0 + h * ISTEP;
-    if (i < rc && j < nbp) Wb[(long)i * ldw + k0 + j] = sh_X[i][j];
-  }
-  CHOL_STAMP(4);
-  if (!has_diag) return;
-  // 3. own diagonal block, rank-NB update
-  if (wv < 4) {
-    const int ti = wv >> 1, tj = wv & 1;
-    v4f64 c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NB / 4; ++t) {
-      const int q = 4 * t + (lane >> 4);
-      c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_X[ti * 16 + (lane & 15)][q], sh_X[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      if (i < rc && j < nbp) Wb[(long)i * ldw + k0 + j] = sh_X[i][j];
     }
+    CHOL_STAMP(4);
+    if (!has_diag) return;
+    // 3. own diagonal block, rank-NB update
+    if (wv < 4) {
+      const int ti = wv >> 1, tj = wv & 1;
+      v4f64 c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh_red[wv][(lane >> 4) + 4 * r][lane & 15] = c[r];
-  }
-  __syncthreads();
+      for (int t = 0; t < NB / 4; ++t) {
+        const int q = 4 * t + (lane >> 4);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(sh_X[ti * 16 + (lane & 15)][q], sh_X[tj * 16 + (lane & 15)][q], c, 0, 0, 0);
+      }
 #pragma unroll
-  for (int h = 0; h < EPT; ++h) {
-    const int i = i0 + h * ISTEP;
-    const double d_new = d_ij[h] - sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
-    if (b != k + 1) {
-      if (i < rc && j < rc) Wb[(long)i * ldw + rb + j] = d_new;
-    } else {
-      sh_D[i][j] = (i < rc && j < rc) ? d_new : (i == j ? 1.0 : 0.0);
+      for (int r = 0; r < 4; ++r) sh_red[wv][(lane >> 4) + 4 * r][lane & 15] = c[r];
     }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < EPT; ++h) {
+      const int i = i0 + h * ISTEP;
+      const double d_new = d_ij[h] - sh_red[(i >> 4) * 2 + (j >> 4)][i & 15][j & 15];
+      if (b != k + 1) {
+        if (i < rc && j < rc) Wb[(long)i * ldw + rb + j] = d_new;
+      } else {
+        sh_D[i][j] = (i < rc && j < rc) ? d_new : (i == j ? 1.0 : 0.0);
+      }
+    }
+    if (b != k + 1) return;
   }
-  if (b != k + 1) return;
   // 4. look-ahead: the next panel's diagonal block
   __syncthreads();
   CHOL_STAMP(5);
