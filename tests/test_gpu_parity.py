@@ -774,7 +774,8 @@ def test_failed_factorisation_on_the_bounded_fused_route_refetches_the_step():
     plain, _ = run({})
     hooked, trace = run({"CBA_TEST_FAIL_FUSED_STEP": "2", "CBA_SOLVE_TRACE": "1"})
     assert "retry 1" in trace, trace[-1500:]
-    assert plain["status"] > 0 and hooked["status"] > 0 and hooked["nfev"] <= plain["nfev"] + 3, (plain["nfev"], hooked["nfev"])
+    # (the retried step sends the 1e-12 solve down another path: 14 against 14-20 evaluations from run to run; the failure this test is about ends at max_nfev = 200)
+    assert plain["status"] > 0 and hooked["status"] > 0 and hooked["nfev"] <= plain["nfev"] + 20, (plain["nfev"], hooked["nfev"])
     assert abs(hooked["cost"] - plain["cost"]) <= 1e-9 * plain["cost"]
     assert np.abs(np.array(hooked["x"]) - np.array(plain["x"])).max() < 1e-5  # (raw vectors: the gauge may drift by a different path)
 
