@@ -103,6 +103,30 @@ def test_two_stage_plan_gives_the_same_solve(monkeypatch):
     assert np.abs(out["full"][2] - out["swap"][2]).max() <= 1e-9 * np.abs(out["full"][2]).max()
 
 
+@pytest.mark.parametrize("refine", [False, True])
+def test_one_launch_reduction_and_finalisation_forms_the_same_system(monkeypatch, refine):
+    """k_reg_finalize (round 6: the pair kernel's partial blocks reduced and S / rhs / the Cholesky work matrix written in ONE launch on the plain
+    single-rank route) against the two launches it replaces (k_reg_reduce + k_schur_finalize, CBA_REG_FINALIZE=0 — still the route of sharded solves,
+    constraint rows and heavy points): the same reduced system up to the order of the sums, the same step.  40 cameras: three camera groups, so diagonal
+    tiles (helper entries), off-diagonal tiles and a ragged last group all occur; beyond the one-workgroup solve of small rigs."""
+    from caliscope_amd.hip_engine import HipEngine
+
+    sc, par, x0 = small_problem(n_cams=40, n_points=1500, k=7, refine=refine)
+    prob = BAProblem(par, sc.camera_indices, sc.image_coords, sc.obj_indices)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CBA_REG_FINALIZE", mode)
+        with HipEngine(prob) as eng:
+            eng.begin(x0); eng.linearize()
+            assert eng.newton_step(1e-4).ok
+            out[mode] = (eng.reduced_system(), eng.get_vector(3).copy())
+    (S1, r1), s1 = out["1"]
+    (S0, r0), s0 = out["0"]
+    assert np.abs(S1 - S0).max() <= 1e-12 * np.abs(S0).max() and np.abs(r1 - r0).max() <= 1e-12 * np.abs(r0).max()
+    assert np.array_equal(S1, S1.T)  # (both triangles are written from one value)
+    assert np.abs(s1 - s0).max() <= 1e-8 * np.abs(s0).max()
+
+
 def test_thousand_cameras_evaluation_and_step():
     """The reference loops over any number of cameras (core/reprojection.py:75-119); rounds 1-3 stopped where the packed per-camera normal blocks
     (27 doubles each) no longer fit the LDS (~650 six-parameter cameras).  Beyond that the linearisation adds a thread's register sums to ONE global
