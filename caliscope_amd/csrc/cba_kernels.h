@@ -142,6 +142,34 @@ __global__ void k_cam_prep(const double* __restrict__ xvec, const double* __rest
   for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab[c * CAMTAB_DOUBLES + i] = src[i];
 }
 
+// Start of a solve (cba_begin / cba_restart, round 6): x <- x0 (and the trial buffer, which the fused trial build only writes where it has
+// observations), scale 1, bound scaling and flags cleared, and the camera table of x0 — ONE launch where two copies, two fills, k_fill and k_cam_prep
+// were six (~22 us of a solve that is 0.5 ms on the reference's own sessions).  The table is prepared from x0 itself by the first threads.
+__global__ void __launch_bounds__(BLOCK)
+k_begin(const double* __restrict__ x0, double* __restrict__ x, double* __restrict__ x_new, double* __restrict__ sinv, double* __restrict__ cam_diag,
+        int* __restrict__ flags, long total, int ncp_pad, const double* __restrict__ cam_const, const int* __restrict__ cam_model,
+        const int* __restrict__ cam_np, const int* __restrict__ cam_off, int n_cams, double* __restrict__ tab) {
+  const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = t0; i < total; i += (long)gridDim.x * blockDim.x) {
+    const double v = x0[i];
+    x[i] = v;
+    if (x_new) x_new[i] = v;
+    sinv[i] = 1.0;
+    if (i < ncp_pad) cam_diag[i] = 0.0;
+    if (i < 4) flags[i] = 0;
+  }
+  if (t0 < n_cams) {
+    const int c = (int)t0;
+    double xc[MAX_NC];
+    const int np = cam_np[c];
+    for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? x0[cam_off[c] + i] : 0.0;
+    CamTab t;
+    cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t, cam_off[c]);
+    const double* src = reinterpret_cast<const double*>(&t);
+    for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab[c * CAMTAB_DOUBLES + i] = src[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // cost (and optionally the residual vector) at xvec:   0.5 * sum rho  is formed by the caller
 template <bool WRITE_R, bool CAMG = false>

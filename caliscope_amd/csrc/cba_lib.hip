@@ -2399,15 +2399,17 @@ int cba_begin_deferred(cba_problem* p, const double* x0) {
 }
 
 static int begin_common(cba_problem* p, double* cost_out, bool evaluate) {
-  HIPCHK(hipMemcpyAsync(p->x, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  // (the fused trial build writes the points of its super-chunks only: points no observation refers to keep their x0 entries in BOTH buffers)
-  if (!p->eval_only && fused_trial(p, true)) HIPCHK(hipMemcpyAsync(p->x_new, p->x0, p->lay.total() * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  HIPCHK(hipMemsetAsync(p->flags, 0, 4 * sizeof(int), p->stream));
-  HIPCHK(hipMemsetAsync(p->cam_diag, 0, (size_t)p->lay.ncp_pad * sizeof(double), p->stream));
+  // x <- x0, the trial buffer too where the fused trial build is used (it writes the points of its super-chunks only: points no observation refers to
+  // keep their x0 entries in BOTH buffers), scale 1, bound scaling and flags cleared, the camera table of x0: one launch (k_begin)
   p->cam_scaled = false; p->cam_state_saved = false;
   p->have_build = false; p->trial_built = false; p->cost_pending = false; p->lf_pending = false;
-  hipLaunchKernelGGL(k_fill, dim3(vec_grid(p->lay.total())), dim3(BLOCK), 0, p->stream, p->sinv, 1.0, p->lay.total());
-  launch_cam_prep(p, p->x, p->tab);
+  {
+    ScopedTimer t(p, T_CAM_PREP);
+    double* trial_buf = (!p->eval_only && fused_trial(p, true)) ? p->x_new : nullptr;
+    hipLaunchKernelGGL(k_begin, dim3(std::max(vec_grid(p->lay.total()), (p->C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, p->stream, (const double*)p->x0, p->x, trial_buf,
+                       p->sinv, p->cam_diag, p->flags, p->lay.total(), p->lay.ncp_pad, (const double*)p->cam_const, (const int*)p->cam_model, (const int*)p->cam_np,
+                       (const int*)p->cam_off, p->C, p->tab);
+  }
   p->first_scale = true;
   p->begun = true; p->linearized = false; p->stepped = false; p->have_trial = false;
   if (!evaluate) {  // the first linearisation (cba_step / cba_linearize) evaluates x0 with its build pass: no pass, no wait here
