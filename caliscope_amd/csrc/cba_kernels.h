@@ -278,6 +278,7 @@ k_reduce_rows_pub(const double* __restrict__ partial, int nrow, int width, doubl
   if (blockIdx.x + 1 < gridDim.x) { reduce_rows_block(partial, nrow, width, out, grad_out, cam_off, cam_np, stride, tri); return; }
   __shared__ double sh_w[2][REDUCE_RY];
   const int t = threadIdx.y * 64 + threadIdx.x;
+  const double own = (t < pub.n_scal) ? pub.scal[t] : 0.0;  // (requested with the partial rows, not behind their sums)
   double a = 0.0, b = 0.0;
   for (int r = t; r < pub.rows_a; r += 64 * REDUCE_RY) a += pub.part_a[r];
   for (int r = t; r < pub.rows_b; r += 64 * REDUCE_RY) b += pub.part_b[r];
@@ -292,7 +293,7 @@ k_reduce_rows_pub(const double* __restrict__ partial, int nrow, int width, doubl
     sh_tot[0] = ta; sh_tot[1] = tb;
   }
   __syncthreads();
-  if (t < pub.n_scal) pub.host_scal[t] = (t == pub.slot_a) ? sh_tot[0] : (t == pub.slot_b) ? sh_tot[1] : pub.scal[t];
+  if (t < pub.n_scal) pub.host_scal[t] = (t == pub.slot_a) ? sh_tot[0] : (t == pub.slot_b) ? sh_tot[1] : own;
   if (t < 4) { pub.host_flags[t] = pub.flags[t]; pub.flags[t] = 0; }
   if (pub.cam_dst)
     for (int e = t; e < 4 * pub.ncp; e += 64 * REDUCE_RY) pub.cam_dst[e] = pub.cam_src[e / pub.ncp][e % pub.ncp];
@@ -2142,9 +2143,8 @@ __device__ __forceinline__ double schur_entry(int row, int col, const double* __
   if (row == col) v += lam * sinv[row] * sinv[row] + cam_diag[row];  // cam_diag: zero unless the caller set a bound scaling
   return v;
 }
-// Xinv != nullptr (round 6): ONE MORE workgroup, the last of the grid, forms the first diagonal block of S itself and factors it — what step k = -1 of the
-// dense solve did in a launch of its own (one workgroup, 9.5 us + a launch gap at the head of the serial chain); the regular threads then leave that
-// block of the work matrix alone.
+// (Round 6 measured ONE MORE workgroup here that formed the first diagonal block itself and factored it — step k = -1 of the dense solve without its
+// launch: 31 us against 9.5 + 3.5, its 1024 entries being chains of dependent loads; removed again, profiles/r06_experiments.txt.)
 template <int NC>
 __global__ void __launch_bounds__(256)
 k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bacc,
@@ -2153,25 +2153,9 @@ k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bac
                  const int* __restrict__ param_loc, int ncp, double lam, const double* __restrict__ lam_dev,
                  const double* __restrict__ cam_diag, double* __restrict__ S, double* __restrict__ rhs,
                  double* __restrict__ W, int ldw, const double* __restrict__ red = nullptr, int g = 0, long tile_elems = 0,
-                 const int* __restrict__ group_cam_begin = nullptr, int b_width = 0, int* __restrict__ flags = nullptr,
-                 double* __restrict__ Xinv = nullptr, double* __restrict__ Tinv = nullptr) {
+                 const int* __restrict__ group_cam_begin = nullptr, int b_width = 0) {
   CBA_STAMP(ST_FINALIZE);
   if (lam_dev) lam = *lam_dev;
-  const int nb0 = min(NB, ncp);
-  if (Xinv && blockIdx.x + 1 == gridDim.x) {
-    __shared__ double sh_D[2 * NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int i = e / NB, j = e % NB;
-      sh_D[i][j] = (i < nb0 && j < nb0) ? schur_entry<NC>(min(i, j), max(i, j), Sacc, Upacked, sinv, param_cam, param_loc, ncp, lam, cam_diag, red, g, tile_elems, group_cam_begin)
-                                        : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (tid < WAVE) chol_factor_block(sh_D, nb0, flags);
-    __syncthreads();
-    chol_factor_store(sh_D, nb0, W, ldw, Xinv, tid, 256, Tinv);  // L_00, X_0, T_00
-    return;
-  }
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)ncp * ncp) return;
   const int row = (int)(t / ncp), col = (int)(t % ncp);
@@ -2184,7 +2168,6 @@ k_schur_finalize(const double* __restrict__ Sacc, const double* __restrict__ bac
   }
   S[(long)row * ncp + col] = v;
   S[(long)col * ncp + row] = v;
-  if (Xinv && col < nb0) return;  // (block (0, 0) of the work matrix belongs to the factoring workgroup)
   W[(long)row * ldw + col] = v;
   W[(long)col * ldw + row] = v;
 }
@@ -3174,7 +3157,8 @@ k_trial_update(const double* __restrict__ x, const double* __restrict__ g, const
 // needs one host synchronisation instead of three.  scal slots: 0 gh_sq, 1 |x D|^2, 12 |J_h g_h|^2, 16 p_sq, 17 <g_h,p>,
 // 20 w_sq; outputs 40 lam, 41 radius, 42 need_host, 43/44 p_S, 45 predicted, 46 alpha, 47 beta.  fz: [0] lam, [2] alpha, [3] beta.
 __device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz);
-__device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz);
+struct SubspaceIn;
+__device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz, const SubspaceIn* pre = nullptr);
 __global__ void k_fused_lam(double* __restrict__ scal, double radius_in, double* __restrict__ fz) { fused_lam(scal, radius_in, fz); }
 __global__ void k_fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
   fused_subspace(scal, flags, fz);
@@ -3188,9 +3172,15 @@ __device__ __forceinline__ void fused_lam(double* __restrict__ scal, double radi
   scal[40] = lam; scal[41] = radius;
 }
 
-__device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz) {
-  const double gh_sq = scal[0], jg_sq = scal[12] + scal[3], p_sq = scal[16], ghp = scal[17];  // H_gg = ||J_h g_h||^2 + C_gg
-  const double lam = fz[0], radius = fz[1], gh_norm = sqrt(gh_sq);
+// (the inputs that do not come from the calling kernel's own sums, loaded ahead of them by k_step_cam)
+struct SubspaceIn { double gh_sq, c_gg, jg, lam, radius; int f1, f2; };
+__device__ __forceinline__ SubspaceIn subspace_inputs(const double* __restrict__ scal, const int* __restrict__ flags, const double* __restrict__ fz) {
+  return SubspaceIn{scal[0], scal[3], scal[12], fz[0], fz[1], flags[1], flags[2]};
+}
+__device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const int* __restrict__ flags, double* __restrict__ fz, const SubspaceIn* pre) {
+  const SubspaceIn in = pre ? *pre : subspace_inputs(scal, flags, fz);
+  const double gh_sq = in.gh_sq, jg_sq = in.jg + in.c_gg, p_sq = scal[16], ghp = scal[17];  // H_gg = ||J_h g_h||^2 + C_gg
+  const double lam = in.lam, radius = in.radius, gh_norm = sqrt(gh_sq);
   const double c = ghp / gh_sq;
   // ||w||^2 = ||p - c g_h||^2 = ||p||^2 - <g_h, p>^2 / ||g_h||^2: relative error ~ eps ||p||^2 / ||w||^2, so it is used
   // only while w is not small against p (the primitives measure ||w||^2 by a pass of its own, k_w_scalar)
@@ -3198,7 +3188,7 @@ __device__ __forceinline__ void fused_subspace(double* __restrict__ scal, const 
   scal[20] = w_sq;
   const bool two_d = true;
   double need_host = 0.0, pS[2] = {0.0, 0.0}, alpha = 0.0, beta = 0.0, predicted = 0.0;
-  const bool ok = flags[1] == 0 && flags[2] == 0 && isfinite(p_sq) && isfinite(ghp) && gh_sq > 0.0;
+  const bool ok = in.f1 == 0 && in.f2 == 0 && isfinite(p_sq) && isfinite(ghp) && gh_sq > 0.0;
   if (!ok || !(w_sq > 1e-3 * p_sq)) {
     need_host = 1.0;  // failed factorisation, or p nearly collinear with g_h: the host takes over with the primitives
   } else {
@@ -3424,9 +3414,36 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
   __shared__ double sh_ab[3];
   __shared__ int sh_outside;
   if (threadIdx.x == 0) sh_outside = 0;
+  // (round 6) everything the later phases read that does not depend on the earlier ones is requested HERE, in the first round trip: the subspace
+  // step's inputs (thread 0), a thread's first two camera entries (all of them up to 512 camera parameters), the constants of the camera whose
+  // table the thread prepares at the end — the kernel was five dependent round trips of one workgroup, 10 us
+  SubspaceIn pre{};
+  if (threadIdx.x == 0) pre = subspace_inputs(scal, flags, fz);
+  constexpr int KEEP = 2;
+  double kx[KEEP], kg[KEEP], ksi[KEEP], ks[KEEP];
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int i = threadIdx.x + q * BLOCK;
+    const bool in = i < ncp_pad;
+    kx[q] = in ? x[i] : 0.0; kg[q] = in ? g[i] : 0.0; ksi[q] = in ? sinv[i] : 1.0; ks[q] = in ? s[i] : 0.0;
+  }
+  const int my_cam = threadIdx.x < n_cams ? threadIdx.x : -1;
+  int my_np = 0, my_off = 0, my_model = 0;
+  double my_const[CAM_CONST_STRIDE];
+  if (my_cam >= 0) {
+    my_np = cam_np[my_cam]; my_off = cam_off[my_cam]; my_model = cam_model[my_cam];
+#pragma unroll
+    for (int i = 0; i < CAM_CONST_STRIDE; ++i) my_const[i] = cam_const[my_cam * CAM_CONST_STRIDE + i];
+  }
   double v[2] = {0.0, 0.0};
   for (int b = threadIdx.x; b < rows; b += BLOCK) { v[0] += partial[(long)b * 4 + 0]; v[1] += partial[(long)b * 4 + 1]; }
-  for (int i = threadIdx.x; i < ncp_pad; i += BLOCK) {
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const double ps = ks[q] * ksi[q];
+    v[0] = fma(ps, ps, v[0]);
+    v[1] = fma(kg[q], ks[q], v[1]);
+  }
+  for (int i = threadIdx.x + KEEP * BLOCK; i < ncp_pad; i += BLOCK) {
     const double si = s[i], ps = si * sinv[i];
     v[0] = fma(ps, ps, v[0]);
     v[1] = fma(g[i], si, v[1]);
@@ -3446,24 +3463,27 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
       scal[16 + j] = r;
     }
     scal[18] = 0.0; scal[19] = 0.0;
-    fused_subspace(scal, flags, fz);
+    fused_subspace(scal, flags, fz, &pre);
     sh_ab[0] = fz[2]; sh_ab[1] = fz[3]; sh_ab[2] = scal[42];
   }
   __syncthreads();
   if (sh_ab[2] != 0.0) return;  // need_host: no trial point (the build pass behind this kernel skips itself)
   const double alpha = sh_ab[0], beta = sh_ab[1];
   double s0 = 0.0;
-  for (int i = threadIdx.x; i < ncp_pad; i += BLOCK) {
-    const double si = sinv[i];
-    const double st = alpha * g[i] / (si * si) + beta * s[i];
-    const double xn = x[i] + st;
+  auto entry = [&](int i, double xi, double gi, double si, double stp) {
+    const double st = alpha * gi / (si * si) + beta * stp;
+    const double xn = xi + st;
     x_new[i] = xn;
     sh_xc[i] = xn;
     s0 = fma(st, st, s0);
     // bounded solve (trf.py:129-202, select_step): a trial point that is not STRICTLY inside the box goes back to the host, which chooses between the
     // truncated step, its reflection and the scaled anti-gradient with the primitives — rare (the bounds of the reference are far from its solutions)
     if (lb && i < ncp && !(xn > lb[i] && xn < ub[i])) sh_outside = 1;
-  }
+  };
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q)
+    if (threadIdx.x + q * BLOCK < ncp_pad) entry(threadIdx.x + q * BLOCK, kx[q], kg[q], ksi[q], ks[q]);
+  for (int i = threadIdx.x + KEEP * BLOCK; i < ncp_pad; i += BLOCK) entry(i, x[i], g[i], sinv[i], s[i]);
   {
     const double r = wave_sum(s0);
     if (lane == 0) sh_red[2][w] = r;
@@ -3482,10 +3502,12 @@ k_step_cam(const double* __restrict__ partial, int rows, const double* __restric
   }
   for (int c = threadIdx.x; c < n_cams; c += BLOCK) {
     double xc[MAX_NC];
-    const int np = cam_np[c], off = cam_off[c];
+    const bool mine = c == my_cam;  // (the first BLOCK cameras: constants loaded at the top)
+    const int np = mine ? my_np : cam_np[c], off = mine ? my_off : cam_off[c];
     for (int i = 0; i < MAX_NC; ++i) xc[i] = (i < np) ? sh_xc[off + i] : 0.0;
     CamTab t;
-    cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t, cam_off[c]);
+    if (mine) cam_prepare(xc, my_const, my_model, np, &t, off);
+    else cam_prepare(xc, cam_const + c * CAM_CONST_STRIDE, cam_model[c], np, &t, off);
     const double* src = reinterpret_cast<const double*>(&t);
     for (int i = 0; i < CAMTAB_DOUBLES; ++i) tab_out[c * CAMTAB_DOUBLES + i] = src[i];
   }

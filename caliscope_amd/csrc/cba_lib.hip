@@ -2047,15 +2047,10 @@ static int run_newton_chain(cba_problem* p, double lam, const double* lam_dev, b
     const long nn = (long)ncp * ncp;
     small_solve = ncp <= SMALL_N && !p->sharded() && !p->chol_trace;
     if (!small_solve && !fused_finalize) {
-      // (+ 1 workgroup that factors the first diagonal block: step k = -1 of the dense solve without a launch of its own; the traced solve of the
-      // profiling build keeps that launch for its stamps)
-      // (round 6, measured and switched off: the factoring workgroup forms its 1024 entries four per thread, each a chain of dependent global loads —
-      // index tables, then the helper-thread sums of the diagonal camera blocks — and took 31 us where the launch it replaces takes 9.5 + 3.5)
-      const bool f0 = false;
-      hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256) + (f0 ? 1 : 0)), dim3(256), 0, p->stream, p->Sacc,
+      hipLaunchKernelGGL((k_schur_finalize<NC>), dim3((int)((nn + 255) / 256)), dim3(256), 0, p->stream, p->Sacc,
                          p->Sacc + (size_t)ncp * ncp, p->Upacked, p->g, p->sinv, p->param_cam, p->param_loc, ncp, lam, lam_dev, p->cam_diag, p->S, p->rhs, p->Lbuf, p->ldw,
                          fold_in_finalize ? (const double*)p->red : (const double*)nullptr, p->tp.g, (long)p->tp.tile_elems, (const int*)p->tp.group_cam_begin,
-                         p->lay.ncp_pad, p->flags, f0 ? p->Xinv : (double*)nullptr, f0 ? p->Tinv : (double*)nullptr);
+                         p->lay.ncp_pad);
     }
   }
   int rc = CBA_OK;
