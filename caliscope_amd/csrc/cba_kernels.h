@@ -1895,6 +1895,24 @@ k_schur_reg3_clk(TilePlan tp, const double* __restrict__ Trec, double* __restric
 // rows — with four ways that is 60 dependent load-add steps per thread, 13 us of cfg2's iteration, 7 with sixteen; cfg4 has 51 rows per tile and
 // is 3 us faster with four).  Off-diagonal blocks go straight into Sacc; the helper-thread entries of diagonal tiles are parked in `red` and
 // folded per camera by k_reg_fold.
+constexpr int kSchurRegMaxGroupK = 16;  // cameras per group of the pair kernel (Reg3Cfg::GROUP)
+// sum of src[w * stride], w = w0 + y, w0 + y + Y, ... < w1, in a fixed order with eight loads in flight (round 6: the row sums of the reduction kernels were
+// two chains of dependent load-add steps per thread — 38 deep for the diagonal camera blocks of cfg3, 17 for cfg2's one tile: 19 and 9 us of latency)
+__device__ __forceinline__ double strided_sum(const double* __restrict__ src, long stride, int w0, int w1, int y, int Y) {
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int w = w0 + y;
+  for (; w + 7 * Y < w1; w += 8 * Y) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += src[(long)(w + q * Y) * stride];
+  }
+  if (w + 3 * Y < w1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] += src[(long)(w + q * Y) * stride];
+    w += 4 * Y;
+  }
+  for (; w < w1; w += Y) a[4] += src[(long)w * stride];  // (at most three)
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
 constexpr int REG_REDUCE_Y_MAX = 16;
 constexpr int B_SLICES = 8;  // the rhs accumulator b is kept as B_SLICES rows of ncp_pad entries (k_reg_reduce); an entry is their sum, slice order
 __device__ __forceinline__ double b_entry(const double* __restrict__ bacc, int b_width, int i) {
@@ -1919,13 +1937,7 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
     const int sl = (int)blockIdx.y - n_tiles;
     const int r0 = (int)((long)b_rows * sl / B_SLICES), r1 = (int)((long)b_rows * (sl + 1) / B_SLICES);
     const int j = blockIdx.x * 64 + threadIdx.x;
-    double a0 = 0.0, a1 = 0.0;
-    if (j < b_width) {
-      int b = r0 + threadIdx.y;
-      for (; b + Y < r1; b += 2 * Y) { a0 += partial_b[(long)b * b_width + j]; a1 += partial_b[(long)(b + Y) * b_width + j]; }
-      if (b < r1) a0 += partial_b[(long)b * b_width + j];
-    }
-    sh[threadIdx.y][threadIdx.x] = a0 + a1;
+    sh[threadIdx.y][threadIdx.x] = (j < b_width) ? strided_sum(partial_b + j, b_width, r0, r1, threadIdx.y, Y) : 0.0;
     __syncthreads();
     if (threadIdx.y == 0 && j < b_width) {
       double tot = 0.0;
@@ -1950,16 +1962,7 @@ k_reg_reduce(TilePlan tp, const int* __restrict__ tile_wg_begin, const double* _
     else if (li < na && lj < nb && r < cam_np[ca0 + li] && c < cam_np[cb0 + lj])
       dst = (long)(cam_off[ca0 + li] + r) * ncp + cam_off[cb0 + lj] + c;
   }
-  double s0 = 0.0, s1 = 0.0;
-  if (dst != -1) {
-    int w = w0 + threadIdx.y;
-    for (; w + Y < w1; w += 2 * Y) {
-      s0 += partial[(long)w * tp.tile_elems + e];
-      s1 += partial[(long)(w + Y) * tp.tile_elems + e];
-    }
-    if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
-  }
-  sh[threadIdx.y][threadIdx.x] = s0 + s1;
+  sh[threadIdx.y][threadIdx.x] = (dst != -1) ? strided_sum(partial + e, tp.tile_elems, w0, w1, threadIdx.y, Y) : 0.0;
   __syncthreads();
   if (threadIdx.y != 0 || dst == -1) return;
   double tot = 0.0;
@@ -2205,13 +2208,7 @@ k_reg_finalize(TilePlan tp, const int* __restrict__ tile_wg_begin, const double*
   const int bid = (int)blockIdx.x;
   if (bid >= G * fold_x && bid < G * fold_x + rhs_x) {  // right-hand side
     const int j = (bid - G * fold_x) * 64 + tx;
-    double a0 = 0.0, a1 = 0.0;
-    if (j < b_width) {
-      int b = ty;
-      for (; b + YM < b_rows; b += 2 * YM) { a0 += partial_b[(long)b * b_width + j]; a1 += partial_b[(long)(b + YM) * b_width + j]; }
-      if (b < b_rows) a0 += partial_b[(long)b * b_width + j];
-    }
-    sh[ty][tx] = a0 + a1;
+    sh[ty][tx] = (j < b_width) ? strided_sum(partial_b + j, b_width, 0, b_rows, ty, YM) : 0.0;
     __syncthreads();
     if (ty == 0 && j < ncp) {
       double tot = 0.0;
@@ -2231,21 +2228,49 @@ k_reg_finalize(TilePlan tp, const int* __restrict__ tile_wg_begin, const double*
     const int q = bx * 64 + tx;
     const int cl = q / bsz, r = (q % bsz) / NC, c = (q % bsz) % NC;
     const bool live = q < g * bsz && cl < na && c >= r && c < cam_np[ca0 + min(cl, max(na - 1, 0))];
-    double s0 = 0.0, s1 = 0.0;
-    if (live) {
-      const int w0 = tile_wg_begin[t] * tp.rep, w1 = tile_wg_begin[t + 1] * tp.rep;
-      for (int k = cl; k < g * (g + 1) / 2; k += na) {  // helper k = (li, lj) with k = li (li + 1) / 2 + lj (schur_entry)
+    // the camera's helpers x the tile's partial rows as ONE list of items, item m = (helper m / R, row m % R), thread ty takes m = ty, ty + 16, ..:
+    // eight loads in flight whatever the split between helpers and rows is (helper by helper the sums were 27-76 dependent steps per thread).  The
+    // helpers' offsets come from a table the workgroup makes first (its 64 entries belong to at most three cameras); (helper, row) advance incrementally.
+    constexpr int HMAX = kSchurRegMaxGroupK * (kSchurRegMaxGroupK + 1) / 2;
+    __shared__ int sh_hoff[3][HMAX];
+    const int cl_first = (bx * 64) / bsz;
+    for (int e = ty * 64 + tx; e < 3 * HMAX; e += 64 * YM) {
+      const int cam_l = cl_first + e / HMAX, h = e % HMAX, k = cam_l + h * max(na, 1);
+      int off = 0;
+      if (cam_l < na && k < g * (g + 1) / 2) {  // helper k = (li, lj), k = li (li + 1) / 2 + lj (schur_entry)
         int li = (int)((sqrtf(8.0f * k + 1.0f) - 1.0f) * 0.5f);
         while (li * (li + 1) / 2 > k) --li;
         while ((li + 1) * (li + 2) / 2 <= k) ++li;
-        const int lj = k - li * (li + 1) / 2;
-        const double* src = partial + (long)(li * g + lj) * bsz + r * NC + c;
-        int w = w0 + ty;
-        for (; w + YM < w1; w += 2 * YM) { s0 += src[(long)w * tp.tile_elems]; s1 += src[(long)(w + YM) * tp.tile_elems]; }
-        if (w < w1) s0 += src[(long)w * tp.tile_elems];
+        off = (li * g + (k - li * (li + 1) / 2)) * bsz;
       }
+      sh_hoff[e / HMAX][h] = off;
     }
-    sh[ty][tx] = s0 + s1;
+    __syncthreads();
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int w0 = tile_wg_begin[t] * tp.rep, R = tile_wg_begin[t + 1] * tp.rep - w0;
+    if (live && R > 0) {
+      const int H = (g * (g + 1) / 2 - cl + na - 1) / na;  // helpers k = cl, cl + na, .. of this camera
+      const int* hoff = sh_hoff[cl - cl_first];
+      const double* base = partial + (long)w0 * tp.tile_elems + r * NC + c;
+      int h = ty / R, w = ty % R;  // item ty
+      auto next = [&]() {  // the item's address; then on to item + 16
+        const double* ptr = base + (long)w * tp.tile_elems + hoff[min(h, H - 1)];
+        w += YM;
+        while (w >= R) { w -= R; ++h; }
+        return ptr;
+      };
+      const int total = H * R;
+      int m = ty;
+      for (; m + 7 * YM < total; m += 8 * YM) {
+        const double* ptr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ptr[q] = next();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += *ptr[q];
+      }
+      for (; m < total; m += YM) a[0] += *next();
+    }
+    sh[ty][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if (ty != 0 || !live) return;
     double tot = 0.0;
@@ -2273,16 +2298,7 @@ k_reg_finalize(TilePlan tp, const int* __restrict__ tile_wg_begin, const double*
       row = cam_off[ca0 + li] + r; col = cam_off[cb0 + lj] + c;
     }
   }
-  double s0 = 0.0, s1 = 0.0;
-  if (row >= 0) {
-    int w = w0 + yy;
-    for (; w + ysplit < w1; w += 2 * ysplit) {
-      s0 += partial[(long)w * tp.tile_elems + e];
-      s1 += partial[(long)(w + ysplit) * tp.tile_elems + e];
-    }
-    if (w < w1) s0 += partial[(long)w * tp.tile_elems + e];
-  }
-  sh[ty][tx] = s0 + s1;
+  sh[ty][tx] = (row >= 0) ? strided_sum(partial + e, tp.tile_elems, w0, w1, yy, ysplit) : 0.0;
   __syncthreads();
   if (yy != 0 || row < 0) return;
   double tot = 0.0;
